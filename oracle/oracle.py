@@ -1,0 +1,230 @@
+"""ctypes binding of the CPU oracle (oracle/pdmp_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` -- never from the product package.  PARITY UNPINNED: see the
+header of ``pdmp_oracle.h``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libpdmp_oracle.so")
+
+ZIGZAG, BPS, BOOMERANG = 0, 1, 2
+T_GAUSS_ISO, T_GAUSS_DIAG, T_BANANA, T_GAUSS_DENSE = 0, 1, 2, 3
+DERIV_FORWARD, DERIV_FINITE_DIFF = 0, 1
+ARITH_REFERENCE, ARITH_WAVE64 = 0, 1
+
+
+class _Cfg(C.Structure):
+    _fields_ = [
+        ("sampler", C.c_int32), ("dim", C.c_int32), ("grid_size", C.c_int32),
+        ("vectorized_bound", C.c_int32), ("signed_bound", C.c_int32), ("adaptive", C.c_int32),
+        ("gaussian_velocity", C.c_int32), ("deriv_mode", C.c_int32), ("target_id", C.c_int32),
+        ("arith", C.c_int32), ("tmax", C.c_double), ("refresh_rate", C.c_double),
+        ("target_params", C.POINTER(C.c_double)), ("n_target_params", C.c_int64),
+        ("max_iter_per_event", C.c_int64),
+    ]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "pdmp_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or (
+        os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_LIB_PATH)
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_normalize_config.argtypes = [C.POINTER(_Cfg)]
+        L.orc_sample_skeleton.argtypes = [C.POINTER(_Cfg), C.c_int64, C.c_int64, C.c_int64, dp, dp, C.c_uint64,
+                                          dp, dp, dp, dp, dp, ip, dp, ip, ip, C.c_int]
+        L.orc_sample_from_skeleton.argtypes = [C.POINTER(_Cfg), C.c_int64, C.c_int64, dp, dp, dp, C.c_int64,
+                                               C.c_int, dp, C.c_int]
+        L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
+        L.orc_log.argtypes = [C.c_double]; L.orc_log.restype = C.c_double
+        L.orc_sincos.argtypes = [C.c_double, dp, dp]
+        L.orc_sincos_2pi.argtypes = [C.c_double, dp, dp]
+        L.orc_rng_dump.argtypes = [C.c_uint64, C.c_int64, C.c_int, C.c_int64, dp]
+        L.orc_upper_bound.argtypes = [C.POINTER(_Cfg), dp, dp, C.c_double, dp, dp, dp]
+        L.orc_upper_bound.restype = C.c_double
+        L.orc_next_event.argtypes = [C.c_int, dp, dp, dp, C.c_double, C.c_double, dp, dp]
+        L.orc_grad.argtypes = [C.POINTER(_Cfg), dp, dp]
+        L.orc_potential.argtypes = [C.POINTER(_Cfg), dp]; L.orc_potential.restype = C.c_double
+        L.orc_num_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class OracleError(ValueError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+@dataclass
+class Config:
+    """Mirror of the reference constructor kwargs + target descriptor."""
+    sampler: int = ZIGZAG
+    dim: int = 1
+    grid_size: int = 10
+    tmax: float = 2.0
+    refresh_rate: float = 0.0
+    vectorized_bound: bool = True
+    signed_bound: bool = True
+    adaptive: bool = True
+    gaussian_velocity: bool = False
+    deriv_mode: int = DERIV_FORWARD
+    target_id: int = T_GAUSS_ISO
+    target_params: np.ndarray | None = None
+    arith: int = ARITH_REFERENCE
+    max_iter_per_event: int = 0
+    _keep: list = field(default_factory=list, repr=False)
+
+    def c(self) -> _Cfg:
+        p = None
+        n = 0
+        if self.target_params is not None:
+            arr = np.ascontiguousarray(np.asarray(self.target_params, dtype=np.float64).ravel())
+            self._keep = [arr]
+            p, n = _dp(arr), arr.size
+        return _Cfg(self.sampler, self.dim, self.grid_size, int(self.vectorized_bound), int(self.signed_bound),
+                    int(self.adaptive), int(self.gaussian_velocity), self.deriv_mode, self.target_id, self.arith,
+                    float(self.tmax), float(self.refresh_rate), p, n, self.max_iter_per_event)
+
+
+def _check(rc):
+    if rc != 0:
+        raise OracleError(rc, lib().orc_last_error().decode())
+
+
+def normalize(cfg: Config) -> Config:
+    c = cfg.c()
+    _check(lib().orc_normalize_config(C.byref(c)))
+    out = Config(**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__ if k != "_keep"})
+    out.tmax, out.adaptive = c.tmax, bool(c.adaptive)
+    out.signed_bound, out.vectorized_bound = bool(c.signed_bound), bool(c.vectorized_bound)
+    return out
+
+
+def sample_skeleton(cfg: Config, n_sk: int, xinit, vinit, seed: int, chain_id_offset: int = 0,
+                    diagnostics: bool = True, n_threads: int = 0) -> dict:
+    """xinit, vinit: (C, d) arrays (row c = chain c; memory layout equals the reference's d x C
+    column-major).  Returns dict of arrays: X, V (C, n_sk, d), t (C, n_sk), + diagnostics."""
+    x = np.ascontiguousarray(np.atleast_2d(np.asarray(xinit, dtype=np.float64)))
+    v = np.ascontiguousarray(np.atleast_2d(np.asarray(vinit, dtype=np.float64)))
+    if x.shape != v.shape or x.shape[1] != cfg.dim:
+        raise OracleError(-2, f"xinit and vinit must have the same dimension as dim ({cfg.dim})")
+    Cn, d = x.shape
+    n = max(int(n_sk), 0)
+    out = {"X": np.empty((Cn, n, d)), "V": np.empty((Cn, n, d)), "t": np.empty((Cn, n))}
+    if diagnostics:
+        out.update(horizon=np.empty((Cn, n)), ar=np.empty((Cn, n)),
+                   errored_bound=np.empty((Cn, n), np.int32), error_value_ar=np.empty((Cn, n, 5)),
+                   rejected=np.empty((Cn, n), np.int32), hitting_horizon=np.empty((Cn, n), np.int32))
+    g = out.get
+    c = cfg.c()
+    _check(lib().orc_sample_skeleton(C.byref(c), Cn, int(n_sk), int(chain_id_offset), _dp(x), _dp(v),
+                                     C.c_uint64(seed & (2**64 - 1)), _dp(out["X"]), _dp(out["V"]), _dp(out["t"]),
+                                     _dp(g("horizon")), _dp(g("ar")), _ip(g("errored_bound")),
+                                     _dp(g("error_value_ar")), _ip(g("rejected")), _ip(g("hitting_horizon")),
+                                     n_threads))
+    return out
+
+
+def sample_from_skeleton(cfg: Config, N: int, X, V, t, discard_vt: bool = True, n_threads: int = 0):
+    X = np.ascontiguousarray(X, dtype=np.float64); V = np.ascontiguousarray(V, dtype=np.float64)
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    if X.ndim == 2:
+        X, V, t = X[None], V[None], t[None]
+    Cn, n_sk, d = X.shape
+    rows = d if discard_vt else 2 * d + 1
+    out = np.empty((Cn, max(int(N), 0), rows))
+    c = cfg.c()
+    _check(lib().orc_sample_from_skeleton(C.byref(c), Cn, n_sk, _dp(X), _dp(V), _dp(t), int(N), int(discard_vt),
+                                          _dp(out), n_threads))
+    return out
+
+
+def philox(ctr, key):
+    a = (C.c_uint32 * 4)(*ctr); k = (C.c_uint32 * 2)(*key); o = (C.c_uint32 * 4)()
+    lib().orc_philox4x32_10(a, k, o)
+    return list(o)
+
+
+def log(x: float) -> float:
+    return lib().orc_log(x)
+
+
+def sincos(x: float):
+    s, c = C.c_double(), C.c_double()
+    lib().orc_sincos(x, C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def sincos_2pi(u: float):
+    s, c = C.c_double(), C.c_double()
+    lib().orc_sincos_2pi(u, C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def rng_dump(seed: int, chain: int, kind: int, n: int) -> np.ndarray:
+    out = np.empty(n)
+    lib().orc_rng_dump(C.c_uint64(seed), chain, kind, n, _dp(out))
+    return out
+
+
+def upper_bound(cfg: Config, x, v, horizon: float):
+    x = np.ascontiguousarray(x, dtype=np.float64); v = np.ascontiguousarray(v, dtype=np.float64)
+    n = cfg.grid_size
+    grid, box, cum = np.empty(n), np.empty(n - 1), np.empty(n)
+    c = cfg.c()
+    step = lib().orc_upper_bound(C.byref(c), _dp(x), _dp(v), horizon, _dp(grid), _dp(box), _dp(cum))
+    return grid, box, cum, step
+
+
+def next_event(grid, box, cum, step, E):
+    tp, lb = C.c_double(), C.c_double()
+    lib().orc_next_event(len(grid), _dp(grid), _dp(box), _dp(cum), step, E, C.byref(tp), C.byref(lb))
+    return tp.value, lb.value
+
+
+def grad(cfg: Config, x):
+    x = np.ascontiguousarray(x, dtype=np.float64); g = np.empty_like(x)
+    c = cfg.c()
+    lib().orc_grad(C.byref(c), _dp(x), _dp(g))
+    return g
+
+
+def potential(cfg: Config, x) -> float:
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    c = cfg.c()
+    return lib().orc_potential(C.byref(c), _dp(x))
+
+
+def num_threads() -> int:
+    return lib().orc_num_threads()

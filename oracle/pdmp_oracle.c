@@ -1,0 +1,721 @@
+/*
+ * pdmp_oracle.c -- CPU restatement (plain C, scalar, one chain at a time) of the PDMPFlux.jl
+ * sample_skeleton()/sample_from_skeleton() hot path.
+ *
+ * TEST INFRASTRUCTURE: checker for the HIP engine and timed CPU baseline ("port").  Never on the
+ * product path.   PARITY UNPINNED (see pdmp_oracle.h): no Julia toolchain, no golden vectors in
+ * the reference; pinned by invariants, statistics, hand-derived answers and Philox/libm KATs.
+ *
+ * Build: see oracle/Makefile   (gcc -O2 -ffp-contract=off -fopenmp; no fast-math: the rounding of
+ * every expression below is part of the specification the HIP engine is compared against).
+ *
+ * Citations are file:line under /root/reference/.
+ */
+#include "pdmp_oracle.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static __thread char g_err[512];
+const char *orc_last_error(void) { return g_err; }
+#define FAIL(code, ...) do { snprintf(g_err, sizeof g_err, __VA_ARGS__); return (code); } while (0)
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Random stream (build-defined; replaces Julia's MersenneTwister/randexp/randn,
+ * AbstractPDMP.jl:100, SamplingLoopInplace.jl:70,136,154,190 -- "third-party arithmetic").
+ *   Philox4x32-10 (Salmon et al., SC'11; Random123 v1.14 known-answer vectors in tests/).
+ *   key = (seed_lo, seed_hi); counter = (blk_lo, blk_hi, chain_lo, chain_hi).
+ *   Variate n of a chain uses block n>>1, 64-bit half n&1: bits = w[2h] | w[2h+1]<<32;
+ *   u = ((bits >> 12) + 0.5) * 2^-52  in (0,1);  Exp(1) = -log(u) with the log below.
+ *   Normal pairs (Box-Muller) consume one whole block: (z0,z1) = sqrt(-2 log u0) (cos,sin)(2 pi u1).
+ * ------------------------------------------------------------------------------------------ */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+typedef struct { uint64_t seed; uint64_t chain; uint64_t n; } rng_t;
+
+static inline double bits_to_u(uint64_t bits) {
+    return ((double)(bits >> 12) + 0.5) * 0x1p-52;
+}
+static void rng_block(const rng_t *r, uint64_t blk, uint32_t w[4]) {
+    uint32_t ctr[4] = { (uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)r->chain, (uint32_t)(r->chain >> 32) };
+    uint32_t key[2] = { (uint32_t)r->seed, (uint32_t)(r->seed >> 32) };
+    orc_philox4x32_10(ctr, key, w);
+}
+static double rng_uniform(rng_t *r) {
+    uint32_t w[4];
+    rng_block(r, r->n >> 1, w);
+    int h = (int)(r->n & 1);
+    r->n++;
+    return bits_to_u((uint64_t)w[2 * h] | ((uint64_t)w[2 * h + 1] << 32));
+}
+
+/* log(x) for normal x > 0: the fdlibm e_log.c algorithm (Sun Microsystems, freely distributable),
+ * written with +,-,*,/ only so that CPU and GPU agree bit for bit. */
+double orc_log(double x) {
+    static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+        Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+        Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+        Lg7 = 1.479819860511658591e-01;
+    uint64_t ix; memcpy(&ix, &x, 8);
+    int32_t hx = (int32_t)(ix >> 32);
+    int32_t k = (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    int32_t i = (hx + 0x95f64) & 0x100000;
+    ix = (ix & 0xffffffffull) | ((uint64_t)(uint32_t)(hx | (i ^ 0x3ff00000)) << 32);
+    memcpy(&x, &ix, 8);
+    k += (i >> 20);
+    double f = x - 1.0, dk = (double)k;
+    if ((0x000fffff & (2 + hx)) < 3) {            /* |f| < 2^-20 */
+        if (f == 0.0) return (k == 0) ? 0.0 : dk * ln2_hi + dk * ln2_lo;
+        double R = f * f * (0.5 - 0.33333333333333333 * f);
+        return (k == 0) ? f - R : dk * ln2_hi - ((R - dk * ln2_lo) - f);
+    }
+    double s = f / (2.0 + f), z = s * s, w = z * z;
+    i = hx - 0x6147a;
+    int32_t j = 0x6b851 - hx;
+    double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    i |= j;
+    double R = t2 + t1;
+    if (i > 0) {
+        double hfsq = 0.5 * f * f;
+        return (k == 0) ? f - (hfsq - s * (hfsq + R)) : dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    }
+    return (k == 0) ? f - s * (f - R) : dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
+
+/* fdlibm k_sin.c / k_cos.c polynomial kernels on |a| <= pi/4 (no tail term). */
+static inline double ksin(double a) {
+    static const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+        S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+        S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    double z = a * a, v = z * a;
+    double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    return a + v * (S1 + z * r);
+}
+static inline double kcos(double a) {
+    static const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+        C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+        C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double z = a * a;
+    double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    return (1.0 - 0.5 * z) + z * r;
+}
+static inline void quadrant(int q, double sa, double ca, double *s, double *c) {
+    switch (q & 3) {
+    case 0: *s = sa;  *c = ca;  break;
+    case 1: *s = ca;  *c = -sa; break;
+    case 2: *s = -sa; *c = -ca; break;
+    default: *s = -ca; *c = sa; break;
+    }
+}
+/* sin/cos(2 pi u), u in (0,1): exact quadrant reduction on u, then the kernels. */
+void orc_sincos_2pi(double u, double *s, double *c) {
+    int q = (int)(4.0 * u + 0.5);
+    double f = u - 0.25 * (double)q;               /* exact, |f| <= 1/8 */
+    double a = f * 6.283185307179586476925;
+    quadrant(q, ksin(a), kcos(a), s, c);
+}
+/* sin/cos(x) for 0 <= |x| < ~1e5: two-term Cody-Waite reduction by pi/2 (fdlibm constants). */
+void orc_sincos(double x, double *s, double *c) {
+    static const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
+        pio2_1t = 6.07710050650619224932e-11;
+    double fn = floor(x * invpio2 + 0.5);
+    double a = (x - fn * pio2_1) - fn * pio2_1t;
+    quadrant((int)((int64_t)fn & 3), ksin(a), kcos(a), s, c);
+}
+
+static double rng_exp(rng_t *r) { return -orc_log(rng_uniform(r)); }
+
+/* d standard normals; aligns the variate counter to a block boundary first. */
+static void rng_normals(rng_t *r, int d, double *z) {
+    if (r->n & 1) r->n++;
+    uint64_t blk0 = r->n >> 1;
+    for (int p = 0; 2 * p < d; ++p) {
+        uint32_t w[4];
+        rng_block(r, blk0 + (uint64_t)p, w);
+        double u0 = bits_to_u((uint64_t)w[0] | ((uint64_t)w[1] << 32));
+        double u1 = bits_to_u((uint64_t)w[2] | ((uint64_t)w[3] << 32));
+        double rad = sqrt(-2.0 * orc_log(u0)), sn, cs;
+        orc_sincos_2pi(u1, &sn, &cs);
+        z[2 * p] = rad * cs;
+        if (2 * p + 1 < d) z[2 * p + 1] = rad * sn;
+    }
+    r->n += 2 * (uint64_t)((d + 1) / 2);
+}
+
+void orc_rng_dump(uint64_t seed, int64_t chain, int kind, int64_t n_draw, double *out) {
+    rng_t r = { seed, (uint64_t)chain, 0 };
+    if (kind == 2) { rng_normals(&r, (int)n_draw, out); return; }
+    for (int64_t i = 0; i < n_draw; ++i) out[i] = (kind == 0) ? rng_uniform(&r) : rng_exp(&r);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Summation orders (orc_config_t.arith)
+ * ------------------------------------------------------------------------------------------ */
+static double sum_seq(const double *a, int d) {
+    double s = 0.0;
+    for (int i = 0; i < d; ++i) s += a[i];
+    return s;
+}
+/* lane l accumulates a[l], a[l+64], ...; then xor-butterfly with offsets 1,2,4,...,32 */
+static double sum_wave64(const double *a, int d) {
+    double p[64], q[64];
+    for (int l = 0; l < 64; ++l) {
+        double s = 0.0;
+        for (int i = l; i < d; i += 64) s += a[i];
+        p[l] = s;
+    }
+    for (int off = 1; off < 64; off <<= 1) {
+        for (int l = 0; l < 64; ++l) q[l] = p[l] + p[l ^ off];
+        memcpy(p, q, sizeof p);
+    }
+    return p[0];
+}
+static double vsum(const orc_config_t *cfg, const double *a, int d) {
+    return cfg->arith == ORC_ARITH_WAVE64 ? sum_wave64(a, d) : sum_seq(a, d);
+}
+/* first index i with inclusive-prefix(p)[i] > u, else d-1.
+ * REFERENCE: Distributions.jl DiscreteNonParametric rand (compat 0.25, Project.toml:31; called at
+ * ZigZagSamplers.jl:104): cp = p[1]; while cp <= draw && i < n: cp += p[i += 1].
+ * WAVE64: chunks of 64, Kogge-Stone inclusive scan inside a chunk, running carry between chunks. */
+static int categorical(const orc_config_t *cfg, const double *p, int d, double u) {
+    if (cfg->arith != ORC_ARITH_WAVE64) {
+        double cp = p[0]; int i = 0;
+        while (cp <= u && i < d - 1) { ++i; cp += p[i]; }
+        return i;
+    }
+    double carry = 0.0;
+    for (int base = 0; base < d; base += 64) {
+        double y[64], z[64];
+        for (int l = 0; l < 64; ++l) y[l] = (base + l < d) ? p[base + l] : 0.0;
+        for (int off = 1; off < 64; off <<= 1) {
+            for (int l = 0; l < 64; ++l) z[l] = (l >= off) ? y[l] + y[l - off] : y[l];
+            memcpy(y, z, sizeof y);
+        }
+        for (int l = 0; l < 64 && base + l < d; ++l)
+            if (carry + y[l] > u) return base + l;
+        carry = carry + y[63];
+    }
+    return d - 1;
+}
+
+/* max without NaN propagation -- both sides of the parity comparison use this form */
+static inline double pmax(double a, double b) { return a > b ? a : b; }
+
+/* ------------------------------------------------------------------------------------------
+ * Built-in potentials U and their gradients, evaluated on dual numbers (val, eps) so that the
+ * time-derivative of the rate is exact forward-mode AD (ForwardDiff.derivative, UpperBound.jl:102,210).
+ * Dual product rule used everywhere: (a*b).eps = a.eps*b.val + a.val*b.eps, no fused multiply-add.
+ * ------------------------------------------------------------------------------------------ */
+static void grad_dual(const orc_config_t *cfg, const double *xv, const double *xe, double *gv, double *ge) {
+    const int d = cfg->dim;
+    switch (cfg->target_id) {
+    case ORC_T_GAUSS_ISO:                       /* U = |x|^2/2  (README.md:36-38) */
+        for (int i = 0; i < d; ++i) { gv[i] = xv[i]; ge[i] = xe[i]; }
+        break;
+    case ORC_T_GAUSS_DIAG: {                    /* U = sum prec_i (x_i-mu_i)^2 / 2 */
+        const double *mu = cfg->target_params, *prec = cfg->target_params + d;
+        for (int i = 0; i < d; ++i) { gv[i] = prec[i] * (xv[i] - mu[i]); ge[i] = prec[i] * xe[i]; }
+        break;
+    }
+    case ORC_T_BANANA: {                        /* test/test_config.jl:33-36; SURVEY Q10 */
+        if (d < 2) { gv[0] = xv[0]; ge[0] = xe[0]; break; }
+        double sq_v = xv[0] * xv[0], sq_e = xe[0] * xv[0] + xv[0] * xe[0];
+        double m_v = sq_v - 1.0, m_e = sq_e;                 /* mean_x2 = x1^2 - 1 */
+        double r_v = xv[1] - m_v, r_e = xe[1] - m_e;         /* r = x2 - mean_x2 */
+        double a_v = 2.0 * xv[0], a_e = 2.0 * xe[0];
+        double pr_v = a_v * r_v, pr_e = a_e * r_v + a_v * r_e;
+        gv[0] = xv[0] - pr_v; ge[0] = xe[0] - pr_e;          /* dU/dx1 = x1 - 2 x1 r */
+        gv[1] = r_v;          ge[1] = r_e;                   /* dU/dx2 = r */
+        for (int i = 2; i < d; ++i) { gv[i] = xv[i]; ge[i] = xe[i]; }
+        break;
+    }
+    case ORC_T_GAUSS_DENSE: {                   /* U = x'Px/2, P column-major */
+        const double *P = cfg->target_params;
+        for (int i = 0; i < d; ++i) {
+            double sv = 0.0, se = 0.0;
+            for (int j = 0; j < d; ++j) { sv += P[i + (size_t)j * d] * xv[j]; se += P[i + (size_t)j * d] * xe[j]; }
+            gv[i] = sv; ge[i] = se;
+        }
+        break;
+    }
+    }
+}
+void orc_grad(const orc_config_t *cfg, const double *x, double *g) {
+    const int d = cfg->dim;
+    double *ze = calloc((size_t)d, 8), *ge = malloc((size_t)d * 8);
+    grad_dual(cfg, x, ze, g, ge);
+    free(ze); free(ge);
+}
+double orc_potential(const orc_config_t *cfg, const double *x) {
+    const int d = cfg->dim; double s = 0.0;
+    switch (cfg->target_id) {
+    case ORC_T_GAUSS_ISO: for (int i = 0; i < d; ++i) s += x[i] * x[i]; return s / 2;
+    case ORC_T_GAUSS_DIAG: { const double *mu = cfg->target_params, *pr = mu + d;
+        for (int i = 0; i < d; ++i) s += pr[i] * (x[i] - mu[i]) * (x[i] - mu[i]); return s / 2; }
+    case ORC_T_BANANA: { if (d < 2) return x[0] * x[0] / 2;
+        double r = x[1] - (x[0] * x[0] - 1.0); s = x[0] * x[0] + r * r;
+        for (int i = 2; i < d; ++i) s += x[i] * x[i]; return s / 2; }
+    default: { const double *P = cfg->target_params;
+        for (int i = 0; i < d; ++i) for (int j = 0; j < d; ++j) s += x[i] * P[i + (size_t)j * d] * x[j];
+        return s / 2; }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Per-chain workspace
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int d, n;
+    double *x, *v;                         /* PDMPState.x / .v (Composites.jl:60-61) */
+    double *xv, *xe, *vv, *ve, *gv, *ge;   /* dual scratch: x_t, v_t, grad */
+    double *tmp, *tmp2;                    /* d-vectors */
+    double *vals, *slps;                   /* d*n (vect) or n (scalar), column j = grid time j */
+    double *fa, *fb;                       /* finite-difference scratch, d */
+    double *grid, *box, *cum;              /* BoundBox (Composites.jl:15-20) */
+    double *cell;                          /* d */
+    double step;
+} ws_t;
+
+static int ws_init(ws_t *w, int d, int n) {
+    memset(w, 0, sizeof *w);
+    w->d = d; w->n = n;
+    size_t D = (size_t)d, N = (size_t)n;
+    double **ptrs[] = { &w->x, &w->v, &w->xv, &w->xe, &w->vv, &w->ve, &w->gv, &w->ge, &w->tmp, &w->tmp2,
+                        &w->fa, &w->fb, &w->cell };
+    for (size_t i = 0; i < sizeof ptrs / sizeof *ptrs; ++i) if (!(*ptrs[i] = malloc(D * 8))) return -1;
+    if (!(w->vals = malloc(D * N * 8)) || !(w->slps = malloc(D * N * 8))) return -1;
+    if (!(w->grid = malloc(N * 8)) || !(w->box = malloc(N * 8)) || !(w->cum = malloc(N * 8))) return -1;
+    return 0;
+}
+static void ws_free(ws_t *w) {
+    free(w->x); free(w->v); free(w->xv); free(w->xe); free(w->vv); free(w->ve); free(w->gv); free(w->ge);
+    free(w->tmp); free(w->tmp2); free(w->fa); free(w->fb); free(w->cell);
+    free(w->vals); free(w->slps); free(w->grid); free(w->box); free(w->cum);
+}
+
+/* flow with a dual time (t, 1): ZigZagSamplers.jl:80, BouncyParticleSamplers.jl:32 (x + v t, v);
+ * BoomerangSamplers.jl:31 (x cos t + v sin t, -x sin t + v cos t). */
+static void flow_dual(const orc_config_t *cfg, ws_t *w, const double *x, const double *v, double t) {
+    const int d = w->d;
+    if (cfg->sampler == ORC_BOOMERANG) {
+        double s, c; orc_sincos(t, &s, &c);
+        /* d/dt: cos -> -sin, sin -> cos */
+        for (int i = 0; i < d; ++i) {
+            w->xv[i] = x[i] * c + v[i] * s;
+            w->xe[i] = x[i] * (-s) + v[i] * c;
+            w->vv[i] = (-x[i]) * s + v[i] * c;
+            w->ve[i] = (-x[i]) * c + v[i] * (-s);
+        }
+    } else {
+        for (int i = 0; i < d; ++i) {
+            w->xv[i] = x[i] + v[i] * t;
+            w->xe[i] = v[i];
+            w->vv[i] = v[i];
+            w->ve[i] = 0.0;
+        }
+    }
+}
+
+/* Vector-valued bounded function and its t-derivative at time t.
+ * signed_rate_vect ZigZagSamplers.jl:95-98 / rate_vect :88-91. */
+static void zz_func_dual(const orc_config_t *cfg, ws_t *w, const double *x, const double *v, double t,
+                         double *val, double *slp) {
+    flow_dual(cfg, w, x, v, t);
+    grad_dual(cfg, w->xv, w->xe, w->gv, w->ge);
+    for (int i = 0; i < w->d; ++i) {
+        double s = w->gv[i] * w->vv[i];
+        double sd = w->ge[i] * w->vv[i] + w->gv[i] * w->ve[i];
+        if (cfg->signed_bound) { val[i] = s; if (slp) slp[i] = sd; }
+        else { val[i] = pmax(0.0, s); if (slp) slp[i] = (0.0 < s) ? sd : 0.0; }
+    }
+}
+/* Scalar bounded function: signed_rate / rate of BPS (BouncyParticleSamplers.jl:39-47) and
+ * Boomerang (BoomerangSamplers.jl:38-46).  Includes refresh_rate (Q2). */
+static double sc_func_dual(const orc_config_t *cfg, ws_t *w, const double *x, const double *v, double t, double *slp) {
+    flow_dual(cfg, w, x, v, t);
+    grad_dual(cfg, w->xv, w->xe, w->gv, w->ge);
+    for (int i = 0; i < w->d; ++i) {
+        w->tmp[i] = w->gv[i] * w->vv[i];
+        w->tmp2[i] = w->ge[i] * w->vv[i] + w->gv[i] * w->ve[i];
+    }
+    double dv = vsum(cfg, w->tmp, w->d), de = vsum(cfg, w->tmp2, w->d);
+    if (cfg->signed_bound) { if (slp) *slp = de; return dv + cfg->refresh_rate; }
+    if (slp) *slp = (0.0 < dv) ? de : 0.0;
+    return pmax(0.0, dv) + cfg->refresh_rate;
+}
+
+/* finite_difference_derivative, UpperBound.jl:50-76 (start = 0, horizon given) */
+static void fd_points(double t, double horizon, double *tm, double *tp) {
+    double h = 1.4901161193847656e-08 /* sqrt(eps(Float64)) */ * pmax(1.0, fabs(t));
+    *tm = pmax(0.0, t - h);
+    *tp = (horizon < t + h) ? horizon : t + h;      /* min(horizon, x+h) */
+}
+
+/* The unsigned total rate used by the accept test (always `sampler.rate`, SamplingLoopInplace.jl:116; Q3) */
+static double true_rate(const orc_config_t *cfg, ws_t *w, double t) {
+    flow_dual(cfg, w, w->x, w->v, t);
+    grad_dual(cfg, w->xv, w->xe, w->gv, w->ge);
+    if (cfg->sampler == ORC_ZIGZAG) {                 /* ZigZagSamplers.jl:83-86 */
+        for (int i = 0; i < w->d; ++i) w->tmp[i] = pmax(0.0, w->gv[i] * w->vv[i]);
+        return vsum(cfg, w->tmp, w->d);
+    }
+    for (int i = 0; i < w->d; ++i) w->tmp[i] = w->gv[i] * w->vv[i];
+    return pmax(0.0, vsum(cfg, w->tmp, w->d)) + cfg->refresh_rate;   /* BPS :39-42, Boomerang :38-41 */
+}
+
+/* upper_bound_grid_vect (UpperBound.jl:203-247) / upper_bound_grid (:92-137); chosen as in
+ * init_state (AbstractPDMP.jl:121-136).  Fills w->grid/box/cum/step. */
+static void upper_bound(const orc_config_t *cfg, ws_t *w, const double *x, const double *v, double horizon) {
+    const int d = w->d, n = w->n;
+    /* t = range(0, stop=horizon, length=n); step_size = t[2]-t[1]  (:204-205 / :94-95).
+     * Build-defined rounding: step = horizon/(n-1), t_j = j*step, t_{n-1} = horizon
+     * (Julia's TwicePrecision range may differ in the last bit -- unpinned). */
+    const double h = horizon / (double)(n - 1);
+    for (int j = 0; j < n; ++j) w->grid[j] = (double)j * h;
+    w->grid[n - 1] = horizon;
+    w->step = h;
+    const double *t = w->grid;
+
+    if (cfg->vectorized_bound) {
+        for (int j = 0; j < n; ++j) {
+            double *val = w->vals + (size_t)j * d, *slp = w->slps + (size_t)j * d;
+            if (cfg->deriv_mode == ORC_DERIV_FORWARD) {
+                zz_func_dual(cfg, w, x, v, t[j], val, slp);                   /* :208-210 */
+            } else {                                                            /* :223-224, :50-76 */
+                zz_func_dual(cfg, w, x, v, t[j], val, NULL);                    /* fx, :56 */
+                double tm, tp; fd_points(t[j], horizon, &tm, &tp);
+                if (tp == tm) { for (int i = 0; i < d; ++i) slp[i] = val[i] - val[i]; }
+                else if (tm == t[j]) { zz_func_dual(cfg, w, x, v, tp, w->fa, NULL);
+                    for (int i = 0; i < d; ++i) slp[i] = (w->fa[i] - val[i]) / (tp - t[j]); }
+                else if (tp == t[j]) { zz_func_dual(cfg, w, x, v, tm, w->fb, NULL);
+                    for (int i = 0; i < d; ++i) slp[i] = (val[i] - w->fb[i]) / (t[j] - tm); }
+                else { zz_func_dual(cfg, w, x, v, tp, w->fa, NULL); zz_func_dual(cfg, w, x, v, tm, w->fb, NULL);
+                    for (int i = 0; i < d; ++i) slp[i] = (w->fa[i] - w->fb[i]) / (tp - tm); }
+            }
+        }
+        if (cfg->arith == ORC_ARITH_REFERENCE) memset(w->cum, 0, (size_t)n * 8);
+        double *run = w->fa;                       /* per-dimension running cumsum (:243-244) */
+        for (int i = 0; i < d; ++i) run[i] = 0.0;
+        for (int j = 0; j + 1 < n; ++j) {
+            const double *v0 = w->vals + (size_t)j * d, *v1 = v0 + d, *g0 = w->slps + (size_t)j * d, *g1 = g0 + d;
+            for (int i = 0; i < d; ++i) {
+                /* :229  absolute-time tangent intersection (Q1) */
+                double p = (((v0[i] - v1[i]) + g1[i] * t[j + 1]) - g0[i] * t[j]) / (g1[i] - g0[i]);
+                if (p != p) p = 0.0;                                   /* :234 */
+                p = (p > h) ? h : ((p < 0.0) ? 0.0 : p);               /* :235 clamp */
+                double inter = v0[i] + g0[i] * p;                      /* :237 */
+                w->cell[i] = pmax(pmax(pmax(v0[i], v1[i]), inter), 0.0); /* :239-241 */
+            }
+            w->box[j] = vsum(cfg, w->cell, d);                         /* :246 sum(box_max, dims=1) */
+            if (cfg->arith == ORC_ARITH_REFERENCE) {
+                for (int i = 0; i < d; ++i) { run[i] += w->cell[i]; w->tmp[i] = run[i] * h; }
+                w->cum[j + 1] = sum_seq(w->tmp, d);                    /* :244,:246 */
+            }
+        }
+        if (cfg->arith == ORC_ARITH_WAVE64) {                          /* engine order: cumsum after the sum */
+            double acc = 0.0; w->cum[0] = 0.0;
+            for (int j = 0; j + 1 < n; ++j) { acc += w->box[j]; w->cum[j + 1] = acc * h; }
+        }
+        return;
+    }
+
+    /* scalar grid bound, :92-137 */
+    double *val = w->vals, *slp = w->slps;
+    const double refresh = cfg->signed_bound ? cfg->refresh_rate : 0.0;    /* AbstractPDMP.jl:104-112 */
+    for (int j = 0; j < n; ++j) {
+        if (cfg->deriv_mode == ORC_DERIV_FORWARD) {
+            val[j] = sc_func_dual(cfg, w, x, v, t[j], &slp[j]);               /* :97,:102 */
+        } else {
+            val[j] = sc_func_dual(cfg, w, x, v, t[j], NULL);
+            double tm, tp; fd_points(t[j], horizon, &tm, &tp);
+            if (tp == tm) slp[j] = val[j] - val[j];
+            else if (tm == t[j]) slp[j] = (sc_func_dual(cfg, w, x, v, tp, NULL) - val[j]) / (tp - t[j]);
+            else if (tp == t[j]) slp[j] = (val[j] - sc_func_dual(cfg, w, x, v, tm, NULL)) / (t[j] - tm);
+            else { double fp = sc_func_dual(cfg, w, x, v, tp, NULL), fm = sc_func_dual(cfg, w, x, v, tm, NULL);
+                slp[j] = (fp - fm) / (tp - tm); }
+        }
+    }
+    double acc = 0.0; w->cum[0] = 0.0;
+    for (int j = 0; j + 1 < n; ++j) {
+        double p = ((val[j] - val[j + 1]) + slp[j + 1] * h) / (slp[j + 1] - slp[j]);   /* :123 relative form */
+        if (p != p) p = 0.0;                                                         /* :124 */
+        p = (p > h) ? h : ((p < 0.0) ? 0.0 : p);                                     /* :125 */
+        double inter = val[j] + slp[j] * p;                                          /* :127 */
+        double b = pmax(pmax(pmax(val[j], val[j + 1]), inter), 0.0);                 /* :128-130 */
+        b += refresh;                                                                /* :131 (Q2) */
+        w->box[j] = b;
+        acc += b; w->cum[j + 1] = acc * h;                                           /* :133-134 */
+    }
+}
+
+/* next_event, UpperBound.jl:264-273 */
+void orc_next_event(int n, const double *grid, const double *box, const double *cum, double step,
+                    double E, double *tp, double *lb) {
+    int idx = 0;                                   /* searchsortedfirst: first cum[idx] >= E (0-based) */
+    while (idx < n && cum[idx] < E) ++idx;
+    if (idx >= n) { *tp = INFINITY; *lb = box[n - 2]; return; }
+    if (idx == 0) idx = 1;                         /* E <= 0 cannot occur (u < 1); guard */
+    *tp = grid[idx - 1] + (E - cum[idx - 1]) / (cum[idx] - cum[idx - 1]) * step;
+    *lb = box[idx - 1];
+}
+
+double orc_upper_bound(const orc_config_t *cfg, const double *x, const double *v, double horizon,
+                       double *grid, double *box_max, double *cum_sum) {
+    ws_t w; ws_init(&w, cfg->dim, cfg->grid_size);
+    upper_bound(cfg, &w, x, v, horizon);
+    memcpy(grid, w.grid, (size_t)w.n * 8); memcpy(box_max, w.box, (size_t)(w.n - 1) * 8);
+    memcpy(cum_sum, w.cum, (size_t)w.n * 8);
+    double s = w.step; ws_free(&w); return s;
+}
+
+/* in-place flow of the state (no dual) */
+static void flow_state(const orc_config_t *cfg, ws_t *w, double t) {
+    if (cfg->sampler == ORC_BOOMERANG) {
+        double s, c; orc_sincos(t, &s, &c);
+        for (int i = 0; i < w->d; ++i) {
+            double xn = w->x[i] * c + w->v[i] * s, vn = (-w->x[i]) * s + w->v[i] * c;
+            w->x[i] = xn; w->v[i] = vn;
+        }
+    } else {
+        for (int i = 0; i < w->d; ++i) w->x[i] = w->x[i] + w->v[i] * t;
+    }
+}
+
+/* velocity_jump: ZigZagSamplers.jl:101-107, BouncyParticleSamplers.jl:50-74, BoomerangSamplers.jl:49-67 */
+static int velocity_jump(const orc_config_t *cfg, ws_t *w, rng_t *rng) {
+    const int d = w->d;
+    for (int i = 0; i < d; ++i) { w->xe[i] = 0.0; }
+    grad_dual(cfg, w->x, w->xe, w->gv, w->ge);
+    if (cfg->sampler == ORC_ZIGZAG) {
+        for (int i = 0; i < d; ++i) w->tmp[i] = pmax(0.0, w->gv[i] * w->v[i]);
+        double S = vsum(cfg, w->tmp, d);
+        double u = rng_uniform(rng);                          /* Categorical draw (1 uniform) */
+        if (!(S > 0.0)) return 1;                             /* Q11: Categorical would throw */
+        for (int i = 0; i < d; ++i) w->tmp[i] = w->tmp[i] / S;
+        int m = categorical(cfg, w->tmp, d, u);
+        w->v[m] = -w->v[m];                                   /* v[m] *= -1 */
+        return 0;
+    }
+    double *g = w->gv;
+    if (cfg->sampler == ORC_BOOMERANG) for (int i = 0; i < d; ++i) g[i] = g[i] - w->x[i];   /* :51-52 (Q8) */
+    for (int i = 0; i < d; ++i) w->tmp[i] = g[i] * w->v[i];
+    double gv_dot = vsum(cfg, w->tmp, d);
+    double bounce = pmax(0.0, gv_dot);
+    double prob = bounce / (bounce + cfg->refresh_rate);      /* NaN when both are 0 (Q9) */
+    double u = rng_uniform(rng);
+    if (u < prob) {
+        for (int i = 0; i < d; ++i) w->tmp[i] = g[i] * g[i];
+        double gg = vsum(cfg, w->tmp, d);
+        if (cfg->sampler == ORC_BPS) {
+            if (gg == 0.0) return 0;
+            double scale = 2.0 * gv_dot / gg;                 /* :60 */
+            for (int i = 0; i < d; ++i) w->v[i] = w->v[i] - scale * g[i];
+        } else {
+            double nrm = sqrt(gg);                            /* e = g/|g|, :58 */
+            for (int i = 0; i < d; ++i) { w->ge[i] = g[i] / nrm; w->tmp[i] = w->v[i] * w->ge[i]; }
+            double ve = 2.0 * vsum(cfg, w->tmp, d);
+            for (int i = 0; i < d; ++i) w->v[i] = w->v[i] - ve * w->ge[i];   /* :59 */
+        }
+    } else {
+        rng_normals(rng, d, w->v);                            /* randn!, :67 / randn(dim), :65 (chain stream, Q8) */
+        if (cfg->sampler == ORC_BPS && !cfg->gaussian_velocity) {
+            for (int i = 0; i < d; ++i) w->tmp[i] = w->v[i] * w->v[i];
+            double inv = 1.0 / sqrt(vsum(cfg, w->tmp, d));    /* normalize!: rmul!(v, inv(norm(v))) */
+            for (int i = 0; i < d; ++i) w->v[i] = w->v[i] * inv;
+        }
+    }
+    return 0;
+}
+
+int orc_normalize_config(orc_config_t *c) {
+    if (c->dim <= 0) FAIL(-1, "dimension dim must be positive. Current value: %d", c->dim);           /* ZigZagSamplers.jl:62-64 */
+    if (c->grid_size < 0) FAIL(-1, "grid_size must be non-negative. Current value: %d", c->grid_size); /* :66-68 */
+    if (c->grid_size == 0) FAIL(-1, "grid_size == 0 (Brent constant bound) is not restated (SURVEY f4)");
+    if (c->grid_size == 1) FAIL(-1, "grid_size == 1: range(...)[2] is a BoundsError in the reference");
+    if (c->sampler < 0 || c->sampler > 2) FAIL(-1, "unknown sampler id %d", c->sampler);
+    if (c->target_id < 0 || c->target_id > 3) FAIL(-1, "unknown target id %d", c->target_id);
+    if (c->tmax == 0.0) { c->tmax = 1.0; c->adaptive = 1; }                                           /* :73 */
+    if (c->sampler == ORC_ZIGZAG) {
+        if (c->signed_bound && !c->vectorized_bound) c->signed_bound = 0;                             /* :75-78 */
+    } else c->vectorized_bound = 0;                                                                  /* BPS :37, Boomerang :36 */
+    if (c->target_id == ORC_T_GAUSS_DIAG && c->n_target_params != 2 * (int64_t)c->dim) FAIL(-1, "GAUSS_DIAG needs 2*dim params");
+    if (c->target_id == ORC_T_GAUSS_DENSE && c->n_target_params != (int64_t)c->dim * c->dim) FAIL(-1, "GAUSS_DENSE needs dim^2 params");
+    return 0;
+}
+
+/* One chain: sample_skeleton (sample.jl:253-284) = init_state (AbstractPDMP.jl:93-153, the unused
+ * first bound of :140 skipped, Q14) + (n_sk-1) x get_event_state! (SamplingLoopInplace.jl:27-39). */
+static int run_chain(const orc_config_t *cfg, ws_t *w, int64_t n_sk, uint64_t seed, uint64_t chain,
+                     const double *xinit, const double *vinit,
+                     double *X, double *V, double *T, double *H, double *AR, int32_t *EB, double *EV,
+                     int32_t *RJ, int32_t *HH) {
+    const int d = w->d, n = w->n;
+    const int64_t cap = cfg->max_iter_per_event > 0 ? cfg->max_iter_per_event : 1000000;
+    rng_t rng = { seed, chain, 0 };
+    memcpy(w->x, xinit, (size_t)d * 8); memcpy(w->v, vinit, (size_t)d * 8);   /* copy: fixes aliasing Q7 */
+    double t = 0.0, horizon = cfg->tmax, ts = 0.0, tp = 0.0, E = 0.0, lb = 0.0, ar = 0.0;
+    int status = 0;
+    for (int64_t k = 0; k < n_sk; ++k) {
+        int32_t errored = 0, rejected = 0, hits = 0; double ev[5] = { 0, 0, 0, 0, 0 };   /* :28-31 */
+        if (k > 0) {
+            int accept = 0; int64_t it = 0;
+            while (!accept) {                                                         /* :33-35 */
+                if (++it > cap) return -4;
+                /* one_step_of_thinning!, :65-85 */
+                upper_bound(cfg, w, w->x, w->v, horizon);
+                E = rng_exp(&rng);
+                orc_next_event(n, w->grid, w->box, w->cum, w->step, E, &tp, &lb);
+                if (tp > horizon) {                                                   /* move_to_horizon!, :87-101 */
+                    flow_state(cfg, w, horizon);
+                    ts += horizon; hits++;
+                    if (cfg->adaptive) horizon = horizon * 1.01;
+                } else {                                                              /* moves_until_horizon!, :103-111 */
+                    while (tp < horizon && !accept) {
+                        if (++it > cap) return -4;
+                        double lam = true_rate(cfg, w, tp);                           /* ac_step!, :113-129 */
+                        ar = lam / lb;
+                        if (ar > 1.0) {                                               /* erroneous_acceptance_rate!, :131-151 */
+                            double h2 = horizon / 2;
+                            upper_bound(cfg, w, w->x, w->v, h2);
+                            E = rng_exp(&rng);
+                            orc_next_event(n, w->grid, w->box, w->cum, w->step, E, &tp, &lb);
+                            if (cfg->adaptive) horizon = h2;
+                            errored++;
+                            ev[errored % 5] = ar;                                     /* :148, 1-based errored%5+1 */
+                        } else {                                                      /* ac_step_with_proxy!, :153-168 */
+                            double u = rng_uniform(&rng);
+                            accept = u < ar;
+                            if (accept) {                                             /* if_accept!, :170-186 */
+                                flow_state(cfg, w, tp);
+                                status |= velocity_jump(cfg, w, &rng);
+                                t = t + tp + ts; ts = 0.0; tp = 0.0;
+                            } else {                                                  /* if_reject!, :188-203 */
+                                E = E + rng_exp(&rng);
+                                orc_next_event(n, w->grid, w->box, w->cum, w->step, E, &tp, &lb);
+                                if (cfg->adaptive) horizon = horizon / 1.04;
+                                rejected++;
+                            }
+                            if (!accept && tp > horizon) {                            /* move_to_horizon2!, :205-217 (tt = Inf) */
+                                flow_state(cfg, w, horizon);
+                                ts += horizon; hits++;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        /* record!, Composites.jl:239-260 */
+        memcpy(X + (size_t)k * d, w->x, (size_t)d * 8);
+        memcpy(V + (size_t)k * d, w->v, (size_t)d * 8);
+        T[k] = t;
+        if (H) H[k] = horizon;
+        if (AR) AR[k] = ar;
+        if (EB) EB[k] = errored;
+        if (EV) memcpy(EV + 5 * (size_t)k, ev, 40);
+        if (RJ) RJ[k] = rejected;
+        if (HH) HH[k] = hits;
+    }
+    (void)status;
+    return 0;
+}
+
+int orc_sample_skeleton(const orc_config_t *cfg_in, int64_t C, int64_t n_sk, int64_t chain_id_offset,
+                        const double *xinit, const double *vinit, uint64_t seed,
+                        double *X, double *V, double *t, double *horizon, double *ar,
+                        int32_t *errored_bound, double *error_value_ar, int32_t *rejected,
+                        int32_t *hitting_horizon, int n_threads) {
+    orc_config_t cfg = *cfg_in;
+    if (orc_normalize_config(&cfg)) return -1;
+    if (n_sk <= 0) FAIL(-1, "n_sk must be positive. Current value: %lld", (long long)n_sk);   /* sample.jl:262-264 */
+    if (C < 0) FAIL(-1, "number of chains must be non-negative");
+    const int d = cfg.dim;
+    int rc = 0;
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+#else
+    n_threads = 1;
+#endif
+#pragma omp parallel num_threads(n_threads)
+    {
+        ws_t w; int ok = ws_init(&w, d, cfg.grid_size) == 0;
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t c = 0; c < C; ++c) {
+            if (!ok) { rc = -1; continue; }
+            size_t o = (size_t)c * (size_t)n_sk;
+            int r = run_chain(&cfg, &w, n_sk, seed, (uint64_t)(chain_id_offset + c),
+                              xinit + (size_t)c * d, vinit + (size_t)c * d,
+                              X + o * d, V + o * d, t + o,
+                              horizon ? horizon + o : NULL, ar ? ar + o : NULL,
+                              errored_bound ? errored_bound + o : NULL,
+                              error_value_ar ? error_value_ar + 5 * o : NULL,
+                              rejected ? rejected + o : NULL, hitting_horizon ? hitting_horizon + o : NULL);
+            if (r) rc = r;
+        }
+        ws_free(&w);
+    }
+    if (rc == -4) FAIL(-4, "a chain hit the per-event iteration cap");
+    if (rc) FAIL(rc, "allocation failure");
+    return 0;
+}
+
+/* sample_from_skeleton(sampler, N, history), sample.jl:475-513 */
+int orc_sample_from_skeleton(const orc_config_t *cfg, int64_t C, int64_t n_sk, const double *X,
+                             const double *V, const double *t, int64_t N, int discard_vt, double *out,
+                             int n_threads) {
+    if (N <= 0) FAIL(-1, "N must be positive. Current value: %lld", (long long)N);           /* :476-478 */
+    if (n_sk <= 0) FAIL(-1, "empty history");
+    const int d = cfg->dim;
+    const size_t rows = discard_vt ? (size_t)d : 2 * (size_t)d + 1;                           /* :487 */
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+#endif
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+    for (int64_t c = 0; c < C; ++c) {
+        const double *Xc = X + (size_t)c * n_sk * d, *Vc = V + (size_t)c * n_sk * d, *tc = t + (size_t)c * n_sk;
+        double *oc = out + (size_t)c * N * rows;
+        const double dt = tc[n_sk - 1] / (double)N;                                          /* :483-484 */
+        int64_t i = 0;
+        for (int64_t j = 1; j <= N; ++j) {
+            double tm = (double)j * dt;                                                      /* :492 */
+            while (i < n_sk - 1 && tc[i + 1] <= tm) ++i;                                     /* :493-495 */
+            double tau = tm - tc[i];                                                         /* :497 */
+            const double *x0 = Xc + (size_t)i * d, *v0 = Vc + (size_t)i * d;
+            double *o = oc + (size_t)(j - 1) * rows;
+            if (cfg->sampler == ORC_BOOMERANG) {
+                double s, cs; orc_sincos(tau, &s, &cs);
+                for (int q = 0; q < d; ++q) {
+                    o[q] = x0[q] * cs + v0[q] * s;
+                    if (!discard_vt) o[d + q] = (-x0[q]) * s + v0[q] * cs;
+                }
+            } else {
+                for (int q = 0; q < d; ++q) { o[q] = x0[q] + v0[q] * tau; if (!discard_vt) o[d + q] = v0[q]; }
+            }
+            if (!discard_vt) o[2 * d] = tm;                                                  /* :505-508 */
+        }
+    }
+    return 0;
+}

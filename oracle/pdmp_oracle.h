@@ -1,0 +1,94 @@
+/*
+ * pdmp_oracle.h -- CPU restatement of PDMPFlux.jl's sample_skeleton()/sample_from_skeleton()
+ * hot path.  TEST INFRASTRUCTURE ONLY: this is the checker, never the product.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ *
+ * PARITY UNPINNED: the reference (pure Julia, /root/reference) cannot be executed in this
+ * pipeline (no Julia toolchain) and holds no golden vectors for this path.  The restatement is
+ * pinned by the reference's invariant / statistical tests, by hand-derived known answers, and by
+ * Philox/libm known-answer vectors for the (build-defined) random stream.
+ *
+ * All file:line citations are relative to /root/reference/.
+ */
+#ifndef PDMP_ORACLE_H
+#define PDMP_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* sampler ids -- src/Samplers/{ZigZag,BouncyParticle,Boomerang}Samplers.jl */
+enum { ORC_ZIGZAG = 0, ORC_BPS = 1, ORC_BOOMERANG = 2 };
+/* built-in potentials (closures cannot cross a C ABI) */
+enum { ORC_T_GAUSS_ISO = 0, ORC_T_GAUSS_DIAG = 1, ORC_T_BANANA = 2, ORC_T_GAUSS_DENSE = 3 };
+/* time-derivative of the bounded rate: UpperBound.jl:209-210 (ForwardDiff) / :223-224 (FiniteDiff) */
+enum { ORC_DERIV_FORWARD = 0, ORC_DERIV_FINITE_DIFF = 1 };
+/* floating-point summation order:
+ *   REFERENCE: plain left-to-right sums over coordinates, per-dimension cumsum before the sum over
+ *              dimensions (UpperBound.jl:243-246), sequential Categorical walk.
+ *   WAVE64   : the order the MI355X engine uses (64-lane ascending xor-butterfly, Kogge-Stone
+ *              prefix scan, cumsum after the sum over dimensions).  Bitwise target for the HIP path. */
+enum { ORC_ARITH_REFERENCE = 0, ORC_ARITH_WAVE64 = 1 };
+
+typedef struct orc_config_t {
+    int32_t sampler;
+    int32_t dim;
+    int32_t grid_size;          /* n >= 2; 0 (Brent constant bound, UpperBound.jl:18-36) is not restated */
+    int32_t vectorized_bound;
+    int32_t signed_bound;
+    int32_t adaptive;
+    int32_t gaussian_velocity;  /* BPS only, BouncyParticleSamplers.jl:24,68-72 */
+    int32_t deriv_mode;
+    int32_t target_id;
+    int32_t arith;
+    double  tmax;
+    double  refresh_rate;
+    const double *target_params; /* DIAG: mu[d], prec[d];  DENSE: P[d*d] column-major */
+    int64_t n_target_params;
+    int64_t max_iter_per_event;  /* 0 = default 1e6; safety cap (status -4) */
+} orc_config_t;
+
+const char *orc_last_error(void);
+
+/* Normalises cfg the way the reference constructors do (ZigZagSamplers.jl:62-78,
+ * BouncyParticleSamplers.jl:26-37, BoomerangSamplers.jl:25-36).  Returns 0 or -1. */
+int orc_normalize_config(orc_config_t *cfg);
+
+/* Ensemble of C independent chains; chain c uses the Philox key (seed, chain_id_offset + c).
+ * Layouts (column-major, as PDMPHistory, Composites.jl:138-149,239-260):
+ *   xinit,vinit: d x C;  X,V: d x n_sk x C;  t,horizon,ar: n_sk x C;  error_value_ar: 5 x n_sk x C;
+ *   errored_bound,rejected,hitting_horizon: int32 n_sk x C.   Diagnostic pointers may be NULL.
+ * n_threads <= 0 -> all OpenMP threads.   Returns 0, -1 (argument), -4 (iteration cap). */
+int orc_sample_skeleton(const orc_config_t *cfg, int64_t C, int64_t n_sk, int64_t chain_id_offset,
+                        const double *xinit, const double *vinit, uint64_t seed,
+                        double *X, double *V, double *t,
+                        double *horizon, double *ar, int32_t *errored_bound, double *error_value_ar,
+                        int32_t *rejected, int32_t *hitting_horizon, int n_threads);
+
+/* sample.jl:475-513, per chain; out: d x N x C (or (2d+1) x N x C if !discard_vt). */
+int orc_sample_from_skeleton(const orc_config_t *cfg, int64_t C, int64_t n_sk,
+                             const double *X, const double *V, const double *t,
+                             int64_t N, int discard_vt, double *out, int n_threads);
+
+/* --- pieces exposed for known-answer tests --- */
+void   orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+double orc_log(double x);
+void   orc_sincos(double x, double *s, double *c);
+void   orc_sincos_2pi(double u, double *s, double *c);
+/* first n_draw variates of chain stream (seed, chain): kind 0 uniform, 1 exp, 2 normal-vector (d=n_draw) */
+void   orc_rng_dump(uint64_t seed, int64_t chain, int kind, int64_t n_draw, double *out);
+/* one bound + inversion: fills grid[n], box_max[n-1], cum_sum[n]; returns step_size (UpperBound.jl) */
+double orc_upper_bound(const orc_config_t *cfg, const double *x, const double *v, double horizon,
+                       double *grid, double *box_max, double *cum_sum);
+void   orc_next_event(int n, const double *grid, const double *box_max, const double *cum_sum,
+                      double step_size, double exp_rv, double *tp, double *lambda_bar);
+/* gradient of the built-in potential (the user's grad-U closure) */
+void   orc_grad(const orc_config_t *cfg, const double *x, double *g);
+double orc_potential(const orc_config_t *cfg, const double *x);
+int    orc_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
