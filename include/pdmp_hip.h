@@ -1,0 +1,137 @@
+/*
+ * pdmp_hip.h -- C ABI of libpdmphip.so, the MI355X (gfx950) engine behind PDMPFlux.jl's
+ * sample_skeleton() / sample_from_skeleton() / sample() for ensembles of independent chains.
+ *
+ * PDMPFlux.jl has no FFI seam of its own (pure Julia, multiple dispatch on AbstractPDMP,
+ * src/Samplers/AbstractPDMP.jl:6); these entry points are what a `ccall` shim bound to the exported
+ * functions of src/PDMPFlux.jl:26 needs.  Each declaration names the reference interface it replaces
+ * (file:line under the reference tree).  Plain pointers and sizes only; no torch / HIP types.
+ *
+ * Conventions
+ *   - All arrays are column-major exactly as the reference's PDMPHistory (src/Composites.jl:138-149):
+ *       xinit, vinit : d x C                       (chain c = column c)
+ *       X, V         : d x n_sk x C                (event k of chain c at offset ((c*n_sk)+k)*d)
+ *       t, horizon, ar            : n_sk x C       (double)
+ *       errored_bound, rejected, hitting_horizon : n_sk x C (int32, Composites.jl:145-148)
+ *       error_value_ar            : 5 x n_sk x C
+ *   - Chain c draws from the Philox4x32-10 stream keyed (seed, chain_id_offset + c): results do not
+ *     depend on how chains are sharded over GPUs (mirrors `seed = 42 + i`, test/test_property_based.jl:138).
+ *   - Return 0 on success; <0 on error with a message in pdmp_last_error():
+ *       PDMP_ERR_ARGUMENT  (-1)  -> Julia ArgumentError   (sample.jl:262-264,476-478; ZigZagSamplers.jl:62-68)
+ *       PDMP_ERR_DIMENSION (-2)  -> Julia DimensionMismatch (AbstractPDMP.jl:96-98)
+ *       PDMP_ERR_RUNTIME   (-3)  HIP runtime failure / no device
+ *       PDMP_ERR_ITERCAP   (-4)  a chain exceeded max_iter_per_event thinning steps for one event
+ *       PDMP_ERR_UNSUPPORTED (-5) configuration outside what the engine implements
+ *   - Inputs are never mutated (deliberate fix of the aliasing quirk, AbstractPDMP.jl:141-149).
+ *   - A handle is not re-entrant; distinct handles may be used from distinct host threads.
+ */
+#ifndef PDMP_HIP_H
+#define PDMP_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDMP_ABI_VERSION 1
+
+enum { PDMP_OK = 0, PDMP_ERR_ARGUMENT = -1, PDMP_ERR_DIMENSION = -2, PDMP_ERR_RUNTIME = -3,
+       PDMP_ERR_ITERCAP = -4, PDMP_ERR_UNSUPPORTED = -5 };
+
+/* src/Samplers/ZigZagSamplers.jl:35-116, BouncyParticleSamplers.jl:1-84, BoomerangSamplers.jl:1-77 */
+enum { PDMP_ZIGZAG = 0, PDMP_BPS = 1, PDMP_BOOMERANG = 2 };
+/* Potential descriptors replacing the Julia closure field `grad-U` (ZigZagSamplers.jl:37): */
+enum { PDMP_T_GAUSS_ISO = 0,   /* U = |x|^2/2                         (README.md:36-38)            */
+       PDMP_T_GAUSS_DIAG = 1,  /* U = sum prec_i (x_i-mu_i)^2/2 ; params = mu[d], prec[d]            */
+       PDMP_T_BANANA = 2,      /* U_banana                           (test/test_config.jl:33-36)   */
+       PDMP_T_GAUSS_DENSE = 3  /* U = x'Px/2 ; params = P[d*d] column-major                         */ };
+/* AD_backend for the time-derivative of the rate (UpperBound.jl:209-224, AbstractPDMP.jl:18-28) */
+enum { PDMP_DERIV_FORWARD = 0 /* "ForwardDiff": exact forward-mode duals */,
+       PDMP_DERIV_FINITE_DIFF = 1 /* "FiniteDiff": UpperBound.jl:50-76 */ };
+
+/* Keyword arguments of the reference constructors as a plain struct. */
+typedef struct pdmp_config_t {
+    int32_t sampler;            /* PDMP_ZIGZAG | PDMP_BPS | PDMP_BOOMERANG */
+    int32_t dim;                /* > 0 */
+    int32_t grid_size;          /* 2..64; 0 (Brent) is PDMP_ERR_UNSUPPORTED */
+    int32_t vectorized_bound;   /* ZigZag default 1; forced 0 for BPS/Boomerang */
+    int32_t signed_bound;       /* default 1 */
+    int32_t adaptive;           /* default 1 */
+    int32_t gaussian_velocity;  /* BPS(Gaussian_velocity=...) */
+    int32_t deriv_mode;         /* PDMP_DERIV_* */
+    int32_t target_id;          /* PDMP_T_* */
+    int32_t device;             /* HIP device ordinal; -1 = current device */
+    double  tmax;               /* 0 -> 1.0 and adaptive=1 (ZigZagSamplers.jl:73) */
+    double  refresh_rate;
+    const double *target_params;/* host pointer, copied by pdmp_create */
+    int64_t n_target_params;
+    int64_t max_iter_per_event; /* 0 -> 1e6 */
+} pdmp_config_t;
+
+typedef struct pdmp_engine *pdmp_handle;
+
+/* Optional per-event diagnostics of PDMPHistory (Composites.jl:143-148); any pointer may be NULL. */
+typedef struct pdmp_diag_t {
+    double  *horizon;
+    double  *ar;
+    int32_t *errored_bound;
+    double  *error_value_ar;
+    int32_t *rejected;
+    int32_t *hitting_horizon;
+} pdmp_diag_t;
+
+typedef struct pdmp_timing_t {
+    double  kernel_ms_total;    /* sum of hipEvent-timed kernel durations since the last reset */
+    double  kernel_ms_last;
+    int64_t launches;
+} pdmp_timing_t;
+
+int         pdmp_abi_version(void);
+const char *pdmp_last_error(void);       /* thread-local */
+int         pdmp_device_count(void);     /* hipGetDeviceCount; 0 when no GPU is visible */
+
+/* Sampler construction: ZigZag/ZigZagAD (ZigZagSamplers.jl:58-126), BPS/BPSAD
+ * (BouncyParticleSamplers.jl:21-94), Boomerang/BoomerangAD (BoomerangSamplers.jl:21-87).
+ * Applies the constructors' normalisations; the normalised values can be read back. */
+int pdmp_create(const pdmp_config_t *cfg, pdmp_handle *out);
+int pdmp_get_config(pdmp_handle h, pdmp_config_t *out);
+int pdmp_destroy(pdmp_handle h);
+
+/* sample_skeleton(sampler, n_sk, xinit, vinit; seed)  (src/sample.jl:253-284) for C chains:
+ * init_state (AbstractPDMP.jl:93-153) + (n_sk-1) x get_event_state! (SamplingLoopInplace.jl:27-39)
+ * + record! (Composites.jl:239-260).  HOST pointers; blocking. */
+int pdmp_sample_skeleton(pdmp_handle h, int64_t C, int64_t n_sk, int64_t chain_id_offset,
+                         const double *xinit, const double *vinit, uint64_t seed,
+                         double *X, double *V, double *t, const pdmp_diag_t *diag);
+
+/* Same with DEVICE pointers (HBM-resident inputs and outputs), enqueued on `stream`
+ * (a hipStream_t passed as void*; NULL = the null stream).  Asynchronous: chain status is checked by
+ * pdmp_check_status().  This is the entry the multi-GPU driver and bench.py use. */
+int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t chain_id_offset,
+                                const double *xinit, const double *vinit, uint64_t seed,
+                                double *X, double *V, double *t, const pdmp_diag_t *diag, void *stream);
+
+/* sample_from_skeleton(sampler, N, history; discard_vt)  (src/sample.jl:475-513) for C chains.
+ * out: rows x N x C with rows = d (discard_vt) or 2d+1. */
+int pdmp_sample_from_skeleton(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
+                              const double *t, int64_t N, int32_t discard_vt, double *out);
+int pdmp_sample_from_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, const double *X,
+                                     const double *V, const double *t, int64_t N, int32_t discard_vt,
+                                     double *out, void *stream);
+
+/* Synchronises the handle's last stream and returns PDMP_ERR_ITERCAP if any chain of the launches
+ * since the previous check hit the iteration cap (Q11 guard events are counted in *n_guard if non-NULL). */
+int pdmp_check_status(pdmp_handle h, int64_t *n_guard);
+
+/* hipEvent timing of the kernels launched through this handle (on the launch stream). */
+int pdmp_get_timing(pdmp_handle h, pdmp_timing_t *out);
+int pdmp_reset_timing(pdmp_handle h);
+
+/* Test hook: first n variates of stream (seed, chain) produced ON THE DEVICE with the engine's
+ * generator; kind 0 uniform, 1 Exp(1), 2 normal vector.  out is a HOST pointer. */
+int pdmp_debug_rng(pdmp_handle h, uint64_t seed, int64_t chain, int32_t kind, int64_t n, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,401 @@
+// engine_api.hip -- C ABI of libpdmphip.so (include/pdmp_hip.h): handle management, argument checks
+// that mirror the reference constructors, kernel dispatch, sample_from_skeleton kernel, hipEvent timing.
+#include "../../include/pdmp_hip.h"
+#include "skeleton_kernel.hpp"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+using namespace pdmp;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(PDMP_ERR_RUNTIME, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct EventPair { hipEvent_t a, b; };
+
+}  // namespace
+
+struct pdmp_engine {
+    pdmp_config_t cfg;
+    int device = 0;
+    double *d_tparams = nullptr;
+    int32_t *d_status = nullptr;      // [0] itercap chains, [1] guard events
+    hipStream_t last_stream = nullptr;
+    std::vector<EventPair> pending;   // launches not yet folded into `timing`
+    std::vector<EventPair> pool;
+    pdmp_timing_t timing = {0.0, 0.0, 0};
+};
+
+namespace {
+
+// ---------------------------------------------------------------- sample_from_skeleton, sample.jl:475-513
+// One wave per (chain, tile of 64 output samples): lane s finds the skeleton segment of sample
+// tile*64+s by binary search in t (equivalent to the reference's monotone pointer walk :493-495 for
+// non-decreasing t), then the wave writes the 64 samples one after the other, lanes over coordinates
+// (coalesced d*8-byte rows).
+template <bool BOOMERANG>
+__global__ __launch_bounds__(256) void from_skeleton_kernel(int d, int64_t C, int64_t n_sk, const double *X,
+                                                            const double *V, const double *t, int64_t N,
+                                                            int discard_vt, double *out) {
+    const int lane = lane_id();
+    const int64_t tiles = (N + WAVE - 1) / WAVE;
+    const int64_t w = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (w >= C * tiles) return;
+    const int64_t c = w / tiles, tile = w % tiles;
+    const double *tc = t + (size_t)c * n_sk;
+    const double dt = tc[n_sk - 1] / (double)N;                       // :483-484
+    const int64_t j = tile * WAVE + lane + 1;                         // 1-based sample index
+    const double tm = (double)j * dt;                                 // :492
+    int64_t lo = 0, hi = n_sk - 1;
+    if (j <= N) {
+        while (lo < hi) {                                             // last index with t[i] <= tm
+            const int64_t mid = (lo + hi + 1) >> 1;
+            if (tc[mid] <= tm) lo = mid; else hi = mid - 1;
+        }
+    }
+    const double tau = tm - tc[lo];                                   // :497
+    const int seg_lo = (int)lo, seg_hi = (int)(lo >> 32);
+    const size_t rows = discard_vt ? (size_t)d : 2 * (size_t)d + 1;   // :487
+    const int64_t nvalid = (N - tile * WAVE) < WAVE ? (N - tile * WAVE) : WAVE;
+    for (int s = 0; s < (int)nvalid; ++s) {
+        const int64_t i = ((int64_t)__builtin_amdgcn_readlane(seg_hi, s) << 32) |
+                          (uint32_t)__builtin_amdgcn_readlane(seg_lo, s);
+        const double ta = readlane_d(tau, s), tms = readlane_d(tm, s);
+        const double *x0 = X + ((size_t)c * n_sk + (size_t)i) * d, *v0 = V + ((size_t)c * n_sk + (size_t)i) * d;
+        double *o = out + ((size_t)c * N + (size_t)(tile * WAVE + s)) * rows;
+        double sn = 0.0, cs = 1.0;
+        if (BOOMERANG) det_sincos(ta, sn, cs);
+        for (int q = lane; q < d; q += WAVE) {
+            const double xq = x0[q], vq = v0[q];
+            if (BOOMERANG) {                                          // BoomerangSamplers.jl:31
+                o[q] = xq * cs + vq * sn;
+                if (!discard_vt) o[d + q] = (-xq) * sn + vq * cs;
+            } else {                                                  // ZigZagSamplers.jl:80
+                o[q] = xq + vq * ta;
+                if (!discard_vt) o[d + q] = vq;
+            }
+        }
+        if (!discard_vt && lane == 0) o[2 * d] = tms;                 // :505-508
+    }
+}
+
+__global__ void debug_rng_kernel(uint64_t seed, int64_t chain, int kind, int64_t n, double *out) {
+    ChainRng rng;
+    rng.init(seed, (uint64_t)chain);
+    const int lane = lane_id();
+    if (kind == 2) {
+        for (int64_t i = lane; i < n; i += WAVE) out[i] = rng.normal_coord((int)i);
+        return;
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        const double r = (kind == 0) ? rng.uniform() : rng.exponential();
+        if (lane == 0) out[i] = r;
+    }
+}
+
+int normalize_config(pdmp_config_t &c) {
+    if (c.dim <= 0) return fail(PDMP_ERR_ARGUMENT, "dimension dim must be positive. Current value: %d", c.dim);          // ZigZagSamplers.jl:62-64
+    if (c.grid_size < 0) return fail(PDMP_ERR_ARGUMENT, "grid_size must be non-negative. Current value: %d", c.grid_size); // :66-68
+    if (c.grid_size == 0) return fail(PDMP_ERR_UNSUPPORTED, "grid_size == 0 (Brent constant bound, UpperBound.jl:18-36) is not implemented");
+    if (c.grid_size == 1 || c.grid_size > WAVE) return fail(PDMP_ERR_UNSUPPORTED, "grid_size must be in 2..64. Current value: %d", c.grid_size);
+    if (c.sampler < PDMP_ZIGZAG || c.sampler > PDMP_BOOMERANG) return fail(PDMP_ERR_ARGUMENT, "unknown sampler id %d", c.sampler);
+    if (c.target_id < 0 || c.target_id > PDMP_T_GAUSS_DENSE) return fail(PDMP_ERR_ARGUMENT, "unknown target id %d", c.target_id);
+    if (c.target_id == PDMP_T_GAUSS_DENSE) return fail(PDMP_ERR_UNSUPPORTED, "dense-precision target is not implemented yet");
+    if (c.deriv_mode != PDMP_DERIV_FORWARD && c.deriv_mode != PDMP_DERIV_FINITE_DIFF) return fail(PDMP_ERR_ARGUMENT, "Unsupported AD_backend id %d", c.deriv_mode);
+    if (!std::isfinite(c.tmax) || c.tmax < 0.0) return fail(PDMP_ERR_ARGUMENT, "tmax must be finite and non-negative");
+    if (c.tmax == 0.0) { c.tmax = 1.0; c.adaptive = 1; }                                            // ZigZagSamplers.jl:73
+    if (c.sampler == PDMP_ZIGZAG) {
+        if (c.signed_bound && !c.vectorized_bound) c.signed_bound = 0;                              // :75-78
+    } else {
+        c.vectorized_bound = 0;                                                                     // BPS :37, Boomerang :36
+    }
+    if (c.dim > 4 * WAVE) return fail(PDMP_ERR_UNSUPPORTED, "dim > %d is not implemented yet", 4 * WAVE);
+    if (c.target_id == PDMP_T_GAUSS_DIAG && (c.n_target_params != 2 * (int64_t)c.dim || !c.target_params))
+        return fail(PDMP_ERR_ARGUMENT, "GAUSS_DIAG needs target_params = mu[dim], prec[dim]");
+    if (c.max_iter_per_event <= 0) c.max_iter_per_event = 1000000;
+    return PDMP_OK;
+}
+
+typedef hipError_t (*launch_fn)(const SkelParams &, hipStream_t);
+launch_fn pick_launcher(int sampler, int target) {
+    static const launch_fn table[3][3] = {
+        {launch_skeleton<S_ZIGZAG, T_GAUSS_ISO>, launch_skeleton<S_ZIGZAG, T_GAUSS_DIAG>, launch_skeleton<S_ZIGZAG, T_BANANA>},
+        {launch_skeleton<S_BPS, T_GAUSS_ISO>, launch_skeleton<S_BPS, T_GAUSS_DIAG>, launch_skeleton<S_BPS, T_BANANA>},
+        {launch_skeleton<S_BOOMERANG, T_GAUSS_ISO>, launch_skeleton<S_BOOMERANG, T_GAUSS_DIAG>, launch_skeleton<S_BOOMERANG, T_BANANA>},
+    };
+    return table[sampler][target];
+}
+
+int begin_timed(pdmp_engine *h, hipStream_t s, EventPair &ev) {
+    if (!h->pool.empty()) { ev = h->pool.back(); h->pool.pop_back(); }
+    else { HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); }
+    HIP_TRY(hipEventRecord(ev.a, s));
+    return PDMP_OK;
+}
+int end_timed(pdmp_engine *h, hipStream_t s, EventPair &ev) {
+    HIP_TRY(hipEventRecord(ev.b, s));
+    h->pending.push_back(ev);
+    h->last_stream = s;
+    return PDMP_OK;
+}
+int fold_timing(pdmp_engine *h) {
+    for (auto &ev : h->pending) {
+        HIP_TRY(hipEventSynchronize(ev.b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
+        h->timing.kernel_ms_total += ms;
+        h->timing.kernel_ms_last = ms;
+        h->timing.launches++;
+        h->pool.push_back(ev);
+    }
+    h->pending.clear();
+    return PDMP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pdmp_abi_version(void) { return PDMP_ABI_VERSION; }
+const char *pdmp_last_error(void) { return g_err; }
+int pdmp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pdmp_create(const pdmp_config_t *cfg, pdmp_handle *out) {
+    if (!cfg || !out) return fail(PDMP_ERR_ARGUMENT, "null argument");
+    *out = nullptr;
+    pdmp_config_t c = *cfg;
+    if (int rc = normalize_config(c)) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(PDMP_ERR_RUNTIME, "no HIP device visible: the PDMP engine has no CPU fallback");
+    int dev = c.device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    if (dev >= ndev) return fail(PDMP_ERR_ARGUMENT, "device %d out of range (%d visible)", dev, ndev);
+    HIP_TRY(hipSetDevice(dev));
+    pdmp_engine *h = new pdmp_engine();
+    h->cfg = c;
+    h->cfg.device = dev;
+    h->device = dev;
+    h->cfg.target_params = nullptr;
+    if (c.n_target_params > 0 && c.target_params) {
+        HIP_TRY(hipMalloc(&h->d_tparams, (size_t)c.n_target_params * 8));
+        HIP_TRY(hipMemcpy(h->d_tparams, c.target_params, (size_t)c.n_target_params * 8, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMalloc(&h->d_status, 2 * sizeof(int32_t)));
+    HIP_TRY(hipMemset(h->d_status, 0, 2 * sizeof(int32_t)));
+    *out = h;
+    return PDMP_OK;
+}
+
+int pdmp_get_config(pdmp_handle h, pdmp_config_t *out) {
+    if (!h || !out) return fail(PDMP_ERR_ARGUMENT, "null argument");
+    *out = h->cfg;
+    return PDMP_OK;
+}
+
+int pdmp_destroy(pdmp_handle h) {
+    if (!h) return PDMP_OK;
+    (void)hipSetDevice(h->device);
+    (void)fold_timing(h);
+    for (auto &ev : h->pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    if (h->d_tparams) (void)hipFree(h->d_tparams);
+    if (h->d_status) (void)hipFree(h->d_status);
+    delete h;
+    return PDMP_OK;
+}
+
+int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t chain_id_offset,
+                                const double *xinit, const double *vinit, uint64_t seed, double *X, double *V,
+                                double *t, const pdmp_diag_t *diag, void *stream) {
+    if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
+    if (n_sk <= 0) return fail(PDMP_ERR_ARGUMENT, "n_sk must be positive. Current value: %lld", (long long)n_sk);   // sample.jl:262-264
+    if (C < 0) return fail(PDMP_ERR_ARGUMENT, "number of chains must be non-negative");
+    if (C == 0) return PDMP_OK;
+    if (!xinit || !vinit || !X || !V || !t) return fail(PDMP_ERR_ARGUMENT, "null buffer");
+    if ((C + 3) / 4 > 0x7fffffffLL) return fail(PDMP_ERR_UNSUPPORTED, "too many chains for one launch");
+    HIP_TRY(hipSetDevice(h->device));
+    SkelParams p;
+    memset(&p, 0, sizeof p);
+    const pdmp_config_t &c = h->cfg;
+    p.d = c.dim; p.n_grid = c.grid_size; p.signed_bound = c.signed_bound; p.adaptive = c.adaptive;
+    p.gaussian_velocity = c.gaussian_velocity; p.deriv_mode = c.deriv_mode; p.vectorized = c.vectorized_bound;
+    p.C = C; p.n_sk = n_sk; p.chain0 = chain_id_offset; p.cap = c.max_iter_per_event; p.seed = seed;
+    p.tmax = c.tmax; p.refresh = c.refresh_rate;
+    p.xinit = xinit; p.vinit = vinit; p.tparams = h->d_tparams;
+    p.X = X; p.V = V; p.t = t;
+    if (diag) {
+        p.H = diag->horizon; p.AR = diag->ar; p.EV = diag->error_value_ar;
+        p.EB = diag->errored_bound; p.RJ = diag->rejected; p.HH = diag->hitting_horizon;
+    }
+    p.status = h->d_status;
+    hipStream_t s = (hipStream_t)stream;
+    EventPair ev;
+    if (int rc = begin_timed(h, s, ev)) return rc;
+    HIP_TRY(pick_launcher(c.sampler, c.target_id)(p, s));
+    return end_timed(h, s, ev);
+}
+
+int pdmp_check_status(pdmp_handle h, int64_t *n_guard) {
+    if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->last_stream));
+    int32_t st[2] = {0, 0};
+    HIP_TRY(hipMemcpy(st, h->d_status, sizeof st, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(h->d_status, 0, sizeof st));
+    if (n_guard) *n_guard = st[1];
+    if (st[0] > 0) return fail(PDMP_ERR_ITERCAP, "%d chain(s) hit the per-event iteration cap (%lld)", st[0],
+                               (long long)h->cfg.max_iter_per_event);
+    return PDMP_OK;
+}
+
+int pdmp_sample_skeleton(pdmp_handle h, int64_t C, int64_t n_sk, int64_t chain_id_offset, const double *xinit,
+                         const double *vinit, uint64_t seed, double *X, double *V, double *t,
+                         const pdmp_diag_t *diag) {
+    if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
+    if (n_sk <= 0) return fail(PDMP_ERR_ARGUMENT, "n_sk must be positive. Current value: %lld", (long long)n_sk);
+    if (C < 0) return fail(PDMP_ERR_ARGUMENT, "number of chains must be non-negative");
+    if (C == 0) return PDMP_OK;
+    if (!xinit || !vinit || !X || !V || !t) return fail(PDMP_ERR_ARGUMENT, "null buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t d = (size_t)h->cfg.dim, ne = (size_t)C * (size_t)n_sk;
+    double *dx = nullptr, *dv = nullptr, *dX = nullptr, *dV = nullptr, *dt = nullptr;
+    double *dH = nullptr, *dAR = nullptr, *dEV = nullptr;
+    int32_t *dEB = nullptr, *dRJ = nullptr, *dHH = nullptr;
+    int rc = PDMP_OK;
+    auto cleanup = [&]() {
+        (void)hipFree(dx); (void)hipFree(dv); (void)hipFree(dX); (void)hipFree(dV); (void)hipFree(dt);
+        (void)hipFree(dH); (void)hipFree(dAR); (void)hipFree(dEV); (void)hipFree(dEB); (void)hipFree(dRJ); (void)hipFree(dHH);
+    };
+#define TRY_OR_CLEAN(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(PDMP_ERR_RUNTIME, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
+    TRY_OR_CLEAN(hipMalloc(&dx, (size_t)C * d * 8));
+    TRY_OR_CLEAN(hipMalloc(&dv, (size_t)C * d * 8));
+    TRY_OR_CLEAN(hipMalloc(&dX, ne * d * 8));
+    TRY_OR_CLEAN(hipMalloc(&dV, ne * d * 8));
+    TRY_OR_CLEAN(hipMalloc(&dt, ne * 8));
+    pdmp_diag_t dd = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (diag) {
+        if (diag->horizon) { TRY_OR_CLEAN(hipMalloc(&dH, ne * 8)); dd.horizon = dH; }
+        if (diag->ar) { TRY_OR_CLEAN(hipMalloc(&dAR, ne * 8)); dd.ar = dAR; }
+        if (diag->error_value_ar) { TRY_OR_CLEAN(hipMalloc(&dEV, ne * 40)); dd.error_value_ar = dEV; }
+        if (diag->errored_bound) { TRY_OR_CLEAN(hipMalloc(&dEB, ne * 4)); dd.errored_bound = dEB; }
+        if (diag->rejected) { TRY_OR_CLEAN(hipMalloc(&dRJ, ne * 4)); dd.rejected = dRJ; }
+        if (diag->hitting_horizon) { TRY_OR_CLEAN(hipMalloc(&dHH, ne * 4)); dd.hitting_horizon = dHH; }
+    }
+    TRY_OR_CLEAN(hipMemcpy(dx, xinit, (size_t)C * d * 8, hipMemcpyHostToDevice));
+    TRY_OR_CLEAN(hipMemcpy(dv, vinit, (size_t)C * d * 8, hipMemcpyHostToDevice));
+    rc = pdmp_sample_skeleton_device(h, C, n_sk, chain_id_offset, dx, dv, seed, dX, dV, dt, diag ? &dd : nullptr, nullptr);
+    if (rc == PDMP_OK) rc = pdmp_check_status(h, nullptr);
+    if (rc == PDMP_OK || rc == PDMP_ERR_ITERCAP) {
+        char keep[sizeof g_err];
+        memcpy(keep, g_err, sizeof keep);
+        TRY_OR_CLEAN(hipMemcpy(X, dX, ne * d * 8, hipMemcpyDeviceToHost));
+        TRY_OR_CLEAN(hipMemcpy(V, dV, ne * d * 8, hipMemcpyDeviceToHost));
+        TRY_OR_CLEAN(hipMemcpy(t, dt, ne * 8, hipMemcpyDeviceToHost));
+        if (dH) TRY_OR_CLEAN(hipMemcpy(diag->horizon, dH, ne * 8, hipMemcpyDeviceToHost));
+        if (dAR) TRY_OR_CLEAN(hipMemcpy(diag->ar, dAR, ne * 8, hipMemcpyDeviceToHost));
+        if (dEV) TRY_OR_CLEAN(hipMemcpy(diag->error_value_ar, dEV, ne * 40, hipMemcpyDeviceToHost));
+        if (dEB) TRY_OR_CLEAN(hipMemcpy(diag->errored_bound, dEB, ne * 4, hipMemcpyDeviceToHost));
+        if (dRJ) TRY_OR_CLEAN(hipMemcpy(diag->rejected, dRJ, ne * 4, hipMemcpyDeviceToHost));
+        if (dHH) TRY_OR_CLEAN(hipMemcpy(diag->hitting_horizon, dHH, ne * 4, hipMemcpyDeviceToHost));
+        memcpy(g_err, keep, sizeof keep);
+    }
+    cleanup();
+    return rc;
+}
+
+int pdmp_sample_from_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
+                                     const double *t, int64_t N, int32_t discard_vt, double *out, void *stream) {
+    if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
+    if (N <= 0) return fail(PDMP_ERR_ARGUMENT, "N must be positive. Current value: %lld", (long long)N);   // sample.jl:476-478
+    if (n_sk <= 0) return fail(PDMP_ERR_ARGUMENT, "empty history");
+    if (C < 0) return fail(PDMP_ERR_ARGUMENT, "number of chains must be non-negative");
+    if (C == 0) return PDMP_OK;
+    if (!X || !V || !t || !out) return fail(PDMP_ERR_ARGUMENT, "null buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    const int64_t tiles = (N + WAVE - 1) / WAVE, waves = C * tiles, blocks = (waves + 3) / 4;
+    if (blocks > 0x7fffffffLL) return fail(PDMP_ERR_UNSUPPORTED, "too many samples for one launch");
+    hipStream_t s = (hipStream_t)stream;
+    EventPair ev;
+    if (int rc = begin_timed(h, s, ev)) return rc;
+    if (h->cfg.sampler == PDMP_BOOMERANG)
+        hipLaunchKernelGGL(from_skeleton_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, (int)discard_vt, out);
+    else
+        hipLaunchKernelGGL(from_skeleton_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, (int)discard_vt, out);
+    HIP_TRY(hipGetLastError());
+    return end_timed(h, s, ev);
+}
+
+int pdmp_sample_from_skeleton(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
+                              const double *t, int64_t N, int32_t discard_vt, double *out) {
+    if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
+    if (N <= 0) return fail(PDMP_ERR_ARGUMENT, "N must be positive. Current value: %lld", (long long)N);
+    if (n_sk <= 0) return fail(PDMP_ERR_ARGUMENT, "empty history");
+    if (C <= 0) return C == 0 ? PDMP_OK : fail(PDMP_ERR_ARGUMENT, "number of chains must be non-negative");
+    if (!X || !V || !t || !out) return fail(PDMP_ERR_ARGUMENT, "null buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t d = (size_t)h->cfg.dim, ne = (size_t)C * (size_t)n_sk;
+    const size_t rows = discard_vt ? d : 2 * d + 1, no = (size_t)C * (size_t)N * rows;
+    double *dX = nullptr, *dV = nullptr, *dt = nullptr, *dout = nullptr;
+    auto cleanup = [&]() { (void)hipFree(dX); (void)hipFree(dV); (void)hipFree(dt); (void)hipFree(dout); };
+    TRY_OR_CLEAN(hipMalloc(&dX, ne * d * 8));
+    TRY_OR_CLEAN(hipMalloc(&dV, ne * d * 8));
+    TRY_OR_CLEAN(hipMalloc(&dt, ne * 8));
+    TRY_OR_CLEAN(hipMalloc(&dout, no * 8));
+    TRY_OR_CLEAN(hipMemcpy(dX, X, ne * d * 8, hipMemcpyHostToDevice));
+    TRY_OR_CLEAN(hipMemcpy(dV, V, ne * d * 8, hipMemcpyHostToDevice));
+    TRY_OR_CLEAN(hipMemcpy(dt, t, ne * 8, hipMemcpyHostToDevice));
+    int rc = pdmp_sample_from_skeleton_device(h, C, n_sk, dX, dV, dt, N, discard_vt, dout, nullptr);
+    if (rc == PDMP_OK) TRY_OR_CLEAN(hipMemcpy(out, dout, no * 8, hipMemcpyDeviceToHost));
+    cleanup();
+    return rc;
+}
+
+int pdmp_get_timing(pdmp_handle h, pdmp_timing_t *out) {
+    if (!h || !out) return fail(PDMP_ERR_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (int rc = fold_timing(h)) return rc;
+    *out = h->timing;
+    return PDMP_OK;
+}
+int pdmp_reset_timing(pdmp_handle h) {
+    if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    if (int rc = fold_timing(h)) return rc;
+    h->timing = {0.0, 0.0, 0};
+    return PDMP_OK;
+}
+
+int pdmp_debug_rng(pdmp_handle h, uint64_t seed, int64_t chain, int32_t kind, int64_t n, double *out) {
+    if (!h || !out || n <= 0 || kind < 0 || kind > 2) return fail(PDMP_ERR_ARGUMENT, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    double *d = nullptr;
+    HIP_TRY(hipMalloc(&d, (size_t)n * 8));
+    hipLaunchKernelGGL(debug_rng_kernel, dim3(1), dim3(WAVE), 0, nullptr, seed, chain, (int)kind, n, d);
+    hipError_t e = hipMemcpy(out, d, (size_t)n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(PDMP_ERR_RUNTIME, "debug_rng: %s", hipGetErrorString(e));
+    return PDMP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,220 @@
+// wave_math.hpp -- wave64 building blocks of the gfx950 PDMP engine: counter-based random stream,
+// bit-reproducible elementary functions, fixed-order wave reductions/scans, forward-mode duals.
+//
+// Every floating-point expression here is part of the engine's numerical specification
+// (DESIGN.md "Arithmetic contract"): compiled with -ffp-contract=off, no fast-math, so that results
+// are bit-identical to the scalar CPU checker run in its WAVE64 summation order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pdmp {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+
+// ---------------------------------------------------------------- cross-lane helpers
+__device__ __forceinline__ double readlane_d(double x, int l) {       // l wave-uniform
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readfirst_d(double x) {
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
+    int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+
+// DPP lane permutations inside a row of 16 lanes (no LDS traffic).  After the xor-1 and xor-2
+// stages all four lanes of a quad hold the same value, so row_half_mirror (i <-> 7-i) is a valid
+// xor-4 partner and row_mirror (i <-> 15-i) a valid xor-8 partner: same operands, same sums.
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1;     // quad_perm [1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;     // quad_perm [2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int DPP_ROW_MIRROR = 0x140;
+
+// Sum over the 64 lanes, result in every lane.  Order (the "WAVE64" order of the checker):
+// xor-butterfly with offsets 1,2,4,8,16,32; IEEE addition is commutative so both partners of a pair
+// compute the same bits.
+__device__ __forceinline__ double wave_sum(double a) {
+    a = a + dpp_d<DPP_QUAD_XOR1>(a);
+    a = a + dpp_d<DPP_QUAD_XOR2>(a);
+    a = a + dpp_d<DPP_ROW_HALF_MIRROR>(a);
+    a = a + dpp_d<DPP_ROW_MIRROR>(a);
+    a = a + __shfl_xor(a, 16, WAVE);
+    a = a + __shfl_xor(a, 32, WAVE);
+    return a;
+}
+
+// Kogge-Stone inclusive prefix sum over the 64 lanes.
+__device__ __forceinline__ double wave_scan_incl(double a, int lane) {
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        double t = __shfl_up(a, off, WAVE);
+        if (lane >= off) a = a + t;
+    }
+    return a;
+}
+
+// ---------------------------------------------------------------- forward-mode dual numbers
+// (val, eps): eps carries d/dt along the flow -- the engine's replacement for
+// ForwardDiff.derivative in UpperBound.jl:102,210.  Product rule without fused multiply-add.
+struct Dual {
+    double v, e;
+};
+__device__ __forceinline__ Dual operator+(Dual a, Dual b) { return {a.v + b.v, a.e + b.e}; }
+__device__ __forceinline__ Dual operator-(Dual a, Dual b) { return {a.v - b.v, a.e - b.e}; }
+__device__ __forceinline__ Dual operator-(Dual a, double b) { return {a.v - b, a.e}; }
+__device__ __forceinline__ Dual operator*(Dual a, Dual b) { return {a.v * b.v, a.e * b.v + a.v * b.e}; }
+__device__ __forceinline__ Dual operator*(double s, Dual a) { return {s * a.v, s * a.e}; }
+__device__ __forceinline__ double value(double a) { return a; }
+__device__ __forceinline__ double value(Dual a) { return a.v; }
+__device__ __forceinline__ double readlane_t(double x, int l) { return readlane_d(x, l); }
+__device__ __forceinline__ Dual readlane_t(Dual x, int l) { return {readlane_d(x.v, l), readlane_d(x.e, l)}; }
+
+__device__ __forceinline__ double pmax(double a, double b) { return a > b ? a : b; }
+
+// ---------------------------------------------------------------- Philox4x32-10
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&w)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    w[0] = c0; w[1] = c1; w[2] = c2; w[3] = c3;
+}
+
+__device__ __forceinline__ double bits_to_u(uint32_t lo, uint32_t hi) {
+    uint64_t bits = ((uint64_t)hi << 32) | lo;
+    return ((double)(bits >> 12) + 0.5) * 0x1p-52;
+}
+
+// log(x), x normal and positive: fdlibm e_log.c algorithm with +,-,*,/ only.
+__device__ __forceinline__ double det_log(double x) {
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    int32_t hx = __double2hiint(x);
+    const int32_t lx = __double2loint(x);
+    int32_t k = (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    int32_t i = (hx + 0x95f64) & 0x100000;
+    x = __hiloint2double(hx | (i ^ 0x3ff00000), lx);
+    k += (i >> 20);
+    const double f = x - 1.0, dk = (double)k;
+    if ((0x000fffff & (2 + hx)) < 3) {
+        if (f == 0.0) return (k == 0) ? 0.0 : dk * ln2_hi + dk * ln2_lo;
+        const double R = f * f * (0.5 - 0.33333333333333333 * f);
+        return (k == 0) ? f - R : dk * ln2_hi - ((R - dk * ln2_lo) - f);
+    }
+    const double s = f / (2.0 + f), z = s * s, w = z * z;
+    i = hx - 0x6147a;
+    const int32_t j = 0x6b851 - hx;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    i |= j;
+    const double R = t2 + t1;
+    if (i > 0) {
+        const double hfsq = 0.5 * f * f;
+        return (k == 0) ? f - (hfsq - s * (hfsq + R))
+                        : dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    }
+    return (k == 0) ? f - s * (f - R) : dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
+
+__device__ __forceinline__ double ksin(double a) {
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double z = a * a, v = z * a;
+    const double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    return a + v * (S1 + z * r);
+}
+__device__ __forceinline__ double kcos(double a) {
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double z = a * a;
+    const double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    return (1.0 - 0.5 * z) + z * r;
+}
+__device__ __forceinline__ void quadrant(int q, double sa, double ca, double &s, double &c) {
+    q &= 3;
+    s = (q == 0) ? sa : (q == 1) ? ca : (q == 2) ? -sa : -ca;
+    c = (q == 0) ? ca : (q == 1) ? -sa : (q == 2) ? -ca : sa;
+}
+__device__ __forceinline__ void det_sincos_2pi(double u, double &s, double &c) {
+    const int q = (int)(4.0 * u + 0.5);
+    const double f = u - 0.25 * (double)q;
+    const double a = f * 6.283185307179586476925;
+    quadrant(q, ksin(a), kcos(a), s, c);
+}
+__device__ __forceinline__ void det_sincos(double x, double &s, double &c) {
+    const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
+                 pio2_1t = 6.07710050650619224932e-11;
+    const double fn = floor(x * invpio2 + 0.5);
+    const double a = (x - fn * pio2_1) - fn * pio2_1t;
+    quadrant((int)((long long)fn & 3), ksin(a), kcos(a), s, c);
+}
+
+// ---------------------------------------------------------------- per-chain random stream
+// One stream per chain (= per wave); all state is wave-uniform so the Philox rounds run on the
+// scalar unit.  Variate n uses block n>>1, half n&1 (spec: DESIGN.md "Random stream").
+struct ChainRng {
+    uint32_t k0, k1, c2, c3;   // key = seed, counter high words = chain id
+    uint64_t n;                // variates consumed
+    uint32_t w2, w3;           // second half of the current block
+
+    __device__ __forceinline__ void init(uint64_t seed, uint64_t chain) {
+        k0 = __builtin_amdgcn_readfirstlane((uint32_t)seed);
+        k1 = __builtin_amdgcn_readfirstlane((uint32_t)(seed >> 32));
+        c2 = __builtin_amdgcn_readfirstlane((uint32_t)chain);
+        c3 = __builtin_amdgcn_readfirstlane((uint32_t)(chain >> 32));
+        n = 0; w2 = 0; w3 = 0;
+    }
+    __device__ __forceinline__ double uniform() {
+        uint32_t lo, hi;
+        if ((n & 1) == 0) {
+            uint32_t w[4];
+            const uint64_t blk = n >> 1;
+            philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), c2, c3, k0, k1, w);
+            lo = w[0]; hi = w[1]; w2 = w[2]; w3 = w[3];
+        } else {
+            lo = w2; hi = w3;
+        }
+        ++n;
+        return bits_to_u(lo, hi);
+    }
+    __device__ __forceinline__ double exponential() { return -det_log(uniform()); }
+    // standard normal for coordinate i of a d-vector; call normals_done(d) once afterwards
+    __device__ __forceinline__ double normal_coord(int i) const {
+        const uint64_t blk = ((n + 1) >> 1) + (uint64_t)(i >> 1);
+        uint32_t w[4];
+        philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), c2, c3, k0, k1, w);
+        const double u0 = bits_to_u(w[0], w[1]), u1 = bits_to_u(w[2], w[3]);
+        const double rad = __dsqrt_rn(-2.0 * det_log(u0));
+        double sn, cs;
+        det_sincos_2pi(u1, sn, cs);
+        return (i & 1) ? rad * sn : rad * cs;
+    }
+    __device__ __forceinline__ void normals_done(int d) {
+        n = ((n + 1) & ~1ull) + 2 * (uint64_t)((d + 1) / 2);
+    }
+};
+
+}  // namespace pdmp

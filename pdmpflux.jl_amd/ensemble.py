@@ -1,0 +1,185 @@
+"""Device-resident ensembles and multi-GPU sharding.
+
+PyTorch is plumbing only (device memory, streams, ``torch.distributed`` = RCCL on ROCm): tensors are
+handed to the C ABI as raw device pointers.  One process per GPU; chains are independent, so ranks
+take contiguous chain ranges, draw from streams keyed by the GLOBAL chain id (results
+do not depend on the number of GPUs) and exchange nothing while sampling.  The only collective is the
+optional final all-gather of skeletons / samples, or an all-reduce of moment sums.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ArgumentError, DimensionMismatch
+from .samplers import AbstractPDMP
+from .sample import _seed
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream_ptr(stream):
+    s = torch.cuda.current_stream() if stream is None else stream
+    return C.c_void_p(s.cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and (not t.is_cuda or t.dtype not in (torch.float64, torch.int32) or not t.is_contiguous()):
+            raise ArgumentError("device entry points need contiguous float64/int32 CUDA tensors "
+                                "(the engine has no CPU fallback)")
+
+
+def sample_skeleton_device(sampler: AbstractPDMP, n_sk: int, xinit: torch.Tensor, vinit: torch.Tensor, *,
+                           seed=None, chain_id_offset: int = 0, diagnostics: bool = False, out: dict | None = None,
+                           stream=None, check: bool = True) -> dict:
+    """pdmp_sample_skeleton_device on HBM-resident ``(C, d)`` inputs; outputs stay on the device:
+    X, V ``(C, n_sk, d)``, t ``(C, n_sk)`` (+ diagnostics).  ``out`` may supply preallocated tensors."""
+    if n_sk <= 0:
+        raise ArgumentError(f"n_sk must be positive. Current value: {n_sk}")
+    if xinit.dim() != 2 or xinit.shape != vinit.shape or xinit.shape[1] != sampler.dim:
+        raise DimensionMismatch(f"xinit and vinit must be (C, {sampler.dim})")
+    _need_cuda(xinit, vinit)
+    Cn, d = xinit.shape
+    dev = xinit.device
+    o = {} if out is None else out
+    def buf(name, shape, dtype=torch.float64):
+        tns = o.get(name)
+        if tns is None or tuple(tns.shape) != tuple(shape):
+            tns = torch.empty(shape, dtype=dtype, device=dev)
+            o[name] = tns
+        _need_cuda(tns)
+        return tns
+    X, V, t = buf("X", (Cn, n_sk, d)), buf("V", (Cn, n_sk, d)), buf("t", (Cn, n_sk))
+    diag = None
+    if diagnostics:
+        diag = _lib.Diag(buf("horizon", (Cn, n_sk)).data_ptr(), buf("ar", (Cn, n_sk)).data_ptr(),
+                         buf("errored_bound", (Cn, n_sk), torch.int32).data_ptr(),
+                         buf("error_value_ar", (Cn, n_sk, 5)).data_ptr(),
+                         buf("rejected", (Cn, n_sk), torch.int32).data_ptr(),
+                         buf("hitting_horizon", (Cn, n_sk), torch.int32).data_ptr())
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        _lib.check(L.pdmp_sample_skeleton_device(sampler.handle(), Cn, int(n_sk), int(chain_id_offset), _ptr(xinit),
+                                                 _ptr(vinit), C.c_uint64(_seed(seed)), _ptr(X), _ptr(V), _ptr(t),
+                                                 C.byref(diag) if diag is not None else None, _stream_ptr(stream)))
+        if check:
+            _lib.check(L.pdmp_check_status(sampler.handle(), None))
+    return o
+
+
+def sample_from_skeleton_device(sampler: AbstractPDMP, N: int, X: torch.Tensor, V: torch.Tensor, t: torch.Tensor, *,
+                                discard_vt: bool = True, out: torch.Tensor | None = None, stream=None):
+    """pdmp_sample_from_skeleton_device: returns ``(C, N, rows)`` on the device."""
+    if N <= 0:
+        raise ArgumentError(f"N must be positive. Current value: {N}")
+    _need_cuda(X, V, t)
+    Cn, n_sk, d = X.shape
+    if d != sampler.dim or V.shape != X.shape or tuple(t.shape) != (Cn, n_sk):
+        raise DimensionMismatch("history tensors do not match the sampler dimension")
+    rows = d if discard_vt else 2 * d + 1
+    if out is None:
+        out = torch.empty((Cn, N, rows), dtype=torch.float64, device=X.device)
+    _need_cuda(out)
+    with torch.cuda.device(X.device):
+        _lib.check(_lib.lib().pdmp_sample_from_skeleton_device(sampler.handle(), Cn, n_sk, _ptr(X), _ptr(V), _ptr(t),
+                                                               int(N), int(bool(discard_vt)), _ptr(out),
+                                                               _stream_ptr(stream)))
+    return out
+
+
+def kernel_timing(sampler: AbstractPDMP, reset: bool = False) -> dict:
+    """hipEvent-timed kernel durations of this sampler's handle (pdmp_get_timing)."""
+    tm = _lib.Timing()
+    _lib.check(_lib.lib().pdmp_get_timing(sampler.handle(), C.byref(tm)))
+    if reset:
+        _lib.check(_lib.lib().pdmp_reset_timing(sampler.handle()))
+    return {"kernel_ms_total": tm.kernel_ms_total, "kernel_ms_last": tm.kernel_ms_last, "launches": tm.launches}
+
+
+# ------------------------------------------------------------------------------------------------
+# sharding
+# ------------------------------------------------------------------------------------------------
+def shard_range(C_total: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous chain range [lo, hi) of ``rank``: sizes differ by at most one."""
+    base, rem = divmod(C_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _all_gather_rows(local: torch.Tensor, C_total: int, world: int, group) -> torch.Tensor:
+    """All-gather along dim 0 of per-rank shards of (possibly) unequal length: pad to the longest shard,
+    one all_gather_into_tensor (RCCL: one direct exchange per peer link), then drop the padding."""
+    import torch.distributed as dist
+    max_rows = -(-C_total // world)
+    pad = max_rows - local.shape[0]
+    if pad:
+        local = torch.cat([local, local.new_zeros((pad,) + tuple(local.shape[1:]))], 0)
+    full = local.new_empty((world * max_rows,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(full, local.contiguous(), group=group)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_range(C_total, r, world)
+        parts.append(full[r * max_rows: r * max_rows + (hi - lo)])
+    return torch.cat(parts, 0) if pad or world > 1 else full
+
+
+def sample_skeleton_sharded(sampler: AbstractPDMP, n_sk: int, xinit: torch.Tensor, vinit: torch.Tensor, *, seed,
+                            gather: str = "none", N_samples: int | None = None, group=None, compute=None) -> dict:
+    """Ensemble over all ranks of ``group``.  ``xinit``/``vinit`` hold ALL ``C_total`` chains on every
+    rank (cheap: 16 d bytes per chain); this rank samples its contiguous shard.
+
+    gather = "none"      local shard only (keys X, V, t + ``chain_range``)
+             "skeleton"  all-gather X, V, t of every chain onto every rank (north-star collective)
+             "samples"   run sample_from_skeleton(N_samples) locally and all-gather the (C, N, d) samples
+             "moments"   all-reduce sum(x), sum(x^2), count of the local samples (2d+1 doubles)
+
+    ``compute`` (tests only) replaces the HIP engine by a callable
+    ``(x_shard, v_shard, chain0) -> {"X","V","t"}`` so the sharding logic can run under gloo on CPU.
+    """
+    import torch.distributed as dist
+    if seed is None:
+        raise ArgumentError("a sharded run needs an explicit seed shared by all ranks")
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    C_total = xinit.shape[0]
+    lo, hi = shard_range(C_total, rank, world)
+    xs, vs = xinit[lo:hi].contiguous(), vinit[lo:hi].contiguous()
+    if compute is None:
+        res = sample_skeleton_device(sampler, n_sk, xs, vs, seed=seed, chain_id_offset=lo)
+    else:
+        res = compute(xs, vs, lo)
+    res = dict(res)
+    res["chain_range"] = (lo, hi)
+    if gather == "none":
+        return res
+    if gather == "skeleton":
+        if world > 1:
+            for k in ("X", "V", "t"):
+                res[k] = _all_gather_rows(res[k], C_total, world, group)
+        res["chain_range"] = (0, C_total)
+        return res
+    if N_samples is None or N_samples <= 0:
+        raise ArgumentError(f"N must be positive. Current value: {N_samples}")
+    if compute is None:
+        smp = sample_from_skeleton_device(sampler, N_samples, res["X"], res["V"], res["t"])
+    else:
+        smp = res["samples"]
+    if gather == "samples":
+        res["samples"] = _all_gather_rows(smp, C_total, world, group) if world > 1 else smp
+        return res
+    if gather == "moments":
+        d = smp.shape[-1]
+        flat = smp.reshape(-1, d)
+        m = torch.cat([flat.sum(0), (flat * flat).sum(0), flat.new_tensor([float(flat.shape[0])])])
+        if world > 1:
+            dist.all_reduce(m, group=group)
+        n = m[-1]
+        mean = m[:d] / n
+        res["mean"], res["var"], res["count"] = mean, m[d:2 * d] / n - mean * mean, n
+        return res
+    raise ArgumentError(f"unknown gather mode {gather!r}")

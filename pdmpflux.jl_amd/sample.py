@@ -1,0 +1,121 @@
+"""``sample``, ``sample_skeleton``, ``sample_from_skeleton`` with the reference's signatures
+(src/sample.jl:27-58, 253-311, 475-513), running on the HIP engine through the C ABI.
+
+Single-chain calls take ``xinit``/``vinit`` vectors (or scalars in 1-D, sample.jl:289-311) and return
+a ``PDMPHistory`` / a ``d x N`` matrix.  Ensemble calls take ``(C, d)`` arrays (row c = chain c) and
+return dicts of ``(C, n_sk, ...)`` arrays; chain ``c`` uses the stream ``(seed, chain_id_offset + c)``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import ArgumentError, DimensionMismatch
+from .history import PDMPHistory, history_from_ensemble
+from .samplers import AbstractPDMP
+
+
+def _vp(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def _seed(seed):
+    if seed is None:                       # Random.default_rng(), AbstractPDMP.jl:100
+        return int.from_bytes(os.urandom(8), "little")
+    return int(seed) & (2**64 - 1)
+
+
+def _as_init(sampler: AbstractPDMP, xinit, vinit):
+    scalar = np.isscalar(xinit) and np.isscalar(vinit)
+    if scalar:                             # sample.jl:289-311
+        if not (math.isfinite(xinit) and math.isfinite(vinit)):
+            raise ArgumentError("initial values contain NaN, Inf, or -Inf.")   # :303-305
+        xinit, vinit = [float(xinit)], [float(vinit)]
+    x = np.ascontiguousarray(np.asarray(xinit, dtype=np.float64))
+    v = np.ascontiguousarray(np.asarray(vinit, dtype=np.float64))
+    single = x.ndim == 1
+    if single:
+        x, v = x[None, :], v[None, :] if v.ndim == 1 else v
+    if x.ndim != 2 or v.ndim != 2 or x.shape[1] != sampler.dim or v.shape[1] != sampler.dim or x.shape != v.shape:
+        raise DimensionMismatch(                                                 # AbstractPDMP.jl:96-98
+            f"xinit and vinit must have the same dimension as pdmp.dim ({sampler.dim}). "
+            f"Current dimensions: xinit ({x.shape[-1]}), vinit ({v.shape[-1]})")
+    return x, v, single
+
+
+def sample_skeleton_ensemble(sampler: AbstractPDMP, n_sk: int, xinit, vinit, *, seed=None,
+                             chain_id_offset: int = 0, diagnostics: bool = True) -> dict:
+    """Host-buffer ensemble call (pdmp_sample_skeleton).  Returns X, V (C, n_sk, d), t (C, n_sk) and,
+    with ``diagnostics``, the PDMPHistory diagnostic arrays."""
+    if n_sk <= 0:
+        raise ArgumentError(f"n_sk must be positive. Current value: {n_sk}")     # sample.jl:262-264
+    x, v, _ = _as_init(sampler, xinit, vinit)
+    Cn, d = x.shape
+    out = {"X": np.empty((Cn, n_sk, d)), "V": np.empty((Cn, n_sk, d)), "t": np.empty((Cn, n_sk))}
+    diag = None
+    if diagnostics:
+        out.update(horizon=np.empty((Cn, n_sk)), ar=np.empty((Cn, n_sk)),
+                   errored_bound=np.empty((Cn, n_sk), np.int32), error_value_ar=np.empty((Cn, n_sk, 5)),
+                   rejected=np.empty((Cn, n_sk), np.int32), hitting_horizon=np.empty((Cn, n_sk), np.int32))
+        diag = _lib.Diag(out["horizon"].ctypes.data, out["ar"].ctypes.data, out["errored_bound"].ctypes.data,
+                         out["error_value_ar"].ctypes.data, out["rejected"].ctypes.data,
+                         out["hitting_horizon"].ctypes.data)
+    L = _lib.lib()
+    _lib.check(L.pdmp_sample_skeleton(sampler.handle(), Cn, int(n_sk), int(chain_id_offset), _vp(x), _vp(v),
+                                      C.c_uint64(_seed(seed)), _vp(out["X"]), _vp(out["V"]), _vp(out["t"]),
+                                      C.byref(diag) if diag is not None else None))
+    return out
+
+
+def sample_skeleton(sampler: AbstractPDMP, n_sk: int, xinit, vinit, *, seed=None, verbose: bool = True):
+    """sample.jl:253-284.  1-D/2-D dispatch: vectors -> PDMPHistory; (C, d) arrays -> ensemble dict."""
+    if n_sk <= 0:
+        raise ArgumentError(f"n_sk must be positive. Current value: {n_sk}")
+    x, v, single = _as_init(sampler, xinit, vinit)
+    out = sample_skeleton_ensemble(sampler, n_sk, x, v, seed=seed)
+    if not single:
+        return out
+    hist = history_from_ensemble(out, 0)
+    sampler.state = hist                       # sampler.state = state, sample.jl:281 (final state is the last column)
+    return hist
+
+
+def sample_from_skeleton_ensemble(sampler: AbstractPDMP, N: int, X, V, t, *, discard_vt: bool = True):
+    """X, V: (C, n_sk, d); t: (C, n_sk).  Returns (C, N, rows) with rows = d or 2d+1."""
+    if N <= 0:
+        raise ArgumentError(f"N must be positive. Current value: {N}")          # sample.jl:476-478
+    X = np.ascontiguousarray(X, dtype=np.float64); V = np.ascontiguousarray(V, dtype=np.float64)
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    Cn, n_sk, d = X.shape
+    if d != sampler.dim or V.shape != X.shape or t.shape != (Cn, n_sk):
+        raise DimensionMismatch("history arrays do not match the sampler dimension")
+    rows = d if discard_vt else 2 * d + 1
+    out = np.empty((Cn, N, rows))
+    _lib.check(_lib.lib().pdmp_sample_from_skeleton(sampler.handle(), Cn, n_sk, _vp(X), _vp(V), _vp(t), int(N),
+                                                    int(bool(discard_vt)), _vp(out)))
+    return out
+
+
+def sample_from_skeleton(sampler: AbstractPDMP, N: int, history, *, discard_vt: bool = True):
+    """sample.jl:475-513.  ``history`` is a PDMPHistory (-> ``rows x N`` matrix, Fortran-ordered view) or
+    an ensemble dict (-> (C, N, rows))."""
+    if N <= 0:
+        raise ArgumentError(f"N must be positive. Current value: {N}")
+    if isinstance(history, dict):
+        return sample_from_skeleton_ensemble(sampler, N, history["X"], history["V"], history["t"],
+                                             discard_vt=discard_vt)
+    X = np.ascontiguousarray(history.X.T)[None]
+    V = np.ascontiguousarray(history.V.T)[None]
+    t = np.ascontiguousarray(history.t)[None]
+    return sample_from_skeleton_ensemble(sampler, N, X, V, t, discard_vt=discard_vt)[0].T
+
+
+def sample(sampler: AbstractPDMP, N_sk: int, N_samples: int, xinit, vinit, *, seed=None, verbose: bool = True,
+           discard_vt: bool = True):
+    """sample.jl:27-41: sample_skeleton then sample_from_skeleton."""
+    history = sample_skeleton(sampler, N_sk, xinit, vinit, seed=seed, verbose=verbose)
+    return sample_from_skeleton(sampler, N_samples, history, discard_vt=discard_vt)

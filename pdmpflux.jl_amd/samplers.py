@@ -1,0 +1,162 @@
+"""Sampler constructors with the reference's names, keyword arguments and defaults:
+``ZigZag``/``ZigZagAD`` (src/Samplers/ZigZagSamplers.jl:58-126), ``BPS``/``BPSAD``
+(BouncyParticleSamplers.jl:21-94), ``Boomerang``/``BoomerangAD`` (BoomerangSamplers.jl:21-87).
+
+The second positional argument is a target descriptor (``targets.py``) instead of a Julia closure.
+Objects are cheap host-side records; the GPU engine handle is created on first use.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import warnings
+
+import numpy as np
+
+from . import _lib
+from ._lib import ArgumentError
+
+ZIGZAG, BPS_ID, BOOMERANG = 0, 1, 2
+DERIV_FORWARD, DERIV_FINITE_DIFF = 0, 1
+
+# AbstractPDMP.jl:18-28 (_pdmp_ad_backend) and UpperBound.jl:209-226: every AD backend yields the exact
+# t-derivative, which the engine computes with forward-mode duals; "FiniteDiff" is central differences.
+_EXACT = {"ForwardDiff", "Zygote", "ReverseDiff", "Enzyme", "PolyesterForwardDiff"}
+_FD = {"FiniteDiff", "Undefined", ""}
+
+
+def _deriv_mode(ad_backend) -> int:
+    ab = "FiniteDiff" if ad_backend is None else str(ad_backend)
+    if ab in _EXACT:
+        return DERIV_FORWARD
+    if ab in _FD:
+        return DERIV_FINITE_DIFF
+    raise ArgumentError(f"Unsupported AD_backend: {ab}")            # UpperBound.jl:120,226
+
+
+class AbstractPDMP:
+    """Common record (fields of ZigZagSamplers.jl:35-52 that the sampling loop reads)."""
+
+    sampler_id = -1
+    name = "AbstractPDMP"
+
+    def __init__(self, dim, target, *, grid_size, tmax, refresh_rate, vectorized_bound, signed_bound,
+                 adaptive, AD_backend, gaussian_velocity=False, device=-1, max_iter_per_event=0):
+        if not isinstance(dim, (int, np.integer)) or isinstance(dim, bool):
+            raise TypeError("dim must be an Int")                    # MethodError in Julia
+        if target is None or not hasattr(target, "target_id"):
+            raise TypeError("target must be a target descriptor (GaussianIso(), GaussianDiag(..), Banana())")
+        if dim <= 0:
+            raise ArgumentError(f"dimension dim must be positive. Current value: {dim}")      # ZigZagSamplers.jl:62-64
+        if grid_size < 0:
+            raise ArgumentError(f"grid_size must be non-negative. Current value: {grid_size}")  # :66-68
+        tmax = float(tmax)
+        if tmax == 0.0:                                              # :73
+            tmax, adaptive = 1.0, True
+        self.dim = int(dim)
+        self.target = target
+        self.grid_size = int(grid_size)
+        self.tmax = tmax
+        self.refresh_rate = float(refresh_rate)
+        self.vectorized_bound = bool(vectorized_bound)
+        self.signed_bound = bool(signed_bound)
+        self.adaptive = bool(adaptive)
+        self.AD_backend = "FiniteDiff" if AD_backend in (None, "", "Undefined") else str(AD_backend)
+        self.deriv_mode = _deriv_mode(AD_backend)
+        self.gaussian_velocity = bool(gaussian_velocity)
+        self.device = int(device)
+        self.max_iter_per_event = int(max_iter_per_event)
+        self._params = target.params(self.dim)
+        self._handle = None
+        self.state = None
+
+    # ---- engine handle -------------------------------------------------------------------
+    def _config(self) -> _lib.Config:
+        p, n = None, 0
+        if self._params is not None:
+            self._params = np.ascontiguousarray(self._params, dtype=np.float64)
+            p, n = self._params.ctypes.data_as(C.POINTER(C.c_double)), self._params.size
+        return _lib.Config(self.sampler_id, self.dim, self.grid_size, int(self.vectorized_bound),
+                           int(self.signed_bound), int(self.adaptive), int(self.gaussian_velocity),
+                           self.deriv_mode, self.target.target_id, self.device, self.tmax, self.refresh_rate,
+                           p, n, self.max_iter_per_event)
+
+    def handle(self):
+        if self._handle is None:
+            h = C.c_void_p()
+            cfg = self._config()
+            _lib.check(_lib.lib().pdmp_create(C.byref(cfg), C.byref(h)))
+            self._handle = h
+        return self._handle
+
+    def close(self):
+        if self._handle is not None:
+            _lib.lib().pdmp_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __repr__(self):
+        return (f"{self.name}(dim={self.dim}, target={self.target}, grid_size={self.grid_size}, tmax={self.tmax}, "
+                f"refresh_rate={self.refresh_rate}, signed_bound={self.signed_bound}, adaptive={self.adaptive}, "
+                f"AD_backend={self.AD_backend!r})")
+
+
+class ZigZag(AbstractPDMP):
+    sampler_id = ZIGZAG
+    name = "ZigZag"
+
+    def __init__(self, dim, target, *, grid_size=10, tmax=2.0, refresh_rate=0.0, vectorized_bound=True,
+                 signed_bound=True, adaptive=True, AD_backend="FiniteDiff", **kw):   # ZigZagSamplers.jl:58-60
+        if signed_bound and not vectorized_bound:                                    # :75-78
+            signed_bound = False
+            warnings.warn("Signed bound is not compatible with non-vectorized bound for ZigZag, "
+                          "switching to unsigned bound")
+        super().__init__(dim, target, grid_size=grid_size, tmax=tmax, refresh_rate=refresh_rate,
+                         vectorized_bound=vectorized_bound, signed_bound=signed_bound, adaptive=adaptive,
+                         AD_backend=AD_backend, **kw)
+
+
+def ZigZagAD(dim, target, *, refresh_rate=0.0, grid_size=10, tmax=2.0, vectorized_bound=True, signed_bound=True,
+             adaptive=True, AD_backend="ForwardDiff", **kw):                         # ZigZagSamplers.jl:118-126
+    return ZigZag(dim, target, refresh_rate=refresh_rate, grid_size=grid_size, tmax=tmax,
+                  vectorized_bound=vectorized_bound, signed_bound=signed_bound, adaptive=adaptive,
+                  AD_backend=AD_backend, **kw)
+
+
+class BPS(AbstractPDMP):
+    sampler_id = BPS_ID
+    name = "BPS"
+
+    def __init__(self, dim, target, *, grid_size=10, tmax=1.0, refresh_rate=0.1, vectorized_bound=False,
+                 signed_bound=True, adaptive=True, AD_backend="ForwardDiff", Gaussian_velocity=False, **kw):
+        # BouncyParticleSamplers.jl:21-24; vectorized_bound forced false (:37)
+        super().__init__(dim, target, grid_size=grid_size, tmax=tmax, refresh_rate=refresh_rate,
+                         vectorized_bound=False, signed_bound=signed_bound, adaptive=adaptive,
+                         AD_backend=AD_backend, gaussian_velocity=Gaussian_velocity, **kw)
+
+
+def BPSAD(dim, target, *, refresh_rate=0.0, grid_size=10, tmax=2.0, vectorized_bound=True, signed_bound=True,
+          adaptive=True, AD_backend="ForwardDiff", **kw):                            # BouncyParticleSamplers.jl:86-94
+    return BPS(dim, target, refresh_rate=refresh_rate, grid_size=grid_size, tmax=tmax, signed_bound=signed_bound,
+               adaptive=adaptive, AD_backend=AD_backend, **kw)
+
+
+class Boomerang(AbstractPDMP):
+    sampler_id = BOOMERANG
+    name = "Boomerang"
+
+    def __init__(self, dim, target, *, grid_size=10, tmax=1.0, refresh_rate=0.1, vectorized_bound=False,
+                 signed_bound=True, adaptive=True, AD_backend="FiniteDiff", **kw):    # BoomerangSamplers.jl:21-23
+        super().__init__(dim, target, grid_size=grid_size, tmax=tmax, refresh_rate=refresh_rate,
+                         vectorized_bound=False, signed_bound=signed_bound, adaptive=adaptive,
+                         AD_backend=AD_backend, **kw)
+
+
+def BoomerangAD(dim, target, *, refresh_rate=0.0, grid_size=10, tmax=2.0, vectorized_bound=True, signed_bound=True,
+                adaptive=True, AD_backend="ForwardDiff", **kw):                      # BoomerangSamplers.jl:79-87
+    return Boomerang(dim, target, refresh_rate=refresh_rate, grid_size=grid_size, tmax=tmax,
+                     signed_bound=signed_bound, adaptive=adaptive, AD_backend=AD_backend, **kw)

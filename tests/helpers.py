@@ -1,0 +1,55 @@
+"""Shared helpers for parity tests: build matching (engine sampler, oracle config) pairs and inputs."""
+import numpy as np
+
+SAMPLER_IDS = {"ZigZag": 0, "BPS": 1, "Boomerang": 2}
+
+
+def make_pair(P, O, kind, dim, target="iso", arith=None, **kw):
+    """Returns (engine sampler, oracle Config) built from the same reference-style kwargs."""
+    rs = np.random.default_rng(dim * 7 + 1)
+    if target == "iso":
+        tg, tid, params = P.GaussianIso(), O.T_GAUSS_ISO, None
+    elif target == "diag":
+        mu, prec = rs.normal(size=dim), np.exp(rs.uniform(-1, 1, size=dim))
+        tg, tid, params = P.GaussianDiag(mu, prec), O.T_GAUSS_DIAG, np.concatenate([mu, prec])
+    elif target == "banana":
+        tg, tid, params = P.Banana(), O.T_BANANA, None
+    else:
+        raise ValueError(target)
+    ctor = {"ZigZag": P.ZigZag, "ZigZagAD": P.ZigZagAD, "BPS": P.BPS, "BPSAD": P.BPSAD,
+            "Boomerang": P.Boomerang, "BoomerangAD": P.BoomerangAD}[kind]
+    s = ctor(dim, tg, **kw)
+    cfg = O.Config(sampler=s.sampler_id, dim=dim, grid_size=s.grid_size, tmax=s.tmax, refresh_rate=s.refresh_rate,
+                   vectorized_bound=s.vectorized_bound, signed_bound=s.signed_bound, adaptive=s.adaptive,
+                   gaussian_velocity=s.gaussian_velocity, deriv_mode=s.deriv_mode, target_id=tid,
+                   target_params=params, arith=O.ARITH_WAVE64 if arith is None else arith)
+    return s, cfg
+
+
+def make_init(kind, dim, C, seed=0, target="iso"):
+    rs = np.random.default_rng(seed + 1000 * dim + C)
+    x = rs.normal(size=(C, dim))
+    if target == "banana":
+        x = 1.0 + 0.1 * x
+    if kind.startswith("ZigZag"):
+        v = rs.choice([-1.0, 1.0], size=(C, dim))
+    elif kind.startswith("BPS"):
+        v = rs.normal(size=(C, dim))
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+    else:
+        v = rs.normal(size=(C, dim))
+    return x, v
+
+
+DIAG_KEYS = ("horizon", "ar", "errored_bound", "error_value_ar", "rejected", "hitting_horizon")
+
+
+def assert_bitwise(got, ref, keys=("X", "V", "t") + DIAG_KEYS):
+    for k in keys:
+        a, b = np.asarray(got[k]), np.asarray(ref[k])
+        assert a.shape == b.shape, k
+        same = (a == b) | (np.isnan(a) & np.isnan(b))
+        if not same.all():
+            idx = np.argwhere(~same)[0]
+            raise AssertionError(f"{k}: first mismatch at {tuple(idx)}: {a[tuple(idx)]!r} vs {b[tuple(idx)]!r} "
+                                 f"({(~same).sum()} of {same.size} differ)")

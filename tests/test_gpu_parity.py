@@ -1,0 +1,116 @@
+"""GPU parity: the HIP engine (through the C ABI) against the CPU oracle on identical inputs and
+identical Philox streams.  The oracle runs in its WAVE64 summation order, so the comparison is
+BIT-EXACT for every field of PDMPHistory (stronger than the 1e-5 relative bound of the north star;
+the tolerance test below states that bound explicitly against the reference-order oracle)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import assert_bitwise, make_init, make_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def run_pair(P, O, kind, dim, target, C_, n_sk, seed=11, offset=0, **kw):
+    s, cfg = make_pair(P, O, kind, dim, target, **kw)
+    x, v = make_init(kind, dim, C_, target=target)
+    got = P.sample_skeleton_ensemble(s, n_sk, x, v, seed=seed, chain_id_offset=offset)
+    ref = O.sample_skeleton(cfg, n_sk, x, v, seed, chain_id_offset=offset)
+    return s, cfg, got, ref
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_rng_stream_bitwise(engine, oracle, kind):
+    s = engine.ZigZagAD(2, engine.GaussianIso())
+    from pdmpflux.jl_amd import _lib
+    n = 1001
+    out = np.empty(n)
+    for seed, chain in [(0, 0), (2024, 7), (2**63 + 5, 2**40 + 3)]:
+        _lib.check(_lib.lib().pdmp_debug_rng(s.handle(), C.c_uint64(seed), chain, kind, n, C.c_void_p(out.ctypes.data)))
+        ref = oracle.rng_dump(seed, chain, kind, n)
+        assert np.array_equal(out, ref), (kind, seed, chain)
+
+
+CASES = [
+    # kind, dim, target, chains, n_sk, kwargs
+    ("ZigZagAD", 50, "iso", 24, 300, {}),
+    ("ZigZagAD", 10, "iso", 5, 400, {}),
+    ("ZigZagAD", 1, "iso", 3, 300, {}),
+    ("ZigZagAD", 64, "diag", 8, 200, {}),
+    ("ZigZagAD", 50, "banana", 16, 300, {}),
+    ("ZigZagAD", 100, "iso", 6, 150, {}),           # two coordinates per lane
+    ("ZigZagAD", 130, "diag", 4, 100, {}),          # K = 4 path, ragged last chunk
+    ("ZigZag", 50, "iso", 8, 200, {}),              # default FiniteDiff slopes (Q13)
+    ("ZigZag", 20, "banana", 8, 200, {}),
+    ("ZigZagAD", 50, "iso", 8, 200, {"signed_bound": False}),
+    ("ZigZagAD", 50, "banana", 8, 200, {"adaptive": False, "tmax": 0.5}),
+    ("ZigZagAD", 50, "iso", 8, 200, {"grid_size": 5}),
+    ("ZigZagAD", 50, "banana", 8, 200, {"grid_size": 20}),
+    ("ZigZagAD", 50, "iso", 8, 100, {"tmax": 0}),   # tmax = 0 -> 1.0 + adaptive
+    ("BPS", 50, "banana", 16, 300, {}),
+    ("BPS", 50, "iso", 8, 300, {}),
+    ("BPS", 100, "diag", 4, 150, {}),
+    ("BPS", 10, "iso", 4, 300, {"Gaussian_velocity": True}),
+    ("BPS", 50, "banana", 8, 200, {"signed_bound": False}),
+    ("BPS", 50, "banana", 8, 200, {"AD_backend": "FiniteDiff"}),
+    ("BPSAD", 20, "iso", 4, 200, {}),               # refresh_rate = 0 (Q9)
+    ("Boomerang", 100, "iso", 6, 200, {}),          # default FiniteDiff
+    ("BoomerangAD", 50, "diag", 6, 200, {"refresh_rate": 0.1}),
+    ("Boomerang", 50, "banana", 6, 200, {"AD_backend": "ForwardDiff"}),
+]
+
+
+@pytest.mark.parametrize("kind,dim,target,chains,n_sk,kw", CASES,
+                         ids=[f"{c[0]}-d{c[1]}-{c[2]}-{'_'.join(f'{k}{v}' for k, v in c[5].items()) or 'default'}" for c in CASES])
+def test_skeleton_bitwise(engine, oracle, kind, dim, target, chains, n_sk, kw):
+    _, _, got, ref = run_pair(engine, oracle, kind, dim, target, chains, n_sk, **kw)
+    assert_bitwise(got, ref)
+
+
+def test_chain_offset_and_sharding_invariance(engine, oracle):
+    """Chain c of a shard starting at offset o equals chain o+c of the full ensemble (multi-GPU contract)."""
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", 50, "iso")
+    x, v = make_init("ZigZagAD", 50, 12)
+    full = engine.sample_skeleton_ensemble(s, 100, x, v, seed=5)
+    part = engine.sample_skeleton_ensemble(s, 100, x[5:9], v[5:9], seed=5, chain_id_offset=5)
+    for k in ("X", "V", "t"):
+        assert np.array_equal(full[k][5:9], part[k])
+
+
+def test_reference_order_within_tolerance(engine, oracle):
+    """North-star bound: event times/positions within 1e-5 relative of the reference-order (sequential
+    sums, per-dimension cumsum) restatement on identical streams."""
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", 50, "iso", arith=oracle.ARITH_REFERENCE)
+    x, v = make_init("ZigZagAD", 50, 8)
+    got = engine.sample_skeleton_ensemble(s, 200, x, v, seed=3)
+    ref = oracle.sample_skeleton(cfg, 200, x, v, 3)
+    rtol = 1e-5
+    assert np.allclose(got["t"], ref["t"], rtol=rtol, atol=0)
+    assert np.allclose(got["X"], ref["X"], rtol=rtol, atol=1e-9)
+    assert np.array_equal(got["V"], ref["V"])
+
+
+@pytest.mark.parametrize("kind,dim,discard", [("ZigZagAD", 50, True), ("ZigZagAD", 100, False), ("Boomerang", 50, True),
+                                              ("Boomerang", 10, False), ("BPS", 3, True)])
+def test_sample_from_skeleton_bitwise(engine, oracle, kind, dim, discard):
+    s, cfg, got, _ = run_pair(engine, oracle, kind, dim, "iso", 6, 120)
+    for N in (1, 63, 64, 65, 500):
+        a = engine.sample_from_skeleton_ensemble(s, N, got["X"], got["V"], got["t"], discard_vt=discard)
+        b = oracle.sample_from_skeleton(cfg, N, got["X"], got["V"], got["t"], discard_vt=discard)
+        assert np.array_equal(a, b), N
+
+
+def test_single_chain_api_matches_reference_shapes(engine, oracle):
+    """test/test_quick.jl:15-26, test_samplers.jl:33-48: shapes and finiteness through the drop-in API."""
+    s = engine.ZigZagAD(3, engine.GaussianIso())
+    h = engine.sample_skeleton(s, 100, np.zeros(3), np.ones(3), seed=42)
+    assert h.X.shape == (3, 100) and h.V.shape == (3, 100) and len(h.t) == 100
+    assert np.isfinite(h.X).all() and np.isfinite(h.V).all() and np.isfinite(h.t).all()
+    assert (np.diff(h.t) > 0).all()                                  # test_comprehensive.jl:147
+    smp = engine.sample_from_skeleton(s, 50, h)
+    assert smp.shape == (3, 50)
+    smp2 = engine.sample(s, 100, 50, np.zeros(3), np.ones(3), seed=42)
+    assert np.array_equal(smp, smp2)                                 # reproducibility, test_quick.jl:96-108
+    h1 = engine.sample_skeleton(engine.ZigZagAD(1, engine.GaussianIso()), 50, 0.0, 1.0, seed=1)   # scalar dispatch
+    assert h1.X.shape == (1, 50)
