@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- skeleton-events/sec of the sample_skeleton() hot path on MI355X.
+
+Workload at N=1 (BASELINE.json configs[1]): Zig-Zag, d=50 standard Gaussian, 10^5 chains per GPU,
+n_sk=1000 skeleton points per chain (9.99e7 events per step), synthetic stationary starts
+(x ~ N(0,I), v = +-1), defaults of ZigZagAD (grid_size=10, tmax=2, signed vectorised bound,
+adaptive, forward-mode slopes).  One "step" = one sample_skeleton() pass over the whole ensemble,
+inputs and outputs resident in HBM.  With N>1 (torchrun, one rank per GPU) every rank runs its own
+10^5 chains (weak scaling; chain ids are global) and each step ends with one RCCL all-gather of the
+chains' end states.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (HBM, algorithmic
+bytes 8(2d+1) per event over hipEvent-timed kernel durations) and `cpu_baseline` (the CPU oracle on
+the host cores of the same box, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--chains", type=int, default=100_000, help="chains per GPU")
+    ap.add_argument("--n-sk", type=int, default=1000)
+    ap.add_argument("--dim", type=int, default=50)
+    ap.add_argument("--sampler", default="ZigZagAD", choices=["ZigZagAD", "ZigZag", "BPS", "BPSAD", "Boomerang", "BoomerangAD"])
+    ap.add_argument("--target", default="iso", choices=["iso", "banana"])
+    ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time; 0 disables it")
+    return ap.parse_args()
+
+
+def make_sampler(P, a):
+    tgt = P.GaussianIso() if a.target == "iso" else P.Banana()
+    return getattr(P, a.sampler)(a.dim, tgt)
+
+
+def make_inputs(torch, a, dev, rank):
+    g = torch.Generator(device=dev)
+    g.manual_seed(a.seed * 1000 + rank)
+    x = torch.randn((a.chains, a.dim), dtype=torch.float64, device=dev, generator=g)
+    if a.target == "banana":
+        x = 1.0 + 0.1 * x
+    if a.sampler.startswith("ZigZag"):
+        v = torch.randint(0, 2, (a.chains, a.dim), device=dev, generator=g).to(torch.float64) * 2 - 1
+    else:
+        v = torch.randn((a.chains, a.dim), dtype=torch.float64, device=dev, generator=g)
+        if a.sampler.startswith("BPS"):
+            v = v / v.norm(dim=1, keepdim=True)
+    return x.contiguous(), v.contiguous()
+
+
+def cpu_baseline(a, sampler):
+    """Oracle ('port' of the reference algorithm, reference summation order) on the host cores: a bounded
+    sample of the same workload -- same d, n_sk, sampler and target, fewer chains."""
+    import numpy as np
+    from oracle import oracle as O
+    cores = min(O.num_threads(), int(os.environ.get("PDMP_CPU_THREADS", "16")))   # CPU share of one GPU slot
+    tid = O.T_GAUSS_ISO if a.target == "iso" else O.T_BANANA
+    cfg = O.Config(sampler=sampler.sampler_id, dim=a.dim, grid_size=sampler.grid_size, tmax=sampler.tmax,
+                   refresh_rate=sampler.refresh_rate, vectorized_bound=sampler.vectorized_bound,
+                   signed_bound=sampler.signed_bound, adaptive=sampler.adaptive, deriv_mode=sampler.deriv_mode,
+                   target_id=tid, arith=O.ARITH_REFERENCE)
+    rs = np.random.default_rng(a.seed)
+    n_sk = min(a.n_sk, 1000)
+
+    def run(C, off):
+        x = rs.normal(size=(C, a.dim))
+        if a.target == "banana":
+            x = 1.0 + 0.1 * x
+        if a.sampler.startswith("ZigZag"):
+            v = rs.choice([-1.0, 1.0], size=(C, a.dim))
+        else:
+            v = rs.normal(size=(C, a.dim))
+            v /= np.linalg.norm(v, axis=1, keepdims=True)
+        t0 = time.perf_counter()
+        O.sample_skeleton(cfg, n_sk, x, v, a.seed, chain_id_offset=off, diagnostics=False, n_threads=cores)
+        return time.perf_counter() - t0
+
+    C0 = 4 * cores
+    dt = run(C0, 0)                                            # calibration (also warms the threads)
+    per_chain = dt / C0
+    cap = max(C0, int(1.5e9 // (n_sk * 8 * (2 * a.dim + 1))))  # keep the host buffers under ~1.5 GB
+    total = max(C0, int(a.cpu_seconds / per_chain))
+    done, spent, off = 0, 0.0, C0
+    while done < total and spent < 2 * a.cpu_seconds:
+        c = min(cap, total - done)
+        spent += run(c, off)
+        done += c
+        off += c
+    events = done * (n_sk - 1)
+    return {"value": events / spent, "unit": "events/s", "cores": cores, "kind": "port",
+            "sample": f"{done} chains x n_sk={n_sk} of the same workload ({events} events, {spent:.1f} s, "
+                      f"OpenMP over chains, -O2 no fast-math, reference summation order)"}
+
+
+def main():
+    a = parse()
+    import torch
+    import pdmpflux.jl_amd as P
+    from pdmpflux.jl_amd import ensemble
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    sampler = make_sampler(P, a)
+    sampler.device = local
+    x, v = make_inputs(torch, a, dev, rank)
+    C, d, n_sk = a.chains, a.dim, a.n_sk
+    out = {"X": torch.empty((C, n_sk, d), dtype=torch.float64, device=dev),
+           "V": torch.empty((C, n_sk, d), dtype=torch.float64, device=dev),
+           "t": torch.empty((C, n_sk), dtype=torch.float64, device=dev)}
+    end_state = torch.empty((C, 2 * d + 1), dtype=torch.float64, device=dev)
+    gathered = torch.empty((world * C, 2 * d + 1), dtype=torch.float64, device=dev) if world > 1 else None
+    chain0 = rank * C
+
+    def step(i):
+        ensemble.sample_skeleton_device(sampler, n_sk, x, v, seed=a.seed + i, chain_id_offset=chain0, out=out,
+                                        check=False)
+        if world > 1:       # the path's only exchange: every rank learns every chain's end state
+            end_state[:, :d] = out["X"][:, -1]
+            end_state[:, d:2 * d] = out["V"][:, -1]
+            end_state[:, 2 * d] = out["t"][:, -1]
+            dist.all_gather_into_tensor(gathered, end_state)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    fence()
+    ensemble.kernel_timing(sampler, reset=True)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    from pdmpflux.jl_amd import _lib
+    _lib.check(_lib.lib().pdmp_check_status(sampler.handle(), None))
+    tm = ensemble.kernel_timing(sampler)
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    # sanity inside the bench: strictly increasing event times on a slice, finite outputs
+    tt = out["t"][:256]
+    assert bool((tt[:, 1:] > tt[:, :-1]).all()) and bool(torch.isfinite(out["X"][:256]).all())
+
+    if rank == 0:
+        events_step = world * C * (n_sk - 1)
+        value = events_step * a.steps / elapsed
+        bytes_per_event = 8 * (2 * d + 1)                         # X, V, t of one event
+        kernel_ms = tm["kernel_ms_total"] / max(tm["launches"], 1)
+        achieved = C * (n_sk - 1) * bytes_per_event / (kernel_ms * 1e-3) / 1e9
+        res = {
+            "metric": "skeleton-events/sec (whole node), Zig-Zag d=50, 10^5 chains",
+            "value": value, "unit": "events/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{a.sampler} d={d} {a.target} target, {C} chains/GPU x n_sk={n_sk} "
+                                   f"(BASELINE configs[1]), grid_size={sampler.grid_size}, tmax={sampler.tmax}, "
+                                   f"adaptive, forward-mode slopes", "chains_per_gpu": C, "n_sk": n_sk, "dim": d,
+                       "events_per_step": events_step,
+                       "exchange": "none" if world == 1 else "all-gather of chain end states (2d+1 doubles per chain)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "skeleton_kernel", "kernel_ms": kernel_ms, "bytes_per_event": bytes_per_event,
+                         "note": "fp64-VALU-bound state machine; HBM fraction is the requested headline"},
+        }
+        if a.cpu_seconds > 0:
+            res["cpu_baseline"] = cpu_baseline(a, sampler)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
