@@ -96,6 +96,10 @@ int         pdmp_device_count(void);     /* hipGetDeviceCount; 0 when no GPU is 
 int pdmp_create(const pdmp_config_t *cfg, pdmp_handle *out);
 int pdmp_get_config(pdmp_handle h, pdmp_config_t *out);
 int pdmp_destroy(pdmp_handle h);
+/* Arithmetic layout the engine chose for this configuration: lanes per chain G of the group kernel
+ * (sums run in the "GROUP(G)" order of DESIGN.md; G = 1 is the reference's left-to-right order), or
+ * 0 when the wave-per-chain kernel ("WAVE64" order) serves it.  Lets a checker pick the matching order. */
+int pdmp_get_group_lanes(pdmp_handle h);
 
 /* sample_skeleton(sampler, n_sk, xinit, vinit; seed)  (src/sample.jl:253-284) for C chains:
  * init_state (AbstractPDMP.jl:93-153) + (n_sk-1) x get_event_state! (SamplingLoopInplace.jl:27-39)

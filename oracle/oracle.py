@@ -19,7 +19,7 @@ _LIB_PATH = os.path.join(_HERE, "libpdmp_oracle.so")
 ZIGZAG, BPS, BOOMERANG = 0, 1, 2
 T_GAUSS_ISO, T_GAUSS_DIAG, T_BANANA, T_GAUSS_DENSE = 0, 1, 2, 3
 DERIV_FORWARD, DERIV_FINITE_DIFF = 0, 1
-ARITH_REFERENCE, ARITH_WAVE64 = 0, 1
+ARITH_REFERENCE, ARITH_WAVE64, ARITH_GROUP = 0, 1, 2
 
 
 class _Cfg(C.Structure):
@@ -29,7 +29,7 @@ class _Cfg(C.Structure):
         ("gaussian_velocity", C.c_int32), ("deriv_mode", C.c_int32), ("target_id", C.c_int32),
         ("arith", C.c_int32), ("tmax", C.c_double), ("refresh_rate", C.c_double),
         ("target_params", C.POINTER(C.c_double)), ("n_target_params", C.c_int64),
-        ("max_iter_per_event", C.c_int64),
+        ("max_iter_per_event", C.c_int64), ("group_lanes", C.c_int32),
     ]
 
 
@@ -103,6 +103,7 @@ class Config:
     target_params: np.ndarray | None = None
     arith: int = ARITH_REFERENCE
     max_iter_per_event: int = 0
+    group_lanes: int = 1
     _keep: list = field(default_factory=list, repr=False)
 
     def c(self) -> _Cfg:
@@ -114,7 +115,7 @@ class Config:
             p, n = _dp(arr), arr.size
         return _Cfg(self.sampler, self.dim, self.grid_size, int(self.vectorized_bound), int(self.signed_bound),
                     int(self.adaptive), int(self.gaussian_velocity), self.deriv_mode, self.target_id, self.arith,
-                    float(self.tmax), float(self.refresh_rate), p, n, self.max_iter_per_event)
+                    float(self.tmax), float(self.refresh_rate), p, n, self.max_iter_per_event, self.group_lanes)
 
 
 def _check(rc):

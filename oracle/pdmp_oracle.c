@@ -194,30 +194,48 @@ static double sum_wave64(const double *a, int d) {
     }
     return p[0];
 }
+/* GROUP(G): lane g of G accumulates a[g], a[g+G], ... left to right; then xor-butterfly 1,2,..,G/2.
+ * GROUP(1) is the reference order, GROUP(64) the WAVE64 order. */
+static double sum_group(const double *a, int d, int G) {
+    double p[64], q[64];
+    for (int g = 0; g < G; ++g) {
+        double s = 0.0;
+        for (int i = g; i < d; i += G) s += a[i];
+        p[g] = s;
+    }
+    for (int off = 1; off < G; off <<= 1) {
+        for (int g = 0; g < G; ++g) q[g] = p[g] + p[g ^ off];
+        memcpy(p, q, sizeof(double) * (size_t)G);
+    }
+    return p[0];
+}
 static double vsum(const orc_config_t *cfg, const double *a, int d) {
-    return cfg->arith == ORC_ARITH_WAVE64 ? sum_wave64(a, d) : sum_seq(a, d);
+    if (cfg->arith == ORC_ARITH_WAVE64) return sum_wave64(a, d);
+    if (cfg->arith == ORC_ARITH_GROUP) return sum_group(a, d, cfg->group_lanes);
+    return sum_seq(a, d);
 }
 /* first index i with inclusive-prefix(p)[i] > u, else d-1.
  * REFERENCE: Distributions.jl DiscreteNonParametric rand (compat 0.25, Project.toml:31; called at
  * ZigZagSamplers.jl:104): cp = p[1]; while cp <= draw && i < n: cp += p[i += 1].
  * WAVE64: chunks of 64, Kogge-Stone inclusive scan inside a chunk, running carry between chunks. */
 static int categorical(const orc_config_t *cfg, const double *p, int d, double u) {
-    if (cfg->arith != ORC_ARITH_WAVE64) {
+    if (cfg->arith == ORC_ARITH_REFERENCE) {
         double cp = p[0]; int i = 0;
         while (cp <= u && i < d - 1) { ++i; cp += p[i]; }
         return i;
     }
+    const int W = (cfg->arith == ORC_ARITH_GROUP) ? cfg->group_lanes : 64;
     double carry = 0.0;
-    for (int base = 0; base < d; base += 64) {
+    for (int base = 0; base < d; base += W) {
         double y[64], z[64];
-        for (int l = 0; l < 64; ++l) y[l] = (base + l < d) ? p[base + l] : 0.0;
-        for (int off = 1; off < 64; off <<= 1) {
-            for (int l = 0; l < 64; ++l) z[l] = (l >= off) ? y[l] + y[l - off] : y[l];
-            memcpy(y, z, sizeof y);
+        for (int l = 0; l < W; ++l) y[l] = (base + l < d) ? p[base + l] : 0.0;
+        for (int off = 1; off < W; off <<= 1) {
+            for (int l = 0; l < W; ++l) z[l] = (l >= off) ? y[l] + y[l - off] : y[l];
+            memcpy(y, z, sizeof(double) * (size_t)W);
         }
-        for (int l = 0; l < 64 && base + l < d; ++l)
+        for (int l = 0; l < W && base + l < d; ++l)
             if (carry + y[l] > u) return base + l;
-        carry = carry + y[63];
+        carry = carry + y[W - 1];
     }
     return d - 1;
 }
@@ -362,6 +380,15 @@ static double sc_func_dual(const orc_config_t *cfg, ws_t *w, const double *x, co
         w->tmp[i] = w->gv[i] * w->vv[i];
         w->tmp2[i] = w->ge[i] * w->vv[i] + w->gv[i] * w->ve[i];
     }
+    if (cfg->sampler == ORC_ZIGZAG) {            /* non-vectorized Zig-Zag: func = rate = sum(max.(0, .)), ZigZagSamplers.jl:83-86 */
+        for (int i = 0; i < w->d; ++i) {
+            double s = w->tmp[i];
+            w->tmp[i] = pmax(0.0, s);
+            w->tmp2[i] = (0.0 < s) ? w->tmp2[i] : 0.0;
+        }
+        if (slp) *slp = vsum(cfg, w->tmp2, w->d);
+        return vsum(cfg, w->tmp, w->d);
+    }
     double dv = vsum(cfg, w->tmp, w->d), de = vsum(cfg, w->tmp2, w->d);
     if (cfg->signed_bound) { if (slp) *slp = de; return dv + cfg->refresh_rate; }
     if (slp) *slp = (0.0 < dv) ? de : 0.0;
@@ -417,7 +444,7 @@ static void upper_bound(const orc_config_t *cfg, ws_t *w, const double *x, const
                     for (int i = 0; i < d; ++i) slp[i] = (w->fa[i] - w->fb[i]) / (tp - tm); }
             }
         }
-        if (cfg->arith == ORC_ARITH_REFERENCE) memset(w->cum, 0, (size_t)n * 8);
+        if (cfg->arith != ORC_ARITH_WAVE64) memset(w->cum, 0, (size_t)n * 8);
         double *run = w->fa;                       /* per-dimension running cumsum (:243-244) */
         for (int i = 0; i < d; ++i) run[i] = 0.0;
         for (int j = 0; j + 1 < n; ++j) {
@@ -431,9 +458,9 @@ static void upper_bound(const orc_config_t *cfg, ws_t *w, const double *x, const
                 w->cell[i] = pmax(pmax(pmax(v0[i], v1[i]), inter), 0.0); /* :239-241 */
             }
             w->box[j] = vsum(cfg, w->cell, d);                         /* :246 sum(box_max, dims=1) */
-            if (cfg->arith == ORC_ARITH_REFERENCE) {
+            if (cfg->arith != ORC_ARITH_WAVE64) {
                 for (int i = 0; i < d; ++i) { run[i] += w->cell[i]; w->tmp[i] = run[i] * h; }
-                w->cum[j + 1] = sum_seq(w->tmp, d);                    /* :244,:246 */
+                w->cum[j + 1] = vsum(cfg, w->tmp, d);                  /* :244,:246 */
             }
         }
         if (cfg->arith == ORC_ARITH_WAVE64) {                          /* engine order: cumsum after the sum */
@@ -562,6 +589,10 @@ int orc_normalize_config(orc_config_t *c) {
     if (c->sampler == ORC_ZIGZAG) {
         if (c->signed_bound && !c->vectorized_bound) c->signed_bound = 0;                             /* :75-78 */
     } else c->vectorized_bound = 0;                                                                  /* BPS :37, Boomerang :36 */
+    if (c->arith == ORC_ARITH_GROUP) {
+        int G = c->group_lanes;
+        if (G < 1 || G > 64 || (G & (G - 1))) FAIL(-1, "group_lanes must be a power of two in 1..64");
+    }
     if (c->target_id == ORC_T_GAUSS_DIAG && c->n_target_params != 2 * (int64_t)c->dim) FAIL(-1, "GAUSS_DIAG needs 2*dim params");
     if (c->target_id == ORC_T_GAUSS_DENSE && c->n_target_params != (int64_t)c->dim * c->dim) FAIL(-1, "GAUSS_DENSE needs dim^2 params");
     return 0;

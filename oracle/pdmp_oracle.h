@@ -29,7 +29,10 @@ enum { ORC_DERIV_FORWARD = 0, ORC_DERIV_FINITE_DIFF = 1 };
  *              dimensions (UpperBound.jl:243-246), sequential Categorical walk.
  *   WAVE64   : the order the MI355X engine uses (64-lane ascending xor-butterfly, Kogge-Stone
  *              prefix scan, cumsum after the sum over dimensions).  Bitwise target for the HIP path. */
-enum { ORC_ARITH_REFERENCE = 0, ORC_ARITH_WAVE64 = 1 };
+/*   GROUP    : G lanes per chain (orc_config_t.group_lanes): per-lane left-to-right partial sums over the
+ *              coordinates i = g, g+G, ..., ascending xor-butterfly over the G lanes; cum_sum in the
+ *              reference's per-dimension form; Categorical walk in slots of G.  GROUP(1) == REFERENCE. */
+enum { ORC_ARITH_REFERENCE = 0, ORC_ARITH_WAVE64 = 1, ORC_ARITH_GROUP = 2 };
 
 typedef struct orc_config_t {
     int32_t sampler;
@@ -47,6 +50,7 @@ typedef struct orc_config_t {
     const double *target_params; /* DIAG: mu[d], prec[d];  DENSE: P[d*d] column-major */
     int64_t n_target_params;
     int64_t max_iter_per_event;  /* 0 = default 1e6; safety cap (status -4) */
+    int32_t group_lanes;         /* G for ORC_ARITH_GROUP */
 } orc_config_t;
 
 const char *orc_last_error(void);

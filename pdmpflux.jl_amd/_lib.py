@@ -54,7 +54,7 @@ class Timing(C.Structure):
 # every symbol include/pdmp_hip.h declares; tests check that the library exports all of them
 SYMBOLS = (
     "pdmp_abi_version", "pdmp_last_error", "pdmp_device_count", "pdmp_create", "pdmp_get_config",
-    "pdmp_destroy", "pdmp_sample_skeleton", "pdmp_sample_skeleton_device", "pdmp_sample_from_skeleton",
+    "pdmp_destroy", "pdmp_get_group_lanes", "pdmp_sample_skeleton", "pdmp_sample_skeleton_device", "pdmp_sample_from_skeleton",
     "pdmp_sample_from_skeleton_device", "pdmp_check_status", "pdmp_get_timing", "pdmp_reset_timing",
     "pdmp_debug_rng",
 )
@@ -85,6 +85,8 @@ def lib():
     L.pdmp_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     L.pdmp_get_config.argtypes = [vp, C.POINTER(Config)]
     L.pdmp_destroy.argtypes = [vp]
+    L.pdmp_get_group_lanes.argtypes = [vp]
+    L.pdmp_get_group_lanes.restype = C.c_int
     L.pdmp_sample_skeleton.argtypes = [vp, i64, i64, i64, vp, vp, u64, vp, vp, vp, C.POINTER(Diag)]
     L.pdmp_sample_skeleton_device.argtypes = [vp, i64, i64, i64, vp, vp, u64, vp, vp, vp, C.POINTER(Diag), vp]
     L.pdmp_sample_from_skeleton.argtypes = [vp, i64, i64, vp, vp, vp, i64, i32, vp]

@@ -1,11 +1,12 @@
 // engine_api.hip -- C ABI of libpdmphip.so (include/pdmp_hip.h): handle management, argument checks
 // that mirror the reference constructors, kernel dispatch, sample_from_skeleton kernel, hipEvent timing.
 #include "../../include/pdmp_hip.h"
-#include "skeleton_kernel.hpp"
+#include "group_kernel.hpp"
 
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -34,6 +35,7 @@ struct EventPair { hipEvent_t a, b; };
 
 struct pdmp_engine {
     pdmp_config_t cfg;
+    int group_lanes = 0;              // 0: wave-per-chain kernel; else lanes per chain of the group kernel
     int device = 0;
     double *d_tparams = nullptr;
     int32_t *d_status = nullptr;      // [0] itercap chains, [1] guard events
@@ -143,6 +145,34 @@ launch_fn pick_launcher(int sampler, int target) {
     return table[sampler][target];
 }
 
+typedef hipError_t (*glaunch_fn)(const GroupParams &, hipStream_t);
+glaunch_fn pick_group_launcher(int sampler, int target) {
+    static const glaunch_fn table[3][3] = {
+        {launch_group<S_ZIGZAG, T_GAUSS_ISO>, launch_group<S_ZIGZAG, T_GAUSS_DIAG>, launch_group<S_ZIGZAG, T_BANANA>},
+        {launch_group<S_BPS, T_GAUSS_ISO>, launch_group<S_BPS, T_GAUSS_DIAG>, launch_group<S_BPS, T_BANANA>},
+        {launch_group<S_BOOMERANG, T_GAUSS_ISO>, launch_group<S_BOOMERANG, T_GAUSS_DIAG>, launch_group<S_BOOMERANG, T_BANANA>},
+    };
+    return table[sampler][target];
+}
+
+// Lanes per chain for the group kernel: the smallest power of two that keeps a wave's LDS tile
+// (2 * ceil(d/G) * 512 B) within `budget` bytes, i.e. at least 160 KiB / (4 * budget) blocks of four
+// waves per CU.  0 = the configuration is served by the wave-per-chain kernel instead.
+int choose_group_lanes(const pdmp_config_t &c) {
+    if (c.grid_size != GNG || c.deriv_mode != PDMP_DERIV_FORWARD) return 0;
+    if (const char *e = getenv("PDMP_GROUP_LANES")) {
+        const int G = atoi(e);
+        if (G == 0) return 0;
+        if (G >= 1 && G <= WAVE && (G & (G - 1)) == 0 && group_waves_per_block((c.dim + G - 1) / G, 2 * c.dim) >= 1) return G;
+    }
+    const size_t budget = 20 * 1024;      // two blocks (8 waves) per CU
+    for (int G = 1; G <= WAVE; G <<= 1) {
+        const size_t K = (size_t)(c.dim + G - 1) / G;
+        if (2 * K * WAVE * sizeof(double) <= budget) return G;
+    }
+    return 0;
+}
+
 int begin_timed(pdmp_engine *h, hipStream_t s, EventPair &ev) {
     if (!h->pool.empty()) { ev = h->pool.back(); h->pool.pop_back(); }
     else { HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); }
@@ -198,6 +228,7 @@ int pdmp_create(const pdmp_config_t *cfg, pdmp_handle *out) {
     h->cfg.device = dev;
     h->device = dev;
     h->cfg.target_params = nullptr;
+    h->group_lanes = choose_group_lanes(c);
     if (c.n_target_params > 0 && c.target_params) {
         HIP_TRY(hipMalloc(&h->d_tparams, (size_t)c.n_target_params * 8));
         HIP_TRY(hipMemcpy(h->d_tparams, c.target_params, (size_t)c.n_target_params * 8, hipMemcpyHostToDevice));
@@ -207,6 +238,8 @@ int pdmp_create(const pdmp_config_t *cfg, pdmp_handle *out) {
     *out = h;
     return PDMP_OK;
 }
+
+int pdmp_get_group_lanes(pdmp_handle h) { return h ? h->group_lanes : -1; }
 
 int pdmp_get_config(pdmp_handle h, pdmp_config_t *out) {
     if (!h || !out) return fail(PDMP_ERR_ARGUMENT, "null argument");
@@ -252,7 +285,16 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
     hipStream_t s = (hipStream_t)stream;
     EventPair ev;
     if (int rc = begin_timed(h, s, ev)) return rc;
-    HIP_TRY(pick_launcher(c.sampler, c.target_id)(p, s));
+    if (h->group_lanes > 0) {
+        GroupParams gp;
+        gp.s = p;
+        gp.G = h->group_lanes;
+        gp.K = (c.dim + gp.G - 1) / gp.G;
+        gp.tpar = (c.target_id == PDMP_T_GAUSS_DIAG) ? 2 * c.dim : 0;
+        HIP_TRY(pick_group_launcher(c.sampler, c.target_id)(gp, s));
+    } else {
+        HIP_TRY(pick_launcher(c.sampler, c.target_id)(p, s));
+    }
     return end_timed(h, s, ev);
 }
 

@@ -1,0 +1,584 @@
+// group_kernel.hpp -- the fast path of sample_skeleton() (src/sample.jl:253-284) for grid_size = 10
+// and forward-mode slopes: G lanes per chain (G = 1,2,4,...,64 chosen from d), 64/G chains per wave.
+//
+// Why this layout (profiles/r1): the wave-per-chain kernel (skeleton_kernel.hpp) is VALU-issue bound
+// (94 % VALU busy, 1100 wave-instructions per event) and most of those instructions are per-chain
+// overhead replicated over 64 lanes: wave reductions of the nine box_max sums, the scalar
+// next_event / RNG / log work, 14 idle lanes at d = 50.  Here
+//   * coordinate i of a chain lives in LDS slot i/G of lane (i mod G) of the chain's lane group
+//     (conflict-free ds_read_b64: consecutive lanes, consecutive 8-byte words);
+//   * each lane walks its d/G coordinates sequentially and keeps the nine box_max / cum_sum
+//     accumulators of the BoundBox (src/Composites.jl:15-20) in registers, so a bound costs
+//     18*log2(G) cross-lane adds instead of 54 full-wave ones and the per-chain scalar work is shared
+//     by 64/G chains per instruction;
+//   * with G = 1 every sum runs in exactly the reference's left-to-right order.
+// The thinning state machine (src/SamplingLoopInplace.jl:27-217) is flattened into two phases per
+// lane -- BOUND (one_step_of_thinning! / erroneous_acceptance_rate!) and PROPOSE (ac_step!) -- so the
+// chains of a wave stay in lock step: with the adaptive horizon a chain needs ~1.2 bounds and ~1.04
+// proposals per event, so almost every iteration every lane does BOUND then PROPOSE -> accept.
+//
+// Arithmetic contract ("GROUP(G)" order of the checker): a sum over coordinates is, per lane, the
+// left-to-right sum of the coordinates it owns (i = g, g+G, ...), then an ascending xor-butterfly
+// over the G lanes; cum_sum is the reference's per-dimension cumsum, times h, summed that way
+// (UpperBound.jl:243-246); the Zig-Zag flip index walks slots of G coordinates with a Kogge-Stone
+// scan inside a slot and a running carry between slots.
+#pragma once
+#include "skeleton_kernel.hpp"
+
+namespace pdmp {
+
+constexpr int GNG = 10;   // grid_size served by this kernel (the default of every reference constructor)
+
+struct GroupParams {
+    SkelParams s;
+    int32_t G;            // lanes per chain (power of two, 1..64)
+    int32_t K;            // coordinate slots per lane = ceil(d / G)
+    int32_t tpar;         // doubles of target parameters staged in LDS (0 or 2d)
+};
+
+// ---------------------------------------------------------------- group-of-lanes primitives (G uniform)
+__device__ __forceinline__ double group_sum(double a, int G) {
+    for (int off = 1; off < G; off <<= 1) a = a + __shfl_xor(a, off, WAVE);
+    return a;
+}
+__device__ __forceinline__ double group_scan_incl(double a, int g, int G) {
+    for (int off = 1; off < G; off <<= 1) {
+        const double t = __shfl_up(a, off, WAVE);
+        if (g >= off) a = a + t;
+    }
+    return a;
+}
+
+struct TimePt { double t, s, c; };   // grid time (+ sin/cos for the Boomerang rotation)
+
+// ---------------------------------------------------------------- targets in the group layout
+// grad(i, x_i, shared): coordinate i of grad-U at a (dual or plain) position; `shared` carries what a
+// non-separable potential needs from other coordinates of the same chain at the same time point.
+struct NoShared {};
+template <int TARGET> struct GTarget;
+
+template <> struct GTarget<T_GAUSS_ISO> {
+    static constexpr bool kShared = false;
+    template <class T> using Sh = NoShared;
+    __device__ __forceinline__ void init(const double *, int) {}
+    template <class T> __device__ __forceinline__ NoShared shared(T, T) const { return {}; }
+    template <class T> __device__ __forceinline__ T grad(int, T x, const NoShared &) const { return x; }
+};
+template <> struct GTarget<T_GAUSS_DIAG> {
+    static constexpr bool kShared = false;
+    template <class T> using Sh = NoShared;
+    const double *mu, *prec;            // LDS copies
+    __device__ __forceinline__ void init(const double *lds_params, int d) { mu = lds_params; prec = lds_params + d; }
+    template <class T> __device__ __forceinline__ NoShared shared(T, T) const { return {}; }
+    __device__ __forceinline__ double grad(int i, double x, const NoShared &) const { return prec[i] * (x - mu[i]); }
+    __device__ __forceinline__ Dual grad(int i, Dual x, const NoShared &) const {
+        const double p = prec[i];
+        return {p * (x.v - mu[i]), p * x.e};
+    }
+};
+template <class T> struct BananaSh { T g0, r; };
+template <> struct GTarget<T_BANANA> {          // test/test_config.jl:33-36
+    static constexpr bool kShared = true;
+    template <class T> using Sh = BananaSh<T>;
+    int d;
+    __device__ __forceinline__ void init(const double *, int dim) { d = dim; }
+    template <class T> __device__ __forceinline__ BananaSh<T> shared(T x0, T x1) const {
+        const T sq = x0 * x0;
+        const T m = sq - 1.0;
+        const T r = x1 - m;
+        const T a = 2.0 * x0;
+        const T pr = a * r;
+        return {x0 - pr, r};
+    }
+    template <class T> __device__ __forceinline__ T grad(int i, T x, const BananaSh<T> &sh) const {
+        if (d < 2) return x;
+        return i == 0 ? sh.g0 : (i == 1 ? sh.r : x);
+    }
+};
+
+struct GBound {                 // BoundBox in registers: box_max[0..8], cum_sum[1..9] (cum_sum[0] = 0)
+    double box[GNG - 1], cum[GNG - 1], h;
+};
+
+template <int SAMPLER, int TARGET>
+struct GroupChain {
+    using Tgt = GTarget<TARGET>;
+    const SkelParams &p;
+    const int G, K, lane, g, base;       // g = lane within the group, base = first lane of the group
+    double *xs, *vs;                     // this wave's LDS tiles: slot s of lane l at [s*64 + l]
+    Tgt tgt;
+    ChainRng rng;
+    int32_t guard = 0;
+
+    __device__ __forceinline__ GroupChain(const GroupParams &gp, int l, double *x_tile, double *v_tile)
+        : p(gp.s), G(gp.G), K(gp.K), lane(l), g(l & (gp.G - 1)), base(l & ~(gp.G - 1)), xs(x_tile), vs(v_tile) {}
+
+    __device__ __forceinline__ double &X(int s) const { return xs[s * WAVE + lane]; }
+    __device__ __forceinline__ double &V(int s) const { return vs[s * WAVE + lane]; }
+    __device__ __forceinline__ void coord(int i, double &x, double &v) const {   // any coordinate of my chain
+        const int s = (G == WAVE) ? (i >> 6) : i / G, l = base + (i - s * G);
+        x = xs[s * WAVE + l];
+        v = vs[s * WAVE + l];
+    }
+    __device__ __forceinline__ void time_pt(double t, TimePt &tp) const {
+        tp.t = t;
+        if constexpr (SAMPLER == S_BOOMERANG) det_sincos(t, tp.s, tp.c); else { tp.s = 0.0; tp.c = 1.0; }
+    }
+    // flow of one coordinate: ZigZagSamplers.jl:80 / BouncyParticleSamplers.jl:32 / BoomerangSamplers.jl:31
+    __device__ __forceinline__ void flow(double x, double v, const TimePt &tp, Dual &xt, Dual &vt) const {
+        if constexpr (SAMPLER == S_BOOMERANG) {
+            xt = {x * tp.c + v * tp.s, x * (-tp.s) + v * tp.c};
+            vt = {(-x) * tp.s + v * tp.c, (-x) * tp.c + v * (-tp.s)};
+        } else {
+            xt = {x + v * tp.t, v};
+            vt = {v, 0.0};
+        }
+    }
+    __device__ __forceinline__ void flow(double x, double v, const TimePt &tp, double &xt, double &vt) const {
+        if constexpr (SAMPLER == S_BOOMERANG) { xt = x * tp.c + v * tp.s; vt = (-x) * tp.s + v * tp.c; }
+        else { xt = x + v * tp.t; vt = v; }
+    }
+    template <class T>
+    __device__ __forceinline__ typename Tgt::template Sh<T> shared_at(const TimePt &tp) const {
+        if constexpr (Tgt::kShared) {
+            if (p.d >= 2) {
+                double x0, v0, x1, v1;
+                coord(0, x0, v0);
+                coord(1, x1, v1);
+                T a, b, va, vb;
+                flow(x0, v0, tp, a, va);
+                flow(x1, v1, tp, b, vb);
+                return tgt.template shared<T>(a, b);
+            }
+            return typename Tgt::template Sh<T>{};
+        } else {
+            return {};
+        }
+    }
+    __device__ __forceinline__ double sdot(const Dual &gd, const Dual &vt) const {   // d/dt of g*v
+        if constexpr (SAMPLER == S_BOOMERANG) return gd.e * vt.v + gd.v * vt.e;
+        else return gd.e * vt.v;
+    }
+
+    // ---- tangent-intersection cell, UpperBound.jl:229-241 (absolute-time form, Q1) / :123-130
+    // den == 0 (every Gaussian coordinate) gives num/0 = +-Inf or NaN, which the reference's
+    // NaN->0 + clamp turns into h or 0: same bits as the division path, no v_div sequence.
+    __device__ __forceinline__ static double cell_q(double num, double den, double h, bool fast) {
+        if (fast) return (num > 0.0) ? h : 0.0;
+        return fmin(fmax(num / den, 0.0), h);       // fmax drops NaN: the reference's replace(NaN => 0)
+    }
+
+    // ---- upper_bound_grid_vect, UpperBound.jl:203-247
+    __device__ __forceinline__ void bound_vect(double harg, GBound &B) const {
+        const double h = harg / (double)(GNG - 1);
+        TimePt tp[GNG];
+        typename Tgt::template Sh<Dual> sh[GNG];
+#pragma unroll
+        for (int j = 0; j < GNG; ++j) {
+            time_pt((j == GNG - 1) ? harg : (double)j * h, tp[j]);
+            sh[j] = shared_at<Dual>(tp[j]);
+        }
+        double box[GNG - 1], cum[GNG - 1];
+#pragma unroll
+        for (int j = 0; j < GNG - 1; ++j) { box[j] = 0.0; cum[j] = 0.0; }
+        const bool sgn = p.signed_bound != 0;
+        for (int s = 0; s < K; ++s) {
+            const int i = s * G + g;
+            const bool valid = i < p.d;
+            const double x = X(s), v = V(s);
+            double val[GNG], slp[GNG];
+#pragma unroll
+            for (int j = 0; j < GNG; ++j) {                           // :208-210
+                Dual xt, vt;
+                flow(x, v, tp[j], xt, vt);
+                const Dual gd = tgt.grad(i, xt, sh[j]);
+                const double sv = gd.v * vt.v, sd = sdot(gd, vt);
+                val[j] = sgn ? sv : fmax(0.0, sv);
+                slp[j] = sgn ? sd : ((0.0 < sv) ? sd : 0.0);
+            }
+            double num[GNG - 1], den[GNG - 1];
+            bool nz = false;
+#pragma unroll
+            for (int j = 0; j < GNG - 1; ++j) {                       // :229
+                num[j] = ((val[j] - val[j + 1]) + slp[j + 1] * tp[j + 1].t) - slp[j] * tp[j].t;
+                den[j] = slp[j + 1] - slp[j];
+                nz = nz || (den[j] != 0.0);
+            }
+            const bool fast = __ballot(nz) == 0ull;                   // wave-uniform
+            double run = 0.0;
+#pragma unroll
+            for (int j = 0; j < GNG - 1; ++j) {
+                const double q = cell_q(num[j], den[j], h, fast);      // :234-235
+                const double inter = val[j] + slp[j] * q;             // :237
+                double cell = fmax(fmax(fmax(val[j], val[j + 1]), inter), 0.0);   // :239-241
+                cell = valid ? cell : 0.0;
+                box[j] += cell;                                       // sum(box_max, dims=1), :246
+                run += cell;                                          // cumsum(box_max, dims=2), :244
+                cum[j] += run * h;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < GNG - 1; ++j) { B.box[j] = group_sum(box[j], G); B.cum[j] = group_sum(cum[j], G); }
+        B.h = h;
+    }
+
+    // ---- upper_bound_grid, UpperBound.jl:92-137 (BPS / Boomerang)
+    __device__ __forceinline__ void bound_scalar(double harg, GBound &B) const {
+        const double h = harg / (double)(GNG - 1);
+        TimePt tp[GNG];
+        typename Tgt::template Sh<Dual> sh[GNG];
+        double fv[GNG], fe[GNG];
+#pragma unroll
+        for (int j = 0; j < GNG; ++j) {
+            time_pt((j == GNG - 1) ? harg : (double)j * h, tp[j]);
+            sh[j] = shared_at<Dual>(tp[j]);
+            fv[j] = 0.0; fe[j] = 0.0;
+        }
+        for (int s = 0; s < K; ++s) {
+            const int i = s * G + g;
+            const bool valid = i < p.d;
+            const double x = X(s), v = V(s);
+#pragma unroll
+            for (int j = 0; j < GNG; ++j) {                           // :97, :102
+                Dual xt, vt;
+                flow(x, v, tp[j], xt, vt);
+                const Dual gd = tgt.grad(i, xt, sh[j]);
+                double a = gd.v * vt.v, b = sdot(gd, vt);
+                if constexpr (SAMPLER == S_ZIGZAG) {       // non-vectorized Zig-Zag bounds rate = sum(max.(0,.)), ZigZagSamplers.jl:83-86
+                    b = (0.0 < a) ? b : 0.0;
+                    a = fmax(0.0, a);
+                }
+                fv[j] += valid ? a : 0.0;
+                fe[j] += valid ? b : 0.0;
+            }
+        }
+        const bool sgn = p.signed_bound != 0;
+        const double refresh = sgn ? p.refresh : 0.0;                 // AbstractPDMP.jl:104-112
+        double val[GNG], slp[GNG];
+#pragma unroll
+        for (int j = 0; j < GNG; ++j) {
+            const double dv = group_sum(fv[j], G), de = group_sum(fe[j], G);
+            if constexpr (SAMPLER == S_ZIGZAG) { val[j] = dv; slp[j] = de; continue; }
+            val[j] = (sgn ? dv : fmax(0.0, dv)) + p.refresh;          // BouncyParticleSamplers.jl:39-47 (Q2)
+            slp[j] = sgn ? de : ((0.0 < dv) ? de : 0.0);
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < GNG - 1; ++j) {
+            const double num = (val[j] - val[j + 1]) + slp[j + 1] * h;   // :123 relative form
+            const double q = cell_q(num, slp[j + 1] - slp[j], h, false); // :124-125
+            const double inter = val[j] + slp[j] * q;                    // :127
+            double b = fmax(fmax(fmax(val[j], val[j + 1]), inter), 0.0); // :128-130
+            b += refresh;                                                // :131
+            acc += b;
+            B.box[j] = b;
+            B.cum[j] = acc * h;                                          // :133-134
+        }
+        B.h = h;
+    }
+    __device__ __forceinline__ void upper_bound(double harg, GBound &B) const {
+        if constexpr (SAMPLER == S_ZIGZAG) {
+            if (p.vectorized) { bound_vect(harg, B); return; }
+        }
+        bound_scalar(harg, B);
+    }
+
+    // ---- next_event, UpperBound.jl:264-273
+    __device__ __forceinline__ static void next_event(const GBound &B, double E, double &tp, double &lb) {
+        int idx = 1;                                        // cum_sum[0] = 0 < E
+#pragma unroll
+        for (int j = 0; j < GNG - 1; ++j) idx += (B.cum[j] < E) ? 1 : 0;
+        double c0 = 0.0, c1 = 0.0, b = B.box[GNG - 2];
+#pragma unroll
+        for (int j = 0; j < GNG - 1; ++j) {
+            if (j + 1 == idx) { c1 = B.cum[j]; b = B.box[j]; }
+            if (j + 2 == idx) c0 = B.cum[j];
+        }
+        const double t = (double)(idx - 1) * B.h + (E - c0) / (c1 - c0) * B.h;
+        tp = (idx >= GNG) ? __builtin_huge_val() : t;
+        lb = b;
+    }
+
+    // ---- unsigned total rate of the accept test (SamplingLoopInplace.jl:116, Q3)
+    __device__ __forceinline__ double true_rate(double t) const {
+        TimePt tp;
+        time_pt(t, tp);
+        const auto sh = shared_at<double>(tp);
+        double acc = 0.0;
+        for (int s = 0; s < K; ++s) {
+            const int i = s * G + g;
+            double xt, vt;
+            flow(X(s), V(s), tp, xt, vt);
+            const double gv = tgt.grad(i, xt, sh) * vt;
+            const double term = (SAMPLER == S_ZIGZAG) ? fmax(0.0, gv) : gv;     // ZigZagSamplers.jl:83-86
+            acc += (i < p.d) ? term : 0.0;
+        }
+        const double tot = group_sum(acc, G);
+        if constexpr (SAMPLER == S_ZIGZAG) return tot;
+        else return fmax(0.0, tot) + p.refresh;                                 // BPS :39-42, Boomerang :38-41
+    }
+
+    __device__ __forceinline__ void flow_state(double t) const {
+        TimePt tp;
+        time_pt(t, tp);
+        for (int s = 0; s < K; ++s) {
+            double xt, vt;
+            flow(X(s), V(s), tp, xt, vt);
+            X(s) = xt;
+            if constexpr (SAMPLER == S_BOOMERANG) V(s) = vt;
+        }
+    }
+
+    // ---- velocity_jump: ZigZagSamplers.jl:101-107, BouncyParticleSamplers.jl:50-74, BoomerangSamplers.jl:49-67
+    __device__ __forceinline__ void velocity_jump() {
+        TimePt t0;
+        t0.t = 0.0; t0.s = 0.0; t0.c = 1.0;
+        typename Tgt::template Sh<double> sh;
+        if constexpr (Tgt::kShared) {
+            if (p.d >= 2) { double x0, v0, x1, v1; coord(0, x0, v0); coord(1, x1, v1); sh = tgt.template shared<double>(x0, x1); }
+        }
+        const int d = p.d;
+        if constexpr (SAMPLER == S_ZIGZAG) {
+            double acc = 0.0;
+            for (int s = 0; s < K; ++s) {
+                const int i = s * G + g;
+                const double lam = fmax(0.0, tgt.grad(i, X(s), sh) * V(s));
+                acc += (i < d) ? lam : 0.0;
+            }
+            const double S = group_sum(acc, G);
+            const double u = rng.uniform();                              // Categorical draw
+            if (!(S > 0.0)) { guard++; return; }                         // Q11
+            double carry = 0.0;
+            int m = -1;
+            for (int s = 0; s < K; ++s) {
+                const int i = s * G + g;
+                const bool valid = i < d;
+                const double lam = valid ? fmax(0.0, tgt.grad(i, X(s), sh) * V(s)) : 0.0;
+                const double inc = group_scan_incl(lam / S, g, G);
+                const unsigned long long ball = __ballot(valid && (carry + inc > u));
+                const unsigned long long grp = (G == WAVE) ? ball : ((ball >> base) & ((1ull << G) - 1ull));
+                if (m < 0 && grp != 0ull) m = s * G + (int)__builtin_ctzll(grp);
+                carry = carry + __shfl(inc, base + G - 1, WAVE);
+                if (__ballot(m < 0) == 0ull) break;
+            }
+            if (m < 0) m = d - 1;
+            const int ms = m / G;
+            if (g == m - ms * G) V(ms) = -V(ms);                         // v[m] *= -1
+            return;
+        } else {
+            double acc = 0.0;
+            for (int s = 0; s < K; ++s) {
+                const int i = s * G + g;
+                double gi = tgt.grad(i, X(s), sh);
+                if constexpr (SAMPLER == S_BOOMERANG) gi = gi - X(s);    // :51-52 (Q8)
+                acc += (i < d) ? gi * V(s) : 0.0;
+            }
+            const double gv = group_sum(acc, G);
+            const double bounce = fmax(0.0, gv);
+            const double prob = bounce / (bounce + p.refresh);           // NaN if both 0 (Q9)
+            const double u = rng.uniform();
+            if (u < prob) {
+                acc = 0.0;
+                for (int s = 0; s < K; ++s) {
+                    const int i = s * G + g;
+                    double gi = tgt.grad(i, X(s), sh);
+                    if constexpr (SAMPLER == S_BOOMERANG) gi = gi - X(s);
+                    acc += (i < d) ? gi * gi : 0.0;
+                }
+                const double gg = group_sum(acc, G);
+                if constexpr (SAMPLER == S_BPS) {
+                    if (gg == 0.0) return;
+                    const double scale = 2.0 * gv / gg;                  // :60
+                    for (int s = 0; s < K; ++s) {
+                        const int i = s * G + g;
+                        const double gi = tgt.grad(i, X(s), sh);
+                        if (i < d) V(s) = V(s) - scale * gi;
+                    }
+                } else {
+                    const double nrm = __dsqrt_rn(gg);                   // :58
+                    acc = 0.0;
+                    for (int s = 0; s < K; ++s) {
+                        const int i = s * G + g;
+                        const double e = (tgt.grad(i, X(s), sh) - X(s)) / nrm;
+                        acc += (i < d) ? V(s) * e : 0.0;
+                    }
+                    const double ve = 2.0 * group_sum(acc, G);
+                    for (int s = 0; s < K; ++s) {
+                        const int i = s * G + g;
+                        const double e = (tgt.grad(i, X(s), sh) - X(s)) / nrm;
+                        if (i < d) V(s) = V(s) - ve * e;                 // :59
+                    }
+                }
+            } else {
+                acc = 0.0;
+                for (int s = 0; s < K; ++s) {
+                    const int i = s * G + g;
+                    const double z = (i < d) ? rng.normal_coord(i) : 0.0;   // randn!, :67 / randn(dim), :65
+                    V(s) = z;
+                    acc += z * z;
+                }
+                rng.normals_done(d);
+                if (SAMPLER == S_BPS && !p.gaussian_velocity) {          // normalize!, :71
+                    const double inv = 1.0 / __dsqrt_rn(group_sum(acc, G));
+                    for (int s = 0; s < K; ++s) V(s) = V(s) * inv;
+                }
+            }
+        }
+    }
+
+    // ---- record!, Composites.jl:239-260
+    __device__ __forceinline__ void record(int64_t c, int64_t k, double t, double horizon, double ar,
+                                           int32_t errored, const double (&ev)[5], int32_t rejected,
+                                           int32_t hits) const {
+        const size_t e = (size_t)c * (size_t)p.n_sk + (size_t)k;
+        double *Xe = p.X + e * (size_t)p.d, *Ve = p.V + e * (size_t)p.d;
+        for (int s = 0; s < K; ++s) {
+            const int i = s * G + g;
+            if (i < p.d) { Xe[i] = X(s); Ve[i] = V(s); }
+        }
+        if (g == 0) {
+            p.t[e] = t;
+            if (p.H) p.H[e] = horizon;
+            if (p.AR) p.AR[e] = ar;
+            if (p.EB) p.EB[e] = errored;
+            if (p.RJ) p.RJ[e] = rejected;
+            if (p.HH) p.HH[e] = hits;
+            if (p.EV) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q) p.EV[5 * e + q] = ev[q];
+            }
+        }
+    }
+
+    // ---- sample_skeleton for the chains of this wave
+    __device__ __forceinline__ void run(int64_t c, bool chain_ok) {
+        const int d = p.d;
+        for (int s = 0; s < K; ++s) {
+            const int i = s * G + g;
+            const bool ok = chain_ok && i < d;
+            X(s) = ok ? p.xinit[(size_t)c * d + i] : 0.0;                // copies: inputs are never mutated (Q7)
+            V(s) = ok ? p.vinit[(size_t)c * d + i] : 0.0;
+        }
+        rng.init_lane(p.seed, (uint64_t)(p.chain0 + c));
+        double t = 0.0, horizon = p.tmax, ts = 0.0, tp = 0.0, E = 0.0, lb = 0.0, ar = 0.0;
+        int32_t errored = 0, rejected = 0, hits = 0;
+        double ev[5] = {0, 0, 0, 0, 0};
+        const bool adaptive = p.adaptive != 0;
+        GBound B;
+#pragma unroll
+        for (int j = 0; j < GNG - 1; ++j) { B.box[j] = 0.0; B.cum[j] = 0.0; }
+        B.h = 0.0;
+        bool done = !chain_ok;
+        if (!done) record(c, 0, t, horizon, ar, 0, ev, 0, 0);             // sample.jl:272
+        int64_t k = 1, it = 0;
+        if (p.n_sk <= 1) done = true;
+        bool propose = false, err_pending = false;
+        while (__ballot(!done) != 0ull) {
+            if (!done && !propose) {
+                // one_step_of_thinning! (:65-85) or erroneous_acceptance_rate! (:131-151)
+                const double harg = err_pending ? horizon / 2 : horizon;
+                upper_bound(harg, B);
+                E = rng.exponential();
+                next_event(B, E, tp, lb);
+                if (err_pending) {
+                    if (adaptive) horizon = harg;
+                    errored++;
+                    const int slot = errored % 5;                         // :148 (1-based errored%5+1)
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) if (q == slot) ev[q] = ar;
+                    err_pending = false;
+                    propose = tp < horizon;                               // moves_until_horizon! loop test, :106
+                } else if (tp > horizon) {                                // move_to_horizon!, :87-101
+                    flow_state(horizon);
+                    ts += horizon;
+                    hits++;
+                    if (adaptive) horizon = horizon * 1.01;
+                } else {
+                    propose = tp < horizon;                               // tp == horizon: retry (Q6)
+                }
+                if (++it > p.cap) { done = true; if (g == 0) atomicAdd(&p.status[0], 1); }
+            }
+            if (!done && propose) {
+                const double lam = true_rate(tp);                         // ac_step!, :113-129
+                ar = lam / lb;
+                if (ar > 1.0) {
+                    err_pending = true;
+                    propose = false;
+                } else {                                                  // ac_step_with_proxy!, :153-168
+                    const double u = rng.uniform();
+                    if (u < ar) {                                         // if_accept!, :170-186
+                        flow_state(tp);
+                        velocity_jump();
+                        t = t + tp + ts;
+                        ts = 0.0;
+                        tp = 0.0;
+                        record(c, k, t, horizon, ar, errored, ev, rejected, hits);
+                        errored = 0; rejected = 0; hits = 0;              // get_event_state!, :28-31
+#pragma unroll
+                        for (int q = 0; q < 5; ++q) ev[q] = 0.0;
+                        it = 0;
+                        if (++k >= p.n_sk) done = true;
+                        propose = false;
+                    } else {                                              // if_reject!, :188-203
+                        E = E + rng.exponential();
+                        next_event(B, E, tp, lb);
+                        if (adaptive) horizon = horizon / 1.04;
+                        rejected++;
+                        if (tp > horizon) {                               // move_to_horizon2!, :205-217
+                            flow_state(horizon);
+                            ts += horizon;
+                            hits++;
+                        }
+                        propose = tp < horizon;
+                    }
+                }
+                if (++it > p.cap && !done) { done = true; if (g == 0) atomicAdd(&p.status[0], 1); }
+            }
+        }
+        if (guard && g == 0) atomicAdd(&p.status[1], guard);
+    }
+};
+
+template <int SAMPLER, int TARGET>
+__global__ __launch_bounds__(256) void group_kernel(const GroupParams gp) {
+    extern __shared__ double smem[];
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    // target parameters (mu, prec) once per block
+    for (int q = threadIdx.x; q < gp.tpar; q += blockDim.x) smem[q] = gp.s.tparams[q];
+    __syncthreads();
+    double *tile = smem + gp.tpar + (size_t)wave * 2 * gp.K * WAVE;
+    const int cpw = WAVE / gp.G;
+    const int64_t wave_global = (int64_t)blockIdx.x * wpb + wave;
+    const int64_t c = wave_global * cpw + lane / gp.G;
+    GroupChain<SAMPLER, TARGET> chain(gp, lane, tile, tile + gp.K * WAVE);
+    chain.tgt.init(smem, gp.s.d);
+    chain.run(c, c < gp.s.C);
+}
+
+// waves per block: as many (up to 4) as fit the CU's 160 KiB of LDS next to the staged parameters
+inline int group_waves_per_block(int K, int tpar) {
+    const size_t tile = 2ull * K * WAVE * sizeof(double), avail = 160 * 1024 - (size_t)tpar * sizeof(double);
+    const size_t w = avail / tile;
+    return w >= 4 ? 4 : (int)w;
+}
+
+template <int SAMPLER, int TARGET>
+hipError_t launch_group(const GroupParams &gp, hipStream_t stream);
+
+#define PDMP_DEFINE_GROUP_LAUNCHER(S, T)                                                            \
+    template <>                                                                                     \
+    hipError_t launch_group<S, T>(const GroupParams &gp, hipStream_t stream) {                      \
+        const int cpw = WAVE / gp.G, wpb = group_waves_per_block(gp.K, gp.tpar);                    \
+        if (wpb < 1) return hipErrorInvalidValue;                                                   \
+        const int64_t waves = (gp.s.C + cpw - 1) / cpw;                                             \
+        const dim3 block(WAVE * wpb), grid((unsigned)((waves + wpb - 1) / wpb));                    \
+        const size_t lds = ((size_t)gp.tpar + (size_t)wpb * 2 * gp.K * WAVE) * sizeof(double);      \
+        hipError_t e = hipFuncSetAttribute((const void *)group_kernel<S, T>,                       \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+        if (e != hipSuccess) return e;                                                              \
+        hipLaunchKernelGGL((group_kernel<S, T>), grid, block, lds, stream, gp);                     \
+        return hipGetLastError();                                                                   \
+    }
+
+}  // namespace pdmp

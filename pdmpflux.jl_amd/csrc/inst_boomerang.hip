@@ -1,9 +1,12 @@
 // Explicit instantiations of the skeleton kernel for sampler S_BOOMERANG (one translation unit per sampler so
 // the three compile in parallel).
-#include "skeleton_kernel.hpp"
+#include "group_kernel.hpp"
 
 namespace pdmp {
 PDMP_DEFINE_LAUNCHER(S_BOOMERANG, T_GAUSS_ISO)
 PDMP_DEFINE_LAUNCHER(S_BOOMERANG, T_GAUSS_DIAG)
 PDMP_DEFINE_LAUNCHER(S_BOOMERANG, T_BANANA)
+PDMP_DEFINE_GROUP_LAUNCHER(S_BOOMERANG, T_GAUSS_ISO)
+PDMP_DEFINE_GROUP_LAUNCHER(S_BOOMERANG, T_GAUSS_DIAG)
+PDMP_DEFINE_GROUP_LAUNCHER(S_BOOMERANG, T_BANANA)
 }  // namespace pdmp

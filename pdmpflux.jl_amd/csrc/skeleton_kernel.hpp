@@ -129,6 +129,10 @@ struct Chain {
                 a[k] = g[k].v * vt[k].v;
                 if constexpr (SAMPLER == S_BOOMERANG) b[k] = g[k].e * vt[k].v + g[k].v * vt[k].e;
                 else b[k] = g[k].e * vt[k].v;
+                if constexpr (SAMPLER == S_ZIGZAG) {      // non-vectorized Zig-Zag bounds rate = sum(max.(0,.)), ZigZagSamplers.jl:83-86
+                    b[k] = (0.0 < a[k]) ? b[k] : 0.0;
+                    a[k] = pmax(0.0, a[k]);
+                }
             }
             dv = wave_sum(lane_sum(a));
             de = wave_sum(lane_sum(b));
@@ -137,9 +141,13 @@ struct Chain {
             flow_plain(t, xt, vt);
             tgt.grad(xt, g, lane);
 #pragma unroll
-            for (int k = 0; k < K; ++k) a[k] = g[k] * vt[k];
+            for (int k = 0; k < K; ++k) {
+                a[k] = g[k] * vt[k];
+                if constexpr (SAMPLER == S_ZIGZAG) a[k] = pmax(0.0, a[k]);
+            }
             dv = wave_sum(lane_sum(a));
         }
+        if constexpr (SAMPLER == S_ZIGZAG) { slp = de; return dv; }
         if (p.signed_bound) { slp = de; return dv + p.refresh; }
         slp = (0.0 < dv) ? de : 0.0;
         return pmax(0.0, dv) + p.refresh;

@@ -187,6 +187,11 @@ struct ChainRng {
         c3 = __builtin_amdgcn_readfirstlane((uint32_t)(chain >> 32));
         n = 0; w2 = 0; w3 = 0;
     }
+    __device__ __forceinline__ void init_lane(uint64_t seed, uint64_t chain) {   // per-lane streams (group kernel)
+        k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
+        c2 = (uint32_t)chain; c3 = (uint32_t)(chain >> 32);
+        n = 0; w2 = 0; w3 = 0;
+    }
     __device__ __forceinline__ double uniform() {
         uint32_t lo, hi;
         if ((n & 1) == 0) {

@@ -88,6 +88,11 @@ class AbstractPDMP:
             self._handle = h
         return self._handle
 
+    def group_lanes(self) -> int:
+        """Arithmetic layout of the engine for this configuration (pdmp_get_group_lanes): lanes per chain
+        G of the group kernel, or 0 for the wave-per-chain kernel."""
+        return int(_lib.lib().pdmp_get_group_lanes(self.handle()))
+
     def close(self):
         if self._handle is not None:
             _lib.lib().pdmp_destroy(self._handle)

@@ -19,10 +19,14 @@ def make_pair(P, O, kind, dim, target="iso", arith=None, **kw):
     ctor = {"ZigZag": P.ZigZag, "ZigZagAD": P.ZigZagAD, "BPS": P.BPS, "BPSAD": P.BPSAD,
             "Boomerang": P.Boomerang, "BoomerangAD": P.BoomerangAD}[kind]
     s = ctor(dim, tg, **kw)
+    group = 1
+    if arith is None:                       # match the summation order the engine uses for this configuration
+        G = s.group_lanes()
+        arith, group = (O.ARITH_GROUP, G) if G > 0 else (O.ARITH_WAVE64, 1)
     cfg = O.Config(sampler=s.sampler_id, dim=dim, grid_size=s.grid_size, tmax=s.tmax, refresh_rate=s.refresh_rate,
                    vectorized_bound=s.vectorized_bound, signed_bound=s.signed_bound, adaptive=s.adaptive,
                    gaussian_velocity=s.gaussian_velocity, deriv_mode=s.deriv_mode, target_id=tid,
-                   target_params=params, arith=O.ARITH_WAVE64 if arith is None else arith)
+                   target_params=params, arith=arith, group_lanes=group)
     return s, cfg
 
 

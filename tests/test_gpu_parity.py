@@ -68,6 +68,30 @@ def test_skeleton_bitwise(engine, oracle, kind, dim, target, chains, n_sk, kw):
     assert_bitwise(got, ref)
 
 
+@pytest.mark.parametrize("G", [0, 1, 2, 4, 8, 16, 32, 64])
+@pytest.mark.parametrize("kind,dim,target", [("ZigZagAD", 50, "iso"), ("ZigZagAD", 37, "banana"), ("BPS", 50, "banana"),
+                                             ("BoomerangAD", 24, "diag"), ("ZigZagAD", 3, "diag")])
+def test_group_layouts_bitwise(engine, oracle, monkeypatch, G, kind, dim, target):
+    """Every lanes-per-chain layout of the group kernel (and G=0: the wave kernel) against the oracle run
+    in the same GROUP(G) summation order; 70 chains so that waves are ragged for every G."""
+    monkeypatch.setenv("PDMP_GROUP_LANES", str(G))
+    kw = {"refresh_rate": 0.1} if kind == "BoomerangAD" else {}
+    s, cfg, got, ref = run_pair(engine, oracle, kind, dim, target, 70, 120, **kw)
+    assert s.group_lanes() == G
+    assert_bitwise(got, ref)
+
+
+def test_group1_is_reference_order(engine, oracle, monkeypatch):
+    """With one lane per chain the engine's sums run in the reference's own left-to-right order: the
+    result is bit-identical to the reference-order restatement (no tolerance)."""
+    monkeypatch.setenv("PDMP_GROUP_LANES", "1")
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", 50, "iso", arith=oracle.ARITH_REFERENCE)
+    x, v = make_init("ZigZagAD", 50, 40)
+    got = engine.sample_skeleton_ensemble(s, 150, x, v, seed=9)
+    ref = oracle.sample_skeleton(cfg, 150, x, v, 9)
+    assert_bitwise(got, ref)
+
+
 def test_chain_offset_and_sharding_invariance(engine, oracle):
     """Chain c of a shard starting at offset o equals chain o+c of the full ensemble (multi-GPU contract)."""
     s, cfg = make_pair(engine, oracle, "ZigZagAD", 50, "iso")
