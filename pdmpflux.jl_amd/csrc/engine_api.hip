@@ -38,7 +38,11 @@ struct pdmp_engine {
     int group_lanes = 0;              // 0: wave-per-chain kernel; else lanes per chain of the group kernel
     int device = 0;
     double *d_tparams = nullptr;
-    int32_t *d_status = nullptr;      // [0] itercap chains, [1] guard events
+    int32_t *d_status = nullptr;      // [0] itercap chains, [1] guard events, [2] lost hand-offs, [3] spare
+    int32_t *d_sched = nullptr;       // group kernel: [0] unit counter, [1..nb] per-batch progress
+    size_t sched_cap = 0;
+    double *d_state = nullptr;        // group kernel: per-chain hand-off state (2d+4 doubles)
+    size_t state_cap = 0;
     hipStream_t last_stream = nullptr;
     std::vector<EventPair> pending;   // launches not yet folded into `timing`
     std::vector<EventPair> pool;
@@ -233,8 +237,8 @@ int pdmp_create(const pdmp_config_t *cfg, pdmp_handle *out) {
         HIP_TRY(hipMalloc(&h->d_tparams, (size_t)c.n_target_params * 8));
         HIP_TRY(hipMemcpy(h->d_tparams, c.target_params, (size_t)c.n_target_params * 8, hipMemcpyHostToDevice));
     }
-    HIP_TRY(hipMalloc(&h->d_status, 2 * sizeof(int32_t)));
-    HIP_TRY(hipMemset(h->d_status, 0, 2 * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&h->d_status, 4 * sizeof(int32_t)));
+    HIP_TRY(hipMemset(h->d_status, 0, 4 * sizeof(int32_t)));
     *out = h;
     return PDMP_OK;
 }
@@ -254,6 +258,8 @@ int pdmp_destroy(pdmp_handle h) {
     for (auto &ev : h->pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     if (h->d_tparams) (void)hipFree(h->d_tparams);
     if (h->d_status) (void)hipFree(h->d_status);
+    if (h->d_sched) (void)hipFree(h->d_sched);
+    if (h->d_state) (void)hipFree(h->d_state);
     delete h;
     return PDMP_OK;
 }
@@ -266,7 +272,7 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
     if (C < 0) return fail(PDMP_ERR_ARGUMENT, "number of chains must be non-negative");
     if (C == 0) return PDMP_OK;
     if (!xinit || !vinit || !X || !V || !t) return fail(PDMP_ERR_ARGUMENT, "null buffer");
-    if ((C + 3) / 4 > 0x7fffffffLL) return fail(PDMP_ERR_UNSUPPORTED, "too many chains for one launch");
+    if ((C + 3) / 4 > 0x7fffffffLL || C * (n_sk / 16 + 1) > 0x7fffffffLL) return fail(PDMP_ERR_UNSUPPORTED, "too many chains x events for one launch");
     HIP_TRY(hipSetDevice(h->device));
     SkelParams p;
     memset(&p, 0, sizeof p);
@@ -283,18 +289,35 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
     }
     p.status = h->d_status;
     hipStream_t s = (hipStream_t)stream;
-    EventPair ev;
-    if (int rc = begin_timed(h, s, ev)) return rc;
+    GroupParams gp;
+    memset(&gp, 0, sizeof gp);
     if (h->group_lanes > 0) {
-        GroupParams gp;
         gp.s = p;
         gp.G = h->group_lanes;
         gp.K = (c.dim + gp.G - 1) / gp.G;
         gp.tpar = (c.target_id == PDMP_T_GAUSS_DIAG) ? 2 * c.dim : 0;
-        HIP_TRY(pick_group_launcher(c.sampler, c.target_id)(gp, s));
-    } else {
-        HIP_TRY(pick_launcher(c.sampler, c.target_id)(p, s));
+        const int64_t nb = (C + WAVE / gp.G - 1) / (WAVE / gp.G);
+        const size_t need_sched = (size_t)nb + 1, need_state = (size_t)C * (size_t)(2 * c.dim + 4);
+        if (need_sched > h->sched_cap) {
+            if (h->d_sched) { HIP_TRY(hipStreamSynchronize(h->last_stream)); HIP_TRY(hipFree(h->d_sched)); h->d_sched = nullptr; h->sched_cap = 0; }
+            HIP_TRY(hipMalloc(&h->d_sched, need_sched * sizeof(int32_t)));
+            h->sched_cap = need_sched;
+        }
+        if (need_state > h->state_cap) {
+            if (h->d_state) { HIP_TRY(hipStreamSynchronize(h->last_stream)); HIP_TRY(hipFree(h->d_state)); h->d_state = nullptr; h->state_cap = 0; }
+            HIP_TRY(hipMalloc(&h->d_state, need_state * sizeof(double)));
+            h->state_cap = need_state;
+        }
+        HIP_TRY(hipMemsetAsync(h->d_sched, 0, need_sched * sizeof(int32_t), s));
+        if (const char *e = getenv("PDMP_FORCE_SEGMENTS")) gp.nseg = atoi(e);   // test hook, see group_schedule
+        gp.ctr = h->d_sched;
+        gp.progress = h->d_sched + 1;
+        gp.state = h->d_state;
     }
+    EventPair ev;
+    if (int rc = begin_timed(h, s, ev)) return rc;
+    if (h->group_lanes > 0) HIP_TRY(pick_group_launcher(c.sampler, c.target_id)(gp, s));
+    else HIP_TRY(pick_launcher(c.sampler, c.target_id)(p, s));
     return end_timed(h, s, ev);
 }
 
@@ -302,10 +325,11 @@ int pdmp_check_status(pdmp_handle h, int64_t *n_guard) {
     if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->last_stream));
-    int32_t st[2] = {0, 0};
+    int32_t st[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpy(st, h->d_status, sizeof st, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(h->d_status, 0, sizeof st));
     if (n_guard) *n_guard = st[1];
+    if (st[2] > 0) return fail(PDMP_ERR_RUNTIME, "%d work unit(s) lost their predecessor's hand-off", st[2]);
     if (st[0] > 0) return fail(PDMP_ERR_ITERCAP, "%d chain(s) hit the per-event iteration cap (%lld)", st[0],
                                (long long)h->cfg.max_iter_per_event);
     return PDMP_OK;

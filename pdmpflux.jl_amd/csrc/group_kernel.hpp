@@ -34,6 +34,13 @@ struct GroupParams {
     int32_t G;            // lanes per chain (power of two, 1..64)
     int32_t K;            // coordinate slots per lane = ceil(d / G)
     int32_t tpar;         // doubles of target parameters staged in LDS (0 or 2d)
+    // dynamic schedule: work unit u = (batch b = u % nb of 64/G chains, segment r = u / nb of seg_len events)
+    int32_t nseg;         // segments per chain
+    int64_t nb;           // batches = ceil(C / (64/G))
+    int64_t seg_len;      // events per segment
+    int32_t *ctr;         // unit counter (zeroed before the launch)
+    int32_t *progress;    // progress[b] = segments of batch b completed (zeroed before the launch)
+    double *state;        // per chain: x[d], v[d], t, horizon, ar, rng counter  (stride 2d+4 doubles)
 };
 
 // ---------------------------------------------------------------- group-of-lanes primitives (G uniform)
@@ -169,6 +176,9 @@ struct GroupChain {
     }
 
     // ---- upper_bound_grid_vect, UpperBound.jl:203-247
+    // Padded coordinates (i >= d) hold x = v = 0, so their val = slope = 0 and cell = max(0,0,0,0) = 0:
+    // they add exact zeros and need no mask; their parameter index is clamped so grad stays finite.
+    template <bool SIGNED>
     __device__ __forceinline__ void bound_vect(double harg, GBound &B) const {
         const double h = harg / (double)(GNG - 1);
         TimePt tp[GNG];
@@ -181,20 +191,19 @@ struct GroupChain {
         double box[GNG - 1], cum[GNG - 1];
 #pragma unroll
         for (int j = 0; j < GNG - 1; ++j) { box[j] = 0.0; cum[j] = 0.0; }
-        const bool sgn = p.signed_bound != 0;
         for (int s = 0; s < K; ++s) {
             const int i = s * G + g;
-            const bool valid = i < p.d;
+            const int ip = (i < p.d) ? i : 0;
             const double x = X(s), v = V(s);
             double val[GNG], slp[GNG];
 #pragma unroll
             for (int j = 0; j < GNG; ++j) {                           // :208-210
                 Dual xt, vt;
                 flow(x, v, tp[j], xt, vt);
-                const Dual gd = tgt.grad(i, xt, sh[j]);
+                const Dual gd = tgt.grad(ip, xt, sh[j]);
                 const double sv = gd.v * vt.v, sd = sdot(gd, vt);
-                val[j] = sgn ? sv : fmax(0.0, sv);
-                slp[j] = sgn ? sd : ((0.0 < sv) ? sd : 0.0);
+                val[j] = SIGNED ? sv : fmax(0.0, sv);
+                slp[j] = SIGNED ? sd : ((0.0 < sv) ? sd : 0.0);
             }
             double num[GNG - 1], den[GNG - 1];
             bool nz = false;
@@ -210,8 +219,7 @@ struct GroupChain {
             for (int j = 0; j < GNG - 1; ++j) {
                 const double q = cell_q(num[j], den[j], h, fast);      // :234-235
                 const double inter = val[j] + slp[j] * q;             // :237
-                double cell = fmax(fmax(fmax(val[j], val[j + 1]), inter), 0.0);   // :239-241
-                cell = valid ? cell : 0.0;
+                const double cell = fmax(fmax(fmax(val[j], val[j + 1]), inter), 0.0);   // :239-241
                 box[j] += cell;                                       // sum(box_max, dims=1), :246
                 run += cell;                                          // cumsum(box_max, dims=2), :244
                 cum[j] += run * h;
@@ -278,7 +286,10 @@ struct GroupChain {
     }
     __device__ __forceinline__ void upper_bound(double harg, GBound &B) const {
         if constexpr (SAMPLER == S_ZIGZAG) {
-            if (p.vectorized) { bound_vect(harg, B); return; }
+            if (p.vectorized) {
+                if (p.signed_bound) bound_vect<true>(harg, B); else bound_vect<false>(harg, B);
+                return;
+            }
         }
         bound_scalar(harg, B);
     }
@@ -450,17 +461,36 @@ struct GroupChain {
         }
     }
 
-    // ---- sample_skeleton for the chains of this wave
-    __device__ __forceinline__ void run(int64_t c, bool chain_ok) {
+    // ---- sample_skeleton (sample.jl:253-284) for the chains of this wave, events of segment r.
+    // Segments end right after an accepted event, where the thinning state is just
+    // (x, v, t, horizon, ar, rng counter): every other field of PDMPState is reset or rebuilt
+    // (SamplingLoopInplace.jl:28-31,69-76,181-183), so the hand-off between segments is 2d+4 doubles.
+    __device__ __forceinline__ void run_segment(int64_t c, bool chain_ok, int r, int64_t seg_len, double *state) {
         const int d = p.d;
+        const int64_t k_begin = 1 + (int64_t)r * seg_len;
+        int64_t k_end = k_begin + seg_len;
+        if (k_end > p.n_sk) k_end = p.n_sk;
+        double *st = state + (size_t)(chain_ok ? c : 0) * (size_t)(2 * d + 4);
+        double t = 0.0, horizon = p.tmax, ar = 0.0;
+        uint64_t n0 = 0;
+        if (r > 0 && chain_ok) {
+            t = st[2 * d]; horizon = st[2 * d + 1]; ar = st[2 * d + 2];
+            n0 = (uint64_t)__double_as_longlong(st[2 * d + 3]);
+        }
         for (int s = 0; s < K; ++s) {
             const int i = s * G + g;
             const bool ok = chain_ok && i < d;
-            X(s) = ok ? p.xinit[(size_t)c * d + i] : 0.0;                // copies: inputs are never mutated (Q7)
-            V(s) = ok ? p.vinit[(size_t)c * d + i] : 0.0;
+            if (r == 0) {
+                X(s) = ok ? p.xinit[(size_t)c * d + i] : 0.0;            // copies: inputs are never mutated (Q7)
+                V(s) = ok ? p.vinit[(size_t)c * d + i] : 0.0;
+            } else {
+                X(s) = ok ? st[i] : 0.0;
+                V(s) = ok ? st[d + i] : 0.0;
+            }
         }
         rng.init_lane(p.seed, (uint64_t)(p.chain0 + c));
-        double t = 0.0, horizon = p.tmax, ts = 0.0, tp = 0.0, E = 0.0, lb = 0.0, ar = 0.0;
+        rng.restore(n0);
+        double ts = 0.0, tp = 0.0, E = 0.0, lb = 0.0;
         int32_t errored = 0, rejected = 0, hits = 0;
         double ev[5] = {0, 0, 0, 0, 0};
         const bool adaptive = p.adaptive != 0;
@@ -469,9 +499,9 @@ struct GroupChain {
         for (int j = 0; j < GNG - 1; ++j) { B.box[j] = 0.0; B.cum[j] = 0.0; }
         B.h = 0.0;
         bool done = !chain_ok;
-        if (!done) record(c, 0, t, horizon, ar, 0, ev, 0, 0);             // sample.jl:272
-        int64_t k = 1, it = 0;
-        if (p.n_sk <= 1) done = true;
+        if (!done && r == 0) record(c, 0, t, horizon, ar, 0, ev, 0, 0);   // sample.jl:272
+        int64_t k = k_begin, it = 0;
+        if (k >= k_end) done = true;
         bool propose = false, err_pending = false;
         while (__ballot(!done) != 0ull) {
             if (!done && !propose) {
@@ -517,7 +547,7 @@ struct GroupChain {
 #pragma unroll
                         for (int q = 0; q < 5; ++q) ev[q] = 0.0;
                         it = 0;
-                        if (++k >= p.n_sk) done = true;
+                        if (++k >= k_end) done = true;
                         propose = false;
                     } else {                                              // if_reject!, :188-203
                         E = E + rng.exponential();
@@ -535,25 +565,68 @@ struct GroupChain {
                 if (++it > p.cap && !done) { done = true; if (g == 0) atomicAdd(&p.status[0], 1); }
             }
         }
-        if (guard && g == 0) atomicAdd(&p.status[1], guard);
+        if (chain_ok) {                                                   // hand-off / final state
+            for (int s = 0; s < K; ++s) {
+                const int i = s * G + g;
+                if (i < d) { st[i] = X(s); st[d + i] = V(s); }
+            }
+            if (g == 0) {
+                st[2 * d] = t; st[2 * d + 1] = horizon; st[2 * d + 2] = ar;
+                st[2 * d + 3] = __longlong_as_double((long long)rng.n);
+            }
+        }
+        if (guard && g == 0) { atomicAdd(&p.status[1], guard); guard = 0; }
     }
 };
+
+// Persistent waves pull work units from one device-wide counter (price: one returning atomic per
+// unit, MI355X_MICROARCH.md row "dequeue").  Unit (b, r) continues unit (b, r-1), pulled nb units
+// earlier by a wave that is resident and waits only on still older units, so the wait below is
+// satisfied on arrival in practice and can never deadlock; it is bounded all the same.
+// Hand-off protocol (cdna_hip_programming.md Guideline 16): plain stores -> agent-scope release fence
+// -> s_waitcnt vmcnt(0) -> relaxed agent flag store;  relaxed poll -> agent-scope acquire -> plain loads.
+// Bounded wait for progress[b] >= r (relaxed agent-scope poll + s_sleep), then the agent-scope acquire.
+__device__ __noinline__ bool wait_progress(const int32_t *flag, int r) {
+    bool ok = false;
+    for (int spins = 0; spins < (1 << 22) && !ok; ++spins) {
+        ok = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= r;
+        if (!ok) __builtin_amdgcn_s_sleep(64);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return ok;
+}
 
 template <int SAMPLER, int TARGET>
 __global__ __launch_bounds__(256) void group_kernel(const GroupParams gp) {
     extern __shared__ double smem[];
     const int lane = lane_id();
-    const int wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int wave = threadIdx.x >> 6;
     // target parameters (mu, prec) once per block
     for (int q = threadIdx.x; q < gp.tpar; q += blockDim.x) smem[q] = gp.s.tparams[q];
     __syncthreads();
     double *tile = smem + gp.tpar + (size_t)wave * 2 * gp.K * WAVE;
     const int cpw = WAVE / gp.G;
-    const int64_t wave_global = (int64_t)blockIdx.x * wpb + wave;
-    const int64_t c = wave_global * cpw + lane / gp.G;
     GroupChain<SAMPLER, TARGET> chain(gp, lane, tile, tile + gp.K * WAVE);
     chain.tgt.init(smem, gp.s.d);
-    chain.run(c, c < gp.s.C);
+    const int nb = (int)gp.nb, n_units = nb * gp.nseg;            // host guarantees nb * nseg < 2^31
+    bool lost = false;
+    for (int pulled = 0; pulled <= n_units && !lost; ++pulled) {  // a wave can never pull more than n_units units
+        int u = 0;
+        if (lane == 0) u = atomicAdd(gp.ctr, 1);
+        u = __builtin_amdgcn_readfirstlane(u);
+        if (u >= n_units) break;
+        const int r = u / nb, b = u - r * nb;
+        if (r > 0) lost = !wait_progress(gp.progress + b, r);
+        if (!lost) {
+            const int64_t c = (int64_t)b * cpw + lane / gp.G;
+            chain.run_segment(c, c < gp.s.C, r, gp.seg_len, gp.state);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&gp.progress[b], r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (lost && lane == 0) atomicAdd(&gp.s.status[2], 1);         // predecessor lost: report, never hang
 }
 
 // waves per block: as many (up to 4) as fit the CU's 160 KiB of LDS next to the staged parameters
@@ -563,21 +636,53 @@ inline int group_waves_per_block(int K, int tpar) {
     return w >= 4 ? 4 : (int)w;
 }
 
+// Segments per chain: enough units for ~32 rounds over the resident wave slots (tail <= ~3 %), at least
+// 16 events per segment (hand-off = 2d+4 doubles per chain), one segment when the machine is not full.
+inline void group_schedule(int64_t nb, int64_t slots, int64_t n_sk, int force, int32_t &nseg, int64_t &seg_len) {
+    const int64_t events = n_sk > 1 ? n_sk - 1 : 1;
+    int64_t want = nb > slots ? (32 * slots + nb - 1) / nb : 1;
+    if (force > 0) {                       // test hook (PDMP_FORCE_SEGMENTS): exercise the hand-off on small ensembles
+        want = force < events ? force : events;
+        seg_len = (events + want - 1) / want;
+        nseg = (int32_t)((events + seg_len - 1) / seg_len);
+        return;
+    }
+    const int64_t max_seg = events / 16 > 0 ? events / 16 : 1;
+    if (want > max_seg) want = max_seg;
+    if (want < 1) want = 1;
+    seg_len = (events + want - 1) / want;
+    nseg = (int32_t)((events + seg_len - 1) / seg_len);
+}
+
 template <int SAMPLER, int TARGET>
 hipError_t launch_group(const GroupParams &gp, hipStream_t stream);
 
+// Fills the schedule fields of gp (nb, nseg, seg_len) and returns the launch geometry.
+struct GroupLaunch { int wpb; unsigned grid; size_t lds; };
+
 #define PDMP_DEFINE_GROUP_LAUNCHER(S, T)                                                            \
     template <>                                                                                     \
-    hipError_t launch_group<S, T>(const GroupParams &gp, hipStream_t stream) {                      \
+    hipError_t launch_group<S, T>(const GroupParams &gp_in, hipStream_t stream) {                   \
+        GroupParams gp = gp_in;                                                                     \
         const int cpw = WAVE / gp.G, wpb = group_waves_per_block(gp.K, gp.tpar);                    \
         if (wpb < 1) return hipErrorInvalidValue;                                                   \
-        const int64_t waves = (gp.s.C + cpw - 1) / cpw;                                             \
-        const dim3 block(WAVE * wpb), grid((unsigned)((waves + wpb - 1) / wpb));                    \
         const size_t lds = ((size_t)gp.tpar + (size_t)wpb * 2 * gp.K * WAVE) * sizeof(double);      \
         hipError_t e = hipFuncSetAttribute((const void *)group_kernel<S, T>,                       \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
         if (e != hipSuccess) return e;                                                              \
-        hipLaunchKernelGGL((group_kernel<S, T>), grid, block, lds, stream, gp);                     \
+        int per_cu = 0, dev = 0, cus = 0;                                                           \
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, group_kernel<S, T>, WAVE * wpb, lds); \
+        if (e != hipSuccess) return e;                                                              \
+        (void)hipGetDevice(&dev);                                                                   \
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);              \
+        if (per_cu < 1) per_cu = 1;                                                                 \
+        if (cus < 1) cus = 256;                                                                     \
+        gp.nb = (gp.s.C + cpw - 1) / cpw;                                                           \
+        const int64_t slots = (int64_t)cus * per_cu * wpb;                                          \
+        group_schedule(gp.nb, slots, gp.s.n_sk, gp.nseg, gp.nseg, gp.seg_len);                               \
+        int64_t blocks = (gp.nb + wpb - 1) / wpb;                                                   \
+        if (blocks > (int64_t)cus * per_cu) blocks = (int64_t)cus * per_cu;                         \
+        hipLaunchKernelGGL((group_kernel<S, T>), dim3((unsigned)blocks), dim3(WAVE * wpb), lds, stream, gp); \
         return hipGetLastError();                                                                   \
     }
 

@@ -25,7 +25,7 @@ struct SkelParams {
     const double *xinit, *vinit, *tparams;
     double *X, *V, *t, *H, *AR, *EV;
     int32_t *EB, *RJ, *HH;
-    int32_t *status;   // [0] chains that hit the iteration cap, [1] Q11 guard events
+    int32_t *status;   // [0] chains that hit the iteration cap, [1] Q11 guard events, [2] lost hand-offs
 };
 
 __device__ __forceinline__ bool uni(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }

@@ -192,6 +192,16 @@ struct ChainRng {
         c2 = (uint32_t)chain; c3 = (uint32_t)(chain >> 32);
         n = 0; w2 = 0; w3 = 0;
     }
+    // resume at variate counter n0: an odd counter needs the second half of its block again
+    __device__ __forceinline__ void restore(uint64_t n0) {
+        n = n0;
+        if (n0 & 1) {
+            uint32_t w[4];
+            const uint64_t blk = n0 >> 1;
+            philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), c2, c3, k0, k1, w);
+            w2 = w[2]; w3 = w[3];
+        }
+    }
     __device__ __forceinline__ double uniform() {
         uint32_t lo, hi;
         if ((n & 1) == 0) {

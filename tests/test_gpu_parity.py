@@ -81,6 +81,36 @@ def test_group_layouts_bitwise(engine, oracle, monkeypatch, G, kind, dim, target
     assert_bitwise(got, ref)
 
 
+@pytest.mark.parametrize("segments", [2, 7, 1000])
+@pytest.mark.parametrize("kind,dim,target", [("ZigZagAD", 50, "iso"), ("BPS", 50, "banana"), ("BoomerangAD", 10, "iso")])
+def test_segment_handoff_bitwise(engine, oracle, monkeypatch, segments, kind, dim, target):
+    """The dynamic schedule splits a chain's events into segments executed by different waves with a
+    (x, v, t, horizon, ar, rng counter) hand-off through HBM; forcing 2 / 7 / one-event segments on a small
+    ensemble must not change a single bit."""
+    monkeypatch.setenv("PDMP_FORCE_SEGMENTS", str(segments))
+    kw = {"refresh_rate": 0.1} if kind == "BoomerangAD" else {}
+    _, _, got, ref = run_pair(engine, oracle, kind, dim, target, 70, 90, **kw)
+    assert_bitwise(got, ref)
+
+
+def test_full_machine_schedule_bitwise(engine, oracle):
+    """More batches than resident wave slots (40 000 chains -> 2 500 batches of 16): the persistent
+    kernel really schedules several segments per chain across waves; a strided sample of chains must
+    equal the oracle bit for bit, and every chain must satisfy the path's invariants."""
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", 50, "iso")
+    x, v = make_init("ZigZagAD", 50, 40000)
+    got = engine.sample_skeleton_ensemble(s, 64, x, v, seed=77, diagnostics=False)
+    idx = np.arange(0, 40000, 797)
+    ref = oracle.sample_skeleton(cfg, 64, x[idx], v[idx], 77, diagnostics=False)
+    # chain ids are global: chain idx[j] of the big run uses stream (seed, idx[j])
+    for j, c in enumerate(idx):
+        r1 = oracle.sample_skeleton(cfg, 64, x[c:c + 1], v[c:c + 1], 77, chain_id_offset=int(c), diagnostics=False)
+        for k in ("X", "V", "t"):
+            assert np.array_equal(got[k][c], r1[k][0]), (k, c)
+    assert (np.diff(got["t"], axis=1) > 0).all()                                  # test_comprehensive.jl:147
+    assert np.abs(np.linalg.norm(got["V"], axis=2) - np.sqrt(50)).max() < 1e-12   # :172-180 speed conservation
+
+
 def test_group1_is_reference_order(engine, oracle, monkeypatch):
     """With one lane per chain the engine's sums run in the reference's own left-to-right order: the
     result is bit-identical to the reference-order restatement (no tolerance)."""
