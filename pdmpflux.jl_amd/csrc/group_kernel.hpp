@@ -598,7 +598,7 @@ __device__ __noinline__ bool wait_progress(const int32_t *flag, int r) {
 }
 
 template <int SAMPLER, int TARGET>
-__global__ __launch_bounds__(256) void group_kernel(const GroupParams gp) {
+__global__ __launch_bounds__(256, 3) void group_kernel(const GroupParams gp) {
     extern __shared__ double smem[];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;

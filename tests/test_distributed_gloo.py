@@ -1,0 +1,78 @@
+"""Multi-GPU path on CPU: world_size 2 over gloo.  The sharding / gather logic of
+pdmpflux.jl_amd.ensemble.sample_skeleton_sharded is the product code; the per-shard compute is injected
+(tests only) with the CPU oracle because this container has no GPU.  The contract checked: chains are
+partitioned into contiguous ranges, keyed by GLOBAL chain id, and every gather mode reassembles exactly the
+single-process result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+D, C_TOTAL, N_SK, N_SMP, SEED = 6, 7, 30, 11, 99          # 7 chains over 2 ranks: ragged shards (4 + 3)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _inputs():
+    rs = np.random.default_rng(4)
+    return rs.normal(size=(C_TOTAL, D)), rs.choice([-1.0, 1.0], size=(C_TOTAL, D))
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pdmpflux.jl_amd as P
+    from pdmpflux.jl_amd import ensemble
+    from oracle import oracle as O
+    cfg = O.Config(sampler=O.ZIGZAG, dim=D)
+    sampler = P.ZigZagAD(D, P.GaussianIso())
+
+    def compute(xs, vs, chain0):            # stand-in for the HIP engine (tests only)
+        r = O.sample_skeleton(cfg, N_SK, xs.numpy(), vs.numpy(), SEED, chain_id_offset=chain0, diagnostics=False)
+        smp = O.sample_from_skeleton(cfg, N_SMP, r["X"], r["V"], r["t"])
+        out = {k: torch.from_numpy(v) for k, v in r.items()}
+        out["samples"] = torch.from_numpy(smp)
+        return out
+
+    x, v = _inputs()
+    x, v = torch.from_numpy(x), torch.from_numpy(v)
+    res = {}
+    for mode in ("none", "skeleton", "samples", "moments"):
+        r = ensemble.sample_skeleton_sharded(sampler, N_SK, x, v, seed=SEED, gather=mode, N_samples=N_SMP, compute=compute)
+        res[mode] = {k: (val.numpy() if torch.is_tensor(val) else val) for k, val in r.items()}
+    np.save(os.path.join(outdir, f"rank{rank}.npy"), np.array([res], dtype=object), allow_pickle=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_ensemble_world2(tmp_path, oracle):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    x, v = _inputs()
+    cfg = oracle.Config(sampler=oracle.ZIGZAG, dim=D)
+    full = oracle.sample_skeleton(cfg, N_SK, x, v, SEED, diagnostics=False)
+    full_s = oracle.sample_from_skeleton(cfg, N_SMP, full["X"], full["V"], full["t"])
+    from pdmpflux.jl_amd.ensemble import shard_range
+    for rank in range(world):
+        res = np.load(os.path.join(str(tmp_path), f"rank{rank}.npy"), allow_pickle=True)[0]
+        lo, hi = shard_range(C_TOTAL, rank, world)
+        assert res["none"]["chain_range"] == (lo, hi)
+        for k in ("X", "V", "t"):
+            assert np.array_equal(res["none"][k], full[k][lo:hi]), (rank, k)           # shard = slice of the global run
+            assert np.array_equal(res["skeleton"][k], full[k]), (rank, k)              # all-gather: everyone has everything
+        assert np.array_equal(res["samples"]["samples"], full_s)
+        flat = full_s.reshape(-1, D)
+        np.testing.assert_allclose(res["moments"]["mean"], flat.mean(0), rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(res["moments"]["var"], flat.var(0), rtol=1e-10)
+        assert res["moments"]["count"] == flat.shape[0]

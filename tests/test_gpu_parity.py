@@ -48,6 +48,9 @@ CASES = [
     ("ZigZagAD", 50, "iso", 8, 200, {"grid_size": 5}),
     ("ZigZagAD", 50, "banana", 8, 200, {"grid_size": 20}),
     ("ZigZagAD", 50, "iso", 8, 100, {"tmax": 0}),   # tmax = 0 -> 1.0 + adaptive
+    ("ZigZagAD", 2, "banana", 8, 1500, {"tmax": 20.0, "adaptive": False}),     # forces ar > 1 (error path), group kernel
+    ("ZigZagAD", 2, "banana", 8, 1500, {"tmax": 2.0, "adaptive": False, "grid_size": 2}),   # same in the wave kernel
+    ("BPS", 2, "banana", 8, 1500, {"tmax": 20.0, "adaptive": False}),
     ("BPS", 50, "banana", 16, 300, {}),
     ("BPS", 50, "iso", 8, 300, {}),
     ("BPS", 100, "diag", 4, 150, {}),
@@ -66,6 +69,8 @@ CASES = [
 def test_skeleton_bitwise(engine, oracle, kind, dim, target, chains, n_sk, kw):
     _, _, got, ref = run_pair(engine, oracle, kind, dim, target, chains, n_sk, **kw)
     assert_bitwise(got, ref)
+    if kw.get("adaptive") is False and kw.get("tmax", 0) >= 2.0 and target == "banana":
+        assert ref["errored_bound"].sum() > 10      # the rare branch really ran (and matched bit for bit)
 
 
 @pytest.mark.parametrize("G", [0, 1, 2, 4, 8, 16, 32, 64])
@@ -101,7 +106,6 @@ def test_full_machine_schedule_bitwise(engine, oracle):
     x, v = make_init("ZigZagAD", 50, 40000)
     got = engine.sample_skeleton_ensemble(s, 64, x, v, seed=77, diagnostics=False)
     idx = np.arange(0, 40000, 797)
-    ref = oracle.sample_skeleton(cfg, 64, x[idx], v[idx], 77, diagnostics=False)
     # chain ids are global: chain idx[j] of the big run uses stream (seed, idx[j])
     for j, c in enumerate(idx):
         r1 = oracle.sample_skeleton(cfg, 64, x[c:c + 1], v[c:c + 1], 77, chain_id_offset=int(c), diagnostics=False)
