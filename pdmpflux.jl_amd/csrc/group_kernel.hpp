@@ -205,19 +205,15 @@ struct GroupChain {
                 val[j] = SIGNED ? sv : fmax(0.0, sv);
                 slp[j] = SIGNED ? sd : ((0.0 < sv) ? sd : 0.0);
             }
-            double num[GNG - 1], den[GNG - 1];
             bool nz = false;
 #pragma unroll
-            for (int j = 0; j < GNG - 1; ++j) {                       // :229
-                num[j] = ((val[j] - val[j + 1]) + slp[j + 1] * tp[j + 1].t) - slp[j] * tp[j].t;
-                den[j] = slp[j + 1] - slp[j];
-                nz = nz || (den[j] != 0.0);
-            }
+            for (int j = 0; j < GNG - 1; ++j) nz = nz || (slp[j + 1] != slp[j]);   // any tangent pair that really intersects?
             const bool fast = __ballot(nz) == 0ull;                   // wave-uniform
             double run = 0.0;
 #pragma unroll
             for (int j = 0; j < GNG - 1; ++j) {
-                const double q = cell_q(num[j], den[j], h, fast);      // :234-235
+                const double num = ((val[j] - val[j + 1]) + slp[j + 1] * tp[j + 1].t) - slp[j] * tp[j].t;   // :229
+                const double q = cell_q(num, slp[j + 1] - slp[j], h, fast);   // :234-235
                 const double inter = val[j] + slp[j] * q;             // :237
                 const double cell = fmax(fmax(fmax(val[j], val[j + 1]), inter), 0.0);   // :239-241
                 box[j] += cell;                                       // sum(box_max, dims=1), :246
@@ -494,30 +490,45 @@ struct GroupChain {
         int32_t errored = 0, rejected = 0, hits = 0;
         double ev[5] = {0, 0, 0, 0, 0};
         const bool adaptive = p.adaptive != 0;
-        GBound B;
-#pragma unroll
-        for (int j = 0; j < GNG - 1; ++j) { B.box[j] = 0.0; B.cum[j] = 0.0; }
-        B.h = 0.0;
         bool done = !chain_ok;
         if (!done && r == 0) record(c, 0, t, horizon, ar, 0, ev, 0, 0);   // sample.jl:272
         int64_t k = k_begin, it = 0;
         if (k >= k_end) done = true;
-        bool propose = false, err_pending = false;
+        // Per-lane phase: BOUND (mode FRESH / ERR / REUSE) or PROPOSE.  The BoundBox is never kept across
+        // loop iterations: after a rejection the reference re-inverts the SAME bound with a larger
+        // exponential (if_reject!, :188-203; Q4); x, v and the horizon the bound was built for (hB) are
+        // unchanged since it was built, so rebuilding it gives the same bits and frees its 38 registers
+        // (3 waves per SIMD instead of 2 for ~4 % more bound evaluations).
+        enum : int { FRESH = 0, ERR = 1, REUSE = 2 };
+        bool propose = false;
+        int mode = FRESH;
+        double hB = horizon;
         while (__ballot(!done) != 0ull) {
             if (!done && !propose) {
-                // one_step_of_thinning! (:65-85) or erroneous_acceptance_rate! (:131-151)
-                const double harg = err_pending ? horizon / 2 : horizon;
+                // one_step_of_thinning! (:65-85), erroneous_acceptance_rate! (:131-151) or if_reject! (:188-203)
+                const double harg = (mode == ERR) ? horizon / 2 : ((mode == REUSE) ? hB : horizon);
+                GBound B;
                 upper_bound(harg, B);
-                E = rng.exponential();
+                hB = harg;
+                const double e1 = rng.exponential();
+                E = (mode == REUSE) ? E + e1 : e1;                        // cumulative only after a rejection (:190)
                 next_event(B, E, tp, lb);
-                if (err_pending) {
+                if (mode == ERR) {
                     if (adaptive) horizon = harg;
                     errored++;
                     const int slot = errored % 5;                         // :148 (1-based errored%5+1)
 #pragma unroll
                     for (int q = 0; q < 5; ++q) if (q == slot) ev[q] = ar;
-                    err_pending = false;
                     propose = tp < horizon;                               // moves_until_horizon! loop test, :106
+                } else if (mode == REUSE) {
+                    if (adaptive) horizon = horizon / 1.04;               // :194
+                    rejected++;
+                    if (tp > horizon) {                                   // move_to_horizon2!, :205-217
+                        flow_state(horizon);
+                        ts += horizon;
+                        hits++;
+                    }
+                    propose = tp < horizon;
                 } else if (tp > horizon) {                                // move_to_horizon!, :87-101
                     flow_state(horizon);
                     ts += horizon;
@@ -526,14 +537,15 @@ struct GroupChain {
                 } else {
                     propose = tp < horizon;                               // tp == horizon: retry (Q6)
                 }
+                mode = FRESH;
                 if (++it > p.cap) { done = true; if (g == 0) atomicAdd(&p.status[0], 1); }
             }
             if (!done && propose) {
                 const double lam = true_rate(tp);                         // ac_step!, :113-129
                 ar = lam / lb;
+                propose = false;
                 if (ar > 1.0) {
-                    err_pending = true;
-                    propose = false;
+                    mode = ERR;
                 } else {                                                  // ac_step_with_proxy!, :153-168
                     const double u = rng.uniform();
                     if (u < ar) {                                         // if_accept!, :170-186
@@ -548,18 +560,8 @@ struct GroupChain {
                         for (int q = 0; q < 5; ++q) ev[q] = 0.0;
                         it = 0;
                         if (++k >= k_end) done = true;
-                        propose = false;
-                    } else {                                              // if_reject!, :188-203
-                        E = E + rng.exponential();
-                        next_event(B, E, tp, lb);
-                        if (adaptive) horizon = horizon / 1.04;
-                        rejected++;
-                        if (tp > horizon) {                               // move_to_horizon2!, :205-217
-                            flow_state(horizon);
-                            ts += horizon;
-                            hits++;
-                        }
-                        propose = tp < horizon;
+                    } else {
+                        mode = REUSE;                                     // if_reject! continues in the BOUND phase
                     }
                 }
                 if (++it > p.cap && !done) { done = true; if (g == 0) atomicAdd(&p.status[0], 1); }
@@ -586,7 +588,7 @@ struct GroupChain {
 // Hand-off protocol (cdna_hip_programming.md Guideline 16): plain stores -> agent-scope release fence
 // -> s_waitcnt vmcnt(0) -> relaxed agent flag store;  relaxed poll -> agent-scope acquire -> plain loads.
 // Bounded wait for progress[b] >= r (relaxed agent-scope poll + s_sleep), then the agent-scope acquire.
-__device__ __noinline__ bool wait_progress(const int32_t *flag, int r) {
+__device__ __forceinline__ bool wait_progress(const int32_t *flag, int r) {
     bool ok = false;
     for (int spins = 0; spins < (1 << 22) && !ok; ++spins) {
         ok = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= r;
@@ -597,8 +599,13 @@ __device__ __noinline__ bool wait_progress(const int32_t *flag, int r) {
     return ok;
 }
 
+// Occupancy target (waves per SIMD).  3 = 168 VGPRs: measured +17 % on config 2 over 2 waves (the kernel is
+// VALU-issue bound and a third wave fills the dependency stalls of the cell arithmetic).  The banana
+// target keeps ten dual "shared" records per bound in registers and would spill heavily under that cap.
+template <int TARGET> struct GroupOcc { static constexpr int kWaves = (TARGET == T_BANANA) ? 2 : 3; };
+
 template <int SAMPLER, int TARGET>
-__global__ __launch_bounds__(256, 3) void group_kernel(const GroupParams gp) {
+__global__ __launch_bounds__(256, GroupOcc<TARGET>::kWaves) void group_kernel(const GroupParams gp) {
     extern __shared__ double smem[];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
