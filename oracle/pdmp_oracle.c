@@ -444,7 +444,7 @@ static void upper_bound(const orc_config_t *cfg, ws_t *w, const double *x, const
                     for (int i = 0; i < d; ++i) slp[i] = (w->fa[i] - w->fb[i]) / (tp - tm); }
             }
         }
-        if (cfg->arith != ORC_ARITH_WAVE64) memset(w->cum, 0, (size_t)n * 8);
+        if (cfg->arith == ORC_ARITH_REFERENCE) memset(w->cum, 0, (size_t)n * 8);
         double *run = w->fa;                       /* per-dimension running cumsum (:243-244) */
         for (int i = 0; i < d; ++i) run[i] = 0.0;
         for (int j = 0; j + 1 < n; ++j) {
@@ -458,12 +458,12 @@ static void upper_bound(const orc_config_t *cfg, ws_t *w, const double *x, const
                 w->cell[i] = pmax(pmax(pmax(v0[i], v1[i]), inter), 0.0); /* :239-241 */
             }
             w->box[j] = vsum(cfg, w->cell, d);                         /* :246 sum(box_max, dims=1) */
-            if (cfg->arith != ORC_ARITH_WAVE64) {
+            if (cfg->arith == ORC_ARITH_REFERENCE) {
                 for (int i = 0; i < d; ++i) { run[i] += w->cell[i]; w->tmp[i] = run[i] * h; }
-                w->cum[j + 1] = vsum(cfg, w->tmp, d);                  /* :244,:246 */
+                w->cum[j + 1] = sum_seq(w->tmp, d);                    /* :244,:246 */
             }
         }
-        if (cfg->arith == ORC_ARITH_WAVE64) {                          /* engine order: cumsum after the sum */
+        if (cfg->arith != ORC_ARITH_REFERENCE) {                       /* engine orders: cumsum after the sum */
             double acc = 0.0; w->cum[0] = 0.0;
             for (int j = 0; j + 1 < n; ++j) { acc += w->box[j]; w->cum[j + 1] = acc * h; }
         }

