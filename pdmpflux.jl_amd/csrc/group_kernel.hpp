@@ -7,10 +7,10 @@
 // next_event / RNG / log work, 14 idle lanes at d = 50.  Here
 //   * coordinate i of a chain lives in LDS slot i/G of lane (i mod G) of the chain's lane group
 //     (conflict-free ds_read_b64: consecutive lanes, consecutive 8-byte words);
-//   * each lane walks its d/G coordinates sequentially and keeps the nine box_max / cum_sum
-//     accumulators of the BoundBox (src/Composites.jl:15-20) in registers, so a bound costs
-//     18*log2(G) cross-lane adds instead of 54 full-wave ones and the per-chain scalar work is shared
-//     by 64/G chains per instruction;
+//   * each lane walks its d/G coordinates sequentially and accumulates one box_max cell of the
+//     BoundBox (src/Composites.jl:15-20) at a time; cells are built lazily in grid order until the
+//     exponential is covered (bit-identical to the full bound, see bound_invert_vect), so a cell costs
+//     log2(G) cross-lane adds and the per-chain scalar work is shared by 64/G chains per instruction;
 //   * with G = 1 every sum over coordinates runs in exactly the reference's left-to-right order.
 // The thinning state machine (src/SamplingLoopInplace.jl:27-217) is flattened into two phases per
 // lane -- BOUND (one_step_of_thinning! / erroneous_acceptance_rate!) and PROPOSE (ac_step!) -- so the
@@ -103,10 +103,6 @@ template <> struct GTarget<T_BANANA> {          // test/test_config.jl:33-36
     }
 };
 
-struct GBound {                 // BoundBox in registers: box_max[0..8], cum_sum[1..9] (cum_sum[0] = 0)
-    double box[GNG - 1], cum[GNG - 1], h;
-};
-
 template <int SAMPLER, int TARGET>
 struct GroupChain {
     using Tgt = GTarget<TARGET>;
@@ -175,139 +171,130 @@ struct GroupChain {
         return fmin(fmax(num / den, 0.0), h);       // fmax drops NaN: the reference's replace(NaN => 0)
     }
 
-    // ---- upper_bound_grid_vect, UpperBound.jl:203-247
-    // Padded coordinates (i >= d) hold x = v = 0, so their val = slope = 0 and cell = max(0,0,0,0) = 0:
-    // they add exact zeros and need no mask; their parameter index is clamped so grad stays finite.
+    // ---- Bound + inversion, fused and LAZY.
+    // next_event (UpperBound.jl:264-273) only reads cum_sum up to the first cell with cum_sum >= E and that
+    // cell's box_max, so the cells of upper_bound_grid_vect / upper_bound_grid (:203-247 / :92-137) are built
+    // in grid order and the loop stops as soon as every chain of the wave has found its cell.  Each cell is
+    // computed with exactly the arithmetic of the full bound, so (tp, lambda_bar) are bit-identical to
+    // building all n-1 cells; with the adaptive horizon several times the typical event time, two or
+    // three cells out of nine are built on average.  E is drawn before the bound (the bound consumes
+    // no random numbers, so the stream position is the reference's).
+    // Padded coordinates (i >= d) hold x = v = 0: val = slope = 0, cell = max(0,0,0,0) = 0, no mask needed;
+    // their parameter index is clamped so grad stays finite.
     template <bool SIGNED>
-    __device__ __forceinline__ void bound_vect(double harg, GBound &B) const {
+    __device__ __forceinline__ void eval_vect(int ip, double x, double v, const TimePt &tp,
+                                              const typename Tgt::template Sh<Dual> &sh, double &val, double &slp) const {
+        Dual xt, vt;                                                  // :208-210
+        flow(x, v, tp, xt, vt);
+        const Dual gd = tgt.grad(ip, xt, sh);
+        const double sv = gd.v * vt.v, sd = sdot(gd, vt);
+        val = SIGNED ? sv : fmax(0.0, sv);
+        slp = SIGNED ? sd : ((0.0 < sv) ? sd : 0.0);
+    }
+    template <bool SIGNED>
+    __device__ __forceinline__ void bound_invert_vect(double harg, double E, double &tpo, double &lbo) const {
         const double h = harg / (double)(GNG - 1);
-        TimePt tp[GNG];
-        typename Tgt::template Sh<Dual> sh[GNG];
-#pragma unroll
-        for (int j = 0; j < GNG; ++j) {
-            time_pt((j == GNG - 1) ? harg : (double)j * h, tp[j]);
-            sh[j] = shared_at<Dual>(tp[j]);
-        }
-        double box[GNG - 1];
-#pragma unroll
-        for (int j = 0; j < GNG - 1; ++j) box[j] = 0.0;
-        for (int s = 0; s < K; ++s) {
-            const int i = s * G + g;
-            const int ip = (i < p.d) ? i : 0;
-            const double x = X(s), v = V(s);
-            double val[GNG], slp[GNG];
-#pragma unroll
-            for (int j = 0; j < GNG; ++j) {                           // :208-210
-                Dual xt, vt;
-                flow(x, v, tp[j], xt, vt);
-                const Dual gd = tgt.grad(ip, xt, sh[j]);
-                const double sv = gd.v * vt.v, sd = sdot(gd, vt);
-                val[j] = SIGNED ? sv : fmax(0.0, sv);
-                slp[j] = SIGNED ? sd : ((0.0 < sv) ? sd : 0.0);
-            }
-            bool nz = false;
-#pragma unroll
-            for (int j = 0; j < GNG - 1; ++j) nz = nz || (slp[j + 1] != slp[j]);   // any tangent pair that really intersects?
-            const bool fast = __ballot(nz) == 0ull;                   // wave-uniform
-#pragma unroll
-            for (int j = 0; j < GNG - 1; ++j) {
-                const double num = ((val[j] - val[j + 1]) + slp[j + 1] * tp[j + 1].t) - slp[j] * tp[j].t;   // :229
-                const double q = cell_q(num, slp[j + 1] - slp[j], h, fast);   // :234-235
-                const double inter = val[j] + slp[j] * q;             // :237
-                const double cell = fmax(fmax(fmax(val[j], val[j + 1]), inter), 0.0);   // :239-241
-                box[j] += cell;                                       // sum(box_max, dims=1), :246
-            }
-        }
-        // cum_sum = cumsum of the summed box_max, times h (engine order: the reference sums the per-dimension
-        // cumsums, :243-246 -- same value up to rounding, 18 fewer live registers and 27 fewer ops per coordinate)
-        double acc = 0.0;
-#pragma unroll
+        double acc = 0.0, cprev = 0.0, bj = 0.0;
+        bool found = false;
+        tpo = __builtin_huge_val();
         for (int j = 0; j < GNG - 1; ++j) {
-            B.box[j] = group_sum(box[j], G);
-            acc += B.box[j];
-            B.cum[j] = acc * h;
+            TimePt p0, p1;
+            time_pt((double)j * h, p0);
+            time_pt((j == GNG - 2) ? harg : (double)(j + 1) * h, p1);
+            const auto sh0 = shared_at<Dual>(p0), sh1 = shared_at<Dual>(p1);
+            double bsum = 0.0;
+            for (int s = 0; s < K; ++s) {
+                const int i = s * G + g;
+                const int ip = (i < p.d) ? i : 0;
+                const double x = X(s), v = V(s);
+                double v0, g0, v1, g1;
+                eval_vect<SIGNED>(ip, x, v, p0, sh0, v0, g0);
+                eval_vect<SIGNED>(ip, x, v, p1, sh1, v1, g1);
+                const double num = ((v0 - v1) + g1 * p1.t) - g0 * p0.t;               // :229 (absolute-time form, Q1)
+                const double den = g1 - g0;
+                const bool fast = __ballot(den != 0.0) == 0ull;                       // wave-uniform
+                const double q = cell_q(num, den, h, fast);                            // :234-235
+                const double inter = v0 + g0 * q;                                      // :237
+                bsum += fmax(fmax(fmax(v0, v1), inter), 0.0);                          // :239-241, sum over dims :246
+            }
+            bj = group_sum(bsum, G);
+            acc += bj;                                                                 // cumsum, :243-244 (engine order)
+            const double cj = acc * h;
+            if (!found && !(cj < E)) {                                                 // searchsortedfirst, :265
+                found = true;
+                tpo = (double)j * h + (E - cprev) / (cj - cprev) * h;                  // :269
+                lbo = bj;                                                              // :270
+            }
+            cprev = cj;
+            if (__ballot(!found) == 0ull) break;
         }
-        B.h = h;
+        if (!found) lbo = bj;                                                          // box_max[end], :270
     }
 
-    // ---- upper_bound_grid, UpperBound.jl:92-137 (BPS / Boomerang)
-    __device__ __forceinline__ void bound_scalar(double harg, GBound &B) const {
-        const double h = harg / (double)(GNG - 1);
-        TimePt tp[GNG];
-        typename Tgt::template Sh<Dual> sh[GNG];
-        double fv[GNG], fe[GNG];
-#pragma unroll
-        for (int j = 0; j < GNG; ++j) {
-            time_pt((j == GNG - 1) ? harg : (double)j * h, tp[j]);
-            sh[j] = shared_at<Dual>(tp[j]);
-            fv[j] = 0.0; fe[j] = 0.0;
-        }
+    // scalar bounded function at one grid time: BouncyParticleSamplers.jl:39-47, BoomerangSamplers.jl:38-46;
+    // non-vectorized Zig-Zag bounds rate = sum(max.(0,.)), ZigZagSamplers.jl:83-86
+    __device__ __forceinline__ void eval_scalar(const TimePt &tp, double &val, double &slp) const {
+        const auto sh = shared_at<Dual>(tp);
+        double fv = 0.0, fe = 0.0;
         for (int s = 0; s < K; ++s) {
             const int i = s * G + g;
             const bool valid = i < p.d;
-            const double x = X(s), v = V(s);
-#pragma unroll
-            for (int j = 0; j < GNG; ++j) {                           // :97, :102
-                Dual xt, vt;
-                flow(x, v, tp[j], xt, vt);
-                const Dual gd = tgt.grad(i, xt, sh[j]);
-                double a = gd.v * vt.v, b = sdot(gd, vt);
-                if constexpr (SAMPLER == S_ZIGZAG) {       // non-vectorized Zig-Zag bounds rate = sum(max.(0,.)), ZigZagSamplers.jl:83-86
-                    b = (0.0 < a) ? b : 0.0;
-                    a = fmax(0.0, a);
-                }
-                fv[j] += valid ? a : 0.0;
-                fe[j] += valid ? b : 0.0;
+            Dual xt, vt;
+            flow(X(s), V(s), tp, xt, vt);
+            const Dual gd = tgt.grad(i, xt, sh);
+            double a = gd.v * vt.v, b = sdot(gd, vt);
+            if constexpr (SAMPLER == S_ZIGZAG) {
+                b = (0.0 < a) ? b : 0.0;
+                a = fmax(0.0, a);
             }
+            fv += valid ? a : 0.0;
+            fe += valid ? b : 0.0;
         }
+        const double dv = group_sum(fv, G), de = group_sum(fe, G);
+        if constexpr (SAMPLER == S_ZIGZAG) { val = dv; slp = de; return; }
         const bool sgn = p.signed_bound != 0;
-        const double refresh = sgn ? p.refresh : 0.0;                 // AbstractPDMP.jl:104-112
-        double val[GNG], slp[GNG];
-#pragma unroll
-        for (int j = 0; j < GNG; ++j) {
-            const double dv = group_sum(fv[j], G), de = group_sum(fe[j], G);
-            if constexpr (SAMPLER == S_ZIGZAG) { val[j] = dv; slp[j] = de; continue; }
-            val[j] = (sgn ? dv : fmax(0.0, dv)) + p.refresh;          // BouncyParticleSamplers.jl:39-47 (Q2)
-            slp[j] = sgn ? de : ((0.0 < dv) ? de : 0.0);
-        }
-        double acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < GNG - 1; ++j) {
-            const double num = (val[j] - val[j + 1]) + slp[j + 1] * h;   // :123 relative form
-            const double q = cell_q(num, slp[j + 1] - slp[j], h, false); // :124-125
-            const double inter = val[j] + slp[j] * q;                    // :127
-            double b = fmax(fmax(fmax(val[j], val[j + 1]), inter), 0.0); // :128-130
-            b += refresh;                                                // :131
-            acc += b;
-            B.box[j] = b;
-            B.cum[j] = acc * h;                                          // :133-134
-        }
-        B.h = h;
+        val = (sgn ? dv : fmax(0.0, dv)) + p.refresh;                 // includes refresh_rate (Q2)
+        slp = sgn ? de : ((0.0 < dv) ? de : 0.0);
     }
-    __device__ __forceinline__ void upper_bound(double harg, GBound &B) const {
+    __device__ __forceinline__ void bound_invert_scalar(double harg, double E, double &tpo, double &lbo) const {
+        const double h = harg / (double)(GNG - 1);
+        const double refresh = (p.signed_bound != 0) ? p.refresh : 0.0;               // AbstractPDMP.jl:104-112
+        double acc = 0.0, cprev = 0.0, bj = 0.0, f0, s0, f1, s1;
+        bool found = false;
+        tpo = __builtin_huge_val();
+        TimePt pt;
+        time_pt(0.0, pt);
+        eval_scalar(pt, f0, s0);                                                       // :97, :102
+        for (int j = 0; j < GNG - 1; ++j) {
+            time_pt((j == GNG - 2) ? harg : (double)(j + 1) * h, pt);
+            eval_scalar(pt, f1, s1);
+            const double num = (f0 - f1) + s1 * h;                                     // :123 relative form
+            const double q = cell_q(num, s1 - s0, h, false);                           // :124-125
+            const double inter = f0 + s0 * q;                                          // :127
+            bj = fmax(fmax(fmax(f0, f1), inter), 0.0);                                 // :128-130
+            bj += refresh;                                                             // :131
+            acc += bj;
+            const double cj = acc * h;                                                 // :133-134
+            if (!found && !(cj < E)) {
+                found = true;
+                tpo = (double)j * h + (E - cprev) / (cj - cprev) * h;
+                lbo = bj;
+            }
+            cprev = cj;
+            f0 = f1;
+            s0 = s1;
+            if (__ballot(!found) == 0ull) break;
+        }
+        if (!found) lbo = bj;
+    }
+    __device__ __forceinline__ void bound_invert(double harg, double E, double &tp, double &lb) const {
         if constexpr (SAMPLER == S_ZIGZAG) {
             if (p.vectorized) {
-                if (p.signed_bound) bound_vect<true>(harg, B); else bound_vect<false>(harg, B);
+                if (p.signed_bound) bound_invert_vect<true>(harg, E, tp, lb); else bound_invert_vect<false>(harg, E, tp, lb);
                 return;
             }
         }
-        bound_scalar(harg, B);
-    }
-
-    // ---- next_event, UpperBound.jl:264-273
-    __device__ __forceinline__ static void next_event(const GBound &B, double E, double &tp, double &lb) {
-        int idx = 1;                                        // cum_sum[0] = 0 < E
-#pragma unroll
-        for (int j = 0; j < GNG - 1; ++j) idx += (B.cum[j] < E) ? 1 : 0;
-        double c0 = 0.0, c1 = 0.0, b = B.box[GNG - 2];
-#pragma unroll
-        for (int j = 0; j < GNG - 1; ++j) {
-            if (j + 1 == idx) { c1 = B.cum[j]; b = B.box[j]; }
-            if (j + 2 == idx) c0 = B.cum[j];
-        }
-        const double t = (double)(idx - 1) * B.h + (E - c0) / (c1 - c0) * B.h;
-        tp = (idx >= GNG) ? __builtin_huge_val() : t;
-        lb = b;
+        bound_invert_scalar(harg, E, tp, lb);
     }
 
     // ---- unsigned total rate of the accept test (SamplingLoopInplace.jl:116, Q3)
@@ -512,12 +499,10 @@ struct GroupChain {
             if (!done && !propose) {
                 // one_step_of_thinning! (:65-85), erroneous_acceptance_rate! (:131-151) or if_reject! (:188-203)
                 const double harg = (mode == ERR) ? horizon / 2 : ((mode == REUSE) ? hB : horizon);
-                GBound B;
-                upper_bound(harg, B);
                 hB = harg;
                 const double e1 = rng.exponential();
                 E = (mode == REUSE) ? E + e1 : e1;                        // cumulative only after a rejection (:190)
-                next_event(B, E, tp, lb);
+                bound_invert(harg, E, tp, lb);
                 if (mode == ERR) {
                     if (adaptive) horizon = harg;
                     errored++;
@@ -604,10 +589,9 @@ __device__ __forceinline__ bool wait_progress(const int32_t *flag, int r) {
     return ok;
 }
 
-// Occupancy target (waves per SIMD).  3 = 168 VGPRs: measured +17 % on config 2 over 2 waves (the kernel is
-// VALU-issue bound and a third wave fills the dependency stalls of the cell arithmetic).  The banana
-// target keeps ten dual "shared" records per bound in registers and would spill heavily under that cap.
-template <int TARGET> struct GroupOcc { static constexpr int kWaves = (TARGET == T_BANANA) ? 2 : 3; };
+// Occupancy target (waves per SIMD): the lazy bound keeps every instantiation under 128 VGPRs, so four
+// waves per SIMD fit the register file; LDS (2*ceil(d/G)*512 B per wave) is what limits residency.
+template <int TARGET> struct GroupOcc { static constexpr int kWaves = 4; };
 
 template <int SAMPLER, int TARGET>
 __global__ __launch_bounds__(256, GroupOcc<TARGET>::kWaves) void group_kernel(const GroupParams gp) {
