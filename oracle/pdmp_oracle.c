@@ -542,8 +542,10 @@ static int velocity_jump(const orc_config_t *cfg, ws_t *w, rng_t *rng) {
         double S = vsum(cfg, w->tmp, d);
         double u = rng_uniform(rng);                          /* Categorical draw (1 uniform) */
         if (!(S > 0.0)) return 1;                             /* Q11: Categorical would throw */
-        for (int i = 0; i < d; ++i) w->tmp[i] = w->tmp[i] / S;
-        int m = categorical(cfg, w->tmp, d, u);
+        double thr = u;
+        if (cfg->arith == ORC_ARITH_GROUP) thr = u * S;       /* engine order: un-normalised walk against u*S */
+        else for (int i = 0; i < d; ++i) w->tmp[i] = w->tmp[i] / S;
+        int m = categorical(cfg, w->tmp, d, thr);
         w->v[m] = -w->v[m];                                   /* v[m] *= -1 */
         return 0;
     }

@@ -31,7 +31,8 @@ enum { ORC_DERIV_FORWARD = 0, ORC_DERIV_FINITE_DIFF = 1 };
  *              prefix scan, cumsum after the sum over dimensions).  Bitwise target for the HIP path. */
 /*   GROUP    : G lanes per chain (orc_config_t.group_lanes): per-lane left-to-right partial sums over the
  *              coordinates i = g, g+G, ..., ascending xor-butterfly over the G lanes; cum_sum after the sum
- *              over dimensions (as WAVE64); Categorical walk in slots of G.  GROUP(1) sums like REFERENCE. */
+ *              over dimensions (as WAVE64); Categorical walk in slots of G over the un-normalised rates
+ *              against u*sum (no division per coordinate).  GROUP(1) sums like REFERENCE. */
 enum { ORC_ARITH_REFERENCE = 0, ORC_ARITH_WAVE64 = 1, ORC_ARITH_GROUP = 2 };
 
 typedef struct orc_config_t {

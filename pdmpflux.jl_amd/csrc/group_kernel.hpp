@@ -44,15 +44,31 @@ struct GroupParams {
 };
 
 // ---------------------------------------------------------------- group-of-lanes primitives (G uniform)
-__device__ __forceinline__ double group_sum(double a, int G) {
-    for (int off = 1; off < G; off <<= 1) a = a + __shfl_xor(a, off, WAVE);
+// Stages inside a row of 16 lanes use DPP (register-to-register, no LDS crossbar latency); only the
+// 16- and 32-lane stages go through ds_bpermute.  Same operands and order as __shfl_xor / __shfl_up.
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+
+__device__ __forceinline__ double group_sum(double a, int G) {       // ascending xor-butterfly over G lanes
+    if (G > 1) a = a + dpp_d<DPP_QUAD_XOR1>(a);
+    if (G > 2) a = a + dpp_d<DPP_QUAD_XOR2>(a);
+    if (G > 4) a = a + dpp_d<DPP_ROW_HALF_MIRROR>(a);   // quads are uniform after the first two stages: partner = xor 4
+    if (G > 8) a = a + dpp_d<DPP_ROW_MIRROR>(a);        // likewise xor 8
+    if (G > 16) a = a + __shfl_xor(a, 16, WAVE);
+    if (G > 32) a = a + __shfl_xor(a, 32, WAVE);
     return a;
 }
-__device__ __forceinline__ double group_scan_incl(double a, int g, int G) {
-    for (int off = 1; off < G; off <<= 1) {
-        const double t = __shfl_up(a, off, WAVE);
-        if (g >= off) a = a + t;
+__device__ __forceinline__ double group_scan_incl(double a, int g, int G) {   // Kogge-Stone inclusive scan over G lanes
+    if (G > 16) {                      // groups spanning several DPP rows: row_shr cannot cross a row boundary
+        for (int off = 1; off < G; off <<= 1) {
+            const double t = __shfl_up(a, off, WAVE);
+            if (g >= off) a = a + t;
+        }
+        return a;
     }
+    if (G > 1) { const double t = dpp_d<DPP_ROW_SHR1>(a); if (g >= 1) a = a + t; }
+    if (G > 2) { const double t = dpp_d<DPP_ROW_SHR2>(a); if (g >= 2) a = a + t; }
+    if (G > 4) { const double t = dpp_d<DPP_ROW_SHR4>(a); if (g >= 4) a = a + t; }
+    if (G > 8) { const double t = dpp_d<DPP_ROW_SHR8>(a); if (g >= 8) a = a + t; }
     return a;
 }
 
@@ -346,14 +362,18 @@ struct GroupChain {
             const double S = group_sum(acc, G);
             const double u = rng.uniform();                              // Categorical draw
             if (!(S > 0.0)) { guard++; return; }                         // Q11
+            // Categorical(lambda / S) (ZigZagSamplers.jl:102-104): the reference walks cp += lambda_i / S until
+            // cp > u; the engine walks the un-normalised cumulative rate against theta = u * S (same index up
+            // to rounding at a cell boundary, no fp64 division per coordinate) -- GROUP order of the checker.
+            const double theta = u * S;
             double carry = 0.0;
             int m = -1;
             for (int s = 0; s < K; ++s) {
                 const int i = s * G + g;
                 const bool valid = i < d;
                 const double lam = valid ? fmax(0.0, tgt.grad(i, X(s), sh) * V(s)) : 0.0;
-                const double inc = group_scan_incl(lam / S, g, G);
-                const unsigned long long ball = __ballot(valid && (carry + inc > u));
+                const double inc = group_scan_incl(lam, g, G);
+                const unsigned long long ball = __ballot(valid && (carry + inc > theta));
                 const unsigned long long grp = (G == WAVE) ? ball : ((ball >> base) & ((1ull << G) - 1ull));
                 if (m < 0 && grp != 0ull) m = s * G + (int)__builtin_ctzll(grp);
                 carry = carry + __shfl(inc, base + G - 1, WAVE);
