@@ -164,7 +164,7 @@ glaunch_fn pick_group_launcher(int sampler, int target) {
 // (2 * ceil(d/G) * 512 B) within `budget` bytes, i.e. at least 160 KiB / (4 * budget) blocks of four
 // waves per CU.  0 = the configuration is served by the wave-per-chain kernel instead.
 int choose_group_lanes(const pdmp_config_t &c) {
-    if (c.grid_size != GNG || c.deriv_mode != PDMP_DERIV_FORWARD) return 0;
+    if (c.grid_size != GNG) return 0;
     if (const char *e = getenv("PDMP_GROUP_LANES")) {
         const int G = atoi(e);
         if (G == 0) return 0;

@@ -119,7 +119,7 @@ template <> struct GTarget<T_BANANA> {          // test/test_config.jl:33-36
     }
 };
 
-template <int SAMPLER, int TARGET>
+template <int SAMPLER, int TARGET, bool FD>
 struct GroupChain {
     using Tgt = GTarget<TARGET>;
     const SkelParams &p;
@@ -207,44 +207,93 @@ struct GroupChain {
         val = SIGNED ? sv : fmax(0.0, sv);
         slp = SIGNED ? sd : ((0.0 < sv) ? sd : 0.0);
     }
+    // finite_difference_derivative (UpperBound.jl:50-76) sample points of one grid time, start = 0
+    struct FdPt {
+        TimePt c, m, pl;            // t, t-h (clamped to 0), t+h (clamped to the horizon)
+        double den;                 // denominator of the difference quotient
+        int kind;                   // 0 central, 1 forward (t-h == t), 2 backward (t+h == t), 3 degenerate
+    };
+    __device__ __forceinline__ void fd_point(double t, double horizon, FdPt &P) const {
+        const double hh = 1.4901161193847656e-08 * fmax(1.0, fabs(t));               // sqrt(eps) * max(1, |t|), :58
+        const double tm = fmax(0.0, t - hh), tq = (horizon < t + hh) ? horizon : t + hh;   // :60-61
+        time_pt(t, P.c); time_pt(tm, P.m); time_pt(tq, P.pl);
+        P.kind = (tq == tm) ? 3 : ((tm == t) ? 1 : ((tq == t) ? 2 : 0));              // :64-75
+        P.den = (P.kind == 1) ? tq - t : ((P.kind == 2) ? t - tm : tq - tm);
+    }
     template <bool SIGNED>
+    __device__ __forceinline__ double fval_vect(int ip, double x, double v, const TimePt &tp,
+                                                const typename Tgt::template Sh<double> &sh) const {
+        double xt, vt;
+        flow(x, v, tp, xt, vt);
+        const double sv = tgt.grad(ip, xt, sh) * vt;
+        return SIGNED ? sv : fmax(0.0, sv);
+    }
+    __device__ __forceinline__ static double fd_slope(const FdPt &P, double fc, double fm, double fp) {
+        const double num = (P.kind == 1) ? fp - fc : ((P.kind == 2) ? fc - fm : fp - fm);
+        return (P.kind == 3) ? fc - fc : num / P.den;
+    }
+
+    template <bool SIGNED, bool FDM>
     __device__ __forceinline__ void bound_invert_vect(double harg, double E, double &tpo, double &lbo) const {
         const double h = harg / (double)(GNG - 1);
         double acc = 0.0, cprev = 0.0, bj = 0.0;
         bool found = false;
         tpo = __builtin_huge_val();
         for (int j = 0; j < GNG - 1; ++j) {
-            TimePt p0, p1;
-            time_pt((double)j * h, p0);
-            time_pt((j == GNG - 2) ? harg : (double)(j + 1) * h, p1);
-            const auto sh0 = shared_at<Dual>(p0), sh1 = shared_at<Dual>(p1);
+            const double t0 = (double)j * h, t1 = (j == GNG - 2) ? harg : (double)(j + 1) * h;
             double bsum = 0.0;
-            for (int s = 0; s < K; ++s) {
-                const int i = s * G + g;
-                const int ip = (i < p.d) ? i : 0;
-                const double x = X(s), v = V(s);
-                double v0, g0, v1, g1;
-                eval_vect<SIGNED>(ip, x, v, p0, sh0, v0, g0);
-                eval_vect<SIGNED>(ip, x, v, p1, sh1, v1, g1);
-                const double num = ((v0 - v1) + g1 * p1.t) - g0 * p0.t;               // :229 (absolute-time form, Q1)
-                const double den = g1 - g0;
-                const bool fast = __ballot(den != 0.0) == 0ull;                       // wave-uniform
-                const double q = cell_q(num, den, h, fast);                            // :234-235
-                const double inter = v0 + g0 * q;                                      // :237
-                bsum += fmax(fmax(fmax(v0, v1), inter), 0.0);                          // :239-241, sum over dims :246
+            if constexpr (!FDM) {
+                TimePt p0, p1;
+                time_pt(t0, p0);
+                time_pt(t1, p1);
+                const auto sh0 = shared_at<Dual>(p0), sh1 = shared_at<Dual>(p1);
+                for (int s = 0; s < K; ++s) {
+                    const int i = s * G + g;
+                    const int ip = (i < p.d) ? i : 0;
+                    const double x = X(s), v = V(s);
+                    double v0, g0, v1, g1;
+                    eval_vect<SIGNED>(ip, x, v, p0, sh0, v0, g0);
+                    eval_vect<SIGNED>(ip, x, v, p1, sh1, v1, g1);
+                    bsum += cell_vect(v0, g0, v1, g1, t0, t1, h);
+                }
+            } else {                                                                   // AD_backend = "FiniteDiff", :223-224
+                FdPt P0, P1;
+                fd_point(t0, harg, P0);
+                fd_point(t1, harg, P1);
+                const auto a0 = shared_at<double>(P0.c), a1 = shared_at<double>(P0.m), a2 = shared_at<double>(P0.pl);
+                const auto b0 = shared_at<double>(P1.c), b1 = shared_at<double>(P1.m), b2 = shared_at<double>(P1.pl);
+                for (int s = 0; s < K; ++s) {
+                    const int i = s * G + g;
+                    const int ip = (i < p.d) ? i : 0;
+                    const double x = X(s), v = V(s);
+                    const double v0 = fval_vect<SIGNED>(ip, x, v, P0.c, a0);
+                    const double g0 = fd_slope(P0, v0, fval_vect<SIGNED>(ip, x, v, P0.m, a1), fval_vect<SIGNED>(ip, x, v, P0.pl, a2));
+                    const double v1 = fval_vect<SIGNED>(ip, x, v, P1.c, b0);
+                    const double g1 = fd_slope(P1, v1, fval_vect<SIGNED>(ip, x, v, P1.m, b1), fval_vect<SIGNED>(ip, x, v, P1.pl, b2));
+                    bsum += cell_vect(v0, g0, v1, g1, t0, t1, h);
+                }
             }
             bj = group_sum(bsum, G);
             acc += bj;                                                                 // cumsum, :243-244 (engine order)
             const double cj = acc * h;
             if (!found && !(cj < E)) {                                                 // searchsortedfirst, :265
                 found = true;
-                tpo = (double)j * h + (E - cprev) / (cj - cprev) * h;                  // :269
+                tpo = t0 + (E - cprev) / (cj - cprev) * h;                             // :269
                 lbo = bj;                                                              // :270
             }
             cprev = cj;
             if (__ballot(!found) == 0ull) break;
         }
         if (!found) lbo = bj;                                                          // box_max[end], :270
+    }
+    // one tangent-intersection cell of one coordinate, UpperBound.jl:229-241 (absolute-time form, Q1)
+    __device__ __forceinline__ static double cell_vect(double v0, double g0, double v1, double g1, double t0, double t1, double h) {
+        const double num = ((v0 - v1) + g1 * t1) - g0 * t0;                            // :229
+        const double den = g1 - g0;
+        const bool fast = __ballot(den != 0.0) == 0ull;                                // wave-uniform
+        const double q = cell_q(num, den, h, fast);                                    // :234-235
+        const double inter = v0 + g0 * q;                                              // :237
+        return fmax(fmax(fmax(v0, v1), inter), 0.0);                                   // :239-241
     }
 
     // scalar bounded function at one grid time: BouncyParticleSamplers.jl:39-47, BoomerangSamplers.jl:38-46;
@@ -272,18 +321,60 @@ struct GroupChain {
         val = (sgn ? dv : fmax(0.0, dv)) + p.refresh;                 // includes refresh_rate (Q2)
         slp = sgn ? de : ((0.0 < dv) ? de : 0.0);
     }
+    // plain value of the scalar bounded function at up to three time points in one pass over the coordinates
+    template <int NPT>
+    __device__ __forceinline__ void fval_scalar(const TimePt (&tp)[NPT], double (&val)[NPT]) const {
+        typename Tgt::template Sh<double> sh[NPT];
+        double f[NPT];
+#pragma unroll
+        for (int q = 0; q < NPT; ++q) { sh[q] = shared_at<double>(tp[q]); f[q] = 0.0; }
+        for (int s = 0; s < K; ++s) {
+            const int i = s * G + g;
+            const bool valid = i < p.d;
+            const double x = X(s), v = V(s);
+#pragma unroll
+            for (int q = 0; q < NPT; ++q) {
+                double xt, vt;
+                flow(x, v, tp[q], xt, vt);
+                double a = tgt.grad(i, xt, sh[q]) * vt;
+                if constexpr (SAMPLER == S_ZIGZAG) a = fmax(0.0, a);
+                f[q] += valid ? a : 0.0;
+            }
+        }
+        const bool sgn = p.signed_bound != 0;
+#pragma unroll
+        for (int q = 0; q < NPT; ++q) {
+            const double dv = group_sum(f[q], G);
+            if constexpr (SAMPLER == S_ZIGZAG) val[q] = dv;
+            else val[q] = (sgn ? dv : fmax(0.0, dv)) + p.refresh;
+        }
+    }
+    template <bool FDM>
+    __device__ __forceinline__ void point_scalar(double t, double harg, double &val, double &slp) const {
+        if constexpr (!FDM) {
+            TimePt pt;
+            time_pt(t, pt);
+            eval_scalar(pt, val, slp);                                                 // :97, :102
+        } else {                                                                       // :117-118
+            FdPt P;
+            fd_point(t, harg, P);
+            const TimePt tp3[3] = {P.c, P.m, P.pl};
+            double f3[3];
+            fval_scalar<3>(tp3, f3);
+            val = f3[0];
+            slp = fd_slope(P, f3[0], f3[1], f3[2]);
+        }
+    }
+    template <bool FDM>
     __device__ __forceinline__ void bound_invert_scalar(double harg, double E, double &tpo, double &lbo) const {
         const double h = harg / (double)(GNG - 1);
         const double refresh = (p.signed_bound != 0) ? p.refresh : 0.0;               // AbstractPDMP.jl:104-112
         double acc = 0.0, cprev = 0.0, bj = 0.0, f0, s0, f1, s1;
         bool found = false;
         tpo = __builtin_huge_val();
-        TimePt pt;
-        time_pt(0.0, pt);
-        eval_scalar(pt, f0, s0);                                                       // :97, :102
+        point_scalar<FDM>(0.0, harg, f0, s0);
         for (int j = 0; j < GNG - 1; ++j) {
-            time_pt((j == GNG - 2) ? harg : (double)(j + 1) * h, pt);
-            eval_scalar(pt, f1, s1);
+            point_scalar<FDM>((j == GNG - 2) ? harg : (double)(j + 1) * h, harg, f1, s1);
             const double num = (f0 - f1) + s1 * h;                                     // :123 relative form
             const double q = cell_q(num, s1 - s0, h, false);                           // :124-125
             const double inter = f0 + s0 * q;                                          // :127
@@ -306,11 +397,11 @@ struct GroupChain {
     __device__ __forceinline__ void bound_invert(double harg, double E, double &tp, double &lb) const {
         if constexpr (SAMPLER == S_ZIGZAG) {
             if (p.vectorized) {
-                if (p.signed_bound) bound_invert_vect<true>(harg, E, tp, lb); else bound_invert_vect<false>(harg, E, tp, lb);
+                if (p.signed_bound) bound_invert_vect<true, FD>(harg, E, tp, lb); else bound_invert_vect<false, FD>(harg, E, tp, lb);
                 return;
             }
         }
-        bound_invert_scalar(harg, E, tp, lb);
+        bound_invert_scalar<FD>(harg, E, tp, lb);
     }
 
     // ---- unsigned total rate of the accept test (SamplingLoopInplace.jl:116, Q3)
@@ -611,9 +702,9 @@ __device__ __forceinline__ bool wait_progress(const int32_t *flag, int r) {
 
 // Occupancy target (waves per SIMD): the lazy bound keeps every instantiation under 128 VGPRs, so four
 // waves per SIMD fit the register file; LDS (2*ceil(d/G)*512 B per wave) is what limits residency.
-template <int TARGET> struct GroupOcc { static constexpr int kWaves = 4; };
+template <int TARGET> struct GroupOcc { static constexpr int kWaves = (TARGET == T_BANANA) ? 3 : 4; };   // banana + finite differences keeps six shared records: 3 waves avoid spills
 
-template <int SAMPLER, int TARGET>
+template <int SAMPLER, int TARGET, bool FD>
 __global__ __launch_bounds__(256, GroupOcc<TARGET>::kWaves) void group_kernel(const GroupParams gp) {
     extern __shared__ double smem[];
     const int lane = lane_id();
@@ -623,7 +714,7 @@ __global__ __launch_bounds__(256, GroupOcc<TARGET>::kWaves) void group_kernel(co
     __syncthreads();
     double *tile = smem + gp.tpar + (size_t)wave * 2 * gp.K * WAVE;
     const int cpw = WAVE / gp.G;
-    GroupChain<SAMPLER, TARGET> chain(gp, lane, tile, tile + gp.K * WAVE);
+    GroupChain<SAMPLER, TARGET, FD> chain(gp, lane, tile, tile + gp.K * WAVE);
     chain.tgt.init(smem, gp.s.d);
     const int nb = (int)gp.nb, n_units = nb * gp.nseg;            // host guarantees nb * nseg < 2^31
     bool lost = false;
@@ -673,33 +764,36 @@ inline void group_schedule(int64_t nb, int64_t slots, int64_t n_sk, int force, i
 template <int SAMPLER, int TARGET>
 hipError_t launch_group(const GroupParams &gp, hipStream_t stream);
 
-// Fills the schedule fields of gp (nb, nseg, seg_len) and returns the launch geometry.
-struct GroupLaunch { int wpb; unsigned grid; size_t lds; };
+template <int SAMPLER, int TARGET, bool FD>
+hipError_t launch_group_impl(const GroupParams &gp_in, hipStream_t stream) {
+    GroupParams gp = gp_in;
+    const int cpw = WAVE / gp.G, wpb = group_waves_per_block(gp.K, gp.tpar);
+    if (wpb < 1) return hipErrorInvalidValue;
+    const size_t lds = ((size_t)gp.tpar + (size_t)wpb * 2 * gp.K * WAVE) * sizeof(double);
+    auto kernel = group_kernel<SAMPLER, TARGET, FD>;
+    hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    int per_cu = 0, dev = 0, cus = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE * wpb, lds);
+    if (e != hipSuccess) return e;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (per_cu < 1) per_cu = 1;
+    if (cus < 1) cus = 256;
+    gp.nb = (gp.s.C + cpw - 1) / cpw;
+    const int64_t slots = (int64_t)cus * per_cu * wpb;
+    group_schedule(gp.nb, slots, gp.s.n_sk, gp.nseg, gp.nseg, gp.seg_len);
+    int64_t blocks = (gp.nb + wpb - 1) / wpb;
+    if (blocks > (int64_t)cus * per_cu) blocks = (int64_t)cus * per_cu;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(WAVE * wpb), lds, stream, gp);
+    return hipGetLastError();
+}
 
 #define PDMP_DEFINE_GROUP_LAUNCHER(S, T)                                                            \
     template <>                                                                                     \
-    hipError_t launch_group<S, T>(const GroupParams &gp_in, hipStream_t stream) {                   \
-        GroupParams gp = gp_in;                                                                     \
-        const int cpw = WAVE / gp.G, wpb = group_waves_per_block(gp.K, gp.tpar);                    \
-        if (wpb < 1) return hipErrorInvalidValue;                                                   \
-        const size_t lds = ((size_t)gp.tpar + (size_t)wpb * 2 * gp.K * WAVE) * sizeof(double);      \
-        hipError_t e = hipFuncSetAttribute((const void *)group_kernel<S, T>,                       \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
-        if (e != hipSuccess) return e;                                                              \
-        int per_cu = 0, dev = 0, cus = 0;                                                           \
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, group_kernel<S, T>, WAVE * wpb, lds); \
-        if (e != hipSuccess) return e;                                                              \
-        (void)hipGetDevice(&dev);                                                                   \
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);              \
-        if (per_cu < 1) per_cu = 1;                                                                 \
-        if (cus < 1) cus = 256;                                                                     \
-        gp.nb = (gp.s.C + cpw - 1) / cpw;                                                           \
-        const int64_t slots = (int64_t)cus * per_cu * wpb;                                          \
-        group_schedule(gp.nb, slots, gp.s.n_sk, gp.nseg, gp.nseg, gp.seg_len);                               \
-        int64_t blocks = (gp.nb + wpb - 1) / wpb;                                                   \
-        if (blocks > (int64_t)cus * per_cu) blocks = (int64_t)cus * per_cu;                         \
-        hipLaunchKernelGGL((group_kernel<S, T>), dim3((unsigned)blocks), dim3(WAVE * wpb), lds, stream, gp); \
-        return hipGetLastError();                                                                   \
+    hipError_t launch_group<S, T>(const GroupParams &gp, hipStream_t stream) {                      \
+        return gp.s.deriv_mode != 0 ? launch_group_impl<S, T, true>(gp, stream)                     \
+                                    : launch_group_impl<S, T, false>(gp, stream);                   \
     }
 
 }  // namespace pdmp
