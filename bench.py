@@ -109,6 +109,19 @@ def cpu_baseline(a, sampler):
                       f"OpenMP over chains, -O2 no fast-math, reference summation order)"}
 
 
+def measured_traffic(a):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (WRITE_SIZE exact, FETCH_SIZE x2
+    on gfx950; collected by profiles/collect.sh in separate --pmc runs and committed as profiles/traffic.json).
+    PMC counters cannot be read from inside this process, so the figure is the committed measurement of the
+    identical workload, or null when none exists for it."""
+    try:
+        table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except (OSError, ValueError):
+        return None
+    key = f"{a.sampler}|{a.target}|d={a.dim}|C={a.chains}|n_sk={a.n_sk}"
+    return table.get(key, {}).get("hbm_bytes_per_launch")
+
+
 def main():
     a = parse()
     import torch
@@ -182,6 +195,9 @@ def main():
         bytes_per_event = 8 * (2 * d + 1)                         # X, V, t of one event
         kernel_ms = tm["kernel_ms_total"] / max(tm["launches"], 1)
         achieved = C * (n_sk - 1) * bytes_per_event / (kernel_ms * 1e-3) / 1e9
+        G = sampler.group_lanes()
+        kernel = (f"group_kernel<{sampler.name},{a.target}> (G={G} lanes per chain)" if G > 0 else
+                  f"skeleton_kernel<{sampler.name},{a.target}> (wave per chain)")
         res = {
             "metric": "skeleton-events/sec (whole node), Zig-Zag d=50, 10^5 chains",
             "value": value, "unit": "events/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -193,8 +209,8 @@ def main():
                        "events_per_step": events_step,
                        "exchange": "none" if world == 1 else "all-gather of chain end states (2d+1 doubles per chain)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "skeleton_kernel", "kernel_ms": kernel_ms, "bytes_per_event": bytes_per_event,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(a),
+                         "kernel": kernel, "kernel_ms": kernel_ms, "bytes_per_event": bytes_per_event,
                          "note": "fp64-VALU-bound state machine; HBM fraction is the requested headline"},
         }
         if a.cpu_seconds > 0:
