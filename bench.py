@@ -39,14 +39,24 @@ def parse():
     ap.add_argument("--n-sk", type=int, default=1000)
     ap.add_argument("--dim", type=int, default=50)
     ap.add_argument("--sampler", default="ZigZagAD", choices=["ZigZagAD", "ZigZag", "BPS", "BPSAD", "Boomerang", "BoomerangAD"])
-    ap.add_argument("--target", default="iso", choices=["iso", "banana"])
+    ap.add_argument("--target", default="iso", choices=["iso", "banana", "dense"])
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time; 0 disables it")
     return ap.parse_args()
 
 
+def dense_precision(a):
+    """BASELINE config 4: P = Q diag(lambda) Q', lambda log-uniform in [0.1, 10], Q from a QR (seed 7)."""
+    import numpy as np
+    rs = np.random.default_rng(7)
+    Q, _ = np.linalg.qr(rs.normal(size=(a.dim, a.dim)))
+    Pm = (Q * np.exp(rs.uniform(np.log(0.1), np.log(10.0), size=a.dim))) @ Q.T
+    return 0.5 * (Pm + Pm.T)
+
+
 def make_sampler(P, a):
-    tgt = P.GaussianIso() if a.target == "iso" else P.Banana()
+    tgt = {"iso": P.GaussianIso, "banana": P.Banana}.get(a.target)
+    tgt = tgt() if tgt else P.GaussianPrecision(dense_precision(a))
     return getattr(P, a.sampler)(a.dim, tgt)
 
 
@@ -71,8 +81,9 @@ def cpu_baseline(a, sampler):
     import numpy as np
     from oracle import oracle as O
     cores = min(O.num_threads(), int(os.environ.get("PDMP_CPU_THREADS", "16")))   # CPU share of one GPU slot
-    tid = O.T_GAUSS_ISO if a.target == "iso" else O.T_BANANA
-    cfg = O.Config(sampler=sampler.sampler_id, dim=a.dim, grid_size=sampler.grid_size, tmax=sampler.tmax,
+    tid = {"iso": O.T_GAUSS_ISO, "banana": O.T_BANANA, "dense": O.T_GAUSS_DENSE}[a.target]
+    tparams = np.asfortranarray(dense_precision(a)).ravel(order="F") if a.target == "dense" else None
+    cfg = O.Config(target_params=tparams, sampler=sampler.sampler_id, dim=a.dim, grid_size=sampler.grid_size, tmax=sampler.tmax,
                    refresh_rate=sampler.refresh_rate, vectorized_bound=sampler.vectorized_bound,
                    signed_bound=sampler.signed_bound, adaptive=sampler.adaptive, deriv_mode=sampler.deriv_mode,
                    target_id=tid, arith=O.ARITH_REFERENCE)

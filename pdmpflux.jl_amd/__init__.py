@@ -4,7 +4,7 @@ sampler API.  Compute happens only in libpdmphip.so (hand-written HIP for gfx950
 include/pdmp_hip.h); there is no CPU fallback.
 """
 from ._lib import ArgumentError, DimensionMismatch, EngineError, LIB_PATH
-from .targets import GaussianIso, GaussianDiag, Banana
+from .targets import GaussianIso, GaussianDiag, Banana, GaussianPrecision
 from .samplers import AbstractPDMP, ZigZag, ZigZagAD, BPS, BPSAD, Boomerang, BoomerangAD
 from .history import PDMPHistory
 from .sample import (sample, sample_skeleton, sample_from_skeleton, sample_skeleton_ensemble,
@@ -12,7 +12,7 @@ from .sample import (sample, sample_skeleton, sample_from_skeleton, sample_skele
 
 __all__ = [
     "ArgumentError", "DimensionMismatch", "EngineError", "LIB_PATH",
-    "GaussianIso", "GaussianDiag", "Banana",
+    "GaussianIso", "GaussianDiag", "Banana", "GaussianPrecision",
     "AbstractPDMP", "ZigZag", "ZigZagAD", "BPS", "BPSAD", "Boomerang", "BoomerangAD",
     "PDMPHistory", "sample", "sample_skeleton", "sample_from_skeleton",
     "sample_skeleton_ensemble", "sample_from_skeleton_ensemble",

@@ -123,7 +123,12 @@ int normalize_config(pdmp_config_t &c) {
     if (c.grid_size == 1 || c.grid_size > WAVE) return fail(PDMP_ERR_UNSUPPORTED, "grid_size must be in 2..64. Current value: %d", c.grid_size);
     if (c.sampler < PDMP_ZIGZAG || c.sampler > PDMP_BOOMERANG) return fail(PDMP_ERR_ARGUMENT, "unknown sampler id %d", c.sampler);
     if (c.target_id < 0 || c.target_id > PDMP_T_GAUSS_DENSE) return fail(PDMP_ERR_ARGUMENT, "unknown target id %d", c.target_id);
-    if (c.target_id == PDMP_T_GAUSS_DENSE) return fail(PDMP_ERR_UNSUPPORTED, "dense-precision target is not implemented yet");
+    if (c.target_id == PDMP_T_GAUSS_DENSE) {
+        if (c.n_target_params != (int64_t)c.dim * c.dim || !c.target_params) return fail(PDMP_ERR_ARGUMENT, "GAUSS_DENSE needs target_params = P[dim*dim] (column-major)");
+        if (c.sampler == PDMP_BOOMERANG || c.deriv_mode != PDMP_DERIV_FORWARD || c.grid_size != 10)
+            return fail(PDMP_ERR_UNSUPPORTED, "dense-precision target: Zig-Zag / BPS with grid_size = 10 and forward-mode slopes only");
+        if (group_waves_per_block((c.dim + WAVE - 1) / WAVE, 0, 6) < 1) return fail(PDMP_ERR_UNSUPPORTED, "dense-precision target: dim too large for the LDS tiles");
+    }
     if (c.deriv_mode != PDMP_DERIV_FORWARD && c.deriv_mode != PDMP_DERIV_FINITE_DIFF) return fail(PDMP_ERR_ARGUMENT, "Unsupported AD_backend id %d", c.deriv_mode);
     if (!std::isfinite(c.tmax) || c.tmax < 0.0) return fail(PDMP_ERR_ARGUMENT, "tmax must be finite and non-negative");
     if (c.tmax == 0.0) { c.tmax = 1.0; c.adaptive = 1; }                                            // ZigZagSamplers.jl:73
@@ -132,7 +137,7 @@ int normalize_config(pdmp_config_t &c) {
     } else {
         c.vectorized_bound = 0;                                                                     // BPS :37, Boomerang :36
     }
-    if (c.dim > 4 * WAVE) return fail(PDMP_ERR_UNSUPPORTED, "dim > %d is not implemented yet", 4 * WAVE);
+
     if (c.target_id == PDMP_T_GAUSS_DIAG && (c.n_target_params != 2 * (int64_t)c.dim || !c.target_params))
         return fail(PDMP_ERR_ARGUMENT, "GAUSS_DIAG needs target_params = mu[dim], prec[dim]");
     if (c.max_iter_per_event <= 0) c.max_iter_per_event = 1000000;
@@ -152,10 +157,10 @@ launch_fn pick_launcher(int sampler, int target) {
 
 typedef hipError_t (*glaunch_fn)(const GroupParams &, hipStream_t);
 glaunch_fn pick_group_launcher(int sampler, int target) {
-    static const glaunch_fn table[3][3] = {
-        {launch_group<S_ZIGZAG, T_GAUSS_ISO>, launch_group<S_ZIGZAG, T_GAUSS_DIAG>, launch_group<S_ZIGZAG, T_BANANA>},
-        {launch_group<S_BPS, T_GAUSS_ISO>, launch_group<S_BPS, T_GAUSS_DIAG>, launch_group<S_BPS, T_BANANA>},
-        {launch_group<S_BOOMERANG, T_GAUSS_ISO>, launch_group<S_BOOMERANG, T_GAUSS_DIAG>, launch_group<S_BOOMERANG, T_BANANA>},
+    static const glaunch_fn table[3][4] = {
+        {launch_group<S_ZIGZAG, T_GAUSS_ISO>, launch_group<S_ZIGZAG, T_GAUSS_DIAG>, launch_group<S_ZIGZAG, T_BANANA>, launch_group<S_ZIGZAG, T_GAUSS_DENSE>},
+        {launch_group<S_BPS, T_GAUSS_ISO>, launch_group<S_BPS, T_GAUSS_DIAG>, launch_group<S_BPS, T_BANANA>, launch_group<S_BPS, T_GAUSS_DENSE>},
+        {launch_group<S_BOOMERANG, T_GAUSS_ISO>, launch_group<S_BOOMERANG, T_GAUSS_DIAG>, launch_group<S_BOOMERANG, T_BANANA>, nullptr},
     };
     return table[sampler][target];
 }
@@ -164,6 +169,7 @@ glaunch_fn pick_group_launcher(int sampler, int target) {
 // (2 * ceil(d/G) * 512 B) within `budget` bytes, i.e. at least 160 KiB / (4 * budget) blocks of four
 // waves per CU.  0 = the configuration is served by the wave-per-chain kernel instead.
 int choose_group_lanes(const pdmp_config_t &c) {
+    if (c.target_id == PDMP_T_GAUSS_DENSE) return WAVE;        // one chain per wave: the gradient is a mat-vec
     if (c.grid_size != GNG) return 0;
     if (const char *e = getenv("PDMP_GROUP_LANES")) {
         const int G = atoi(e);
@@ -228,6 +234,8 @@ int pdmp_create(const pdmp_config_t *cfg, pdmp_handle *out) {
     if (dev < 0) HIP_TRY(hipGetDevice(&dev));
     if (dev >= ndev) return fail(PDMP_ERR_ARGUMENT, "device %d out of range (%d visible)", dev, ndev);
     HIP_TRY(hipSetDevice(dev));
+    if (choose_group_lanes(c) == 0 && c.dim > 4 * WAVE)
+        return fail(PDMP_ERR_UNSUPPORTED, "dim > %d needs grid_size = 10 (group kernel); the wave-per-chain kernel holds at most 4 coordinates per lane", 4 * WAVE);
     pdmp_engine *h = new pdmp_engine();
     h->cfg = c;
     h->cfg.device = dev;
@@ -297,6 +305,7 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
         gp.G = h->group_lanes;
         gp.K = (c.dim + gp.G - 1) / gp.G;
         gp.tpar = (c.target_id == PDMP_T_GAUSS_DIAG) ? 2 * c.dim : 0;
+        gp.tiles = (c.target_id == PDMP_T_GAUSS_DENSE) ? 6 : 2;
         const int64_t nb = (C + WAVE / gp.G - 1) / (WAVE / gp.G);
         const size_t need_sched = (size_t)nb + 1, need_state = (size_t)C * (size_t)(2 * c.dim + 4);
         if (need_sched > h->sched_cap) {

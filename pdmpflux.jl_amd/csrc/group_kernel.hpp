@@ -34,6 +34,7 @@ struct GroupParams {
     int32_t G;            // lanes per chain (power of two, 1..64)
     int32_t K;            // coordinate slots per lane = ceil(d / G)
     int32_t tpar;         // doubles of target parameters staged in LDS (0 or 2d)
+    int32_t tiles;        // K*64-double LDS tiles per wave: 2 (x, v) + the target's scratch tiles
     // dynamic schedule: work unit u = (batch b = u % nb of 64/G chains, segment r = u / nb of seg_len events)
     int32_t nseg;         // segments per chain
     int64_t nb;           // batches = ceil(C / (64/G))
@@ -81,14 +82,14 @@ struct NoShared {};
 template <int TARGET> struct GTarget;
 
 template <> struct GTarget<T_GAUSS_ISO> {
-    static constexpr bool kShared = false;
+    static constexpr bool kShared = false, kTile = false;
     template <class T> using Sh = NoShared;
     __device__ __forceinline__ void init(const double *, int) {}
     template <class T> __device__ __forceinline__ NoShared shared(T, T) const { return {}; }
     template <class T> __device__ __forceinline__ T grad(int, T x, const NoShared &) const { return x; }
 };
 template <> struct GTarget<T_GAUSS_DIAG> {
-    static constexpr bool kShared = false;
+    static constexpr bool kShared = false, kTile = false;
     template <class T> using Sh = NoShared;
     const double *mu, *prec;            // LDS copies
     __device__ __forceinline__ void init(const double *lds_params, int d) { mu = lds_params; prec = lds_params + d; }
@@ -101,7 +102,7 @@ template <> struct GTarget<T_GAUSS_DIAG> {
 };
 template <class T> struct BananaSh { T g0, r; };
 template <> struct GTarget<T_BANANA> {          // test/test_config.jl:33-36
-    static constexpr bool kShared = true;
+    static constexpr bool kShared = true, kTile = false;
     template <class T> using Sh = BananaSh<T>;
     int d;
     __device__ __forceinline__ void init(const double *, int dim) { d = dim; }
@@ -157,9 +158,48 @@ struct GroupChain {
         if constexpr (SAMPLER == S_BOOMERANG) { xt = x * tp.c + v * tp.s; vt = (-x) * tp.s + v * tp.c; }
         else { xt = x + v * tp.t; vt = v; }
     }
+    // out[i] = sum_j P[i,j] in[j], j left to right per row (row i owned by lane i % 64, slot i / 64).
+    // Eight rows per lane are accumulated together so that eight independent 512-byte column pieces are in
+    // flight per j (a single running sum per lane would be bound by the load latency); padded rows read row 0
+    // and are zeroed at the end.
+    __device__ __forceinline__ void matvec(const double *P, const double *in, double *out) const {
+        constexpr int R = 8;
+        const int d = p.d;
+        for (int s0 = 0; s0 < K; s0 += R) {
+            double acc[R];
+            const double *row[R];
+            bool ok[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const int i = (s0 + q) * WAVE + lane;
+                ok[q] = (s0 + q < K) && (i < d);
+                row[q] = P + (ok[q] ? i : 0);
+                acc[q] = 0.0;
+            }
+#pragma unroll 4
+            for (int j = 0; j < d; ++j) {
+                const double xj = in[j];
+                const size_t off = (size_t)j * d;
+#pragma unroll
+                for (int q = 0; q < R; ++q) acc[q] += row[q][off] * xj;
+            }
+#pragma unroll
+            for (int q = 0; q < R; ++q)
+                if (s0 + q < K) out[(s0 + q) * WAVE + lane] = ok[q] ? acc[q] : 0.0;
+        }
+    }
     template <class T>
-    __device__ __forceinline__ typename Tgt::template Sh<T> shared_at(const TimePt &tp) const {
-        if constexpr (Tgt::kShared) {
+    __device__ __forceinline__ typename Tgt::template Sh<T> shared_at(const TimePt &tp, int which = 0) {
+        if constexpr (Tgt::kTile) {
+            for (int s = 0; s < K; ++s) {
+                double xt, vt;
+                flow(X(s), V(s), tp, xt, vt);
+                tgt.tx[s * WAVE + lane] = xt;
+            }
+            matvec(tgt.P, tgt.tx, tgt.tg[which]);
+            if (!tgt.b_valid) { matvec(tgt.P, vs, tgt.tb); tgt.b_valid = true; }   // G = 64: the v tile is the vector v
+            return {tgt.tg[which], tgt.tb};
+        } else if constexpr (Tgt::kShared) {
             if (p.d >= 2) {
                 double x0, v0, x1, v1;
                 coord(0, x0, v0);
@@ -234,11 +274,12 @@ struct GroupChain {
     }
 
     template <bool SIGNED, bool FDM>
-    __device__ __forceinline__ void bound_invert_vect(double harg, double E, double &tpo, double &lbo) const {
+    __device__ __forceinline__ void bound_invert_vect(double harg, double E, double &tpo, double &lbo) {
         const double h = harg / (double)(GNG - 1);
         double acc = 0.0, cprev = 0.0, bj = 0.0;
         bool found = false;
         tpo = __builtin_huge_val();
+        typename Tgt::template Sh<Dual> shf{};
         for (int j = 0; j < GNG - 1; ++j) {
             const double t0 = (double)j * h, t1 = (j == GNG - 2) ? harg : (double)(j + 1) * h;
             double bsum = 0.0;
@@ -246,7 +287,8 @@ struct GroupChain {
                 TimePt p0, p1;
                 time_pt(t0, p0);
                 time_pt(t1, p1);
-                const auto sh0 = shared_at<Dual>(p0), sh1 = shared_at<Dual>(p1);
+                if (j == 0) shf = shared_at<Dual>(p0, 0);                 // left endpoint: carried over from the previous cell
+                const auto sh0 = shf, sh1 = shared_at<Dual>(p1, (j + 1) & 1);
                 for (int s = 0; s < K; ++s) {
                     const int i = s * G + g;
                     const int ip = (i < p.d) ? i : 0;
@@ -256,6 +298,7 @@ struct GroupChain {
                     eval_vect<SIGNED>(ip, x, v, p1, sh1, v1, g1);
                     bsum += cell_vect(v0, g0, v1, g1, t0, t1, h);
                 }
+                shf = sh1;
             } else {                                                                   // AD_backend = "FiniteDiff", :223-224
                 FdPt P0, P1;
                 fd_point(t0, harg, P0);
@@ -298,7 +341,7 @@ struct GroupChain {
 
     // scalar bounded function at one grid time: BouncyParticleSamplers.jl:39-47, BoomerangSamplers.jl:38-46;
     // non-vectorized Zig-Zag bounds rate = sum(max.(0,.)), ZigZagSamplers.jl:83-86
-    __device__ __forceinline__ void eval_scalar(const TimePt &tp, double &val, double &slp) const {
+    __device__ __forceinline__ void eval_scalar(const TimePt &tp, double &val, double &slp) {
         const auto sh = shared_at<Dual>(tp);
         double fv = 0.0, fe = 0.0;
         for (int s = 0; s < K; ++s) {
@@ -323,7 +366,7 @@ struct GroupChain {
     }
     // plain value of the scalar bounded function at up to three time points in one pass over the coordinates
     template <int NPT>
-    __device__ __forceinline__ void fval_scalar(const TimePt (&tp)[NPT], double (&val)[NPT]) const {
+    __device__ __forceinline__ void fval_scalar(const TimePt (&tp)[NPT], double (&val)[NPT]) {
         typename Tgt::template Sh<double> sh[NPT];
         double f[NPT];
 #pragma unroll
@@ -350,7 +393,7 @@ struct GroupChain {
         }
     }
     template <bool FDM>
-    __device__ __forceinline__ void point_scalar(double t, double harg, double &val, double &slp) const {
+    __device__ __forceinline__ void point_scalar(double t, double harg, double &val, double &slp) {
         if constexpr (!FDM) {
             TimePt pt;
             time_pt(t, pt);
@@ -366,7 +409,7 @@ struct GroupChain {
         }
     }
     template <bool FDM>
-    __device__ __forceinline__ void bound_invert_scalar(double harg, double E, double &tpo, double &lbo) const {
+    __device__ __forceinline__ void bound_invert_scalar(double harg, double E, double &tpo, double &lbo) {
         const double h = harg / (double)(GNG - 1);
         const double refresh = (p.signed_bound != 0) ? p.refresh : 0.0;               // AbstractPDMP.jl:104-112
         double acc = 0.0, cprev = 0.0, bj = 0.0, f0, s0, f1, s1;
@@ -394,7 +437,7 @@ struct GroupChain {
         }
         if (!found) lbo = bj;
     }
-    __device__ __forceinline__ void bound_invert(double harg, double E, double &tp, double &lb) const {
+    __device__ __forceinline__ void bound_invert(double harg, double E, double &tp, double &lb) {
         if constexpr (SAMPLER == S_ZIGZAG) {
             if (p.vectorized) {
                 if (p.signed_bound) bound_invert_vect<true, FD>(harg, E, tp, lb); else bound_invert_vect<false, FD>(harg, E, tp, lb);
@@ -405,7 +448,10 @@ struct GroupChain {
     }
 
     // ---- unsigned total rate of the accept test (SamplingLoopInplace.jl:116, Q3)
-    __device__ __forceinline__ double true_rate(double t) const {
+    // `raw` = the summed term before max/refresh: at an accepted proposal the state flows to exactly the
+    // point evaluated here (same expression x + v*tp, same stored doubles), so the velocity jump's
+    // sum(lambda) (Zig-Zag) / dot(grad-U, v) (BPS) is this very number and is not recomputed.
+    __device__ __forceinline__ double true_rate(double t, double &raw) {
         TimePt tp;
         time_pt(t, tp);
         const auto sh = shared_at<double>(tp);
@@ -419,6 +465,7 @@ struct GroupChain {
             acc += (i < p.d) ? term : 0.0;
         }
         const double tot = group_sum(acc, G);
+        raw = tot;
         if constexpr (SAMPLER == S_ZIGZAG) return tot;
         else return fmax(0.0, tot) + p.refresh;                                 // BPS :39-42, Boomerang :38-41
     }
@@ -435,22 +482,19 @@ struct GroupChain {
     }
 
     // ---- velocity_jump: ZigZagSamplers.jl:101-107, BouncyParticleSamplers.jl:50-74, BoomerangSamplers.jl:49-67
-    __device__ __forceinline__ void velocity_jump() {
+    __device__ __forceinline__ void velocity_jump(double raw) {
         TimePt t0;
         t0.t = 0.0; t0.s = 0.0; t0.c = 1.0;
         typename Tgt::template Sh<double> sh;
-        if constexpr (Tgt::kShared) {
+        if constexpr (Tgt::kTile) {
+            sh = {tgt.tg[0], tgt.tb};            // grad-U at the accepted point: tile 0 was filled by true_rate(tp)
+            tgt.b_valid = false;                 // v is about to change
+        } else if constexpr (Tgt::kShared) {
             if (p.d >= 2) { double x0, v0, x1, v1; coord(0, x0, v0); coord(1, x1, v1); sh = tgt.template shared<double>(x0, x1); }
         }
         const int d = p.d;
         if constexpr (SAMPLER == S_ZIGZAG) {
-            double acc = 0.0;
-            for (int s = 0; s < K; ++s) {
-                const int i = s * G + g;
-                const double lam = fmax(0.0, tgt.grad(i, X(s), sh) * V(s));
-                acc += (i < d) ? lam : 0.0;
-            }
-            const double S = group_sum(acc, G);
+            const double S = raw;                                        // sum(max.(0, grad-U .* v)), ZigZagSamplers.jl:102-103
             const double u = rng.uniform();                              // Categorical draw
             if (!(S > 0.0)) { guard++; return; }                         // Q11
             // Categorical(lambda / S) (ZigZagSamplers.jl:102-104): the reference walks cp += lambda_i / S until
@@ -476,13 +520,17 @@ struct GroupChain {
             return;
         } else {
             double acc = 0.0;
-            for (int s = 0; s < K; ++s) {
-                const int i = s * G + g;
-                double gi = tgt.grad(i, X(s), sh);
-                if constexpr (SAMPLER == S_BOOMERANG) gi = gi - X(s);    // :51-52 (Q8)
-                acc += (i < d) ? gi * V(s) : 0.0;
+            double gv;
+            if constexpr (SAMPLER == S_BPS) {
+                gv = raw;                                                // dot(grad-U(x), v), BouncyParticleSamplers.jl:51-52
+            } else {
+                for (int s = 0; s < K; ++s) {
+                    const int i = s * G + g;
+                    const double gi = tgt.grad(i, X(s), sh) - X(s);      // grad-U_effective, BoomerangSamplers.jl:51-52 (Q8)
+                    acc += (i < d) ? gi * V(s) : 0.0;
+                }
+                gv = group_sum(acc, G);
             }
-            const double gv = group_sum(acc, G);
             const double bounce = fmax(0.0, gv);
             const double prob = bounce / (bounce + p.refresh);           // NaN if both 0 (Q9)
             const double u = rng.uniform();
@@ -588,6 +636,7 @@ struct GroupChain {
         }
         rng.init_lane(p.seed, (uint64_t)(p.chain0 + c));
         rng.restore(n0);
+        if constexpr (Tgt::kTile) tgt.b_valid = false;
         double ts = 0.0, tp = 0.0, E = 0.0, lb = 0.0;
         int32_t errored = 0, rejected = 0, hits = 0;
         double ev[5] = {0, 0, 0, 0, 0};
@@ -642,7 +691,8 @@ struct GroupChain {
                 if (++it > cap) { done = true; if (g == 0) atomicAdd(&p.status[0], 1); }
             }
             if (!done && propose) {
-                const double lam = true_rate(tp);                         // ac_step!, :113-129
+                double raw;
+                const double lam = true_rate(tp, raw);                    // ac_step!, :113-129
                 ar = lam / lb;
                 propose = false;
                 if (ar > 1.0) {
@@ -651,7 +701,7 @@ struct GroupChain {
                     const double u = rng.uniform();
                     if (u < ar) {                                         // if_accept!, :170-186
                         flow_state(tp);
-                        velocity_jump();
+                        velocity_jump(raw);
                         t = t + tp + ts;
                         ts = 0.0;
                         tp = 0.0;
@@ -688,6 +738,25 @@ struct GroupChain {
 // satisfied on arrival in practice and can never deadlock; it is bounded all the same.
 // Hand-off protocol (cdna_hip_programming.md Guideline 16): plain stores -> agent-scope release fence
 // -> s_waitcnt vmcnt(0) -> relaxed agent flag store;  relaxed poll -> agent-scope acquire -> plain loads.
+// U = x'Px/2, grad-U = P x with a dense precision matrix (BASELINE config 4).  One chain per wave (G = 64);
+// the gradient of a whole time point is a mat-vec: x_t is written to an LDS scratch tile, row i of P x_t is
+// accumulated left to right over j (the order of the checker) by the lane that owns coordinate i, P streams
+// column-major from L2 / Infinity Cache (coalesced 512-byte pieces).  d/dt of grad-U along a linear flow is
+// P v, the same for every time point of a bound and until the next velocity change, so it is cached.
+// First correct version: per-chain mat-vecs; the lock-step fp64-MFMA GEMM over chains is the planned upgrade.
+template <class T> struct DenseSh { const double *g, *b; };
+template <> struct GTarget<T_GAUSS_DENSE> {
+    static constexpr bool kShared = true, kTile = true;
+    static constexpr int kExtraTiles = 4;          // two gradient tiles, P v, scratch x_t
+    template <class T> using Sh = DenseSh<T>;
+    const double *P;
+    double *tg[2], *tb, *tx;
+    bool b_valid;
+    __device__ __forceinline__ void init(const double *, int) {}
+    __device__ __forceinline__ double grad(int i, double, const DenseSh<double> &sh) const { return sh.g[i]; }
+    __device__ __forceinline__ Dual grad(int i, Dual, const DenseSh<Dual> &sh) const { return {sh.g[i], sh.b[i]}; }
+};
+
 // Bounded wait for progress[b] >= r (relaxed agent-scope poll + s_sleep), then the agent-scope acquire.
 __device__ __forceinline__ bool wait_progress(const int32_t *flag, int r) {
     bool ok = false;
@@ -712,10 +781,17 @@ __global__ __launch_bounds__(256, GroupOcc<TARGET>::kWaves) void group_kernel(co
     // target parameters (mu, prec) once per block
     for (int q = threadIdx.x; q < gp.tpar; q += blockDim.x) smem[q] = gp.s.tparams[q];
     __syncthreads();
-    double *tile = smem + gp.tpar + (size_t)wave * 2 * gp.K * WAVE;
+    const size_t tsz = (size_t)gp.K * WAVE;
+    double *tile = smem + gp.tpar + (size_t)wave * gp.tiles * tsz;
     const int cpw = WAVE / gp.G;
-    GroupChain<SAMPLER, TARGET, FD> chain(gp, lane, tile, tile + gp.K * WAVE);
+    GroupChain<SAMPLER, TARGET, FD> chain(gp, lane, tile, tile + tsz);
     chain.tgt.init(smem, gp.s.d);
+    if constexpr (GTarget<TARGET>::kTile) {
+        chain.tgt.P = gp.s.tparams;
+        chain.tgt.tg[0] = tile + 2 * tsz; chain.tgt.tg[1] = tile + 3 * tsz;
+        chain.tgt.tb = tile + 4 * tsz; chain.tgt.tx = tile + 5 * tsz;
+        chain.tgt.b_valid = false;
+    }
     const int nb = (int)gp.nb, n_units = nb * gp.nseg;            // host guarantees nb * nseg < 2^31
     bool lost = false;
     for (int pulled = 0; pulled <= n_units && !lost; ++pulled) {  // a wave can never pull more than n_units units
@@ -737,8 +813,8 @@ __global__ __launch_bounds__(256, GroupOcc<TARGET>::kWaves) void group_kernel(co
 }
 
 // waves per block: as many (up to 4) as fit the CU's 160 KiB of LDS next to the staged parameters
-inline int group_waves_per_block(int K, int tpar) {
-    const size_t tile = 2ull * K * WAVE * sizeof(double), avail = 160 * 1024 - (size_t)tpar * sizeof(double);
+inline int group_waves_per_block(int K, int tpar, int tiles = 2) {
+    const size_t tile = (size_t)tiles * K * WAVE * sizeof(double), avail = 160 * 1024 - (size_t)tpar * sizeof(double);
     const size_t w = avail / tile;
     return w >= 4 ? 4 : (int)w;
 }
@@ -767,9 +843,9 @@ hipError_t launch_group(const GroupParams &gp, hipStream_t stream);
 template <int SAMPLER, int TARGET, bool FD>
 hipError_t launch_group_impl(const GroupParams &gp_in, hipStream_t stream) {
     GroupParams gp = gp_in;
-    const int cpw = WAVE / gp.G, wpb = group_waves_per_block(gp.K, gp.tpar);
+    const int cpw = WAVE / gp.G, wpb = group_waves_per_block(gp.K, gp.tpar, gp.tiles);
     if (wpb < 1) return hipErrorInvalidValue;
-    const size_t lds = ((size_t)gp.tpar + (size_t)wpb * 2 * gp.K * WAVE) * sizeof(double);
+    const size_t lds = ((size_t)gp.tpar + (size_t)wpb * gp.tiles * gp.K * WAVE) * sizeof(double);
     auto kernel = group_kernel<SAMPLER, TARGET, FD>;
     hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -9,4 +9,5 @@ PDMP_DEFINE_LAUNCHER(S_ZIGZAG, T_BANANA)
 PDMP_DEFINE_GROUP_LAUNCHER(S_ZIGZAG, T_GAUSS_ISO)
 PDMP_DEFINE_GROUP_LAUNCHER(S_ZIGZAG, T_GAUSS_DIAG)
 PDMP_DEFINE_GROUP_LAUNCHER(S_ZIGZAG, T_BANANA)
+PDMP_DEFINE_GROUP_LAUNCHER(S_ZIGZAG, T_GAUSS_DENSE)
 }  // namespace pdmp

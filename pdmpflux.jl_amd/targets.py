@@ -48,3 +48,29 @@ class Banana:
 
     def params(self, dim):
         return None
+
+
+@dataclass(frozen=True)
+class GaussianPrecision:
+    """U(x) = x' P x / 2 with a dense symmetric precision matrix P (BASELINE config 4: grad-U = P x)."""
+    P: tuple
+    dim: int
+    target_id: int = T_GAUSS_DENSE
+
+    def __init__(self, P):
+        P = np.asarray(P, dtype=np.float64)
+        if P.ndim != 2 or P.shape[0] != P.shape[1]:
+            from ._lib import DimensionMismatch
+            raise DimensionMismatch("P must be a square matrix")
+        object.__setattr__(self, "P", tuple(np.asfortranarray(P).ravel(order="F")))   # column-major, as Julia
+        object.__setattr__(self, "dim", P.shape[0])
+        object.__setattr__(self, "target_id", T_GAUSS_DENSE)
+
+    def params(self, dim):
+        if dim != self.dim:
+            from ._lib import DimensionMismatch
+            raise DimensionMismatch(f"P is {self.dim}x{self.dim} but dim = {dim}")
+        return np.asarray(self.P)
+
+    def __repr__(self):
+        return f"GaussianPrecision(dim={self.dim})"

@@ -14,6 +14,11 @@ def make_pair(P, O, kind, dim, target="iso", arith=None, **kw):
         tg, tid, params = P.GaussianDiag(mu, prec), O.T_GAUSS_DIAG, np.concatenate([mu, prec])
     elif target == "banana":
         tg, tid, params = P.Banana(), O.T_BANANA, None
+    elif target == "dense":                      # P = Q diag(lambda) Q', lambda log-uniform in [0.1, 10] (BASELINE config 4)
+        Q, _ = np.linalg.qr(rs.normal(size=(dim, dim)))
+        Pm = (Q * np.exp(rs.uniform(np.log(0.1), np.log(10.0), size=dim))) @ Q.T
+        Pm = 0.5 * (Pm + Pm.T)
+        tg, tid, params = P.GaussianPrecision(Pm), O.T_GAUSS_DENSE, np.asfortranarray(Pm).ravel(order="F")
     else:
         raise ValueError(target)
     ctor = {"ZigZag": P.ZigZag, "ZigZagAD": P.ZigZagAD, "BPS": P.BPS, "BPSAD": P.BPSAD,

@@ -58,6 +58,10 @@ CASES = [
     ("BPS", 50, "banana", 8, 200, {"signed_bound": False}),
     ("BPS", 50, "banana", 8, 200, {"AD_backend": "FiniteDiff"}),
     ("BPSAD", 20, "iso", 4, 200, {}),               # refresh_rate = 0 (Q9)
+    ("ZigZagAD", 100, "dense", 5, 120, {}),         # dense precision: grad-U = P x by per-chain mat-vecs (config 4 shape)
+    ("ZigZagAD", 7, "dense", 3, 200, {}),
+    ("BPS", 70, "dense", 4, 120, {}),
+    ("ZigZagAD", 300, "dense", 2, 40, {}),
     ("Boomerang", 100, "iso", 6, 200, {}),          # default FiniteDiff
     ("BoomerangAD", 50, "diag", 6, 200, {"refresh_rate": 0.1}),
     ("Boomerang", 50, "banana", 6, 200, {"AD_backend": "ForwardDiff"}),
