@@ -501,18 +501,28 @@ struct GroupChain {
             // cp > u; the engine walks the un-normalised cumulative rate against theta = u * S (same index up
             // to rounding at a cell boundary, no fp64 division per coordinate) -- GROUP order of the checker.
             const double theta = u * S;
-            double carry = 0.0;
-            int m = -1;
+            // Level 1: slot totals T_s (the butterfly value equals the last lane of the Kogge-Stone scan bit
+            // for bit), first slot whose running total exceeds theta.  Level 2: one scan inside that slot.
+            double carry = 0.0, carry_at = 0.0;
+            int ms_hit = -1;
             for (int s = 0; s < K; ++s) {
                 const int i = s * G + g;
-                const bool valid = i < d;
-                const double lam = valid ? fmax(0.0, tgt.grad(i, X(s), sh) * V(s)) : 0.0;
+                const double lam = (i < d) ? fmax(0.0, tgt.grad(i, X(s), sh) * V(s)) : 0.0;
+                const double T = group_sum(lam, G);
+                if (ms_hit < 0 && (carry + T > theta)) { ms_hit = s; carry_at = carry; }
+                carry = carry + T;
+                if (__ballot(ms_hit < 0) == 0ull) break;
+            }
+            int m = -1;
+            {
+                const int sq = (ms_hit < 0) ? 0 : ms_hit;
+                const int i = sq * G + g;
+                const bool valid = (ms_hit >= 0) && (i < d);
+                const double lam = valid ? fmax(0.0, tgt.grad(i, X(sq), sh) * V(sq)) : 0.0;
                 const double inc = group_scan_incl(lam, g, G);
-                const unsigned long long ball = __ballot(valid && (carry + inc > theta));
+                const unsigned long long ball = __ballot(valid && (carry_at + inc > theta));
                 const unsigned long long grp = (G == WAVE) ? ball : ((ball >> base) & ((1ull << G) - 1ull));
-                if (m < 0 && grp != 0ull) m = s * G + (int)__builtin_ctzll(grp);
-                carry = carry + __shfl(inc, base + G - 1, WAVE);
-                if (__ballot(m < 0) == 0ull) break;
+                if (grp != 0ull) m = sq * G + (int)__builtin_ctzll(grp);
             }
             if (m < 0) m = d - 1;
             const int ms = m / G;
