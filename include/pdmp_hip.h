@@ -123,6 +123,12 @@ int pdmp_sample_from_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, con
                                      const double *V, const double *t, int64_t N, int32_t discard_vt,
                                      double *out, void *stream);
 
+/* The step right after the path: per-chain sums of x and x^2 over the N samples that
+ * sample_from_skeleton(sampler, N, history) (src/sample.jl:475-513) would return, without writing them:
+ * sum_x, sum_x2 are d x C (DEVICE pointers).  mean = sum_x / N, var = sum_x2 / N - mean^2 per chain, or pooled. */
+int pdmp_sample_moments_device(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
+                               const double *t, int64_t N, double *sum_x, double *sum_x2, void *stream);
+
 /* Synchronises the handle's last stream and returns PDMP_ERR_ITERCAP if any chain of the launches
  * since the previous check hit the iteration cap (Q11 guard events are counted in *n_guard if non-NULL). */
 int pdmp_check_status(pdmp_handle h, int64_t *n_guard);

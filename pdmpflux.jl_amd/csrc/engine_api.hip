@@ -102,6 +102,63 @@ __global__ __launch_bounds__(256) void from_skeleton_kernel(int d, int64_t C, in
     }
 }
 
+// Fused sample_from_skeleton + moment sums: per chain the sums of x_j and x_j^2 over the N
+// equispaced samples of sample.jl:475-513, without materialising the d x N x C sample array.  One wave per chain,
+// samples in order, each lane accumulates its coordinates left to right: deterministic (no atomics), equal to
+// a sequential sum over the samples of sample_from_skeleton.
+template <bool BOOMERANG>
+__global__ __launch_bounds__(256) void moments_kernel(int d, int64_t C, int64_t n_sk, const double *X, const double *V,
+                                                      const double *t, int64_t N, double *sum_x, double *sum_x2) {
+    const int lane = lane_id();
+    const int64_t c = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (c >= C) return;
+    const double *tc = t + (size_t)c * n_sk;
+    const double dt = tc[n_sk - 1] / (double)N;
+    const int64_t tiles = (N + WAVE - 1) / WAVE;
+    constexpr int M = 4;
+    for (int q0 = 0; q0 < d; q0 += M * WAVE) {
+        double s1[M], s2[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) { s1[m] = 0.0; s2[m] = 0.0; }
+        for (int64_t tile = 0; tile < tiles; ++tile) {
+            const int64_t j = tile * WAVE + lane + 1;
+            const double tm = (double)j * dt;
+            int64_t lo = 0, hi = n_sk - 1;
+            if (j <= N) {
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi + 1) >> 1;
+                    if (tc[mid] <= tm) lo = mid; else hi = mid - 1;
+                }
+            }
+            const double tau = tm - tc[lo];
+            const int seg_lo = (int)lo, seg_hi = (int)(lo >> 32);
+            const int nvalid = (int)((N - tile * WAVE) < WAVE ? (N - tile * WAVE) : WAVE);
+            for (int s = 0; s < nvalid; ++s) {
+                const int64_t i = ((int64_t)__builtin_amdgcn_readlane(seg_hi, s) << 32) | (uint32_t)__builtin_amdgcn_readlane(seg_lo, s);
+                const double ta = readlane_d(tau, s);
+                const double *x0 = X + ((size_t)c * n_sk + (size_t)i) * d, *v0 = V + ((size_t)c * n_sk + (size_t)i) * d;
+                double sn = 0.0, cs = 1.0;
+                if (BOOMERANG) det_sincos(ta, sn, cs);
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const int q = q0 + m * WAVE + lane;
+                    if (q < d) {
+                        const double xq = x0[q], vq = v0[q];
+                        const double xs = BOOMERANG ? xq * cs + vq * sn : xq + vq * ta;
+                        s1[m] += xs;
+                        s2[m] += xs * xs;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const int q = q0 + m * WAVE + lane;
+            if (q < d) { sum_x[(size_t)c * d + q] = s1[m]; sum_x2[(size_t)c * d + q] = s2[m]; }
+        }
+    }
+}
+
 __global__ void debug_rng_kernel(uint64_t seed, int64_t chain, int kind, int64_t n, double *out) {
     ChainRng rng;
     rng.init(seed, (uint64_t)chain);
@@ -445,6 +502,28 @@ int pdmp_sample_from_skeleton(pdmp_handle h, int64_t C, int64_t n_sk, const doub
     if (rc == PDMP_OK) TRY_OR_CLEAN(hipMemcpy(out, dout, no * 8, hipMemcpyDeviceToHost));
     cleanup();
     return rc;
+}
+
+int pdmp_sample_moments_device(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V, const double *t,
+                               int64_t N, double *sum_x, double *sum_x2, void *stream) {
+    if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
+    if (N <= 0) return fail(PDMP_ERR_ARGUMENT, "N must be positive. Current value: %lld", (long long)N);   // sample.jl:476-478
+    if (n_sk <= 0) return fail(PDMP_ERR_ARGUMENT, "empty history");
+    if (C < 0) return fail(PDMP_ERR_ARGUMENT, "number of chains must be non-negative");
+    if (C == 0) return PDMP_OK;
+    if (!X || !V || !t || !sum_x || !sum_x2) return fail(PDMP_ERR_ARGUMENT, "null buffer");
+    if ((C + 3) / 4 > 0x7fffffffLL) return fail(PDMP_ERR_UNSUPPORTED, "too many chains for one launch");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    EventPair ev;
+    if (int rc = begin_timed(h, s, ev)) return rc;
+    const dim3 grid((unsigned)((C + 3) / 4)), block(256);
+    if (h->cfg.sampler == PDMP_BOOMERANG)
+        hipLaunchKernelGGL(moments_kernel<true>, grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, N, sum_x, sum_x2);
+    else
+        hipLaunchKernelGGL(moments_kernel<false>, grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, N, sum_x, sum_x2);
+    HIP_TRY(hipGetLastError());
+    return end_timed(h, s, ev);
 }
 
 int pdmp_get_timing(pdmp_handle h, pdmp_timing_t *out) {

@@ -92,6 +92,23 @@ def sample_from_skeleton_device(sampler: AbstractPDMP, N: int, X: torch.Tensor, 
     return out
 
 
+def sample_moments_device(sampler: AbstractPDMP, N: int, X: torch.Tensor, V: torch.Tensor, t: torch.Tensor, *, stream=None):
+    """pdmp_sample_moments_device: per-chain sums of x and x^2 over the N samples sample_from_skeleton would
+    return (never materialised).  Returns (sum_x, sum_x2), each ``(C, d)`` on the device."""
+    if N <= 0:
+        raise ArgumentError(f"N must be positive. Current value: {N}")
+    _need_cuda(X, V, t)
+    Cn, n_sk, d = X.shape
+    if d != sampler.dim or V.shape != X.shape or tuple(t.shape) != (Cn, n_sk):
+        raise DimensionMismatch("history tensors do not match the sampler dimension")
+    s1 = torch.empty((Cn, d), dtype=torch.float64, device=X.device)
+    s2 = torch.empty((Cn, d), dtype=torch.float64, device=X.device)
+    with torch.cuda.device(X.device):
+        _lib.check(_lib.lib().pdmp_sample_moments_device(sampler.handle(), Cn, n_sk, _ptr(X), _ptr(V), _ptr(t), int(N),
+                                                         _ptr(s1), _ptr(s2), _stream_ptr(stream)))
+    return s1, s2
+
+
 def kernel_timing(sampler: AbstractPDMP, reset: bool = False) -> dict:
     """hipEvent-timed kernel durations of this sampler's handle (pdmp_get_timing)."""
     tm = _lib.Timing()
@@ -165,17 +182,22 @@ def sample_skeleton_sharded(sampler: AbstractPDMP, n_sk: int, xinit: torch.Tenso
         return res
     if N_samples is None or N_samples <= 0:
         raise ArgumentError(f"N must be positive. Current value: {N_samples}")
-    if compute is None:
-        smp = sample_from_skeleton_device(sampler, N_samples, res["X"], res["V"], res["t"])
+    if gather == "moments" and compute is None:
+        # fused on the device: the d x N x C samples are never written (pdmp_sample_moments_device)
+        s1, s2 = sample_moments_device(sampler, N_samples, res["X"], res["V"], res["t"])
+        d = s1.shape[-1]
+        m = torch.cat([s1.sum(0), s2.sum(0), s1.new_tensor([float(s1.shape[0] * N_samples)])])
+        smp = None
     else:
-        smp = res["samples"]
+        smp = sample_from_skeleton_device(sampler, N_samples, res["X"], res["V"], res["t"]) if compute is None else res["samples"]
     if gather == "samples":
         res["samples"] = _all_gather_rows(smp, C_total, world, group) if world > 1 else smp
         return res
     if gather == "moments":
-        d = smp.shape[-1]
-        flat = smp.reshape(-1, d)
-        m = torch.cat([flat.sum(0), (flat * flat).sum(0), flat.new_tensor([float(flat.shape[0])])])
+        if smp is not None:
+            d = smp.shape[-1]
+            flat = smp.reshape(-1, d)
+            m = torch.cat([flat.sum(0), (flat * flat).sum(0), flat.new_tensor([float(flat.shape[0])])])
         if world > 1:
             dist.all_reduce(m, group=group)
         n = m[-1]

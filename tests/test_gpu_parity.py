@@ -181,3 +181,33 @@ def test_single_chain_api_matches_reference_shapes(engine, oracle):
     assert np.array_equal(smp, smp2)                                 # reproducibility, test_quick.jl:96-108
     h1 = engine.sample_skeleton(engine.ZigZagAD(1, engine.GaussianIso()), 50, 0.0, 1.0, seed=1)   # scalar dispatch
     assert h1.X.shape == (1, 50)
+
+
+@pytest.mark.parametrize("kind,dim", [("ZigZagAD", 50), ("Boomerang", 70), ("BPS", 300)])
+def test_fused_moments_equal_sequential_sums_of_samples(engine, oracle, kind, dim):
+    """pdmp_sample_moments_device against sequential sums over the oracle's sample_from_skeleton."""
+    import torch
+    from pdmpflux.jl_amd import ensemble
+    s, cfg, got, _ = run_pair(engine, oracle, kind, dim, "iso", 5, 80)
+    dev = torch.device("cuda:0")
+    X, V, t = (torch.from_numpy(got[k]).to(dev) for k in ("X", "V", "t"))
+    for N in (1, 64, 130):
+        s1, s2 = ensemble.sample_moments_device(s, N, X, V, t)
+        smp = oracle.sample_from_skeleton(cfg, N, got["X"], got["V"], got["t"])       # (C, N, d)
+        assert np.array_equal(s1.cpu().numpy(), np.cumsum(smp, axis=1)[:, -1, :])      # cumsum = left-to-right sums
+        assert np.array_equal(s2.cpu().numpy(), np.cumsum(smp * smp, axis=1)[:, -1, :])
+
+
+def test_sharded_driver_single_rank_moments(engine, oracle):
+    """ensemble.sample_skeleton_sharded on one rank (no process group): device path, fused moments."""
+    import torch
+    from pdmpflux.jl_amd import ensemble
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", 50, "iso")
+    x, v = make_init("ZigZagAD", 50, 256)
+    dev = torch.device("cuda:0")
+    r = ensemble.sample_skeleton_sharded(s, 400, torch.from_numpy(x).to(dev), torch.from_numpy(v).to(dev), seed=3,
+                                         gather="moments", N_samples=400)
+    assert r["chain_range"] == (0, 256) and int(r["count"]) == 256 * 400
+    assert float(r["mean"].abs().max()) < 0.15 and float((r["var"] - 1).abs().max()) < 0.25
+    ref = oracle.sample_skeleton(cfg, 400, x[:4], v[:4], 3, diagnostics=False)
+    assert np.array_equal(r["t"][:4].cpu().numpy(), ref["t"])
