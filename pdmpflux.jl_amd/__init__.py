@@ -8,12 +8,12 @@ from .targets import GaussianIso, GaussianDiag, Banana, GaussianPrecision
 from .samplers import AbstractPDMP, ZigZag, ZigZagAD, BPS, BPSAD, Boomerang, BoomerangAD
 from .history import PDMPHistory
 from .sample import (sample, sample_skeleton, sample_from_skeleton, sample_skeleton_ensemble,
-                     sample_from_skeleton_ensemble)
+                     sample_from_skeleton_ensemble, sample_skeleton_until)
 
 __all__ = [
     "ArgumentError", "DimensionMismatch", "EngineError", "LIB_PATH",
     "GaussianIso", "GaussianDiag", "Banana", "GaussianPrecision",
     "AbstractPDMP", "ZigZag", "ZigZagAD", "BPS", "BPSAD", "Boomerang", "BoomerangAD",
     "PDMPHistory", "sample", "sample_skeleton", "sample_from_skeleton",
-    "sample_skeleton_ensemble", "sample_from_skeleton_ensemble",
+    "sample_skeleton_ensemble", "sample_from_skeleton_ensemble", "sample_skeleton_until",
 ]

@@ -71,8 +71,63 @@ def sample_skeleton_ensemble(sampler: AbstractPDMP, n_sk: int, xinit, vinit, *, 
     return out
 
 
-def sample_skeleton(sampler: AbstractPDMP, n_sk: int, xinit, vinit, *, seed=None, verbose: bool = True):
-    """sample.jl:253-284.  1-D/2-D dispatch: vectors -> PDMPHistory; (C, d) arrays -> ensemble dict."""
+def _flow_host(sampler: AbstractPDMP, x, v, tau):
+    """Deterministic flow of one state on the host (ZigZagSamplers.jl:80, BouncyParticleSamplers.jl:32,
+    BoomerangSamplers.jl:31) -- only used for the single closing point of the time-horizon variant."""
+    if sampler.sampler_id == 2:
+        c, s_ = math.cos(tau), math.sin(tau)
+        return x * c + v * s_, (-x) * s_ + v * c
+    return x + v * tau, v.copy()
+
+
+def sample_skeleton_until(sampler: AbstractPDMP, T: float, xinit, vinit, *, seed=None, verbose: bool = True,
+                          init_capacity: int = 1024):
+    """Time-horizon variant ``sample_skeleton(sampler, T::Float64, xinit, vinit; seed, init_capacity)``
+    (src/sample.jl:323-439): advance every chain to time ``T``; the history ends with one closing point at
+    exactly ``t == T`` obtained by deterministic flow from the last event before ``T`` (:385-420).
+
+    The events before ``T`` are, by construction of the reference loop, the first events of the fixed-count
+    skeleton for the same seed, so the engine's fixed-count kernel is run with a capacity that doubles
+    (as ``_grow_history`` does, Composites.jl:172-191) until every chain has passed ``T``; the closing point
+    and the trimming (``_trim_history``, :198-214) happen on the host.  Returns a PDMPHistory for vector
+    inputs, a list of PDMPHistory (one per chain, ragged lengths) for ``(C, d)`` inputs."""
+    T = float(T)
+    if not math.isfinite(T) or T < 0:
+        raise ArgumentError(f"T must be finite and non-negative. Current value: {T}")      # sample.jl:335-337
+    x, v, single = _as_init(sampler, xinit, vinit)
+    seed = _seed(seed)
+    cap = max(2, int(init_capacity))
+    while True:
+        out = sample_skeleton_ensemble(sampler, cap, x, v, seed=seed)
+        if T == 0.0 or bool((out["t"][:, -1] > T).all()):
+            break
+        cap *= 2                                                                          # newcap = 2 * size, :375-377
+    hists = []
+    for c in range(x.shape[0]):
+        t = out["t"][c]
+        k = 1 if T == 0.0 else int(np.searchsorted(t, T, side="right"))                   # events with t <= T are recorded (:372)
+        h = history_from_ensemble({key: val[c:c + 1, :k] for key, val in out.items()}, 0)
+        if T > 0.0 and t[k - 1] < T:                                                      # overshoot: closing point at t = T (:385-420)
+            xT, vT = _flow_host(sampler, out["X"][c, k - 1], out["V"][c, k - 1], T - t[k - 1])
+            app = lambda a, val: np.concatenate([a, np.asarray(val, dtype=a.dtype).reshape(a.shape[:-1] + (1,))], axis=-1)
+            h = PDMPHistory(
+                X=app(h.X, xT), V=app(h.V, vT), t=app(h.t, T), is_active=np.ones((h.X.shape[0], k + 1), dtype=bool),
+                horizon=app(h.horizon, out["horizon"][c, k]),        # the state object keeps the overshooting event's horizon
+                ar=app(h.ar, 0.0), errored_bound=app(h.errored_bound, 0), error_value_ar=app(h.error_value_ar, np.zeros(5)),
+                rejected=app(h.rejected, 0), hitting_horizon=app(h.hitting_horizon, 0))
+        hists.append(h)
+    if single:
+        sampler.state = hists[0]
+        return hists[0]
+    return hists
+
+
+def sample_skeleton(sampler: AbstractPDMP, n_sk, xinit, vinit, *, seed=None, verbose: bool = True, init_capacity: int = 1024):
+    """sample.jl:253-284 (``n_sk::Int``: fixed number of skeleton points) and :323-439 (``T::Float64``: time
+    horizon) -- dispatch on the type of the second argument, as Julia does.  Vectors -> PDMPHistory; (C, d)
+    arrays -> ensemble dict (fixed count) / list of PDMPHistory (time horizon)."""
+    if isinstance(n_sk, float):
+        return sample_skeleton_until(sampler, n_sk, xinit, vinit, seed=seed, verbose=verbose, init_capacity=init_capacity)
     if n_sk <= 0:
         raise ArgumentError(f"n_sk must be positive. Current value: {n_sk}")
     x, v, single = _as_init(sampler, xinit, vinit)

@@ -211,3 +211,27 @@ def test_sharded_driver_single_rank_moments(engine, oracle):
     assert float(r["mean"].abs().max()) < 0.15 and float((r["var"] - 1).abs().max()) < 0.25
     ref = oracle.sample_skeleton(cfg, 400, x[:4], v[:4], 3, diagnostics=False)
     assert np.array_equal(r["t"][:4].cpu().numpy(), ref["t"])
+
+
+def test_time_horizon_variant(engine, oracle):
+    """sample_skeleton(sampler, T::Float64, ...) (src/sample.jl:323-439): t[end] == T exactly and monotone
+    (test/test_samplers.jl:56-62); the events before T are the fixed-count skeleton's; closing point by flow."""
+    P = engine
+    s = P.ZigZagAD(3, P.GaussianIso())
+    x0, v0 = np.zeros(3), np.ones(3)
+    T = 25.0
+    h = P.sample_skeleton(s, T, x0, v0, seed=42, init_capacity=8)        # forces several capacity doublings
+    assert h.t[-1] == T and h.t[0] == 0.0 and (np.diff(h.t) > 0).all()
+    n = len(h.t)
+    fixed = P.sample_skeleton(s, n + 3, x0, v0, seed=42)
+    assert np.array_equal(h.t[:-1], fixed.t[:n - 1]) and np.array_equal(h.X[:, :-1], fixed.X[:, :n - 1])
+    assert fixed.t[n - 1] > T                                             # the next event overshoots
+    assert np.array_equal(h.X[:, -1], fixed.X[:, n - 2] + fixed.V[:, n - 2] * (T - fixed.t[n - 2]))
+    assert np.array_equal(h.V[:, -1], fixed.V[:, n - 2])
+    assert h.ar[-1] == 0.0 and h.rejected[-1] == 0 and h.horizon[-1] == fixed.horizon[n - 1]
+    smp = P.sample_from_skeleton(s, 100, h)                               # t[end] == T is the time scale of the samples
+    assert smp.shape == (3, 100) and np.isfinite(smp).all()
+    h0 = P.sample_skeleton(s, 0.0, x0, v0, seed=42)                       # T == 0: the initial point alone (:356-359)
+    assert len(h0.t) == 1 and h0.t[0] == 0.0
+    hs = P.sample_skeleton(s, 5.0, np.zeros((4, 3)), np.ones((4, 3)), seed=1)   # ensemble: ragged lengths
+    assert len(hs) == 4 and all(hh.t[-1] == 5.0 for hh in hs) and len({len(hh.t) for hh in hs}) > 1

@@ -68,6 +68,9 @@ def test_error_conventions(engine):
         P.sample_skeleton(s, 10, np.zeros(3), np.ones(3), seed=1)              # AbstractPDMP.jl:96-98
     with pytest.raises(P.DimensionMismatch):
         P.sample_skeleton(s, 10, np.zeros(2), np.ones(3), seed=1)
+    for badT in (-1.0, float("inf"), float("nan")):                            # sample.jl:335-337
+        with pytest.raises(P.ArgumentError):
+            P.sample_skeleton(s, badT, np.zeros(2), np.ones(2), seed=1)
     s1 = P.ZigZagAD(1, t)
     for x0, v0 in ((float("nan"), 1.0), (0.0, float("inf")), (float("-inf"), 1.0)):
         with pytest.raises(P.ArgumentError):
