@@ -123,6 +123,14 @@ int pdmp_sample_from_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, con
                                      const double *V, const double *t, int64_t N, int32_t discard_vt,
                                      double *out, void *stream);
 
+/* sample_from_skeleton(sampler, dt::Float64, history; discard_vt) (src/sample.jl:573-646): samples at j*dt,
+ * j = 1..N; the caller passes N = floor(t[end]/dt) (:608).  dt == 0 selects the N::Int method above. */
+int pdmp_sample_from_skeleton_dt(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
+                                 const double *t, int64_t N, double dt, int32_t discard_vt, double *out);
+int pdmp_sample_from_skeleton_dt_device(pdmp_handle h, int64_t C, int64_t n_sk, const double *X,
+                                        const double *V, const double *t, int64_t N, double dt,
+                                        int32_t discard_vt, double *out, void *stream);
+
 /* The step right after the path: per-chain sums of x and x^2 over the N samples that
  * sample_from_skeleton(sampler, N, history) (src/sample.jl:475-513) would return, without writing them:
  * sum_x, sum_x2 are d x C (DEVICE pointers).  mean = sum_x / N, var = sum_x2 / N - mean^2 per chain, or pooled. */

@@ -57,6 +57,8 @@ def lib():
                                           dp, dp, dp, dp, dp, ip, dp, ip, ip, C.c_int]
         L.orc_sample_from_skeleton.argtypes = [C.POINTER(_Cfg), C.c_int64, C.c_int64, dp, dp, dp, C.c_int64,
                                                C.c_int, dp, C.c_int]
+        L.orc_sample_from_skeleton_dt.argtypes = [C.POINTER(_Cfg), C.c_int64, C.c_int64, dp, dp, dp, C.c_int64,
+                                                  C.c_double, C.c_int, dp, C.c_int]
         L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
         L.orc_log.argtypes = [C.c_double]; L.orc_log.restype = C.c_double
         L.orc_sincos.argtypes = [C.c_double, dp, dp]
@@ -157,7 +159,7 @@ def sample_skeleton(cfg: Config, n_sk: int, xinit, vinit, seed: int, chain_id_of
     return out
 
 
-def sample_from_skeleton(cfg: Config, N: int, X, V, t, discard_vt: bool = True, n_threads: int = 0):
+def sample_from_skeleton(cfg: Config, N: int, X, V, t, discard_vt: bool = True, n_threads: int = 0, dt: float = 0.0):
     X = np.ascontiguousarray(X, dtype=np.float64); V = np.ascontiguousarray(V, dtype=np.float64)
     t = np.ascontiguousarray(t, dtype=np.float64)
     if X.ndim == 2:
@@ -166,8 +168,8 @@ def sample_from_skeleton(cfg: Config, N: int, X, V, t, discard_vt: bool = True, 
     rows = d if discard_vt else 2 * d + 1
     out = np.empty((Cn, max(int(N), 0), rows))
     c = cfg.c()
-    _check(lib().orc_sample_from_skeleton(C.byref(c), Cn, n_sk, _dp(X), _dp(V), _dp(t), int(N), int(discard_vt),
-                                          _dp(out), n_threads))
+    _check(lib().orc_sample_from_skeleton_dt(C.byref(c), Cn, n_sk, _dp(X), _dp(V), _dp(t), int(N), float(dt),
+                                             int(discard_vt), _dp(out), n_threads))
     return out
 
 

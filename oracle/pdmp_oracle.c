@@ -719,6 +719,14 @@ int orc_sample_skeleton(const orc_config_t *cfg_in, int64_t C, int64_t n_sk, int
 int orc_sample_from_skeleton(const orc_config_t *cfg, int64_t C, int64_t n_sk, const double *X,
                              const double *V, const double *t, int64_t N, int discard_vt, double *out,
                              int n_threads) {
+    return orc_sample_from_skeleton_dt(cfg, C, n_sk, X, V, t, N, 0.0, discard_vt, out, n_threads);
+}
+
+/* dt_in > 0: the `dt::Float64` method (sample.jl:573-646): samples at j*dt_in, j = 1..N (the caller passes
+ * N = floor(t[end]/dt), :608); dt_in <= 0: the `N::Int` method (:475-513), dt = t[end]/N. */
+int orc_sample_from_skeleton_dt(const orc_config_t *cfg, int64_t C, int64_t n_sk, const double *X,
+                                const double *V, const double *t, int64_t N, double dt_in, int discard_vt, double *out,
+                                int n_threads) {
     if (N <= 0) FAIL(-1, "N must be positive. Current value: %lld", (long long)N);           /* :476-478 */
     if (n_sk <= 0) FAIL(-1, "empty history");
     const int d = cfg->dim;
@@ -730,7 +738,7 @@ int orc_sample_from_skeleton(const orc_config_t *cfg, int64_t C, int64_t n_sk, c
     for (int64_t c = 0; c < C; ++c) {
         const double *Xc = X + (size_t)c * n_sk * d, *Vc = V + (size_t)c * n_sk * d, *tc = t + (size_t)c * n_sk;
         double *oc = out + (size_t)c * N * rows;
-        const double dt = tc[n_sk - 1] / (double)N;                                          /* :483-484 */
+        const double dt = dt_in > 0.0 ? dt_in : tc[n_sk - 1] / (double)N;                    /* :483-484 */
         int64_t i = 0;
         for (int64_t j = 1; j <= N; ++j) {
             double tm = (double)j * dt;                                                      /* :492 */

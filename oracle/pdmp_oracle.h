@@ -76,6 +76,10 @@ int orc_sample_from_skeleton(const orc_config_t *cfg, int64_t C, int64_t n_sk,
                              const double *X, const double *V, const double *t,
                              int64_t N, int discard_vt, double *out, int n_threads);
 
+int orc_sample_from_skeleton_dt(const orc_config_t *cfg, int64_t C, int64_t n_sk,
+                                const double *X, const double *V, const double *t,
+                                int64_t N, double dt, int discard_vt, double *out, int n_threads);
+
 /* --- pieces exposed for known-answer tests --- */
 void   orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 double orc_log(double x);

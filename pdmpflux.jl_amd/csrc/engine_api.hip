@@ -59,14 +59,14 @@ namespace {
 template <bool BOOMERANG>
 __global__ __launch_bounds__(256) void from_skeleton_kernel(int d, int64_t C, int64_t n_sk, const double *X,
                                                             const double *V, const double *t, int64_t N,
-                                                            int discard_vt, double *out) {
+                                                            double dt_in, int discard_vt, double *out) {
     const int lane = lane_id();
     const int64_t tiles = (N + WAVE - 1) / WAVE;
     const int64_t w = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (w >= C * tiles) return;
     const int64_t c = w / tiles, tile = w % tiles;
     const double *tc = t + (size_t)c * n_sk;
-    const double dt = tc[n_sk - 1] / (double)N;                       // :483-484
+    const double dt = dt_in > 0.0 ? dt_in : tc[n_sk - 1] / (double)N; // :483-484; dt_in: the dt::Float64 method, :573-646
     const int64_t j = tile * WAVE + lane + 1;                         // 1-based sample index
     const double tm = (double)j * dt;                                 // :492
     int64_t lo = 0, hi = n_sk - 1;
@@ -459,7 +459,13 @@ int pdmp_sample_skeleton(pdmp_handle h, int64_t C, int64_t n_sk, int64_t chain_i
 
 int pdmp_sample_from_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
                                      const double *t, int64_t N, int32_t discard_vt, double *out, void *stream) {
+    return pdmp_sample_from_skeleton_dt_device(h, C, n_sk, X, V, t, N, 0.0, discard_vt, out, stream);
+}
+
+int pdmp_sample_from_skeleton_dt_device(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
+                                        const double *t, int64_t N, double dt, int32_t discard_vt, double *out, void *stream) {
     if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
+    if (!(dt >= 0.0) || !std::isfinite(dt)) return fail(PDMP_ERR_ARGUMENT, "dt must be finite and non-negative");
     if (N <= 0) return fail(PDMP_ERR_ARGUMENT, "N must be positive. Current value: %lld", (long long)N);   // sample.jl:476-478
     if (n_sk <= 0) return fail(PDMP_ERR_ARGUMENT, "empty history");
     if (C < 0) return fail(PDMP_ERR_ARGUMENT, "number of chains must be non-negative");
@@ -472,15 +478,20 @@ int pdmp_sample_from_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, con
     EventPair ev;
     if (int rc = begin_timed(h, s, ev)) return rc;
     if (h->cfg.sampler == PDMP_BOOMERANG)
-        hipLaunchKernelGGL(from_skeleton_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, (int)discard_vt, out);
+        hipLaunchKernelGGL(from_skeleton_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, dt, (int)discard_vt, out);
     else
-        hipLaunchKernelGGL(from_skeleton_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, (int)discard_vt, out);
+        hipLaunchKernelGGL(from_skeleton_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, dt, (int)discard_vt, out);
     HIP_TRY(hipGetLastError());
     return end_timed(h, s, ev);
 }
 
 int pdmp_sample_from_skeleton(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
                               const double *t, int64_t N, int32_t discard_vt, double *out) {
+    return pdmp_sample_from_skeleton_dt(h, C, n_sk, X, V, t, N, 0.0, discard_vt, out);
+}
+
+int pdmp_sample_from_skeleton_dt(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
+                                 const double *t, int64_t N, double dt, int32_t discard_vt, double *out) {
     if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
     if (N <= 0) return fail(PDMP_ERR_ARGUMENT, "N must be positive. Current value: %lld", (long long)N);
     if (n_sk <= 0) return fail(PDMP_ERR_ARGUMENT, "empty history");
@@ -489,16 +500,16 @@ int pdmp_sample_from_skeleton(pdmp_handle h, int64_t C, int64_t n_sk, const doub
     HIP_TRY(hipSetDevice(h->device));
     const size_t d = (size_t)h->cfg.dim, ne = (size_t)C * (size_t)n_sk;
     const size_t rows = discard_vt ? d : 2 * d + 1, no = (size_t)C * (size_t)N * rows;
-    double *dX = nullptr, *dV = nullptr, *dt = nullptr, *dout = nullptr;
-    auto cleanup = [&]() { (void)hipFree(dX); (void)hipFree(dV); (void)hipFree(dt); (void)hipFree(dout); };
+    double *dX = nullptr, *dV = nullptr, *dt_buf = nullptr, *dout = nullptr;
+    auto cleanup = [&]() { (void)hipFree(dX); (void)hipFree(dV); (void)hipFree(dt_buf); (void)hipFree(dout); };
     TRY_OR_CLEAN(hipMalloc(&dX, ne * d * 8));
     TRY_OR_CLEAN(hipMalloc(&dV, ne * d * 8));
-    TRY_OR_CLEAN(hipMalloc(&dt, ne * 8));
+    TRY_OR_CLEAN(hipMalloc(&dt_buf, ne * 8));
     TRY_OR_CLEAN(hipMalloc(&dout, no * 8));
     TRY_OR_CLEAN(hipMemcpy(dX, X, ne * d * 8, hipMemcpyHostToDevice));
     TRY_OR_CLEAN(hipMemcpy(dV, V, ne * d * 8, hipMemcpyHostToDevice));
-    TRY_OR_CLEAN(hipMemcpy(dt, t, ne * 8, hipMemcpyHostToDevice));
-    int rc = pdmp_sample_from_skeleton_device(h, C, n_sk, dX, dV, dt, N, discard_vt, dout, nullptr);
+    TRY_OR_CLEAN(hipMemcpy(dt_buf, t, ne * 8, hipMemcpyHostToDevice));
+    int rc = pdmp_sample_from_skeleton_dt_device(h, C, n_sk, dX, dV, dt_buf, N, dt, discard_vt, dout, nullptr);
     if (rc == PDMP_OK) TRY_OR_CLEAN(hipMemcpy(out, dout, no * 8, hipMemcpyDeviceToHost));
     cleanup();
     return rc;

@@ -139,8 +139,9 @@ def sample_skeleton(sampler: AbstractPDMP, n_sk, xinit, vinit, *, seed=None, ver
     return hist
 
 
-def sample_from_skeleton_ensemble(sampler: AbstractPDMP, N: int, X, V, t, *, discard_vt: bool = True):
-    """X, V: (C, n_sk, d); t: (C, n_sk).  Returns (C, N, rows) with rows = d or 2d+1."""
+def sample_from_skeleton_ensemble(sampler: AbstractPDMP, N: int, X, V, t, *, discard_vt: bool = True, dt: float = 0.0):
+    """X, V: (C, n_sk, d); t: (C, n_sk).  Returns (C, N, rows) with rows = d or 2d+1.  ``dt > 0``: samples at
+    ``j*dt`` (the ``dt::Float64`` method); the caller guarantees ``N*dt <= t[:, -1]``."""
     if N <= 0:
         raise ArgumentError(f"N must be positive. Current value: {N}")          # sample.jl:476-478
     X = np.ascontiguousarray(X, dtype=np.float64); V = np.ascontiguousarray(V, dtype=np.float64)
@@ -150,14 +151,30 @@ def sample_from_skeleton_ensemble(sampler: AbstractPDMP, N: int, X, V, t, *, dis
         raise DimensionMismatch("history arrays do not match the sampler dimension")
     rows = d if discard_vt else 2 * d + 1
     out = np.empty((Cn, N, rows))
-    _lib.check(_lib.lib().pdmp_sample_from_skeleton(sampler.handle(), Cn, n_sk, _vp(X), _vp(V), _vp(t), int(N),
-                                                    int(bool(discard_vt)), _vp(out)))
+    _lib.check(_lib.lib().pdmp_sample_from_skeleton_dt(sampler.handle(), Cn, n_sk, _vp(X), _vp(V), _vp(t), int(N),
+                                                       float(dt), int(bool(discard_vt)), _vp(out)))
     return out
 
 
-def sample_from_skeleton(sampler: AbstractPDMP, N: int, history, *, discard_vt: bool = True):
-    """sample.jl:475-513.  ``history`` is a PDMPHistory (-> ``rows x N`` matrix, Fortran-ordered view) or
-    an ensemble dict (-> (C, N, rows))."""
+def sample_from_skeleton(sampler: AbstractPDMP, N, history, *, discard_vt: bool = True):
+    """``N::Int``: sample.jl:475-513 (N equispaced samples, dt = t[end]/N).  ``dt::Float64``: :573-646
+    (samples at j*dt, j = 1..floor(t[end]/dt)) -- dispatch on the type of the second argument, as Julia does.
+    ``history`` is a PDMPHistory (-> ``rows x N`` matrix, Fortran-ordered view) or, for the Int method, an
+    ensemble dict (-> (C, N, rows))."""
+    if isinstance(N, float):
+        dt = N
+        if isinstance(history, dict):
+            raise ArgumentError("the dt::Float64 method takes one PDMPHistory (sample counts differ per chain)")
+        if not (dt > 0.0) or not math.isfinite(dt):
+            raise ArgumentError(f"dt must be positive and finite. Current value: {dt}")
+        n = int(math.floor(history.t[-1] / dt))                                  # n_skel = Int(floor(T_end / dt)), :608
+        rows = history.X.shape[0] if discard_vt else 2 * history.X.shape[0] + 1
+        if n <= 0:
+            return np.empty((rows, 0))
+        X = np.ascontiguousarray(history.X.T)[None]
+        V = np.ascontiguousarray(history.V.T)[None]
+        t = np.ascontiguousarray(history.t)[None]
+        return sample_from_skeleton_ensemble(sampler, n, X, V, t, discard_vt=discard_vt, dt=dt)[0].T
     if N <= 0:
         raise ArgumentError(f"N must be positive. Current value: {N}")
     if isinstance(history, dict):

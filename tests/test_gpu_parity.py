@@ -235,3 +235,18 @@ def test_time_horizon_variant(engine, oracle):
     assert len(h0.t) == 1 and h0.t[0] == 0.0
     hs = P.sample_skeleton(s, 5.0, np.zeros((4, 3)), np.ones((4, 3)), seed=1)   # ensemble: ragged lengths
     assert len(hs) == 4 and all(hh.t[-1] == 5.0 for hh in hs) and len({len(hh.t) for hh in hs}) > 1
+
+
+def test_sample_from_skeleton_dt_method(engine, oracle):
+    """sample_from_skeleton(sampler, dt::Float64, history) (src/sample.jl:573-646): n = floor(t[end]/dt) samples at j*dt."""
+    s, cfg, got, _ = run_pair(engine, oracle, "ZigZagAD", 5, "iso", 1, 200)
+    h = engine.sample_skeleton(s, 200, *make_init("ZigZagAD", 5, 1), seed=11)
+    h = engine.PDMPHistory(got["X"][0].T, got["V"][0].T, got["t"][0], np.ones((5, 200), bool), got["horizon"][0], got["ar"][0],
+                           got["errored_bound"][0], got["error_value_ar"][0].T, got["rejected"][0], got["hitting_horizon"][0])
+    dt = 0.37
+    a = engine.sample_from_skeleton(s, dt, h, discard_vt=False)
+    n = int(np.floor(h.t[-1] / dt))
+    assert a.shape == (11, n)
+    b = oracle.sample_from_skeleton(cfg, n, got["X"], got["V"], got["t"], discard_vt=False, dt=dt)[0].T
+    assert np.array_equal(a, b)
+    assert np.array_equal(a[10], np.arange(1, n + 1) * dt)                 # out[2d+1, j] = j*dt, :640
