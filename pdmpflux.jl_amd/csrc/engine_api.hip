@@ -15,6 +15,9 @@ using namespace pdmp;
 namespace {
 
 thread_local char g_err[512] = "";
+#ifdef PDMP_STAMP
+unsigned long long *g_stamps = nullptr;
+#endif
 
 int fail(int code, const char *fmt, ...) {
     va_list ap;
@@ -354,6 +357,13 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
         p.EB = diag->errored_bound; p.RJ = diag->rejected; p.HH = diag->hitting_horizon;
     }
     p.status = h->d_status;
+#ifdef PDMP_STAMP
+    static unsigned long long *d_stamps = nullptr;
+    if (!d_stamps) { HIP_TRY(hipMalloc(&d_stamps, 64)); }
+    HIP_TRY(hipMemset(d_stamps, 0, 64));
+    p.stamps = d_stamps;
+    g_stamps = d_stamps;
+#endif
     hipStream_t s = (hipStream_t)stream;
     GroupParams gp;
     memset(&gp, 0, sizeof gp);
@@ -536,6 +546,14 @@ int pdmp_sample_moments_device(pdmp_handle h, int64_t C, int64_t n_sk, const dou
     HIP_TRY(hipGetLastError());
     return end_timed(h, s, ev);
 }
+
+#ifdef PDMP_STAMP
+int pdmp_debug_stamps(unsigned long long *out6) {       // diagnostic build only
+    if (!g_stamps) return -1;
+    (void)hipDeviceSynchronize();
+    return hipMemcpy(out6, g_stamps, 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+#endif
 
 int pdmp_get_timing(pdmp_handle h, pdmp_timing_t *out) {
     if (!h || !out) return fail(PDMP_ERR_ARGUMENT, "null argument");

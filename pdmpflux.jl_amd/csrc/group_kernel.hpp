@@ -280,7 +280,13 @@ struct GroupChain {
         bool found = false;
         tpo = __builtin_huge_val();
         typename Tgt::template Sh<Dual> shf{};
+#ifdef PDMP_STAMP
+        if (lane == 0 && p.stamps) atomicAdd(&p.stamps[7], 1ull);
+#endif
         for (int j = 0; j < GNG - 1; ++j) {
+#ifdef PDMP_STAMP
+            if (lane == 0 && p.stamps) atomicAdd(&p.stamps[6], 1ull);
+#endif
             const double t0 = (double)j * h, t1 = (j == GNG - 2) ? harg : (double)(j + 1) * h;
             double bsum = 0.0;
             if constexpr (!FDM) {
@@ -665,7 +671,15 @@ struct GroupChain {
         bool propose = false;
         int mode = FRESH;
         double hB = horizon;
+#ifdef PDMP_STAMP
+        unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+#define STAMP(k) do { unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[k] += now_ - st_last; st_last = now_; } while (0)
+        unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#else
+#define STAMP(k)
+#endif
         while (__ballot(!done) != 0ull) {
+            STAMP(5);
             if (!done && !propose) {
                 // one_step_of_thinning! (:65-85), erroneous_acceptance_rate! (:131-151) or if_reject! (:188-203)
                 const double harg = (mode == ERR) ? horizon / 2 : ((mode == REUSE) ? hB : horizon);
@@ -700,10 +714,12 @@ struct GroupChain {
                 mode = FRESH;
                 if (++it > cap) { done = true; if (g == 0) atomicAdd(&p.status[0], 1); }
             }
+            STAMP(0);
             if (!done && propose) {
                 double raw;
                 const double lam = true_rate(tp, raw);                    // ac_step!, :113-129
                 ar = lam / lb;
+                STAMP(1);
                 propose = false;
                 if (ar > 1.0) {
                     mode = ERR;
@@ -711,11 +727,14 @@ struct GroupChain {
                     const double u = rng.uniform();
                     if (u < ar) {                                         // if_accept!, :170-186
                         flow_state(tp);
+                        STAMP(2);
                         velocity_jump(raw);
+                        STAMP(3);
                         t = t + tp + ts;
                         ts = 0.0;
                         tp = 0.0;
                         record(c, k, t, horizon, ar, errored, ev, rejected, hits);
+                        STAMP(4);
                         errored = 0; rejected = 0; hits = 0;              // get_event_state!, :28-31
 #pragma unroll
                         for (int q = 0; q < 5; ++q) ev[q] = 0.0;
@@ -728,6 +747,9 @@ struct GroupChain {
                 if (++it > cap && !done) { done = true; if (g == 0) atomicAdd(&p.status[0], 1); }
             }
         }
+#ifdef PDMP_STAMP
+        if (lane == 0 && p.stamps) for (int q = 0; q < 6; ++q) atomicAdd(&p.stamps[q], st_acc[q]);
+#endif
         if (chain_ok) {                                                   // hand-off / final state
             for (int s = 0; s < K; ++s) {
                 const int i = s * G + g;

@@ -26,6 +26,7 @@ struct SkelParams {
     double *X, *V, *t, *H, *AR, *EV;
     int32_t *EB, *RJ, *HH;
     int32_t *status;   // [0] chains that hit the iteration cap, [1] Q11 guard events, [2] lost hand-offs
+    unsigned long long *stamps;   // diagnostic build only (-DPDMP_STAMP): per-phase cycle sums, else null
 };
 
 __device__ __forceinline__ bool uni(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }
