@@ -53,7 +53,7 @@ enum { PDMP_DERIV_FORWARD = 0 /* "ForwardDiff": exact forward-mode duals */,
 typedef struct pdmp_config_t {
     int32_t sampler;            /* PDMP_ZIGZAG | PDMP_BPS | PDMP_BOOMERANG */
     int32_t dim;                /* > 0 */
-    int32_t grid_size;          /* 2..64; 0 (Brent) is PDMP_ERR_UNSUPPORTED */
+    int32_t grid_size;          /* 2..64 grid bound; 0 = Brent constant bound (UpperBound.jl:18-36) */
     int32_t vectorized_bound;   /* ZigZag default 1; forced 0 for BPS/Boomerang */
     int32_t signed_bound;       /* default 1 */
     int32_t adaptive;           /* default 1 */

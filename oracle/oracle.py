@@ -203,7 +203,7 @@ def rng_dump(seed: int, chain: int, kind: int, n: int) -> np.ndarray:
 
 def upper_bound(cfg: Config, x, v, horizon: float):
     x = np.ascontiguousarray(x, dtype=np.float64); v = np.ascontiguousarray(v, dtype=np.float64)
-    n = cfg.grid_size
+    n = cfg.grid_size if cfg.grid_size > 0 else 2
     grid, box, cum = np.empty(n), np.empty(n - 1), np.empty(n)
     c = cfg.c()
     step = lib().orc_upper_bound(C.byref(c), _dp(x), _dp(v), horizon, _dp(grid), _dp(box), _dp(cum))

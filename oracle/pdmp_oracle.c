@@ -414,10 +414,20 @@ static double true_rate(const orc_config_t *cfg, ws_t *w, double t) {
     return pmax(0.0, vsum(cfg, w->tmp, w->d)) + cfg->refresh_rate;   /* BPS :39-42, Boomerang :38-41 */
 }
 
+static double brent_max_rate(const orc_config_t *cfg, ws_t *w, double x_lower, double x_upper);
+
 /* upper_bound_grid_vect (UpperBound.jl:203-247) / upper_bound_grid (:92-137); chosen as in
  * init_state (AbstractPDMP.jl:121-136).  Fills w->grid/box/cum/step. */
 static void upper_bound(const orc_config_t *cfg, ws_t *w, const double *x, const double *v, double horizon) {
     const int d = w->d, n = w->n;
+    if (cfg->grid_size == 0) {                      /* constant bound, AbstractPDMP.jl:121-125 (x, v are the state: w->x, w->v) */
+        const double m = brent_max_rate(cfg, w, 0.0, horizon);
+        w->grid[0] = 0.0; w->grid[1] = horizon;     /* :27 */
+        w->box[0] = m;                              /* refresh_rate = 0.0 default: nothing added, :29 */
+        w->cum[0] = 0.0; w->cum[1] = m * (horizon - 0.0);   /* :32-33 */
+        w->step = horizon - 0.0;                    /* :35 */
+        return;
+    }
     /* t = range(0, stop=horizon, length=n); step_size = t[2]-t[1]  (:204-205 / :94-95).
      * Build-defined rounding: step = horizon/(n-1), t_j = j*step, t_{n-1} = horizon
      * (Julia's TwicePrecision range may differ in the last bit -- unpinned). */
@@ -499,6 +509,61 @@ static void upper_bound(const orc_config_t *cfg, ws_t *w, const double *x, const
     }
 }
 
+/* upper_bound_constant, UpperBound.jl:18-36: maximise the UNSIGNED rate (AbstractPDMP.jl:121-125) on
+ * [0, horizon] with Brent's method and bound it by that one constant (2-point grid, cum_sum = [0, max*horizon]).
+ * The minimiser is Optim.jl's univariate Brent() (compat "1.9.4, 2", Project.toml:35 -- third-party, not in the
+ * reference tree, version unpinned): Brent (1973) golden-section + parabolic interpolation with Optim's default
+ * rel_tol = sqrt(eps), abs_tol = eps, iterations = 1000, restated from the published algorithm. */
+static double brent_max_rate(const orc_config_t *cfg, ws_t *w, double x_lower, double x_upper) {
+    const double rel_tol = 1.4901161193847656e-08, abs_tol = 2.220446049250313e-16;
+    const double golden = 0.5 * (3.0 - 2.23606797749979);      /* (3 - sqrt(5)) / 2 */
+    double new_x = x_lower + golden * (x_upper - x_lower);
+    double new_f = -true_rate(cfg, w, new_x);                   /* func_min = x -> -func(x), :21 */
+    double step = 0.0, old_step = 0.0;
+    double old_x = new_x, old_old_x = new_x, old_f = new_f, old_old_f = new_f;
+    for (int iteration = 0; iteration < 1000;) {
+        double p = 0.0, q = 0.0;
+        const double x_tol = rel_tol * fabs(new_x) + abs_tol;
+        const double x_mid = (x_upper + x_lower) / 2;
+        if (fabs(new_x - x_mid) <= 2 * x_tol - (x_upper - x_lower) / 2) break;        /* converged */
+        ++iteration;
+        if (fabs(old_step) > x_tol) {                           /* parabolic interpolation through the three best points */
+            double r = (new_x - old_x) * (new_f - old_old_f);
+            q = (new_x - old_old_x) * (new_f - old_f);
+            p = (new_x - old_old_x) * q - (new_x - old_x) * r;
+            q = 2 * (q - r);
+            if (q > 0) p = -p; else q = -q;
+        }
+        if (fabs(p) < fabs(q * old_step / 2) && p < q * (x_upper - new_x) && p < q * (new_x - x_lower)) {
+            old_step = step;
+            step = p / q;
+            const double x_temp = new_x + step;                 /* not too close to the ends of the bracket */
+            if ((x_temp - x_lower) < 2 * x_tol || (x_upper - x_temp) < 2 * x_tol)
+                step = (new_x < x_mid) ? x_tol : -x_tol;
+        } else {                                                /* golden section */
+            old_step = (new_x < x_mid) ? x_upper - new_x : x_lower - new_x;
+            step = golden * old_step;
+        }
+        const double xt = (fabs(step) >= x_tol) ? new_x + step : new_x + ((step > 0) ? x_tol : -x_tol);
+        const double ft = -true_rate(cfg, w, xt);
+        if (ft < new_f) {
+            if (xt < new_x) x_upper = new_x; else x_lower = new_x;
+            old_old_x = old_x; old_old_f = old_f;
+            old_x = new_x; old_f = new_f;
+            new_x = xt; new_f = ft;
+        } else {
+            if (xt < new_x) x_lower = xt; else x_upper = xt;
+            if (ft <= old_f || old_x == new_x) {
+                old_old_x = old_x; old_old_f = old_f;
+                old_x = xt; old_f = ft;
+            } else if (ft <= old_old_f || old_old_x == new_x || old_old_x == old_x) {
+                old_old_x = xt; old_old_f = ft;
+            }
+        }
+    }
+    return -new_f;                                              /* box_max = [-Optim.minimum(result)], :28 */
+}
+
 /* next_event, UpperBound.jl:264-273 */
 void orc_next_event(int n, const double *grid, const double *box, const double *cum, double step,
                     double E, double *tp, double *lb) {
@@ -512,7 +577,8 @@ void orc_next_event(int n, const double *grid, const double *box, const double *
 
 double orc_upper_bound(const orc_config_t *cfg, const double *x, const double *v, double horizon,
                        double *grid, double *box_max, double *cum_sum) {
-    ws_t w; ws_init(&w, cfg->dim, cfg->grid_size);
+    ws_t w; ws_init(&w, cfg->dim, cfg->grid_size == 0 ? 2 : cfg->grid_size);
+    memcpy(w.x, x, (size_t)cfg->dim * 8); memcpy(w.v, v, (size_t)cfg->dim * 8);
     upper_bound(cfg, &w, x, v, horizon);
     memcpy(grid, w.grid, (size_t)w.n * 8); memcpy(box_max, w.box, (size_t)(w.n - 1) * 8);
     memcpy(cum_sum, w.cum, (size_t)w.n * 8);
@@ -583,7 +649,6 @@ static int velocity_jump(const orc_config_t *cfg, ws_t *w, rng_t *rng) {
 int orc_normalize_config(orc_config_t *c) {
     if (c->dim <= 0) FAIL(-1, "dimension dim must be positive. Current value: %d", c->dim);           /* ZigZagSamplers.jl:62-64 */
     if (c->grid_size < 0) FAIL(-1, "grid_size must be non-negative. Current value: %d", c->grid_size); /* :66-68 */
-    if (c->grid_size == 0) FAIL(-1, "grid_size == 0 (Brent constant bound) is not restated (SURVEY f4)");
     if (c->grid_size == 1) FAIL(-1, "grid_size == 1: range(...)[2] is a BoundsError in the reference");
     if (c->sampler < 0 || c->sampler > 2) FAIL(-1, "unknown sampler id %d", c->sampler);
     if (c->target_id < 0 || c->target_id > 3) FAIL(-1, "unknown target id %d", c->target_id);
@@ -694,7 +759,7 @@ int orc_sample_skeleton(const orc_config_t *cfg_in, int64_t C, int64_t n_sk, int
 #endif
 #pragma omp parallel num_threads(n_threads)
     {
-        ws_t w; int ok = ws_init(&w, d, cfg.grid_size) == 0;
+        ws_t w; int ok = ws_init(&w, d, cfg.grid_size == 0 ? 2 : cfg.grid_size) == 0;
 #pragma omp for schedule(dynamic, 4)
         for (int64_t c = 0; c < C; ++c) {
             if (!ok) { rc = -1; continue; }

@@ -179,13 +179,12 @@ __global__ void debug_rng_kernel(uint64_t seed, int64_t chain, int kind, int64_t
 int normalize_config(pdmp_config_t &c) {
     if (c.dim <= 0) return fail(PDMP_ERR_ARGUMENT, "dimension dim must be positive. Current value: %d", c.dim);          // ZigZagSamplers.jl:62-64
     if (c.grid_size < 0) return fail(PDMP_ERR_ARGUMENT, "grid_size must be non-negative. Current value: %d", c.grid_size); // :66-68
-    if (c.grid_size == 0) return fail(PDMP_ERR_UNSUPPORTED, "grid_size == 0 (Brent constant bound, UpperBound.jl:18-36) is not implemented");
     if (c.grid_size == 1 || c.grid_size > WAVE) return fail(PDMP_ERR_UNSUPPORTED, "grid_size must be in 2..64. Current value: %d", c.grid_size);
     if (c.sampler < PDMP_ZIGZAG || c.sampler > PDMP_BOOMERANG) return fail(PDMP_ERR_ARGUMENT, "unknown sampler id %d", c.sampler);
     if (c.target_id < 0 || c.target_id > PDMP_T_GAUSS_DENSE) return fail(PDMP_ERR_ARGUMENT, "unknown target id %d", c.target_id);
     if (c.target_id == PDMP_T_GAUSS_DENSE) {
         if (c.n_target_params != (int64_t)c.dim * c.dim || !c.target_params) return fail(PDMP_ERR_ARGUMENT, "GAUSS_DENSE needs target_params = P[dim*dim] (column-major)");
-        if (c.sampler == PDMP_BOOMERANG || c.deriv_mode != PDMP_DERIV_FORWARD || c.grid_size != 10)
+        if (c.sampler == PDMP_BOOMERANG || c.deriv_mode != PDMP_DERIV_FORWARD || (c.grid_size != 10 && c.grid_size != 0))
             return fail(PDMP_ERR_UNSUPPORTED, "dense-precision target: Zig-Zag / BPS with grid_size = 10 and forward-mode slopes only");
         if (group_waves_per_block((c.dim + WAVE - 1) / WAVE, 0, 6) < 1) return fail(PDMP_ERR_UNSUPPORTED, "dense-precision target: dim too large for the LDS tiles");
     }
@@ -230,7 +229,7 @@ glaunch_fn pick_group_launcher(int sampler, int target) {
 // waves per CU.  0 = the configuration is served by the wave-per-chain kernel instead.
 int choose_group_lanes(const pdmp_config_t &c) {
     if (c.target_id == PDMP_T_GAUSS_DENSE) return WAVE;        // one chain per wave: the gradient is a mat-vec
-    if (c.grid_size != GNG) return 0;
+    if (c.grid_size != GNG && c.grid_size != 0) return 0;           // 0: Brent constant bound (group kernel only)
     if (const char *e = getenv("PDMP_GROUP_LANES")) {
         const int G = atoi(e);
         if (G == 0) return 0;
@@ -294,6 +293,8 @@ int pdmp_create(const pdmp_config_t *cfg, pdmp_handle *out) {
     if (dev < 0) HIP_TRY(hipGetDevice(&dev));
     if (dev >= ndev) return fail(PDMP_ERR_ARGUMENT, "device %d out of range (%d visible)", dev, ndev);
     HIP_TRY(hipSetDevice(dev));
+    if (choose_group_lanes(c) == 0 && c.grid_size == 0)
+        return fail(PDMP_ERR_UNSUPPORTED, "grid_size == 0 (Brent constant bound) is served by the group kernel only");
     if (choose_group_lanes(c) == 0 && c.dim > 4 * WAVE)
         return fail(PDMP_ERR_UNSUPPORTED, "dim > %d needs grid_size = 10 (group kernel); the wave-per-chain kernel holds at most 4 coordinates per lane", 4 * WAVE);
     pdmp_engine *h = new pdmp_engine();

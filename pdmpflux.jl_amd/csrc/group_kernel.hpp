@@ -443,7 +443,73 @@ struct GroupChain {
         }
         if (!found) lbo = bj;
     }
+    // ---- upper_bound_constant (UpperBound.jl:18-36) + next_event for grid_size == 0: the UNSIGNED rate
+    // (AbstractPDMP.jl:121-125) is maximised over [0, harg] by Brent's method -- Optim.jl's univariate Brent()
+    // with its default rel_tol = sqrt(eps), abs_tol = eps, iterations = 1000 (third-party, restated from the
+    // published algorithm; same statement order as the checker) -- and bounds the rate by that one constant.
+    __device__ __forceinline__ void bound_constant(double harg, double E, double &tpo, double &lbo) {
+        const double rel_tol = 1.4901161193847656e-08, abs_tol = 2.220446049250313e-16;
+        const double golden = 0.5 * (3.0 - 2.23606797749979);
+        double x_lower = 0.0, x_upper = harg, raw;
+        double new_x = x_lower + golden * (x_upper - x_lower);
+        double new_f = -true_rate(new_x, raw);
+        double step = 0.0, old_step = 0.0;
+        double old_x = new_x, old_old_x = new_x, old_f = new_f, old_old_f = new_f;
+        int iteration = 0;
+        bool active = true;
+        while (__ballot(active) != 0ull) {
+            if (active) {
+                double pp = 0.0, q = 0.0;
+                const double x_tol = rel_tol * fabs(new_x) + abs_tol;
+                const double x_mid = (x_upper + x_lower) / 2;
+                if (iteration >= 1000 || fabs(new_x - x_mid) <= 2 * x_tol - (x_upper - x_lower) / 2) {
+                    active = false;
+                } else {
+                    ++iteration;
+                    if (fabs(old_step) > x_tol) {
+                        const double r = (new_x - old_x) * (new_f - old_old_f);
+                        q = (new_x - old_old_x) * (new_f - old_f);
+                        pp = (new_x - old_old_x) * q - (new_x - old_x) * r;
+                        q = 2 * (q - r);
+                        if (q > 0) pp = -pp; else q = -q;
+                    }
+                    if (fabs(pp) < fabs(q * old_step / 2) && pp < q * (x_upper - new_x) && pp < q * (new_x - x_lower)) {
+                        old_step = step;
+                        step = pp / q;
+                        const double x_temp = new_x + step;
+                        if ((x_temp - x_lower) < 2 * x_tol || (x_upper - x_temp) < 2 * x_tol)
+                            step = (new_x < x_mid) ? x_tol : -x_tol;
+                    } else {
+                        old_step = (new_x < x_mid) ? x_upper - new_x : x_lower - new_x;
+                        step = golden * old_step;
+                    }
+                    const double xt = (fabs(step) >= x_tol) ? new_x + step : new_x + ((step > 0) ? x_tol : -x_tol);
+                    const double ft = -true_rate(xt, raw);
+                    if (ft < new_f) {
+                        if (xt < new_x) x_upper = new_x; else x_lower = new_x;
+                        old_old_x = old_x; old_old_f = old_f;
+                        old_x = new_x; old_f = new_f;
+                        new_x = xt; new_f = ft;
+                    } else {
+                        if (xt < new_x) x_lower = xt; else x_upper = xt;
+                        if (ft <= old_f || old_x == new_x) {
+                            old_old_x = old_x; old_old_f = old_f;
+                            old_x = xt; old_f = ft;
+                        } else if (ft <= old_old_f || old_old_x == new_x || old_old_x == old_x) {
+                            old_old_x = xt; old_old_f = ft;
+                        }
+                    }
+                }
+            }
+        }
+        const double m = -new_f;                               // box_max = [-minimum], :28
+        const double c1 = m * (harg - 0.0);                    // cum_sum[2], :32-33; step_size = harg - 0, :35
+        lbo = m;
+        tpo = (c1 < E) ? __builtin_huge_val() : 0.0 + (E - 0.0) / (c1 - 0.0) * (harg - 0.0);   // next_event, :264-273
+    }
+
     __device__ __forceinline__ void bound_invert(double harg, double E, double &tp, double &lb) {
+        if (p.n_grid == 0) { bound_constant(harg, E, tp, lb); return; }
         if constexpr (SAMPLER == S_ZIGZAG) {
             if (p.vectorized) {
                 if (p.signed_bound) bound_invert_vect<true, FD>(harg, E, tp, lb); else bound_invert_vect<false, FD>(harg, E, tp, lb);

@@ -62,6 +62,11 @@ CASES = [
     ("ZigZagAD", 7, "dense", 3, 200, {}),
     ("BPS", 70, "dense", 4, 120, {}),
     ("ZigZagAD", 300, "dense", 2, 40, {}),
+    ("ZigZagAD", 50, "iso", 8, 150, {"grid_size": 0}),          # Brent constant bound (what most reference tests use)
+    ("ZigZagAD", 3, "banana", 8, 400, {"grid_size": 0}),
+    ("BPSAD", 20, "banana", 6, 150, {"grid_size": 0}),
+    ("BoomerangAD", 10, "diag", 6, 150, {"grid_size": 0, "refresh_rate": 0.1}),
+    ("ZigZagAD", 70, "dense", 3, 60, {"grid_size": 0}),
     ("Boomerang", 100, "iso", 6, 200, {}),          # default FiniteDiff
     ("BoomerangAD", 50, "diag", 6, 200, {"refresh_rate": 0.1}),
     ("Boomerang", 50, "banana", 6, 200, {"AD_backend": "ForwardDiff"}),
@@ -250,3 +255,13 @@ def test_sample_from_skeleton_dt_method(engine, oracle):
     b = oracle.sample_from_skeleton(cfg, n, got["X"], got["V"], got["t"], discard_vt=False, dt=dt)[0].T
     assert np.array_equal(a, b)
     assert np.array_equal(a[10], np.arange(1, n + 1) * dt)                 # out[2d+1, j] = j*dt, :640
+
+
+def test_reference_ergodicity_test_with_brent_bound(engine):
+    """test/test_property_based.jl:87-100 verbatim: ZigZagAD(1, U_Gauss_1D, grid_size=0), 5000 events, 5000 samples,
+    seed 42: |mean| < 0.2 and 0.8 < var < 1.2 -- through the drop-in API on the GPU."""
+    s = engine.ZigZagAD(1, engine.GaussianIso(), grid_size=0)
+    out = engine.sample_skeleton(s, 5000, 0.0, 1.0, seed=42)
+    smp = engine.sample_from_skeleton(s, 5000, out)
+    assert abs(smp.mean()) < 0.2 and 0.8 < smp.var() < 1.2
+    assert len(out.t) == 5000 and (np.diff(out.t) > 0).all()

@@ -121,10 +121,10 @@ def test_fails_loudly_without_gpu(engine):
     with pytest.raises(engine.EngineError, match="no HIP device"):
         engine.sample_skeleton(s, 10, np.zeros(2), np.ones(2), seed=1)
     cfg = s._config()
-    cfg.grid_size = 0                                                          # argument checks come before the device check
+    cfg.grid_size = 1                                                          # argument checks come before the device check
     h = C.c_void_p()
     assert _lib.lib().pdmp_create(C.byref(cfg), C.byref(h)) == _lib.ERR_UNSUPPORTED
-    assert b"Brent" in _lib.lib().pdmp_last_error()
+    assert b"grid_size" in _lib.lib().pdmp_last_error()
     cfg = s._config(); cfg.dim = 0
     assert _lib.lib().pdmp_create(C.byref(cfg), C.byref(h)) == _lib.ERR_ARGUMENT
 

@@ -17,6 +17,16 @@ def test_ergodicity_1d_gaussian(oracle):
     assert abs(s.mean()) < 0.2 and 0.8 < s.var() < 1.2
 
 
+def test_ergodicity_1d_gaussian_brent(oracle):
+    """The same test with the bound the reference test actually uses: grid_size=0 (Brent constant bound, UpperBound.jl:18-36)."""
+    cfg = zz(oracle, 1, grid_size=0)
+    r = oracle.sample_skeleton(cfg, 5000, [[0.0]], [[1.0]], 42)
+    s = oracle.sample_from_skeleton(cfg, 5000, r["X"], r["V"], r["t"])[0, :, 0]
+    assert abs(s.mean()) < 0.2 and 0.8 < s.var() < 1.2
+    grid, box, cum, step = oracle.upper_bound(cfg, [-1.0], [1.0], 2.0)      # rate (t-1)+ on [0,2]: max 1 at the right end
+    assert grid.tolist() == [0.0, 2.0] and step == 2.0 and abs(box[0] - 1.0) < 1e-6 and cum[1] == box[0] * 2.0
+
+
 def test_central_limit_over_seeds(oracle):
     """test/test_property_based.jl:129-149: 100 runs with seed = 42 + i."""
     cfg = zz(oracle, 1)
