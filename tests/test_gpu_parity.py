@@ -265,3 +265,32 @@ def test_reference_ergodicity_test_with_brent_bound(engine):
     smp = engine.sample_from_skeleton(s, 5000, out)
     assert abs(smp.mean()) < 0.2 and 0.8 < smp.var() < 1.2
     assert len(out.t) == 5000 and (np.diff(out.t) > 0).all()
+
+
+def test_iteration_cap_is_reported_not_hung(engine):
+    """A chain that exceeds max_iter_per_event thinning steps for one event stops and the call returns
+    PDMP_ERR_ITERCAP (-4) -- never an endless loop on the GPU (failure detection)."""
+    from pdmpflux.jl_amd import _lib
+    x, v = make_init("ZigZagAD", 2, 8, target="banana")
+    for kw in ({}, {"grid_size": 5}):                      # group kernel and wave kernel
+        s = engine.ZigZagAD(2, engine.Banana(), tmax=20.0, adaptive=False, max_iter_per_event=1, **kw)
+        with pytest.raises(engine.EngineError) as e:
+            engine.sample_skeleton_ensemble(s, 400, x, v, seed=3)
+        assert e.value.code == _lib.ERR_ITERCAP
+        ok = engine.ZigZagAD(2, engine.Banana(), tmax=20.0, adaptive=False, **kw)     # same run with the default cap is fine
+        out = engine.sample_skeleton_ensemble(ok, 400, x, v, seed=3)
+        assert np.isfinite(out["t"]).all()
+
+
+def test_empty_and_degenerate_ensembles(engine, oracle):
+    """Edge cases: no chains, one skeleton point (initial state only), one chain, ragged last wave."""
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", 50, "iso")
+    e = engine.sample_skeleton_ensemble(s, 10, np.zeros((0, 50)), np.zeros((0, 50)), seed=1)
+    assert e["X"].shape == (0, 10, 50)
+    x, v = make_init("ZigZagAD", 50, 17)
+    one = engine.sample_skeleton_ensemble(s, 1, x, v, seed=1)
+    assert np.array_equal(one["X"][:, 0], x) and np.array_equal(one["V"][:, 0], v) and (one["t"] == 0).all()
+    got = engine.sample_skeleton_ensemble(s, 33, x, v, seed=1)
+    ref = oracle.sample_skeleton(cfg, 33, x, v, 1)
+    assert_bitwise(got, ref)
+    assert np.array_equal(x, make_init("ZigZagAD", 50, 17)[0])          # inputs are never mutated (Q7)
