@@ -146,13 +146,21 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
+    # Rehearsal hook for a one-GPU box (never used by the driver): all ranks share device 0 and the exchange goes
+    # through gloo on host copies, because RCCL refuses two ranks on one device.
+    rehearsal = os.environ.get("PDMP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     sampler = make_sampler(P, a)
     sampler.device = local
@@ -172,7 +180,12 @@ def main():
             end_state[:, :d] = out["X"][:, -1]
             end_state[:, d:2 * d] = out["V"][:, -1]
             end_state[:, 2 * d] = out["t"][:, -1]
-            dist.all_gather_into_tensor(gathered, end_state)
+            if rehearsal:
+                parts = [torch.empty((C, 2 * d + 1), dtype=torch.float64) for _ in range(world)]
+                dist.all_gather(parts, end_state.cpu())
+                gathered.copy_(torch.cat(parts, 0))
+            else:
+                dist.all_gather_into_tensor(gathered, end_state)
 
     def fence():
         if world > 1:
@@ -192,7 +205,7 @@ def main():
     _lib.check(_lib.lib().pdmp_check_status(sampler.handle(), None))
     tm = ensemble.kernel_timing(sampler)
     if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        te = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
@@ -224,7 +237,7 @@ def main():
                          "kernel": kernel, "kernel_ms": kernel_ms, "bytes_per_event": bytes_per_event,
                          "note": "fp64-VALU-bound state machine; HBM fraction is the requested headline"},
         }
-        if a.cpu_seconds > 0:
+        if a.cpu_seconds > 0 and world == 1:                     # CPU baseline: rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(a, sampler)
         print(json.dumps(res), flush=True)
     if world > 1:
