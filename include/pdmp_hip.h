@@ -101,6 +101,16 @@ int pdmp_destroy(pdmp_handle h);
  * 0 when the wave-per-chain kernel ("WAVE64" order) serves it.  Lets a checker pick the matching order. */
 int pdmp_get_group_lanes(pdmp_handle h);
 
+/* Tape source: replace the built-in Philox stream (the engine's stand-in for Julia's
+ * MersenneTwister, AbstractPDMP.jl:100) by pre-recorded variates, one tape per kind in consumption order --
+ * randexp (SamplingLoopInplace.jl:70,136,190), rand (:154 and the samplers' jumps), randn (BouncyParticleSamplers.jl:67)
+ * -- so that a run of ANY generator (e.g. a dump from Julia) can be replayed draw for draw.  HOST pointers, C x n_*
+ * doubles, chain-major, indexed by the global chain id; copied.  While a tape is set, seeds are ignored and the
+ * wave-per-chain kernel runs ("WAVE64" order; pdmp_get_group_lanes() returns 0).  An exhausted tape fails the call. */
+int pdmp_set_tape(pdmp_handle h, int64_t C, int64_t n_exp, int64_t n_uni, int64_t n_nrm,
+                  const double *exp_tape, const double *uni_tape, const double *nrm_tape);
+int pdmp_clear_tape(pdmp_handle h);
+
 /* sample_skeleton(sampler, n_sk, xinit, vinit; seed)  (src/sample.jl:253-284) for C chains:
  * init_state (AbstractPDMP.jl:93-153) + (n_sk-1) x get_event_state! (SamplingLoopInplace.jl:27-39)
  * + record! (Composites.jl:239-260).  HOST pointers; blocking. */

@@ -30,6 +30,8 @@ class _Cfg(C.Structure):
         ("arith", C.c_int32), ("tmax", C.c_double), ("refresh_rate", C.c_double),
         ("target_params", C.POINTER(C.c_double)), ("n_target_params", C.c_int64),
         ("max_iter_per_event", C.c_int64), ("group_lanes", C.c_int32),
+        ("tape_exp", C.POINTER(C.c_double)), ("tape_uni", C.POINTER(C.c_double)), ("tape_nrm", C.POINTER(C.c_double)),
+        ("tape_n_exp", C.c_int64), ("tape_n_uni", C.c_int64), ("tape_n_nrm", C.c_int64),
     ]
 
 
@@ -106,6 +108,7 @@ class Config:
     arith: int = ARITH_REFERENCE
     max_iter_per_event: int = 0
     group_lanes: int = 1
+    tape: tuple | None = None          # (exp, uni, nrm) arrays of shape (C, n_kind): replay instead of Philox
     _keep: list = field(default_factory=list, repr=False)
 
     def c(self) -> _Cfg:
@@ -115,9 +118,16 @@ class Config:
             arr = np.ascontiguousarray(np.asarray(self.target_params, dtype=np.float64).ravel())
             self._keep = [arr]
             p, n = _dp(arr), arr.size
+        te = tu = tn = None
+        ne = nu = nn = 0
+        if self.tape is not None:
+            arrs = [np.ascontiguousarray(np.atleast_2d(np.asarray(a, dtype=np.float64))) for a in self.tape]
+            self._keep = list(self._keep) + arrs
+            (te, tu, tn), (ne, nu, nn) = [_dp(a) for a in arrs], [a.shape[1] for a in arrs]
         return _Cfg(self.sampler, self.dim, self.grid_size, int(self.vectorized_bound), int(self.signed_bound),
                     int(self.adaptive), int(self.gaussian_velocity), self.deriv_mode, self.target_id, self.arith,
-                    float(self.tmax), float(self.refresh_rate), p, n, self.max_iter_per_event, self.group_lanes)
+                    float(self.tmax), float(self.refresh_rate), p, n, self.max_iter_per_event, self.group_lanes,
+                    te, tu, tn, ne, nu, nn)
 
 
 def _check(rc):

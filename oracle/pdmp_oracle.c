@@ -53,7 +53,12 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-typedef struct { uint64_t seed; uint64_t chain; uint64_t n; } rng_t;
+/* Tape source: when te/tu/tn are set the chain replays pre-recorded Exp(1), U(0,1) and N(0,1)
+ * variates (one tape per kind, each in consumption order -- enough to replay a run of ANY generator, e.g. a dump of
+ * Julia's MersenneTwister randexp/rand/randn, because the control flow is a function of the variates) instead of
+ * drawing from Philox.  An exhausted tape yields 1.0 / 0.5 / 0.0 and sets *overrun. */
+typedef struct { uint64_t seed; uint64_t chain; uint64_t n;
+                 const double *te, *tu, *tn; int64_t ne, nu, nn, ie, iu, in; int *overrun; } rng_t;
 
 static inline double bits_to_u(uint64_t bits) {
     return ((double)(bits >> 12) + 0.5) * 0x1p-52;
@@ -64,6 +69,7 @@ static void rng_block(const rng_t *r, uint64_t blk, uint32_t w[4]) {
     orc_philox4x32_10(ctr, key, w);
 }
 static double rng_uniform(rng_t *r) {
+    if (r->tu) { if (r->iu < r->nu) return r->tu[r->iu++]; if (r->overrun) *r->overrun = 1; return 0.5; }
     uint32_t w[4];
     rng_block(r, r->n >> 1, w);
     int h = (int)(r->n & 1);
@@ -147,10 +153,17 @@ void orc_sincos(double x, double *s, double *c) {
     quadrant((int)((int64_t)fn & 3), ksin(a), kcos(a), s, c);
 }
 
-static double rng_exp(rng_t *r) { return -orc_log(rng_uniform(r)); }
+static double rng_exp(rng_t *r) {
+    if (r->te) { if (r->ie < r->ne) return r->te[r->ie++]; if (r->overrun) *r->overrun = 1; return 1.0; }
+    return -orc_log(rng_uniform(r));
+}
 
 /* d standard normals; aligns the variate counter to a block boundary first. */
 static void rng_normals(rng_t *r, int d, double *z) {
+    if (r->tn) {
+        for (int i = 0; i < d; ++i) { if (r->in < r->nn) z[i] = r->tn[r->in++]; else { z[i] = 0.0; if (r->overrun) *r->overrun = 1; } }
+        return;
+    }
     if (r->n & 1) r->n++;
     uint64_t blk0 = r->n >> 1;
     for (int p = 0; 2 * p < d; ++p) {
@@ -167,7 +180,7 @@ static void rng_normals(rng_t *r, int d, double *z) {
 }
 
 void orc_rng_dump(uint64_t seed, int64_t chain, int kind, int64_t n_draw, double *out) {
-    rng_t r = { seed, (uint64_t)chain, 0 };
+    rng_t r = { seed, (uint64_t)chain, 0, NULL, NULL, NULL, 0, 0, 0, 0, 0, 0, NULL };
     if (kind == 2) { rng_normals(&r, (int)n_draw, out); return; }
     for (int64_t i = 0; i < n_draw; ++i) out[i] = (kind == 0) ? rng_uniform(&r) : rng_exp(&r);
 }
@@ -673,7 +686,14 @@ static int run_chain(const orc_config_t *cfg, ws_t *w, int64_t n_sk, uint64_t se
                      int32_t *RJ, int32_t *HH) {
     const int d = w->d, n = w->n;
     const int64_t cap = cfg->max_iter_per_event > 0 ? cfg->max_iter_per_event : 1000000;
-    rng_t rng = { seed, chain, 0 };
+    int overrun = 0;
+    rng_t rng = { seed, chain, 0, NULL, NULL, NULL, 0, 0, 0, 0, 0, 0, &overrun };
+    if (cfg->tape_exp) {
+        const int64_t c = (int64_t)chain;          /* tapes are indexed by the global chain id */
+        rng.te = cfg->tape_exp + c * cfg->tape_n_exp; rng.ne = cfg->tape_n_exp;
+        rng.tu = cfg->tape_uni + c * cfg->tape_n_uni; rng.nu = cfg->tape_n_uni;
+        rng.tn = cfg->tape_nrm + c * cfg->tape_n_nrm; rng.nn = cfg->tape_n_nrm;
+    }
     memcpy(w->x, xinit, (size_t)d * 8); memcpy(w->v, vinit, (size_t)d * 8);   /* copy: fixes aliasing Q7 */
     double t = 0.0, horizon = cfg->tmax, ts = 0.0, tp = 0.0, E = 0.0, lb = 0.0, ar = 0.0;
     int status = 0;
@@ -683,6 +703,7 @@ static int run_chain(const orc_config_t *cfg, ws_t *w, int64_t n_sk, uint64_t se
             int accept = 0; int64_t it = 0;
             while (!accept) {                                                         /* :33-35 */
                 if (++it > cap) return -4;
+                if (overrun) return -6;
                 /* one_step_of_thinning!, :65-85 */
                 upper_bound(cfg, w, w->x, w->v, horizon);
                 E = rng_exp(&rng);
@@ -694,6 +715,7 @@ static int run_chain(const orc_config_t *cfg, ws_t *w, int64_t n_sk, uint64_t se
                 } else {                                                              /* moves_until_horizon!, :103-111 */
                     while (tp < horizon && !accept) {
                         if (++it > cap) return -4;
+                        if (overrun) return -6;
                         double lam = true_rate(cfg, w, tp);                           /* ac_step!, :113-129 */
                         ar = lam / lb;
                         if (ar > 1.0) {                                               /* erroneous_acceptance_rate!, :131-151 */
@@ -738,7 +760,7 @@ static int run_chain(const orc_config_t *cfg, ws_t *w, int64_t n_sk, uint64_t se
         if (HH) HH[k] = hits;
     }
     (void)status;
-    return 0;
+    return overrun ? -6 : 0;
 }
 
 int orc_sample_skeleton(const orc_config_t *cfg_in, int64_t C, int64_t n_sk, int64_t chain_id_offset,
@@ -776,6 +798,7 @@ int orc_sample_skeleton(const orc_config_t *cfg_in, int64_t C, int64_t n_sk, int
         ws_free(&w);
     }
     if (rc == -4) FAIL(-4, "a chain hit the per-event iteration cap");
+    if (rc == -6) FAIL(-6, "a random-variate tape was exhausted");
     if (rc) FAIL(rc, "allocation failure");
     return 0;
 }

@@ -52,6 +52,9 @@ typedef struct orc_config_t {
     int64_t n_target_params;
     int64_t max_iter_per_event;  /* 0 = default 1e6; safety cap (status -4) */
     int32_t group_lanes;         /* G for ORC_ARITH_GROUP */
+    /* tape source (all three or none): per chain tape_n_* variates, chain-major (chain c at c*tape_n_*) */
+    const double *tape_exp, *tape_uni, *tape_nrm;
+    int64_t tape_n_exp, tape_n_uni, tape_n_nrm;
 } orc_config_t;
 
 const char *orc_last_error(void);

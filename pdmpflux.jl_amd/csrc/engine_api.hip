@@ -46,6 +46,8 @@ struct pdmp_engine {
     size_t sched_cap = 0;
     double *d_state = nullptr;        // group kernel: per-chain hand-off state (2d+4 doubles)
     size_t state_cap = 0;
+    double *d_tape[3] = {nullptr, nullptr, nullptr};   // tape source: exp, uni, nrm (chain-major)
+    int64_t tape_n[3] = {0, 0, 0}, tape_chains = 0;
     hipStream_t last_stream = nullptr;
     std::vector<EventPair> pending;   // launches not yet folded into `timing`
     std::vector<EventPair> pool;
@@ -313,7 +315,33 @@ int pdmp_create(const pdmp_config_t *cfg, pdmp_handle *out) {
     return PDMP_OK;
 }
 
-int pdmp_get_group_lanes(pdmp_handle h) { return h ? h->group_lanes : -1; }
+int pdmp_get_group_lanes(pdmp_handle h) { return h ? (h->tape_chains > 0 ? 0 : h->group_lanes) : -1; }
+
+int pdmp_clear_tape(pdmp_handle h) {
+    if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->last_stream));
+    for (int q = 0; q < 3; ++q) { if (h->d_tape[q]) (void)hipFree(h->d_tape[q]); h->d_tape[q] = nullptr; h->tape_n[q] = 0; }
+    h->tape_chains = 0;
+    return PDMP_OK;
+}
+
+int pdmp_set_tape(pdmp_handle h, int64_t C, int64_t n_exp, int64_t n_uni, int64_t n_nrm, const double *exp_tape,
+                  const double *uni_tape, const double *nrm_tape) {
+    if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
+    if (C <= 0 || n_exp <= 0 || n_uni <= 0 || n_nrm <= 0 || !exp_tape || !uni_tape || !nrm_tape)
+        return fail(PDMP_ERR_ARGUMENT, "pdmp_set_tape needs C > 0 chains and three non-empty tapes");
+    if (int rc = pdmp_clear_tape(h)) return rc;
+    const double *src[3] = {exp_tape, uni_tape, nrm_tape};
+    const int64_t n[3] = {n_exp, n_uni, n_nrm};
+    for (int q = 0; q < 3; ++q) {
+        HIP_TRY(hipMalloc(&h->d_tape[q], (size_t)C * (size_t)n[q] * 8));
+        HIP_TRY(hipMemcpy(h->d_tape[q], src[q], (size_t)C * (size_t)n[q] * 8, hipMemcpyHostToDevice));
+        h->tape_n[q] = n[q];
+    }
+    h->tape_chains = C;
+    return PDMP_OK;
+}
 
 int pdmp_get_config(pdmp_handle h, pdmp_config_t *out) {
     if (!h || !out) return fail(PDMP_ERR_ARGUMENT, "null argument");
@@ -330,6 +358,7 @@ int pdmp_destroy(pdmp_handle h) {
     if (h->d_status) (void)hipFree(h->d_status);
     if (h->d_sched) (void)hipFree(h->d_sched);
     if (h->d_state) (void)hipFree(h->d_state);
+    for (int q = 0; q < 3; ++q) if (h->d_tape[q]) (void)hipFree(h->d_tape[q]);
     delete h;
     return PDMP_OK;
 }
@@ -358,6 +387,16 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
         p.EB = diag->errored_bound; p.RJ = diag->rejected; p.HH = diag->hitting_horizon;
     }
     p.status = h->d_status;
+    const bool taped = h->tape_chains > 0;
+    if (taped) {
+        if (chain_id_offset < 0 || chain_id_offset + C > h->tape_chains)
+            return fail(PDMP_ERR_ARGUMENT, "tape holds %lld chains; requested chains [%lld, %lld)", (long long)h->tape_chains,
+                        (long long)chain_id_offset, (long long)(chain_id_offset + C));
+        if (c.grid_size < 2 || c.dim > 4 * WAVE || c.target_id == PDMP_T_GAUSS_DENSE)
+            return fail(PDMP_ERR_UNSUPPORTED, "tape replay runs on the wave-per-chain kernel: grid_size >= 2, dim <= %d, no dense target", 4 * WAVE);
+        p.tape_exp = h->d_tape[0]; p.tape_uni = h->d_tape[1]; p.tape_nrm = h->d_tape[2];
+        p.tape_n_exp = h->tape_n[0]; p.tape_n_uni = h->tape_n[1]; p.tape_n_nrm = h->tape_n[2];
+    }
 #ifdef PDMP_STAMP
     static unsigned long long *d_stamps = nullptr;
     if (!d_stamps) { HIP_TRY(hipMalloc(&d_stamps, 64)); }
@@ -368,7 +407,7 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
     hipStream_t s = (hipStream_t)stream;
     GroupParams gp;
     memset(&gp, 0, sizeof gp);
-    if (h->group_lanes > 0) {
+    if (h->group_lanes > 0 && !taped) {
         gp.s = p;
         gp.G = h->group_lanes;
         gp.K = (c.dim + gp.G - 1) / gp.G;
@@ -394,7 +433,7 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
     }
     EventPair ev;
     if (int rc = begin_timed(h, s, ev)) return rc;
-    if (h->group_lanes > 0) HIP_TRY(pick_group_launcher(c.sampler, c.target_id)(gp, s));
+    if (h->group_lanes > 0 && !taped) HIP_TRY(pick_group_launcher(c.sampler, c.target_id)(gp, s));
     else HIP_TRY(pick_launcher(c.sampler, c.target_id)(p, s));
     return end_timed(h, s, ev);
 }
@@ -408,6 +447,7 @@ int pdmp_check_status(pdmp_handle h, int64_t *n_guard) {
     HIP_TRY(hipMemset(h->d_status, 0, sizeof st));
     if (n_guard) *n_guard = st[1];
     if (st[2] > 0) return fail(PDMP_ERR_RUNTIME, "%d work unit(s) lost their predecessor's hand-off", st[2]);
+    if (st[3] > 0) return fail(PDMP_ERR_ARGUMENT, "%d chain(s) exhausted their random-variate tape", st[3]);
     if (st[0] > 0) return fail(PDMP_ERR_ITERCAP, "%d chain(s) hit the per-event iteration cap (%lld)", st[0],
                                (long long)h->cfg.max_iter_per_event);
     return PDMP_OK;

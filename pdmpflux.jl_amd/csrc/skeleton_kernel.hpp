@@ -25,8 +25,11 @@ struct SkelParams {
     const double *xinit, *vinit, *tparams;
     double *X, *V, *t, *H, *AR, *EV;
     int32_t *EB, *RJ, *HH;
-    int32_t *status;   // [0] chains that hit the iteration cap, [1] Q11 guard events, [2] lost hand-offs
+    int32_t *status;   // [0] chains that hit the iteration cap, [1] Q11 guard events, [2] lost hand-offs, [3] chains whose tape ran out
     unsigned long long *stamps;   // diagnostic build only (-DPDMP_STAMP): per-phase cycle sums, else null
+    // tape source: replay pre-recorded variates instead of Philox; chain-major, indexed by global chain id
+    const double *tape_exp, *tape_uni, *tape_nrm;
+    int64_t tape_n_exp, tape_n_uni, tape_n_nrm;
 };
 
 __device__ __forceinline__ bool uni(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }
@@ -46,6 +49,28 @@ struct Chain {
     double x[K], v[K];
     bool act[K];
     int32_t guard = 0;
+    const double *te = nullptr, *tu = nullptr, *tn = nullptr;   // this chain's tapes (null: Philox)
+    int64_t ie = 0, iu = 0, in = 0;
+    bool overrun = false;
+
+    // random variates: the chain's Philox stream, or its tapes when a tape is set (an exhausted tape yields
+    // 1.0 / 0.5 / 0.0 and flags the launch)
+    __device__ __forceinline__ double r_exp() {
+        if (te) { if (ie < p.tape_n_exp) return te[ie++]; overrun = true; return 1.0; }
+        return rng.exponential();
+    }
+    __device__ __forceinline__ double r_uni() {
+        if (tu) { if (iu < p.tape_n_uni) return tu[iu++]; overrun = true; return 0.5; }
+        return rng.uniform();
+    }
+    __device__ __forceinline__ double r_normal(int i) {          // coordinate i of a d-vector of normals
+        if (tn) { if (in + i < p.tape_n_nrm) return tn[in + i]; overrun = true; return 0.0; }
+        return rng.normal_coord(i);
+    }
+    __device__ __forceinline__ void r_normals_done(int d) {
+        if (tn) { in += d; return; }
+        rng.normals_done(d);
+    }
 
     __device__ __forceinline__ Chain(const SkelParams &pp, int l) : p(pp), lane(l) {}
 
@@ -304,7 +329,7 @@ struct Chain {
 #pragma unroll
             for (int k = 0; k < K; ++k) lam[k] = act[k] ? pmax(0.0, g[k] * v[k]) : 0.0;
             const double S = wave_sum(lane_sum(lam));
-            const double u = rng.uniform();                          // Categorical draw
+            const double u = r_uni();                                // Categorical draw
             if (!uni(S > 0.0)) { guard++; return; }                  // Q11
             double carry = 0.0;
             int m = -1;
@@ -332,7 +357,7 @@ struct Chain {
             const double gv = wave_sum(lane_sum(a));
             const double bounce = pmax(0.0, gv);
             const double prob = bounce / (bounce + p.refresh);       // NaN if both 0 (Q9)
-            const double u = rng.uniform();
+            const double u = r_uni();
             if (uni(u < prob)) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) a[k] = g[k] * g[k];
@@ -353,8 +378,8 @@ struct Chain {
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < K; ++k) v[k] = act[k] ? rng.normal_coord(lane + WAVE * k) : 0.0;
-                rng.normals_done(p.d);
+                for (int k = 0; k < K; ++k) v[k] = act[k] ? r_normal(lane + WAVE * k) : 0.0;
+                r_normals_done(p.d);
                 if (SAMPLER == S_BPS && !p.gaussian_velocity) {      // normalize!, :71
 #pragma unroll
                     for (int k = 0; k < K; ++k) a[k] = v[k] * v[k];
@@ -396,6 +421,12 @@ struct Chain {
         const int d = p.d;
         tgt.load(p.tparams, d, lane);
         rng.init(p.seed, (uint64_t)(p.chain0 + c));
+        if (p.tape_exp) {
+            const size_t gc = (size_t)(p.chain0 + c);
+            te = p.tape_exp + gc * (size_t)p.tape_n_exp;
+            tu = p.tape_uni + gc * (size_t)p.tape_n_uni;
+            tn = p.tape_nrm + gc * (size_t)p.tape_n_nrm;
+        }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int i = lane + WAVE * k;
@@ -418,9 +449,10 @@ struct Chain {
             int64_t it = 0;
             while (!accept) {                                         // :33-35
                 if (++it > p.cap) { if (lane == 0) atomicAdd(&p.status[0], 1); return; }
+                if (uni(overrun)) { if (lane == 0) atomicAdd(&p.status[3], 1); return; }   // tape exhausted: stop this chain
                 // one_step_of_thinning!, :65-85
                 B = upper_bound(horizon);
-                E = rng.exponential();
+                E = r_exp();
                 next_event(B, E, tp, lb);
                 if (uni(tp > horizon)) {                              // move_to_horizon!, :87-101
                     flow_state(horizon);
@@ -430,12 +462,13 @@ struct Chain {
                 } else {                                              // moves_until_horizon!, :103-111
                     while (uni(tp < horizon) && !accept) {
                         if (++it > p.cap) { if (lane == 0) atomicAdd(&p.status[0], 1); return; }
+                        if (uni(overrun)) { if (lane == 0) atomicAdd(&p.status[3], 1); return; }
                         const double lam = true_rate(tp);             // ac_step!, :113-129
                         ar = lam / lb;
                         if (uni(ar > 1.0)) {                          // erroneous_acceptance_rate!, :131-151
                             const double h2 = horizon / 2;
                             B = upper_bound(h2);
-                            E = rng.exponential();
+                            E = r_exp();
                             next_event(B, E, tp, lb);
                             if (adaptive) horizon = h2;
                             errored++;
@@ -443,7 +476,7 @@ struct Chain {
 #pragma unroll
                             for (int q = 0; q < 5; ++q) if (q == slot) ev[q] = ar;
                         } else {                                      // ac_step_with_proxy!, :153-168
-                            const double u = rng.uniform();
+                            const double u = r_uni();
                             accept = uni(u < ar);
                             if (accept) {                             // if_accept!, :170-186
                                 flow_state(tp);
@@ -452,7 +485,7 @@ struct Chain {
                                 ts = 0.0;
                                 tp = 0.0;
                             } else {                                  // if_reject!, :188-203
-                                E = E + rng.exponential();
+                                E = E + r_exp();
                                 next_event(B, E, tp, lb);
                                 if (adaptive) horizon = horizon / 1.04;
                                 rejected++;
@@ -469,6 +502,7 @@ struct Chain {
             record(c, k, t, horizon, ar, errored, ev, rejected, hits);
         }
         if (guard && lane == 0) atomicAdd(&p.status[1], guard);
+        if (overrun && lane == 0) atomicAdd(&p.status[3], 1);
     }
 };
 

@@ -93,6 +93,19 @@ class AbstractPDMP:
         G of the group kernel, or 0 for the wave-per-chain kernel."""
         return int(_lib.lib().pdmp_get_group_lanes(self.handle()))
 
+    def set_tape(self, exp_tape, uni_tape, nrm_tape):
+        """Replay pre-recorded Exp(1) / U(0,1) / N(0,1) variates (arrays of shape ``(C, n_kind)``, row c = chain c,
+        each kind in consumption order) instead of the Philox stream (pdmp_set_tape)."""
+        arrs = [np.ascontiguousarray(np.atleast_2d(np.asarray(a, dtype=np.float64))) for a in (exp_tape, uni_tape, nrm_tape)]
+        if len({a.shape[0] for a in arrs}) != 1:
+            raise ArgumentError("the three tapes must hold the same number of chains")
+        _lib.check(_lib.lib().pdmp_set_tape(self.handle(), arrs[0].shape[0], arrs[0].shape[1], arrs[1].shape[1], arrs[2].shape[1],
+                                            C.c_void_p(arrs[0].ctypes.data), C.c_void_p(arrs[1].ctypes.data),
+                                            C.c_void_p(arrs[2].ctypes.data)))
+
+    def clear_tape(self):
+        _lib.check(_lib.lib().pdmp_clear_tape(self.handle()))
+
     def close(self):
         if self._handle is not None:
             _lib.lib().pdmp_destroy(self._handle)

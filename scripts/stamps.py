@@ -11,7 +11,13 @@ C_, d, n_sk = 100000, 50, 1000
 g = torch.Generator(device=dev); g.manual_seed(1)
 x = torch.randn((C_, d), dtype=torch.float64, device=dev, generator=g)
 v = torch.randint(0, 2, (C_, d), device=dev, generator=g).to(torch.float64) * 2 - 1
-s = P.ZigZagAD(d, P.GaussianIso())
+kind = sys.argv[1] if len(sys.argv) > 1 else "zz"
+if kind == "bps":
+    x = 1.0 + 0.1 * x
+    v = torch.randn((C_, d), dtype=torch.float64, device=dev, generator=g); v = (v / v.norm(dim=1, keepdim=True)).contiguous()
+    s = P.BPS(d, P.Banana())
+else:
+    s = P.ZigZagAD(d, P.GaussianIso())
 out = ensemble.sample_skeleton_device(s, n_sk, x, v, seed=1)
 torch.cuda.synchronize()
 lib = L.lib()

@@ -294,3 +294,26 @@ def test_empty_and_degenerate_ensembles(engine, oracle):
     ref = oracle.sample_skeleton(cfg, 33, x, v, 1)
     assert_bitwise(got, ref)
     assert np.array_equal(x, make_init("ZigZagAD", 50, 17)[0])          # inputs are never mutated (Q7)
+
+
+@pytest.mark.parametrize("kind,dim,target,kw", [("ZigZagAD", 50, "iso", {}), ("BPS", 20, "banana", {"refresh_rate": 0.5}),
+                                                ("Boomerang", 9, "diag", {})])
+def test_tape_replay_bitwise(engine, oracle, kind, dim, target, kw):
+    """Tape source: both sides replay the same externally generated variates (numpy's generators here,
+    a Julia dump in the intended use) instead of Philox; trajectories must still agree bit for bit."""
+    rs = np.random.default_rng(5)
+    C_ = 6
+    tape = (rs.exponential(size=(C_, 3000)), rs.random(size=(C_, 3000)), rs.normal(size=(C_, 6000)))
+    s, cfg = make_pair(engine, oracle, kind, dim, target, arith=oracle.ARITH_WAVE64, **kw)
+    s.set_tape(*tape)
+    assert s.group_lanes() == 0
+    cfg.tape = tape
+    x, v = make_init(kind, dim, C_, target=target)
+    got = engine.sample_skeleton_ensemble(s, 150, x[2:5], v[2:5], seed=0, chain_id_offset=2)   # tapes follow the global chain id
+    ref = oracle.sample_skeleton(cfg, 150, x[2:5], v[2:5], 0, chain_id_offset=2)
+    assert_bitwise(got, ref)
+    with pytest.raises(engine.ArgumentError):                                   # tape too short for 5000 events
+        engine.sample_skeleton_ensemble(s, 5000, x, v, seed=0)
+    s.clear_tape()
+    again = engine.sample_skeleton_ensemble(s, 20, x, v, seed=3)               # back on Philox and the fast kernel
+    assert np.isfinite(again["t"]).all() and s.group_lanes() > 0
