@@ -253,6 +253,11 @@ static int categorical(const orc_config_t *cfg, const double *p, int d, double u
     return d - 1;
 }
 
+/* GROUP order only: the engine's group kernel fuses the multiply-add of the linear flow x + v t, of the tangent
+ * intersection numerator and of the intersection value (one rounding instead of two; the reference and the other
+ * orders keep them separate).  fma() is exact IEEE fusedMultiplyAdd on both sides. */
+#define FUSED(cfg) ((cfg)->arith == ORC_ARITH_GROUP)
+
 /* max without NaN propagation -- both sides of the parity comparison use this form */
 static inline double pmax(double a, double b) { return a > b ? a : b; }
 
@@ -363,7 +368,7 @@ static void flow_dual(const orc_config_t *cfg, ws_t *w, const double *x, const d
         }
     } else {
         for (int i = 0; i < d; ++i) {
-            w->xv[i] = x[i] + v[i] * t;
+            w->xv[i] = FUSED(cfg) ? fma(v[i], t, x[i]) : x[i] + v[i] * t;
             w->xe[i] = v[i];
             w->vv[i] = v[i];
             w->ve[i] = 0.0;
@@ -474,10 +479,12 @@ static void upper_bound(const orc_config_t *cfg, ws_t *w, const double *x, const
             const double *v0 = w->vals + (size_t)j * d, *v1 = v0 + d, *g0 = w->slps + (size_t)j * d, *g1 = g0 + d;
             for (int i = 0; i < d; ++i) {
                 /* :229  absolute-time tangent intersection (Q1) */
-                double p = (((v0[i] - v1[i]) + g1[i] * t[j + 1]) - g0[i] * t[j]) / (g1[i] - g0[i]);
+                double num = FUSED(cfg) ? fma(-g0[i], t[j], fma(g1[i], t[j + 1], v0[i] - v1[i]))
+                                        : ((v0[i] - v1[i]) + g1[i] * t[j + 1]) - g0[i] * t[j];
+                double p = num / (g1[i] - g0[i]);
                 if (p != p) p = 0.0;                                   /* :234 */
                 p = (p > h) ? h : ((p < 0.0) ? 0.0 : p);               /* :235 clamp */
-                double inter = v0[i] + g0[i] * p;                      /* :237 */
+                double inter = FUSED(cfg) ? fma(g0[i], p, v0[i]) : v0[i] + g0[i] * p;   /* :237 */
                 w->cell[i] = pmax(pmax(pmax(v0[i], v1[i]), inter), 0.0); /* :239-241 */
             }
             w->box[j] = vsum(cfg, w->cell, d);                         /* :246 sum(box_max, dims=1) */
@@ -511,10 +518,11 @@ static void upper_bound(const orc_config_t *cfg, ws_t *w, const double *x, const
     }
     double acc = 0.0; w->cum[0] = 0.0;
     for (int j = 0; j + 1 < n; ++j) {
-        double p = ((val[j] - val[j + 1]) + slp[j + 1] * h) / (slp[j + 1] - slp[j]);   /* :123 relative form */
+        double num = FUSED(cfg) ? fma(slp[j + 1], h, val[j] - val[j + 1]) : (val[j] - val[j + 1]) + slp[j + 1] * h;
+        double p = num / (slp[j + 1] - slp[j]);                                      /* :123 relative form */
         if (p != p) p = 0.0;                                                         /* :124 */
         p = (p > h) ? h : ((p < 0.0) ? 0.0 : p);                                     /* :125 */
-        double inter = val[j] + slp[j] * p;                                          /* :127 */
+        double inter = FUSED(cfg) ? fma(slp[j], p, val[j]) : val[j] + slp[j] * p;    /* :127 */
         double b = pmax(pmax(pmax(val[j], val[j + 1]), inter), 0.0);                 /* :128-130 */
         b += refresh;                                                                /* :131 (Q2) */
         w->box[j] = b;
@@ -607,7 +615,7 @@ static void flow_state(const orc_config_t *cfg, ws_t *w, double t) {
             w->x[i] = xn; w->v[i] = vn;
         }
     } else {
-        for (int i = 0; i < w->d; ++i) w->x[i] = w->x[i] + w->v[i] * t;
+        for (int i = 0; i < w->d; ++i) w->x[i] = FUSED(cfg) ? fma(w->v[i], t, w->x[i]) : w->x[i] + w->v[i] * t;
     }
 }
 

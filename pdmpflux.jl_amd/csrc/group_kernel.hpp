@@ -150,13 +150,13 @@ struct GroupChain {
             xt = {x * tp.c + v * tp.s, x * (-tp.s) + v * tp.c};
             vt = {(-x) * tp.s + v * tp.c, (-x) * tp.c + v * (-tp.s)};
         } else {
-            xt = {x + v * tp.t, v};
+            xt = {fma(v, tp.t, x), v};                       // fused: GROUP order of the checker
             vt = {v, 0.0};
         }
     }
     __device__ __forceinline__ void flow(double x, double v, const TimePt &tp, double &xt, double &vt) const {
         if constexpr (SAMPLER == S_BOOMERANG) { xt = x * tp.c + v * tp.s; vt = (-x) * tp.s + v * tp.c; }
-        else { xt = x + v * tp.t; vt = v; }
+        else { xt = fma(v, tp.t, x); vt = v; }
     }
     // out[i] = sum_j P[i,j] in[j], j left to right per row (row i owned by lane i % 64, slot i / 64).
     // Eight rows per lane are accumulated together so that eight independent 512-byte column pieces are in
@@ -337,11 +337,11 @@ struct GroupChain {
     }
     // one tangent-intersection cell of one coordinate, UpperBound.jl:229-241 (absolute-time form, Q1)
     __device__ __forceinline__ static double cell_vect(double v0, double g0, double v1, double g1, double t0, double t1, double h) {
-        const double num = ((v0 - v1) + g1 * t1) - g0 * t0;                            // :229
+        const double num = fma(-g0, t0, fma(g1, t1, v0 - v1));                         // :229 ((v0-v1) + g1 t1) - g0 t0, fused
         const double den = g1 - g0;
         const bool fast = __ballot(den != 0.0) == 0ull;                                // wave-uniform
         const double q = cell_q(num, den, h, fast);                                    // :234-235
-        const double inter = v0 + g0 * q;                                              // :237
+        const double inter = fma(g0, q, v0);                                           // :237
         return fmax(fmax(fmax(v0, v1), inter), 0.0);                                   // :239-241
     }
 
@@ -424,9 +424,9 @@ struct GroupChain {
         point_scalar<FDM>(0.0, harg, f0, s0);
         for (int j = 0; j < GNG - 1; ++j) {
             point_scalar<FDM>((j == GNG - 2) ? harg : (double)(j + 1) * h, harg, f1, s1);
-            const double num = (f0 - f1) + s1 * h;                                     // :123 relative form
+            const double num = fma(s1, h, f0 - f1);                                    // :123 relative form
             const double q = cell_q(num, s1 - s0, h, false);                           // :124-125
-            const double inter = f0 + s0 * q;                                          // :127
+            const double inter = fma(s0, q, f0);                                       // :127
             bj = fmax(fmax(fmax(f0, f1), inter), 0.0);                                 // :128-130
             bj += refresh;                                                             // :131
             acc += bj;
