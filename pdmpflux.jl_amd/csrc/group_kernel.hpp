@@ -83,6 +83,7 @@ template <int TARGET> struct GTarget;
 
 template <> struct GTarget<T_GAUSS_ISO> {
     static constexpr bool kShared = false, kTile = false;
+    static constexpr bool kLinear = true;      // grad-U is affine in x: along a linear flow the rate's slope is the same at every grid time
     template <class T> using Sh = NoShared;
     __device__ __forceinline__ void init(const double *, int) {}
     template <class T> __device__ __forceinline__ NoShared shared(T, T) const { return {}; }
@@ -90,6 +91,7 @@ template <> struct GTarget<T_GAUSS_ISO> {
 };
 template <> struct GTarget<T_GAUSS_DIAG> {
     static constexpr bool kShared = false, kTile = false;
+    static constexpr bool kLinear = true;
     template <class T> using Sh = NoShared;
     const double *mu, *prec;            // LDS copies
     __device__ __forceinline__ void init(const double *lds_params, int d) { mu = lds_params; prec = lds_params + d; }
@@ -103,6 +105,7 @@ template <> struct GTarget<T_GAUSS_DIAG> {
 template <class T> struct BananaSh { T g0, r; };
 template <> struct GTarget<T_BANANA> {          // test/test_config.jl:33-36
     static constexpr bool kShared = true, kTile = false;
+    static constexpr bool kLinear = false;
     template <class T> using Sh = BananaSh<T>;
     int d;
     __device__ __forceinline__ void init(const double *, int dim) { d = dim; }
@@ -339,7 +342,11 @@ struct GroupChain {
     __device__ __forceinline__ static double cell_vect(double v0, double g0, double v1, double g1, double t0, double t1, double h) {
         const double num = fma(-g0, t0, fma(g1, t1, v0 - v1));                         // :229 ((v0-v1) + g1 t1) - g0 t0, fused
         const double den = g1 - g0;
-        const bool fast = __ballot(den != 0.0) == 0ull;                                // wave-uniform
+        // Zig-Zag on a potential with affine gradient and forward-mode slopes: slope = (d grad_i/dx_i) v_i^2 at every
+        // grid time, the same double each time, so den == 0 exactly for every lane -- known at compile time, no ballot
+        // (a convergent operation that would also keep the compiler from overlapping consecutive coordinates).
+        constexpr bool always_fast = (SAMPLER == S_ZIGZAG) && Tgt::kLinear && !FD;
+        const bool fast = always_fast ? true : (__ballot(den != 0.0) == 0ull);         // wave-uniform
         const double q = cell_q(num, den, h, fast);                                    // :234-235
         const double inter = fma(g0, q, v0);                                           // :237
         return fmax(fmax(fmax(v0, v1), inter), 0.0);                                   // :239-241
@@ -845,6 +852,7 @@ struct GroupChain {
 template <class T> struct DenseSh { const double *g, *b; };
 template <> struct GTarget<T_GAUSS_DENSE> {
     static constexpr bool kShared = true, kTile = true;
+    static constexpr bool kLinear = false;     // (it is affine, but its slope lives in an LDS tile: keep the generic path)
     static constexpr int kExtraTiles = 4;          // two gradient tiles, P v, scratch x_t
     template <class T> using Sh = DenseSh<T>;
     const double *P;
