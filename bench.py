@@ -235,7 +235,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(a),
                          "kernel": kernel, "kernel_ms": kernel_ms, "bytes_per_event": bytes_per_event,
-                         "note": "fp64-VALU-bound state machine; HBM fraction is the requested headline"},
+                         "note": "fp64 state machine bound by VALU issue + dependency latency (63 % VALU busy at 3 waves/SIMD, LDS-limited); "
+                                 "HBM fraction is the requested headline"},
         }
         if a.cpu_seconds > 0 and world == 1:                     # CPU baseline: rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(a, sampler)
