@@ -405,6 +405,43 @@ struct GroupChain {
             else val[q] = (sgn ? dv : fmax(0.0, dv)) + p.refresh;
         }
     }
+    // NP grid times in ONE pass over the coordinates (x, v of a slot are read once and the NP dependency chains
+    // interleave); per grid time the arithmetic and the summation order are those of eval_scalar.
+    template <int NP>
+    __device__ __forceinline__ void eval_scalar_multi(const TimePt (&tp)[NP], double (&val)[NP], double (&slp)[NP]) {
+        typename Tgt::template Sh<Dual> sh[NP];
+        double fv[NP], fe[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { sh[q] = shared_at<Dual>(tp[q]); fv[q] = 0.0; fe[q] = 0.0; }
+        for (int s = 0; s < K; ++s) {
+            const int i = s * G + g;
+            const bool valid = i < p.d;
+            const double x = X(s), v = V(s);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                Dual xt, vt;
+                flow(x, v, tp[q], xt, vt);
+                const Dual gd = tgt.grad(i, xt, sh[q]);
+                double a = gd.v * vt.v, b = sdot(gd, vt);
+                if constexpr (SAMPLER == S_ZIGZAG) {
+                    b = (0.0 < a) ? b : 0.0;
+                    a = fmax(0.0, a);
+                }
+                fv[q] += valid ? a : 0.0;
+                fe[q] += valid ? b : 0.0;
+            }
+        }
+        const bool sgn = p.signed_bound != 0;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const double dv = group_sum(fv[q], G), de = group_sum(fe[q], G);
+            if constexpr (SAMPLER == S_ZIGZAG) { val[q] = dv; slp[q] = de; }
+            else {
+                val[q] = (sgn ? dv : fmax(0.0, dv)) + p.refresh;              // includes refresh_rate (Q2)
+                slp[q] = sgn ? de : ((0.0 < dv) ? de : 0.0);
+            }
+        }
+    }
     template <bool FDM>
     __device__ __forceinline__ void point_scalar(double t, double harg, double &val, double &slp) {
         if constexpr (!FDM) {
@@ -425,12 +462,10 @@ struct GroupChain {
     __device__ __forceinline__ void bound_invert_scalar(double harg, double E, double &tpo, double &lbo) {
         const double h = harg / (double)(GNG - 1);
         const double refresh = (p.signed_bound != 0) ? p.refresh : 0.0;               // AbstractPDMP.jl:104-112
-        double acc = 0.0, cprev = 0.0, bj = 0.0, f0, s0, f1, s1;
+        double acc = 0.0, cprev = 0.0, bj = 0.0, f0, s0;
         bool found = false;
         tpo = __builtin_huge_val();
-        point_scalar<FDM>(0.0, harg, f0, s0);
-        for (int j = 0; j < GNG - 1; ++j) {
-            point_scalar<FDM>((j == GNG - 2) ? harg : (double)(j + 1) * h, harg, f1, s1);
+        auto cell = [&](int j, double f1, double s1) {                                 // cell j from grid times j (f0, s0) and j+1
             const double num = fma(s1, h, f0 - f1);                                    // :123 relative form
             const double q = cell_q(num, s1 - s0, h, false);                           // :124-125
             const double inter = fma(s0, q, f0);                                       // :127
@@ -446,7 +481,36 @@ struct GroupChain {
             cprev = cj;
             f0 = f1;
             s0 = s1;
-            if (__ballot(!found) == 0ull) break;
+        };
+        if constexpr (!FDM && !Tgt::kTile) {
+            // lazy in batches of three cells: grid times {0,1,2,3}, {4,5,6}, {7,8,9}, one coordinate pass per batch
+            {
+                TimePt tp[4];
+                double f[4], sl[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) time_pt((double)q * h, tp[q]);
+                eval_scalar_multi<4>(tp, f, sl);                                       // :97, :102
+                f0 = f[0]; s0 = sl[0];
+#pragma unroll
+                for (int q = 1; q < 4; ++q) cell(q - 1, f[q], sl[q]);
+            }
+            for (int jb = 3; jb < GNG - 1 && __ballot(!found) != 0ull; jb += 3) {
+                TimePt tp[3];
+                double f[3], sl[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) time_pt((jb + q == GNG - 2) ? harg : (double)(jb + q + 1) * h, tp[q]);
+                eval_scalar_multi<3>(tp, f, sl);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) cell(jb + q, f[q], sl[q]);
+            }
+        } else {
+            double f1, s1;
+            point_scalar<FDM>(0.0, harg, f0, s0);
+            for (int j = 0; j < GNG - 1; ++j) {
+                point_scalar<FDM>((j == GNG - 2) ? harg : (double)(j + 1) * h, harg, f1, s1);
+                cell(j, f1, s1);
+                if (__ballot(!found) == 0ull) break;
+            }
         }
         if (!found) lbo = bj;
     }
