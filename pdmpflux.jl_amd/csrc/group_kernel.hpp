@@ -720,14 +720,23 @@ struct GroupChain {
                     }
                 }
             } else {
+                // randn!, :67 / randn(dim), :65: the G lanes of the chain share the Box-Muller pairs -- lane g draws pairs
+                // g, g+G, ... (one Philox block, log, sqrt, sincos per PAIR) and writes both normals into the chain's v tile
+                const int logG = __builtin_ctz(G);
+                for (int P = g; 2 * P < d; P += G) {
+                    double z0, z1;
+                    rng.normal_pair(P, z0, z1);
+                    const int i0 = 2 * P, i1 = 2 * P + 1;
+                    vs[(i0 >> logG) * WAVE + base + (i0 & (G - 1))] = z0;
+                    if (i1 < d) vs[(i1 >> logG) * WAVE + base + (i1 & (G - 1))] = z1;
+                }
+                rng.normals_done(d);
                 acc = 0.0;
                 for (int s = 0; s < K; ++s) {
                     const int i = s * G + g;
-                    const double z = (i < d) ? rng.normal_coord(i) : 0.0;   // randn!, :67 / randn(dim), :65
-                    V(s) = z;
-                    acc += z * z;
+                    const double z = V(s);
+                    acc += (i < d) ? z * z : 0.0;
                 }
-                rng.normals_done(d);
                 if (SAMPLER == S_BPS && !p.gaussian_velocity) {          // normalize!, :71
                     const double inv = 1.0 / __dsqrt_rn(group_sum(acc, G));
                     for (int s = 0; s < K; ++s) V(s) = V(s) * inv;

@@ -226,6 +226,18 @@ struct ChainRng {
         det_sincos_2pi(u1, sn, cs);
         return (i & 1) ? rad * sn : rad * cs;
     }
+    // both normals of pair P (coordinates 2P and 2P+1) from one Philox block
+    __device__ __forceinline__ void normal_pair(int P, double &z0, double &z1) const {
+        const uint64_t blk = ((n + 1) >> 1) + (uint64_t)P;
+        uint32_t w[4];
+        philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), c2, c3, k0, k1, w);
+        const double u0 = bits_to_u(w[0], w[1]), u1 = bits_to_u(w[2], w[3]);
+        const double rad = __dsqrt_rn(-2.0 * det_log(u0));
+        double sn, cs;
+        det_sincos_2pi(u1, sn, cs);
+        z0 = rad * cs;
+        z1 = rad * sn;
+    }
     __device__ __forceinline__ void normals_done(int d) {
         n = ((n + 1) & ~1ull) + 2 * (uint64_t)((d + 1) / 2);
     }
