@@ -155,6 +155,10 @@ int pdmp_check_status(pdmp_handle h, int64_t *n_guard);
 int pdmp_get_timing(pdmp_handle h, pdmp_timing_t *out);
 int pdmp_reset_timing(pdmp_handle h);
 
+/* Diagnostics: number of GEMM phases (one d x d by d x 2C fp64 GEMM each) of the last dense-precision batched run
+ * on this process (pdmpflux.jl_amd/csrc/dense_batched.hip); 0 if that path has not run. */
+long long pdmp_dense_batched_last_phases(void);
+
 /* Test hook: first n variates of stream (seed, chain) produced ON THE DEVICE with the engine's
  * generator; kind 0 uniform, 1 Exp(1), 2 normal vector.  out is a HOST pointer. */
 int pdmp_debug_rng(pdmp_handle h, uint64_t seed, int64_t chain, int32_t kind, int64_t n, double *out);

@@ -1,0 +1,331 @@
+// dense_batched.hip -- Zig-Zag on a dense-precision Gaussian, U = x'Px/2 (BASELINE config 4), for MANY chains:
+// the only O(d^2) operation of the path, grad-U(x_t) = P x_t, is taken out of the per-chain state machine and
+// done for all chains at once as ONE fp64 GEMM per phase on the matrix cores (rocBLAS dgemm -> v_mfma_f64 on
+// gfx950), instead of C independent mat-vecs that each stream the 8 MB of P out of L2 / Infinity Cache
+// (group_kernel.hpp, GTarget<T_GAUSS_DENSE>: 7e4 events/s at d = 1000).
+//
+// The thinning state machine of src/SamplingLoopInplace.jl:27-217 becomes a coroutine per chain that yields
+// every time it needs a gradient: each phase every live chain posts exactly one request vector (x + v t for
+// the next grid time of its bound, UpperBound.jl:203-247 built lazily cell by cell, or for the proposed event
+// time, SamplingLoopInplace.jl:113-129); the phase's GEMM multiplies P with [requests | velocities] (the
+// second half gives P v, the time-derivative of grad-U along the flow, for the forward-mode slopes); the step
+// kernel consumes the products, advances every chain to its next request and records accepted events.
+// Chains advance at their own pace (no lock-step waste: a chain builds only the cells it reads).
+//
+// Arithmetic: everything except the GEMM is the engine's WAVE64 order (wave_math.hpp).  The GEMM's accumulation
+// order is rocBLAS' (MFMA k-blocks), so this path is checked against the oracle to a tolerance (1e-9 relative on
+// event times / positions over short runs), not bit for bit; PDMP_DENSE_MODE=matvec selects the bit-exact kernel.
+#include "skeleton_kernel.hpp"
+
+#include <rocblas/rocblas.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace pdmp {
+
+enum : int { DB_LEFT = 0, DB_CELL = 1, DB_RATE = 2 };
+enum : int { DB_FRESH = 0, DB_ERR = 1, DB_REUSE = 2 };
+
+struct DbState {                 // per-chain coroutine state (one 256-byte record per chain)
+    double t, horizon, ts, tp, E, lb, ar, hB, harg, h, acc, cprev, bj, ev[5];
+    unsigned long long rng_n;
+    int32_t phase, mode, j, k, it, errored, rejected, hits, done, pad;
+};
+
+struct DbParams {
+    int32_t d, signed_bound, adaptive;
+    int64_t C, n_sk, chain0, cap;
+    uint64_t seed;
+    double tmax;
+    const double *xinit, *vinit;
+    double *Xs;                  // C x d chain-major positions
+    double *In;                  // d x 2C column-major: [requests | velocities]   (GEMM input)
+    double *Out;                 // d x 2C column-major: [P requests | P velocities] (GEMM output)
+    double *Gprev;               // C x d: gradient at the left grid time of the cell under construction
+    DbState *st;
+    double *X, *V, *t, *H, *AR, *EV;
+    int32_t *EB, *RJ, *HH;
+    int32_t *status;             // [0] itercap, [1] guard
+    int32_t *remaining;          // live chains
+};
+
+__device__ __forceinline__ void db_record(const DbParams &p, int64_t c, int lane, const double *x, const double *v,
+                                          const DbState &s) {
+    const size_t e = (size_t)c * (size_t)p.n_sk + (size_t)s.k;
+    double *Xe = p.X + e * (size_t)p.d, *Ve = p.V + e * (size_t)p.d;
+    for (int i = lane; i < p.d; i += WAVE) { Xe[i] = x[i]; Ve[i] = v[i]; }
+    if (lane == 0) {
+        p.t[e] = s.t;
+        if (p.H) p.H[e] = s.horizon;
+        if (p.AR) p.AR[e] = s.ar;
+        if (p.EB) p.EB[e] = s.errored;
+        if (p.RJ) p.RJ[e] = s.rejected;
+        if (p.HH) p.HH[e] = s.hits;
+        if (p.EV) for (int q = 0; q < 5; ++q) p.EV[5 * e + q] = s.ev[q];
+    }
+}
+
+// request = x + v * t  (ZigZagSamplers.jl:80), fused as in the group kernel
+__device__ __forceinline__ void db_request(const DbParams &p, int lane, const double *x, const double *v, double t, double *req) {
+    for (int i = lane; i < p.d; i += WAVE) req[i] = fma(v[i], t, x[i]);
+}
+__device__ __forceinline__ void db_flow(const DbParams &p, int lane, double *x, const double *v, double t) {
+    for (int i = lane; i < p.d; i += WAVE) x[i] = fma(v[i], t, x[i]);
+}
+
+// init_state (AbstractPDMP.jl:93-153) + record of the initial state (sample.jl:271-272) + first request (t = 0)
+__global__ __launch_bounds__(256) void db_init_kernel(const DbParams p) {
+    const int lane = lane_id();
+    const int64_t c = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (c >= p.C) return;
+    double *x = p.Xs + (size_t)c * p.d, *req = p.In + (size_t)c * p.d, *v = p.In + ((size_t)p.C + (size_t)c) * p.d;
+    for (int i = lane; i < p.d; i += WAVE) {
+        const double xi = p.xinit[(size_t)c * p.d + i], vi = p.vinit[(size_t)c * p.d + i];
+        x[i] = xi; v[i] = vi; req[i] = xi;
+    }
+    DbState s;
+    s.t = 0.0; s.horizon = p.tmax; s.ts = 0.0; s.tp = 0.0; s.E = 0.0; s.lb = 0.0; s.ar = 0.0; s.hB = p.tmax;
+    s.harg = 0.0; s.h = 0.0; s.acc = 0.0; s.cprev = 0.0; s.bj = 0.0;
+    for (int q = 0; q < 5; ++q) s.ev[q] = 0.0;
+    s.rng_n = 0; s.phase = DB_LEFT; s.mode = DB_FRESH; s.j = 0; s.k = 0; s.it = 0;
+    s.errored = 0; s.rejected = 0; s.hits = 0; s.done = (p.n_sk <= 1) ? 1 : 0; s.pad = 0;
+    db_record(p, c, lane, x, v, s);
+    s.k = 1;
+    if (lane == 0) {
+        p.st[c] = s;
+        if (!s.done) atomicAdd(p.remaining, 1);
+    }
+}
+
+// Start a bound over [0, harg]: one_step_of_thinning! (SamplingLoopInplace.jl:65-85), erroneous_acceptance_rate!
+// (:131-151) or the rebuild after a rejection (if_reject!, :188-203).  The exponential is drawn first (the bound
+// consumes no random numbers).  Posts the request for grid time t_1.
+__device__ __forceinline__ void db_begin_bound(const DbParams &p, int lane, DbState &s, ChainRng &rng, const double *x,
+                                               const double *v, double *req) {
+    const double harg = (s.mode == DB_ERR) ? s.horizon / 2 : ((s.mode == DB_REUSE) ? s.hB : s.horizon);
+    s.hB = harg; s.harg = harg; s.h = harg / 9.0;
+    const double e1 = rng.exponential();
+    s.E = (s.mode == DB_REUSE) ? s.E + e1 : e1;
+    s.acc = 0.0; s.cprev = 0.0; s.bj = 0.0; s.j = 0;
+    db_request(p, lane, x, v, s.h, req);                         // t_1 = 1 * h
+    s.phase = DB_CELL;
+}
+
+__global__ __launch_bounds__(256) void db_step_kernel(const DbParams p) {
+    const int lane = lane_id();
+    const int64_t c = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (c >= p.C) return;
+    DbState s = p.st[c];
+    if (s.done) return;
+    const int d = p.d;
+    double *x = p.Xs + (size_t)c * d, *req = p.In + (size_t)c * d, *v = p.In + ((size_t)p.C + (size_t)c) * d;
+    const double *G = p.Out + (size_t)c * d;                     // P * (last request)
+    const double *B = p.Out + ((size_t)p.C + (size_t)c) * d;     // P * v
+    double *Gp = p.Gprev + (size_t)c * d;
+    ChainRng rng;
+    rng.init(p.seed, (uint64_t)(p.chain0 + c));
+    rng.restore(s.rng_n);
+    const bool adaptive = p.adaptive != 0, sgn = p.signed_bound != 0;
+
+    if (++s.it > p.cap * 4) {                                    // phases, not thinning steps: generous cap
+        s.done = 1;
+        if (lane == 0) { atomicAdd(&p.status[0], 1); atomicSub(p.remaining, 1); p.st[c] = s; }
+        return;
+    }
+
+    if (s.phase == DB_LEFT) {
+        // G = grad-U at the current state (grid time 0 of a new bound)
+        for (int i = lane; i < d; i += WAVE) Gp[i] = G[i];
+        db_begin_bound(p, lane, s, rng, x, v, req);
+    } else if (s.phase == DB_CELL) {
+        // cell j from grid times j (Gp) and j+1 (G); slopes from B = P v: upper_bound_grid_vect, UpperBound.jl:208-246
+        const double h = s.h, t0 = (double)s.j * h, t1 = (s.j == 8) ? s.harg : (double)(s.j + 1) * h;
+        double part = 0.0;
+        for (int i = lane; i < d; i += WAVE) {
+            const double vi = v[i], bi = B[i];
+            double v0 = Gp[i] * vi, v1 = G[i] * vi, g = bi * vi;          // signed_rate_vect and its t-derivative
+            double g0 = g, g1 = g;
+            if (!sgn) { g0 = (0.0 < v0) ? g : 0.0; g1 = (0.0 < v1) ? g : 0.0; v0 = fmax(0.0, v0); v1 = fmax(0.0, v1); }
+            const double num = fma(-g0, t0, fma(g1, t1, v0 - v1));         // :229
+            const double den = g1 - g0;
+            const double q = (den == 0.0) ? ((num > 0.0) ? h : 0.0) : fmin(fmax(num / den, 0.0), h);   // :234-235
+            const double inter = fma(g0, q, v0);                           // :237
+            part += fmax(fmax(fmax(v0, v1), inter), 0.0);                  // :239-241
+        }
+        const double bj = wave_sum(part);                                  // :246
+        s.bj = bj;
+        s.acc += bj;
+        const double cj = s.acc * h;
+        bool fin = false;
+        if (!(cj < s.E)) {                                                 // next_event, :264-273
+            s.tp = t0 + (s.E - s.cprev) / (cj - s.cprev) * h;
+            s.lb = bj;
+            fin = true;
+        } else {
+            s.cprev = cj;
+            if (s.j == 8) { s.tp = __builtin_huge_val(); s.lb = bj; fin = true; }
+        }
+        if (!fin) {
+            for (int i = lane; i < d; i += WAVE) Gp[i] = G[i];             // right grid time becomes the left one
+            s.j++;
+            db_request(p, lane, x, v, (s.j == 8) ? s.harg : (double)(s.j + 1) * h, req);
+        } else {
+            bool propose;
+            if (s.mode == DB_ERR) {                                        // :131-151
+                if (adaptive) s.horizon = s.hB;
+                s.errored++;
+                { const int slot = s.errored % 5;                          // :148
+#pragma unroll
+                  for (int q = 0; q < 5; ++q) if (q == slot) s.ev[q] = s.ar; }
+                propose = s.tp < s.horizon;
+            } else if (s.mode == DB_REUSE) {                               // :188-203
+                if (adaptive) s.horizon = s.horizon / 1.04;
+                s.rejected++;
+                if (s.tp > s.horizon) { db_flow(p, lane, x, v, s.horizon); s.ts += s.horizon; s.hits++; }
+                propose = s.tp < s.horizon;
+            } else if (s.tp > s.horizon) {                                 // move_to_horizon!, :87-101
+                db_flow(p, lane, x, v, s.horizon);
+                s.ts += s.horizon;
+                s.hits++;
+                if (adaptive) s.horizon = s.horizon * 1.01;
+                propose = false;
+            } else {
+                propose = s.tp < s.horizon;
+            }
+            s.mode = DB_FRESH;
+            if (propose) { db_request(p, lane, x, v, s.tp, req); s.phase = DB_RATE; }
+            else { db_request(p, lane, x, v, 0.0, req); s.phase = DB_LEFT; }    // new bound from the (possibly moved) state
+        }
+    } else {  // DB_RATE: G = grad-U at x + v tp
+        double part = 0.0;
+        for (int i = lane; i < d; i += WAVE) part += fmax(0.0, G[i] * v[i]);      // ZigZagSamplers.jl:83-86
+        const double lam = wave_sum(part);
+        s.ar = lam / s.lb;
+        if (s.ar > 1.0) {
+            s.mode = DB_ERR;
+            db_request(p, lane, x, v, 0.0, req);
+            s.phase = DB_LEFT;
+        } else {
+            const double u = rng.uniform();
+            if (u < s.ar) {                                                // if_accept!, :170-186
+                db_flow(p, lane, x, v, s.tp);
+                // velocity_jump (ZigZagSamplers.jl:101-107): Categorical over lambda_i / S, un-normalised walk against u2*S
+                const double u2 = rng.uniform();
+                if (lam > 0.0) {
+                    const double theta = u2 * lam;
+                    double carry = 0.0;
+                    int m = -1;
+                    for (int base = 0; base < d && m < 0; base += WAVE) {
+                        const int i = base + lane;
+                        const double li = (i < d) ? fmax(0.0, G[i] * v[i]) : 0.0;
+                        const double inc = wave_scan_incl(li, lane);
+                        const unsigned long long hit = __ballot((i < d) && (carry + inc > theta));
+                        if (hit != 0ull) m = base + (int)__builtin_ctzll(hit);
+                        carry = carry + readlane_d(inc, WAVE - 1);
+                    }
+                    if (m < 0) m = d - 1;
+                    if (lane == (m & (WAVE - 1))) v[m] = -v[m];
+                } else if (lane == 0) {
+                    atomicAdd(&p.status[1], 1);                            // Q11 guard
+                }
+                s.t = s.t + s.tp + s.ts;
+                s.ts = 0.0;
+                s.tp = 0.0;
+                db_record(p, c, lane, x, v, s);
+                s.errored = 0; s.rejected = 0; s.hits = 0;
+                for (int q = 0; q < 5; ++q) s.ev[q] = 0.0;
+                s.it = 0;
+                if (++s.k >= p.n_sk) {
+                    s.done = 1;
+                    if (lane == 0) atomicSub(p.remaining, 1);
+                } else {
+                    // grad-U at the new state is the product just consumed: it is the left grid time of the next bound
+                    for (int i = lane; i < d; i += WAVE) Gp[i] = G[i];
+                    db_begin_bound(p, lane, s, rng, x, v, req);            // P v_new arrives with the next GEMM
+                }
+            } else {
+                s.mode = DB_REUSE;                                         // if_reject!: rebuild from the unchanged state
+                db_request(p, lane, x, v, 0.0, req);
+                s.phase = DB_LEFT;
+            }
+        }
+    }
+    s.rng_n = rng.n;
+    if (lane == 0) p.st[c] = s;
+}
+
+}  // namespace pdmp
+
+using namespace pdmp;
+
+static long long g_last_phases = 0;
+extern "C" long long pdmp_dense_batched_last_phases(void) { return g_last_phases; }   // GEMM phases of the last run (diagnostics)
+
+// Host driver.  Returns hipSuccess-like 0, or a negative code: -3 runtime, -5 unsupported.
+extern "C" int pdmp_dense_batched_run(int device, int d, int signed_bound, int adaptive, double tmax, int64_t cap,
+                                      const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
+                                      const double *xinit, const double *vinit, double *X, double *V, double *t,
+                                      double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
+                                      int32_t *status, void *stream_v, char *err, int errlen) {
+    hipStream_t stream = (hipStream_t)stream_v;
+#define DB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { snprintf(err, errlen, "%s: %s", #expr, hipGetErrorString(e_)); goto fail; } } while (0)
+#define DB_BLAS(expr) do { rocblas_status s_ = (expr); if (s_ != rocblas_status_success) { snprintf(err, errlen, "%s: rocblas status %d", #expr, (int)s_); goto fail; } } while (0)
+    static rocblas_handle handles[16] = {nullptr};
+    double *Xs = nullptr, *In = nullptr, *Out = nullptr, *Gprev = nullptr;
+    DbState *st = nullptr;
+    int32_t *remaining = nullptr;
+    int rc = -3;
+    {
+        const size_t n = (size_t)C * (size_t)d;
+        DB_TRY(hipMalloc(&Xs, n * 8));
+        DB_TRY(hipMalloc(&In, 2 * n * 8));
+        DB_TRY(hipMalloc(&Out, 2 * n * 8));
+        DB_TRY(hipMalloc(&Gprev, n * 8));
+        DB_TRY(hipMalloc(&st, (size_t)C * sizeof(DbState)));
+        DB_TRY(hipMalloc(&remaining, sizeof(int32_t)));
+        DB_TRY(hipMemsetAsync(remaining, 0, sizeof(int32_t), stream));
+        DB_TRY(hipMemsetAsync(Out, 0, 2 * n * 8, stream));
+        if (device < 0 || device >= 16) { snprintf(err, errlen, "device ordinal out of range"); goto fail; }
+        if (!handles[device]) DB_BLAS(rocblas_create_handle(&handles[device]));
+        DB_BLAS(rocblas_set_stream(handles[device], stream));
+        DB_BLAS(rocblas_set_pointer_mode(handles[device], rocblas_pointer_mode_host));
+
+        DbParams p;
+        p.d = d; p.signed_bound = signed_bound; p.adaptive = adaptive;
+        p.C = C; p.n_sk = n_sk; p.chain0 = chain0; p.cap = cap; p.seed = seed; p.tmax = tmax;
+        p.xinit = xinit; p.vinit = vinit; p.Xs = Xs; p.In = In; p.Out = Out; p.Gprev = Gprev; p.st = st;
+        p.X = X; p.V = V; p.t = t; p.H = H; p.AR = AR; p.EV = EV; p.EB = EB; p.RJ = RJ; p.HH = HH;
+        p.status = status; p.remaining = remaining;
+        const dim3 grid((unsigned)((C + 3) / 4)), block(256);
+        hipLaunchKernelGGL(db_init_kernel, grid, block, 0, stream, p);
+        DB_TRY(hipGetLastError());
+        const double one = 1.0, zero = 0.0;
+        // a chain needs ~1.4 cells + 1 proposal per event (+ horizon moves, rejections): budget 16 phases per event
+        const int64_t max_phases = 16 * n_sk + 64;
+        int32_t live = 1;
+        g_last_phases = 0;
+        for (int64_t ph = 0; ph < max_phases && live > 0; ++ph) {
+            ++g_last_phases;
+            // Out (d x 2C) = P (d x d) * In (d x 2C): grad-U of every request and P v of every chain
+            DB_BLAS(rocblas_dgemm(handles[device], rocblas_operation_none, rocblas_operation_none, d, (int)(2 * C), d, &one,
+                                  P_dev, d, In, d, &zero, Out, d));
+            hipLaunchKernelGGL(db_step_kernel, grid, block, 0, stream, p);
+            if ((ph & 7) == 7) {
+                DB_TRY(hipMemcpyAsync(&live, remaining, sizeof live, hipMemcpyDeviceToHost, stream));
+                DB_TRY(hipStreamSynchronize(stream));
+            }
+        }
+        DB_TRY(hipGetLastError());
+        DB_TRY(hipMemcpyAsync(&live, remaining, sizeof live, hipMemcpyDeviceToHost, stream));
+        DB_TRY(hipStreamSynchronize(stream));
+        if (live > 0) { snprintf(err, errlen, "%d chain(s) did not finish within the phase budget", (int)live); rc = -4; goto fail; }
+        rc = 0;
+    }
+fail:
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(Xs); (void)hipFree(In); (void)hipFree(Out); (void)hipFree(Gprev); (void)hipFree(st); (void)hipFree(remaining);
+    return rc;
+#undef DB_TRY
+#undef DB_BLAS
+}

@@ -36,6 +36,12 @@ struct EventPair { hipEvent_t a, b; };
 
 }  // namespace
 
+extern "C" int pdmp_dense_batched_run(int device, int d, int signed_bound, int adaptive, double tmax, int64_t cap,
+                                      const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
+                                      const double *xinit, const double *vinit, double *X, double *V, double *t,
+                                      double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
+                                      int32_t *status, void *stream, char *err, int errlen);
+
 struct pdmp_engine {
     pdmp_config_t cfg;
     int group_lanes = 0;              // 0: wave-per-chain kernel; else lanes per chain of the group kernel
@@ -433,6 +439,20 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
     }
     EventPair ev;
     if (int rc = begin_timed(h, s, ev)) return rc;
+    // Dense-precision Zig-Zag on many chains: grad-U of all chains as one fp64 GEMM per phase (dense_batched.hip);
+    // small ensembles and PDMP_DENSE_MODE=matvec keep the bit-exact per-chain mat-vec kernel.
+    const char *dense_mode = getenv("PDMP_DENSE_MODE");
+    const bool batched = c.target_id == PDMP_T_GAUSS_DENSE && c.sampler == PDMP_ZIGZAG && c.vectorized_bound && c.grid_size == GNG &&
+                         c.deriv_mode == PDMP_DERIV_FORWARD && !taped && 2 * C < 0x7fffffffLL &&
+                         (dense_mode ? strcmp(dense_mode, "gemm") == 0 : C >= 64);
+    if (batched) {
+        char msg[256] = "";
+        const int rc = pdmp_dense_batched_run(h->device, c.dim, c.signed_bound, c.adaptive, c.tmax, c.max_iter_per_event, h->d_tparams, C, n_sk,
+                                              chain_id_offset, seed, xinit, vinit, X, V, t, p.H, p.AR, p.EB, p.EV, p.RJ, p.HH,
+                                              h->d_status, stream, msg, (int)sizeof msg);
+        if (rc != 0) return fail(rc == -4 ? PDMP_ERR_ITERCAP : PDMP_ERR_RUNTIME, "dense batched path: %s", msg);
+        return end_timed(h, s, ev);
+    }
     if (h->group_lanes > 0 && !taped) HIP_TRY(pick_group_launcher(c.sampler, c.target_id)(gp, s));
     else HIP_TRY(pick_launcher(c.sampler, c.target_id)(p, s));
     return end_timed(h, s, ev);

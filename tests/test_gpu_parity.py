@@ -317,3 +317,24 @@ def test_tape_replay_bitwise(engine, oracle, kind, dim, target, kw):
     s.clear_tape()
     again = engine.sample_skeleton_ensemble(s, 20, x, v, seed=3)               # back on Philox and the fast kernel
     assert np.isfinite(again["t"]).all() and s.group_lanes() > 0
+
+
+@pytest.mark.parametrize("dim,chains,n_sk", [(100, 64, 80), (257, 70, 40)])
+def test_dense_precision_gemm_path_matches_oracle(engine, oracle, monkeypatch, dim, chains, n_sk):
+    """Config-4 path: for >= 64 chains grad-U = P x of ALL chains is one fp64 GEMM per phase on the matrix cores
+    (dense_batched.hip).  rocBLAS' MFMA accumulation order is not the checker's left-to-right row sums, so this path is
+    held to a tolerance -- event times and positions within 1e-9 relative of the reference-order restatement, velocities
+    and counters identical -- while PDMP_DENSE_MODE=matvec (the per-chain mat-vec kernel) stays bit-exact."""
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", dim, "dense", arith=oracle.ARITH_REFERENCE)
+    x, v = make_init("ZigZagAD", dim, chains)
+    got = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=21)
+    ref = oracle.sample_skeleton(cfg, n_sk, x, v, 21)
+    assert np.array_equal(got["V"], ref["V"])
+    for k in ("rejected", "hitting_horizon", "errored_bound"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert np.allclose(got["t"], ref["t"], rtol=1e-9, atol=0)
+    assert np.allclose(got["X"], ref["X"], rtol=1e-7, atol=1e-9)
+    monkeypatch.setenv("PDMP_DENSE_MODE", "matvec")
+    s2, cfg2 = make_pair(engine, oracle, "ZigZagAD", dim, "dense")
+    got2 = engine.sample_skeleton_ensemble(s2, 12, x[:6], v[:6], seed=21)
+    assert_bitwise(got2, oracle.sample_skeleton(cfg2, 12, x[:6], v[:6], 21))
