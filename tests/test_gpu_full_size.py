@@ -1,0 +1,92 @@
+"""Full-size runs of the BASELINE configurations on one MI355X, checked through size-independent properties of the
+path (the oracle cannot cover 10^8 events in seconds) plus bit-exact spot checks of a strided sample of chains."""
+import numpy as np
+import pytest
+
+from helpers import make_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_inputs(torch, kind, C, d, banana=False):
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev); g.manual_seed(1234)
+    x = torch.randn((C, d), dtype=torch.float64, device=dev, generator=g)
+    if banana:
+        x = 1.0 + 0.1 * x
+    if kind == "zz":
+        v = torch.randint(0, 2, (C, d), device=dev, generator=g).to(torch.float64) * 2 - 1
+    else:
+        v = torch.randn((C, d), dtype=torch.float64, device=dev, generator=g)
+        v = v / v.norm(dim=1, keepdim=True)
+    return x.contiguous(), v.contiguous()
+
+
+def test_config2_zigzag_gaussian_1e5_chains(engine, oracle):
+    """BASELINE configs[1]: Zig-Zag d=50 Gaussian, 10^5 chains x 1000 skeleton points (9.99e7 events, 80.8 GB)."""
+    import torch
+    from pdmpflux.jl_amd import ensemble
+    C, d, n_sk = 100_000, 50, 1000
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", d, "iso")
+    x, v = _device_inputs(torch, "zz", C, d)
+    out = ensemble.sample_skeleton_device(s, n_sk, x, v, seed=2024, diagnostics=True)
+    t, X, V = out["t"], out["X"], out["V"]
+    assert bool((t[:, 1:] > t[:, :-1]).all())                                   # diff(t) > 0, test_comprehensive.jl:147
+    assert bool((t[:, 0] == 0).all()) and bool(torch.isfinite(X).all())
+    assert bool((V.abs() == 1.0).all())                                         # flips only change signs
+    flips = (V[:, 1:] != V[:, :-1]).sum(dim=2)
+    assert bool((flips == 1).all())                                             # exactly one coordinate flips per event
+    # each event moves x along v for the elapsed time (flows are linear): x_k = x_{k-1} + v_{k-1} * dt up to the
+    # roundings of the horizon moves in between
+    dt = (t[:, 1:] - t[:, :-1]).unsqueeze(2)
+    resid = (X[:, 1:] - (X[:, :-1] + V[:, :-1] * dt)).abs().max()
+    assert float(resid) < 1e-12
+    rate = (n_sk - 1) / t[:, -1]
+    assert abs(float(rate.mean()) / (d / np.sqrt(2 * np.pi)) - 1) < 0.02        # stationary event rate d/sqrt(2 pi)
+    assert int(out["errored_bound"].sum()) == 0                                 # linear rate: the grid bound is exact
+    s1, s2 = ensemble.sample_moments_device(s, 1000, X, V, t)                   # fused moments of 10^8 samples
+    mean = s1.sum(0) / (C * 1000); var = s2.sum(0) / (C * 1000) - mean * mean
+    assert float(mean.abs().max()) < 0.01 and float((var - 1).abs().max()) < 0.02
+    idx = np.arange(0, C, 9973)                                                 # 11 chains, bit for bit against the oracle
+    xh, vh = x.cpu().numpy(), v.cpu().numpy()
+    th, Xh = t.cpu().numpy(), None
+    for c in idx:
+        ref = oracle.sample_skeleton(cfg, n_sk, xh[c:c + 1], vh[c:c + 1], 2024, chain_id_offset=int(c), diagnostics=False)
+        assert np.array_equal(th[c], ref["t"][0]), c
+        assert np.array_equal(X[c].cpu().numpy(), ref["X"][0]), c
+
+
+def test_config3_bps_banana_1e5_chains(engine, oracle):
+    """BASELINE configs[2] on one GPU: BPS d=50 banana (true gradient of U_banana), 10^5 chains x 300 skeleton points."""
+    import torch
+    from pdmpflux.jl_amd import ensemble
+    C, d, n_sk = 100_000, 50, 300
+    s, cfg = make_pair(engine, oracle, "BPS", d, "banana")
+    x, v = _device_inputs(torch, "bps", C, d, banana=True)
+    out = ensemble.sample_skeleton_device(s, n_sk, x, v, seed=7)
+    t, X, V = out["t"], out["X"], out["V"]
+    assert bool((t[:, 1:] > t[:, :-1]).all()) and bool(torch.isfinite(X).all())
+    assert float((V.norm(dim=2) - 1).abs().max()) < 1e-12                       # reflections and normalize! keep |v| = 1
+    idx = np.arange(0, C, 19997)
+    xh, vh = x.cpu().numpy(), v.cpu().numpy()
+    for c in idx:
+        ref = oracle.sample_skeleton(cfg, n_sk, xh[c:c + 1], vh[c:c + 1], 7, chain_id_offset=int(c), diagnostics=False)
+        assert np.array_equal(t[c].cpu().numpy(), ref["t"][0]), c
+        assert np.array_equal(V[c].cpu().numpy(), ref["V"][0]), c
+
+
+def test_config5_boomerang_d100(engine, oracle):
+    """BASELINE configs[4] on one GPU: Boomerang d=100 (defaults tmax=1, refresh 0.1, FiniteDiff), 2x10^4 chains x 200."""
+    import torch
+    from pdmpflux.jl_amd import ensemble
+    C, d, n_sk = 20_000, 100, 200
+    s, cfg = make_pair(engine, oracle, "Boomerang", d, "iso")
+    x, v = _device_inputs(torch, "boom", C, d)
+    out = ensemble.sample_skeleton_device(s, n_sk, x, v, seed=5)
+    t = out["t"]
+    assert bool((t[:, 1:] > t[:, :-1]).all()) and bool(torch.isfinite(out["X"]).all())
+    xh, vh = x.cpu().numpy(), v.cpu().numpy()
+    for c in (0, 7777, 19999):
+        ref = oracle.sample_skeleton(cfg, n_sk, xh[c:c + 1], vh[c:c + 1], 5, chain_id_offset=int(c), diagnostics=False)
+        assert np.array_equal(t[c].cpu().numpy(), ref["t"][0]), c
+        assert np.array_equal(out["X"][c].cpu().numpy(), ref["X"][0]), c
