@@ -39,7 +39,8 @@ def parse():
     ap.add_argument("--n-sk", type=int, default=1000)
     ap.add_argument("--dim", type=int, default=50)
     ap.add_argument("--sampler", default="ZigZagAD", choices=["ZigZagAD", "ZigZag", "BPS", "BPSAD", "Boomerang", "BoomerangAD"])
-    ap.add_argument("--target", default="iso", choices=["iso", "banana", "dense"])
+    ap.add_argument("--target", default="iso", choices=["iso", "banana", "dense", "src_banana"],
+                    help="src_banana: U_banana given as source, differentiated by forward mode on the GPU (pdmp_create_from_source)")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time; 0 disables it")
     return ap.parse_args()
@@ -55,7 +56,7 @@ def dense_precision(a):
 
 
 def make_sampler(P, a):
-    tgt = {"iso": P.GaussianIso, "banana": P.Banana}.get(a.target)
+    tgt = {"iso": P.GaussianIso, "banana": P.Banana, "src_banana": lambda: P.SourcePotential(P.U_BANANA_SOURCE)}.get(a.target)
     tgt = tgt() if tgt else P.GaussianPrecision(dense_precision(a))
     return getattr(P, a.sampler)(a.dim, tgt)
 
@@ -64,7 +65,7 @@ def make_inputs(torch, a, dev, rank):
     g = torch.Generator(device=dev)
     g.manual_seed(a.seed * 1000 + rank)
     x = torch.randn((a.chains, a.dim), dtype=torch.float64, device=dev, generator=g)
-    if a.target == "banana":
+    if a.target in ("banana", "src_banana"):
         x = 1.0 + 0.1 * x
     if a.sampler.startswith("ZigZag"):
         v = torch.randint(0, 2, (a.chains, a.dim), device=dev, generator=g).to(torch.float64) * 2 - 1
@@ -81,7 +82,7 @@ def cpu_baseline(a, sampler):
     import numpy as np
     from oracle import oracle as O
     cores = min(O.num_threads(), int(os.environ.get("PDMP_CPU_THREADS", "16")))   # CPU share of one GPU slot
-    tid = {"iso": O.T_GAUSS_ISO, "banana": O.T_BANANA, "dense": O.T_GAUSS_DENSE}[a.target]
+    tid = {"iso": O.T_GAUSS_ISO, "banana": O.T_BANANA, "dense": O.T_GAUSS_DENSE, "src_banana": O.T_AD_BANANA}[a.target]
     tparams = np.asfortranarray(dense_precision(a)).ravel(order="F") if a.target == "dense" else None
     cfg = O.Config(target_params=tparams, sampler=sampler.sampler_id, dim=a.dim, grid_size=sampler.grid_size, tmax=sampler.tmax,
                    refresh_rate=sampler.refresh_rate, vectorized_bound=sampler.vectorized_bound,
@@ -92,7 +93,7 @@ def cpu_baseline(a, sampler):
 
     def run(C, off):
         x = rs.normal(size=(C, a.dim))
-        if a.target == "banana":
+        if a.target in ("banana", "src_banana"):
             x = 1.0 + 0.1 * x
         if a.sampler.startswith("ZigZag"):
             v = rs.choice([-1.0, 1.0], size=(C, a.dim))

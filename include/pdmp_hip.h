@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PDMP_ABI_VERSION 1
+#define PDMP_ABI_VERSION 2   /* 2: + pdmp_create_from_source, PDMP_T_USER */
 
 enum { PDMP_OK = 0, PDMP_ERR_ARGUMENT = -1, PDMP_ERR_DIMENSION = -2, PDMP_ERR_RUNTIME = -3,
        PDMP_ERR_ITERCAP = -4, PDMP_ERR_UNSUPPORTED = -5 };
@@ -44,7 +44,8 @@ enum { PDMP_ZIGZAG = 0, PDMP_BPS = 1, PDMP_BOOMERANG = 2 };
 enum { PDMP_T_GAUSS_ISO = 0,   /* U = |x|^2/2                         (README.md:36-38)            */
        PDMP_T_GAUSS_DIAG = 1,  /* U = sum prec_i (x_i-mu_i)^2/2 ; params = mu[d], prec[d]            */
        PDMP_T_BANANA = 2,      /* U_banana                           (test/test_config.jl:33-36)   */
-       PDMP_T_GAUSS_DENSE = 3  /* U = x'Px/2 ; params = P[d*d] column-major                         */ };
+       PDMP_T_GAUSS_DENSE = 3, /* U = x'Px/2 ; params = P[d*d] column-major                         */
+       PDMP_T_USER = 4         /* potential given as source: pdmp_create_from_source only              */ };
 /* AD_backend for the time-derivative of the rate (UpperBound.jl:209-224, AbstractPDMP.jl:18-28) */
 enum { PDMP_DERIV_FORWARD = 0 /* "ForwardDiff": exact forward-mode duals */,
        PDMP_DERIV_FINITE_DIFF = 1 /* "FiniteDiff": UpperBound.jl:50-76 */ };
@@ -94,6 +95,19 @@ int         pdmp_device_count(void);     /* hipGetDeviceCount; 0 when no GPU is 
  * (BouncyParticleSamplers.jl:21-94), Boomerang/BoomerangAD (BoomerangSamplers.jl:21-87).
  * Applies the constructors' normalisations; the normalised values can be read back. */
 int pdmp_create(const pdmp_config_t *cfg, pdmp_handle *out);
+/* The `U::Function` argument of the *AD constructors and create_gradient_function (src/ADBackend.jl:30-142), which
+ * accepts a scalar potential (differentiated by ForwardDiff, :95-109) or an already-differentiated gradient (:55-66).
+ * A Julia closure cannot cross a C ABI; the engine takes the function as a few lines of HIP source instead, compiled at
+ * run time (hiprtc) into the same kernel as the built-in potentials:
+ *   PDMP_SRC_POTENTIAL:  template <class X> __device__ auto U(const X &x, int d)              x[j] = coordinate j (0-based)
+ *   PDMP_SRC_GRADIENT:   template <class X> __device__ auto grad_i(int i, const X &x, int d)   coordinate i of grad-U
+ * written with + - * /, sq (= x^2), sqrt_, log_, sin_, cos_ so that it runs on doubles, on forward-mode numbers in time
+ * (the slope of the rate along the flow, UpperBound.jl:102,210) and -- for a potential -- on the nested forward-mode
+ * numbers that yield grad-U (one partial per pass; pdmpflux.jl_amd/csrc/user_ad.hpp states every rule).  cfg->target_id
+ * and target_params are ignored.  A source that does not compile returns PDMP_ERR_ARGUMENT with the compiler's log in
+ * pdmp_last_error().  grid_size must be 10 (or 0, the Brent bound). */
+enum { PDMP_SRC_POTENTIAL = 0, PDMP_SRC_GRADIENT = 1 };
+int pdmp_create_from_source(const pdmp_config_t *cfg, const char *source, int32_t kind, pdmp_handle *out);
 int pdmp_get_config(pdmp_handle h, pdmp_config_t *out);
 int pdmp_destroy(pdmp_handle h);
 /* Arithmetic layout the engine chose for this configuration: lanes per chain G of the group kernel

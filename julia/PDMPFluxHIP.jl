@@ -27,6 +27,25 @@ struct GaussianDiag <: Target; mu::Vector{Float64}; prec::Vector{Float64}; end
 struct Banana <: Target end
 target_id(::GaussianIso) = 0; target_id(::GaussianDiag) = 1; target_id(::Banana) = 2
 params(::Target) = Float64[]; params(t::GaussianDiag) = vcat(t.mu, t.prec)
+# an arbitrary `U::Function` / `∇U` (ADBackend.jl:30-142) crosses the ABI as HIP source text, compiled by the library:
+#   HIPSource("template <class X> __device__ auto U(const X &x, int d) { ... }")                 scalar potential
+#   HIPGradient("template <class X> __device__ auto grad_i(int i, const X &x, int d) { ... }")   coordinate i of ∇U
+struct HIPSource <: Target; text::String; end
+struct HIPGradient <: Target; text::String; end
+target_id(::Union{HIPSource,HIPGradient}) = 4
+source_kind(::HIPSource) = 0; source_kind(::HIPGradient) = 1
+
+# pdmp_create or, for a source target, pdmp_create_from_source
+function create(cfg::Config, target::Target)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    if target isa Union{HIPSource,HIPGradient}
+        check(ccall((:pdmp_create_from_source, LIB), Cint, (Ref{Config}, Cstring, Int32, Ref{Ptr{Cvoid}}),
+                    cfg, target.text, source_kind(target), h))
+    else
+        check(ccall((:pdmp_create, LIB), Cint, (Ref{Config}, Ref{Ptr{Cvoid}}), cfg, h))
+    end
+    return h[]
+end
 
 mutable struct HIPSampler <: AbstractPDMP
     handle::Ptr{Cvoid}; dim::Int; sampler::Int
@@ -46,9 +65,8 @@ function ZigZagAD(dim::Int, target::Target; refresh_rate=0.0, grid_size=10, tmax
     p = params(target)
     cfg = Config(0, dim, grid_size, vectorized_bound, signed_bound, adaptive, 0, AD_backend == "FiniteDiff" ? 1 : 0,
                  target_id(target), device, Float64(tmax), refresh_rate, pointer(p), length(p), 0)
-    h = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve p check(ccall((:pdmp_create, LIB), Cint, (Ref{Config}, Ref{Ptr{Cvoid}}), cfg, h))
-    s = HIPSampler(h[], dim, 0)
+    handle = GC.@preserve p create(cfg, target)
+    s = HIPSampler(handle, dim, 0)
     finalizer(x -> ccall((:pdmp_destroy, LIB), Cint, (Ptr{Cvoid},), x.handle), s)
     return s
 end

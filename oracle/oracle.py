@@ -18,6 +18,7 @@ _LIB_PATH = os.path.join(_HERE, "libpdmp_oracle.so")
 
 ZIGZAG, BPS, BOOMERANG = 0, 1, 2
 T_GAUSS_ISO, T_GAUSS_DIAG, T_BANANA, T_GAUSS_DENSE = 0, 1, 2, 3
+T_AD_BANANA, T_AD_FUNNEL, T_AD_RIDGED = 16, 17, 18      # grad-U by forward mode over U (ad_potentials.c)
 DERIV_FORWARD, DERIV_FINITE_DIFF = 0, 1
 ARITH_REFERENCE, ARITH_WAVE64, ARITH_GROUP = 0, 1, 2
 

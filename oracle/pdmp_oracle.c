@@ -298,6 +298,9 @@ static void grad_dual(const orc_config_t *cfg, const double *xv, const double *x
         }
         break;
     }
+    case ORC_T_AD_BANANA: case ORC_T_AD_FUNNEL: case ORC_T_AD_RIDGED:      /* ForwardDiff.gradient(U, x), ADBackend.jl:107 */
+        orc_ad_grad_dual(cfg->target_id, d, xv, xe, gv, ge);
+        break;
     }
 }
 void orc_grad(const orc_config_t *cfg, const double *x, double *g) {
@@ -309,6 +312,7 @@ void orc_grad(const orc_config_t *cfg, const double *x, double *g) {
 double orc_potential(const orc_config_t *cfg, const double *x) {
     const int d = cfg->dim; double s = 0.0;
     switch (cfg->target_id) {
+    case ORC_T_AD_BANANA: case ORC_T_AD_FUNNEL: case ORC_T_AD_RIDGED: return orc_ad_potential(cfg->target_id, d, x);
     case ORC_T_GAUSS_ISO: for (int i = 0; i < d; ++i) s += x[i] * x[i]; return s / 2;
     case ORC_T_GAUSS_DIAG: { const double *mu = cfg->target_params, *pr = mu + d;
         for (int i = 0; i < d; ++i) s += pr[i] * (x[i] - mu[i]) * (x[i] - mu[i]); return s / 2; }
@@ -672,7 +676,7 @@ int orc_normalize_config(orc_config_t *c) {
     if (c->grid_size < 0) FAIL(-1, "grid_size must be non-negative. Current value: %d", c->grid_size); /* :66-68 */
     if (c->grid_size == 1) FAIL(-1, "grid_size == 1: range(...)[2] is a BoundsError in the reference");
     if (c->sampler < 0 || c->sampler > 2) FAIL(-1, "unknown sampler id %d", c->sampler);
-    if (c->target_id < 0 || c->target_id > 3) FAIL(-1, "unknown target id %d", c->target_id);
+    if (c->target_id < 0 || (c->target_id > 3 && (c->target_id < ORC_T_AD_BANANA || c->target_id > ORC_T_AD_RIDGED))) FAIL(-1, "unknown target id %d", c->target_id);
     if (c->tmax == 0.0) { c->tmax = 1.0; c->adaptive = 1; }                                           /* :73 */
     if (c->sampler == ORC_ZIGZAG) {
         if (c->signed_bound && !c->vectorized_bound) c->signed_bound = 0;                             /* :75-78 */

@@ -21,7 +21,10 @@ extern "C" {
 /* sampler ids -- src/Samplers/{ZigZag,BouncyParticle,Boomerang}Samplers.jl */
 enum { ORC_ZIGZAG = 0, ORC_BPS = 1, ORC_BOOMERANG = 2 };
 /* built-in potentials (closures cannot cross a C ABI) */
-enum { ORC_T_GAUSS_ISO = 0, ORC_T_GAUSS_DIAG = 1, ORC_T_BANANA = 2, ORC_T_GAUSS_DENSE = 3 };
+enum { ORC_T_GAUSS_ISO = 0, ORC_T_GAUSS_DIAG = 1, ORC_T_BANANA = 2, ORC_T_GAUSS_DENSE = 3,
+       /* grad-U by forward-mode differentiation of a scalar potential (ADBackend.jl:95-109), ad_potentials.c:
+        * the reference's test potentials U_banana, U_funnel, U_ridged_gauss (test/test_config.jl:33-46) */
+       ORC_T_AD_BANANA = 16, ORC_T_AD_FUNNEL = 17, ORC_T_AD_RIDGED = 18 };
 /* time-derivative of the bounded rate: UpperBound.jl:209-210 (ForwardDiff) / :223-224 (FiniteDiff) */
 enum { ORC_DERIV_FORWARD = 0, ORC_DERIV_FINITE_DIFF = 1 };
 /* floating-point summation order:
@@ -98,6 +101,9 @@ void   orc_next_event(int n, const double *grid, const double *box_max, const do
 /* gradient of the built-in potential (the user's grad-U closure) */
 void   orc_grad(const orc_config_t *cfg, const double *x, double *g);
 double orc_potential(const orc_config_t *cfg, const double *x);
+/* ad_potentials.c: grad-U of ORC_T_AD_* by forward mode, value gv and directional derivative ge along xe */
+void   orc_ad_grad_dual(int target, int d, const double *xv, const double *xe, double *gv, double *ge);
+double orc_ad_potential(int target, int d, const double *x);
 int    orc_num_threads(void);
 
 #ifdef __cplusplus

@@ -4,7 +4,8 @@ sampler API.  Compute happens only in libpdmphip.so (hand-written HIP for gfx950
 include/pdmp_hip.h); there is no CPU fallback.
 """
 from ._lib import ArgumentError, DimensionMismatch, EngineError, LIB_PATH
-from .targets import GaussianIso, GaussianDiag, Banana, GaussianPrecision
+from .targets import (GaussianIso, GaussianDiag, Banana, GaussianPrecision, SourcePotential, SourceGradient,
+                      U_BANANA_SOURCE, U_FUNNEL_SOURCE, U_RIDGED_GAUSS_SOURCE)
 from .samplers import AbstractPDMP, ZigZag, ZigZagAD, BPS, BPSAD, Boomerang, BoomerangAD
 from .history import PDMPHistory
 from .sample import (sample, sample_skeleton, sample_from_skeleton, sample_skeleton_ensemble,
@@ -12,7 +13,8 @@ from .sample import (sample, sample_skeleton, sample_from_skeleton, sample_skele
 
 __all__ = [
     "ArgumentError", "DimensionMismatch", "EngineError", "LIB_PATH",
-    "GaussianIso", "GaussianDiag", "Banana", "GaussianPrecision",
+    "GaussianIso", "GaussianDiag", "Banana", "GaussianPrecision", "SourcePotential", "SourceGradient",
+    "U_BANANA_SOURCE", "U_FUNNEL_SOURCE", "U_RIDGED_GAUSS_SOURCE",
     "AbstractPDMP", "ZigZag", "ZigZagAD", "BPS", "BPSAD", "Boomerang", "BoomerangAD",
     "PDMPHistory", "sample", "sample_skeleton", "sample_from_skeleton",
     "sample_skeleton_ensemble", "sample_from_skeleton_ensemble", "sample_skeleton_until",

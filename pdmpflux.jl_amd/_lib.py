@@ -53,7 +53,7 @@ class Timing(C.Structure):
 
 # every symbol include/pdmp_hip.h declares; tests check that the library exports all of them
 SYMBOLS = (
-    "pdmp_abi_version", "pdmp_last_error", "pdmp_device_count", "pdmp_create", "pdmp_get_config",
+    "pdmp_abi_version", "pdmp_last_error", "pdmp_device_count", "pdmp_create", "pdmp_create_from_source", "pdmp_get_config",
     "pdmp_destroy", "pdmp_get_group_lanes", "pdmp_set_tape", "pdmp_clear_tape", "pdmp_sample_skeleton", "pdmp_sample_skeleton_device", "pdmp_sample_from_skeleton",
     "pdmp_sample_from_skeleton_device", "pdmp_sample_from_skeleton_dt", "pdmp_sample_from_skeleton_dt_device", "pdmp_sample_moments_device", "pdmp_check_status", "pdmp_get_timing", "pdmp_reset_timing",
     "pdmp_debug_rng", "pdmp_dense_batched_last_phases",
@@ -83,6 +83,7 @@ def lib():
     L.pdmp_last_error.restype = C.c_char_p
     L.pdmp_device_count.restype = C.c_int
     L.pdmp_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.pdmp_create_from_source.argtypes = [C.POINTER(Config), C.c_char_p, i32, C.POINTER(vp)]
     L.pdmp_get_config.argtypes = [vp, C.POINTER(Config)]
     L.pdmp_destroy.argtypes = [vp]
     L.pdmp_get_group_lanes.argtypes = [vp]
@@ -101,7 +102,7 @@ def lib():
     L.pdmp_reset_timing.argtypes = [vp]
     L.pdmp_debug_rng.argtypes = [vp, u64, i64, i32, i64, vp]
     L.pdmp_dense_batched_last_phases.restype = C.c_longlong
-    if L.pdmp_abi_version() != 1:
+    if L.pdmp_abi_version() != 2:
         raise EngineError(ERR_RUNTIME, "ABI version mismatch")
     _lib = L
     return L

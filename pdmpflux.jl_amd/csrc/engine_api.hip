@@ -14,7 +14,7 @@ using namespace pdmp;
 
 namespace {
 
-thread_local char g_err[512] = "";
+thread_local char g_err[4096] = "";
 #ifdef PDMP_STAMP
 unsigned long long *g_stamps = nullptr;
 #endif
@@ -42,8 +42,12 @@ extern "C" int pdmp_dense_batched_run(int device, int d, int signed_bound, int a
                                       double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
                                       int32_t *status, void *stream, char *err, int errlen);
 
+extern "C" int pdmp_user_compile(int device, int sampler, int fd, int kind, const char *source, void **fn_out, char *err, int errlen);
+extern "C" int pdmp_user_launch(void *fn, const GroupParams *gp, void *stream);
+
 struct pdmp_engine {
     pdmp_config_t cfg;
+    void *user_fn = nullptr;          // PDMP_T_USER: the runtime-compiled group kernel (user_jit.hip)
     int group_lanes = 0;              // 0: wave-per-chain kernel; else lanes per chain of the group kernel
     int device = 0;
     double *d_tparams = nullptr;
@@ -184,12 +188,15 @@ __global__ void debug_rng_kernel(uint64_t seed, int64_t chain, int kind, int64_t
     }
 }
 
-int normalize_config(pdmp_config_t &c) {
+int normalize_config(pdmp_config_t &c, bool from_source = false) {
     if (c.dim <= 0) return fail(PDMP_ERR_ARGUMENT, "dimension dim must be positive. Current value: %d", c.dim);          // ZigZagSamplers.jl:62-64
     if (c.grid_size < 0) return fail(PDMP_ERR_ARGUMENT, "grid_size must be non-negative. Current value: %d", c.grid_size); // :66-68
     if (c.grid_size == 1 || c.grid_size > WAVE) return fail(PDMP_ERR_UNSUPPORTED, "grid_size must be in 2..64. Current value: %d", c.grid_size);
     if (c.sampler < PDMP_ZIGZAG || c.sampler > PDMP_BOOMERANG) return fail(PDMP_ERR_ARGUMENT, "unknown sampler id %d", c.sampler);
-    if (c.target_id < 0 || c.target_id > PDMP_T_GAUSS_DENSE) return fail(PDMP_ERR_ARGUMENT, "unknown target id %d", c.target_id);
+    if (c.target_id == PDMP_T_USER && !from_source) return fail(PDMP_ERR_ARGUMENT, "PDMP_T_USER handles are made by pdmp_create_from_source");
+    if (c.target_id < 0 || c.target_id > PDMP_T_USER) return fail(PDMP_ERR_ARGUMENT, "unknown target id %d", c.target_id);
+    if (c.target_id == PDMP_T_USER && c.grid_size != GNG && c.grid_size != 0)
+        return fail(PDMP_ERR_UNSUPPORTED, "potentials given as source run on the group kernel: grid_size = 10 (or 0, Brent)");
     if (c.target_id == PDMP_T_GAUSS_DENSE) {
         if (c.n_target_params != (int64_t)c.dim * c.dim || !c.target_params) return fail(PDMP_ERR_ARGUMENT, "GAUSS_DENSE needs target_params = P[dim*dim] (column-major)");
         if (c.sampler == PDMP_BOOMERANG || c.deriv_mode != PDMP_DERIV_FORWARD || (c.grid_size != 10 && c.grid_size != 0))
@@ -289,11 +296,12 @@ int pdmp_device_count(void) {
     return n;
 }
 
-int pdmp_create(const pdmp_config_t *cfg, pdmp_handle *out) {
+static int create_impl(const pdmp_config_t *cfg, const char *source, int32_t kind, pdmp_handle *out) {
     if (!cfg || !out) return fail(PDMP_ERR_ARGUMENT, "null argument");
     *out = nullptr;
     pdmp_config_t c = *cfg;
-    if (int rc = normalize_config(c)) return rc;
+    if (source) { c.target_id = PDMP_T_USER; c.target_params = nullptr; c.n_target_params = 0; }
+    if (int rc = normalize_config(c, source != nullptr)) return rc;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(PDMP_ERR_RUNTIME, "no HIP device visible: the PDMP engine has no CPU fallback");
@@ -317,8 +325,27 @@ int pdmp_create(const pdmp_config_t *cfg, pdmp_handle *out) {
     }
     HIP_TRY(hipMalloc(&h->d_status, 4 * sizeof(int32_t)));
     HIP_TRY(hipMemset(h->d_status, 0, 4 * sizeof(int32_t)));
+    if (source) {
+        if (h->group_lanes <= 0) { pdmp_destroy(h); return fail(PDMP_ERR_UNSUPPORTED, "potentials given as source: dim too large for the LDS tiles"); }
+        static thread_local char log[sizeof g_err];
+        log[0] = '\0';
+        const int rc = pdmp_user_compile(dev, c.sampler, c.deriv_mode == PDMP_DERIV_FINITE_DIFF, kind, source, &h->user_fn, log, (int)sizeof log);
+        if (rc != 0) {
+            pdmp_destroy(h);
+            // a potential that does not compile is the caller's mistake: the ArgumentError of ADBackend.jl:68-70
+            return fail(rc == -1 ? PDMP_ERR_ARGUMENT : PDMP_ERR_RUNTIME, "potential source: %s", log);
+        }
+    }
     *out = h;
     return PDMP_OK;
+}
+
+int pdmp_create(const pdmp_config_t *cfg, pdmp_handle *out) { return create_impl(cfg, nullptr, 0, out); }
+
+int pdmp_create_from_source(const pdmp_config_t *cfg, const char *source, int32_t kind, pdmp_handle *out) {
+    if (!source) return fail(PDMP_ERR_ARGUMENT, "null source");
+    if (kind != PDMP_SRC_POTENTIAL && kind != PDMP_SRC_GRADIENT) return fail(PDMP_ERR_ARGUMENT, "source kind must be PDMP_SRC_POTENTIAL or PDMP_SRC_GRADIENT");
+    return create_impl(cfg, source, kind, out);
 }
 
 int pdmp_get_group_lanes(pdmp_handle h) { return h ? (h->tape_chains > 0 ? 0 : h->group_lanes) : -1; }
@@ -453,7 +480,11 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
         if (rc != 0) return fail(rc == -4 ? PDMP_ERR_ITERCAP : PDMP_ERR_RUNTIME, "dense batched path: %s", msg);
         return end_timed(h, s, ev);
     }
-    if (h->group_lanes > 0 && !taped) HIP_TRY(pick_group_launcher(c.sampler, c.target_id)(gp, s));
+    if (c.target_id == PDMP_T_USER) {
+        if (taped || h->group_lanes <= 0 || !h->user_fn) return fail(PDMP_ERR_UNSUPPORTED, "potentials given as source: no tape replay");
+        const int e = pdmp_user_launch(h->user_fn, &gp, s);
+        if (e != 0) return fail(PDMP_ERR_RUNTIME, "launching the compiled potential: %s", hipGetErrorString((hipError_t)e));
+    } else if (h->group_lanes > 0 && !taped) HIP_TRY(pick_group_launcher(c.sampler, c.target_id)(gp, s));
     else HIP_TRY(pick_launcher(c.sampler, c.target_id)(p, s));
     return end_timed(h, s, ev);
 }

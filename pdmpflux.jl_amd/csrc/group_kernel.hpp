@@ -24,6 +24,7 @@
 // slots of G coordinates with a Kogge-Stone scan inside a slot and a running carry between slots.
 #pragma once
 #include "skeleton_kernel.hpp"
+#include "user_ad.hpp"
 
 namespace pdmp {
 
@@ -75,6 +76,44 @@ __device__ __forceinline__ double group_scan_incl(double a, int g, int G) {   //
 
 struct TimePt { double t, s, c; };   // grid time (+ sin/cos for the Boomerang rotation)
 
+// flow of one coordinate: ZigZagSamplers.jl:80 / BouncyParticleSamplers.jl:32 (x + v t, v); BoomerangSamplers.jl:31 (rotation)
+template <bool ROT> __device__ __forceinline__ void flow_coord(double x, double v, const TimePt &tp, Dual &xt, Dual &vt) {
+    if constexpr (ROT) {
+        xt = {x * tp.c + v * tp.s, x * (-tp.s) + v * tp.c};
+        vt = {(-x) * tp.s + v * tp.c, (-x) * tp.c + v * (-tp.s)};
+    } else {
+        xt = {fma(v, tp.t, x), v};                           // fused: GROUP order of the checker
+        vt = {v, 0.0};
+    }
+}
+template <bool ROT> __device__ __forceinline__ void flow_coord(double x, double v, const TimePt &tp, double &xt, double &vt) {
+    if constexpr (ROT) { xt = x * tp.c + v * tp.s; vt = (-x) * tp.s + v * tp.c; }
+    else { xt = fma(v, tp.t, x); vt = v; }
+}
+
+// A chain's position at one time point as an indexable vector, for potentials given as source (user_jit.hip):
+// w[j] = coordinate j of the flow at w.tp, read from the chain's LDS tiles (any lane of the group may read any slot).
+template <class T> struct UserView {
+    const double *xs, *vs;
+    int base, logG, d;
+    bool rot;                          // Boomerang rotation instead of the linear flow
+    TimePt tp;
+    __device__ __forceinline__ int size() const { return d; }
+    __device__ __forceinline__ T operator[](int j) const {
+        const int o = (j >> logG) * WAVE + base + (j & ((1 << logG) - 1));
+        T xt, vt;
+        if (rot) flow_coord<true>(xs[o], vs[o], tp, xt, vt); else flow_coord<false>(xs[o], vs[o], tp, xt, vt);
+        return xt;
+    }
+};
+// the same vector seeded for the partial with respect to coordinate i (one forward-mode pass of ForwardDiff.gradient)
+template <class T> struct SeededView {
+    const UserView<T> &w;
+    int i;
+    __device__ __forceinline__ int size() const { return w.d; }
+    __device__ __forceinline__ Fwd<T> operator[](int j) const { return {w[j], lift<T>(j == i ? 1.0 : 0.0)}; }
+};
+
 // ---------------------------------------------------------------- targets in the group layout
 // grad(i, x_i, shared): coordinate i of grad-U at a (dual or plain) position; `shared` carries what a
 // non-separable potential needs from other coordinates of the same chain at the same time point.
@@ -82,7 +121,7 @@ struct NoShared {};
 template <int TARGET> struct GTarget;
 
 template <> struct GTarget<T_GAUSS_ISO> {
-    static constexpr bool kShared = false, kTile = false;
+    static constexpr bool kShared = false, kTile = false, kUser = false;
     static constexpr bool kLinear = true;      // grad-U is affine in x: along a linear flow the rate's slope is the same at every grid time
     template <class T> using Sh = NoShared;
     __device__ __forceinline__ void init(const double *, int) {}
@@ -90,7 +129,7 @@ template <> struct GTarget<T_GAUSS_ISO> {
     template <class T> __device__ __forceinline__ T grad(int, T x, const NoShared &) const { return x; }
 };
 template <> struct GTarget<T_GAUSS_DIAG> {
-    static constexpr bool kShared = false, kTile = false;
+    static constexpr bool kShared = false, kTile = false, kUser = false;
     static constexpr bool kLinear = true;
     template <class T> using Sh = NoShared;
     const double *mu, *prec;            // LDS copies
@@ -104,7 +143,7 @@ template <> struct GTarget<T_GAUSS_DIAG> {
 };
 template <class T> struct BananaSh { T g0, r; };
 template <> struct GTarget<T_BANANA> {          // test/test_config.jl:33-36
-    static constexpr bool kShared = true, kTile = false;
+    static constexpr bool kShared = true, kTile = false, kUser = false;
     static constexpr bool kLinear = false;
     template <class T> using Sh = BananaSh<T>;
     int d;
@@ -122,6 +161,26 @@ template <> struct GTarget<T_BANANA> {          // test/test_config.jl:33-36
         return i == 0 ? sh.g0 : (i == 1 ? sh.r : x);
     }
 };
+
+#ifdef PDMP_USER_KIND
+// Potential given as source (pdmp_create_from_source): PDMP_USER_KIND 0 = scalar potential pdmp_user::U(x, d), differentiated
+// here by forward mode (ADBackend.jl:95-109); 1 = coordinate i of the gradient, pdmp_user::grad_i(i, x, d) (ADBackend.jl:55-66).
+template <> struct GTarget<T_USER> {
+    static constexpr bool kShared = true, kTile = false, kUser = true;
+    static constexpr bool kLinear = false;
+    template <class T> using Sh = UserView<T>;
+    __device__ __forceinline__ void init(const double *, int) {}
+    template <class T> __device__ __forceinline__ T grad(int i, T, const UserView<T> &w) const {
+#if PDMP_USER_KIND == 0
+        const SeededView<T> sx{w, i};
+        const Fwd<T> u = pdmp_user::U(sx, w.d);
+        return u.e;
+#else
+        return pdmp_user::grad_i(i, w, w.d);
+#endif
+    }
+};
+#endif
 
 template <int SAMPLER, int TARGET, bool FD>
 struct GroupChain {
@@ -148,18 +207,8 @@ struct GroupChain {
         if constexpr (SAMPLER == S_BOOMERANG) det_sincos(t, tp.s, tp.c); else { tp.s = 0.0; tp.c = 1.0; }
     }
     // flow of one coordinate: ZigZagSamplers.jl:80 / BouncyParticleSamplers.jl:32 / BoomerangSamplers.jl:31
-    __device__ __forceinline__ void flow(double x, double v, const TimePt &tp, Dual &xt, Dual &vt) const {
-        if constexpr (SAMPLER == S_BOOMERANG) {
-            xt = {x * tp.c + v * tp.s, x * (-tp.s) + v * tp.c};
-            vt = {(-x) * tp.s + v * tp.c, (-x) * tp.c + v * (-tp.s)};
-        } else {
-            xt = {fma(v, tp.t, x), v};                       // fused: GROUP order of the checker
-            vt = {v, 0.0};
-        }
-    }
-    __device__ __forceinline__ void flow(double x, double v, const TimePt &tp, double &xt, double &vt) const {
-        if constexpr (SAMPLER == S_BOOMERANG) { xt = x * tp.c + v * tp.s; vt = (-x) * tp.s + v * tp.c; }
-        else { xt = fma(v, tp.t, x); vt = v; }
+    template <class T> __device__ __forceinline__ void flow(double x, double v, const TimePt &tp, T &xt, T &vt) const {
+        flow_coord<SAMPLER == S_BOOMERANG>(x, v, tp, xt, vt);
     }
     // out[i] = sum_j P[i,j] in[j], j left to right per row (row i owned by lane i % 64, slot i / 64).
     // Eight rows per lane are accumulated together so that eight independent 512-byte column pieces are in
@@ -202,6 +251,8 @@ struct GroupChain {
             matvec(tgt.P, tgt.tx, tgt.tg[which]);
             if (!tgt.b_valid) { matvec(tgt.P, vs, tgt.tb); tgt.b_valid = true; }   // G = 64: the v tile is the vector v
             return {tgt.tg[which], tgt.tb};
+        } else if constexpr (Tgt::kUser) {
+            return UserView<T>{xs, vs, base, __builtin_ctz(G), p.d, SAMPLER == S_BOOMERANG, tp};
         } else if constexpr (Tgt::kShared) {
             if (p.d >= 2) {
                 double x0, v0, x1, v1;
@@ -632,6 +683,8 @@ struct GroupChain {
         if constexpr (Tgt::kTile) {
             sh = {tgt.tg[0], tgt.tb};            // grad-U at the accepted point: tile 0 was filled by true_rate(tp)
             tgt.b_valid = false;                 // v is about to change
+        } else if constexpr (Tgt::kUser) {
+            sh = shared_at<double>(t0);          // the state already sits at the accepted point: flow by t = 0 is exact
         } else if constexpr (Tgt::kShared) {
             if (p.d >= 2) { double x0, v0, x1, v1; coord(0, x0, v0); coord(1, x1, v1); sh = tgt.template shared<double>(x0, x1); }
         }
@@ -924,7 +977,7 @@ struct GroupChain {
 // First correct version: per-chain mat-vecs; the lock-step fp64-MFMA GEMM over chains is the planned upgrade.
 template <class T> struct DenseSh { const double *g, *b; };
 template <> struct GTarget<T_GAUSS_DENSE> {
-    static constexpr bool kShared = true, kTile = true;
+    static constexpr bool kShared = true, kTile = true, kUser = false;
     static constexpr bool kLinear = false;     // (it is affine, but its slope lives in an LDS tile: keep the generic path)
     static constexpr int kExtraTiles = 4;          // two gradient tiles, P v, scratch x_t
     template <class T> using Sh = DenseSh<T>;
@@ -953,7 +1006,7 @@ __device__ __forceinline__ bool wait_progress(const int32_t *flag, int r) {
 template <int TARGET> struct GroupOcc { static constexpr int kWaves = (TARGET == T_BANANA) ? 3 : 4; };   // banana + finite differences keeps six shared records: 3 waves avoid spills
 
 template <int SAMPLER, int TARGET, bool FD>
-__global__ __launch_bounds__(256, GroupOcc<TARGET>::kWaves) void group_kernel(const GroupParams gp) {
+__device__ __forceinline__ void group_kernel_body(const GroupParams &gp) {
     extern __shared__ double smem[];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
@@ -991,6 +1044,12 @@ __global__ __launch_bounds__(256, GroupOcc<TARGET>::kWaves) void group_kernel(co
     if (lost && lane == 0) atomicAdd(&gp.s.status[2], 1);         // predecessor lost: report, never hang
 }
 
+template <int SAMPLER, int TARGET, bool FD>
+__global__ __launch_bounds__(256, GroupOcc<TARGET>::kWaves) void group_kernel(const GroupParams gp) {
+    group_kernel_body<SAMPLER, TARGET, FD>(gp);
+}
+
+#ifndef __HIPCC_RTC__   // host side (not part of a runtime-compiled user kernel)
 // waves per block: as many (up to 4) as fit the CU's 160 KiB of LDS next to the staged parameters
 inline int group_waves_per_block(int K, int tpar, int tiles = 2) {
     const size_t tile = (size_t)tiles * K * WAVE * sizeof(double), avail = 160 * 1024 - (size_t)tpar * sizeof(double);
@@ -1050,5 +1109,7 @@ hipError_t launch_group_impl(const GroupParams &gp_in, hipStream_t stream) {
         return gp.s.deriv_mode != 0 ? launch_group_impl<S, T, true>(gp, stream)                     \
                                     : launch_group_impl<S, T, false>(gp, stream);                   \
     }
+
+#endif  // __HIPCC_RTC__
 
 }  // namespace pdmp

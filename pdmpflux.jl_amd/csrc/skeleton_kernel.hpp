@@ -514,6 +514,7 @@ __global__ __launch_bounds__(256) void skeleton_kernel(const SkelParams p) {
     chain.run(c);
 }
 
+#ifndef __HIPCC_RTC__
 // host-side launcher, one per (sampler, target); defined in inst_*.hip
 template <int SAMPLER, int TARGET>
 hipError_t launch_skeleton(const SkelParams &p, hipStream_t stream);
@@ -531,5 +532,6 @@ hipError_t launch_skeleton(const SkelParams &p, hipStream_t stream);
         }                                                                                           \
         return hipGetLastError();                                                                   \
     }
+#endif  // __HIPCC_RTC__
 
 }  // namespace pdmp

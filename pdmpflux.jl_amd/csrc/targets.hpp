@@ -6,7 +6,7 @@
 
 namespace pdmp {
 
-enum : int { T_GAUSS_ISO = 0, T_GAUSS_DIAG = 1, T_BANANA = 2, T_GAUSS_DENSE = 3 };
+enum : int { T_GAUSS_ISO = 0, T_GAUSS_DIAG = 1, T_BANANA = 2, T_GAUSS_DENSE = 3, T_USER = 4 };
 
 template <int TARGET, int K>
 struct Target;

@@ -5,8 +5,16 @@
 // (DESIGN.md "Arithmetic contract"): compiled with -ffp-contract=off, no fast-math, so that results
 // are bit-identical to the scalar CPU checker run in its WAVE64 summation order.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else   // runtime compilation of a user potential (user_jit.hip): hiprtc brings the HIP device API, not <stdint.h>
+typedef signed int int32_t;
+typedef unsigned int uint32_t;
+typedef signed long long int64_t;
+typedef unsigned long long uint64_t;
+typedef unsigned long size_t;
+#endif
 
 namespace pdmp {
 
@@ -76,6 +84,14 @@ __device__ __forceinline__ Dual operator-(Dual a, Dual b) { return {a.v - b.v, a
 __device__ __forceinline__ Dual operator-(Dual a, double b) { return {a.v - b, a.e}; }
 __device__ __forceinline__ Dual operator*(Dual a, Dual b) { return {a.v * b.v, a.e * b.v + a.v * b.e}; }
 __device__ __forceinline__ Dual operator*(double s, Dual a) { return {s * a.v, s * a.e}; }
+__device__ __forceinline__ Dual operator*(Dual a, double s) { return {a.v * s, a.e * s}; }
+__device__ __forceinline__ Dual operator+(Dual a, double b) { return {a.v + b, a.e}; }
+__device__ __forceinline__ Dual operator+(double a, Dual b) { return {a + b.v, b.e}; }
+__device__ __forceinline__ Dual operator-(double a, Dual b) { return {a - b.v, -b.e}; }
+__device__ __forceinline__ Dual operator-(Dual a) { return {-a.v, -a.e}; }
+__device__ __forceinline__ Dual operator/(Dual a, Dual b) { const double q = a.v / b.v; return {q, (a.e - q * b.e) / b.v}; }
+__device__ __forceinline__ Dual operator/(Dual a, double b) { return {a.v / b, a.e / b}; }
+__device__ __forceinline__ Dual operator/(double a, Dual b) { const double q = a / b.v; return {q, (-(q * b.e)) / b.v}; }
 __device__ __forceinline__ double value(double a) { return a; }
 __device__ __forceinline__ double value(Dual a) { return a.v; }
 __device__ __forceinline__ double readlane_t(double x, int l) { return readlane_d(x, l); }

@@ -84,7 +84,11 @@ class AbstractPDMP:
         if self._handle is None:
             h = C.c_void_p()
             cfg = self._config()
-            _lib.check(_lib.lib().pdmp_create(C.byref(cfg), C.byref(h)))
+            src = getattr(self.target, "source", None)
+            if src is not None:     # potential / gradient given as source: compiled by the engine at run time
+                _lib.check(_lib.lib().pdmp_create_from_source(C.byref(cfg), src.encode(), int(self.target.kind), C.byref(h)))
+            else:
+                _lib.check(_lib.lib().pdmp_create(C.byref(cfg), C.byref(h)))
             self._handle = h
         return self._handle
 

@@ -19,6 +19,10 @@ def make_pair(P, O, kind, dim, target="iso", arith=None, **kw):
         Pm = (Q * np.exp(rs.uniform(np.log(0.1), np.log(10.0), size=dim))) @ Q.T
         Pm = 0.5 * (Pm + Pm.T)
         tg, tid, params = P.GaussianPrecision(Pm), O.T_GAUSS_DENSE, np.asfortranarray(Pm).ravel(order="F")
+    elif target in ("src_banana", "src_funnel", "src_ridged"):    # potentials given as source vs the checker's forward-mode restatement
+        src, tid = {"src_banana": (P.U_BANANA_SOURCE, O.T_AD_BANANA), "src_funnel": (P.U_FUNNEL_SOURCE, O.T_AD_FUNNEL),
+                    "src_ridged": (P.U_RIDGED_GAUSS_SOURCE, O.T_AD_RIDGED)}[target]
+        tg, params = P.SourcePotential(src), None
     else:
         raise ValueError(target)
     ctor = {"ZigZag": P.ZigZag, "ZigZagAD": P.ZigZagAD, "BPS": P.BPS, "BPSAD": P.BPSAD,
@@ -38,8 +42,10 @@ def make_pair(P, O, kind, dim, target="iso", arith=None, **kw):
 def make_init(kind, dim, C, seed=0, target="iso"):
     rs = np.random.default_rng(seed + 1000 * dim + C)
     x = rs.normal(size=(C, dim))
-    if target == "banana":
+    if target in ("banana", "src_banana"):
         x = 1.0 + 0.1 * x
+    if target == "src_funnel":                   # U_funnel lives on x[1] > 0 (log(v), test/test_config.jl:38-42)
+        x[:, 0] = 2.0 + 0.2 * x[:, 0]
     if kind.startswith("ZigZag"):
         v = rs.choice([-1.0, 1.0], size=(C, dim))
     elif kind.startswith("BPS"):
