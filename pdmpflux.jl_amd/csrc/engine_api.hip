@@ -11,6 +11,7 @@
 #include <vector>
 
 using namespace pdmp;
+namespace pdmp { hipError_t launch_group_reg(int sampler, int target, bool fd, const GroupParams &gp, hipStream_t stream); }
 
 namespace {
 
@@ -250,6 +251,9 @@ int choose_group_lanes(const pdmp_config_t &c) {
         if (G == 0) return 0;
         if (G >= 1 && G <= WAVE && (G & (G - 1)) == 0 && group_waves_per_block((c.dim + G - 1) / G, 2 * c.dim) >= 1) return G;
     }
+    if (c.sampler == PDMP_ZIGZAG)          // register form (inst_reg.hip): at most KREG slots per lane, G <= 16
+        for (int G = 1; G <= 16; G <<= 1)
+            if ((c.dim + G - 1) / G <= KREG) return G;
     const size_t budget = 20 * 1024;      // two blocks (8 waves) per CU
     for (int G = 1; G <= WAVE; G <<= 1) {
         const size_t K = (size_t)(c.dim + G - 1) / G;
@@ -484,7 +488,13 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
         if (taped || h->group_lanes <= 0 || !h->user_fn) return fail(PDMP_ERR_UNSUPPORTED, "potentials given as source: no tape replay");
         const int e = pdmp_user_launch(h->user_fn, &gp, s);
         if (e != 0) return fail(PDMP_ERR_RUNTIME, "launching the compiled potential: %s", hipGetErrorString((hipError_t)e));
-    } else if (h->group_lanes > 0 && !taped) HIP_TRY(pick_group_launcher(c.sampler, c.target_id)(gp, s));
+    } else if (h->group_lanes > 0 && !taped) {
+        hipError_t e = hipErrorNotSupported;
+        const char *reg = getenv("PDMP_REG");               // PDMP_REG=0: keep x, v in LDS tiles (test hook)
+        if (!(reg && atoi(reg) == 0)) e = launch_group_reg(c.sampler, c.target_id, c.deriv_mode != 0, gp, s);
+        if (e == hipErrorNotSupported) e = pick_group_launcher(c.sampler, c.target_id)(gp, s);
+        HIP_TRY(e);
+    }
     else HIP_TRY(pick_launcher(c.sampler, c.target_id)(p, s));
     return end_timed(h, s, ev);
 }

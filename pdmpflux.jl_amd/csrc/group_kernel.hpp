@@ -29,6 +29,7 @@
 namespace pdmp {
 
 constexpr int GNG = 10;   // grid_size served by this kernel (the default of every reference constructor)
+constexpr int KREG = 13;  // slots per lane of the register form (x, v in VGPRs): d <= 13 G
 
 struct GroupParams {
     SkelParams s;
@@ -182,12 +183,25 @@ template <> struct GTarget<T_USER> {
 };
 #endif
 
-template <int SAMPLER, int TARGET, bool FD>
+// KC = 0: K = ceil(d/G) slots per lane at run time, x and v in LDS tiles.  KC > 0 (register form): up to KC slots, x and v in
+// REGISTERS, every slot loop fully unrolled with a scalar skip of the slots >= K -- no ds_read latency in the loops, no slot
+// addressing.  Same operations in the same order: the two forms agree bit for bit.
+#define PDMP_SLOTS(s) _Pragma("unroll kUnroll") for (int s = 0; s < nk(); ++s, slot_fence()) if (!kReg || s < K)
+template <int SAMPLER, int TARGET, bool FD, int KC = 0>
 struct GroupChain {
     using Tgt = GTarget<TARGET>;
+    static constexpr bool kReg = KC > 0;
+    static constexpr int kUnroll = KC > 0 ? KC : 1;   // slot loops: fully unrolled in the register form, left alone otherwise
+    static_assert(!kReg || (!Tgt::kTile && !Tgt::kUser && KC >= 2), "register form: separable / banana targets only");
     const SkelParams &p;
     const int G, K, lane, g, base;       // g = lane within the group, base = first lane of the group
     double *xs, *vs;                     // this wave's LDS tiles: slot s of lane l at [s*64 + l]
+    mutable double xr[kReg ? KC : 1], vr[kReg ? KC : 1];   // register form: slot s of this lane
+    __device__ __forceinline__ int nk() const { if constexpr (kReg) return KC; else return K; }
+    // register form: keep the scheduler from interleaving all KC unrolled slots (their temporaries would not fit the register file)
+    __device__ __forceinline__ static void slot_fence() { if constexpr (kReg) __builtin_amdgcn_sched_barrier(0); }
+    // coordinate i = s*G + g exists (i < d): only the last slot K-1 can be partly padded (register form: a scalar test for the others)
+    __device__ __forceinline__ bool in_dim(int s, int i) const { if constexpr (kReg) return s < K - 1 || i < p.d; else return i < p.d; }
     Tgt tgt;
     ChainRng rng;
     int32_t guard = 0;
@@ -195,12 +209,17 @@ struct GroupChain {
     __device__ __forceinline__ GroupChain(const GroupParams &gp, int l, double *x_tile, double *v_tile)
         : p(gp.s), G(gp.G), K(gp.K), lane(l), g(l & (gp.G - 1)), base(l & ~(gp.G - 1)), xs(x_tile), vs(v_tile) {}
 
-    __device__ __forceinline__ double &X(int s) const { return xs[s * WAVE + lane]; }
-    __device__ __forceinline__ double &V(int s) const { return vs[s * WAVE + lane]; }
-    __device__ __forceinline__ void coord(int i, double &x, double &v) const {   // any coordinate of my chain
+    __device__ __forceinline__ double &X(int s) const { if constexpr (kReg) return xr[s]; else return xs[s * WAVE + lane]; }
+    __device__ __forceinline__ double &V(int s) const { if constexpr (kReg) return vr[s]; else return vs[s * WAVE + lane]; }
+    __device__ __forceinline__ void coord(int i, double &x, double &v) const {   // any coordinate of my chain (i = 0, 1 in the register form)
         const int s = (G == WAVE) ? (i >> 6) : i / G, l = base + (i - s * G);
-        x = xs[s * WAVE + l];
-        v = vs[s * WAVE + l];
+        if constexpr (kReg) {
+            x = __shfl((s == 0) ? xr[0] : xr[1], l, WAVE);
+            v = __shfl((s == 0) ? vr[0] : vr[1], l, WAVE);
+        } else {
+            x = xs[s * WAVE + l];
+            v = vs[s * WAVE + l];
+        }
     }
     __device__ __forceinline__ void time_pt(double t, TimePt &tp) const {
         tp.t = t;
@@ -243,7 +262,7 @@ struct GroupChain {
     template <class T>
     __device__ __forceinline__ typename Tgt::template Sh<T> shared_at(const TimePt &tp, int which = 0) {
         if constexpr (Tgt::kTile) {
-            for (int s = 0; s < K; ++s) {
+            PDMP_SLOTS(s) {
                 double xt, vt;
                 flow(X(s), V(s), tp, xt, vt);
                 tgt.tx[s * WAVE + lane] = xt;
@@ -349,10 +368,12 @@ struct GroupChain {
                 time_pt(t1, p1);
                 if (j == 0) shf = shared_at<Dual>(p0, 0);                 // left endpoint: carried over from the previous cell
                 const auto sh0 = shf, sh1 = shared_at<Dual>(p1, (j + 1) & 1);
-                for (int s = 0; s < K; ++s) {
+                PDMP_SLOTS(s) {
                     const int i = s * G + g;
-                    const int ip = (i < p.d) ? i : 0;
-                    const double x = X(s), v = V(s);
+                    const int ip = (in_dim(s, i)) ? i : 0;
+                    const double x = X(s);
+                    double v = V(s);
+                    if constexpr (kReg) asm volatile("" : "+v"(v));       // keeps v*v (same for every cell) from being hoisted into KC more registers
                     double v0, g0, v1, g1;
                     eval_vect<SIGNED>(ip, x, v, p0, sh0, v0, g0);
                     eval_vect<SIGNED>(ip, x, v, p1, sh1, v1, g1);
@@ -365,9 +386,9 @@ struct GroupChain {
                 fd_point(t1, harg, P1);
                 const auto a0 = shared_at<double>(P0.c), a1 = shared_at<double>(P0.m), a2 = shared_at<double>(P0.pl);
                 const auto b0 = shared_at<double>(P1.c), b1 = shared_at<double>(P1.m), b2 = shared_at<double>(P1.pl);
-                for (int s = 0; s < K; ++s) {
+                PDMP_SLOTS(s) {
                     const int i = s * G + g;
-                    const int ip = (i < p.d) ? i : 0;
+                    const int ip = (in_dim(s, i)) ? i : 0;
                     const double x = X(s), v = V(s);
                     const double v0 = fval_vect<SIGNED>(ip, x, v, P0.c, a0);
                     const double g0 = fd_slope(P0, v0, fval_vect<SIGNED>(ip, x, v, P0.m, a1), fval_vect<SIGNED>(ip, x, v, P0.pl, a2));
@@ -408,9 +429,9 @@ struct GroupChain {
     __device__ __forceinline__ void eval_scalar(const TimePt &tp, double &val, double &slp) {
         const auto sh = shared_at<Dual>(tp);
         double fv = 0.0, fe = 0.0;
-        for (int s = 0; s < K; ++s) {
+        PDMP_SLOTS(s) {
             const int i = s * G + g;
-            const bool valid = i < p.d;
+            const bool valid = in_dim(s, i);
             Dual xt, vt;
             flow(X(s), V(s), tp, xt, vt);
             const Dual gd = tgt.grad(i, xt, sh);
@@ -435,9 +456,9 @@ struct GroupChain {
         double f[NPT];
 #pragma unroll
         for (int q = 0; q < NPT; ++q) { sh[q] = shared_at<double>(tp[q]); f[q] = 0.0; }
-        for (int s = 0; s < K; ++s) {
+        PDMP_SLOTS(s) {
             const int i = s * G + g;
-            const bool valid = i < p.d;
+            const bool valid = in_dim(s, i);
             const double x = X(s), v = V(s);
 #pragma unroll
             for (int q = 0; q < NPT; ++q) {
@@ -464,9 +485,9 @@ struct GroupChain {
         double fv[NP], fe[NP];
 #pragma unroll
         for (int q = 0; q < NP; ++q) { sh[q] = shared_at<Dual>(tp[q]); fv[q] = 0.0; fe[q] = 0.0; }
-        for (int s = 0; s < K; ++s) {
+        PDMP_SLOTS(s) {
             const int i = s * G + g;
-            const bool valid = i < p.d;
+            const bool valid = in_dim(s, i);
             const double x = X(s), v = V(s);
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
@@ -650,13 +671,13 @@ struct GroupChain {
         time_pt(t, tp);
         const auto sh = shared_at<double>(tp);
         double acc = 0.0;
-        for (int s = 0; s < K; ++s) {
+        PDMP_SLOTS(s) {
             const int i = s * G + g;
             double xt, vt;
             flow(X(s), V(s), tp, xt, vt);
             const double gv = tgt.grad(i, xt, sh) * vt;
             const double term = (SAMPLER == S_ZIGZAG) ? fmax(0.0, gv) : gv;     // ZigZagSamplers.jl:83-86
-            acc += (i < p.d) ? term : 0.0;
+            acc += (in_dim(s, i)) ? term : 0.0;
         }
         const double tot = group_sum(acc, G);
         raw = tot;
@@ -665,9 +686,12 @@ struct GroupChain {
     }
 
     __device__ __forceinline__ void flow_state(double t) const {
+        // register form: an opaque copy of t keeps the compiler from holding the KC positions true_rate just computed
+        // (same expression, same bits) in registers across the accept test
+        if constexpr (kReg) asm volatile("" : "+v"(t));
         TimePt tp;
         time_pt(t, tp);
-        for (int s = 0; s < K; ++s) {
+        PDMP_SLOTS(s) {
             double xt, vt;
             flow(X(s), V(s), tp, xt, vt);
             X(s) = xt;
@@ -701,9 +725,9 @@ struct GroupChain {
             // for bit), first slot whose running total exceeds theta.  Level 2: one scan inside that slot.
             double carry = 0.0, carry_at = 0.0;
             int ms_hit = -1;
-            for (int s = 0; s < K; ++s) {
+            PDMP_SLOTS(s) {
                 const int i = s * G + g;
-                const double lam = (i < d) ? fmax(0.0, tgt.grad(i, X(s), sh) * V(s)) : 0.0;
+                const double lam = (in_dim(s, i)) ? fmax(0.0, tgt.grad(i, X(s), sh) * V(s)) : 0.0;
                 const double T = group_sum(lam, G);
                 if (ms_hit < 0 && (carry + T > theta)) { ms_hit = s; carry_at = carry; }
                 carry = carry + T;
@@ -713,8 +737,11 @@ struct GroupChain {
             {
                 const int sq = (ms_hit < 0) ? 0 : ms_hit;
                 const int i = sq * G + g;
-                const bool valid = (ms_hit >= 0) && (i < d);
-                const double lam = valid ? fmax(0.0, tgt.grad(i, X(sq), sh) * V(sq)) : 0.0;
+                const bool valid = (ms_hit >= 0) && in_dim(sq, i);
+                double xq, vq;
+                if constexpr (kReg) { xq = 0.0; vq = 0.0; PDMP_SLOTS(s) if (s == sq) { xq = X(s); vq = V(s); } }
+                else { xq = X(sq); vq = V(sq); }
+                const double lam = valid ? fmax(0.0, tgt.grad(i, xq, sh) * vq) : 0.0;
                 const double inc = group_scan_incl(lam, g, G);
                 const unsigned long long ball = __ballot(valid && (carry_at + inc > theta));
                 const unsigned long long grp = (G == WAVE) ? ball : ((ball >> base) & ((1ull << G) - 1ull));
@@ -722,7 +749,8 @@ struct GroupChain {
             }
             if (m < 0) m = d - 1;
             const int ms = m / G;
-            if (g == m - ms * G) V(ms) = -V(ms);                         // v[m] *= -1
+            if constexpr (kReg) { PDMP_SLOTS(s) if (s == ms && g == m - ms * G) V(s) = -V(s); }
+            else if (g == m - ms * G) V(ms) = -V(ms);                    // v[m] *= -1
             return;
         } else {
             double acc = 0.0;
@@ -730,10 +758,10 @@ struct GroupChain {
             if constexpr (SAMPLER == S_BPS) {
                 gv = raw;                                                // dot(grad-U(x), v), BouncyParticleSamplers.jl:51-52
             } else {
-                for (int s = 0; s < K; ++s) {
+                PDMP_SLOTS(s) {
                     const int i = s * G + g;
                     const double gi = tgt.grad(i, X(s), sh) - X(s);      // grad-U_effective, BoomerangSamplers.jl:51-52 (Q8)
-                    acc += (i < d) ? gi * V(s) : 0.0;
+                    acc += (in_dim(s, i)) ? gi * V(s) : 0.0;
                 }
                 gv = group_sum(acc, G);
             }
@@ -742,34 +770,34 @@ struct GroupChain {
             const double u = rng.uniform();
             if (u < prob) {
                 acc = 0.0;
-                for (int s = 0; s < K; ++s) {
+                PDMP_SLOTS(s) {
                     const int i = s * G + g;
                     double gi = tgt.grad(i, X(s), sh);
                     if constexpr (SAMPLER == S_BOOMERANG) gi = gi - X(s);
-                    acc += (i < d) ? gi * gi : 0.0;
+                    acc += (in_dim(s, i)) ? gi * gi : 0.0;
                 }
                 const double gg = group_sum(acc, G);
                 if constexpr (SAMPLER == S_BPS) {
                     if (gg == 0.0) return;
                     const double scale = 2.0 * gv / gg;                  // :60
-                    for (int s = 0; s < K; ++s) {
+                    PDMP_SLOTS(s) {
                         const int i = s * G + g;
                         const double gi = tgt.grad(i, X(s), sh);
-                        if (i < d) V(s) = V(s) - scale * gi;
+                        if (in_dim(s, i)) V(s) = V(s) - scale * gi;
                     }
                 } else {
                     const double nrm = __dsqrt_rn(gg);                   // :58
                     acc = 0.0;
-                    for (int s = 0; s < K; ++s) {
+                    PDMP_SLOTS(s) {
                         const int i = s * G + g;
                         const double e = (tgt.grad(i, X(s), sh) - X(s)) / nrm;
-                        acc += (i < d) ? V(s) * e : 0.0;
+                        acc += (in_dim(s, i)) ? V(s) * e : 0.0;
                     }
                     const double ve = 2.0 * group_sum(acc, G);
-                    for (int s = 0; s < K; ++s) {
+                    PDMP_SLOTS(s) {
                         const int i = s * G + g;
                         const double e = (tgt.grad(i, X(s), sh) - X(s)) / nrm;
-                        if (i < d) V(s) = V(s) - ve * e;                 // :59
+                        if (in_dim(s, i)) V(s) = V(s) - ve * e;                 // :59
                     }
                 }
             } else {
@@ -785,14 +813,14 @@ struct GroupChain {
                 }
                 rng.normals_done(d);
                 acc = 0.0;
-                for (int s = 0; s < K; ++s) {
+                PDMP_SLOTS(s) {
                     const int i = s * G + g;
                     const double z = V(s);
-                    acc += (i < d) ? z * z : 0.0;
+                    acc += (in_dim(s, i)) ? z * z : 0.0;
                 }
                 if (SAMPLER == S_BPS && !p.gaussian_velocity) {          // normalize!, :71
                     const double inv = 1.0 / __dsqrt_rn(group_sum(acc, G));
-                    for (int s = 0; s < K; ++s) V(s) = V(s) * inv;
+                    PDMP_SLOTS(s) V(s) = V(s) * inv;
                 }
             }
         }
@@ -804,9 +832,9 @@ struct GroupChain {
                                            int32_t hits) const {
         const size_t e = (size_t)c * (size_t)p.n_sk + (size_t)k;
         double *Xe = p.X + e * (size_t)p.d, *Ve = p.V + e * (size_t)p.d;
-        for (int s = 0; s < K; ++s) {
+        PDMP_SLOTS(s) {
             const int i = s * G + g;
-            if (i < p.d) { Xe[i] = X(s); Ve[i] = V(s); }
+            if (in_dim(s, i)) { Xe[i] = X(s); Ve[i] = V(s); }
         }
         if (g == 0) {
             p.t[e] = t;
@@ -838,9 +866,9 @@ struct GroupChain {
             t = st[2 * d]; horizon = st[2 * d + 1]; ar = st[2 * d + 2];
             n0 = (uint64_t)__double_as_longlong(st[2 * d + 3]);
         }
-        for (int s = 0; s < K; ++s) {
+        PDMP_SLOTS(s) {
             const int i = s * G + g;
-            const bool ok = chain_ok && i < d;
+            const bool ok = chain_ok && in_dim(s, i);
             if (r == 0) {
                 X(s) = ok ? p.xinit[(size_t)c * d + i] : 0.0;            // copies: inputs are never mutated (Q7)
                 V(s) = ok ? p.vinit[(size_t)c * d + i] : 0.0;
@@ -950,9 +978,9 @@ struct GroupChain {
         if (lane == 0 && p.stamps) for (int q = 0; q < 6; ++q) atomicAdd(&p.stamps[q], st_acc[q]);
 #endif
         if (chain_ok) {                                                   // hand-off / final state
-            for (int s = 0; s < K; ++s) {
+            PDMP_SLOTS(s) {
                 const int i = s * G + g;
-                if (i < d) { st[i] = X(s); st[d + i] = V(s); }
+                if (in_dim(s, i)) { st[i] = X(s); st[d + i] = V(s); }
             }
             if (g == 0) {
                 st[2 * d] = t; st[2 * d + 1] = horizon; st[2 * d + 2] = ar;
@@ -1005,7 +1033,7 @@ __device__ __forceinline__ bool wait_progress(const int32_t *flag, int r) {
 // waves per SIMD fit the register file; LDS (2*ceil(d/G)*512 B per wave) is what limits residency.
 template <int TARGET> struct GroupOcc { static constexpr int kWaves = (TARGET == T_BANANA) ? 3 : 4; };   // banana + finite differences keeps six shared records: 3 waves avoid spills
 
-template <int SAMPLER, int TARGET, bool FD>
+template <int SAMPLER, int TARGET, bool FD, int KC = 0>
 __device__ __forceinline__ void group_kernel_body(const GroupParams &gp) {
     extern __shared__ double smem[];
     const int lane = lane_id();
@@ -1016,7 +1044,7 @@ __device__ __forceinline__ void group_kernel_body(const GroupParams &gp) {
     const size_t tsz = (size_t)gp.K * WAVE;
     double *tile = smem + gp.tpar + (size_t)wave * gp.tiles * tsz;
     const int cpw = WAVE / gp.G;
-    GroupChain<SAMPLER, TARGET, FD> chain(gp, lane, tile, tile + tsz);
+    GroupChain<SAMPLER, TARGET, FD, KC> chain(gp, lane, tile, tile + tsz);
     chain.tgt.init(smem, gp.s.d);
     if constexpr (GTarget<TARGET>::kTile) {
         chain.tgt.P = gp.s.tparams;
@@ -1048,6 +1076,16 @@ template <int SAMPLER, int TARGET, bool FD>
 __global__ __launch_bounds__(256, GroupOcc<TARGET>::kWaves) void group_kernel(const GroupParams gp) {
     group_kernel_body<SAMPLER, TARGET, FD>(gp);
 }
+// register form (x, v in VGPRs, up to KC slots per lane, G fixed at compile time): no LDS tiles; 2 waves per SIMD -- the
+// instantiations must stay free of VGPR spills (a spill under a partial exec mask loses the inactive lanes' values, and
+// lanes of different chains run different branches here): `make check-spills`
+template <int SAMPLER, int TARGET, bool FD, int KC, int GC, bool FULL>
+__global__ __launch_bounds__(256, 2) void group_kernel_reg(const GroupParams gp_in) {
+    GroupParams gp = gp_in;
+    gp.G = GC;                 // the host launches this instantiation only for G == GC, K <= KC: folds every use of G
+    if (FULL) gp.K = KC;       // ... and the FULL one only for K == KC: the per-slot skips fold away too
+    group_kernel_body<SAMPLER, TARGET, FD, KC>(gp);
+}
 
 #ifndef __HIPCC_RTC__   // host side (not part of a runtime-compiled user kernel)
 // waves per block: as many (up to 4) as fit the CU's 160 KiB of LDS next to the staged parameters
@@ -1078,13 +1116,19 @@ inline void group_schedule(int64_t nb, int64_t slots, int64_t n_sk, int force, i
 template <int SAMPLER, int TARGET>
 hipError_t launch_group(const GroupParams &gp, hipStream_t stream);
 
-template <int SAMPLER, int TARGET, bool FD>
+template <int SAMPLER, int TARGET, bool FD, int KC = 0, int GC = 0>
 hipError_t launch_group_impl(const GroupParams &gp_in, hipStream_t stream) {
     GroupParams gp = gp_in;
-    const int cpw = WAVE / gp.G, wpb = group_waves_per_block(gp.K, gp.tpar, gp.tiles);
+    if (KC > 0) gp.tiles = 0;
+    const int cpw = WAVE / gp.G, wpb = KC > 0 ? 4 : group_waves_per_block(gp.K, gp.tpar, gp.tiles);
     if (wpb < 1) return hipErrorInvalidValue;
     const size_t lds = ((size_t)gp.tpar + (size_t)wpb * gp.tiles * gp.K * WAVE) * sizeof(double);
-    auto kernel = group_kernel<SAMPLER, TARGET, FD>;
+    void (*kernel)(const GroupParams);
+    if constexpr (KC > 0) {
+        kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, false>;
+        // (the fully unrolled banana kernel would spill VGPRs: it keeps the per-slot skips)
+        if constexpr (!GTarget<TARGET>::kShared) if (gp.K == KC) kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, true>;
+    } else kernel = group_kernel<SAMPLER, TARGET, FD>;
     hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     int per_cu = 0, dev = 0, cus = 0;

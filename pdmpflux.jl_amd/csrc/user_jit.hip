@@ -61,8 +61,8 @@ extern "C" int pdmp_user_compile(int device, int sampler, int fd, int kind, cons
         std::string a(prop.gcnArchName);
         arch = "--offload-arch=" + a.substr(0, a.find(':'));
     }
-    const char *opts[] = {arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off"};   // the arithmetic contract of the static build
-    const hiprtcResult r = hiprtcCompileProgram(p, 4, opts);
+    const char *opts[] = {arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-w"};   // the arithmetic contract of the static build; -w: the log is for errors
+    const hiprtcResult r = hiprtcCompileProgram(p, 5, opts);
     if (r != HIPRTC_SUCCESS) {
         size_t n = 0;
         hiprtcGetProgramLogSize(p, &n);

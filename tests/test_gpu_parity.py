@@ -338,3 +338,22 @@ def test_dense_precision_gemm_path_matches_oracle(engine, oracle, monkeypatch, d
     s2, cfg2 = make_pair(engine, oracle, "ZigZagAD", dim, "dense")
     got2 = engine.sample_skeleton_ensemble(s2, 12, x[:6], v[:6], seed=21)
     assert_bitwise(got2, oracle.sample_skeleton(cfg2, 12, x[:6], v[:6], 21))
+
+
+@pytest.mark.parametrize("dim,target,kw", [
+    (5, "iso", {}), (13, "diag", {}), (26, "banana", {}), (50, "iso", {}), (50, "banana", {"AD_backend": "FiniteDiff"}),
+    (100, "diag", {}), (200, "iso", {}), (50, "iso", {"signed_bound": False}), (50, "diag", {"grid_size": 0}),
+])
+def test_register_and_lds_forms_agree(engine, oracle, monkeypatch, dim, target, kw):
+    """Zig-Zag runs with x, v in registers (inst_reg.hip) when ceil(d/G) <= 13; PDMP_REG=0 keeps them in LDS tiles.
+    Same operations in the same order: both forms equal the checker bit for bit."""
+    kind = "ZigZag" if kw.get("AD_backend") == "FiniteDiff" else "ZigZagAD"
+    s, cfg = make_pair(engine, oracle, kind, dim, target, **kw)
+    C, n_sk = 21, 40
+    x, v = make_init(kind, dim, C, seed=8, target=target)
+    ref = oracle.sample_skeleton(cfg, n_sk, x, v, 17, diagnostics=True)
+    reg = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=17, diagnostics=True)
+    monkeypatch.setenv("PDMP_REG", "0")
+    lds = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=17, diagnostics=True)
+    assert_bitwise(reg, ref)
+    assert_bitwise(lds, ref)
