@@ -221,7 +221,11 @@ def main():
         kernel_ms = tm["kernel_ms_total"] / max(tm["launches"], 1)
         achieved = C * (n_sk - 1) * bytes_per_event / (kernel_ms * 1e-3) / 1e9
         G = sampler.group_lanes()
-        kernel = (f"group_kernel<{sampler.name},{a.target}> (G={G} lanes per chain)" if G > 0 else
+        K = (d + G - 1) // G if G > 0 else 0
+        reg_form = G > 0 and sampler.sampler_id == 0 and sampler.deriv_mode == 0 and K <= 13 and G <= 16 and a.target in ("iso", "banana") \
+            and os.environ.get("PDMP_REG", "1") != "0"
+        kernel = (f"group_kernel_reg<{sampler.name},{a.target}> (G={G} lanes per chain, x and v in registers)" if reg_form else
+                  f"group_kernel<{sampler.name},{a.target}> (G={G} lanes per chain)" if G > 0 else
                   f"skeleton_kernel<{sampler.name},{a.target}> (wave per chain)")
         res = {
             "metric": "skeleton-events/sec (whole node), Zig-Zag d=50, 10^5 chains",

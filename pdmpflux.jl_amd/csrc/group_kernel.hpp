@@ -186,7 +186,7 @@ template <> struct GTarget<T_USER> {
 // KC = 0: K = ceil(d/G) slots per lane at run time, x and v in LDS tiles.  KC > 0 (register form): up to KC slots, x and v in
 // REGISTERS, every slot loop fully unrolled with a scalar skip of the slots >= K -- no ds_read latency in the loops, no slot
 // addressing.  Same operations in the same order: the two forms agree bit for bit.
-#define PDMP_SLOTS(s) _Pragma("unroll kUnroll") for (int s = 0; s < nk(); ++s, slot_fence()) if (!kReg || s < K)
+#define PDMP_SLOTS(s) _Pragma("unroll kUnroll") for (int s = 0; s < nk(); ++s) if (!kReg || s < K)
 template <int SAMPLER, int TARGET, bool FD, int KC = 0>
 struct GroupChain {
     using Tgt = GTarget<TARGET>;
@@ -198,8 +198,6 @@ struct GroupChain {
     double *xs, *vs;                     // this wave's LDS tiles: slot s of lane l at [s*64 + l]
     mutable double xr[kReg ? KC : 1], vr[kReg ? KC : 1];   // register form: slot s of this lane
     __device__ __forceinline__ int nk() const { if constexpr (kReg) return KC; else return K; }
-    // register form: keep the scheduler from interleaving all KC unrolled slots (their temporaries would not fit the register file)
-    __device__ __forceinline__ static void slot_fence() { if constexpr (kReg) __builtin_amdgcn_sched_barrier(0); }
     // coordinate i = s*G + g exists (i < d): only the last slot K-1 can be partly padded (register form: a scalar test for the others)
     __device__ __forceinline__ bool in_dim(int s, int i) const { if constexpr (kReg) return s < K - 1 || i < p.d; else return i < p.d; }
     Tgt tgt;
