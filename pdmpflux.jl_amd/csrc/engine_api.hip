@@ -11,7 +11,11 @@
 #include <vector>
 
 using namespace pdmp;
-namespace pdmp { hipError_t launch_group_reg(int sampler, int target, bool fd, const GroupParams &gp, hipStream_t stream); }
+namespace pdmp {
+hipError_t launch_group_reg_zigzag(int target, bool fd, const GroupParams &gp, hipStream_t stream);
+hipError_t launch_group_reg_bps(int target, bool fd, const GroupParams &gp, hipStream_t stream);
+hipError_t launch_group_reg_boomerang(int target, bool fd, const GroupParams &gp, hipStream_t stream);
+}
 
 namespace {
 
@@ -251,9 +255,8 @@ int choose_group_lanes(const pdmp_config_t &c) {
         if (G == 0) return 0;
         if (G >= 1 && G <= WAVE && (G & (G - 1)) == 0 && group_waves_per_block((c.dim + G - 1) / G, 2 * c.dim) >= 1) return G;
     }
-    if (c.sampler == PDMP_ZIGZAG)          // register form (inst_reg.hip): at most KREG slots per lane, G <= 16
-        for (int G = 1; G <= 16; G <<= 1)
-            if ((c.dim + G - 1) / G <= KREG) return G;
+    for (int G = 1; G <= 16; G <<= 1)      // register form (inst_reg_*.hip): at most KREG slots per lane, G <= 16
+        if ((c.dim + G - 1) / G <= KREG) return G;
     const size_t budget = 20 * 1024;      // two blocks (8 waves) per CU
     for (int G = 1; G <= WAVE; G <<= 1) {
         const size_t K = (size_t)(c.dim + G - 1) / G;
@@ -491,7 +494,12 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
     } else if (h->group_lanes > 0 && !taped) {
         hipError_t e = hipErrorNotSupported;
         const char *reg = getenv("PDMP_REG");               // PDMP_REG=0: keep x, v in LDS tiles (test hook)
-        if (!(reg && atoi(reg) == 0)) e = launch_group_reg(c.sampler, c.target_id, c.deriv_mode != 0, gp, s);
+        if (!(reg && atoi(reg) == 0)) {
+            const bool fd = c.deriv_mode != 0;
+            e = c.sampler == PDMP_ZIGZAG ? launch_group_reg_zigzag(c.target_id, fd, gp, s)
+              : c.sampler == PDMP_BPS    ? launch_group_reg_bps(c.target_id, fd, gp, s)
+                                         : launch_group_reg_boomerang(c.target_id, fd, gp, s);
+        }
         if (e == hipErrorNotSupported) e = pick_group_launcher(c.sampler, c.target_id)(gp, s);
         HIP_TRY(e);
     }

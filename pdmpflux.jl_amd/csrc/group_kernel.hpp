@@ -810,6 +810,7 @@ struct GroupChain {
                     if (i1 < d) vs[(i1 >> logG) * WAVE + base + (i1 & (G - 1))] = z1;
                 }
                 rng.normals_done(d);
+                if constexpr (kReg) { PDMP_SLOTS(s) vr[s] = in_dim(s, s * G + g) ? vs[s * WAVE + lane] : 0.0; }   // register form: vs is an exchange tile only
                 acc = 0.0;
                 PDMP_SLOTS(s) {
                     const int i = s * G + g;
@@ -1042,7 +1043,8 @@ __device__ __forceinline__ void group_kernel_body(const GroupParams &gp) {
     const size_t tsz = (size_t)gp.K * WAVE;
     double *tile = smem + gp.tpar + (size_t)wave * gp.tiles * tsz;
     const int cpw = WAVE / gp.G;
-    GroupChain<SAMPLER, TARGET, FD, KC> chain(gp, lane, tile, tile + tsz);
+    // register form: no x tile; one K*64-double tile per wave only where refreshed velocities are exchanged between lanes
+    GroupChain<SAMPLER, TARGET, FD, KC> chain(gp, lane, tile, KC > 0 ? tile : tile + tsz);
     chain.tgt.init(smem, gp.s.d);
     if constexpr (GTarget<TARGET>::kTile) {
         chain.tgt.P = gp.s.tparams;
@@ -1074,6 +1076,16 @@ template <int SAMPLER, int TARGET, bool FD>
 __global__ __launch_bounds__(256, GroupOcc<TARGET>::kWaves) void group_kernel(const GroupParams gp) {
     group_kernel_body<SAMPLER, TARGET, FD>(gp);
 }
+// Which register-form kernels exist.  kAny: the form is used at all; kPartial: also for K < KC (with the per-slot skips);
+// kFull: a separate instantiation without the skips for K == KC.  Set from the compiler's resource-usage remarks so that no
+// instantiation spills a VGPR (see below), and from measurements (Zig-Zag with finite differences: the LDS form is faster).
+template <int SAMPLER, int TARGET, bool FD> struct RegForm {
+    static constexpr bool kSlowZz = SAMPLER == S_ZIGZAG && FD;                       // measured: 88 ms against 73 ms in the LDS form
+    static constexpr bool kPartial = !kSlowZz && !(SAMPLER == S_BOOMERANG && TARGET != T_GAUSS_DIAG);   // would spill: Boomerang iso / banana
+    static constexpr bool kFull = !kSlowZz && !GTarget<TARGET>::kShared && !(SAMPLER == S_BOOMERANG && TARGET == T_GAUSS_DIAG);   // would spill: banana, Boomerang diag
+    static constexpr bool kAny = kPartial || kFull;
+};
+
 // register form (x, v in VGPRs, up to KC slots per lane, G fixed at compile time): no LDS tiles; 2 waves per SIMD -- the
 // instantiations must stay free of VGPR spills (a spill under a partial exec mask loses the inactive lanes' values, and
 // lanes of different chains run different branches here): `make check-spills`
@@ -1117,16 +1129,17 @@ hipError_t launch_group(const GroupParams &gp, hipStream_t stream);
 template <int SAMPLER, int TARGET, bool FD, int KC = 0, int GC = 0>
 hipError_t launch_group_impl(const GroupParams &gp_in, hipStream_t stream) {
     GroupParams gp = gp_in;
-    if (KC > 0) gp.tiles = 0;
+    if (KC > 0) gp.tiles = (SAMPLER == S_ZIGZAG) ? 0 : 1;
     const int cpw = WAVE / gp.G, wpb = KC > 0 ? 4 : group_waves_per_block(gp.K, gp.tpar, gp.tiles);
     if (wpb < 1) return hipErrorInvalidValue;
     const size_t lds = ((size_t)gp.tpar + (size_t)wpb * gp.tiles * gp.K * WAVE) * sizeof(double);
-    void (*kernel)(const GroupParams);
+    void (*kernel)(const GroupParams) = nullptr;
     if constexpr (KC > 0) {
-        kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, false>;
-        // (the fully unrolled banana kernel would spill VGPRs: it keeps the per-slot skips)
-        if constexpr (!GTarget<TARGET>::kShared) if (gp.K == KC) kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, true>;
+        using RF = RegForm<SAMPLER, TARGET, FD>;
+        if constexpr (RF::kPartial) kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, false>;
+        if constexpr (RF::kFull) if (gp.K == KC) kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, true>;
     } else kernel = group_kernel<SAMPLER, TARGET, FD>;
+    if (!kernel) return hipErrorNotSupported;
     hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     int per_cu = 0, dev = 0, cus = 0;

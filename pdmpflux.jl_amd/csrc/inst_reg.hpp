@@ -1,0 +1,35 @@
+// Register-form instantiations of the group kernel (x, v in VGPRs; GroupChain<..., KC>): up to KREG slots per lane, lanes
+// per chain G fixed at compile time, and a second instantiation for K == KREG exactly (d = 50, G = 4; d = 100, G = 8; ...)
+// where that one stays free of spills.  One translation unit per sampler (inst_reg_*.hip) so they compile in parallel.
+#pragma once
+#include "group_kernel.hpp"
+
+namespace pdmp {
+
+template <int S, int T, bool FD>
+static hipError_t reg_by_lanes(const GroupParams &gp, hipStream_t stream) {
+    if constexpr (!RegForm<S, T, FD>::kAny) return hipErrorNotSupported;
+    else {
+        switch (gp.G) {
+        case 1: return launch_group_impl<S, T, FD, KREG, 1>(gp, stream);
+        case 2: return launch_group_impl<S, T, FD, KREG, 2>(gp, stream);
+        case 4: return launch_group_impl<S, T, FD, KREG, 4>(gp, stream);
+        case 8: return launch_group_impl<S, T, FD, KREG, 8>(gp, stream);
+        case 16: return launch_group_impl<S, T, FD, KREG, 16>(gp, stream);
+        default: return hipErrorNotSupported;
+        }
+    }
+}
+
+template <int S>
+static hipError_t reg_by_target(int target, bool fd, const GroupParams &gp, hipStream_t stream) {
+    if (gp.K > KREG) return hipErrorNotSupported;
+    switch (target) {
+    case T_GAUSS_ISO: return fd ? reg_by_lanes<S, T_GAUSS_ISO, true>(gp, stream) : reg_by_lanes<S, T_GAUSS_ISO, false>(gp, stream);
+    case T_GAUSS_DIAG: return fd ? reg_by_lanes<S, T_GAUSS_DIAG, true>(gp, stream) : reg_by_lanes<S, T_GAUSS_DIAG, false>(gp, stream);
+    case T_BANANA: return fd ? reg_by_lanes<S, T_BANANA, true>(gp, stream) : reg_by_lanes<S, T_BANANA, false>(gp, stream);
+    default: return hipErrorNotSupported;
+    }
+}
+
+}  // namespace pdmp

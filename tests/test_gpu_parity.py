@@ -340,14 +340,19 @@ def test_dense_precision_gemm_path_matches_oracle(engine, oracle, monkeypatch, d
     assert_bitwise(got2, oracle.sample_skeleton(cfg2, 12, x[:6], v[:6], 21))
 
 
-@pytest.mark.parametrize("dim,target,kw", [
-    (5, "iso", {}), (13, "diag", {}), (26, "banana", {}), (50, "iso", {}), (50, "banana", {"AD_backend": "FiniteDiff"}),
-    (100, "diag", {}), (200, "iso", {}), (50, "iso", {"signed_bound": False}), (50, "diag", {"grid_size": 0}),
+@pytest.mark.parametrize("kind,dim,target,kw", [
+    ("ZigZagAD", 5, "iso", {}), ("ZigZagAD", 13, "diag", {}), ("ZigZagAD", 26, "banana", {}), ("ZigZagAD", 50, "iso", {}),
+    ("ZigZag", 50, "banana", {}), ("ZigZagAD", 100, "diag", {}), ("ZigZagAD", 200, "iso", {}),
+    ("ZigZagAD", 50, "iso", {"signed_bound": False}), ("ZigZagAD", 50, "diag", {"grid_size": 0}),
+    ("BPS", 50, "iso", {}), ("BPS", 50, "banana", {}), ("BPS", 30, "diag", {"AD_backend": "FiniteDiff"}), ("BPS", 13, "iso", {"Gaussian_velocity": True}),
+    ("BPS", 104, "banana", {"AD_backend": "FiniteDiff"}), ("BPS", 50, "iso", {"grid_size": 0}),
+    ("Boomerang", 100, "iso", {}), ("BoomerangAD", 100, "iso", {}), ("BoomerangAD", 60, "diag", {}), ("Boomerang", 26, "iso", {}),
+    ("BoomerangAD", 50, "banana", {}),
 ])
-def test_register_and_lds_forms_agree(engine, oracle, monkeypatch, dim, target, kw):
-    """Zig-Zag runs with x, v in registers (inst_reg.hip) when ceil(d/G) <= 13; PDMP_REG=0 keeps them in LDS tiles.
-    Same operations in the same order: both forms equal the checker bit for bit."""
-    kind = "ZigZag" if kw.get("AD_backend") == "FiniteDiff" else "ZigZagAD"
+def test_register_and_lds_forms_agree(engine, oracle, monkeypatch, kind, dim, target, kw):
+    """With ceil(d/G) <= 13 the group kernel keeps x, v in registers (inst_reg_*.hip; RegForm says for which sampler /
+    target / slope mode); PDMP_REG=0 keeps them in LDS tiles.  Same operations in the same order: both forms equal the
+    checker bit for bit."""
     s, cfg = make_pair(engine, oracle, kind, dim, target, **kw)
     C, n_sk = 21, 40
     x, v = make_init(kind, dim, C, seed=8, target=target)
