@@ -75,6 +75,13 @@ __device__ __forceinline__ double group_scan_incl(double a, int g, int G) {   //
     return a;
 }
 
+// One 8-byte word of the hand-off state, stored write-through (global_store_dwordx2 ... sc1): visible to the other XCDs' L2s
+// once the storing wave's s_waitcnt vmcnt(0) has passed, with no release fence (cdna_hip_programming.md Guideline 16, R1).
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+__device__ __forceinline__ void publish(double *p, double x) {
+    __hip_atomic_store((gu64 *)p, (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 struct TimePt { double t, s, c; };   // grid time (+ sin/cos for the Boomerang rotation)
 
 // flow of one coordinate: ZigZagSamplers.jl:80 / BouncyParticleSamplers.jl:32 (x + v t, v); BoomerangSamplers.jl:31 (rotation)
@@ -976,14 +983,14 @@ struct GroupChain {
 #ifdef PDMP_STAMP
         if (lane == 0 && p.stamps) for (int q = 0; q < 6; ++q) atomicAdd(&p.stamps[q], st_acc[q]);
 #endif
-        if (chain_ok) {                                                   // hand-off / final state
+        if (chain_ok) {                                                   // hand-off / final state: write-through (sc1) stores, see group_kernel_body
             PDMP_SLOTS(s) {
                 const int i = s * G + g;
-                if (in_dim(s, i)) { st[i] = X(s); st[d + i] = V(s); }
+                if (in_dim(s, i)) { publish(st + i, X(s)); publish(st + d + i, V(s)); }
             }
             if (g == 0) {
-                st[2 * d] = t; st[2 * d + 1] = horizon; st[2 * d + 2] = ar;
-                st[2 * d + 3] = __longlong_as_double((long long)rng.n);
+                publish(st + 2 * d, t); publish(st + 2 * d + 1, horizon); publish(st + 2 * d + 2, ar);
+                publish(st + 2 * d + 3, __longlong_as_double((long long)rng.n));
             }
         }
         if (guard && g == 0) { atomicAdd(&p.status[1], guard); guard = 0; }
@@ -994,8 +1001,9 @@ struct GroupChain {
 // unit, MI355X_MICROARCH.md row "dequeue").  Unit (b, r) continues unit (b, r-1), pulled nb units
 // earlier by a wave that is resident and waits only on still older units, so the wait below is
 // satisfied on arrival in practice and can never deadlock; it is bounded all the same.
-// Hand-off protocol (cdna_hip_programming.md Guideline 16): plain stores -> agent-scope release fence
-// -> s_waitcnt vmcnt(0) -> relaxed agent flag store;  relaxed poll -> agent-scope acquire -> plain loads.
+// Hand-off protocol (cdna_hip_programming.md Guideline 16, form R1): write-through (sc1) stores of the 2d+4 state words
+// -> the storing wave's s_waitcnt vmcnt(0) -> relaxed agent flag store by the same wave;  relaxed poll -> agent-scope
+// acquire (invalidates this CU's L1 only) -> plain loads.
 // U = x'Px/2, grad-U = P x with a dense precision matrix (BASELINE config 4).  One chain per wave (G = 64);
 // the gradient of a whole time point is a mat-vec: x_t is written to an LDS scratch tile, row i of P x_t is
 // accumulated left to right over j (the order of the checker) by the lane that owns coordinate i, P streams
@@ -1064,7 +1072,9 @@ __device__ __forceinline__ void group_kernel_body(const GroupParams &gp) {
         if (!lost) {
             const int64_t c = (int64_t)b * cpw + lane / gp.G;
             chain.run_segment(c, c < gp.s.C, r, gp.seg_len, gp.state);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            // no agent-scope release here: it is a buffer_wbl2, a write-back of the XCD's whole L2, which the event stores of
+            // every wave keep full of dirty lines (measured: 35 -> 52 ms when the segments were made 3x shorter); the
+            // hand-off state went out write-through instead, and the drain below covers it
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(&gp.progress[b], r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
