@@ -453,6 +453,8 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
         gp.K = (c.dim + gp.G - 1) / gp.G;
         gp.tpar = (c.target_id == PDMP_T_GAUSS_DIAG) ? 2 * c.dim : 0;
         gp.tiles = (c.target_id == PDMP_T_GAUSS_DENSE) ? 6 : 2;
+        gp.cell_budget = 3;
+        if (const char *e = getenv("PDMP_CELL_BUDGET")) { const int b = atoi(e); if (b >= 1 && b <= GNG - 1) gp.cell_budget = b; }   // tuning / tests
         const int64_t nb = (C + WAVE / gp.G - 1) / (WAVE / gp.G);
         const size_t need_sched = (size_t)nb + 1, need_state = (size_t)C * (size_t)(2 * c.dim + 4);
         if (need_sched > h->sched_cap) {

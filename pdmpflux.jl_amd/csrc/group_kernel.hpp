@@ -37,6 +37,7 @@ struct GroupParams {
     int32_t K;            // coordinate slots per lane = ceil(d / G)
     int32_t tpar;         // doubles of target parameters staged in LDS (0 or 2d)
     int32_t tiles;        // K*64-double LDS tiles per wave: 2 (x, v) + the target's scratch tiles
+    int32_t cell_budget;  // cells of a lazily built Zig-Zag bound per pass of the state machine (1..9)
     // dynamic schedule: work unit u = (batch b = u % nb of 64/G chains, segment r = u / nb of seg_len events)
     int32_t nseg;         // segments per chain
     int64_t nb;           // batches = ceil(C / (64/G))
@@ -211,8 +212,10 @@ struct GroupChain {
     ChainRng rng;
     int32_t guard = 0;
 
+    const int cell_budget;               // cells of a lazily built bound per pass of the state machine (bound_advance_vect)
     __device__ __forceinline__ GroupChain(const GroupParams &gp, int l, double *x_tile, double *v_tile)
-        : p(gp.s), G(gp.G), K(gp.K), lane(l), g(l & (gp.G - 1)), base(l & ~(gp.G - 1)), xs(x_tile), vs(v_tile) {}
+        : p(gp.s), G(gp.G), K(gp.K), lane(l), g(l & (gp.G - 1)), base(l & ~(gp.G - 1)), xs(x_tile), vs(v_tile),
+          cell_budget(gp.cell_budget) {}
 
     __device__ __forceinline__ double &X(int s) const { if constexpr (kReg) return xr[s]; else return xs[s * WAVE + lane]; }
     __device__ __forceinline__ double &V(int s) const { if constexpr (kReg) return vr[s]; else return vs[s * WAVE + lane]; }
@@ -351,69 +354,86 @@ struct GroupChain {
         return (P.kind == 3) ? fc - fc : num / P.den;
     }
 
+    // Progress of this lane's chain through its lazily built bound: cells [0, b_next) are summed.  The cells are built at most
+    // `gp.cell_budget` per pass of the state machine: a chain that needs more (the ~2 % that run to the horizon need all nine)
+    // resumes in the next pass beside the fresh bounds of the other chains of the wave, instead of holding all of them for
+    // six more cells.  Same cells, same order, same sums per chain: nothing changes in any chain's arithmetic.
+    int b_next = 0;
+    double b_acc = 0.0, b_cprev = 0.0, b_last = 0.0;
+    typename Tgt::template Sh<Dual> b_shf{};
+    __device__ __forceinline__ void bound_begin(double &tpo) { b_next = 0; b_acc = 0.0; b_cprev = 0.0; b_last = 0.0; tpo = __builtin_huge_val(); }
+
+    // returns true when this lane's bound is finished: its cell was found (tpo, lbo set) or all cells are built (lbo = box_max[end])
     template <bool SIGNED, bool FDM>
-    __device__ __forceinline__ void bound_invert_vect(double harg, double E, double &tpo, double &lbo) {
+    __device__ __forceinline__ bool bound_advance_vect(double harg, double E, double &tpo, double &lbo, int budget) {
         const double h = harg / (double)(GNG - 1);
-        double acc = 0.0, cprev = 0.0, bj = 0.0;
         bool found = false;
-        tpo = __builtin_huge_val();
-        typename Tgt::template Sh<Dual> shf{};
 #ifdef PDMP_STAMP
         if (lane == 0 && p.stamps) atomicAdd(&p.stamps[7], 1ull);
 #endif
-        for (int j = 0; j < GNG - 1; ++j) {
+        for (int pass = 0; pass < budget; ++pass) {
+            const bool act = !found && b_next < GNG - 1;                                // the lanes of a chain agree
+            if (__ballot(act) == 0ull) break;
 #ifdef PDMP_STAMP
             if (lane == 0 && p.stamps) atomicAdd(&p.stamps[6], 1ull);
 #endif
-            const double t0 = (double)j * h, t1 = (j == GNG - 2) ? harg : (double)(j + 1) * h;
-            double bsum = 0.0;
-            if constexpr (!FDM) {
-                TimePt p0, p1;
-                time_pt(t0, p0);
-                time_pt(t1, p1);
-                if (j == 0) shf = shared_at<Dual>(p0, 0);                 // left endpoint: carried over from the previous cell
-                const auto sh0 = shf, sh1 = shared_at<Dual>(p1, (j + 1) & 1);
-                PDMP_SLOTS(s) {
-                    const int i = s * G + g;
-                    const int ip = (in_dim(s, i)) ? i : 0;
-                    const double x = X(s);
-                    double v = V(s);
-                    if constexpr (kReg) asm volatile("" : "+v"(v));       // keeps v*v (same for every cell) from being hoisted into KC more registers
-                    double v0, g0, v1, g1;
-                    eval_vect<SIGNED>(ip, x, v, p0, sh0, v0, g0);
-                    eval_vect<SIGNED>(ip, x, v, p1, sh1, v1, g1);
-                    bsum += cell_vect(v0, g0, v1, g1, t0, t1, h);
+            if (act) {
+                const int j = b_next;
+                const double t0 = (double)j * h, t1 = (j == GNG - 2) ? harg : (double)(j + 1) * h;
+                double bsum = 0.0;
+                if constexpr (!FDM) {
+                    TimePt p0, p1;
+                    time_pt(t0, p0);
+                    time_pt(t1, p1);
+                    if constexpr (Tgt::kShared) {                                      // left endpoint: carried over from the previous cell
+                        if (__ballot(j == 0) != 0ull) { const auto f = shared_at<Dual>(p0, 0); if (j == 0) b_shf = f; }
+                    }
+                    const auto sh0 = b_shf, sh1 = shared_at<Dual>(p1, (j + 1) & 1);
+                    PDMP_SLOTS(s) {
+                        const int i = s * G + g;
+                        const int ip = (in_dim(s, i)) ? i : 0;
+                        const double x = X(s);
+                        double v = V(s);
+                        if constexpr (kReg) asm volatile("" : "+v"(v));       // keeps v*v (same for every cell) from being hoisted into KC more registers
+                        double v0, g0, v1, g1;
+                        eval_vect<SIGNED>(ip, x, v, p0, sh0, v0, g0);
+                        eval_vect<SIGNED>(ip, x, v, p1, sh1, v1, g1);
+                        bsum += cell_vect(v0, g0, v1, g1, t0, t1, h);
+                    }
+                    b_shf = sh1;
+                } else {                                                               // AD_backend = "FiniteDiff", :223-224
+                    FdPt P0, P1;
+                    fd_point(t0, harg, P0);
+                    fd_point(t1, harg, P1);
+                    const auto a0 = shared_at<double>(P0.c), a1 = shared_at<double>(P0.m), a2 = shared_at<double>(P0.pl);
+                    const auto b0 = shared_at<double>(P1.c), b1 = shared_at<double>(P1.m), b2 = shared_at<double>(P1.pl);
+                    PDMP_SLOTS(s) {
+                        const int i = s * G + g;
+                        const int ip = (in_dim(s, i)) ? i : 0;
+                        const double x = X(s), v = V(s);
+                        const double v0 = fval_vect<SIGNED>(ip, x, v, P0.c, a0);
+                        const double g0 = fd_slope(P0, v0, fval_vect<SIGNED>(ip, x, v, P0.m, a1), fval_vect<SIGNED>(ip, x, v, P0.pl, a2));
+                        const double v1 = fval_vect<SIGNED>(ip, x, v, P1.c, b0);
+                        const double g1 = fd_slope(P1, v1, fval_vect<SIGNED>(ip, x, v, P1.m, b1), fval_vect<SIGNED>(ip, x, v, P1.pl, b2));
+                        bsum += cell_vect(v0, g0, v1, g1, t0, t1, h);
+                    }
                 }
-                shf = sh1;
-            } else {                                                                   // AD_backend = "FiniteDiff", :223-224
-                FdPt P0, P1;
-                fd_point(t0, harg, P0);
-                fd_point(t1, harg, P1);
-                const auto a0 = shared_at<double>(P0.c), a1 = shared_at<double>(P0.m), a2 = shared_at<double>(P0.pl);
-                const auto b0 = shared_at<double>(P1.c), b1 = shared_at<double>(P1.m), b2 = shared_at<double>(P1.pl);
-                PDMP_SLOTS(s) {
-                    const int i = s * G + g;
-                    const int ip = (in_dim(s, i)) ? i : 0;
-                    const double x = X(s), v = V(s);
-                    const double v0 = fval_vect<SIGNED>(ip, x, v, P0.c, a0);
-                    const double g0 = fd_slope(P0, v0, fval_vect<SIGNED>(ip, x, v, P0.m, a1), fval_vect<SIGNED>(ip, x, v, P0.pl, a2));
-                    const double v1 = fval_vect<SIGNED>(ip, x, v, P1.c, b0);
-                    const double g1 = fd_slope(P1, v1, fval_vect<SIGNED>(ip, x, v, P1.m, b1), fval_vect<SIGNED>(ip, x, v, P1.pl, b2));
-                    bsum += cell_vect(v0, g0, v1, g1, t0, t1, h);
+                const double bj = group_sum(bsum, G);
+                b_acc += bj;                                                           // cumsum, :243-244 (engine order)
+                const double cj = b_acc * h;
+                if (!(cj < E)) {                                                       // searchsortedfirst, :265
+                    found = true;
+                    tpo = t0 + (E - b_cprev) / (cj - b_cprev) * h;                     // :269
+                    lbo = bj;                                                          // :270
                 }
+                b_cprev = cj;
+                b_last = bj;
+                b_next = j + 1;
             }
-            bj = group_sum(bsum, G);
-            acc += bj;                                                                 // cumsum, :243-244 (engine order)
-            const double cj = acc * h;
-            if (!found && !(cj < E)) {                                                 // searchsortedfirst, :265
-                found = true;
-                tpo = t0 + (E - cprev) / (cj - cprev) * h;                             // :269
-                lbo = bj;                                                              // :270
-            }
-            cprev = cj;
-            if (__ballot(!found) == 0ull) break;
         }
-        if (!found) lbo = bj;                                                          // box_max[end], :270
+        const bool fin = found || b_next >= GNG - 1;
+        if (fin && !found) lbo = b_last;                                               // box_max[end], :270
+        return fin;
     }
     // one tangent-intersection cell of one coordinate, UpperBound.jl:229-241 (absolute-time form, Q1)
     __device__ __forceinline__ static double cell_vect(double v0, double g0, double v1, double g1, double t0, double t1, double h) {
@@ -656,15 +676,16 @@ struct GroupChain {
         tpo = (c1 < E) ? __builtin_huge_val() : 0.0 + (E - 0.0) / (c1 - 0.0) * (harg - 0.0);   // next_event, :264-273
     }
 
-    __device__ __forceinline__ void bound_invert(double harg, double E, double &tp, double &lb) {
-        if (p.n_grid == 0) { bound_constant(harg, E, tp, lb); return; }
+    // one pass over the bound of every lane that is in the BOUND phase; true = finished (only the vectorized grid bound is
+    // built in instalments, the others finish in one call)
+    __device__ __forceinline__ bool bound_advance(double harg, double E, double &tp, double &lb, int budget) {
+        if (p.n_grid == 0) { bound_constant(harg, E, tp, lb); return true; }
         if constexpr (SAMPLER == S_ZIGZAG) {
-            if (p.vectorized) {
-                if (p.signed_bound) bound_invert_vect<true, FD>(harg, E, tp, lb); else bound_invert_vect<false, FD>(harg, E, tp, lb);
-                return;
-            }
+            if (p.vectorized)
+                return p.signed_bound ? bound_advance_vect<true, FD>(harg, E, tp, lb, budget) : bound_advance_vect<false, FD>(harg, E, tp, lb, budget);
         }
         bound_invert_scalar<FD>(harg, E, tp, lb);
+        return true;
     }
 
     // ---- unsigned total rate of the accept test (SamplingLoopInplace.jl:116, Q3)
@@ -901,9 +922,10 @@ struct GroupChain {
         // unchanged since it was built, so rebuilding it gives the same bits and frees its 38 registers
         // (3 waves per SIMD instead of 2 for ~4 % more bound evaluations).
         enum : int { FRESH = 0, ERR = 1, REUSE = 2 };
-        bool propose = false;
+        bool propose = false, brun = false;                              // brun: this lane's bound is under construction (bound_advance)
         int mode = FRESH;
         double hB = horizon;
+        const int budget = (G == WAVE) ? GNG : cell_budget;               // one chain per wave: nobody to wait for
 #ifdef PDMP_STAMP
         unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
 #define STAMP(k) do { unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[k] += now_ - st_last; st_last = now_; } while (0)
@@ -915,37 +937,44 @@ struct GroupChain {
             STAMP(5);
             if (!done && !propose) {
                 // one_step_of_thinning! (:65-85), erroneous_acceptance_rate! (:131-151) or if_reject! (:188-203)
-                const double harg = (mode == ERR) ? horizon / 2 : ((mode == REUSE) ? hB : horizon);
-                hB = harg;
-                const double e1 = rng.exponential();
-                E = (mode == REUSE) ? E + e1 : e1;                        // cumulative only after a rejection (:190)
-                bound_invert(harg, E, tp, lb);
-                if (mode == ERR) {
-                    if (adaptive) horizon = harg;
-                    errored++;
-                    const int slot = errored % 5;                         // :148 (1-based errored%5+1)
+                if (!brun) {
+                    const double harg = (mode == ERR) ? horizon / 2 : ((mode == REUSE) ? hB : horizon);
+                    hB = harg;
+                    const double e1 = rng.exponential();
+                    E = (mode == REUSE) ? E + e1 : e1;                    // cumulative only after a rejection (:190)
+                    bound_begin(tp);
+                    brun = true;
+                }
+                if (bound_advance(hB, E, tp, lb, budget)) {
+                    const double harg = hB;
+                    brun = false;
+                    if (mode == ERR) {
+                        if (adaptive) horizon = harg;
+                        errored++;
+                        const int slot = errored % 5;                     // :148 (1-based errored%5+1)
 #pragma unroll
-                    for (int q = 0; q < 5; ++q) if (q == slot) ev[q] = ar;
-                    propose = tp < horizon;                               // moves_until_horizon! loop test, :106
-                } else if (mode == REUSE) {
-                    if (adaptive) horizon = horizon / 1.04;               // :194
-                    rejected++;
-                    if (tp > horizon) {                                   // move_to_horizon2!, :205-217
+                        for (int q = 0; q < 5; ++q) if (q == slot) ev[q] = ar;
+                        propose = tp < horizon;                           // moves_until_horizon! loop test, :106
+                    } else if (mode == REUSE) {
+                        if (adaptive) horizon = horizon / 1.04;           // :194
+                        rejected++;
+                        if (tp > horizon) {                               // move_to_horizon2!, :205-217
+                            flow_state(horizon);
+                            ts += horizon;
+                            hits++;
+                        }
+                        propose = tp < horizon;
+                    } else if (tp > horizon) {                            // move_to_horizon!, :87-101
                         flow_state(horizon);
                         ts += horizon;
                         hits++;
+                        if (adaptive) horizon = horizon * 1.01;
+                    } else {
+                        propose = tp < horizon;                           // tp == horizon: retry (Q6)
                     }
-                    propose = tp < horizon;
-                } else if (tp > horizon) {                                // move_to_horizon!, :87-101
-                    flow_state(horizon);
-                    ts += horizon;
-                    hits++;
-                    if (adaptive) horizon = horizon * 1.01;
-                } else {
-                    propose = tp < horizon;                               // tp == horizon: retry (Q6)
+                    mode = FRESH;
+                    if (++it > cap) { done = true; if (g == 0) atomicAdd(&p.status[0], 1); }
                 }
-                mode = FRESH;
-                if (++it > cap) { done = true; if (g == 0) atomicAdd(&p.status[0], 1); }
             }
             STAMP(0);
             if (!done && propose) {
@@ -1092,7 +1121,7 @@ __global__ __launch_bounds__(256, GroupOcc<TARGET>::kWaves) void group_kernel(co
 template <int SAMPLER, int TARGET, bool FD> struct RegForm {
     static constexpr bool kSlowZz = SAMPLER == S_ZIGZAG && FD;                       // measured: 88 ms against 73 ms in the LDS form
     static constexpr bool kPartial = !kSlowZz && !(SAMPLER == S_BOOMERANG && TARGET != T_GAUSS_DIAG);   // would spill: Boomerang iso / banana
-    static constexpr bool kFull = !kSlowZz && !GTarget<TARGET>::kShared && !(SAMPLER == S_BOOMERANG && TARGET == T_GAUSS_DIAG);   // would spill: banana, Boomerang diag
+    static constexpr bool kFull = !kSlowZz && !GTarget<TARGET>::kShared && !(SAMPLER != S_BPS && TARGET == T_GAUSS_DIAG);   // would spill: banana, Zig-Zag / Boomerang diag
     static constexpr bool kAny = kPartial || kFull;
 };
 
