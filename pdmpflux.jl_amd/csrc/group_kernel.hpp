@@ -359,9 +359,17 @@ struct GroupChain {
     // resumes in the next pass beside the fresh bounds of the other chains of the wave, instead of holding all of them for
     // six more cells.  Same cells, same order, same sums per chain: nothing changes in any chain's arithmetic.
     int b_next = 0;
-    double b_acc = 0.0, b_cprev = 0.0, b_last = 0.0;
+    double b_acc = 0.0, b_cprev = 0.0, b_last = 0.0, b_cbefore = 0.0;    // b_cbefore: cum_sum before the last built cell
+    bool b_recheck = false;
     typename Tgt::template Sh<Dual> b_shf{};
-    __device__ __forceinline__ void bound_begin(double &tpo) { b_next = 0; b_acc = 0.0; b_cprev = 0.0; b_last = 0.0; tpo = __builtin_huge_val(); }
+    __device__ __forceinline__ void bound_begin(double &tpo) {
+        b_next = 0; b_acc = 0.0; b_cprev = 0.0; b_last = 0.0; b_cbefore = 0.0; b_recheck = false;
+        tpo = __builtin_huge_val();
+    }
+    // After a rejection the reference inverts the SAME bound again with a larger exponential (if_reject!, :188-203; Q4): x, v
+    // and the bound's horizon are unchanged, the cumulative sums are monotone and the new exponential is larger, so the new
+    // cell is the one found last time or a later one -- the built cells are kept and the inversion resumes at the last one.
+    __device__ __forceinline__ void bound_resume(double &tpo) { b_recheck = true; tpo = __builtin_huge_val(); }
 
     // returns true when this lane's bound is finished: its cell was found (tpo, lbo set) or all cells are built (lbo = box_max[end])
     template <bool SIGNED, bool FDM>
@@ -371,6 +379,14 @@ struct GroupChain {
 #ifdef PDMP_STAMP
         if (lane == 0 && p.stamps) atomicAdd(&p.stamps[7], 1ull);
 #endif
+        if (b_recheck) {                                                                // resumed after a rejection: the cell found last time first
+            b_recheck = false;
+            if (b_next > 0 && !(b_cprev < E)) {                                         // b_cprev = cum_sum including cell b_next - 1
+                found = true;
+                tpo = (double)(b_next - 1) * h + (E - b_cbefore) / (b_cprev - b_cbefore) * h;
+                lbo = b_last;
+            }
+        }
         for (int pass = 0; pass < budget; ++pass) {
             const bool act = !found && b_next < GNG - 1;                                // the lanes of a chain agree
             if (__ballot(act) == 0ull) break;
@@ -426,6 +442,7 @@ struct GroupChain {
                     tpo = t0 + (E - b_cprev) / (cj - b_cprev) * h;                     // :269
                     lbo = bj;                                                          // :270
                 }
+                b_cbefore = b_cprev;
                 b_cprev = cj;
                 b_last = bj;
                 b_next = j + 1;
@@ -926,6 +943,7 @@ struct GroupChain {
         int mode = FRESH;
         double hB = horizon;
         const int budget = (G == WAVE) ? GNG : cell_budget;               // one chain per wave: nobody to wait for
+        const bool resumable = SAMPLER == S_ZIGZAG && p.vectorized && p.n_grid != 0 && !Tgt::kTile;   // bounds built by bound_advance_vect
 #ifdef PDMP_STAMP
         unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
 #define STAMP(k) do { unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[k] += now_ - st_last; st_last = now_; } while (0)
@@ -942,7 +960,7 @@ struct GroupChain {
                     hB = harg;
                     const double e1 = rng.exponential();
                     E = (mode == REUSE) ? E + e1 : e1;                    // cumulative only after a rejection (:190)
-                    bound_begin(tp);
+                    if (mode == REUSE && resumable) bound_resume(tp); else bound_begin(tp);
                     brun = true;
                 }
                 if (bound_advance(hB, E, tp, lb, budget)) {
