@@ -362,3 +362,20 @@ def test_register_and_lds_forms_agree(engine, oracle, monkeypatch, kind, dim, ta
     lds = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=17, diagnostics=True)
     assert_bitwise(reg, ref)
     assert_bitwise(lds, ref)
+
+
+@pytest.mark.parametrize("budget", ["1", "2", "5", "8"])
+@pytest.mark.parametrize("kind,dim,target,kw", [
+    ("ZigZagAD", 50, "iso", {}), ("ZigZagAD", 50, "banana", {}), ("ZigZag", 20, "banana", {}), ("ZigZagAD", 7, "diag", {"signed_bound": False}),
+    ("ZigZagAD", 300, "iso", {}),
+])
+def test_bound_instalments_do_not_change_results(engine, oracle, monkeypatch, budget, kind, dim, target, kw):
+    """The lazily built Zig-Zag bound is advanced `PDMP_CELL_BUDGET` cells per pass of the state machine (default 3) and
+    resumed after rejections; per chain the cells, their order and the sums are the same for every budget."""
+    monkeypatch.setenv("PDMP_CELL_BUDGET", budget)
+    s, cfg = make_pair(engine, oracle, kind, dim, target, **kw)
+    C, n_sk = 37, 50
+    x, v = make_init(kind, dim, C, seed=21, target=target)
+    got = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=5, diagnostics=True)
+    ref = oracle.sample_skeleton(cfg, n_sk, x, v, 5, diagnostics=True)
+    assert_bitwise(got, ref)
