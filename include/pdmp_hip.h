@@ -161,6 +161,14 @@ int pdmp_sample_from_skeleton_dt_device(pdmp_handle h, int64_t C, int64_t n_sk, 
 int pdmp_sample_moments_device(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
                                const double *t, int64_t N, double *sum_x, double *sum_x2, void *stream);
 
+/* The cut of the time-horizon variant sample_skeleton(sampler, T::Float64, xinit, vinit) (src/sample.jl:323-439) on a
+ * fixed-count skeleton held in HBM (DEVICE pointers; the first events of both variants coincide for one seed): count[c] =
+ * number of history columns of chain c -- the events with t <= T (:372) plus one closing column at exactly t = T, written in
+ * place over the overshooting event by flow from the last event before T (:385-420).  count[c] < 0: the chain has not passed
+ * T within n_sk events (-count[c]-1 events so far); rerun with a larger n_sk (Composites.jl:172-191 doubles). */
+int pdmp_close_at_time_device(pdmp_handle h, int64_t C, int64_t n_sk, double *X, double *V, double *t, double T,
+                              int64_t *count, void *stream);
+
 /* Synchronises the handle's last stream and returns PDMP_ERR_ITERCAP if any chain of the launches
  * since the previous check hit the iteration cap (Q11 guard events are counted in *n_guard if non-NULL). */
 int pdmp_check_status(pdmp_handle h, int64_t *n_guard);

@@ -55,7 +55,7 @@ class Timing(C.Structure):
 SYMBOLS = (
     "pdmp_abi_version", "pdmp_last_error", "pdmp_device_count", "pdmp_create", "pdmp_create_from_source", "pdmp_get_config",
     "pdmp_destroy", "pdmp_get_group_lanes", "pdmp_set_tape", "pdmp_clear_tape", "pdmp_sample_skeleton", "pdmp_sample_skeleton_device", "pdmp_sample_from_skeleton",
-    "pdmp_sample_from_skeleton_device", "pdmp_sample_from_skeleton_dt", "pdmp_sample_from_skeleton_dt_device", "pdmp_sample_moments_device", "pdmp_check_status", "pdmp_get_timing", "pdmp_reset_timing",
+    "pdmp_sample_from_skeleton_device", "pdmp_sample_from_skeleton_dt", "pdmp_sample_from_skeleton_dt_device", "pdmp_sample_moments_device", "pdmp_close_at_time_device", "pdmp_check_status", "pdmp_get_timing", "pdmp_reset_timing",
     "pdmp_debug_rng", "pdmp_dense_batched_last_phases",
 )
 
@@ -97,6 +97,7 @@ def lib():
     L.pdmp_sample_from_skeleton_dt.argtypes = [vp, i64, i64, vp, vp, vp, i64, C.c_double, i32, vp]
     L.pdmp_sample_from_skeleton_dt_device.argtypes = [vp, i64, i64, vp, vp, vp, i64, C.c_double, i32, vp, vp]
     L.pdmp_sample_moments_device.argtypes = [vp, i64, i64, vp, vp, vp, i64, vp, vp, vp]
+    L.pdmp_close_at_time_device.argtypes = [vp, i64, i64, vp, vp, vp, C.c_double, vp, vp]
     L.pdmp_check_status.argtypes = [vp, C.POINTER(i64)]
     L.pdmp_get_timing.argtypes = [vp, C.POINTER(Timing)]
     L.pdmp_reset_timing.argtypes = [vp]

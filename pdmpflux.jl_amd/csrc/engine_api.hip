@@ -122,6 +122,41 @@ __global__ __launch_bounds__(256) void from_skeleton_kernel(int d, int64_t C, in
     }
 }
 
+// Closing point of the time-horizon variant sample_skeleton(sampler, T::Float64, ...) (src/sample.jl:323-439), on the device:
+// per chain, count[c] = number of history columns once the chain is cut at T -- the events with t <= T (:372) plus, when the
+// last of them lies strictly before T, one closing column at exactly t = T obtained by flow from it (:385-420), which
+// overwrites the overshooting event in place; count[c] = -(events) - 1 when the chain has not passed T yet (capacity too
+// small: the caller reruns with a larger n_sk, as _grow_history does, Composites.jl:172-191).  One wave per chain.
+template <bool BOOMERANG>
+__global__ __launch_bounds__(256) void close_at_kernel(int d, int64_t C, int64_t n_sk, double *X, double *V, double *t, double T,
+                                                       int64_t *count) {
+    const int lane = lane_id();
+    const int64_t c = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (c >= C) return;
+    double *tc = t + (size_t)c * n_sk;
+    int64_t lo = 0, hi = n_sk - 1;                                    // last index with t[i] <= T (t[0] = 0 <= T)
+    while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if (tc[mid] <= T) lo = mid; else hi = mid - 1;
+    }
+    const int64_t k = lo + 1;                                         // events recorded by the reference loop
+    if (T > 0.0 && lo == n_sk - 1 && tc[lo] <= T) {                   // the chain has not provably passed T within this capacity
+        if (tc[lo] < T) { if (lane == 0) count[c] = -k - 1; return; }
+    }
+    if (T == 0.0 || tc[lo] == T) { if (lane == 0) count[c] = (T == 0.0) ? 1 : k; return; }
+    const double tau = T - tc[lo];
+    const double *x0 = X + ((size_t)c * n_sk + (size_t)lo) * d, *v0 = V + ((size_t)c * n_sk + (size_t)lo) * d;
+    double *x1 = X + ((size_t)c * n_sk + (size_t)k) * d, *v1 = V + ((size_t)c * n_sk + (size_t)k) * d;
+    double sn = 0.0, cs = 1.0;
+    if (BOOMERANG) det_sincos(tau, sn, cs);
+    for (int q = lane; q < d; q += WAVE) {
+        const double xq = x0[q], vq = v0[q];
+        if (BOOMERANG) { x1[q] = xq * cs + vq * sn; v1[q] = (-xq) * sn + vq * cs; }      // BoomerangSamplers.jl:31
+        else { x1[q] = xq + vq * tau; v1[q] = vq; }                                       // ZigZagSamplers.jl:80
+    }
+    if (lane == 0) { tc[k] = T; count[c] = k + 1; }
+}
+
 // Fused sample_from_skeleton + moment sums: per chain the sums of x_j and x_j^2 over the N
 // equispaced samples of sample.jl:475-513, without materialising the d x N x C sample array.  One wave per chain,
 // samples in order, each lane accumulates its coordinates left to right: deterministic (no atomics), equal to
@@ -635,6 +670,25 @@ int pdmp_sample_from_skeleton_dt(pdmp_handle h, int64_t C, int64_t n_sk, const d
     if (rc == PDMP_OK) TRY_OR_CLEAN(hipMemcpy(out, dout, no * 8, hipMemcpyDeviceToHost));
     cleanup();
     return rc;
+}
+
+int pdmp_close_at_time_device(pdmp_handle h, int64_t C, int64_t n_sk, double *X, double *V, double *t, double T,
+                              int64_t *count, void *stream) {
+    if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
+    if (!(T >= 0.0) || !std::isfinite(T)) return fail(PDMP_ERR_ARGUMENT, "T must be finite and non-negative. Current value: %g", T);   // sample.jl:335-337
+    if (n_sk <= 0 || C < 0) return fail(PDMP_ERR_ARGUMENT, "n_sk must be positive and C non-negative");
+    if (C == 0) return PDMP_OK;
+    if (!X || !V || !t || !count) return fail(PDMP_ERR_ARGUMENT, "null buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 block(256), grid((unsigned)((C + 3) / 4));
+    if (h->cfg.sampler == PDMP_BOOMERANG)
+        hipLaunchKernelGGL(close_at_kernel<true>, grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, T, count);
+    else
+        hipLaunchKernelGGL(close_at_kernel<false>, grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, T, count);
+    HIP_TRY(hipGetLastError());
+    h->last_stream = s;
+    return PDMP_OK;
 }
 
 int pdmp_sample_moments_device(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V, const double *t,

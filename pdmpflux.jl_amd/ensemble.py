@@ -109,6 +109,45 @@ def sample_moments_device(sampler: AbstractPDMP, N: int, X: torch.Tensor, V: tor
     return s1, s2
 
 
+def sample_skeleton_until_device(sampler: AbstractPDMP, T: float, xinit: torch.Tensor, vinit: torch.Tensor, *, seed=None,
+                                 chain_id_offset: int = 0, diagnostics: bool = False, init_capacity: int = 1024,
+                                 stream=None) -> dict:
+    """Time-horizon variant ``sample_skeleton(sampler, T::Float64, xinit, vinit)`` (src/sample.jl:323-439) for an ensemble
+    held on the device: the fixed-count kernel runs with a capacity that doubles (``_grow_history``, Composites.jl:172-191)
+    until every chain has passed ``T``; ``pdmp_close_at_time_device`` then writes each chain's closing column at ``t == T``
+    in place (:385-420) and returns the ragged lengths.  Returns the skeleton tensors plus ``count`` ``(C,)`` int64: chain c's
+    history is columns ``[0, count[c])``; columns beyond are the discarded overshoot."""
+    import math
+    T = float(T)
+    if not math.isfinite(T) or T < 0:
+        raise ArgumentError(f"T must be finite and non-negative. Current value: {T}")      # sample.jl:335-337
+    cap = max(2, int(init_capacity))
+    seed = _seed(seed)
+    while True:
+        out = sample_skeleton_device(sampler, cap, xinit, vinit, seed=seed, chain_id_offset=chain_id_offset,
+                                     diagnostics=diagnostics, stream=stream)
+        Cn = xinit.shape[0]
+        count = torch.empty((Cn,), dtype=torch.int64, device=xinit.device)
+        with torch.cuda.device(xinit.device):
+            _lib.check(_lib.lib().pdmp_close_at_time_device(sampler.handle(), Cn, cap, _ptr(out["X"]), _ptr(out["V"]), _ptr(out["t"]),
+                                                            C.c_double(T), C.c_void_p(count.data_ptr()), _stream_ptr(stream)))
+        if bool((count > 0).all()):
+            break
+        cap *= 2                                                                          # newcap = 2 * size, :375-377
+    if diagnostics:                                     # statistics of the closing column are those of a non-event point (:402-408)
+        closed = out["t"].gather(1, (count - 1).unsqueeze(1)).squeeze(1) == T
+        prev_t = out["t"].gather(1, (count - 2).clamp(min=0).unsqueeze(1)).squeeze(1)
+        closed &= (count >= 2) & (prev_t < T)
+        idx = (count - 1)[closed]
+        rows = torch.nonzero(closed).squeeze(1)
+        out["ar"][rows, idx] = 0.0
+        for key in ("errored_bound", "rejected", "hitting_horizon"):
+            out[key][rows, idx] = 0
+        out["error_value_ar"][rows, idx] = 0.0
+    out["count"] = count
+    return out
+
+
 def kernel_timing(sampler: AbstractPDMP, reset: bool = False) -> dict:
     """hipEvent-timed kernel durations of this sampler's handle (pdmp_get_timing)."""
     tm = _lib.Timing()
