@@ -743,7 +743,9 @@ struct GroupChain {
     }
 
     // ---- velocity_jump: ZigZagSamplers.jl:101-107, BouncyParticleSamplers.jl:50-74, BoomerangSamplers.jl:49-67
-    __device__ __forceinline__ void velocity_jump(double raw) {
+    // returns true when the chain asks for a velocity refresh: the normals are drawn by refresh_velocities(), outside the
+    // divergent accept branch, with all 64 lanes of the wave
+    __device__ __forceinline__ bool velocity_jump(double raw) {
         TimePt t0;
         t0.t = 0.0; t0.s = 0.0; t0.c = 1.0;
         typename Tgt::template Sh<double> sh;
@@ -759,7 +761,7 @@ struct GroupChain {
         if constexpr (SAMPLER == S_ZIGZAG) {
             const double S = raw;                                        // sum(max.(0, grad-U .* v)), ZigZagSamplers.jl:102-103
             const double u = rng.uniform();                              // Categorical draw
-            if (!(S > 0.0)) { guard++; return; }                         // Q11
+            if (!(S > 0.0)) { guard++; return false; }                         // Q11
             // Categorical(lambda / S) (ZigZagSamplers.jl:102-104): the reference walks cp += lambda_i / S until
             // cp > u; the engine walks the un-normalised cumulative rate against theta = u * S (same index up
             // to rounding at a cell boundary, no fp64 division per coordinate) -- GROUP order of the checker.
@@ -794,7 +796,7 @@ struct GroupChain {
             const int ms = m / G;
             if constexpr (kReg) { PDMP_SLOTS(s) if (s == ms && g == m - ms * G) V(s) = -V(s); }
             else if (g == m - ms * G) V(ms) = -V(ms);                    // v[m] *= -1
-            return;
+            return false;
         } else {
             double acc = 0.0;
             double gv;
@@ -821,7 +823,7 @@ struct GroupChain {
                 }
                 const double gg = group_sum(acc, G);
                 if constexpr (SAMPLER == S_BPS) {
-                    if (gg == 0.0) return;
+                    if (gg == 0.0) return false;
                     const double scale = 2.0 * gv / gg;                  // :60
                     PDMP_SLOTS(s) {
                         const int i = s * G + g;
@@ -844,28 +846,48 @@ struct GroupChain {
                     }
                 }
             } else {
-                // randn!, :67 / randn(dim), :65: the G lanes of the chain share the Box-Muller pairs -- lane g draws pairs
-                // g, g+G, ... (one Philox block, log, sqrt, sincos per PAIR) and writes both normals into the chain's v tile
-                const int logG = __builtin_ctz(G);
-                for (int P = g; 2 * P < d; P += G) {
-                    double z0, z1;
-                    rng.normal_pair(P, z0, z1);
-                    const int i0 = 2 * P, i1 = 2 * P + 1;
-                    vs[(i0 >> logG) * WAVE + base + (i0 & (G - 1))] = z0;
-                    if (i1 < d) vs[(i1 >> logG) * WAVE + base + (i1 & (G - 1))] = z1;
-                }
-                rng.normals_done(d);
-                if constexpr (kReg) { PDMP_SLOTS(s) vr[s] = in_dim(s, s * G + g) ? vs[s * WAVE + lane] : 0.0; }   // register form: vs is an exchange tile only
-                acc = 0.0;
-                PDMP_SLOTS(s) {
-                    const int i = s * G + g;
-                    const double z = V(s);
-                    acc += (in_dim(s, i)) ? z * z : 0.0;
-                }
-                if (SAMPLER == S_BPS && !p.gaussian_velocity) {          // normalize!, :71
-                    const double inv = 1.0 / __dsqrt_rn(group_sum(acc, G));
-                    PDMP_SLOTS(s) V(s) = V(s) * inv;
-                }
+                return true;                                               // randn!, :67 / randn(dim), :65 -> refresh_velocities
+            }
+        }
+        return false;
+    }
+
+    // Velocity refresh of the chains whose lanes pass `mine` (BouncyParticleSamplers.jl:65-71, BoomerangSamplers.jl:61-65).
+    // Called by the whole wave: for each refreshing chain the Box-Muller pairs (one Philox block, log, sqrt, sincos per
+    // PAIR; pair P = normals 2P, 2P+1 of the chain's stream) are spread over all 64 lanes -- one pass for d <= 128 --
+    // instead of ceil(d / 2G) passes on the chain's own G lanes while the rest of the wave idles.  Same stream positions,
+    // same arithmetic: the normals are those of the chain-local loop.
+    __device__ __forceinline__ void refresh_velocities(bool mine) {
+        const int d = p.d, logG = __builtin_ctz(G);
+        unsigned long long todo = __ballot(mine && g == 0);
+        while (todo != 0ull) {
+            const int L = (int)__builtin_ctzll(todo);                     // first lane of the chain
+            todo &= todo - 1ull;
+            ChainRng r = rng;                                             // seed words are the same in every lane
+            r.c2 = (uint32_t)__builtin_amdgcn_readlane((int)rng.c2, L);
+            r.c3 = (uint32_t)__builtin_amdgcn_readlane((int)rng.c3, L);
+            r.n = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rng.n >> 32), L) << 32) |
+                  (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rng.n, L);
+            for (int P = lane; 2 * P < d; P += WAVE) {
+                double z0, z1;
+                r.normal_pair(P, z0, z1);
+                const int i0 = 2 * P, i1 = 2 * P + 1;
+                vs[(i0 >> logG) * WAVE + L + (i0 & (G - 1))] = z0;
+                if (i1 < d) vs[(i1 >> logG) * WAVE + L + (i1 & (G - 1))] = z1;
+            }
+        }
+        if (mine) {
+            rng.normals_done(d);
+            if constexpr (kReg) { PDMP_SLOTS(s) vr[s] = in_dim(s, s * G + g) ? vs[s * WAVE + lane] : 0.0; }   // register form: vs is an exchange tile only
+            double acc = 0.0;
+            PDMP_SLOTS(s) {
+                const int i = s * G + g;
+                const double z = V(s);
+                acc += (in_dim(s, i)) ? z * z : 0.0;
+            }
+            if (SAMPLER == S_BPS && !p.gaussian_velocity) {              // normalize!, :71
+                const double inv = 1.0 / __dsqrt_rn(group_sum(acc, G));
+                PDMP_SLOTS(s) V(s) = V(s) * inv;
             }
         }
     }
@@ -995,6 +1017,7 @@ struct GroupChain {
                 }
             }
             STAMP(0);
+            bool accepted = false, refresh = false, proposed = false;
             if (!done && propose) {
                 double raw;
                 const double lam = true_rate(tp, raw);                    // ac_step!, :113-129
@@ -1008,24 +1031,31 @@ struct GroupChain {
                     if (u < ar) {                                         // if_accept!, :170-186
                         flow_state(tp);
                         STAMP(2);
-                        velocity_jump(raw);
-                        STAMP(3);
-                        t = t + tp + ts;
-                        ts = 0.0;
-                        tp = 0.0;
-                        record(c, k, t, horizon, ar, errored, ev, rejected, hits);
-                        STAMP(4);
-                        errored = 0; rejected = 0; hits = 0;              // get_event_state!, :28-31
-#pragma unroll
-                        for (int q = 0; q < 5; ++q) ev[q] = 0.0;
-                        it = 0;
-                        if (++k >= kend) done = true;
+                        refresh = velocity_jump(raw);
+                        accepted = true;
                     } else {
                         mode = REUSE;                                     // if_reject! continues in the BOUND phase
                     }
                 }
-                if (++it > cap && !done) { done = true; if (g == 0) atomicAdd(&p.status[0], 1); }
+                proposed = true;
             }
+            if constexpr (SAMPLER != S_ZIGZAG) {                          // the whole wave draws the normals of its refreshing chains
+                if (__ballot(refresh) != 0ull) refresh_velocities(refresh);
+            }
+            STAMP(3);
+            if (accepted) {
+                t = t + tp + ts;
+                ts = 0.0;
+                tp = 0.0;
+                record(c, k, t, horizon, ar, errored, ev, rejected, hits);
+                errored = 0; rejected = 0; hits = 0;                      // get_event_state!, :28-31
+#pragma unroll
+                for (int q = 0; q < 5; ++q) ev[q] = 0.0;
+                it = 0;
+                if (++k >= kend) done = true;
+            }
+            STAMP(4);
+            if (proposed && ++it > cap && !done) { done = true; if (g == 0) atomicAdd(&p.status[0], 1); }
         }
 #ifdef PDMP_STAMP
         if (lane == 0 && p.stamps) for (int q = 0; q < 6; ++q) atomicAdd(&p.stamps[q], st_acc[q]);
