@@ -768,13 +768,13 @@ struct GroupChain {
             const double theta = u * S;
             // Level 1: slot totals T_s (the butterfly value equals the last lane of the Kogge-Stone scan bit
             // for bit), first slot whose running total exceeds theta.  Level 2: one scan inside that slot.
-            double carry = 0.0, carry_at = 0.0;
+            double carry = 0.0, carry_at = 0.0, lam_hit = 0.0;           // lam_hit: this lane's rate in the slot that was hit
             int ms_hit = -1;
             PDMP_SLOTS(s) {
                 const int i = s * G + g;
                 const double lam = (in_dim(s, i)) ? fmax(0.0, tgt.grad(i, X(s), sh) * V(s)) : 0.0;
                 const double T = group_sum(lam, G);
-                if (ms_hit < 0 && (carry + T > theta)) { ms_hit = s; carry_at = carry; }
+                if (ms_hit < 0 && (carry + T > theta)) { ms_hit = s; carry_at = carry; lam_hit = lam; }
                 carry = carry + T;
                 if (__ballot(ms_hit < 0) == 0ull) break;
             }
@@ -783,10 +783,7 @@ struct GroupChain {
                 const int sq = (ms_hit < 0) ? 0 : ms_hit;
                 const int i = sq * G + g;
                 const bool valid = (ms_hit >= 0) && in_dim(sq, i);
-                double xq, vq;
-                if constexpr (kReg) { xq = 0.0; vq = 0.0; PDMP_SLOTS(s) if (s == sq) { xq = X(s); vq = V(s); } }
-                else { xq = X(sq); vq = V(sq); }
-                const double lam = valid ? fmax(0.0, tgt.grad(i, xq, sh) * vq) : 0.0;
+                const double lam = lam_hit;                              // 0 where the coordinate is padding or no slot was hit
                 const double inc = group_scan_incl(lam, g, G);
                 const unsigned long long ball = __ballot(valid && (carry_at + inc > theta));
                 const unsigned long long grp = (G == WAVE) ? ball : ((ball >> base) & ((1ull << G) - 1ull));
