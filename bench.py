@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--chains", type=int, default=100_000, help="chains per GPU")
     ap.add_argument("--n-sk", type=int, default=1000)
     ap.add_argument("--dim", type=int, default=50)
-    ap.add_argument("--sampler", default="ZigZagAD", choices=["ZigZagAD", "ZigZag", "BPS", "BPSAD", "Boomerang", "BoomerangAD"])
+    ap.add_argument("--sampler", default="ZigZagAD", choices=["ZigZagAD", "ZigZag", "BPS", "BPSAD", "Boomerang", "BoomerangAD", "ForwardECMC", "ForwardECMCAD"])
     ap.add_argument("--target", default="iso", choices=["iso", "banana", "dense", "src_banana"],
                     help="src_banana: U_banana given as source, differentiated by forward mode on the GPU (pdmp_create_from_source)")
     ap.add_argument("--seed", type=int, default=2024)
@@ -71,7 +71,7 @@ def make_inputs(torch, a, dev, rank):
         v = torch.randint(0, 2, (a.chains, a.dim), device=dev, generator=g).to(torch.float64) * 2 - 1
     else:
         v = torch.randn((a.chains, a.dim), dtype=torch.float64, device=dev, generator=g)
-        if a.sampler.startswith("BPS"):
+        if a.sampler.startswith(("BPS", "ForwardECMC")):
             v = v / v.norm(dim=1, keepdim=True)
     return x.contiguous(), v.contiguous()
 

@@ -14,6 +14,7 @@ struct Config
     adaptive::Cint; gaussian_velocity::Cint; deriv_mode::Cint; target_id::Cint; device::Cint
     tmax::Cdouble; refresh_rate::Cdouble
     target_params::Ptr{Cdouble}; n_target_params::Int64; max_iter_per_event::Int64
+    fe_mix_p::Cdouble; fe_ran_p::Cint; fe_switch::Cint; fe_positive::Cint; fe_reserved::Cint   # ForwardECMC keywords (ABI 3)
 end
 struct Diag   # pdmp_diag_t
     horizon::Ptr{Cdouble}; ar::Ptr{Cdouble}; errored_bound::Ptr{Int32}
@@ -64,9 +65,21 @@ function ZigZagAD(dim::Int, target::Target; refresh_rate=0.0, grid_size=10, tmax
                   signed_bound=true, adaptive=true, AD_backend="ForwardDiff", device=-1)
     p = params(target)
     cfg = Config(0, dim, grid_size, vectorized_bound, signed_bound, adaptive, 0, AD_backend == "FiniteDiff" ? 1 : 0,
-                 target_id(target), device, Float64(tmax), refresh_rate, pointer(p), length(p), 0)
+                 target_id(target), device, Float64(tmax), refresh_rate, pointer(p), length(p), 0, 0.5, 0, 1, 1, 0)
     handle = GC.@preserve p create(cfg, target)
     s = HIPSampler(handle, dim, 0)
+    finalizer(x -> ccall((:pdmp_destroy, LIB), Cint, (Ptr{Cvoid},), x.handle), s)
+    return s
+end
+
+# ForwardECMC(dim, target; ran_p, mix_p, switch, positive, ...) with the defaults of ForwardEventChainMonteCarlo.jl:290-292
+function ForwardECMC(dim::Int, target::Target; grid_size=10, tmax=2.0, signed_bound=true, adaptive=true, ran_p=false,
+                     mix_p=0.5, switch=true, positive=true, AD_backend="ForwardDiff", device=-1)
+    p = params(target)
+    cfg = Config(3, dim, grid_size, 0, signed_bound, adaptive, 0, AD_backend == "FiniteDiff" ? 1 : 0,
+                 target_id(target), device, Float64(tmax), 0.0, pointer(p), length(p), 0, mix_p, ran_p, switch, positive, 0)
+    handle = GC.@preserve p create(cfg, target)
+    s = HIPSampler(handle, dim, 3)
     finalizer(x -> ccall((:pdmp_destroy, LIB), Cint, (Ptr{Cvoid},), x.handle), s)
     return s
 end

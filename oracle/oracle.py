@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libpdmp_oracle.so")
 
-ZIGZAG, BPS, BOOMERANG = 0, 1, 2
+ZIGZAG, BPS, BOOMERANG, FECMC = 0, 1, 2, 3
 T_GAUSS_ISO, T_GAUSS_DIAG, T_BANANA, T_GAUSS_DENSE = 0, 1, 2, 3
 T_AD_BANANA, T_AD_FUNNEL, T_AD_RIDGED = 16, 17, 18      # grad-U by forward mode over U (ad_potentials.c)
 DERIV_FORWARD, DERIV_FINITE_DIFF = 0, 1
@@ -33,6 +33,7 @@ class _Cfg(C.Structure):
         ("max_iter_per_event", C.c_int64), ("group_lanes", C.c_int32),
         ("tape_exp", C.POINTER(C.c_double)), ("tape_uni", C.POINTER(C.c_double)), ("tape_nrm", C.POINTER(C.c_double)),
         ("tape_n_exp", C.c_int64), ("tape_n_uni", C.c_int64), ("tape_n_nrm", C.c_int64),
+        ("fe_mix_p", C.c_double), ("fe_ran_p", C.c_int32), ("fe_switch", C.c_int32), ("fe_positive", C.c_int32),
     ]
 
 
@@ -110,6 +111,10 @@ class Config:
     max_iter_per_event: int = 0
     group_lanes: int = 1
     tape: tuple | None = None          # (exp, uni, nrm) arrays of shape (C, n_kind): replay instead of Philox
+    mix_p: float = 0.5                 # ForwardECMC keywords (ForwardEventChainMonteCarlo.jl:290-292)
+    ran_p: bool = False
+    switch: bool = True
+    positive: bool = True
     _keep: list = field(default_factory=list, repr=False)
 
     def c(self) -> _Cfg:
@@ -128,7 +133,7 @@ class Config:
         return _Cfg(self.sampler, self.dim, self.grid_size, int(self.vectorized_bound), int(self.signed_bound),
                     int(self.adaptive), int(self.gaussian_velocity), self.deriv_mode, self.target_id, self.arith,
                     float(self.tmax), float(self.refresh_rate), p, n, self.max_iter_per_event, self.group_lanes,
-                    te, tu, tn, ne, nu, nn)
+                    te, tu, tn, ne, nu, nn, float(self.mix_p), int(self.ran_p), int(self.switch), int(self.positive))
 
 
 def _check(rc):

@@ -112,6 +112,50 @@ double orc_log(double x) {
     return (k == 0) ? f - s * (f - R) : dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
 }
 
+/* exp(x): the fdlibm e_exp.c algorithm (Sun Microsystems, freely distributable) with +,-,*,/ and integer operations on the
+ * exponent field only, so that CPU and GPU agree bit for bit.  Overflow -> +Inf, underflow below -745.13 -> 0. */
+double orc_exp(double x) {
+    static const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+        invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+        P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (x != x) return x;
+    if (x > 7.09782712893383973096e+02) return INFINITY;
+    if (x < -7.45133219101941108420e+02) return 0.0;
+    uint64_t ix; memcpy(&ix, &x, 8);
+    const uint32_t hx = (uint32_t)(ix >> 32) & 0x7fffffffu;
+    const int xsb = (int)(ix >> 63);
+    double hi = 0.0, lo = 0.0;
+    int32_t k = 0;
+    if (hx > 0x3fd62e42u) {                         /* |x| > 0.5 ln2 */
+        if (hx < 0x3FF0A2B2u) {                     /* and |x| < 1.5 ln2 */
+            hi = xsb ? x + ln2HI : x - ln2HI;
+            lo = xsb ? -ln2LO : ln2LO;
+            k = 1 - xsb - xsb;
+        } else {
+            k = (int32_t)(invln2 * x + (xsb ? -0.5 : 0.5));
+            const double t = (double)k;
+            hi = x - t * ln2HI;
+            lo = t * ln2LO;
+        }
+        x = hi - lo;
+    } else if (hx < 0x3e300000u) {                  /* |x| < 2^-28 */
+        return 1.0 + x;
+    }
+    const double t = x * x;
+    const double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
+    double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+    uint64_t iy; memcpy(&iy, &y, 8);
+    if (k >= -1021) {
+        iy += (uint64_t)(int64_t)k << 52;           /* add k to y's exponent */
+        memcpy(&y, &iy, 8);
+        return y;
+    }
+    iy += (uint64_t)(int64_t)(k + 1000) << 52;
+    memcpy(&y, &iy, 8);
+    return y * 9.33263618503218878990e-302;         /* 2^-1000 */
+}
+
 /* fdlibm k_sin.c / k_cos.c polynomial kernels on |a| <= pi/4 (no tail term). */
 static inline double ksin(double a) {
     static const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
@@ -337,6 +381,7 @@ typedef struct {
     double *fa, *fb;                       /* finite-difference scratch, d */
     double *grid, *box, *cum;              /* BoundBox (Composites.jl:15-20) */
     double *cell;                          /* d */
+    double *fe_vo, *fe_e1, *fe_e2, *fe_z, *fe_g;   /* ForwardECMC velocity jump: d, d, d, d, 2d */
     double step;
 } ws_t;
 
@@ -345,9 +390,9 @@ static int ws_init(ws_t *w, int d, int n) {
     w->d = d; w->n = n;
     size_t D = (size_t)d, N = (size_t)n;
     double **ptrs[] = { &w->x, &w->v, &w->xv, &w->xe, &w->vv, &w->ve, &w->gv, &w->ge, &w->tmp, &w->tmp2,
-                        &w->fa, &w->fb, &w->cell };
+                        &w->fa, &w->fb, &w->cell, &w->fe_vo, &w->fe_e1, &w->fe_e2, &w->fe_z };
     for (size_t i = 0; i < sizeof ptrs / sizeof *ptrs; ++i) if (!(*ptrs[i] = malloc(D * 8))) return -1;
-    if (!(w->vals = malloc(D * N * 8)) || !(w->slps = malloc(D * N * 8))) return -1;
+    if (!(w->vals = malloc(D * N * 8)) || !(w->slps = malloc(D * N * 8)) || !(w->fe_g = malloc(2 * D * 8))) return -1;
     if (!(w->grid = malloc(N * 8)) || !(w->box = malloc(N * 8)) || !(w->cum = malloc(N * 8))) return -1;
     return 0;
 }
@@ -355,6 +400,7 @@ static void ws_free(ws_t *w) {
     free(w->x); free(w->v); free(w->xv); free(w->xe); free(w->vv); free(w->ve); free(w->gv); free(w->ge);
     free(w->tmp); free(w->tmp2); free(w->fa); free(w->fb); free(w->cell);
     free(w->vals); free(w->slps); free(w->grid); free(w->box); free(w->cum);
+    free(w->fe_vo); free(w->fe_e1); free(w->fe_e2); free(w->fe_z); free(w->fe_g);
 }
 
 /* flow with a dual time (t, 1): ZigZagSamplers.jl:80, BouncyParticleSamplers.jl:32 (x + v t, v);
@@ -623,6 +669,78 @@ static void flow_state(const orc_config_t *cfg, ws_t *w, double t) {
     }
 }
 
+/* dot product / norm in the configured summation order (LinearAlgebra's dot and norm are BLAS calls of unspecified order) */
+static double vdot(const orc_config_t *cfg, ws_t *w, const double *a, const double *b) {
+    for (int i = 0; i < w->d; ++i) w->tmp[i] = a[i] * b[i];
+    return vsum(cfg, w->tmp, w->d);
+}
+static double vnorm(const orc_config_t *cfg, ws_t *w, const double *a) { return sqrt(vdot(cfg, w, a, a)); }
+
+/* _velocity_jump_event_chain, ForwardEventChainMonteCarlo.jl:127-175 (the default variant: normal = false, speed_factor = 1),
+ * with _orthogonal_switch (:60-91) / _full_refresh (:108-117).  grad-U(x) is in w->gv on entry.  u^(2/(dim-1)) is restated as
+ * exp(log(u) * (2/(dim-1))) with the checker's log / exp; randn(key, 2, dim) is column-major: g1[j], g2[j] = normals 2j, 2j+1. */
+static int fecmc_jump(const orc_config_t *cfg, ws_t *w, rng_t *rng) {
+    const int d = w->d;
+    double *n = w->gv, *vo = w->fe_vo, *e1 = w->fe_e1, *e2 = w->fe_e2, *z = w->fe_z;
+    const double u = rng_uniform(rng);                                       /* :134 */
+    const double pw = orc_exp(orc_log(u) * (2.0 / (double)(d - 1)));
+    const double rho = -sqrt(1.0 - pw);                                      /* :135 */
+    const double ng = vnorm(cfg, w, n);                                      /* :143-149 */
+    if (ng == 0.0) { for (int i = 0; i < d; ++i) n[i] = 0.0; }
+    else for (int i = 0; i < d; ++i) n[i] = n[i] / ng;
+    const double vn = vdot(cfg, w, w->v, n);                                 /* :152-153 */
+    for (int i = 0; i < d; ++i) { double vp = vn * n[i]; vo[i] = w->v[i] - vp; }
+    if (vnorm(cfg, w, vo) < 1e-10) {                                         /* :156-159 */
+        rng_normals(rng, d, vo);
+        const double dn = vdot(cfg, w, vo, n);
+        for (int i = 0; i < d; ++i) vo[i] = vo[i] - dn * n[i];
+    }
+    const double u2 = rng_uniform(rng);                                      /* :161 */
+    const double sq = sqrt(1.0 - rho * rho);
+    if (u2 >= cfg->fe_mix_p) {                                               /* :162-166 */
+        const double nv = vnorm(cfg, w, vo);
+        for (int i = 0; i < d; ++i) w->v[i] = vo[i] / nv * sq + rho * n[i];
+        return 0;
+    }
+    double *prop = w->fe_z;
+    if (cfg->fe_switch) {                                                    /* _orthogonal_switch, :60-91 */
+        rng_normals(rng, 2 * d, w->fe_g);
+        for (int i = 0; i < d; ++i) { e1[i] = w->fe_g[2 * i]; e2[i] = w->fe_g[2 * i + 1]; }
+        const double d1 = vdot(cfg, w, e1, n);
+        for (int i = 0; i < d; ++i) e1[i] = e1[i] - d1 * n[i];               /* :67 */
+        const double d2 = vdot(cfg, w, e2, n);
+        for (int i = 0; i < d; ++i) e2[i] = e2[i] - d2 * n[i];               /* :68 */
+        const double n1 = vnorm(cfg, w, e1);
+        for (int i = 0; i < d; ++i) e1[i] = e1[i] / n1;                      /* :71 */
+        const double d21 = vdot(cfg, w, e2, e1);
+        for (int i = 0; i < d; ++i) e2[i] = e2[i] - d21 * e1[i];             /* :72 */
+        const double n2 = vnorm(cfg, w, e2);
+        for (int i = 0; i < d; ++i) e2[i] = e2[i] / n2;                      /* :73 */
+        const double a = vdot(cfg, w, vo, e1), b = vdot(cfg, w, vo, e2);
+        double sn = 0.0, cs = 0.0;
+        if (cfg->fe_ran_p) { const double ut = rng_uniform(rng); orc_sincos_2pi(ut, &sn, &cs); }   /* theta = rand * 2pi, :79 */
+        for (int i = 0; i < d; ++i) {
+            const double vr = (vo[i] - a * e1[i]) - b * e2[i];               /* :76 */
+            if (cfg->fe_ran_p) z[i] = (vr + (cs * e1[i] + sn * e2[i]) * a) + (sn * e1[i] - cs * e2[i]) * b;   /* :80 */
+            else z[i] = (vr + e2[i] * a) + e1[i] * b;                        /* :77 */
+        }
+        if (cfg->fe_positive) {                                              /* :83-85 */
+            const double sdot = vdot(cfg, w, vo, z);
+            const double sg = (sdot > 0.0) ? 1.0 : ((sdot < 0.0) ? -1.0 : sdot);
+            for (int i = 0; i < d; ++i) z[i] = z[i] * sg;
+        }
+    } else {                                                                 /* _full_refresh, :108-117 */
+        rng_normals(rng, d, z);
+        const double nz = vnorm(cfg, w, z);
+        for (int i = 0; i < d; ++i) z[i] = z[i] / nz;
+        const double dn = vdot(cfg, w, z, n);
+        for (int i = 0; i < d; ++i) z[i] = z[i] - dn * n[i];
+    }
+    const double np = vnorm(cfg, w, prop);                                   /* :170-172 */
+    for (int i = 0; i < d; ++i) w->v[i] = prop[i] / np * sq + rho * n[i];
+    return 0;
+}
+
 /* velocity_jump: ZigZagSamplers.jl:101-107, BouncyParticleSamplers.jl:50-74, BoomerangSamplers.jl:49-67 */
 static int velocity_jump(const orc_config_t *cfg, ws_t *w, rng_t *rng) {
     const int d = w->d;
@@ -640,6 +758,7 @@ static int velocity_jump(const orc_config_t *cfg, ws_t *w, rng_t *rng) {
         w->v[m] = -w->v[m];                                   /* v[m] *= -1 */
         return 0;
     }
+    if (cfg->sampler == ORC_FECMC) return fecmc_jump(cfg, w, rng);
     double *g = w->gv;
     if (cfg->sampler == ORC_BOOMERANG) for (int i = 0; i < d; ++i) g[i] = g[i] - w->x[i];   /* :51-52 (Q8) */
     for (int i = 0; i < d; ++i) w->tmp[i] = g[i] * w->v[i];
@@ -675,7 +794,12 @@ int orc_normalize_config(orc_config_t *c) {
     if (c->dim <= 0) FAIL(-1, "dimension dim must be positive. Current value: %d", c->dim);           /* ZigZagSamplers.jl:62-64 */
     if (c->grid_size < 0) FAIL(-1, "grid_size must be non-negative. Current value: %d", c->grid_size); /* :66-68 */
     if (c->grid_size == 1) FAIL(-1, "grid_size == 1: range(...)[2] is a BoundsError in the reference");
-    if (c->sampler < 0 || c->sampler > 2) FAIL(-1, "unknown sampler id %d", c->sampler);
+    if (c->sampler < 0 || c->sampler > 3) FAIL(-1, "unknown sampler id %d", c->sampler);
+    if (c->sampler == ORC_FECMC) {                                                                    /* ForwardEventChainMonteCarlo.jl:298-310 */
+        if (c->dim < 2) FAIL(-1, "The dimension must be at least 2 to use the ForwardEventChain. Got dimension %d", c->dim);
+        if (c->dim == 2) c->fe_mix_p = 0.0;
+        c->refresh_rate = 0.0;
+    }
     if (c->target_id < 0 || (c->target_id > 3 && (c->target_id < ORC_T_AD_BANANA || c->target_id > ORC_T_AD_RIDGED))) FAIL(-1, "unknown target id %d", c->target_id);
     if (c->tmax == 0.0) { c->tmax = 1.0; c->adaptive = 1; }                                           /* :73 */
     if (c->sampler == ORC_ZIGZAG) {

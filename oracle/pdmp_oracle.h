@@ -19,7 +19,8 @@ extern "C" {
 #endif
 
 /* sampler ids -- src/Samplers/{ZigZag,BouncyParticle,Boomerang}Samplers.jl */
-enum { ORC_ZIGZAG = 0, ORC_BPS = 1, ORC_BOOMERANG = 2 };
+enum { ORC_ZIGZAG = 0, ORC_BPS = 1, ORC_BOOMERANG = 2,
+       ORC_FECMC = 3 /* ForwardECMC, src/Samplers/ForwardEventChainMonteCarlo.jl (default velocity jump, :127-175) */ };
 /* built-in potentials (closures cannot cross a C ABI) */
 enum { ORC_T_GAUSS_ISO = 0, ORC_T_GAUSS_DIAG = 1, ORC_T_BANANA = 2, ORC_T_GAUSS_DENSE = 3,
        /* grad-U by forward-mode differentiation of a scalar potential (ADBackend.jl:95-109), ad_potentials.c:
@@ -58,6 +59,9 @@ typedef struct orc_config_t {
     /* tape source (all three or none): per chain tape_n_* variates, chain-major (chain c at c*tape_n_*) */
     const double *tape_exp, *tape_uni, *tape_nrm;
     int64_t tape_n_exp, tape_n_uni, tape_n_nrm;
+    /* ForwardECMC keywords (ForwardEventChainMonteCarlo.jl:290-292): mix_p = 0.5, ran_p = false, switch = true, positive = true */
+    double  fe_mix_p;
+    int32_t fe_ran_p, fe_switch, fe_positive;
 } orc_config_t;
 
 const char *orc_last_error(void);
@@ -89,6 +93,7 @@ int orc_sample_from_skeleton_dt(const orc_config_t *cfg, int64_t C, int64_t n_sk
 /* --- pieces exposed for known-answer tests --- */
 void   orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 double orc_log(double x);
+double orc_exp(double x);
 void   orc_sincos(double x, double *s, double *c);
 void   orc_sincos_2pi(double u, double *s, double *c);
 /* first n_draw variates of chain stream (seed, chain): kind 0 uniform, 1 exp, 2 normal-vector (d=n_draw) */

@@ -232,7 +232,14 @@ int normalize_config(pdmp_config_t &c, bool from_source = false) {
     if (c.dim <= 0) return fail(PDMP_ERR_ARGUMENT, "dimension dim must be positive. Current value: %d", c.dim);          // ZigZagSamplers.jl:62-64
     if (c.grid_size < 0) return fail(PDMP_ERR_ARGUMENT, "grid_size must be non-negative. Current value: %d", c.grid_size); // :66-68
     if (c.grid_size == 1 || c.grid_size > WAVE) return fail(PDMP_ERR_UNSUPPORTED, "grid_size must be in 2..64. Current value: %d", c.grid_size);
-    if (c.sampler < PDMP_ZIGZAG || c.sampler > PDMP_BOOMERANG) return fail(PDMP_ERR_ARGUMENT, "unknown sampler id %d", c.sampler);
+    if (c.sampler < PDMP_ZIGZAG || c.sampler > PDMP_FECMC) return fail(PDMP_ERR_ARGUMENT, "unknown sampler id %d", c.sampler);
+    if (c.sampler == PDMP_FECMC) {                                                                   // ForwardEventChainMonteCarlo.jl:298-310
+        if (c.dim < 2) return fail(PDMP_ERR_ARGUMENT, "The dimension must be at least 2 to use the ForwardEventChain. Got dimension %d", c.dim);
+        if (c.dim == 2) c.fe_mix_p = 0.0;
+        c.refresh_rate = 0.0;
+        if (c.target_id == PDMP_T_GAUSS_DENSE) return fail(PDMP_ERR_UNSUPPORTED, "ForwardECMC: no dense-precision target");
+        if (c.grid_size != GNG && c.grid_size != 0) return fail(PDMP_ERR_UNSUPPORTED, "ForwardECMC runs on the group kernel: grid_size = 10 (or 0, Brent)");
+    }
     if (c.target_id == PDMP_T_USER && !from_source) return fail(PDMP_ERR_ARGUMENT, "PDMP_T_USER handles are made by pdmp_create_from_source");
     if (c.target_id < 0 || c.target_id > PDMP_T_USER) return fail(PDMP_ERR_ARGUMENT, "unknown target id %d", c.target_id);
     if (c.target_id == PDMP_T_USER && c.grid_size != GNG && c.grid_size != 0)
@@ -271,10 +278,11 @@ launch_fn pick_launcher(int sampler, int target) {
 
 typedef hipError_t (*glaunch_fn)(const GroupParams &, hipStream_t);
 glaunch_fn pick_group_launcher(int sampler, int target) {
-    static const glaunch_fn table[3][4] = {
+    static const glaunch_fn table[4][4] = {
         {launch_group<S_ZIGZAG, T_GAUSS_ISO>, launch_group<S_ZIGZAG, T_GAUSS_DIAG>, launch_group<S_ZIGZAG, T_BANANA>, launch_group<S_ZIGZAG, T_GAUSS_DENSE>},
         {launch_group<S_BPS, T_GAUSS_ISO>, launch_group<S_BPS, T_GAUSS_DIAG>, launch_group<S_BPS, T_BANANA>, launch_group<S_BPS, T_GAUSS_DENSE>},
         {launch_group<S_BOOMERANG, T_GAUSS_ISO>, launch_group<S_BOOMERANG, T_GAUSS_DIAG>, launch_group<S_BOOMERANG, T_BANANA>, nullptr},
+        {launch_group<S_FECMC, T_GAUSS_ISO>, launch_group<S_FECMC, T_GAUSS_DIAG>, launch_group<S_FECMC, T_BANANA>, nullptr},
     };
     return table[sampler][target];
 }
@@ -292,6 +300,11 @@ int choose_group_lanes(const pdmp_config_t &c) {
     }
     for (int G = 1; G <= 16; G <<= 1)      // register form (inst_reg_*.hip): at most KREG slots per lane, G <= 16
         if ((c.dim + G - 1) / G <= KREG) return G;
+    if (c.sampler == PDMP_FECMC) {         // six tiles per wave (x, v, n, v_orth, e1, e2): keep one wave's tiles within 40 KB
+        for (int G = 32; G <= WAVE; G <<= 1)
+            if (6 * (size_t)((c.dim + G - 1) / G) * WAVE * sizeof(double) <= 40 * 1024) return G;
+        return 0;
+    }
     const size_t budget = 20 * 1024;      // two blocks (8 waves) per CU
     for (int G = 1; G <= WAVE; G <<= 1) {
         const size_t K = (size_t)(c.dim + G - 1) / G;
@@ -353,6 +366,8 @@ static int create_impl(const pdmp_config_t *cfg, const char *source, int32_t kin
     HIP_TRY(hipSetDevice(dev));
     if (choose_group_lanes(c) == 0 && c.grid_size == 0)
         return fail(PDMP_ERR_UNSUPPORTED, "grid_size == 0 (Brent constant bound) is served by the group kernel only");
+    if (choose_group_lanes(c) == 0 && c.sampler == PDMP_FECMC)
+        return fail(PDMP_ERR_UNSUPPORTED, "ForwardECMC: dim too large for the LDS tiles of the group kernel");
     if (choose_group_lanes(c) == 0 && c.dim > 4 * WAVE)
         return fail(PDMP_ERR_UNSUPPORTED, "dim > %d needs grid_size = 10 (group kernel); the wave-per-chain kernel holds at most 4 coordinates per lane", 4 * WAVE);
     pdmp_engine *h = new pdmp_engine();
@@ -455,6 +470,7 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
     p.gaussian_velocity = c.gaussian_velocity; p.deriv_mode = c.deriv_mode; p.vectorized = c.vectorized_bound;
     p.C = C; p.n_sk = n_sk; p.chain0 = chain_id_offset; p.cap = c.max_iter_per_event; p.seed = seed;
     p.tmax = c.tmax; p.refresh = c.refresh_rate;
+    p.fe_mix_p = c.fe_mix_p; p.fe_ran_p = c.fe_ran_p; p.fe_switch = c.fe_switch; p.fe_positive = c.fe_positive;
     p.xinit = xinit; p.vinit = vinit; p.tparams = h->d_tparams;
     p.X = X; p.V = V; p.t = t;
     if (diag) {
@@ -487,7 +503,7 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
         gp.G = h->group_lanes;
         gp.K = (c.dim + gp.G - 1) / gp.G;
         gp.tpar = (c.target_id == PDMP_T_GAUSS_DIAG) ? 2 * c.dim : 0;
-        gp.tiles = (c.target_id == PDMP_T_GAUSS_DENSE) ? 6 : 2;
+        gp.tiles = (c.target_id == PDMP_T_GAUSS_DENSE || c.sampler == PDMP_FECMC) ? 6 : 2;   // ForwardECMC: n, v_orth, e1, e2
         gp.cell_budget = 3;
         if (const char *e = getenv("PDMP_CELL_BUDGET")) { const int b = atoi(e); if (b >= 1 && b <= GNG - 1) gp.cell_budget = b; }   // tuning / tests
         const int64_t nb = (C + WAVE / gp.G - 1) / (WAVE / gp.G);
@@ -533,9 +549,10 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
         const char *reg = getenv("PDMP_REG");               // PDMP_REG=0: keep x, v in LDS tiles (test hook)
         if (!(reg && atoi(reg) == 0)) {
             const bool fd = c.deriv_mode != 0;
-            e = c.sampler == PDMP_ZIGZAG ? launch_group_reg_zigzag(c.target_id, fd, gp, s)
-              : c.sampler == PDMP_BPS    ? launch_group_reg_bps(c.target_id, fd, gp, s)
-                                         : launch_group_reg_boomerang(c.target_id, fd, gp, s);
+            e = c.sampler == PDMP_ZIGZAG    ? launch_group_reg_zigzag(c.target_id, fd, gp, s)
+              : c.sampler == PDMP_BPS       ? launch_group_reg_bps(c.target_id, fd, gp, s)
+              : c.sampler == PDMP_BOOMERANG ? launch_group_reg_boomerang(c.target_id, fd, gp, s)
+                                            : hipErrorNotSupported;
         }
         if (e == hipErrorNotSupported) e = pick_group_launcher(c.sampler, c.target_id)(gp, s);
         HIP_TRY(e);

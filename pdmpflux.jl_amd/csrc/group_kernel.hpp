@@ -205,6 +205,7 @@ struct GroupChain {
     const int G, K, lane, g, base;       // g = lane within the group, base = first lane of the group
     double *xs, *vs;                     // this wave's LDS tiles: slot s of lane l at [s*64 + l]
     mutable double xr[kReg ? KC : 1], vr[kReg ? KC : 1];   // register form: slot s of this lane
+    double *fe_t[4] = {nullptr, nullptr, nullptr, nullptr};   // ForwardECMC: LDS tiles for n, v_orth, e1 / g1, e2 / g2 / the proposal
     __device__ __forceinline__ int nk() const { if constexpr (kReg) return KC; else return K; }
     // coordinate i = s*G + g exists (i < d): only the last slot K-1 can be partly padded (register form: a scalar test for the others)
     __device__ __forceinline__ bool in_dim(int s, int i) const { if constexpr (kReg) return s < K - 1 || i < p.d; else return i < p.d; }
@@ -743,6 +744,96 @@ struct GroupChain {
     }
 
     // ---- velocity_jump: ZigZagSamplers.jl:101-107, BouncyParticleSamplers.jl:50-74, BoomerangSamplers.jl:49-67
+    // ---- _velocity_jump_event_chain (ForwardEventChainMonteCarlo.jl:127-175; default variant: normal = false, speed_factor = 1)
+    // with _orthogonal_switch (:60-91) / _full_refresh (:108-117).  The d-vectors n, v_orth, e1, e2 live in four LDS tiles;
+    // every dot product is a per-lane left-to-right sum over the lane's coordinates and a butterfly over the group (padded
+    // coordinates hold exact zeros).  u^(2/(dim-1)) = exp(log(u) * (2/(dim-1))) with the engine's log / exp, as in the checker;
+    // randn(key, 2, dim) is column-major: g1[j], g2[j] = the two normals of Box-Muller pair j of the chain's stream.
+    __device__ __forceinline__ double tdot(const double *a, const double *b) const {
+        double acc = 0.0;
+        PDMP_SLOTS(s) acc += a[s * WAVE + lane] * b[s * WAVE + lane];
+        return group_sum(acc, G);
+    }
+    __device__ __forceinline__ bool fecmc_jump(const typename Tgt::template Sh<double> &sh) {
+        const int d = p.d;
+        double *tn = fe_t[0], *tvo = fe_t[1], *t1 = fe_t[2], *t2 = fe_t[3];
+        const double u = rng.uniform();                                             // :134
+        const double pw = det_exp(det_log(u) * (2.0 / (double)(d - 1)));
+        const double rho = -__dsqrt_rn(1.0 - pw);                                   // :135
+        PDMP_SLOTS(s) {
+            const int i = s * G + g;
+            tn[s * WAVE + lane] = in_dim(s, i) ? tgt.grad(i, X(s), sh) : 0.0;       // n = copy(grad-U(x)), :143
+            if (!in_dim(s, i)) V(s) = 0.0;
+        }
+        const double ng = __dsqrt_rn(tdot(tn, tn));
+        PDMP_SLOTS(s) tn[s * WAVE + lane] = (ng == 0.0) ? 0.0 : tn[s * WAVE + lane] / ng;   // :144-149
+        double acc = 0.0;
+        PDMP_SLOTS(s) acc += V(s) * tn[s * WAVE + lane];
+        const double vn = group_sum(acc, G);                                        // v . n, :152
+        PDMP_SLOTS(s) { const double vp = vn * tn[s * WAVE + lane]; tvo[s * WAVE + lane] = V(s) - vp; }   // :152-153
+        double nvo = __dsqrt_rn(tdot(tvo, tvo));
+        if (nvo < 1e-10) {                                                          // :156-159
+            PDMP_SLOTS(s) { const int i = s * G + g; tvo[s * WAVE + lane] = in_dim(s, i) ? rng.normal_coord(i) : 0.0; }
+            rng.normals_done(d);
+            const double dn = tdot(tvo, tn);
+            PDMP_SLOTS(s) tvo[s * WAVE + lane] = tvo[s * WAVE + lane] - dn * tn[s * WAVE + lane];
+            nvo = __dsqrt_rn(tdot(tvo, tvo));
+        }
+        const double u2 = rng.uniform();                                            // :161
+        const double sq = __dsqrt_rn(1.0 - rho * rho);
+        if (u2 >= p.fe_mix_p) {                                                     // :162-166
+            PDMP_SLOTS(s) { const int i = s * G + g; if (in_dim(s, i)) V(s) = tvo[s * WAVE + lane] / nvo * sq + rho * tn[s * WAVE + lane]; }
+            return false;
+        }
+        if (p.fe_switch) {                                                          // _orthogonal_switch, :60-91
+            PDMP_SLOTS(s) {
+                const int i = s * G + g;
+                double z0 = 0.0, z1 = 0.0;
+                if (in_dim(s, i)) rng.normal_pair(i, z0, z1);
+                t1[s * WAVE + lane] = z0;
+                t2[s * WAVE + lane] = z1;
+            }
+            rng.normals_done(2 * d);
+            const double d1 = tdot(t1, tn);
+            PDMP_SLOTS(s) t1[s * WAVE + lane] = t1[s * WAVE + lane] - d1 * tn[s * WAVE + lane];        // :67
+            const double d2 = tdot(t2, tn);
+            PDMP_SLOTS(s) t2[s * WAVE + lane] = t2[s * WAVE + lane] - d2 * tn[s * WAVE + lane];        // :68
+            const double n1 = __dsqrt_rn(tdot(t1, t1));
+            PDMP_SLOTS(s) t1[s * WAVE + lane] = t1[s * WAVE + lane] / n1;                              // :71
+            const double d21 = tdot(t2, t1);
+            PDMP_SLOTS(s) t2[s * WAVE + lane] = t2[s * WAVE + lane] - d21 * t1[s * WAVE + lane];       // :72
+            const double n2 = __dsqrt_rn(tdot(t2, t2));
+            PDMP_SLOTS(s) t2[s * WAVE + lane] = t2[s * WAVE + lane] / n2;                              // :73
+            const double a = tdot(tvo, t1), b = tdot(tvo, t2);
+            double sn = 0.0, cs = 0.0;
+            if (p.fe_ran_p) { const double ut = rng.uniform(); det_sincos_2pi(ut, sn, cs); }           // theta = rand * 2pi, :79
+            acc = 0.0;
+            PDMP_SLOTS(s) {
+                const double vo = tvo[s * WAVE + lane], e1 = t1[s * WAVE + lane], e2 = t2[s * WAVE + lane];
+                const double vr = (vo - a * e1) - b * e2;                                              // :76
+                const double z = p.fe_ran_p ? (vr + (cs * e1 + sn * e2) * a) + (sn * e1 - cs * e2) * b  // :80
+                                            : (vr + e2 * a) + e1 * b;                                  // :77
+                acc += vo * z;
+                t2[s * WAVE + lane] = z;
+            }
+            if (p.fe_positive) {                                                                       // :83-85
+                const double sdot = group_sum(acc, G);
+                const double sg = (sdot > 0.0) ? 1.0 : ((sdot < 0.0) ? -1.0 : sdot);
+                PDMP_SLOTS(s) t2[s * WAVE + lane] = t2[s * WAVE + lane] * sg;
+            }
+        } else {                                                                    // _full_refresh, :108-117
+            PDMP_SLOTS(s) { const int i = s * G + g; t2[s * WAVE + lane] = in_dim(s, i) ? rng.normal_coord(i) : 0.0; }
+            rng.normals_done(d);
+            const double nz = __dsqrt_rn(tdot(t2, t2));
+            PDMP_SLOTS(s) t2[s * WAVE + lane] = t2[s * WAVE + lane] / nz;
+            const double dn = tdot(t2, tn);
+            PDMP_SLOTS(s) t2[s * WAVE + lane] = t2[s * WAVE + lane] - dn * tn[s * WAVE + lane];
+        }
+        const double np = __dsqrt_rn(tdot(t2, t2));                                 // :170-172
+        PDMP_SLOTS(s) { const int i = s * G + g; if (in_dim(s, i)) V(s) = t2[s * WAVE + lane] / np * sq + rho * tn[s * WAVE + lane]; }
+        return false;
+    }
+
     // returns true when the chain asks for a velocity refresh: the normals are drawn by refresh_velocities(), outside the
     // divergent accept branch, with all 64 lanes of the wave
     __device__ __forceinline__ bool velocity_jump(double raw) {
@@ -794,6 +885,8 @@ struct GroupChain {
             if constexpr (kReg) { PDMP_SLOTS(s) if (s == ms && g == m - ms * G) V(s) = -V(s); }
             else if (g == m - ms * G) V(ms) = -V(ms);                    // v[m] *= -1
             return false;
+        } else if constexpr (SAMPLER == S_FECMC) {
+            return fecmc_jump(sh);
         } else {
             double acc = 0.0;
             double gv;
@@ -1036,7 +1129,7 @@ struct GroupChain {
                 }
                 proposed = true;
             }
-            if constexpr (SAMPLER != S_ZIGZAG) {                          // the whole wave draws the normals of its refreshing chains
+            if constexpr (SAMPLER == S_BPS || SAMPLER == S_BOOMERANG) {   // the whole wave draws the normals of its refreshing chains
                 if (__ballot(refresh) != 0ull) refresh_velocities(refresh);
             }
             STAMP(3);
@@ -1128,6 +1221,9 @@ __device__ __forceinline__ void group_kernel_body(const GroupParams &gp) {
     // register form: no x tile; one K*64-double tile per wave only where refreshed velocities are exchanged between lanes
     GroupChain<SAMPLER, TARGET, FD, KC> chain(gp, lane, tile, KC > 0 ? tile : tile + tsz);
     chain.tgt.init(smem, gp.s.d);
+    if constexpr (SAMPLER == S_FECMC) {
+        for (int q = 0; q < 4; ++q) chain.fe_t[q] = tile + (2 + q) * tsz;
+    }
     if constexpr (GTarget<TARGET>::kTile) {
         chain.tgt.P = gp.s.tparams;
         chain.tgt.tg[0] = tile + 2 * tsz; chain.tgt.tg[1] = tile + 3 * tsz;
@@ -1167,7 +1263,7 @@ template <int SAMPLER, int TARGET, bool FD> struct RegForm {
     static constexpr bool kSlowZz = SAMPLER == S_ZIGZAG && FD;                       // measured: 88 ms against 73 ms in the LDS form
     static constexpr bool kPartial = !kSlowZz && !(SAMPLER == S_BOOMERANG && TARGET != T_GAUSS_DIAG);   // would spill: Boomerang iso / banana
     static constexpr bool kFull = !kSlowZz && !GTarget<TARGET>::kShared && !(SAMPLER != S_BPS && TARGET == T_GAUSS_DIAG);   // would spill: banana, Zig-Zag / Boomerang diag
-    static constexpr bool kAny = kPartial || kFull;
+    static constexpr bool kAny = (kPartial || kFull) && SAMPLER != S_FECMC;
 };
 
 // register form (x, v in VGPRs, up to KC slots per lane, G fixed at compile time): no LDS tiles; 2 waves per SIMD -- the

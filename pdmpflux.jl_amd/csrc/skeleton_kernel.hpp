@@ -15,7 +15,7 @@
 
 namespace pdmp {
 
-enum : int { S_ZIGZAG = 0, S_BPS = 1, S_BOOMERANG = 2 };
+enum : int { S_ZIGZAG = 0, S_BPS = 1, S_BOOMERANG = 2, S_FECMC = 3 };   // S_FECMC: group kernel only
 
 struct SkelParams {
     int32_t d, n_grid, signed_bound, adaptive, gaussian_velocity, deriv_mode, vectorized;
@@ -30,6 +30,9 @@ struct SkelParams {
     // tape source: replay pre-recorded variates instead of Philox; chain-major, indexed by global chain id
     const double *tape_exp, *tape_uni, *tape_nrm;
     int64_t tape_n_exp, tape_n_uni, tape_n_nrm;
+    // ForwardECMC keywords (ForwardEventChainMonteCarlo.jl:290-292)
+    double fe_mix_p;
+    int32_t fe_ran_p, fe_switch, fe_positive;
 };
 
 __device__ __forceinline__ bool uni(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }

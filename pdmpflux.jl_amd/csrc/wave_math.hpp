@@ -152,6 +152,42 @@ __device__ __forceinline__ double det_log(double x) {
     return (k == 0) ? f - s * (f - R) : dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
 }
 
+// exp(x): fdlibm e_exp.c algorithm with +,-,*,/ and integer operations on the exponent field only (same statements as the checker).
+__device__ __forceinline__ double det_exp(double x) {
+    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+                 invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+                 P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (x != x) return x;
+    if (x > 7.09782712893383973096e+02) return __builtin_huge_val();
+    if (x < -7.45133219101941108420e+02) return 0.0;
+    const uint32_t hx = (uint32_t)__double2hiint(x) & 0x7fffffffu;
+    const int xsb = (int)((uint32_t)__double2hiint(x) >> 31);
+    double hi = 0.0, lo = 0.0;
+    int32_t k = 0;
+    if (hx > 0x3fd62e42u) {
+        if (hx < 0x3FF0A2B2u) {
+            hi = xsb ? x + ln2HI : x - ln2HI;
+            lo = xsb ? -ln2LO : ln2LO;
+            k = 1 - xsb - xsb;
+        } else {
+            k = (int32_t)(invln2 * x + (xsb ? -0.5 : 0.5));
+            const double t = (double)k;
+            hi = x - t * ln2HI;
+            lo = t * ln2LO;
+        }
+        x = hi - lo;
+    } else if (hx < 0x3e300000u) {
+        return 1.0 + x;
+    }
+    const double t = x * x;
+    const double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
+    const double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+    long long iy = __double_as_longlong(y);
+    if (k >= -1021) return __longlong_as_double(iy + ((long long)k << 52));
+    return __longlong_as_double(iy + ((long long)(k + 1000) << 52)) * 9.33263618503218878990e-302;
+}
+
 __device__ __forceinline__ double ksin(double a) {
     const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
                  S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,

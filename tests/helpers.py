@@ -26,7 +26,8 @@ def make_pair(P, O, kind, dim, target="iso", arith=None, **kw):
     else:
         raise ValueError(target)
     ctor = {"ZigZag": P.ZigZag, "ZigZagAD": P.ZigZagAD, "BPS": P.BPS, "BPSAD": P.BPSAD,
-            "Boomerang": P.Boomerang, "BoomerangAD": P.BoomerangAD}[kind]
+            "Boomerang": P.Boomerang, "BoomerangAD": P.BoomerangAD, "ForwardECMC": P.ForwardECMC,
+            "ForwardECMCAD": P.ForwardECMCAD}[kind]
     s = ctor(dim, tg, **kw)
     group = 1
     if arith is None:                       # match the summation order the engine uses for this configuration
@@ -35,7 +36,9 @@ def make_pair(P, O, kind, dim, target="iso", arith=None, **kw):
     cfg = O.Config(sampler=s.sampler_id, dim=dim, grid_size=s.grid_size, tmax=s.tmax, refresh_rate=s.refresh_rate,
                    vectorized_bound=s.vectorized_bound, signed_bound=s.signed_bound, adaptive=s.adaptive,
                    gaussian_velocity=s.gaussian_velocity, deriv_mode=s.deriv_mode, target_id=tid,
-                   target_params=params, arith=arith, group_lanes=group)
+                   target_params=params, arith=arith, group_lanes=group,
+                   mix_p=getattr(s, "mix_p", 0.5), ran_p=getattr(s, "ran_p", False), switch=getattr(s, "switch", True),
+                   positive=getattr(s, "positive", True))
     return s, cfg
 
 
@@ -48,7 +51,7 @@ def make_init(kind, dim, C, seed=0, target="iso"):
         x[:, 0] = 2.0 + 0.2 * x[:, 0]
     if kind.startswith("ZigZag"):
         v = rs.choice([-1.0, 1.0], size=(C, dim))
-    elif kind.startswith("BPS"):
+    elif kind.startswith("BPS") or kind.startswith("ForwardECMC"):
         v = rs.normal(size=(C, dim))
         v /= np.linalg.norm(v, axis=1, keepdims=True)
     else:
