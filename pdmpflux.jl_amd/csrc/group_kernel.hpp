@@ -785,14 +785,48 @@ struct GroupChain {
             PDMP_SLOTS(s) { const int i = s * G + g; if (in_dim(s, i)) V(s) = tvo[s * WAVE + lane] / nvo * sq + rho * tn[s * WAVE + lane]; }
             return false;
         }
-        if (p.fe_switch) {                                                          // _orthogonal_switch, :60-91
-            PDMP_SLOTS(s) {
-                const int i = s * G + g;
-                double z0 = 0.0, z1 = 0.0;
-                if (in_dim(s, i)) rng.normal_pair(i, z0, z1);
-                t1[s * WAVE + lane] = z0;
-                t2[s * WAVE + lane] = z1;
+        fe_rho = rho; fe_sq = sq;
+        return true;                                                                // refresh of the orthogonal part: fecmc_refresh()
+    }
+
+    // Second half of the jump for the chains whose lanes pass `mine`, called by the whole wave: the normals of
+    // randn(key, 2, dim) (orthogonal switch) or randn(key, dim) (full refresh) are drawn one Box-Muller pair per LANE of the
+    // wave into the chain's tiles (one pass for dim <= 64 resp. 128) instead of one pair per coordinate on the chain's own lanes.
+    double fe_rho = 0.0, fe_sq = 0.0;
+    __device__ __forceinline__ void fecmc_refresh(bool mine) {
+        const int d = p.d, logG = __builtin_ctz(G);
+        double *tn = fe_t[0], *tvo = fe_t[1], *t1 = fe_t[2], *t2 = fe_t[3];
+        unsigned long long todo = __ballot(mine && g == 0);
+        while (todo != 0ull) {
+            const int L = (int)__builtin_ctzll(todo);                               // first lane of the chain
+            todo &= todo - 1ull;
+            ChainRng r = rng;                                                       // seed words are the same in every lane
+            r.c2 = (uint32_t)__builtin_amdgcn_readlane((int)rng.c2, L);
+            r.c3 = (uint32_t)__builtin_amdgcn_readlane((int)rng.c3, L);
+            r.n = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rng.n >> 32), L) << 32) |
+                  (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rng.n, L);
+            if (p.fe_switch) {                                                      // g1[P], g2[P] = pair P
+                for (int P = lane; P < d; P += WAVE) {
+                    double z0, z1;
+                    r.normal_pair(P, z0, z1);
+                    const int o = (P >> logG) * WAVE + L + (P & (G - 1));
+                    t1[o] = z0;
+                    t2[o] = z1;
+                }
+            } else {                                                                // z[2P], z[2P+1] = pair P
+                for (int P = lane; 2 * P < d; P += WAVE) {
+                    double z0, z1;
+                    r.normal_pair(P, z0, z1);
+                    const int i0 = 2 * P, i1 = 2 * P + 1;
+                    t2[(i0 >> logG) * WAVE + L + (i0 & (G - 1))] = z0;
+                    if (i1 < d) t2[(i1 >> logG) * WAVE + L + (i1 & (G - 1))] = z1;
+                }
             }
+        }
+        if (!mine) return;
+        const double rho = fe_rho, sq = fe_sq;
+        PDMP_SLOTS(s) { const int i = s * G + g; if (!in_dim(s, i)) { t1[s * WAVE + lane] = 0.0; t2[s * WAVE + lane] = 0.0; } }
+        if (p.fe_switch) {                                                          // _orthogonal_switch, :60-91
             rng.normals_done(2 * d);
             const double d1 = tdot(t1, tn);
             PDMP_SLOTS(s) t1[s * WAVE + lane] = t1[s * WAVE + lane] - d1 * tn[s * WAVE + lane];        // :67
@@ -807,7 +841,7 @@ struct GroupChain {
             const double a = tdot(tvo, t1), b = tdot(tvo, t2);
             double sn = 0.0, cs = 0.0;
             if (p.fe_ran_p) { const double ut = rng.uniform(); det_sincos_2pi(ut, sn, cs); }           // theta = rand * 2pi, :79
-            acc = 0.0;
+            double acc = 0.0;
             PDMP_SLOTS(s) {
                 const double vo = tvo[s * WAVE + lane], e1 = t1[s * WAVE + lane], e2 = t2[s * WAVE + lane];
                 const double vr = (vo - a * e1) - b * e2;                                              // :76
@@ -822,7 +856,6 @@ struct GroupChain {
                 PDMP_SLOTS(s) t2[s * WAVE + lane] = t2[s * WAVE + lane] * sg;
             }
         } else {                                                                    // _full_refresh, :108-117
-            PDMP_SLOTS(s) { const int i = s * G + g; t2[s * WAVE + lane] = in_dim(s, i) ? rng.normal_coord(i) : 0.0; }
             rng.normals_done(d);
             const double nz = __dsqrt_rn(tdot(t2, t2));
             PDMP_SLOTS(s) t2[s * WAVE + lane] = t2[s * WAVE + lane] / nz;
@@ -831,7 +864,6 @@ struct GroupChain {
         }
         const double np = __dsqrt_rn(tdot(t2, t2));                                 // :170-172
         PDMP_SLOTS(s) { const int i = s * G + g; if (in_dim(s, i)) V(s) = t2[s * WAVE + lane] / np * sq + rho * tn[s * WAVE + lane]; }
-        return false;
     }
 
     // returns true when the chain asks for a velocity refresh: the normals are drawn by refresh_velocities(), outside the
@@ -1131,6 +1163,8 @@ struct GroupChain {
             }
             if constexpr (SAMPLER == S_BPS || SAMPLER == S_BOOMERANG) {   // the whole wave draws the normals of its refreshing chains
                 if (__ballot(refresh) != 0ull) refresh_velocities(refresh);
+            } else if constexpr (SAMPLER == S_FECMC) {
+                if (__ballot(refresh) != 0ull) fecmc_refresh(refresh);
             }
             STAMP(3);
             if (accepted) {
