@@ -298,13 +298,13 @@ int choose_group_lanes(const pdmp_config_t &c) {
         if (G == 0) return 0;
         if (G >= 1 && G <= WAVE && (G & (G - 1)) == 0 && group_waves_per_block((c.dim + G - 1) / G, 2 * c.dim) >= 1) return G;
     }
+    if (c.sampler == PDMP_FECMC) {         // six LDS tiles per wave (x, v, n, v_orth, e1, e2): 20 KB keep two blocks per CU (measured
+        for (int G = 1; G <= WAVE; G <<= 1)   // at d = 50: G = 4 / 8 / 16 -> 467 / 566 / 306 ms); 40 KB for very large d
+            if (6 * (size_t)((c.dim + G - 1) / G) * WAVE * sizeof(double) <= 20 * 1024) return G;
+        return (6 * (size_t)((c.dim + WAVE - 1) / WAVE) * WAVE * sizeof(double) <= 40 * 1024) ? WAVE : 0;
+    }
     for (int G = 1; G <= 16; G <<= 1)      // register form (inst_reg_*.hip): at most KREG slots per lane, G <= 16
         if ((c.dim + G - 1) / G <= KREG) return G;
-    if (c.sampler == PDMP_FECMC) {         // six tiles per wave (x, v, n, v_orth, e1, e2): keep one wave's tiles within 40 KB
-        for (int G = 32; G <= WAVE; G <<= 1)
-            if (6 * (size_t)((c.dim + G - 1) / G) * WAVE * sizeof(double) <= 40 * 1024) return G;
-        return 0;
-    }
     const size_t budget = 20 * 1024;      // two blocks (8 waves) per CU
     for (int G = 1; G <= WAVE; G <<= 1) {
         const size_t K = (size_t)(c.dim + G - 1) / G;
