@@ -40,7 +40,8 @@ enum { PDMP_OK = 0, PDMP_ERR_ARGUMENT = -1, PDMP_ERR_DIMENSION = -2, PDMP_ERR_RU
 
 /* src/Samplers/ZigZagSamplers.jl:35-116, BouncyParticleSamplers.jl:1-84, BoomerangSamplers.jl:1-77,
  * ForwardEventChainMonteCarlo.jl:262-344 (ForwardECMC with its default velocity jump, :127-175) */
-enum { PDMP_ZIGZAG = 0, PDMP_BPS = 1, PDMP_BOOMERANG = 2, PDMP_FECMC = 3 };
+enum { PDMP_ZIGZAG = 0, PDMP_BPS = 1, PDMP_BOOMERANG = 2, PDMP_FECMC = 3,
+       PDMP_SUZZ = 4 /* SpeedUpZigZag, src/Samplers/SpeedUpZigZagSamplers.jl (sample_skeleton only) */ };
 /* Potential descriptors replacing the Julia closure field `grad-U` (ZigZagSamplers.jl:37): */
 enum { PDMP_T_GAUSS_ISO = 0,   /* U = |x|^2/2                         (README.md:36-38)            */
        PDMP_T_GAUSS_DIAG = 1,  /* U = sum prec_i (x_i-mu_i)^2/2 ; params = mu[d], prec[d]            */
@@ -53,7 +54,7 @@ enum { PDMP_DERIV_FORWARD = 0 /* "ForwardDiff": exact forward-mode duals */,
 
 /* Keyword arguments of the reference constructors as a plain struct. */
 typedef struct pdmp_config_t {
-    int32_t sampler;            /* PDMP_ZIGZAG | PDMP_BPS | PDMP_BOOMERANG | PDMP_FECMC */
+    int32_t sampler;            /* PDMP_ZIGZAG | PDMP_BPS | PDMP_BOOMERANG | PDMP_FECMC | PDMP_SUZZ */
     int32_t dim;                /* > 0 */
     int32_t grid_size;          /* 2..64 grid bound; 0 = Brent constant bound (UpperBound.jl:18-36) */
     int32_t vectorized_bound;   /* ZigZag default 1; forced 0 for BPS/Boomerang */

@@ -84,6 +84,18 @@ function ForwardECMC(dim::Int, target::Target; grid_size=10, tmax=2.0, signed_bo
     return s
 end
 
+# SpeedUpZigZag(dim, target; ...) with the defaults of SpeedUpZigZagSamplers.jl:56-59 (sampler id 4)
+function SpeedUpZigZag(dim::Int, target::Target; grid_size=10, tmax=2.0, refresh_rate=0.0, vectorized_bound=true,
+                       signed_bound=true, adaptive=true, AD_backend="FiniteDiff", device=-1)
+    p = params(target)
+    cfg = Config(4, dim, grid_size, vectorized_bound, signed_bound, adaptive, 0, AD_backend == "FiniteDiff" ? 1 : 0,
+                 target_id(target), device, Float64(tmax), refresh_rate, pointer(p), length(p), 0, 0.5, 0, 1, 1, 0)
+    handle = GC.@preserve p create(cfg, target)
+    s = HIPSampler(handle, dim, 4)
+    finalizer(x -> ccall((:pdmp_destroy, LIB), Cint, (Ptr{Cvoid},), x.handle), s)
+    return s
+end
+
 # sample_skeleton(sampler, n_sk, xinit, vinit; seed) -> PDMPHistory      (src/sample.jl:253-284)
 function sample_skeleton(s::HIPSampler, n_sk::Int, xinit::Vector{Float64}, vinit::Vector{Float64};
                          seed::Union{Int,Nothing}=nothing, verbose::Bool=true)

@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libpdmp_oracle.so")
 
-ZIGZAG, BPS, BOOMERANG, FECMC = 0, 1, 2, 3
+ZIGZAG, BPS, BOOMERANG, FECMC, SUZZ = 0, 1, 2, 3, 4
 T_GAUSS_ISO, T_GAUSS_DIAG, T_BANANA, T_GAUSS_DENSE = 0, 1, 2, 3
 T_AD_BANANA, T_AD_FUNNEL, T_AD_RIDGED = 16, 17, 18      # grad-U by forward mode over U (ad_potentials.c)
 DERIV_FORWARD, DERIV_FINITE_DIFF = 0, 1

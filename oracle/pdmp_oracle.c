@@ -403,9 +403,60 @@ static void ws_free(ws_t *w) {
     free(w->fe_vo); free(w->fe_e1); free(w->fe_e2); free(w->fe_z); free(w->fe_g);
 }
 
+static inline int is_zz(const orc_config_t *cfg) { return cfg->sampler == ORC_ZIGZAG || cfg->sampler == ORC_SUZZ; }
+
+/* SpeedUpZigZag flow (SpeedUpZigZagSamplers.jl:71-79) with a dual time: x_t = y + (v1 X1(t)) v where
+ *   y = x - (v1 x1) v,  c = v1 (y.v),  a = (1 + y.y)/dim - c^2/dim^2,  Y0 = x1 + c/dim,
+ *   b_t = (Y0 + sqrt(Y0^2 + a)) exp(sqrt(dim) v1 t),  X1 = (b_t^2 - a)/(2 b_t) - c/dim,
+ * every operation in the order written there, the t-derivative by the forward-mode rules of the checker (no fma). */
+static double vsum(const orc_config_t *cfg, const double *a, int d);
+static void suzz_flow_dual(const orc_config_t *cfg, ws_t *w, const double *x, const double *v, double t) {
+    const int d = w->d;
+    double *y = w->fe_vo;                                                 /* scratch of its own (fa / fb hold finite-difference values) */
+    const double av = v[0] * x[0];
+    for (int i = 0; i < d; ++i) { y[i] = x[i] - av * v[i]; w->tmp[i] = y[i] * v[i]; }          /* y, y.v */
+    const double yv = vsum(cfg, w->tmp, d);
+    for (int i = 0; i < d; ++i) w->tmp[i] = y[i] * y[i];
+    const double yy = vsum(cfg, w->tmp, d);
+    const double dd = (double)d;
+    const double c = v[0] * yv;
+    const double a = (1.0 + yy) / dd - (c * c) / (dd * dd);
+    const double Y0 = x[0] + c / dd;
+    const double base = Y0 + sqrt(Y0 * Y0 + a);
+    const double sd = sqrt(dd) * v[0];
+    const double ev = orc_exp(sd * t), ee = sd * ev;                      /* exp(sd t), d/dt */
+    const double bv = base * ev, be = base * ee;                          /* b_t */
+    const double b2v = bv * bv, b2e = be * bv + bv * be;                  /* b_t^2 */
+    const double nv = b2v - a, ne = b2e;
+    const double dv = 2.0 * bv, de = 2.0 * be;
+    const double qv = nv / dv, qe = (ne - qv * de) / dv;
+    const double X1v = qv - c / dd, X1e = qe;
+    const double kv = v[0] * X1v, ke = v[0] * X1e;                         /* v1 * X1 */
+    for (int i = 0; i < d; ++i) {
+        w->xv[i] = y[i] + kv * v[i];
+        w->xe[i] = ke * v[i];
+        w->vv[i] = v[i];
+        w->ve[i] = 0.0;
+    }
+}
+/* grad-U_effective(x) = speed(x) grad-U(x) - x / speed(x), speed = sqrt(1 + x.x) (SpeedUpZigZagSamplers.jl:81-83), on duals */
+static void suzz_effective(const orc_config_t *cfg, ws_t *w, const double *xv, const double *xe, double *gv, double *ge) {
+    const int d = w->d;
+    for (int i = 0; i < d; ++i) { w->tmp[i] = xv[i] * xv[i]; w->tmp2[i] = xe[i] * xv[i] + xv[i] * xe[i]; }
+    const double s2v = 1.0 + vsum(cfg, w->tmp, d), s2e = vsum(cfg, w->tmp2, d);
+    const double spv = sqrt(s2v), spe = s2e / (2.0 * spv);
+    for (int i = 0; i < d; ++i) {
+        const double mv = spv * gv[i], me = spe * gv[i] + spv * ge[i];   /* speed * grad-U */
+        const double qv = xv[i] / spv, qe = (xe[i] - qv * spe) / spv;    /* x / speed */
+        gv[i] = mv - qv;
+        ge[i] = me - qe;
+    }
+}
+
 /* flow with a dual time (t, 1): ZigZagSamplers.jl:80, BouncyParticleSamplers.jl:32 (x + v t, v);
  * BoomerangSamplers.jl:31 (x cos t + v sin t, -x sin t + v cos t). */
 static void flow_dual(const orc_config_t *cfg, ws_t *w, const double *x, const double *v, double t) {
+    if (cfg->sampler == ORC_SUZZ) { suzz_flow_dual(cfg, w, x, v, t); return; }
     const int d = w->d;
     if (cfg->sampler == ORC_BOOMERANG) {
         double s, c; orc_sincos(t, &s, &c);
@@ -432,6 +483,7 @@ static void zz_func_dual(const orc_config_t *cfg, ws_t *w, const double *x, cons
                          double *val, double *slp) {
     flow_dual(cfg, w, x, v, t);
     grad_dual(cfg, w->xv, w->xe, w->gv, w->ge);
+    if (cfg->sampler == ORC_SUZZ) suzz_effective(cfg, w, w->xv, w->xe, w->gv, w->ge);
     for (int i = 0; i < w->d; ++i) {
         double s = w->gv[i] * w->vv[i];
         double sd = w->ge[i] * w->vv[i] + w->gv[i] * w->ve[i];
@@ -444,11 +496,12 @@ static void zz_func_dual(const orc_config_t *cfg, ws_t *w, const double *x, cons
 static double sc_func_dual(const orc_config_t *cfg, ws_t *w, const double *x, const double *v, double t, double *slp) {
     flow_dual(cfg, w, x, v, t);
     grad_dual(cfg, w->xv, w->xe, w->gv, w->ge);
+    if (cfg->sampler == ORC_SUZZ) suzz_effective(cfg, w, w->xv, w->xe, w->gv, w->ge);
     for (int i = 0; i < w->d; ++i) {
         w->tmp[i] = w->gv[i] * w->vv[i];
         w->tmp2[i] = w->ge[i] * w->vv[i] + w->gv[i] * w->ve[i];
     }
-    if (cfg->sampler == ORC_ZIGZAG) {            /* non-vectorized Zig-Zag: func = rate = sum(max.(0, .)), ZigZagSamplers.jl:83-86 */
+    if (is_zz(cfg)) {                            /* non-vectorized Zig-Zag: func = rate = sum(max.(0, .)), ZigZagSamplers.jl:83-86 */
         for (int i = 0; i < w->d; ++i) {
             double s = w->tmp[i];
             w->tmp[i] = pmax(0.0, s);
@@ -474,7 +527,8 @@ static void fd_points(double t, double horizon, double *tm, double *tp) {
 static double true_rate(const orc_config_t *cfg, ws_t *w, double t) {
     flow_dual(cfg, w, w->x, w->v, t);
     grad_dual(cfg, w->xv, w->xe, w->gv, w->ge);
-    if (cfg->sampler == ORC_ZIGZAG) {                 /* ZigZagSamplers.jl:83-86 */
+    if (cfg->sampler == ORC_SUZZ) suzz_effective(cfg, w, w->xv, w->xe, w->gv, w->ge);
+    if (is_zz(cfg)) {                                 /* ZigZagSamplers.jl:83-86 */
         for (int i = 0; i < w->d; ++i) w->tmp[i] = pmax(0.0, w->gv[i] * w->vv[i]);
         return vsum(cfg, w->tmp, w->d);
     }
@@ -658,6 +712,11 @@ double orc_upper_bound(const orc_config_t *cfg, const double *x, const double *v
 
 /* in-place flow of the state (no dual) */
 static void flow_state(const orc_config_t *cfg, ws_t *w, double t) {
+    if (cfg->sampler == ORC_SUZZ) {                      /* SpeedUpZigZagSamplers.jl:71-79 */
+        suzz_flow_dual(cfg, w, w->x, w->v, t);
+        for (int i = 0; i < w->d; ++i) w->x[i] = w->xv[i];
+        return;
+    }
     if (cfg->sampler == ORC_BOOMERANG) {
         double s, c; orc_sincos(t, &s, &c);
         for (int i = 0; i < w->d; ++i) {
@@ -746,7 +805,8 @@ static int velocity_jump(const orc_config_t *cfg, ws_t *w, rng_t *rng) {
     const int d = w->d;
     for (int i = 0; i < d; ++i) { w->xe[i] = 0.0; }
     grad_dual(cfg, w->x, w->xe, w->gv, w->ge);
-    if (cfg->sampler == ORC_ZIGZAG) {
+    if (cfg->sampler == ORC_SUZZ) suzz_effective(cfg, w, w->x, w->xe, w->gv, w->ge);     /* SpeedUpZigZagSamplers.jl:104 */
+    if (is_zz(cfg)) {
         for (int i = 0; i < d; ++i) w->tmp[i] = pmax(0.0, w->gv[i] * w->v[i]);
         double S = vsum(cfg, w->tmp, d);
         double u = rng_uniform(rng);                          /* Categorical draw (1 uniform) */
@@ -794,7 +854,7 @@ int orc_normalize_config(orc_config_t *c) {
     if (c->dim <= 0) FAIL(-1, "dimension dim must be positive. Current value: %d", c->dim);           /* ZigZagSamplers.jl:62-64 */
     if (c->grid_size < 0) FAIL(-1, "grid_size must be non-negative. Current value: %d", c->grid_size); /* :66-68 */
     if (c->grid_size == 1) FAIL(-1, "grid_size == 1: range(...)[2] is a BoundsError in the reference");
-    if (c->sampler < 0 || c->sampler > 3) FAIL(-1, "unknown sampler id %d", c->sampler);
+    if (c->sampler < 0 || c->sampler > 4) FAIL(-1, "unknown sampler id %d", c->sampler);
     if (c->sampler == ORC_FECMC) {                                                                    /* ForwardEventChainMonteCarlo.jl:298-310 */
         if (c->dim < 2) FAIL(-1, "The dimension must be at least 2 to use the ForwardEventChain. Got dimension %d", c->dim);
         if (c->dim == 2) c->fe_mix_p = 0.0;
@@ -802,7 +862,7 @@ int orc_normalize_config(orc_config_t *c) {
     }
     if (c->target_id < 0 || (c->target_id > 3 && (c->target_id < ORC_T_AD_BANANA || c->target_id > ORC_T_AD_RIDGED))) FAIL(-1, "unknown target id %d", c->target_id);
     if (c->tmax == 0.0) { c->tmax = 1.0; c->adaptive = 1; }                                           /* :73 */
-    if (c->sampler == ORC_ZIGZAG) {
+    if (c->sampler == ORC_ZIGZAG || c->sampler == ORC_SUZZ) {
         if (c->signed_bound && !c->vectorized_bound) c->signed_bound = 0;                             /* :75-78 */
     } else c->vectorized_bound = 0;                                                                  /* BPS :37, Boomerang :36 */
     if (c->arith == ORC_ARITH_GROUP) {
@@ -970,7 +1030,21 @@ int orc_sample_from_skeleton_dt(const orc_config_t *cfg, int64_t C, int64_t n_sk
             double tau = tm - tc[i];                                                         /* :497 */
             const double *x0 = Xc + (size_t)i * d, *v0 = Vc + (size_t)i * d;
             double *o = oc + (size_t)(j - 1) * rows;
-            if (cfg->sampler == ORC_BOOMERANG) {
+            if (cfg->sampler == ORC_SUZZ) {             /* the sampler's own flow (sample.jl:499), SpeedUpZigZagSamplers.jl:71-79; dot
+                                                         * products in the engine's wave order (lane q sums q, q+64, ...; butterfly) */
+                double *yb = malloc((size_t)d * 8), *pb = malloc((size_t)d * 8);
+                const double av = v0[0] * x0[0], dd = (double)d;
+                for (int q = 0; q < d; ++q) { yb[q] = x0[q] - av * v0[q]; pb[q] = yb[q] * v0[q]; }
+                const double yv = sum_wave64(pb, d);
+                for (int q = 0; q < d; ++q) pb[q] = yb[q] * yb[q];
+                const double yy = sum_wave64(pb, d);
+                const double c = v0[0] * yv, a = (1.0 + yy) / dd - (c * c) / (dd * dd), Y0 = x0[0] + c / dd;
+                const double bt = (Y0 + sqrt(Y0 * Y0 + a)) * orc_exp(sqrt(dd) * v0[0] * tau);
+                const double X1 = (bt * bt - a) / (2.0 * bt) - c / dd;
+                const double kv = v0[0] * X1;
+                for (int q = 0; q < d; ++q) { o[q] = yb[q] + kv * v0[q]; if (!discard_vt) o[d + q] = v0[q]; }
+                free(yb); free(pb);
+            } else if (cfg->sampler == ORC_BOOMERANG) {
                 double s, cs; orc_sincos(tau, &s, &cs);
                 for (int q = 0; q < d; ++q) {
                     o[q] = x0[q] * cs + v0[q] * s;

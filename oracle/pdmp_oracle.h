@@ -20,7 +20,8 @@ extern "C" {
 
 /* sampler ids -- src/Samplers/{ZigZag,BouncyParticle,Boomerang}Samplers.jl */
 enum { ORC_ZIGZAG = 0, ORC_BPS = 1, ORC_BOOMERANG = 2,
-       ORC_FECMC = 3 /* ForwardECMC, src/Samplers/ForwardEventChainMonteCarlo.jl (default velocity jump, :127-175) */ };
+       ORC_FECMC = 3, /* ForwardECMC, src/Samplers/ForwardEventChainMonteCarlo.jl (default velocity jump, :127-175) */
+       ORC_SUZZ = 4   /* SpeedUpZigZag, src/Samplers/SpeedUpZigZagSamplers.jl: closed-form non-linear flow (:71-79), effective gradient (:81-83) */ };
 /* built-in potentials (closures cannot cross a C ABI) */
 enum { ORC_T_GAUSS_ISO = 0, ORC_T_GAUSS_DIAG = 1, ORC_T_BANANA = 2, ORC_T_GAUSS_DENSE = 3,
        /* grad-U by forward-mode differentiation of a scalar potential (ADBackend.jl:95-109), ad_potentials.c:

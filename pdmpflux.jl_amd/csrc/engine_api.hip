@@ -79,7 +79,7 @@ namespace {
 template <bool BOOMERANG>
 __global__ __launch_bounds__(256) void from_skeleton_kernel(int d, int64_t C, int64_t n_sk, const double *X,
                                                             const double *V, const double *t, int64_t N,
-                                                            double dt_in, int discard_vt, double *out) {
+                                                            double dt_in, int discard_vt, double *out, int suzz = 0) {
     const int lane = lane_id();
     const int64_t tiles = (N + WAVE - 1) / WAVE;
     const int64_t w = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -108,6 +108,22 @@ __global__ __launch_bounds__(256) void from_skeleton_kernel(int d, int64_t C, in
         double *o = out + ((size_t)c * N + (size_t)(tile * WAVE + s)) * rows;
         double sn = 0.0, cs = 1.0;
         if (BOOMERANG) det_sincos(ta, sn, cs);
+        if (suzz) {                                                   // SpeedUpZigZagSamplers.jl:71-79: x_t = y + (v1 X1(t)) v
+            const double x1 = x0[0], v1 = v0[0], av = v1 * x1, dd = (double)d;
+            double yv = 0.0, yy = 0.0;
+            for (int q = lane; q < d; q += WAVE) { const double y = x0[q] - av * v0[q]; yv += y * v0[q]; yy += y * y; }
+            yv = wave_sum(yv);
+            yy = wave_sum(yy);
+            const double c = v1 * yv, a = (1.0 + yy) / dd - (c * c) / (dd * dd), Y0 = x1 + c / dd;
+            const double bt = (Y0 + __dsqrt_rn(Y0 * Y0 + a)) * det_exp(__dsqrt_rn(dd) * v1 * ta);
+            const double X1 = (bt * bt - a) / (2.0 * bt) - c / dd;
+            const double kv = v1 * X1;
+            for (int q = lane; q < d; q += WAVE) {
+                const double vq = v0[q], y = x0[q] - av * vq;
+                o[q] = y + kv * vq;
+                if (!discard_vt) o[d + q] = vq;
+            }
+        } else
         for (int q = lane; q < d; q += WAVE) {
             const double xq = x0[q], vq = v0[q];
             if (BOOMERANG) {                                          // BoomerangSamplers.jl:31
@@ -232,7 +248,11 @@ int normalize_config(pdmp_config_t &c, bool from_source = false) {
     if (c.dim <= 0) return fail(PDMP_ERR_ARGUMENT, "dimension dim must be positive. Current value: %d", c.dim);          // ZigZagSamplers.jl:62-64
     if (c.grid_size < 0) return fail(PDMP_ERR_ARGUMENT, "grid_size must be non-negative. Current value: %d", c.grid_size); // :66-68
     if (c.grid_size == 1 || c.grid_size > WAVE) return fail(PDMP_ERR_UNSUPPORTED, "grid_size must be in 2..64. Current value: %d", c.grid_size);
-    if (c.sampler < PDMP_ZIGZAG || c.sampler > PDMP_FECMC) return fail(PDMP_ERR_ARGUMENT, "unknown sampler id %d", c.sampler);
+    if (c.sampler < PDMP_ZIGZAG || c.sampler > PDMP_SUZZ) return fail(PDMP_ERR_ARGUMENT, "unknown sampler id %d", c.sampler);
+    if (c.sampler == PDMP_SUZZ) {
+        if (c.target_id == PDMP_T_GAUSS_DENSE || c.target_id == PDMP_T_USER) return fail(PDMP_ERR_UNSUPPORTED, "SpeedUpZigZag: built-in separable / banana targets only");
+        if (c.grid_size != GNG && c.grid_size != 0) return fail(PDMP_ERR_UNSUPPORTED, "SpeedUpZigZag runs on the group kernel: grid_size = 10 (or 0, Brent)");
+    }
     if (c.sampler == PDMP_FECMC) {                                                                   // ForwardEventChainMonteCarlo.jl:298-310
         if (c.dim < 2) return fail(PDMP_ERR_ARGUMENT, "The dimension must be at least 2 to use the ForwardEventChain. Got dimension %d", c.dim);
         if (c.dim == 2) c.fe_mix_p = 0.0;
@@ -253,8 +273,8 @@ int normalize_config(pdmp_config_t &c, bool from_source = false) {
     if (c.deriv_mode != PDMP_DERIV_FORWARD && c.deriv_mode != PDMP_DERIV_FINITE_DIFF) return fail(PDMP_ERR_ARGUMENT, "Unsupported AD_backend id %d", c.deriv_mode);
     if (!std::isfinite(c.tmax) || c.tmax < 0.0) return fail(PDMP_ERR_ARGUMENT, "tmax must be finite and non-negative");
     if (c.tmax == 0.0) { c.tmax = 1.0; c.adaptive = 1; }                                            // ZigZagSamplers.jl:73
-    if (c.sampler == PDMP_ZIGZAG) {
-        if (c.signed_bound && !c.vectorized_bound) c.signed_bound = 0;                              // :75-78
+    if (c.sampler == PDMP_ZIGZAG || c.sampler == PDMP_SUZZ) {
+        if (c.signed_bound && !c.vectorized_bound) c.signed_bound = 0;                              // :75-78 (SpeedUpZigZagSamplers.jl:65-68)
     } else {
         c.vectorized_bound = 0;                                                                     // BPS :37, Boomerang :36
     }
@@ -278,11 +298,12 @@ launch_fn pick_launcher(int sampler, int target) {
 
 typedef hipError_t (*glaunch_fn)(const GroupParams &, hipStream_t);
 glaunch_fn pick_group_launcher(int sampler, int target) {
-    static const glaunch_fn table[4][4] = {
+    static const glaunch_fn table[5][4] = {
         {launch_group<S_ZIGZAG, T_GAUSS_ISO>, launch_group<S_ZIGZAG, T_GAUSS_DIAG>, launch_group<S_ZIGZAG, T_BANANA>, launch_group<S_ZIGZAG, T_GAUSS_DENSE>},
         {launch_group<S_BPS, T_GAUSS_ISO>, launch_group<S_BPS, T_GAUSS_DIAG>, launch_group<S_BPS, T_BANANA>, launch_group<S_BPS, T_GAUSS_DENSE>},
         {launch_group<S_BOOMERANG, T_GAUSS_ISO>, launch_group<S_BOOMERANG, T_GAUSS_DIAG>, launch_group<S_BOOMERANG, T_BANANA>, nullptr},
         {launch_group<S_FECMC, T_GAUSS_ISO>, launch_group<S_FECMC, T_GAUSS_DIAG>, launch_group<S_FECMC, T_BANANA>, nullptr},
+        {launch_group<S_SUZZ, T_GAUSS_ISO>, launch_group<S_SUZZ, T_GAUSS_DIAG>, launch_group<S_SUZZ, T_BANANA>, nullptr},
     };
     return table[sampler][target];
 }
@@ -366,8 +387,8 @@ static int create_impl(const pdmp_config_t *cfg, const char *source, int32_t kin
     HIP_TRY(hipSetDevice(dev));
     if (choose_group_lanes(c) == 0 && c.grid_size == 0)
         return fail(PDMP_ERR_UNSUPPORTED, "grid_size == 0 (Brent constant bound) is served by the group kernel only");
-    if (choose_group_lanes(c) == 0 && c.sampler == PDMP_FECMC)
-        return fail(PDMP_ERR_UNSUPPORTED, "ForwardECMC: dim too large for the LDS tiles of the group kernel");
+    if (choose_group_lanes(c) == 0 && (c.sampler == PDMP_FECMC || c.sampler == PDMP_SUZZ))
+        return fail(PDMP_ERR_UNSUPPORTED, "ForwardECMC / SpeedUpZigZag: dim too large for the LDS tiles of the group kernel");
     if (choose_group_lanes(c) == 0 && c.dim > 4 * WAVE)
         return fail(PDMP_ERR_UNSUPPORTED, "dim > %d needs grid_size = 10 (group kernel); the wave-per-chain kernel holds at most 4 coordinates per lane", 4 * WAVE);
     pdmp_engine *h = new pdmp_engine();
@@ -652,9 +673,10 @@ int pdmp_sample_from_skeleton_dt_device(pdmp_handle h, int64_t C, int64_t n_sk, 
     EventPair ev;
     if (int rc = begin_timed(h, s, ev)) return rc;
     if (h->cfg.sampler == PDMP_BOOMERANG)
-        hipLaunchKernelGGL(from_skeleton_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, dt, (int)discard_vt, out);
+        hipLaunchKernelGGL(from_skeleton_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, dt, (int)discard_vt, out, 0);
     else
-        hipLaunchKernelGGL(from_skeleton_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, dt, (int)discard_vt, out);
+        hipLaunchKernelGGL(from_skeleton_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, dt, (int)discard_vt, out,
+                           (int)(h->cfg.sampler == PDMP_SUZZ));
     HIP_TRY(hipGetLastError());
     return end_timed(h, s, ev);
 }
@@ -692,6 +714,7 @@ int pdmp_sample_from_skeleton_dt(pdmp_handle h, int64_t C, int64_t n_sk, const d
 int pdmp_close_at_time_device(pdmp_handle h, int64_t C, int64_t n_sk, double *X, double *V, double *t, double T,
                               int64_t *count, void *stream) {
     if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
+    if (h->cfg.sampler == PDMP_SUZZ) return fail(PDMP_ERR_UNSUPPORTED, "SpeedUpZigZag: not implemented for this entry point (it needs the non-linear flow, SpeedUpZigZagSamplers.jl:71-79)");
     if (!(T >= 0.0) || !std::isfinite(T)) return fail(PDMP_ERR_ARGUMENT, "T must be finite and non-negative. Current value: %g", T);   // sample.jl:335-337
     if (n_sk <= 0 || C < 0) return fail(PDMP_ERR_ARGUMENT, "n_sk must be positive and C non-negative");
     if (C == 0) return PDMP_OK;
@@ -711,6 +734,7 @@ int pdmp_close_at_time_device(pdmp_handle h, int64_t C, int64_t n_sk, double *X,
 int pdmp_sample_moments_device(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V, const double *t,
                                int64_t N, double *sum_x, double *sum_x2, void *stream) {
     if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
+    if (h->cfg.sampler == PDMP_SUZZ) return fail(PDMP_ERR_UNSUPPORTED, "SpeedUpZigZag: not implemented for this entry point (it needs the non-linear flow, SpeedUpZigZagSamplers.jl:71-79)");
     if (N <= 0) return fail(PDMP_ERR_ARGUMENT, "N must be positive. Current value: %lld", (long long)N);   // sample.jl:476-478
     if (n_sk <= 0) return fail(PDMP_ERR_ARGUMENT, "empty history");
     if (C < 0) return fail(PDMP_ERR_ARGUMENT, "number of chains must be non-negative");

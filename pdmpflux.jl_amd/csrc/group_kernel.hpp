@@ -83,7 +83,8 @@ __device__ __forceinline__ void publish(double *p, double x) {
     __hip_atomic_store((gu64 *)p, (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-struct TimePt { double t, s, c; };   // grid time (+ sin/cos for the Boomerang rotation)
+struct TimePt { double t, s, c, sp, spe; };   // grid time (+ sin/cos for the Boomerang rotation; SpeedUpZigZag: s, c = the flow's
+                                              // scalar v1 X1(t) and its t-derivative, sp, spe = speed(x_t) and its t-derivative)
 
 // flow of one coordinate: ZigZagSamplers.jl:80 / BouncyParticleSamplers.jl:32 (x + v t, v); BoomerangSamplers.jl:31 (rotation)
 template <bool ROT> __device__ __forceinline__ void flow_coord(double x, double v, const TimePt &tp, Dual &xt, Dual &vt) {
@@ -199,6 +200,7 @@ template <int SAMPLER, int TARGET, bool FD, int KC = 0>
 struct GroupChain {
     using Tgt = GTarget<TARGET>;
     static constexpr bool kReg = KC > 0;
+    static constexpr bool kZz = SAMPLER == S_ZIGZAG || SAMPLER == S_SUZZ;   // Zig-Zag family: per-coordinate rates, flips
     static constexpr int kUnroll = KC > 0 ? KC : 1;   // slot loops: fully unrolled in the register form, left alone otherwise
     static_assert(!kReg || (!Tgt::kTile && !Tgt::kUser && KC >= 2), "register form: separable / banana targets only");
     const SkelParams &p;
@@ -230,13 +232,79 @@ struct GroupChain {
             v = vs[s * WAVE + l];
         }
     }
+    // ---- SpeedUpZigZag (SpeedUpZigZagSamplers.jl:71-83).  The closed-form flow is x_t = y + (v1 X1(t)) v with y = x - (v1 x1) v:
+    // per (x, v) a context of chain-level scalars (two dot products), per time point the scalar k(t) = v1 X1(t) as a dual in t
+    // and, for grad-U_effective = speed grad-U - x / speed, speed(x_t) = sqrt(1 + x_t.x_t) as a dual (one more dot product).
+    // Every operation in the order written in the reference; derivatives by the forward-mode rules, no fma.
+    mutable double sz_a = 0.0, sz_A = 0.0, sz_cd = 0.0, sz_base = 0.0, sz_sd = 0.0, sz_v1 = 0.0;
+    mutable bool sz_ok = false;
+    __device__ __forceinline__ void suzz_ctx() const {
+        if (__ballot(!sz_ok) == 0ull) return;
+        double x1, v1;
+        coord(0, x1, v1);
+        const double av = v1 * x1;
+        double yv = 0.0, yy = 0.0;
+        PDMP_SLOTS(s) { const double y = X(s) - av * V(s); yv += y * V(s); yy += y * y; }
+        yv = group_sum(yv, G);
+        yy = group_sum(yy, G);
+        const double dd = (double)p.d;
+        const double c = v1 * yv;
+        sz_a = av;
+        sz_A = (1.0 + yy) / dd - (c * c) / (dd * dd);
+        sz_cd = c / dd;
+        const double Y0 = x1 + sz_cd;
+        sz_base = Y0 + __dsqrt_rn(Y0 * Y0 + sz_A);
+        sz_sd = __dsqrt_rn(dd) * v1;
+        sz_v1 = v1;
+        sz_ok = true;
+    }
+    __device__ __forceinline__ void suzz_speed(TimePt &tp, bool at_state) const {     // speed(x_t) (at_state: of the stored x itself)
+        double sv = 0.0, se = 0.0;
+        PDMP_SLOTS(s) {
+            Dual xt, vt;
+            if (at_state) xt = {X(s), 0.0}; else flow(X(s), V(s), tp, xt, vt);
+            sv += xt.v * xt.v;
+            se += xt.e * xt.v + xt.v * xt.e;
+        }
+        const double s2v = 1.0 + group_sum(sv, G), s2e = group_sum(se, G);
+        tp.sp = __dsqrt_rn(s2v);
+        tp.spe = s2e / (2.0 * tp.sp);
+    }
     __device__ __forceinline__ void time_pt(double t, TimePt &tp) const {
         tp.t = t;
-        if constexpr (SAMPLER == S_BOOMERANG) det_sincos(t, tp.s, tp.c); else { tp.s = 0.0; tp.c = 1.0; }
+        tp.sp = 1.0; tp.spe = 0.0;
+        if constexpr (SAMPLER == S_BOOMERANG) det_sincos(t, tp.s, tp.c);
+        else if constexpr (SAMPLER == S_SUZZ) {
+            suzz_ctx();
+            const double ev = det_exp(sz_sd * t), ee = sz_sd * ev;
+            const double bv = sz_base * ev, be = sz_base * ee;
+            const double b2v = bv * bv, b2e = be * bv + bv * be;
+            const double nv = b2v - sz_A, dv = 2.0 * bv, de = 2.0 * be;
+            const double qv = nv / dv, qe = (b2e - qv * de) / dv;
+            tp.s = sz_v1 * (qv - sz_cd);
+            tp.c = sz_v1 * qe;
+            suzz_speed(tp, false);
+        } else { tp.s = 0.0; tp.c = 1.0; }
     }
-    // flow of one coordinate: ZigZagSamplers.jl:80 / BouncyParticleSamplers.jl:32 / BoomerangSamplers.jl:31
-    template <class T> __device__ __forceinline__ void flow(double x, double v, const TimePt &tp, T &xt, T &vt) const {
-        flow_coord<SAMPLER == S_BOOMERANG>(x, v, tp, xt, vt);
+    // flow of one coordinate: ZigZagSamplers.jl:80 / BouncyParticleSamplers.jl:32 / BoomerangSamplers.jl:31 / SpeedUpZigZagSamplers.jl:71-79
+    __device__ __forceinline__ void flow(double x, double v, const TimePt &tp, Dual &xt, Dual &vt) const {
+        if constexpr (SAMPLER == S_SUZZ) { const double y = x - sz_a * v; xt = {y + tp.s * v, tp.c * v}; vt = {v, 0.0}; }
+        else flow_coord<SAMPLER == S_BOOMERANG>(x, v, tp, xt, vt);
+    }
+    __device__ __forceinline__ void flow(double x, double v, const TimePt &tp, double &xt, double &vt) const {
+        if constexpr (SAMPLER == S_SUZZ) { const double y = x - sz_a * v; xt = y + tp.s * v; vt = v; }
+        else flow_coord<SAMPLER == S_BOOMERANG>(x, v, tp, xt, vt);
+    }
+    // grad-U_effective(x_t) = speed grad-U - x_t / speed (SpeedUpZigZagSamplers.jl:81-83); identity for the other samplers
+    __device__ __forceinline__ Dual eff(Dual g, Dual xt, const TimePt &tp) const {
+        if constexpr (SAMPLER == S_SUZZ) {
+            const double mv = tp.sp * g.v, me = tp.spe * g.v + tp.sp * g.e;
+            const double qv = xt.v / tp.sp, qe = (xt.e - qv * tp.spe) / tp.sp;
+            return {mv - qv, me - qe};
+        } else return g;
+    }
+    __device__ __forceinline__ double eff(double g, double xt, const TimePt &tp) const {
+        if constexpr (SAMPLER == S_SUZZ) return tp.sp * g - xt / tp.sp; else return g;
     }
     // out[i] = sum_j P[i,j] in[j], j left to right per row (row i owned by lane i % 64, slot i / 64).
     // Eight rows per lane are accumulated together so that eight independent 512-byte column pieces are in
@@ -324,7 +392,7 @@ struct GroupChain {
                                               const typename Tgt::template Sh<Dual> &sh, double &val, double &slp) const {
         Dual xt, vt;                                                  // :208-210
         flow(x, v, tp, xt, vt);
-        const Dual gd = tgt.grad(ip, xt, sh);
+        const Dual gd = eff(tgt.grad(ip, xt, sh), xt, tp);
         const double sv = gd.v * vt.v, sd = sdot(gd, vt);
         val = SIGNED ? sv : fmax(0.0, sv);
         slp = SIGNED ? sd : ((0.0 < sv) ? sd : 0.0);
@@ -347,7 +415,7 @@ struct GroupChain {
                                                 const typename Tgt::template Sh<double> &sh) const {
         double xt, vt;
         flow(x, v, tp, xt, vt);
-        const double sv = tgt.grad(ip, xt, sh) * vt;
+        const double sv = eff(tgt.grad(ip, xt, sh), xt, tp) * vt;
         return SIGNED ? sv : fmax(0.0, sv);
     }
     __device__ __forceinline__ static double fd_slope(const FdPt &P, double fc, double fm, double fp) {
@@ -477,9 +545,9 @@ struct GroupChain {
             const bool valid = in_dim(s, i);
             Dual xt, vt;
             flow(X(s), V(s), tp, xt, vt);
-            const Dual gd = tgt.grad(i, xt, sh);
+            const Dual gd = eff(tgt.grad(i, xt, sh), xt, tp);
             double a = gd.v * vt.v, b = sdot(gd, vt);
-            if constexpr (SAMPLER == S_ZIGZAG) {
+            if constexpr (kZz) {
                 b = (0.0 < a) ? b : 0.0;
                 a = fmax(0.0, a);
             }
@@ -487,7 +555,7 @@ struct GroupChain {
             fe += valid ? b : 0.0;
         }
         const double dv = group_sum(fv, G), de = group_sum(fe, G);
-        if constexpr (SAMPLER == S_ZIGZAG) { val = dv; slp = de; return; }
+        if constexpr (kZz) { val = dv; slp = de; return; }
         const bool sgn = p.signed_bound != 0;
         val = (sgn ? dv : fmax(0.0, dv)) + p.refresh;                 // includes refresh_rate (Q2)
         slp = sgn ? de : ((0.0 < dv) ? de : 0.0);
@@ -507,8 +575,8 @@ struct GroupChain {
             for (int q = 0; q < NPT; ++q) {
                 double xt, vt;
                 flow(x, v, tp[q], xt, vt);
-                double a = tgt.grad(i, xt, sh[q]) * vt;
-                if constexpr (SAMPLER == S_ZIGZAG) a = fmax(0.0, a);
+                double a = eff(tgt.grad(i, xt, sh[q]), xt, tp[q]) * vt;
+                if constexpr (kZz) a = fmax(0.0, a);
                 f[q] += valid ? a : 0.0;
             }
         }
@@ -516,7 +584,7 @@ struct GroupChain {
 #pragma unroll
         for (int q = 0; q < NPT; ++q) {
             const double dv = group_sum(f[q], G);
-            if constexpr (SAMPLER == S_ZIGZAG) val[q] = dv;
+            if constexpr (kZz) val[q] = dv;
             else val[q] = (sgn ? dv : fmax(0.0, dv)) + p.refresh;
         }
     }
@@ -536,9 +604,9 @@ struct GroupChain {
             for (int q = 0; q < NP; ++q) {
                 Dual xt, vt;
                 flow(x, v, tp[q], xt, vt);
-                const Dual gd = tgt.grad(i, xt, sh[q]);
+                const Dual gd = eff(tgt.grad(i, xt, sh[q]), xt, tp[q]);
                 double a = gd.v * vt.v, b = sdot(gd, vt);
-                if constexpr (SAMPLER == S_ZIGZAG) {
+                if constexpr (kZz) {
                     b = (0.0 < a) ? b : 0.0;
                     a = fmax(0.0, a);
                 }
@@ -550,7 +618,7 @@ struct GroupChain {
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             const double dv = group_sum(fv[q], G), de = group_sum(fe[q], G);
-            if constexpr (SAMPLER == S_ZIGZAG) { val[q] = dv; slp[q] = de; }
+            if constexpr (kZz) { val[q] = dv; slp[q] = de; }
             else {
                 val[q] = (sgn ? dv : fmax(0.0, dv)) + p.refresh;              // includes refresh_rate (Q2)
                 slp[q] = sgn ? de : ((0.0 < dv) ? de : 0.0);
@@ -698,7 +766,7 @@ struct GroupChain {
     // built in instalments, the others finish in one call)
     __device__ __forceinline__ bool bound_advance(double harg, double E, double &tp, double &lb, int budget) {
         if (p.n_grid == 0) { bound_constant(harg, E, tp, lb); return true; }
-        if constexpr (SAMPLER == S_ZIGZAG) {
+        if constexpr (kZz) {
             if (p.vectorized)
                 return p.signed_bound ? bound_advance_vect<true, FD>(harg, E, tp, lb, budget) : bound_advance_vect<false, FD>(harg, E, tp, lb, budget);
         }
@@ -719,13 +787,13 @@ struct GroupChain {
             const int i = s * G + g;
             double xt, vt;
             flow(X(s), V(s), tp, xt, vt);
-            const double gv = tgt.grad(i, xt, sh) * vt;
-            const double term = (SAMPLER == S_ZIGZAG) ? fmax(0.0, gv) : gv;     // ZigZagSamplers.jl:83-86
+            const double gv = eff(tgt.grad(i, xt, sh), xt, tp) * vt;
+            const double term = (kZz) ? fmax(0.0, gv) : gv;     // ZigZagSamplers.jl:83-86
             acc += (in_dim(s, i)) ? term : 0.0;
         }
         const double tot = group_sum(acc, G);
         raw = tot;
-        if constexpr (SAMPLER == S_ZIGZAG) return tot;
+        if constexpr (kZz) return tot;
         else return fmax(0.0, tot) + p.refresh;                                 // BPS :39-42, Boomerang :38-41
     }
 
@@ -741,6 +809,7 @@ struct GroupChain {
             X(s) = xt;
             if constexpr (SAMPLER == S_BOOMERANG) V(s) = vt;
         }
+        sz_ok = false;
     }
 
     // ---- velocity_jump: ZigZagSamplers.jl:101-107, BouncyParticleSamplers.jl:50-74, BoomerangSamplers.jl:49-67
@@ -870,7 +939,8 @@ struct GroupChain {
     // divergent accept branch, with all 64 lanes of the wave
     __device__ __forceinline__ bool velocity_jump(double raw) {
         TimePt t0;
-        t0.t = 0.0; t0.s = 0.0; t0.c = 1.0;
+        t0.t = 0.0; t0.s = 0.0; t0.c = 1.0; t0.sp = 1.0; t0.spe = 0.0;
+        if constexpr (SAMPLER == S_SUZZ) suzz_speed(t0, true);          // speed(x) of the state itself, SpeedUpZigZagSamplers.jl:104
         typename Tgt::template Sh<double> sh;
         if constexpr (Tgt::kTile) {
             sh = {tgt.tg[0], tgt.tb};            // grad-U at the accepted point: tile 0 was filled by true_rate(tp)
@@ -881,7 +951,7 @@ struct GroupChain {
             if (p.d >= 2) { double x0, v0, x1, v1; coord(0, x0, v0); coord(1, x1, v1); sh = tgt.template shared<double>(x0, x1); }
         }
         const int d = p.d;
-        if constexpr (SAMPLER == S_ZIGZAG) {
+        if constexpr (kZz) {
             const double S = raw;                                        // sum(max.(0, grad-U .* v)), ZigZagSamplers.jl:102-103
             const double u = rng.uniform();                              // Categorical draw
             if (!(S > 0.0)) { guard++; return false; }                         // Q11
@@ -895,7 +965,7 @@ struct GroupChain {
             int ms_hit = -1;
             PDMP_SLOTS(s) {
                 const int i = s * G + g;
-                const double lam = (in_dim(s, i)) ? fmax(0.0, tgt.grad(i, X(s), sh) * V(s)) : 0.0;
+                const double lam = (in_dim(s, i)) ? fmax(0.0, eff(tgt.grad(i, X(s), sh), X(s), t0) * V(s)) : 0.0;
                 const double T = group_sum(lam, G);
                 if (ms_hit < 0 && (carry + T > theta)) { ms_hit = s; carry_at = carry; lam_hit = lam; }
                 carry = carry + T;
@@ -916,6 +986,7 @@ struct GroupChain {
             const int ms = m / G;
             if constexpr (kReg) { PDMP_SLOTS(s) if (s == ms && g == m - ms * G) V(s) = -V(s); }
             else if (g == m - ms * G) V(ms) = -V(ms);                    // v[m] *= -1
+            sz_ok = false;
             return false;
         } else if constexpr (SAMPLER == S_FECMC) {
             return fecmc_jump(sh);
@@ -1087,7 +1158,7 @@ struct GroupChain {
         int mode = FRESH;
         double hB = horizon;
         const int budget = (G == WAVE) ? GNG : cell_budget;               // one chain per wave: nobody to wait for
-        const bool resumable = SAMPLER == S_ZIGZAG && p.vectorized && p.n_grid != 0 && !Tgt::kTile;   // bounds built by bound_advance_vect
+        const bool resumable = kZz && p.vectorized && p.n_grid != 0 && !Tgt::kTile;   // bounds built by bound_advance_vect
 #ifdef PDMP_STAMP
         unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
 #define STAMP(k) do { unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[k] += now_ - st_last; st_last = now_; } while (0)

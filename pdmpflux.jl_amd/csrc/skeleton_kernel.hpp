@@ -15,7 +15,7 @@
 
 namespace pdmp {
 
-enum : int { S_ZIGZAG = 0, S_BPS = 1, S_BOOMERANG = 2, S_FECMC = 3 };   // S_FECMC: group kernel only
+enum : int { S_ZIGZAG = 0, S_BPS = 1, S_BOOMERANG = 2, S_FECMC = 3, S_SUZZ = 4 };   // S_FECMC, S_SUZZ: group kernel only
 
 struct SkelParams {
     int32_t d, n_grid, signed_bound, adaptive, gaussian_velocity, deriv_mode, vectorized;

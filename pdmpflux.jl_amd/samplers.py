@@ -210,3 +210,29 @@ def ForwardECMCAD(dim, target, *, grid_size=10, tmax=2.0, signed_bound=True, ada
     return ForwardECMC(dim, target, grid_size=grid_size, tmax=tmax, signed_bound=signed_bound, adaptive=adaptive,
                        ran_p=ran_p, mix_p=mix_p, switch=switch, positive=positive, AD_backend=AD_backend,
                        speed_factor=speed_factor, **kw)
+
+
+class SpeedUpZigZag(AbstractPDMP):
+    """SpeedUpZigZag(dim, grad-U; grid_size=10, tmax=2.0, refresh_rate=0.0, vectorized_bound=true, signed_bound=true,
+    adaptive=true, AD_backend="FiniteDiff") (SpeedUpZigZagSamplers.jl:56-59): the Zig-Zag loop with the closed-form
+    non-linear flow (:71-79) and grad-U_effective = speed grad-U - grad speed, speed(x) = sqrt(1 + |x|^2) (:81-83).
+    ``sample_skeleton`` and ``sample_from_skeleton`` (which interpolates with this flow, sample.jl:499); the fused moment
+    sums and the device-side time-horizon cut are not implemented for it."""
+    sampler_id = 4
+    name = "SpeedUpZigZag"
+
+    def __init__(self, dim, target, *, grid_size=10, tmax=2.0, refresh_rate=0.0, vectorized_bound=True,
+                 signed_bound=True, adaptive=True, AD_backend="FiniteDiff", **kw):
+        if signed_bound and not vectorized_bound:                                      # :65-68
+            warnings.warn("Signed bound is not compatible with non-vectorized bound for ZigZag, switching to unsigned bound")
+            signed_bound = False
+        super().__init__(dim, target, grid_size=grid_size, tmax=tmax, refresh_rate=refresh_rate,
+                         vectorized_bound=vectorized_bound, signed_bound=signed_bound, adaptive=adaptive,
+                         AD_backend=AD_backend, **kw)
+
+
+def SpeedUpZigZagAD(dim, target, *, refresh_rate=0.0, grid_size=10, tmax=2.0, vectorized_bound=True, signed_bound=True,
+                    adaptive=True, AD_backend="ForwardDiff", **kw):                   # SpeedUpZigZagSamplers.jl:120-130
+    return SpeedUpZigZag(dim, target, refresh_rate=refresh_rate, grid_size=grid_size, tmax=tmax,
+                         vectorized_bound=vectorized_bound, signed_bound=signed_bound, adaptive=adaptive,
+                         AD_backend=AD_backend, **kw)

@@ -27,7 +27,7 @@ def make_pair(P, O, kind, dim, target="iso", arith=None, **kw):
         raise ValueError(target)
     ctor = {"ZigZag": P.ZigZag, "ZigZagAD": P.ZigZagAD, "BPS": P.BPS, "BPSAD": P.BPSAD,
             "Boomerang": P.Boomerang, "BoomerangAD": P.BoomerangAD, "ForwardECMC": P.ForwardECMC,
-            "ForwardECMCAD": P.ForwardECMCAD}[kind]
+            "ForwardECMCAD": P.ForwardECMCAD, "SpeedUpZigZag": P.SpeedUpZigZag, "SpeedUpZigZagAD": P.SpeedUpZigZagAD}[kind]
     s = ctor(dim, tg, **kw)
     group = 1
     if arith is None:                       # match the summation order the engine uses for this configuration
@@ -49,7 +49,7 @@ def make_init(kind, dim, C, seed=0, target="iso"):
         x = 1.0 + 0.1 * x
     if target == "src_funnel":                   # U_funnel lives on x[1] > 0 (log(v), test/test_config.jl:38-42)
         x[:, 0] = 2.0 + 0.2 * x[:, 0]
-    if kind.startswith("ZigZag"):
+    if kind.startswith(("ZigZag", "SpeedUpZigZag")):
         v = rs.choice([-1.0, 1.0], size=(C, dim))
     elif kind.startswith("BPS") or kind.startswith("ForwardECMC"):
         v = rs.normal(size=(C, dim))
