@@ -477,9 +477,7 @@ struct GroupChain {
                     PDMP_SLOTS(s) {
                         const int i = s * G + g;
                         const int ip = (in_dim(s, i)) ? i : 0;
-                        const double x = X(s);
-                        double v = V(s);
-                        if constexpr (kReg) asm volatile("" : "+v"(v));       // keeps v*v (same for every cell) from being hoisted into KC more registers
+                        const double x = X(s), v = V(s);
                         double v0, g0, v1, g1;
                         eval_vect<SIGNED>(ip, x, v, p0, sh0, v0, g0);
                         eval_vect<SIGNED>(ip, x, v, p1, sh1, v1, g1);
