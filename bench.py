@@ -240,8 +240,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(a),
                          "kernel": kernel, "kernel_ms": kernel_ms, "bytes_per_event": bytes_per_event,
-                         "note": "fp64 state machine bound by VALU issue (config 2: 122 VALU instructions per event, VALU busy 83 % "
-                                 "at 2 waves/SIMD, profiles/r1/final2_zz_iso_pmc.json); HBM fraction is the requested headline"},
+                         "note": "fp64 state machine bound by VALU issue (config 2: 115 VALU instructions per event, VALU busy 81 % "
+                                 "at 2 waves/SIMD, profiles/r1/final3_zz_iso_pmc.json); HBM fraction is the requested headline"},
         }
         phases = int(_lib.lib().pdmp_dense_batched_last_phases()) if a.target == "dense" else 0
         if phases > 0:      # dense-precision path: the dominant kernel is the fp64 GEMM P x [requests | velocities] per phase
