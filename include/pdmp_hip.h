@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PDMP_ABI_VERSION 3   /* 2: + pdmp_create_from_source, PDMP_T_USER; 3: + PDMP_FECMC and its keywords at the end of pdmp_config_t */
+#define PDMP_ABI_VERSION 4   /* 2: + pdmp_create_from_source, PDMP_T_USER; 3: + PDMP_FECMC and its keywords at the end of pdmp_config_t; 4: + PDMP_SUZZ, PDMP_RHMC and its keywords */
 
 enum { PDMP_OK = 0, PDMP_ERR_ARGUMENT = -1, PDMP_ERR_DIMENSION = -2, PDMP_ERR_RUNTIME = -3,
        PDMP_ERR_ITERCAP = -4, PDMP_ERR_UNSUPPORTED = -5 };
@@ -41,7 +41,8 @@ enum { PDMP_OK = 0, PDMP_ERR_ARGUMENT = -1, PDMP_ERR_DIMENSION = -2, PDMP_ERR_RU
 /* src/Samplers/ZigZagSamplers.jl:35-116, BouncyParticleSamplers.jl:1-84, BoomerangSamplers.jl:1-77,
  * ForwardEventChainMonteCarlo.jl:262-344 (ForwardECMC with its default velocity jump, :127-175) */
 enum { PDMP_ZIGZAG = 0, PDMP_BPS = 1, PDMP_BOOMERANG = 2, PDMP_FECMC = 3,
-       PDMP_SUZZ = 4 /* SpeedUpZigZag, src/Samplers/SpeedUpZigZagSamplers.jl (sample_skeleton only) */ };
+       PDMP_SUZZ = 4, /* SpeedUpZigZag, src/Samplers/SpeedUpZigZagSamplers.jl */
+       PDMP_RHMC = 5  /* RHMC, src/Samplers/RandomizedHamiltonianMonteCarlo.jl (velocity-Verlet flow, constant refresh clock) */ };
 /* Potential descriptors replacing the Julia closure field `grad-U` (ZigZagSamplers.jl:37): */
 enum { PDMP_T_GAUSS_ISO = 0,   /* U = |x|^2/2                         (README.md:36-38)            */
        PDMP_T_GAUSS_DIAG = 1,  /* U = sum prec_i (x_i-mu_i)^2/2 ; params = mu[d], prec[d]            */
@@ -54,7 +55,7 @@ enum { PDMP_DERIV_FORWARD = 0 /* "ForwardDiff": exact forward-mode duals */,
 
 /* Keyword arguments of the reference constructors as a plain struct. */
 typedef struct pdmp_config_t {
-    int32_t sampler;            /* PDMP_ZIGZAG | PDMP_BPS | PDMP_BOOMERANG | PDMP_FECMC | PDMP_SUZZ */
+    int32_t sampler;            /* PDMP_ZIGZAG | PDMP_BPS | PDMP_BOOMERANG | PDMP_FECMC | PDMP_SUZZ | PDMP_RHMC */
     int32_t dim;                /* > 0 */
     int32_t grid_size;          /* 2..64 grid bound; 0 = Brent constant bound (UpperBound.jl:18-36) */
     int32_t vectorized_bound;   /* ZigZag default 1; forced 0 for BPS/Boomerang */
@@ -73,6 +74,9 @@ typedef struct pdmp_config_t {
      * ignored by the other samplers.  speed_factor != 1 and normal = true are not implemented. */
     double  fe_mix_p;
     int32_t fe_ran_p, fe_switch, fe_positive, fe_reserved;
+    /* RHMC(dim, grad-U; refresh_rate = 1.0 (or 1 / mean_duration), phi = pi/2, step_size = 0.05, tmax = 10.0, adaptive = false)
+     * (RandomizedHamiltonianMonteCarlo.jl:48-57); ignored by the other samplers. */
+    double  rh_step_size, rh_phi;
 } pdmp_config_t;
 
 typedef struct pdmp_engine *pdmp_handle;

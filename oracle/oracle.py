@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libpdmp_oracle.so")
 
-ZIGZAG, BPS, BOOMERANG, FECMC, SUZZ = 0, 1, 2, 3, 4
+ZIGZAG, BPS, BOOMERANG, FECMC, SUZZ, RHMC = 0, 1, 2, 3, 4, 5
 T_GAUSS_ISO, T_GAUSS_DIAG, T_BANANA, T_GAUSS_DENSE = 0, 1, 2, 3
 T_AD_BANANA, T_AD_FUNNEL, T_AD_RIDGED = 16, 17, 18      # grad-U by forward mode over U (ad_potentials.c)
 DERIV_FORWARD, DERIV_FINITE_DIFF = 0, 1
@@ -34,6 +34,7 @@ class _Cfg(C.Structure):
         ("tape_exp", C.POINTER(C.c_double)), ("tape_uni", C.POINTER(C.c_double)), ("tape_nrm", C.POINTER(C.c_double)),
         ("tape_n_exp", C.c_int64), ("tape_n_uni", C.c_int64), ("tape_n_nrm", C.c_int64),
         ("fe_mix_p", C.c_double), ("fe_ran_p", C.c_int32), ("fe_switch", C.c_int32), ("fe_positive", C.c_int32),
+        ("rh_reserved", C.c_int32), ("rh_step_size", C.c_double), ("rh_phi", C.c_double),
     ]
 
 
@@ -115,6 +116,8 @@ class Config:
     ran_p: bool = False
     switch: bool = True
     positive: bool = True
+    step_size: float = 0.05            # RHMC keywords (RandomizedHamiltonianMonteCarlo.jl:48-57)
+    phi: float = 1.5707963267948966
     _keep: list = field(default_factory=list, repr=False)
 
     def c(self) -> _Cfg:
@@ -133,7 +136,8 @@ class Config:
         return _Cfg(self.sampler, self.dim, self.grid_size, int(self.vectorized_bound), int(self.signed_bound),
                     int(self.adaptive), int(self.gaussian_velocity), self.deriv_mode, self.target_id, self.arith,
                     float(self.tmax), float(self.refresh_rate), p, n, self.max_iter_per_event, self.group_lanes,
-                    te, tu, tn, ne, nu, nn, float(self.mix_p), int(self.ran_p), int(self.switch), int(self.positive))
+                    te, tu, tn, ne, nu, nn, float(self.mix_p), int(self.ran_p), int(self.switch), int(self.positive), 0,
+                    float(self.step_size), float(self.phi))
 
 
 def _check(rc):

@@ -525,6 +525,7 @@ static void fd_points(double t, double horizon, double *tm, double *tp) {
 
 /* The unsigned total rate used by the accept test (always `sampler.rate`, SamplingLoopInplace.jl:116; Q3) */
 static double true_rate(const orc_config_t *cfg, ws_t *w, double t) {
+    if (cfg->sampler == ORC_RHMC) return cfg->refresh_rate;          /* rate = (_x0, _v0, _t) -> refresh_rate, :133 */
     flow_dual(cfg, w, w->x, w->v, t);
     grad_dual(cfg, w->xv, w->xe, w->gv, w->ge);
     if (cfg->sampler == ORC_SUZZ) suzz_effective(cfg, w, w->xv, w->xe, w->gv, w->ge);
@@ -543,7 +544,8 @@ static double brent_max_rate(const orc_config_t *cfg, ws_t *w, double x_lower, d
 static void upper_bound(const orc_config_t *cfg, ws_t *w, const double *x, const double *v, double horizon) {
     const int d = w->d, n = w->n;
     if (cfg->grid_size == 0) {                      /* constant bound, AbstractPDMP.jl:121-125 (x, v are the state: w->x, w->v) */
-        const double m = brent_max_rate(cfg, w, 0.0, horizon);
+        /* RHMC: its own init_state builds the 2-point BoundBox of the constant rate (RandomizedHamiltonianMonteCarlo.jl:208-218) */
+        const double m = (cfg->sampler == ORC_RHMC) ? cfg->refresh_rate : brent_max_rate(cfg, w, 0.0, horizon);
         w->grid[0] = 0.0; w->grid[1] = horizon;     /* :27 */
         w->box[0] = m;                              /* refresh_rate = 0.0 default: nothing added, :29 */
         w->cum[0] = 0.0; w->cum[1] = m * (horizon - 0.0);   /* :32-33 */
@@ -711,7 +713,26 @@ double orc_upper_bound(const orc_config_t *cfg, const double *x, const double *v
 }
 
 /* in-place flow of the state (no dual) */
+/* velocity-Verlet flow of RHMC (RandomizedHamiltonianMonteCarlo.jl:97-130) on (x, v) in place: n = floor(t/h) steps of size h and
+ * one of size r = t - n h; g, xe, ge are d-vector scratch. */
+static void rhmc_step(const orc_config_t *cfg, double *x, double *v, int d, double h, double *xe, double *g, double *ge) {
+    grad_dual(cfg, x, xe, g, ge);
+    for (int i = 0; i < d; ++i) { v[i] = v[i] - (0.5 * h) * g[i]; x[i] = x[i] + h * v[i]; }
+    grad_dual(cfg, x, xe, g, ge);
+    for (int i = 0; i < d; ++i) v[i] = v[i] - (0.5 * h) * g[i];
+}
+static void rhmc_flow(const orc_config_t *cfg, double *x, double *v, int d, double t, double *xe, double *g, double *ge) {
+    if (t == 0.0) return;
+    for (int i = 0; i < d; ++i) xe[i] = 0.0;
+    const double h = cfg->rh_step_size;
+    const int64_t n = (int64_t)floor(t / h);
+    const double r = t - (double)n * h;
+    for (int64_t k = 0; k < n; ++k) rhmc_step(cfg, x, v, d, h, xe, g, ge);
+    if (r > 0.0) rhmc_step(cfg, x, v, d, r, xe, g, ge);
+}
+
 static void flow_state(const orc_config_t *cfg, ws_t *w, double t) {
+    if (cfg->sampler == ORC_RHMC) { rhmc_flow(cfg, w->x, w->v, w->d, t, w->xe, w->gv, w->ge); return; }
     if (cfg->sampler == ORC_SUZZ) {                      /* SpeedUpZigZagSamplers.jl:71-79 */
         suzz_flow_dual(cfg, w, w->x, w->v, t);
         for (int i = 0; i < w->d; ++i) w->x[i] = w->xv[i];
@@ -803,6 +824,13 @@ static int fecmc_jump(const orc_config_t *cfg, ws_t *w, rng_t *rng) {
 /* velocity_jump: ZigZagSamplers.jl:101-107, BouncyParticleSamplers.jl:50-74, BoomerangSamplers.jl:49-67 */
 static int velocity_jump(const orc_config_t *cfg, ws_t *w, rng_t *rng) {
     const int d = w->d;
+    if (cfg->sampler == ORC_RHMC) {                /* Horowitz refreshment v <- cos(phi) v + sin(phi) xi, :144-149 */
+        double sphi, cphi;
+        orc_sincos(cfg->rh_phi, &sphi, &cphi);
+        rng_normals(rng, d, w->tmp);
+        for (int i = 0; i < d; ++i) w->v[i] = cphi * w->v[i] + sphi * w->tmp[i];
+        return 0;
+    }
     for (int i = 0; i < d; ++i) { w->xe[i] = 0.0; }
     grad_dual(cfg, w->x, w->xe, w->gv, w->ge);
     if (cfg->sampler == ORC_SUZZ) suzz_effective(cfg, w, w->x, w->xe, w->gv, w->ge);     /* SpeedUpZigZagSamplers.jl:104 */
@@ -854,7 +882,13 @@ int orc_normalize_config(orc_config_t *c) {
     if (c->dim <= 0) FAIL(-1, "dimension dim must be positive. Current value: %d", c->dim);           /* ZigZagSamplers.jl:62-64 */
     if (c->grid_size < 0) FAIL(-1, "grid_size must be non-negative. Current value: %d", c->grid_size); /* :66-68 */
     if (c->grid_size == 1) FAIL(-1, "grid_size == 1: range(...)[2] is a BoundsError in the reference");
-    if (c->sampler < 0 || c->sampler > 4) FAIL(-1, "unknown sampler id %d", c->sampler);
+    if (c->sampler < 0 || c->sampler > 5) FAIL(-1, "unknown sampler id %d", c->sampler);
+    if (c->sampler == ORC_RHMC) {                                                                     /* RandomizedHamiltonianMonteCarlo.jl:59-95 */
+        if (!(c->refresh_rate > 0.0) || !isfinite(c->refresh_rate)) FAIL(-1, "refresh_rate must be finite and positive. Current value: %g", c->refresh_rate);
+        if (!(0.0 < c->rh_phi && c->rh_phi <= 1.5707963267948966)) FAIL(-1, "phi must satisfy 0 < phi <= pi/2. Current value: %g", c->rh_phi);
+        if (!(c->rh_step_size > 0.0) || !isfinite(c->rh_step_size)) FAIL(-1, "step_size must be finite and positive. Current value: %g", c->rh_step_size);
+        c->grid_size = 0; c->vectorized_bound = 0; c->signed_bound = 0;
+    }
     if (c->sampler == ORC_FECMC) {                                                                    /* ForwardEventChainMonteCarlo.jl:298-310 */
         if (c->dim < 2) FAIL(-1, "The dimension must be at least 2 to use the ForwardEventChain. Got dimension %d", c->dim);
         if (c->dim == 2) c->fe_mix_p = 0.0;
@@ -1030,7 +1064,13 @@ int orc_sample_from_skeleton_dt(const orc_config_t *cfg, int64_t C, int64_t n_sk
             double tau = tm - tc[i];                                                         /* :497 */
             const double *x0 = Xc + (size_t)i * d, *v0 = Vc + (size_t)i * d;
             double *o = oc + (size_t)(j - 1) * rows;
-            if (cfg->sampler == ORC_SUZZ) {             /* the sampler's own flow (sample.jl:499), SpeedUpZigZagSamplers.jl:71-79; dot
+            if (cfg->sampler == ORC_RHMC) {             /* the sampler's own flow (sample.jl:499): velocity-Verlet from the event's (x, v) */
+                double *xb = malloc((size_t)d * 8 * 5), *vb = xb + d, *xe = vb + d, *g = xe + d, *ge = g + d;
+                for (int q = 0; q < d; ++q) { xb[q] = x0[q]; vb[q] = v0[q]; }
+                rhmc_flow(cfg, xb, vb, d, tau, xe, g, ge);
+                for (int q = 0; q < d; ++q) { o[q] = xb[q]; if (!discard_vt) o[d + q] = vb[q]; }
+                free(xb);
+            } else if (cfg->sampler == ORC_SUZZ) {      /* the sampler's own flow (sample.jl:499), SpeedUpZigZagSamplers.jl:71-79; dot
                                                          * products in the engine's wave order (lane q sums q, q+64, ...; butterfly) */
                 double *yb = malloc((size_t)d * 8), *pb = malloc((size_t)d * 8);
                 const double av = v0[0] * x0[0], dd = (double)d;

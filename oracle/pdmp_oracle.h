@@ -21,7 +21,8 @@ extern "C" {
 /* sampler ids -- src/Samplers/{ZigZag,BouncyParticle,Boomerang}Samplers.jl */
 enum { ORC_ZIGZAG = 0, ORC_BPS = 1, ORC_BOOMERANG = 2,
        ORC_FECMC = 3, /* ForwardECMC, src/Samplers/ForwardEventChainMonteCarlo.jl (default velocity jump, :127-175) */
-       ORC_SUZZ = 4   /* SpeedUpZigZag, src/Samplers/SpeedUpZigZagSamplers.jl: closed-form non-linear flow (:71-79), effective gradient (:81-83) */ };
+       ORC_SUZZ = 4,  /* SpeedUpZigZag, src/Samplers/SpeedUpZigZagSamplers.jl: closed-form non-linear flow (:71-79), effective gradient (:81-83) */
+       ORC_RHMC = 5   /* RHMC, src/Samplers/RandomizedHamiltonianMonteCarlo.jl: velocity-Verlet flow (:97-130), constant refresh clock, Horowitz refreshment (:144-149) */ };
 /* built-in potentials (closures cannot cross a C ABI) */
 enum { ORC_T_GAUSS_ISO = 0, ORC_T_GAUSS_DIAG = 1, ORC_T_BANANA = 2, ORC_T_GAUSS_DENSE = 3,
        /* grad-U by forward-mode differentiation of a scalar potential (ADBackend.jl:95-109), ad_potentials.c:
@@ -63,6 +64,9 @@ typedef struct orc_config_t {
     /* ForwardECMC keywords (ForwardEventChainMonteCarlo.jl:290-292): mix_p = 0.5, ran_p = false, switch = true, positive = true */
     double  fe_mix_p;
     int32_t fe_ran_p, fe_switch, fe_positive;
+    int32_t rh_reserved;
+    /* RHMC keywords (RandomizedHamiltonianMonteCarlo.jl:48-57): step_size = 0.05, phi = pi/2 (refresh_rate = 1, tmax = 10, adaptive = false) */
+    double  rh_step_size, rh_phi;
 } orc_config_t;
 
 const char *orc_last_error(void);

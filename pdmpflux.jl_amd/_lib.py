@@ -40,7 +40,7 @@ class Config(C.Structure):
         ("target_params", C.POINTER(C.c_double)), ("n_target_params", C.c_int64),
         ("max_iter_per_event", C.c_int64),
         ("fe_mix_p", C.c_double), ("fe_ran_p", C.c_int32), ("fe_switch", C.c_int32), ("fe_positive", C.c_int32),
-        ("fe_reserved", C.c_int32),
+        ("fe_reserved", C.c_int32), ("rh_step_size", C.c_double), ("rh_phi", C.c_double),
     ]
 
 
@@ -105,7 +105,7 @@ def lib():
     L.pdmp_reset_timing.argtypes = [vp]
     L.pdmp_debug_rng.argtypes = [vp, u64, i64, i32, i64, vp]
     L.pdmp_dense_batched_last_phases.restype = C.c_longlong
-    if L.pdmp_abi_version() != 3:
+    if L.pdmp_abi_version() != 4:
         raise EngineError(ERR_RUNTIME, "ABI version mismatch")
     _lib = L
     return L

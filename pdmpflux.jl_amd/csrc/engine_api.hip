@@ -248,7 +248,14 @@ int normalize_config(pdmp_config_t &c, bool from_source = false) {
     if (c.dim <= 0) return fail(PDMP_ERR_ARGUMENT, "dimension dim must be positive. Current value: %d", c.dim);          // ZigZagSamplers.jl:62-64
     if (c.grid_size < 0) return fail(PDMP_ERR_ARGUMENT, "grid_size must be non-negative. Current value: %d", c.grid_size); // :66-68
     if (c.grid_size == 1 || c.grid_size > WAVE) return fail(PDMP_ERR_UNSUPPORTED, "grid_size must be in 2..64. Current value: %d", c.grid_size);
-    if (c.sampler < PDMP_ZIGZAG || c.sampler > PDMP_SUZZ) return fail(PDMP_ERR_ARGUMENT, "unknown sampler id %d", c.sampler);
+    if (c.sampler < PDMP_ZIGZAG || c.sampler > PDMP_RHMC) return fail(PDMP_ERR_ARGUMENT, "unknown sampler id %d", c.sampler);
+    if (c.sampler == PDMP_RHMC) {                                                                    // RandomizedHamiltonianMonteCarlo.jl:59-95
+        if (!(c.refresh_rate > 0.0) || !std::isfinite(c.refresh_rate)) return fail(PDMP_ERR_ARGUMENT, "refresh_rate must be finite and positive. Current value: %g", c.refresh_rate);
+        if (!(0.0 < c.rh_phi && c.rh_phi <= 1.5707963267948966)) return fail(PDMP_ERR_ARGUMENT, "phi must satisfy 0 < phi <= pi/2. Current value: %g", c.rh_phi);
+        if (!(c.rh_step_size > 0.0) || !std::isfinite(c.rh_step_size)) return fail(PDMP_ERR_ARGUMENT, "step_size must be finite and positive. Current value: %g", c.rh_step_size);
+        if (c.target_id == PDMP_T_GAUSS_DENSE) return fail(PDMP_ERR_UNSUPPORTED, "RHMC: no dense-precision target");
+        c.grid_size = 0; c.vectorized_bound = 0; c.signed_bound = 0;                                  // :91-95
+    }
     if (c.sampler == PDMP_SUZZ) {
         if (c.target_id == PDMP_T_GAUSS_DENSE || c.target_id == PDMP_T_USER) return fail(PDMP_ERR_UNSUPPORTED, "SpeedUpZigZag: built-in separable / banana targets only");
         if (c.grid_size != GNG && c.grid_size != 0) return fail(PDMP_ERR_UNSUPPORTED, "SpeedUpZigZag runs on the group kernel: grid_size = 10 (or 0, Brent)");
@@ -298,12 +305,13 @@ launch_fn pick_launcher(int sampler, int target) {
 
 typedef hipError_t (*glaunch_fn)(const GroupParams &, hipStream_t);
 glaunch_fn pick_group_launcher(int sampler, int target) {
-    static const glaunch_fn table[5][4] = {
+    static const glaunch_fn table[6][4] = {
         {launch_group<S_ZIGZAG, T_GAUSS_ISO>, launch_group<S_ZIGZAG, T_GAUSS_DIAG>, launch_group<S_ZIGZAG, T_BANANA>, launch_group<S_ZIGZAG, T_GAUSS_DENSE>},
         {launch_group<S_BPS, T_GAUSS_ISO>, launch_group<S_BPS, T_GAUSS_DIAG>, launch_group<S_BPS, T_BANANA>, launch_group<S_BPS, T_GAUSS_DENSE>},
         {launch_group<S_BOOMERANG, T_GAUSS_ISO>, launch_group<S_BOOMERANG, T_GAUSS_DIAG>, launch_group<S_BOOMERANG, T_BANANA>, nullptr},
         {launch_group<S_FECMC, T_GAUSS_ISO>, launch_group<S_FECMC, T_GAUSS_DIAG>, launch_group<S_FECMC, T_BANANA>, nullptr},
         {launch_group<S_SUZZ, T_GAUSS_ISO>, launch_group<S_SUZZ, T_GAUSS_DIAG>, launch_group<S_SUZZ, T_BANANA>, nullptr},
+        {launch_group<S_RHMC, T_GAUSS_ISO>, launch_group<S_RHMC, T_GAUSS_DIAG>, launch_group<S_RHMC, T_BANANA>, nullptr},
     };
     return table[sampler][target];
 }
@@ -387,8 +395,8 @@ static int create_impl(const pdmp_config_t *cfg, const char *source, int32_t kin
     HIP_TRY(hipSetDevice(dev));
     if (choose_group_lanes(c) == 0 && c.grid_size == 0)
         return fail(PDMP_ERR_UNSUPPORTED, "grid_size == 0 (Brent constant bound) is served by the group kernel only");
-    if (choose_group_lanes(c) == 0 && (c.sampler == PDMP_FECMC || c.sampler == PDMP_SUZZ))
-        return fail(PDMP_ERR_UNSUPPORTED, "ForwardECMC / SpeedUpZigZag: dim too large for the LDS tiles of the group kernel");
+    if (choose_group_lanes(c) == 0 && (c.sampler == PDMP_FECMC || c.sampler == PDMP_SUZZ || c.sampler == PDMP_RHMC))
+        return fail(PDMP_ERR_UNSUPPORTED, "ForwardECMC / SpeedUpZigZag / RHMC: dim too large for the LDS tiles of the group kernel");
     if (choose_group_lanes(c) == 0 && c.dim > 4 * WAVE)
         return fail(PDMP_ERR_UNSUPPORTED, "dim > %d needs grid_size = 10 (group kernel); the wave-per-chain kernel holds at most 4 coordinates per lane", 4 * WAVE);
     pdmp_engine *h = new pdmp_engine();
@@ -492,6 +500,7 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
     p.C = C; p.n_sk = n_sk; p.chain0 = chain_id_offset; p.cap = c.max_iter_per_event; p.seed = seed;
     p.tmax = c.tmax; p.refresh = c.refresh_rate;
     p.fe_mix_p = c.fe_mix_p; p.fe_ran_p = c.fe_ran_p; p.fe_switch = c.fe_switch; p.fe_positive = c.fe_positive;
+    p.rh_step_size = c.rh_step_size; p.rh_phi = c.rh_phi;
     p.xinit = xinit; p.vinit = vinit; p.tparams = h->d_tparams;
     p.X = X; p.V = V; p.t = t;
     if (diag) {
@@ -660,6 +669,7 @@ int pdmp_sample_from_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, con
 int pdmp_sample_from_skeleton_dt_device(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
                                         const double *t, int64_t N, double dt, int32_t discard_vt, double *out, void *stream) {
     if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
+    if (h->cfg.sampler == PDMP_RHMC) return fail(PDMP_ERR_UNSUPPORTED, "RHMC: sample_from_skeleton needs the velocity-Verlet flow (not implemented on the device yet)");
     if (!(dt >= 0.0) || !std::isfinite(dt)) return fail(PDMP_ERR_ARGUMENT, "dt must be finite and non-negative");
     if (N <= 0) return fail(PDMP_ERR_ARGUMENT, "N must be positive. Current value: %lld", (long long)N);   // sample.jl:476-478
     if (n_sk <= 0) return fail(PDMP_ERR_ARGUMENT, "empty history");
@@ -714,7 +724,7 @@ int pdmp_sample_from_skeleton_dt(pdmp_handle h, int64_t C, int64_t n_sk, const d
 int pdmp_close_at_time_device(pdmp_handle h, int64_t C, int64_t n_sk, double *X, double *V, double *t, double T,
                               int64_t *count, void *stream) {
     if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
-    if (h->cfg.sampler == PDMP_SUZZ) return fail(PDMP_ERR_UNSUPPORTED, "SpeedUpZigZag: not implemented for this entry point (it needs the non-linear flow, SpeedUpZigZagSamplers.jl:71-79)");
+    if (h->cfg.sampler == PDMP_SUZZ || h->cfg.sampler == PDMP_RHMC) return fail(PDMP_ERR_UNSUPPORTED, "SpeedUpZigZag / RHMC: not implemented for this entry point (it needs the sampler's own flow)");
     if (!(T >= 0.0) || !std::isfinite(T)) return fail(PDMP_ERR_ARGUMENT, "T must be finite and non-negative. Current value: %g", T);   // sample.jl:335-337
     if (n_sk <= 0 || C < 0) return fail(PDMP_ERR_ARGUMENT, "n_sk must be positive and C non-negative");
     if (C == 0) return PDMP_OK;
@@ -734,7 +744,7 @@ int pdmp_close_at_time_device(pdmp_handle h, int64_t C, int64_t n_sk, double *X,
 int pdmp_sample_moments_device(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V, const double *t,
                                int64_t N, double *sum_x, double *sum_x2, void *stream) {
     if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
-    if (h->cfg.sampler == PDMP_SUZZ) return fail(PDMP_ERR_UNSUPPORTED, "SpeedUpZigZag: not implemented for this entry point (it needs the non-linear flow, SpeedUpZigZagSamplers.jl:71-79)");
+    if (h->cfg.sampler == PDMP_SUZZ || h->cfg.sampler == PDMP_RHMC) return fail(PDMP_ERR_UNSUPPORTED, "SpeedUpZigZag / RHMC: not implemented for this entry point (it needs the sampler's own flow)");
     if (N <= 0) return fail(PDMP_ERR_ARGUMENT, "N must be positive. Current value: %lld", (long long)N);   // sample.jl:476-478
     if (n_sk <= 0) return fail(PDMP_ERR_ARGUMENT, "empty history");
     if (C < 0) return fail(PDMP_ERR_ARGUMENT, "number of chains must be non-negative");

@@ -763,6 +763,13 @@ struct GroupChain {
     // one pass over the bound of every lane that is in the BOUND phase; true = finished (only the vectorized grid bound is
     // built in instalments, the others finish in one call)
     __device__ __forceinline__ bool bound_advance(double harg, double E, double &tp, double &lb, int budget) {
+        if constexpr (SAMPLER == S_RHMC) {      // the 2-point BoundBox of the constant refresh clock (RandomizedHamiltonianMonteCarlo.jl:208-218) + next_event
+            const double m = p.refresh;
+            const double c1 = m * (harg - 0.0);
+            lb = m;
+            tp = (c1 < E) ? __builtin_huge_val() : 0.0 + (E - 0.0) / (c1 - 0.0) * (harg - 0.0);
+            return true;
+        }
         if (p.n_grid == 0) { bound_constant(harg, E, tp, lb); return true; }
         if constexpr (kZz) {
             if (p.vectorized)
@@ -777,6 +784,7 @@ struct GroupChain {
     // point evaluated here (same expression x + v*tp, same stored doubles), so the velocity jump's
     // sum(lambda) (Zig-Zag) / dot(grad-U, v) (BPS) is this very number and is not recomputed.
     __device__ __forceinline__ double true_rate(double t, double &raw) {
+        if constexpr (SAMPLER == S_RHMC) { raw = 0.0; return p.refresh; }      // rate = (_x0, _v0, _t) -> refresh_rate, :133
         TimePt tp;
         time_pt(t, tp);
         const auto sh = shared_at<double>(tp);
@@ -795,7 +803,50 @@ struct GroupChain {
         else return fmax(0.0, tot) + p.refresh;                                 // BPS :39-42, Boomerang :38-41
     }
 
-    __device__ __forceinline__ void flow_state(double t) const {
+    // grad-U's shared part at the stored state itself (no flow)
+    __device__ __forceinline__ typename Tgt::template Sh<double> shared_state() {
+        typename Tgt::template Sh<double> sh{};
+        if constexpr (Tgt::kUser) {
+            TimePt t0; t0.t = 0.0; t0.s = 0.0; t0.c = 1.0; t0.sp = 1.0; t0.spe = 0.0;
+            sh = shared_at<double>(t0);
+        } else if constexpr (Tgt::kShared && !Tgt::kTile) {
+            if (p.d >= 2) { double x0, v0, x1, v1; coord(0, x0, v0); coord(1, x1, v1); sh = tgt.template shared<double>(x0, x1); }
+        }
+        return sh;
+    }
+    // ---- RHMC: velocity-Verlet flow (RandomizedHamiltonianMonteCarlo.jl:97-130) of (x, v) in place: n = floor(t/h) steps of
+    // size h and one of size r = t - n h; chains of a wave take their own numbers of steps (per-lane predicate).
+    __device__ __forceinline__ void rhmc_step(double hh) {
+        auto sh = shared_state();
+        PDMP_SLOTS(s) {
+            const int i = s * G + g;
+            if (in_dim(s, i)) {
+                const double gi = tgt.grad(i, X(s), sh);
+                V(s) = V(s) - (0.5 * hh) * gi;
+                X(s) = X(s) + hh * V(s);
+            }
+        }
+        sh = shared_state();
+        PDMP_SLOTS(s) {
+            const int i = s * G + g;
+            if (in_dim(s, i)) V(s) = V(s) - (0.5 * hh) * tgt.grad(i, X(s), sh);
+        }
+    }
+    __device__ __forceinline__ void rhmc_flow(double t) {
+        const double h = p.rh_step_size;
+        const long long n = (t == 0.0) ? 0 : (long long)floor(t / h);
+        const double r = t - (double)n * h;
+        const long long steps = (t == 0.0) ? 0 : n + ((r > 0.0) ? 1 : 0);
+        for (long long k = 0; __ballot(k < steps) != 0ull; ++k) {
+            if (k < steps) rhmc_step((k < n) ? h : r);
+        }
+    }
+
+    __device__ __forceinline__ void flow_state(double t) {
+        if constexpr (SAMPLER == S_RHMC) { rhmc_flow(t); return; }
+        flow_state_closed(t);
+    }
+    __device__ __forceinline__ void flow_state_closed(double t) const {
         // register form: an opaque copy of t keeps the compiler from holding the KC positions true_rate just computed
         // (same expression, same bits) in registers across the accept test
         if constexpr (kReg) asm volatile("" : "+v"(t));
@@ -985,6 +1036,22 @@ struct GroupChain {
             if constexpr (kReg) { PDMP_SLOTS(s) if (s == ms && g == m - ms * G) V(s) = -V(s); }
             else if (g == m - ms * G) V(ms) = -V(ms);                    // v[m] *= -1
             sz_ok = false;
+            return false;
+        } else if constexpr (SAMPLER == S_RHMC) {
+            // Horowitz refreshment v <- cos(phi) v + sin(phi) xi (:144-149): every accepted event of every chain needs d normals, so
+            // the pairs are shared inside the chain's own lane group (lane g: pairs g, g+G, ...), each updating its two coordinates
+            double sphi, cphi;
+            det_sincos(p.rh_phi, sphi, cphi);
+            const int logG = __builtin_ctz(G);
+            for (int P = g; 2 * P < d; P += G) {
+                double z0, z1;
+                rng.normal_pair(P, z0, z1);
+                const int i0 = 2 * P, i1 = 2 * P + 1;
+                const int o0 = (i0 >> logG) * WAVE + base + (i0 & (G - 1)), o1 = (i1 >> logG) * WAVE + base + (i1 & (G - 1));
+                vs[o0] = cphi * vs[o0] + sphi * z0;
+                if (i1 < d) vs[o1] = cphi * vs[o1] + sphi * z1;
+            }
+            rng.normals_done(d);
             return false;
         } else if constexpr (SAMPLER == S_FECMC) {
             return fecmc_jump(sh);

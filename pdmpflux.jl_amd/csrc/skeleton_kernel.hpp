@@ -15,7 +15,7 @@
 
 namespace pdmp {
 
-enum : int { S_ZIGZAG = 0, S_BPS = 1, S_BOOMERANG = 2, S_FECMC = 3, S_SUZZ = 4 };   // S_FECMC, S_SUZZ: group kernel only
+enum : int { S_ZIGZAG = 0, S_BPS = 1, S_BOOMERANG = 2, S_FECMC = 3, S_SUZZ = 4, S_RHMC = 5 };   // S_FECMC, S_SUZZ, S_RHMC: group kernel only
 
 struct SkelParams {
     int32_t d, n_grid, signed_bound, adaptive, gaussian_velocity, deriv_mode, vectorized;
@@ -33,6 +33,8 @@ struct SkelParams {
     // ForwardECMC keywords (ForwardEventChainMonteCarlo.jl:290-292)
     double fe_mix_p;
     int32_t fe_ran_p, fe_switch, fe_positive;
+    // RHMC keywords (RandomizedHamiltonianMonteCarlo.jl:48-57)
+    double rh_step_size, rh_phi;
 };
 
 __device__ __forceinline__ bool uni(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }

@@ -8,6 +8,7 @@ Objects are cheap host-side records; the GPU engine handle is created on first u
 from __future__ import annotations
 
 import ctypes as C
+import math
 import warnings
 
 import numpy as np
@@ -79,7 +80,8 @@ class AbstractPDMP:
                            int(self.signed_bound), int(self.adaptive), int(self.gaussian_velocity),
                            self.deriv_mode, self.target.target_id, self.device, self.tmax, self.refresh_rate,
                            p, n, self.max_iter_per_event, float(getattr(self, "mix_p", 0.5)), int(getattr(self, "ran_p", False)),
-                           int(getattr(self, "switch", True)), int(getattr(self, "positive", True)), 0)
+                           int(getattr(self, "switch", True)), int(getattr(self, "positive", True)), 0,
+                           float(getattr(self, "step_size", 0.05)), float(getattr(self, "phi", math.pi / 2)))
 
     def handle(self):
         if self._handle is None:
@@ -236,3 +238,39 @@ def SpeedUpZigZagAD(dim, target, *, refresh_rate=0.0, grid_size=10, tmax=2.0, ve
     return SpeedUpZigZag(dim, target, refresh_rate=refresh_rate, grid_size=grid_size, tmax=tmax,
                          vectorized_bound=vectorized_bound, signed_bound=signed_bound, adaptive=adaptive,
                          AD_backend=AD_backend, **kw)
+
+
+class RHMC(AbstractPDMP):
+    """RHMC(dim, grad-U; mean_duration=nothing, refresh_rate=1.0, phi=pi/2, step_size=0.05, tmax=10.0, adaptive=false,
+    AD_backend="Undefined") (RandomizedHamiltonianMonteCarlo.jl:48-57): Hamiltonian flow by velocity-Verlet (:97-130), a constant
+    Poisson refresh clock (:133, the 2-point BoundBox of :208-218) and Horowitz refreshment v <- cos(phi) v + sin(phi) xi
+    (:144-149).  ``sample_skeleton`` only so far: interpolating samples needs the integrator on the device."""
+    sampler_id = 5
+    name = "RHMC"
+
+    def __init__(self, dim, target, *, mean_duration=None, refresh_rate=1.0, phi=math.pi / 2, step_size=0.05, tmax=10.0,
+                 adaptive=False, AD_backend="Undefined", **kw):
+        if mean_duration is not None:                                                    # :63-69
+            md = float(mean_duration)
+            if not math.isfinite(md) or md <= 0:
+                raise ArgumentError(f"mean_duration must be finite and positive. Current value: {mean_duration}")
+            refresh_rate = 1.0 / md
+        refresh_rate = float(refresh_rate)
+        if not math.isfinite(refresh_rate) or refresh_rate <= 0:                         # :71-74
+            raise ArgumentError(f"refresh_rate must be finite and positive. Current value: {refresh_rate}")
+        phi = float(phi)
+        if not (0.0 < phi <= math.pi / 2):                                               # :76-79
+            raise ArgumentError(f"phi must satisfy 0 < phi <= pi/2. Current value: {phi}")
+        step_size = float(step_size)
+        if not math.isfinite(step_size) or step_size <= 0:                               # :81-84
+            raise ArgumentError(f"step_size must be finite and positive. Current value: {step_size}")
+        tmax = float(tmax)
+        if not math.isfinite(tmax) or tmax < 0:                                          # :86-89
+            raise ArgumentError(f"tmax must be finite and non-negative. Current value: {tmax}")
+        super().__init__(dim, target, grid_size=0, tmax=tmax, refresh_rate=refresh_rate, vectorized_bound=False,
+                         signed_bound=False, adaptive=adaptive, AD_backend=AD_backend, **kw)      # :91-95
+        self.step_size, self.phi = step_size, phi
+
+
+def RHMCAD(dim, target, *, AD_backend="ForwardDiff", **kw):                              # RandomizedHamiltonianMonteCarlo.jl:178-182
+    return RHMC(dim, target, AD_backend=AD_backend, **kw)

@@ -27,7 +27,8 @@ def make_pair(P, O, kind, dim, target="iso", arith=None, **kw):
         raise ValueError(target)
     ctor = {"ZigZag": P.ZigZag, "ZigZagAD": P.ZigZagAD, "BPS": P.BPS, "BPSAD": P.BPSAD,
             "Boomerang": P.Boomerang, "BoomerangAD": P.BoomerangAD, "ForwardECMC": P.ForwardECMC,
-            "ForwardECMCAD": P.ForwardECMCAD, "SpeedUpZigZag": P.SpeedUpZigZag, "SpeedUpZigZagAD": P.SpeedUpZigZagAD}[kind]
+            "ForwardECMCAD": P.ForwardECMCAD, "SpeedUpZigZag": P.SpeedUpZigZag, "SpeedUpZigZagAD": P.SpeedUpZigZagAD,
+            "RHMC": P.RHMC}[kind]
     s = ctor(dim, tg, **kw)
     group = 1
     if arith is None:                       # match the summation order the engine uses for this configuration
@@ -38,7 +39,7 @@ def make_pair(P, O, kind, dim, target="iso", arith=None, **kw):
                    gaussian_velocity=s.gaussian_velocity, deriv_mode=s.deriv_mode, target_id=tid,
                    target_params=params, arith=arith, group_lanes=group,
                    mix_p=getattr(s, "mix_p", 0.5), ran_p=getattr(s, "ran_p", False), switch=getattr(s, "switch", True),
-                   positive=getattr(s, "positive", True))
+                   positive=getattr(s, "positive", True), step_size=getattr(s, "step_size", 0.05), phi=getattr(s, "phi", 1.5707963267948966))
     return s, cfg
 
 
