@@ -79,7 +79,8 @@ namespace {
 template <bool BOOMERANG>
 __global__ __launch_bounds__(256) void from_skeleton_kernel(int d, int64_t C, int64_t n_sk, const double *X,
                                                             const double *V, const double *t, int64_t N,
-                                                            double dt_in, int discard_vt, double *out, int suzz = 0) {
+                                                            double dt_in, int discard_vt, double *out, int suzz = 0,
+                                                            int rhmc_target = -1, double rhmc_h = 0.0, const double *tparams = nullptr) {
     const int lane = lane_id();
     const int64_t tiles = (N + WAVE - 1) / WAVE;
     const int64_t w = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -108,7 +109,42 @@ __global__ __launch_bounds__(256) void from_skeleton_kernel(int d, int64_t C, in
         double *o = out + ((size_t)c * N + (size_t)(tile * WAVE + s)) * rows;
         double sn = 0.0, cs = 1.0;
         if (BOOMERANG) det_sincos(ta, sn, cs);
-        if (suzz) {                                                   // SpeedUpZigZagSamplers.jl:71-79: x_t = y + (v1 X1(t)) v
+        if (rhmc_target >= 0) {                                       // RHMC: velocity-Verlet from the event's (x, v), RandomizedHamiltonianMonteCarlo.jl:97-130
+            constexpr int KW = 4;                                     // coordinates lane, lane + 64, ...: d <= 256 (checked by the host)
+            double xq[KW], vq[KW];
+#pragma unroll
+            for (int k = 0; k < KW; ++k) { const int q = lane + k * WAVE; xq[k] = (q < d) ? x0[q] : 0.0; vq[k] = (q < d) ? v0[q] : 0.0; }
+            auto half_kick = [&](double hh) {                         // v <- v - (0.5 hh) grad-U(x)
+                double g0 = 0.0, g1 = 0.0;
+                if (rhmc_target == PDMP_T_BANANA && d >= 2) {         // test/test_config.jl:33-36, as GTarget<T_BANANA>
+                    const double b0 = readlane_d(xq[0], 0), b1 = readlane_d(xq[0], 1);
+                    const double sq = b0 * b0, m = sq - 1.0, r = b1 - m, a2 = 2.0 * b0, pr = a2 * r;
+                    g0 = b0 - pr; g1 = r;
+                }
+#pragma unroll
+                for (int k = 0; k < KW; ++k) {
+                    const int q = lane + k * WAVE;
+                    if (q < d) {
+                        double gq = xq[k];
+                        if (rhmc_target == PDMP_T_GAUSS_DIAG) gq = tparams[d + q] * (xq[k] - tparams[q]);
+                        else if (rhmc_target == PDMP_T_BANANA && d >= 2 && q < 2) gq = (q == 0) ? g0 : g1;
+                        vq[k] = vq[k] - (0.5 * hh) * gq;
+                    }
+                }
+            };
+            const long long n = (ta == 0.0) ? 0 : (long long)floor(ta / rhmc_h);
+            const double r = ta - (double)n * rhmc_h;
+            const long long steps = (ta == 0.0) ? 0 : n + ((r > 0.0) ? 1 : 0);
+            for (long long k2 = 0; k2 < steps; ++k2) {
+                const double hh = (k2 < n) ? rhmc_h : r;
+                half_kick(hh);
+#pragma unroll
+                for (int k = 0; k < KW; ++k) if (lane + k * WAVE < d) xq[k] = xq[k] + hh * vq[k];
+                half_kick(hh);
+            }
+#pragma unroll
+            for (int k = 0; k < KW; ++k) { const int q = lane + k * WAVE; if (q < d) { o[q] = xq[k]; if (!discard_vt) o[d + q] = vq[k]; } }
+        } else if (suzz) {                                            // SpeedUpZigZagSamplers.jl:71-79: x_t = y + (v1 X1(t)) v
             const double x1 = x0[0], v1 = v0[0], av = v1 * x1, dd = (double)d;
             double yv = 0.0, yy = 0.0;
             for (int q = lane; q < d; q += WAVE) { const double y = x0[q] - av * v0[q]; yv += y * v0[q]; yy += y * y; }
@@ -669,7 +705,8 @@ int pdmp_sample_from_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, con
 int pdmp_sample_from_skeleton_dt_device(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
                                         const double *t, int64_t N, double dt, int32_t discard_vt, double *out, void *stream) {
     if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
-    if (h->cfg.sampler == PDMP_RHMC) return fail(PDMP_ERR_UNSUPPORTED, "RHMC: sample_from_skeleton needs the velocity-Verlet flow (not implemented on the device yet)");
+    if (h->cfg.sampler == PDMP_RHMC && (h->cfg.dim > 4 * WAVE || h->cfg.target_id > PDMP_T_BANANA))
+        return fail(PDMP_ERR_UNSUPPORTED, "RHMC: sample_from_skeleton integrates the flow with up to 4 coordinates per lane (dim <= 256) on the built-in targets");
     if (!(dt >= 0.0) || !std::isfinite(dt)) return fail(PDMP_ERR_ARGUMENT, "dt must be finite and non-negative");
     if (N <= 0) return fail(PDMP_ERR_ARGUMENT, "N must be positive. Current value: %lld", (long long)N);   // sample.jl:476-478
     if (n_sk <= 0) return fail(PDMP_ERR_ARGUMENT, "empty history");
@@ -686,7 +723,8 @@ int pdmp_sample_from_skeleton_dt_device(pdmp_handle h, int64_t C, int64_t n_sk, 
         hipLaunchKernelGGL(from_skeleton_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, dt, (int)discard_vt, out, 0);
     else
         hipLaunchKernelGGL(from_skeleton_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, dt, (int)discard_vt, out,
-                           (int)(h->cfg.sampler == PDMP_SUZZ));
+                           (int)(h->cfg.sampler == PDMP_SUZZ), h->cfg.sampler == PDMP_RHMC ? h->cfg.target_id : -1, h->cfg.rh_step_size,
+                           (const double *)h->d_tparams);
     HIP_TRY(hipGetLastError());
     return end_timed(h, s, ev);
 }

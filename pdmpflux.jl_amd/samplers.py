@@ -244,7 +244,8 @@ class RHMC(AbstractPDMP):
     """RHMC(dim, grad-U; mean_duration=nothing, refresh_rate=1.0, phi=pi/2, step_size=0.05, tmax=10.0, adaptive=false,
     AD_backend="Undefined") (RandomizedHamiltonianMonteCarlo.jl:48-57): Hamiltonian flow by velocity-Verlet (:97-130), a constant
     Poisson refresh clock (:133, the 2-point BoundBox of :208-218) and Horowitz refreshment v <- cos(phi) v + sin(phi) xi
-    (:144-149).  ``sample_skeleton`` only so far: interpolating samples needs the integrator on the device."""
+    (:144-149).  ``sample_from_skeleton`` integrates the same flow from the last event (built-in targets, dim <= 256); the fused
+    moment sums and the device-side time-horizon cut are not implemented for it."""
     sampler_id = 5
     name = "RHMC"
 

@@ -3,6 +3,7 @@ identical Philox streams.  The oracle runs in its WAVE64 summation order, so the
 BIT-EXACT for every field of PDMPHistory (stronger than the 1e-5 relative bound of the north star;
 the tolerance test below states that bound explicitly against the reference-order oracle)."""
 import ctypes as C
+import math
 
 import numpy as np
 import pytest
@@ -416,7 +417,7 @@ def _random_cases(n, seed):
     rs = np.random.default_rng(seed)
     cases = []
     for q in range(n):
-        kind = ["ZigZag", "ZigZagAD", "BPS", "BPSAD", "Boomerang", "BoomerangAD", "ForwardECMC", "SpeedUpZigZagAD"][rs.integers(8)]
+        kind = ["ZigZag", "ZigZagAD", "BPS", "BPSAD", "Boomerang", "BoomerangAD", "ForwardECMC", "SpeedUpZigZagAD", "RHMC"][rs.integers(9)]
         target = ["iso", "diag", "banana"][rs.integers(3)]
         dim = int(rs.choice([2, 3, 5, 9, 13, 14, 27, 40, 52, 53, 77, 104, 130, 209, 260]))
         kw = {}
@@ -436,18 +437,21 @@ def _random_cases(n, seed):
             kw.update(ran_p=bool(rs.integers(2)), switch=bool(rs.integers(2)), positive=bool(rs.integers(2)), mix_p=float(rs.choice([0.0, 0.5, 1.0])))
         if rs.random() < 0.15:
             kw["grid_size"] = int(rs.choice([0, 5, 10, 33]))
+        if kind == "RHMC":
+            kw = {k: v for k, v in kw.items() if k in ("adaptive",)}
+            kw.update(step_size=float(rs.choice([0.05, 0.11])), phi=float(rs.choice([math.pi / 2, 0.9])), tmax=float(rs.choice([10.0, 0.6])))
         if kind.startswith("SpeedUp"):          # exp(sqrt(d) v1 t): a fixed long horizon makes the grid bound fail forever (in the reference too)
             kw.pop("adaptive", None); kw.pop("tmax", None)
         cases.append((kind, dim, target, kw, int(rs.integers(1, 70)), int(rs.integers(2, 45)), int(rs.integers(1 << 30))))
     return cases
 
 
-@pytest.mark.parametrize("kind,dim,target,kw,C,n_sk,seed", _random_cases(100, 20261003),
+@pytest.mark.parametrize("kind,dim,target,kw,C,n_sk,seed", _random_cases(120, 20261003),
                          ids=lambda v: str(v).replace(" ", "") if not isinstance(v, dict) else ",".join(f"{k}={x}" for k, x in v.items()) or "-")
 def test_random_configurations_match_checker(engine, oracle, kind, dim, target, kw, C, n_sk, seed):
     """Random sampler / target / dimension / keyword combinations (whatever kernel form the engine picks for them:
     register, LDS or wave-per-chain) against the checker, bit for bit."""
-    if kw.get("grid_size") in (5, 33) and (dim > 256 or kind in ("ForwardECMC", "SpeedUpZigZagAD")):
+    if kw.get("grid_size") in (5, 33) and (dim > 256 or kind in ("ForwardECMC", "SpeedUpZigZagAD", "RHMC")):
         pytest.skip("wave-per-chain kernel: dim <= 256, no ForwardECMC / SpeedUpZigZag")
     s, cfg = make_pair(engine, oracle, kind, dim, target, **kw)
     x, v = make_init(kind, dim, C, seed=seed % 1000, target=target)

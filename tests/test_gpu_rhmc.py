@@ -50,3 +50,27 @@ def test_rhmc_argument_errors(engine):
     for kw in ({"refresh_rate": 0.0}, {"phi": 0.0}, {"phi": 2.0}, {"step_size": -1.0}, {"mean_duration": 0.0}, {"tmax": math.inf}):
         with pytest.raises(engine.ArgumentError):                        # RandomizedHamiltonianMonteCarlo.jl:59-89
             engine.RHMC(3, engine.GaussianIso(), **kw)
+
+
+@pytest.mark.parametrize("dim,target,kw", [(6, "iso", {}), (70, "diag", {"phi": 1.0}), (9, "banana", {"step_size": 0.02}), (200, "iso", {})])
+def test_rhmc_samples_integrate_the_flow(engine, oracle, dim, target, kw):
+    """sample_from_skeleton interpolates with the sampler's own flow (sample.jl:499): velocity-Verlet from the last event,
+    bit for bit against the checker (positions and, with discard_vt = false, velocities and times)."""
+    s, cfg = make_pair(engine, oracle, "RHMC", dim, target, **kw)
+    C = 11
+    x, v = make_init("RHMC", dim, C, seed=5, target=target)
+    sk = engine.sample_skeleton_ensemble(s, 25, x, v, seed=6, diagnostics=False)
+    for discard in (True, False):
+        got = engine.sample_from_skeleton_ensemble(s, 40, sk["X"], sk["V"], sk["t"], discard_vt=discard)
+        ref = oracle.sample_from_skeleton(cfg, 40, sk["X"], sk["V"], sk["t"], discard_vt=discard)
+        assert np.array_equal(got, ref)
+
+
+def test_rhmc_samples_have_the_target_moments(engine):
+    d, C = 3, 128
+    s = engine.RHMC(d, engine.Banana())
+    rs = np.random.default_rng(4)
+    sk = engine.sample_skeleton_ensemble(s, 800, 1 + 0.1 * rs.normal(size=(C, d)), rs.normal(size=(C, d)), seed=3, diagnostics=False)
+    smp = engine.sample_from_skeleton_ensemble(s, 800, sk["X"], sk["V"], sk["t"])[:, 100:].reshape(-1, d)
+    assert np.abs(smp.mean(0)).max() < 0.08                                  # banana: E x = 0, Var x1 = 1, Var x2 = 3, Var x3 = 1
+    assert abs(smp[:, 0].var() - 1) < 0.08 and abs(smp[:, 1].var() - 3) < 0.35 and abs(smp[:, 2].var() - 1) < 0.08
