@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--chains", type=int, default=100_000, help="chains per GPU")
     ap.add_argument("--n-sk", type=int, default=1000)
     ap.add_argument("--dim", type=int, default=50)
-    ap.add_argument("--sampler", default="ZigZagAD", choices=["ZigZagAD", "ZigZag", "BPS", "BPSAD", "Boomerang", "BoomerangAD", "ForwardECMC", "ForwardECMCAD"])
+    ap.add_argument("--sampler", default="ZigZagAD", choices=["ZigZagAD", "ZigZag", "BPS", "BPSAD", "Boomerang", "BoomerangAD", "ForwardECMC", "ForwardECMCAD", "SpeedUpZigZag", "SpeedUpZigZagAD", "RHMC"])
     ap.add_argument("--target", default="iso", choices=["iso", "banana", "dense", "src_banana"],
                     help="src_banana: U_banana given as source, differentiated by forward mode on the GPU (pdmp_create_from_source)")
     ap.add_argument("--seed", type=int, default=2024)
@@ -67,7 +67,7 @@ def make_inputs(torch, a, dev, rank):
     x = torch.randn((a.chains, a.dim), dtype=torch.float64, device=dev, generator=g)
     if a.target in ("banana", "src_banana"):
         x = 1.0 + 0.1 * x
-    if a.sampler.startswith("ZigZag"):
+    if a.sampler.startswith(("ZigZag", "SpeedUp")):
         v = torch.randint(0, 2, (a.chains, a.dim), device=dev, generator=g).to(torch.float64) * 2 - 1
     else:
         v = torch.randn((a.chains, a.dim), dtype=torch.float64, device=dev, generator=g)
@@ -87,7 +87,9 @@ def cpu_baseline(a, sampler):
     cfg = O.Config(target_params=tparams, sampler=sampler.sampler_id, dim=a.dim, grid_size=sampler.grid_size, tmax=sampler.tmax,
                    refresh_rate=sampler.refresh_rate, vectorized_bound=sampler.vectorized_bound,
                    signed_bound=sampler.signed_bound, adaptive=sampler.adaptive, deriv_mode=sampler.deriv_mode,
-                   target_id=tid, arith=O.ARITH_REFERENCE)
+                   target_id=tid, arith=O.ARITH_REFERENCE, mix_p=getattr(sampler, "mix_p", 0.5), ran_p=getattr(sampler, "ran_p", False),
+                   switch=getattr(sampler, "switch", True), positive=getattr(sampler, "positive", True),
+                   step_size=getattr(sampler, "step_size", 0.05), phi=getattr(sampler, "phi", 1.5707963267948966))
     rs = np.random.default_rng(a.seed)
     n_sk = min(a.n_sk, 1000)
 
@@ -95,7 +97,7 @@ def cpu_baseline(a, sampler):
         x = rs.normal(size=(C, a.dim))
         if a.target in ("banana", "src_banana"):
             x = 1.0 + 0.1 * x
-        if a.sampler.startswith("ZigZag"):
+        if a.sampler.startswith(("ZigZag", "SpeedUp")):
             v = rs.choice([-1.0, 1.0], size=(C, a.dim))
         else:
             v = rs.normal(size=(C, a.dim))
