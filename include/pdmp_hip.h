@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PDMP_ABI_VERSION 4   /* 2: + pdmp_create_from_source, PDMP_T_USER; 3: + PDMP_FECMC and its keywords at the end of pdmp_config_t; 4: + PDMP_SUZZ, PDMP_RHMC and its keywords */
+#define PDMP_ABI_VERSION 5   /* 5: + PDMP_STICKY, pdmp_diag_t.is_active; 2: + pdmp_create_from_source, PDMP_T_USER; 3: + PDMP_FECMC and its keywords at the end of pdmp_config_t; 4: + PDMP_SUZZ, PDMP_RHMC and its keywords */
 
 enum { PDMP_OK = 0, PDMP_ERR_ARGUMENT = -1, PDMP_ERR_DIMENSION = -2, PDMP_ERR_RUNTIME = -3,
        PDMP_ERR_ITERCAP = -4, PDMP_ERR_UNSUPPORTED = -5 };
@@ -42,7 +42,8 @@ enum { PDMP_OK = 0, PDMP_ERR_ARGUMENT = -1, PDMP_ERR_DIMENSION = -2, PDMP_ERR_RU
  * ForwardEventChainMonteCarlo.jl:262-344 (ForwardECMC with its default velocity jump, :127-175) */
 enum { PDMP_ZIGZAG = 0, PDMP_BPS = 1, PDMP_BOOMERANG = 2, PDMP_FECMC = 3,
        PDMP_SUZZ = 4, /* SpeedUpZigZag, src/Samplers/SpeedUpZigZagSamplers.jl */
-       PDMP_RHMC = 5  /* RHMC, src/Samplers/RandomizedHamiltonianMonteCarlo.jl (velocity-Verlet flow, constant refresh clock) */ };
+       PDMP_RHMC = 5, /* RHMC, src/Samplers/RandomizedHamiltonianMonteCarlo.jl (velocity-Verlet flow, constant refresh clock) */
+       PDMP_STICKY = 6 /* StickyZigZag, src/Samplers/StickyZigZagSamplers.jl + src/StickySamplingLoop.jl; kappa[dim] = the LAST dim doubles of target_params */ };
 /* Potential descriptors replacing the Julia closure field `grad-U` (ZigZagSamplers.jl:37): */
 enum { PDMP_T_GAUSS_ISO = 0,   /* U = |x|^2/2                         (README.md:36-38)            */
        PDMP_T_GAUSS_DIAG = 1,  /* U = sum prec_i (x_i-mu_i)^2/2 ; params = mu[d], prec[d]            */
@@ -55,7 +56,7 @@ enum { PDMP_DERIV_FORWARD = 0 /* "ForwardDiff": exact forward-mode duals */,
 
 /* Keyword arguments of the reference constructors as a plain struct. */
 typedef struct pdmp_config_t {
-    int32_t sampler;            /* PDMP_ZIGZAG | PDMP_BPS | PDMP_BOOMERANG | PDMP_FECMC | PDMP_SUZZ | PDMP_RHMC */
+    int32_t sampler;            /* PDMP_ZIGZAG | PDMP_BPS | PDMP_BOOMERANG | PDMP_FECMC | PDMP_SUZZ | PDMP_RHMC | PDMP_STICKY */
     int32_t dim;                /* > 0 */
     int32_t grid_size;          /* 2..64 grid bound; 0 = Brent constant bound (UpperBound.jl:18-36) */
     int32_t vectorized_bound;   /* ZigZag default 1; forced 0 for BPS/Boomerang */
@@ -89,6 +90,7 @@ typedef struct pdmp_diag_t {
     double  *error_value_ar;
     int32_t *rejected;
     int32_t *hitting_horizon;
+    uint8_t *is_active;         /* StickyZigZag: PDMPHistory.is_active (Composites.jl:142,256), d x n_sk x C bytes; NULL otherwise */
 } pdmp_diag_t;
 
 typedef struct pdmp_timing_t {

@@ -20,6 +20,7 @@ end
 struct Diag   # pdmp_diag_t
     horizon::Ptr{Cdouble}; ar::Ptr{Cdouble}; errored_bound::Ptr{Int32}
     error_value_ar::Ptr{Cdouble}; rejected::Ptr{Int32}; hitting_horizon::Ptr{Int32}
+    is_active::Ptr{UInt8}   # StickyZigZag (ABI 5): d x n_sk x C bytes -> PDMPHistory.is_active; C_NULL otherwise
 end
 
 # target descriptors replacing the closure field `∇U` (ZigZagSamplers.jl:37)
@@ -116,7 +117,7 @@ function sample_skeleton(s::HIPSampler, n_sk::Int, xinit::Matrix{Float64}, vinit
     eb = Array{Int32}(undef, n, C); rj = similar(eb); hh = similar(eb)
     sd = seed === nothing ? rand(UInt64) : reinterpret(UInt64, Int64(seed))
     GC.@preserve xinit vinit X V t hz ar ev eb rj hh begin
-        diag = Diag(pointer(hz), pointer(ar), pointer(eb), pointer(ev), pointer(rj), pointer(hh))
+        diag = Diag(pointer(hz), pointer(ar), pointer(eb), pointer(ev), pointer(rj), pointer(hh), Ptr{UInt8}(C_NULL))
         check(ccall((:pdmp_sample_skeleton, LIB), Cint,
                     (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cdouble}, Ptr{Cdouble}, UInt64,
                      Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ref{Diag}),

@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libpdmp_oracle.so")
 
-ZIGZAG, BPS, BOOMERANG, FECMC, SUZZ, RHMC = 0, 1, 2, 3, 4, 5
+ZIGZAG, BPS, BOOMERANG, FECMC, SUZZ, RHMC, STICKY = 0, 1, 2, 3, 4, 5, 6
 T_GAUSS_ISO, T_GAUSS_DIAG, T_BANANA, T_GAUSS_DENSE = 0, 1, 2, 3
 T_AD_BANANA, T_AD_FUNNEL, T_AD_RIDGED = 16, 17, 18      # grad-U by forward mode over U (ad_potentials.c)
 DERIV_FORWARD, DERIV_FINITE_DIFF = 0, 1
@@ -35,6 +35,7 @@ class _Cfg(C.Structure):
         ("tape_n_exp", C.c_int64), ("tape_n_uni", C.c_int64), ("tape_n_nrm", C.c_int64),
         ("fe_mix_p", C.c_double), ("fe_ran_p", C.c_int32), ("fe_switch", C.c_int32), ("fe_positive", C.c_int32),
         ("rh_reserved", C.c_int32), ("rh_step_size", C.c_double), ("rh_phi", C.c_double),
+        ("is_active_out", C.c_void_p),
     ]
 
 
@@ -118,6 +119,7 @@ class Config:
     positive: bool = True
     step_size: float = 0.05            # RHMC keywords (RandomizedHamiltonianMonteCarlo.jl:48-57)
     phi: float = 1.5707963267948966
+    is_active_out: int | None = None   # StickyZigZag: address of a (C, n_sk, d) uint8 array receiving PDMPHistory.is_active
     _keep: list = field(default_factory=list, repr=False)
 
     def c(self) -> _Cfg:
@@ -137,7 +139,7 @@ class Config:
                     int(self.adaptive), int(self.gaussian_velocity), self.deriv_mode, self.target_id, self.arith,
                     float(self.tmax), float(self.refresh_rate), p, n, self.max_iter_per_event, self.group_lanes,
                     te, tu, tn, ne, nu, nn, float(self.mix_p), int(self.ran_p), int(self.switch), int(self.positive), 0,
-                    float(self.step_size), float(self.phi))
+                    float(self.step_size), float(self.phi), self.is_active_out)
 
 
 def _check(rc):
@@ -171,6 +173,9 @@ def sample_skeleton(cfg: Config, n_sk: int, xinit, vinit, seed: int, chain_id_of
                    rejected=np.empty((Cn, n), np.int32), hitting_horizon=np.empty((Cn, n), np.int32))
     g = out.get
     c = cfg.c()
+    if cfg.sampler == STICKY:           # PDMPHistory.is_active (Composites.jl:142)
+        out["is_active"] = np.empty((Cn, n, d), np.uint8)
+        c.is_active_out = out["is_active"].ctypes.data
     _check(lib().orc_sample_skeleton(C.byref(c), Cn, int(n_sk), int(chain_id_offset), _dp(x), _dp(v),
                                      C.c_uint64(seed & (2**64 - 1)), _dp(out["X"]), _dp(out["V"]), _dp(out["t"]),
                                      _dp(g("horizon")), _dp(g("ar")), _ip(g("errored_bound")),

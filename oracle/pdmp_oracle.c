@@ -382,6 +382,7 @@ typedef struct {
     double *grid, *box, *cum;              /* BoundBox (Composites.jl:15-20) */
     double *cell;                          /* d */
     double *fe_vo, *fe_e1, *fe_e2, *fe_z, *fe_g;   /* ForwardECMC velocity jump: d, d, d, d, 2d */
+    double *vu, *actf;                     /* StickyZigZag: v .* is_active (PDMPState.v_active) and is_active as 0.0 / 1.0 */
     double step;
 } ws_t;
 
@@ -390,7 +391,7 @@ static int ws_init(ws_t *w, int d, int n) {
     w->d = d; w->n = n;
     size_t D = (size_t)d, N = (size_t)n;
     double **ptrs[] = { &w->x, &w->v, &w->xv, &w->xe, &w->vv, &w->ve, &w->gv, &w->ge, &w->tmp, &w->tmp2,
-                        &w->fa, &w->fb, &w->cell, &w->fe_vo, &w->fe_e1, &w->fe_e2, &w->fe_z };
+                        &w->fa, &w->fb, &w->cell, &w->fe_vo, &w->fe_e1, &w->fe_e2, &w->fe_z, &w->vu, &w->actf };
     for (size_t i = 0; i < sizeof ptrs / sizeof *ptrs; ++i) if (!(*ptrs[i] = malloc(D * 8))) return -1;
     if (!(w->vals = malloc(D * N * 8)) || !(w->slps = malloc(D * N * 8)) || !(w->fe_g = malloc(2 * D * 8))) return -1;
     if (!(w->grid = malloc(N * 8)) || !(w->box = malloc(N * 8)) || !(w->cum = malloc(N * 8))) return -1;
@@ -400,10 +401,10 @@ static void ws_free(ws_t *w) {
     free(w->x); free(w->v); free(w->xv); free(w->xe); free(w->vv); free(w->ve); free(w->gv); free(w->ge);
     free(w->tmp); free(w->tmp2); free(w->fa); free(w->fb); free(w->cell);
     free(w->vals); free(w->slps); free(w->grid); free(w->box); free(w->cum);
-    free(w->fe_vo); free(w->fe_e1); free(w->fe_e2); free(w->fe_z); free(w->fe_g);
+    free(w->fe_vo); free(w->fe_e1); free(w->fe_e2); free(w->fe_z); free(w->fe_g); free(w->vu); free(w->actf);
 }
 
-static inline int is_zz(const orc_config_t *cfg) { return cfg->sampler == ORC_ZIGZAG || cfg->sampler == ORC_SUZZ; }
+static inline int is_zz(const orc_config_t *cfg) { return cfg->sampler == ORC_ZIGZAG || cfg->sampler == ORC_SUZZ || cfg->sampler == ORC_STICKY; }
 
 /* SpeedUpZigZag flow (SpeedUpZigZagSamplers.jl:71-79) with a dual time: x_t = y + (v1 X1(t)) v where
  *   y = x - (v1 x1) v,  c = v1 (y.v),  a = (1 + y.y)/dim - c^2/dim^2,  Y0 = x1 + c/dim,
@@ -882,7 +883,8 @@ int orc_normalize_config(orc_config_t *c) {
     if (c->dim <= 0) FAIL(-1, "dimension dim must be positive. Current value: %d", c->dim);           /* ZigZagSamplers.jl:62-64 */
     if (c->grid_size < 0) FAIL(-1, "grid_size must be non-negative. Current value: %d", c->grid_size); /* :66-68 */
     if (c->grid_size == 1) FAIL(-1, "grid_size == 1: range(...)[2] is a BoundsError in the reference");
-    if (c->sampler < 0 || c->sampler > 5) FAIL(-1, "unknown sampler id %d", c->sampler);
+    if (c->sampler < 0 || c->sampler > 6) FAIL(-1, "unknown sampler id %d", c->sampler);
+    if (c->sampler == ORC_STICKY && (c->n_target_params < c->dim || !c->target_params)) FAIL(-1, "StickyZigZag needs kappa[dim] as the last dim target_params");
     if (c->sampler == ORC_RHMC) {                                                                     /* RandomizedHamiltonianMonteCarlo.jl:59-95 */
         if (!(c->refresh_rate > 0.0) || !isfinite(c->refresh_rate)) FAIL(-1, "refresh_rate must be finite and positive. Current value: %g", c->refresh_rate);
         if (!(0.0 < c->rh_phi && c->rh_phi <= 1.5707963267948966)) FAIL(-1, "phi must satisfy 0 < phi <= pi/2. Current value: %g", c->rh_phi);
@@ -896,16 +898,46 @@ int orc_normalize_config(orc_config_t *c) {
     }
     if (c->target_id < 0 || (c->target_id > 3 && (c->target_id < ORC_T_AD_BANANA || c->target_id > ORC_T_AD_RIDGED))) FAIL(-1, "unknown target id %d", c->target_id);
     if (c->tmax == 0.0) { c->tmax = 1.0; c->adaptive = 1; }                                           /* :73 */
-    if (c->sampler == ORC_ZIGZAG || c->sampler == ORC_SUZZ) {
+    if (c->sampler == ORC_ZIGZAG || c->sampler == ORC_SUZZ || c->sampler == ORC_STICKY) {
         if (c->signed_bound && !c->vectorized_bound) c->signed_bound = 0;                             /* :75-78 */
     } else c->vectorized_bound = 0;                                                                  /* BPS :37, Boomerang :36 */
     if (c->arith == ORC_ARITH_GROUP) {
         int G = c->group_lanes;
         if (G < 1 || G > 64 || (G & (G - 1))) FAIL(-1, "group_lanes must be a power of two in 1..64");
     }
-    if (c->target_id == ORC_T_GAUSS_DIAG && c->n_target_params != 2 * (int64_t)c->dim) FAIL(-1, "GAUSS_DIAG needs 2*dim params");
+    if (c->target_id == ORC_T_GAUSS_DIAG && c->n_target_params != (2 + (c->sampler == ORC_STICKY)) * (int64_t)c->dim) FAIL(-1, "GAUSS_DIAG needs 2*dim params");
     if (c->target_id == ORC_T_GAUSS_DENSE && c->n_target_params != (int64_t)c->dim * c->dim) FAIL(-1, "GAUSS_DENSE needs dim^2 params");
     return 0;
+}
+
+/* ---- StickyZigZag (src/StickySamplingLoop.jl).  Sums over the frozen coordinates in the configured order; the thawing draw walks
+ * the frozen coordinates in index order (`acc >= u`, :150-158), in GROUP order by slots of G with a scan inside the slot. */
+static double sticky_thaw_rate(const orc_config_t *cfg, ws_t *w, const double *kappa) {
+    for (int i = 0; i < w->d; ++i) w->tmp[i] = (w->actf[i] != 0.0) ? 0.0 : kappa[i];
+    return vsum(cfg, w->tmp, w->d);
+}
+static int sticky_thaw_pick(const orc_config_t *cfg, ws_t *w, const double *kappa, double u) {
+    const int d = w->d;
+    int last = -1;
+    if (cfg->arith == ORC_ARITH_REFERENCE) {
+        double acc = 0.0;
+        for (int j = 0; j < d; ++j) if (w->actf[j] == 0.0) { last = j; acc += kappa[j]; if (acc >= u) return j; }
+        return last;
+    }
+    const int W = (cfg->arith == ORC_ARITH_GROUP) ? cfg->group_lanes : 64;
+    double carry = 0.0;
+    for (int base = 0; base < d; base += W) {
+        double y[64], z[64];
+        for (int l = 0; l < W; ++l) y[l] = (base + l < d && w->actf[base + l] == 0.0) ? kappa[base + l] : 0.0;
+        for (int off = 1; off < W; off <<= 1) {
+            for (int l = 0; l < W; ++l) z[l] = (l >= off) ? y[l] + y[l - off] : y[l];
+            memcpy(y, z, sizeof(double) * (size_t)W);
+        }
+        for (int l = 0; l < W && base + l < d; ++l)
+            if (w->actf[base + l] == 0.0) { last = base + l; if (carry + y[l] >= u) return base + l; }
+        carry = carry + y[W - 1];
+    }
+    return last;
 }
 
 /* One chain: sample_skeleton (sample.jl:253-284) = init_state (AbstractPDMP.jl:93-153, the unused
@@ -913,7 +945,7 @@ int orc_normalize_config(orc_config_t *c) {
 static int run_chain(const orc_config_t *cfg, ws_t *w, int64_t n_sk, uint64_t seed, uint64_t chain,
                      const double *xinit, const double *vinit,
                      double *X, double *V, double *T, double *H, double *AR, int32_t *EB, double *EV,
-                     int32_t *RJ, int32_t *HH) {
+                     int32_t *RJ, int32_t *HH, uint8_t *IA) {
     const int d = w->d, n = w->n;
     const int64_t cap = cfg->max_iter_per_event > 0 ? cfg->max_iter_per_event : 1000000;
     int overrun = 0;
@@ -925,11 +957,97 @@ static int run_chain(const orc_config_t *cfg, ws_t *w, int64_t n_sk, uint64_t se
         rng.tn = cfg->tape_nrm + c * cfg->tape_n_nrm; rng.nn = cfg->tape_n_nrm;
     }
     memcpy(w->x, xinit, (size_t)d * 8); memcpy(w->v, vinit, (size_t)d * 8);   /* copy: fixes aliasing Q7 */
+    for (int i = 0; i < d; ++i) w->actf[i] = 1.0;                              /* is_active = trues(d), Composites.jl:95 */
     double t = 0.0, horizon = cfg->tmax, ts = 0.0, tp = 0.0, E = 0.0, lb = 0.0, ar = 0.0;
     int status = 0;
     for (int64_t k = 0; k < n_sk; ++k) {
         int32_t errored = 0, rejected = 0, hits = 0; double ev[5] = { 0, 0, 0, 0, 0 };   /* :28-31 */
-        if (k > 0) {
+        if (k > 0 && cfg->sampler == ORC_STICKY) {
+            /* get_event_state(state, sampler::StickyPDMP), StickySamplingLoop.jl:13-29: an accepted flip, the crossing of an axis
+             * (the coordinate sticks) and the thawing of a coordinate are all events. */
+            const double *kappa = cfg->target_params + (cfg->n_target_params - d);
+            int accept = 0, event = 0; int64_t it = 0;
+#define SET_VU() do { for (int q_ = 0; q_ < d; ++q_) w->vu[q_] = (w->actf[q_] != 0.0) ? w->v[q_] : 0.0; } while (0)
+#define WITH_VU(stmt) do { double *vs_ = w->v; SET_VU(); w->v = w->vu; stmt; w->v = vs_; } while (0)
+            while (!accept && !event) {                                               /* :23-25 */
+                if (++it > cap) return -4;
+                if (overrun) return -6;
+                /* one_step_of_thinning_or_sticking_or_thawing, :31-67 */
+                WITH_VU(upper_bound(cfg, w, w->x, w->vu, horizon));                   /* (the Brent bound reads the state's velocity: masked too) */
+                E = rng_exp(&rng);
+                orc_next_event(n, w->grid, w->box, w->cum, w->step, E, &tp, &lb);
+                const double rate_thaw = sticky_thaw_rate(cfg, w, kappa);             /* :40-45 */
+                const double tt = (rate_thaw == 0.0) ? INFINITY : rng_exp(&rng) / rate_thaw;   /* :46 */
+                double event_time = tp < horizon ? tp : horizon;                      /* min(tp, horizon, tt), :50 */
+                if (tt < event_time) event_time = tt;
+                int crossed = 0;
+                for (int i = 0; i < d && !crossed; ++i) {                             /* :51-58 */
+                    const double xe = FUSED(cfg) ? fma(w->vu[i], event_time, w->x[i]) : w->x[i] + w->vu[i] * event_time;
+                    if (w->x[i] * xe < 0.0) crossed = 1;
+                }
+                if (crossed) {                                                        /* move_to_axes_and_stick, :73-107 */
+                    double t_togo = INFINITY; int ia = -1;
+                    for (int j = 0; j < d; ++j) if (w->actf[j] != 0.0) {
+                        const double dj = w->x[j] * w->v[j];
+                        if (dj < 0.0) { const double tj = -dj; if (tj < t_togo) { t_togo = tj; ia = j; } }
+                    }
+                    if (ia < 0) FAIL(-7, "erronous t_togo, although no axis is crossed");
+                    WITH_VU(flow_state(cfg, w, t_togo));
+                    w->actf[ia] = 0.0;
+                    t = t + (t_togo + ts); ts = 0.0;                                  /* state.t += t_togo + state.ts, :101 */
+                    event = 1;
+                } else if ((tp < tt ? tp : tt) > horizon) {                           /* move_to_horizon, :61-62 */
+                    WITH_VU(flow_state(cfg, w, horizon));
+                    ts += horizon; hits++;
+                    if (cfg->adaptive) horizon = horizon * 1.01;
+                } else {                                                              /* moves_until_horizon_or_axes, :120-131 */
+                    while ((tp < tt ? tp : tt) < horizon && !accept && !event) {
+                        if (++it > cap) return -4;
+                        if (overrun) return -6;
+                        if (tp < tt) {                                                /* ac_step (SamplingLoopInplace.jl:113-168 with v .* is_active) */
+                            double lam; WITH_VU(lam = true_rate(cfg, w, tp));
+                            ar = lam / lb;
+                            if (ar > 1.0) {
+                                double h2 = horizon / 2;
+                                WITH_VU(upper_bound(cfg, w, w->x, w->vu, h2));
+                                E = rng_exp(&rng);
+                                orc_next_event(n, w->grid, w->box, w->cum, w->step, E, &tp, &lb);
+                                if (cfg->adaptive) horizon = h2;
+                                errored++;
+                                ev[errored % 5] = ar;
+                            } else {
+                                double u = rng_uniform(&rng);
+                                accept = u < ar;
+                                if (accept) {
+                                    WITH_VU(flow_state(cfg, w, tp));
+                                    status |= velocity_jump(cfg, w, &rng);            /* on the full v, :180 */
+                                    t = t + tp + ts; ts = 0.0; tp = 0.0;
+                                } else {
+                                    E = E + rng_exp(&rng);
+                                    orc_next_event(n, w->grid, w->box, w->cum, w->step, E, &tp, &lb);
+                                    if (cfg->adaptive) horizon = horizon / 1.04;
+                                    rejected++;
+                                }
+                                if (!accept && (tp < tt ? tp : tt) > horizon) {       /* move_to_horizon2!, :163-165 */
+                                    WITH_VU(flow_state(cfg, w, horizon));
+                                    ts += horizon; hits++;
+                                }
+                            }
+                        } else {                                                      /* thaw_one_coordinate, :138-164 */
+                            WITH_VU(flow_state(cfg, w, tt));
+                            const double total = sticky_thaw_rate(cfg, w, kappa);
+                            const double u = rng_uniform(&rng) * total;
+                            const int ia = sticky_thaw_pick(cfg, w, kappa, u);
+                            if (ia >= 0) w->actf[ia] = 1.0;
+                            t = t + tt; ts = 0.0;                                     /* state.t += state.tt (ts is dropped, :160-161) */
+                            event = 1;
+                        }
+                    }
+                }
+            }
+#undef WITH_VU
+#undef SET_VU
+        } else if (k > 0) {
             int accept = 0; int64_t it = 0;
             while (!accept) {                                                         /* :33-35 */
                 if (++it > cap) return -4;
@@ -988,6 +1106,7 @@ static int run_chain(const orc_config_t *cfg, ws_t *w, int64_t n_sk, uint64_t se
         if (EV) memcpy(EV + 5 * (size_t)k, ev, 40);
         if (RJ) RJ[k] = rejected;
         if (HH) HH[k] = hits;
+        if (IA) for (int i = 0; i < d; ++i) IA[(size_t)k * d + i] = (uint8_t)(w->actf[i] != 0.0);   /* Composites.jl:256 */
     }
     (void)status;
     return overrun ? -6 : 0;
@@ -1022,13 +1141,15 @@ int orc_sample_skeleton(const orc_config_t *cfg_in, int64_t C, int64_t n_sk, int
                               horizon ? horizon + o : NULL, ar ? ar + o : NULL,
                               errored_bound ? errored_bound + o : NULL,
                               error_value_ar ? error_value_ar + 5 * o : NULL,
-                              rejected ? rejected + o : NULL, hitting_horizon ? hitting_horizon + o : NULL);
+                              rejected ? rejected + o : NULL, hitting_horizon ? hitting_horizon + o : NULL,
+                              cfg.is_active_out ? cfg.is_active_out + o * d : NULL);
             if (r) rc = r;
         }
         ws_free(&w);
     }
     if (rc == -4) FAIL(-4, "a chain hit the per-event iteration cap");
     if (rc == -6) FAIL(-6, "a random-variate tape was exhausted");
+    if (rc == -7) return -7;
     if (rc) FAIL(rc, "allocation failure");
     return 0;
 }

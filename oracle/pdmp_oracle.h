@@ -22,7 +22,9 @@ extern "C" {
 enum { ORC_ZIGZAG = 0, ORC_BPS = 1, ORC_BOOMERANG = 2,
        ORC_FECMC = 3, /* ForwardECMC, src/Samplers/ForwardEventChainMonteCarlo.jl (default velocity jump, :127-175) */
        ORC_SUZZ = 4,  /* SpeedUpZigZag, src/Samplers/SpeedUpZigZagSamplers.jl: closed-form non-linear flow (:71-79), effective gradient (:81-83) */
-       ORC_RHMC = 5   /* RHMC, src/Samplers/RandomizedHamiltonianMonteCarlo.jl: velocity-Verlet flow (:97-130), constant refresh clock, Horowitz refreshment (:144-149) */ };
+       ORC_RHMC = 5,  /* RHMC, src/Samplers/RandomizedHamiltonianMonteCarlo.jl: velocity-Verlet flow (:97-130), constant refresh clock, Horowitz refreshment (:144-149) */
+       ORC_STICKY = 6 /* StickyZigZag, src/Samplers/StickyZigZagSamplers.jl + src/StickySamplingLoop.jl: coordinates stick at 0 and thaw at rates kappa;
+                       * kappa[d] = the LAST d doubles of target_params */ };
 /* built-in potentials (closures cannot cross a C ABI) */
 enum { ORC_T_GAUSS_ISO = 0, ORC_T_GAUSS_DIAG = 1, ORC_T_BANANA = 2, ORC_T_GAUSS_DENSE = 3,
        /* grad-U by forward-mode differentiation of a scalar potential (ADBackend.jl:95-109), ad_potentials.c:
@@ -67,6 +69,7 @@ typedef struct orc_config_t {
     int32_t rh_reserved;
     /* RHMC keywords (RandomizedHamiltonianMonteCarlo.jl:48-57): step_size = 0.05, phi = pi/2 (refresh_rate = 1, tmax = 10, adaptive = false) */
     double  rh_step_size, rh_phi;
+    uint8_t *is_active_out;      /* StickyZigZag: PDMPHistory.is_active (Composites.jl:142,256), d x n_sk x C bytes, or NULL */
 } orc_config_t;
 
 const char *orc_last_error(void);

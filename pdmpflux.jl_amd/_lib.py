@@ -46,7 +46,8 @@ class Config(C.Structure):
 
 class Diag(C.Structure):
     _fields_ = [("horizon", C.c_void_p), ("ar", C.c_void_p), ("errored_bound", C.c_void_p),
-                ("error_value_ar", C.c_void_p), ("rejected", C.c_void_p), ("hitting_horizon", C.c_void_p)]
+                ("error_value_ar", C.c_void_p), ("rejected", C.c_void_p), ("hitting_horizon", C.c_void_p),
+                ("is_active", C.c_void_p)]
 
 
 class Timing(C.Structure):
@@ -105,7 +106,7 @@ def lib():
     L.pdmp_reset_timing.argtypes = [vp]
     L.pdmp_debug_rng.argtypes = [vp, u64, i64, i32, i64, vp]
     L.pdmp_dense_batched_last_phases.restype = C.c_longlong
-    if L.pdmp_abi_version() != 4:
+    if L.pdmp_abi_version() != 5:
         raise EngineError(ERR_RUNTIME, "ABI version mismatch")
     _lib = L
     return L

@@ -284,7 +284,13 @@ int normalize_config(pdmp_config_t &c, bool from_source = false) {
     if (c.dim <= 0) return fail(PDMP_ERR_ARGUMENT, "dimension dim must be positive. Current value: %d", c.dim);          // ZigZagSamplers.jl:62-64
     if (c.grid_size < 0) return fail(PDMP_ERR_ARGUMENT, "grid_size must be non-negative. Current value: %d", c.grid_size); // :66-68
     if (c.grid_size == 1 || c.grid_size > WAVE) return fail(PDMP_ERR_UNSUPPORTED, "grid_size must be in 2..64. Current value: %d", c.grid_size);
-    if (c.sampler < PDMP_ZIGZAG || c.sampler > PDMP_RHMC) return fail(PDMP_ERR_ARGUMENT, "unknown sampler id %d", c.sampler);
+    if (c.sampler < PDMP_ZIGZAG || c.sampler > PDMP_STICKY) return fail(PDMP_ERR_ARGUMENT, "unknown sampler id %d", c.sampler);
+    if (c.sampler == PDMP_STICKY) {
+        if (c.target_id == PDMP_T_GAUSS_DENSE || c.target_id == PDMP_T_USER) return fail(PDMP_ERR_UNSUPPORTED, "StickyZigZag: built-in separable / banana targets only");
+        if (c.grid_size != GNG && c.grid_size != 0) return fail(PDMP_ERR_UNSUPPORTED, "StickyZigZag runs on the group kernel: grid_size = 10 (or 0, Brent)");
+        const int64_t base_params = (c.target_id == PDMP_T_GAUSS_DIAG) ? 2 * (int64_t)c.dim : 0;
+        if (c.n_target_params != base_params + c.dim || !c.target_params) return fail(PDMP_ERR_ARGUMENT, "StickyZigZag needs kappa[dim] as the last dim target_params");
+    }
     if (c.sampler == PDMP_RHMC) {                                                                    // RandomizedHamiltonianMonteCarlo.jl:59-95
         if (!(c.refresh_rate > 0.0) || !std::isfinite(c.refresh_rate)) return fail(PDMP_ERR_ARGUMENT, "refresh_rate must be finite and positive. Current value: %g", c.refresh_rate);
         if (!(0.0 < c.rh_phi && c.rh_phi <= 1.5707963267948966)) return fail(PDMP_ERR_ARGUMENT, "phi must satisfy 0 < phi <= pi/2. Current value: %g", c.rh_phi);
@@ -316,13 +322,13 @@ int normalize_config(pdmp_config_t &c, bool from_source = false) {
     if (c.deriv_mode != PDMP_DERIV_FORWARD && c.deriv_mode != PDMP_DERIV_FINITE_DIFF) return fail(PDMP_ERR_ARGUMENT, "Unsupported AD_backend id %d", c.deriv_mode);
     if (!std::isfinite(c.tmax) || c.tmax < 0.0) return fail(PDMP_ERR_ARGUMENT, "tmax must be finite and non-negative");
     if (c.tmax == 0.0) { c.tmax = 1.0; c.adaptive = 1; }                                            // ZigZagSamplers.jl:73
-    if (c.sampler == PDMP_ZIGZAG || c.sampler == PDMP_SUZZ) {
+    if (c.sampler == PDMP_ZIGZAG || c.sampler == PDMP_SUZZ || c.sampler == PDMP_STICKY) {
         if (c.signed_bound && !c.vectorized_bound) c.signed_bound = 0;                              // :75-78 (SpeedUpZigZagSamplers.jl:65-68)
     } else {
         c.vectorized_bound = 0;                                                                     // BPS :37, Boomerang :36
     }
 
-    if (c.target_id == PDMP_T_GAUSS_DIAG && (c.n_target_params != 2 * (int64_t)c.dim || !c.target_params))
+    if (c.target_id == PDMP_T_GAUSS_DIAG && c.sampler != PDMP_STICKY && (c.n_target_params != 2 * (int64_t)c.dim || !c.target_params))
         return fail(PDMP_ERR_ARGUMENT, "GAUSS_DIAG needs target_params = mu[dim], prec[dim]");
     if (c.max_iter_per_event <= 0) c.max_iter_per_event = 1000000;
     if (c.max_iter_per_event > 0x7fffffff) c.max_iter_per_event = 0x7fffffff;
@@ -341,13 +347,14 @@ launch_fn pick_launcher(int sampler, int target) {
 
 typedef hipError_t (*glaunch_fn)(const GroupParams &, hipStream_t);
 glaunch_fn pick_group_launcher(int sampler, int target) {
-    static const glaunch_fn table[6][4] = {
+    static const glaunch_fn table[7][4] = {
         {launch_group<S_ZIGZAG, T_GAUSS_ISO>, launch_group<S_ZIGZAG, T_GAUSS_DIAG>, launch_group<S_ZIGZAG, T_BANANA>, launch_group<S_ZIGZAG, T_GAUSS_DENSE>},
         {launch_group<S_BPS, T_GAUSS_ISO>, launch_group<S_BPS, T_GAUSS_DIAG>, launch_group<S_BPS, T_BANANA>, launch_group<S_BPS, T_GAUSS_DENSE>},
         {launch_group<S_BOOMERANG, T_GAUSS_ISO>, launch_group<S_BOOMERANG, T_GAUSS_DIAG>, launch_group<S_BOOMERANG, T_BANANA>, nullptr},
         {launch_group<S_FECMC, T_GAUSS_ISO>, launch_group<S_FECMC, T_GAUSS_DIAG>, launch_group<S_FECMC, T_BANANA>, nullptr},
         {launch_group<S_SUZZ, T_GAUSS_ISO>, launch_group<S_SUZZ, T_GAUSS_DIAG>, launch_group<S_SUZZ, T_BANANA>, nullptr},
         {launch_group<S_RHMC, T_GAUSS_ISO>, launch_group<S_RHMC, T_GAUSS_DIAG>, launch_group<S_RHMC, T_BANANA>, nullptr},
+        {launch_group<S_STICKY, T_GAUSS_ISO>, launch_group<S_STICKY, T_GAUSS_DIAG>, launch_group<S_STICKY, T_BANANA>, nullptr},
     };
     return table[sampler][target];
 }
@@ -431,7 +438,7 @@ static int create_impl(const pdmp_config_t *cfg, const char *source, int32_t kin
     HIP_TRY(hipSetDevice(dev));
     if (choose_group_lanes(c) == 0 && c.grid_size == 0)
         return fail(PDMP_ERR_UNSUPPORTED, "grid_size == 0 (Brent constant bound) is served by the group kernel only");
-    if (choose_group_lanes(c) == 0 && (c.sampler == PDMP_FECMC || c.sampler == PDMP_SUZZ || c.sampler == PDMP_RHMC))
+    if (choose_group_lanes(c) == 0 && c.sampler >= PDMP_FECMC)
         return fail(PDMP_ERR_UNSUPPORTED, "ForwardECMC / SpeedUpZigZag / RHMC: dim too large for the LDS tiles of the group kernel");
     if (choose_group_lanes(c) == 0 && c.dim > 4 * WAVE)
         return fail(PDMP_ERR_UNSUPPORTED, "dim > %d needs grid_size = 10 (group kernel); the wave-per-chain kernel holds at most 4 coordinates per lane", 4 * WAVE);
@@ -542,6 +549,7 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
     if (diag) {
         p.H = diag->horizon; p.AR = diag->ar; p.EV = diag->error_value_ar;
         p.EB = diag->errored_bound; p.RJ = diag->rejected; p.HH = diag->hitting_horizon;
+        p.IA = diag->is_active;
     }
     p.status = h->d_status;
     const bool taped = h->tape_chains > 0;
@@ -568,7 +576,7 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
         gp.s = p;
         gp.G = h->group_lanes;
         gp.K = (c.dim + gp.G - 1) / gp.G;
-        gp.tpar = (c.target_id == PDMP_T_GAUSS_DIAG) ? 2 * c.dim : 0;
+        gp.tpar = ((c.target_id == PDMP_T_GAUSS_DIAG) ? 2 * c.dim : 0) + ((c.sampler == PDMP_STICKY) ? c.dim : 0);   // mu, prec | kappa staged in LDS
         gp.tiles = (c.target_id == PDMP_T_GAUSS_DENSE || c.sampler == PDMP_FECMC) ? 6 : 2;   // ForwardECMC: n, v_orth, e1, e2
         gp.cell_budget = 3;
         if (const char *e = getenv("PDMP_CELL_BUDGET")) { const int b = atoi(e); if (b >= 1 && b <= GNG - 1) gp.cell_budget = b; }   // tuning / tests
@@ -586,6 +594,7 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
         }
         HIP_TRY(hipMemsetAsync(h->d_sched, 0, need_sched * sizeof(int32_t), s));
         if (const char *e = getenv("PDMP_FORCE_SEGMENTS")) gp.nseg = atoi(e);   // test hook, see group_schedule
+        if (c.sampler == PDMP_STICKY) gp.nseg = 1;                              // the hand-off state does not carry is_active
         gp.ctr = h->d_sched;
         gp.progress = h->d_sched + 1;
         gp.state = h->d_state;
@@ -655,10 +664,11 @@ int pdmp_sample_skeleton(pdmp_handle h, int64_t C, int64_t n_sk, int64_t chain_i
     double *dx = nullptr, *dv = nullptr, *dX = nullptr, *dV = nullptr, *dt = nullptr;
     double *dH = nullptr, *dAR = nullptr, *dEV = nullptr;
     int32_t *dEB = nullptr, *dRJ = nullptr, *dHH = nullptr;
+    uint8_t *dIA = nullptr;
     int rc = PDMP_OK;
     auto cleanup = [&]() {
         (void)hipFree(dx); (void)hipFree(dv); (void)hipFree(dX); (void)hipFree(dV); (void)hipFree(dt);
-        (void)hipFree(dH); (void)hipFree(dAR); (void)hipFree(dEV); (void)hipFree(dEB); (void)hipFree(dRJ); (void)hipFree(dHH);
+        (void)hipFree(dH); (void)hipFree(dAR); (void)hipFree(dEV); (void)hipFree(dEB); (void)hipFree(dRJ); (void)hipFree(dHH); (void)hipFree(dIA);
     };
 #define TRY_OR_CLEAN(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(PDMP_ERR_RUNTIME, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
     TRY_OR_CLEAN(hipMalloc(&dx, (size_t)C * d * 8));
@@ -666,7 +676,7 @@ int pdmp_sample_skeleton(pdmp_handle h, int64_t C, int64_t n_sk, int64_t chain_i
     TRY_OR_CLEAN(hipMalloc(&dX, ne * d * 8));
     TRY_OR_CLEAN(hipMalloc(&dV, ne * d * 8));
     TRY_OR_CLEAN(hipMalloc(&dt, ne * 8));
-    pdmp_diag_t dd = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    pdmp_diag_t dd = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (diag) {
         if (diag->horizon) { TRY_OR_CLEAN(hipMalloc(&dH, ne * 8)); dd.horizon = dH; }
         if (diag->ar) { TRY_OR_CLEAN(hipMalloc(&dAR, ne * 8)); dd.ar = dAR; }
@@ -674,6 +684,7 @@ int pdmp_sample_skeleton(pdmp_handle h, int64_t C, int64_t n_sk, int64_t chain_i
         if (diag->errored_bound) { TRY_OR_CLEAN(hipMalloc(&dEB, ne * 4)); dd.errored_bound = dEB; }
         if (diag->rejected) { TRY_OR_CLEAN(hipMalloc(&dRJ, ne * 4)); dd.rejected = dRJ; }
         if (diag->hitting_horizon) { TRY_OR_CLEAN(hipMalloc(&dHH, ne * 4)); dd.hitting_horizon = dHH; }
+        if (diag->is_active) { TRY_OR_CLEAN(hipMalloc(&dIA, ne * d)); TRY_OR_CLEAN(hipMemset(dIA, 1, ne * d)); dd.is_active = dIA; }
     }
     TRY_OR_CLEAN(hipMemcpy(dx, xinit, (size_t)C * d * 8, hipMemcpyHostToDevice));
     TRY_OR_CLEAN(hipMemcpy(dv, vinit, (size_t)C * d * 8, hipMemcpyHostToDevice));
@@ -691,6 +702,7 @@ int pdmp_sample_skeleton(pdmp_handle h, int64_t C, int64_t n_sk, int64_t chain_i
         if (dEB) TRY_OR_CLEAN(hipMemcpy(diag->errored_bound, dEB, ne * 4, hipMemcpyDeviceToHost));
         if (dRJ) TRY_OR_CLEAN(hipMemcpy(diag->rejected, dRJ, ne * 4, hipMemcpyDeviceToHost));
         if (dHH) TRY_OR_CLEAN(hipMemcpy(diag->hitting_horizon, dHH, ne * 4, hipMemcpyDeviceToHost));
+        if (dIA) TRY_OR_CLEAN(hipMemcpy(diag->is_active, dIA, ne * d, hipMemcpyDeviceToHost));
         memcpy(g_err, keep, sizeof keep);
     }
     cleanup();

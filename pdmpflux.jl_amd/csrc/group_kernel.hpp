@@ -200,7 +200,8 @@ template <int SAMPLER, int TARGET, bool FD, int KC = 0>
 struct GroupChain {
     using Tgt = GTarget<TARGET>;
     static constexpr bool kReg = KC > 0;
-    static constexpr bool kZz = SAMPLER == S_ZIGZAG || SAMPLER == S_SUZZ;   // Zig-Zag family: per-coordinate rates, flips
+    static constexpr bool kZz = SAMPLER == S_ZIGZAG || SAMPLER == S_SUZZ || SAMPLER == S_STICKY;   // Zig-Zag family: per-coordinate rates, flips
+    static constexpr bool kSticky = SAMPLER == S_STICKY;
     static constexpr int kUnroll = KC > 0 ? KC : 1;   // slot loops: fully unrolled in the register form, left alone otherwise
     static_assert(!kReg || (!Tgt::kTile && !Tgt::kUser && KC >= 2), "register form: separable / banana targets only");
     const SkelParams &p;
@@ -222,8 +223,21 @@ struct GroupChain {
 
     __device__ __forceinline__ double &X(int s) const { if constexpr (kReg) return xr[s]; else return xs[s * WAVE + lane]; }
     __device__ __forceinline__ double &V(int s) const { if constexpr (kReg) return vr[s]; else return vs[s * WAVE + lane]; }
+    // ---- StickyZigZag (src/StickySamplingLoop.jl): bit s of amask = the coordinate of slot s is active (not stuck at 0);
+    // flows, rates and bounds use v .* is_active (PDMPState.v_active, SamplingLoopInplace.jl:13-25), the velocity jump the full v
+    uint32_t amask = 0xffffffffu;
+    const double *kap = nullptr;         // kappa[d] in LDS (thawing rates)
+    double tt = 0.0, thaw_rate = 0.0;    // time to thaw and the rate it was drawn with (StickySamplingLoop.jl:40-46)
+    __device__ __forceinline__ bool active(int s) const { if constexpr (kSticky) return (amask >> s) & 1u; else return true; }
+    __device__ __forceinline__ double VU(int s) const { if constexpr (kSticky) return active(s) ? V(s) : 0.0; else return V(s); }
     __device__ __forceinline__ void coord(int i, double &x, double &v) const {   // any coordinate of my chain (i = 0, 1 in the register form)
         const int s = (G == WAVE) ? (i >> 6) : i / G, l = base + (i - s * G);
+        if constexpr (kSticky) {
+            const uint32_t m = (uint32_t)__shfl((int)amask, l, WAVE);
+            x = xs[s * WAVE + l];
+            v = ((m >> s) & 1u) ? vs[s * WAVE + l] : 0.0;
+            return;
+        }
         if constexpr (kReg) {
             x = __shfl((s == 0) ? xr[0] : xr[1], l, WAVE);
             v = __shfl((s == 0) ? vr[0] : vr[1], l, WAVE);
@@ -341,7 +355,7 @@ struct GroupChain {
         if constexpr (Tgt::kTile) {
             PDMP_SLOTS(s) {
                 double xt, vt;
-                flow(X(s), V(s), tp, xt, vt);
+                flow(X(s), VU(s), tp, xt, vt);
                 tgt.tx[s * WAVE + lane] = xt;
             }
             matvec(tgt.P, tgt.tx, tgt.tg[which]);
@@ -477,7 +491,7 @@ struct GroupChain {
                     PDMP_SLOTS(s) {
                         const int i = s * G + g;
                         const int ip = (in_dim(s, i)) ? i : 0;
-                        const double x = X(s), v = V(s);
+                        const double x = X(s), v = VU(s);
                         double v0, g0, v1, g1;
                         eval_vect<SIGNED>(ip, x, v, p0, sh0, v0, g0);
                         eval_vect<SIGNED>(ip, x, v, p1, sh1, v1, g1);
@@ -493,7 +507,7 @@ struct GroupChain {
                     PDMP_SLOTS(s) {
                         const int i = s * G + g;
                         const int ip = (in_dim(s, i)) ? i : 0;
-                        const double x = X(s), v = V(s);
+                        const double x = X(s), v = VU(s);
                         const double v0 = fval_vect<SIGNED>(ip, x, v, P0.c, a0);
                         const double g0 = fd_slope(P0, v0, fval_vect<SIGNED>(ip, x, v, P0.m, a1), fval_vect<SIGNED>(ip, x, v, P0.pl, a2));
                         const double v1 = fval_vect<SIGNED>(ip, x, v, P1.c, b0);
@@ -542,7 +556,7 @@ struct GroupChain {
             const int i = s * G + g;
             const bool valid = in_dim(s, i);
             Dual xt, vt;
-            flow(X(s), V(s), tp, xt, vt);
+            flow(X(s), VU(s), tp, xt, vt);
             const Dual gd = eff(tgt.grad(i, xt, sh), xt, tp);
             double a = gd.v * vt.v, b = sdot(gd, vt);
             if constexpr (kZz) {
@@ -568,7 +582,7 @@ struct GroupChain {
         PDMP_SLOTS(s) {
             const int i = s * G + g;
             const bool valid = in_dim(s, i);
-            const double x = X(s), v = V(s);
+            const double x = X(s), v = VU(s);
 #pragma unroll
             for (int q = 0; q < NPT; ++q) {
                 double xt, vt;
@@ -597,7 +611,7 @@ struct GroupChain {
         PDMP_SLOTS(s) {
             const int i = s * G + g;
             const bool valid = in_dim(s, i);
-            const double x = X(s), v = V(s);
+            const double x = X(s), v = VU(s);
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
                 Dual xt, vt;
@@ -792,7 +806,7 @@ struct GroupChain {
         PDMP_SLOTS(s) {
             const int i = s * G + g;
             double xt, vt;
-            flow(X(s), V(s), tp, xt, vt);
+            flow(X(s), VU(s), tp, xt, vt);
             const double gv = eff(tgt.grad(i, xt, sh), xt, tp) * vt;
             const double term = (kZz) ? fmax(0.0, gv) : gv;     // ZigZagSamplers.jl:83-86
             acc += (in_dim(s, i)) ? term : 0.0;
@@ -854,7 +868,7 @@ struct GroupChain {
         time_pt(t, tp);
         PDMP_SLOTS(s) {
             double xt, vt;
-            flow(X(s), V(s), tp, xt, vt);
+            flow(X(s), VU(s), tp, xt, vt);
             X(s) = xt;
             if constexpr (SAMPLER == S_BOOMERANG) V(s) = vt;
         }
@@ -1001,7 +1015,12 @@ struct GroupChain {
         }
         const int d = p.d;
         if constexpr (kZz) {
-            const double S = raw;                                        // sum(max.(0, grad-U .* v)), ZigZagSamplers.jl:102-103
+            double S = raw;                                              // sum(max.(0, grad-U .* v)), ZigZagSamplers.jl:102-103
+            if constexpr (kSticky) {                                     // the accepted rate used v .* is_active; the jump uses the full v
+                double a = 0.0;
+                PDMP_SLOTS(s) { const int i = s * G + g; a += (in_dim(s, i)) ? fmax(0.0, eff(tgt.grad(i, X(s), sh), X(s), t0) * V(s)) : 0.0; }
+                S = group_sum(a, G);
+            }
             const double u = rng.uniform();                              // Categorical draw
             if (!(S > 0.0)) { guard++; return false; }                         // Q11
             // Categorical(lambda / S) (ZigZagSamplers.jl:102-104): the reference walks cp += lambda_i / S until
@@ -1150,6 +1169,66 @@ struct GroupChain {
         }
     }
 
+    // ---- StickyZigZag events (src/StickySamplingLoop.jl)
+    __device__ __forceinline__ bool group_any(bool b) const {
+        const unsigned long long ball = __ballot(b);
+        return ((G == WAVE) ? ball : ((ball >> base) & ((1ull << G) - 1ull))) != 0ull;
+    }
+    __device__ __forceinline__ double sticky_thaw_rate() const {           // sum of kappa over the frozen coordinates, :40-45
+        double a = 0.0;
+        PDMP_SLOTS(s) { const int i = s * G + g; a += (in_dim(s, i) && !active(s)) ? kap[i] : 0.0; }
+        return group_sum(a, G);
+    }
+    __device__ __forceinline__ bool sticky_crosses(double et) const {      // any(x .* flow(x, v_active, et) .< 0), :51-58
+        bool cr = false;
+        PDMP_SLOTS(s) { const double xe = fma(VU(s), et, X(s)); cr = cr || (X(s) * xe < 0.0); }
+        return group_any(cr);
+    }
+    // move_to_axes_and_stick, :73-107: the first axis the active coordinates reach (ties: lowest index); returns the time
+    __device__ __forceinline__ double sticky_stick() {
+        double tmin = __builtin_huge_val();
+        int imin = 0x7fffffff;
+        PDMP_SLOTS(s) {
+            const int i = s * G + g;
+            if (in_dim(s, i) && active(s)) {
+                const double dj = X(s) * V(s);
+                if (dj < 0.0) { const double tj = -dj; if (tj < tmin) { tmin = tj; imin = i; } }
+            }
+        }
+        for (int off = 1; off < G; off <<= 1) {                              // (time, index) minimum over the group
+            const double to = __shfl_xor(tmin, off, WAVE);
+            const int io = __shfl_xor(imin, off, WAVE);
+            if (to < tmin || (to == tmin && io < imin)) { tmin = to; imin = io; }
+        }
+        flow_state_closed(tmin);
+        PDMP_SLOTS(s) { if (s * G + g == imin) amask &= ~(1u << s); }
+        sz_ok = false;
+        return tmin;
+    }
+    // thaw_one_coordinate, :138-164: the frozen coordinates walked in index order against u = rand * total (`acc >= u`), slots of G
+    // with an inclusive scan inside the slot (GROUP order of the checker)
+    __device__ __forceinline__ void sticky_thaw() {
+        flow_state_closed(tt);
+        const double u = rng.uniform() * thaw_rate;
+        double carry = 0.0;
+        int pick = -1, last = -1;
+        PDMP_SLOTS(s) {
+            const int i = s * G + g;
+            const bool fr = in_dim(s, i) && !active(s);
+            const double inc = group_scan_incl(fr ? kap[i] : 0.0, g, G);
+            const unsigned long long ball = __ballot(pick < 0 && fr && (carry + inc >= u));
+            const unsigned long long grp = (G == WAVE) ? ball : ((ball >> base) & ((1ull << G) - 1ull));
+            const unsigned long long fb = __ballot(fr);
+            const unsigned long long fg = (G == WAVE) ? fb : ((fb >> base) & ((1ull << G) - 1ull));
+            if (fg != 0ull) last = s * G + 63 - (int)__builtin_clzll(fg);
+            if (pick < 0 && grp != 0ull) pick = s * G + (int)__builtin_ctzll(grp);
+            carry = carry + __shfl(inc, base + G - 1, WAVE);                 // the slot's total = the scan's last lane
+        }
+        if (pick < 0) pick = last;
+        PDMP_SLOTS(s) { if (s * G + g == pick) amask |= (1u << s); }
+        sz_ok = false;
+    }
+
     // ---- record!, Composites.jl:239-260
     __device__ __forceinline__ void record(int64_t c, int64_t k, double t, double horizon, double ar,
                                            int32_t errored, const double (&ev)[5], int32_t rejected,
@@ -1159,6 +1238,7 @@ struct GroupChain {
         PDMP_SLOTS(s) {
             const int i = s * G + g;
             if (in_dim(s, i)) { Xe[i] = X(s); Ve[i] = V(s); }
+            if constexpr (kSticky) { if (p.IA && in_dim(s, i)) p.IA[e * (size_t)p.d + i] = (uint8_t)active(s); }   // Composites.jl:256
         }
         if (g == 0) {
             p.t[e] = t;
@@ -1203,6 +1283,7 @@ struct GroupChain {
         }
         rng.init_lane(p.seed, (uint64_t)(p.chain0 + c));
         rng.restore(n0);
+        amask = 0xffffffffu;                                              // is_active = trues(d), Composites.jl:95 (StickyZigZag runs in one segment)
         if constexpr (Tgt::kTile) tgt.b_valid = false;
         double ts = 0.0, tp = 0.0, E = 0.0, lb = 0.0;
         int32_t errored = 0, rejected = 0, hits = 0;
@@ -1233,6 +1314,7 @@ struct GroupChain {
 #endif
         while (__ballot(!done) != 0ull) {
             STAMP(5);
+            bool accepted = false, refresh = false, proposed = false, event_out = false;   // event_out: a StickyZigZag stick / thaw event
             if (!done && !propose) {
                 // one_step_of_thinning! (:65-85), erroneous_acceptance_rate! (:131-151) or if_reject! (:188-203)
                 if (!brun) {
@@ -1246,36 +1328,56 @@ struct GroupChain {
                 if (bound_advance(hB, E, tp, lb, budget)) {
                     const double harg = hB;
                     brun = false;
+                    if constexpr (kSticky) {
+                        if (mode == FRESH) {                              // one_step_of_thinning_or_sticking_or_thawing, StickySamplingLoop.jl:40-46
+                            thaw_rate = sticky_thaw_rate();
+                            tt = __builtin_huge_val();
+                            if (thaw_rate != 0.0) tt = rng.exponential() / thaw_rate;
+                        }
+                    }
+                    const double tnext = kSticky ? ((tp < tt) ? tp : tt) : tp;   // min(tp, tt); tt = Inf for the other samplers (Composites.jl:100)
                     if (mode == ERR) {
                         if (adaptive) horizon = harg;
                         errored++;
                         const int slot = errored % 5;                     // :148 (1-based errored%5+1)
 #pragma unroll
                         for (int q = 0; q < 5; ++q) if (q == slot) ev[q] = ar;
-                        propose = tp < horizon;                           // moves_until_horizon! loop test, :106
+                        propose = tnext < horizon;                        // moves_until_horizon! loop test, :106
                     } else if (mode == REUSE) {
                         if (adaptive) horizon = horizon / 1.04;           // :194
                         rejected++;
-                        if (tp > horizon) {                               // move_to_horizon2!, :205-217
+                        if (tnext > horizon) {                            // move_to_horizon2!, :205-217 (SamplingLoopInplace.jl:163)
                             flow_state(horizon);
                             ts += horizon;
                             hits++;
                         }
-                        propose = tp < horizon;
-                    } else if (tp > horizon) {                            // move_to_horizon!, :87-101
+                        propose = tnext < horizon;
+                    } else if (kSticky && sticky_crosses((tnext < horizon) ? tnext : horizon)) {   // StickySamplingLoop.jl:50-60
+                        const double t_togo = sticky_stick();             // move_to_axes_and_stick, :73-107
+                        t = t + (t_togo + ts);
+                        ts = 0.0;
+                        event_out = true;
+                    } else if (tnext > horizon) {                         // move_to_horizon!, :87-101
                         flow_state(horizon);
                         ts += horizon;
                         hits++;
                         if (adaptive) horizon = horizon * 1.01;
                     } else {
-                        propose = tp < horizon;                           // tp == horizon: retry (Q6)
+                        propose = tnext < horizon;                        // tp == horizon: retry (Q6)
                     }
                     mode = FRESH;
                     if (++it > cap) { done = true; if (g == 0) atomicAdd(&p.status[0], 1); }
                 }
             }
             STAMP(0);
-            bool accepted = false, refresh = false, proposed = false;
+            if (!done && propose && kSticky && !(tp < tt)) {              // thaw_one_coordinate, StickySamplingLoop.jl:125-129,138-164
+                sticky_thaw();
+                t = t + tt;                                               // (the reference drops ts here, :160-161)
+                ts = 0.0;
+                propose = false;
+                event_out = true;
+                proposed = true;
+            }
             if (!done && propose) {
                 double raw;
                 const double lam = true_rate(tp, raw);                    // ac_step!, :113-129
@@ -1303,10 +1405,12 @@ struct GroupChain {
                 if (__ballot(refresh) != 0ull) fecmc_refresh(refresh);
             }
             STAMP(3);
-            if (accepted) {
-                t = t + tp + ts;
-                ts = 0.0;
-                tp = 0.0;
+            if (accepted || event_out) {
+                if (accepted) {
+                    t = t + tp + ts;
+                    ts = 0.0;
+                    tp = 0.0;
+                }
                 record(c, k, t, horizon, ar, errored, ev, rejected, hits);
                 errored = 0; rejected = 0; hits = 0;                      // get_event_state!, :28-31
 #pragma unroll
@@ -1394,6 +1498,7 @@ __device__ __forceinline__ void group_kernel_body(const GroupParams &gp) {
     if constexpr (SAMPLER == S_FECMC) {
         for (int q = 0; q < 4; ++q) chain.fe_t[q] = tile + (2 + q) * tsz;
     }
+    if constexpr (SAMPLER == S_STICKY) chain.kap = smem + (gp.tpar - gp.s.d);   // kappa[d]: the last d staged parameters
     if constexpr (GTarget<TARGET>::kTile) {
         chain.tgt.P = gp.s.tparams;
         chain.tgt.tg[0] = tile + 2 * tsz; chain.tgt.tg[1] = tile + 3 * tsz;

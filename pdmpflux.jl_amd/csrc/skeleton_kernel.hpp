@@ -15,7 +15,7 @@
 
 namespace pdmp {
 
-enum : int { S_ZIGZAG = 0, S_BPS = 1, S_BOOMERANG = 2, S_FECMC = 3, S_SUZZ = 4, S_RHMC = 5 };   // S_FECMC, S_SUZZ, S_RHMC: group kernel only
+enum : int { S_ZIGZAG = 0, S_BPS = 1, S_BOOMERANG = 2, S_FECMC = 3, S_SUZZ = 4, S_RHMC = 5, S_STICKY = 6 };   // ids >= 3: group kernel only
 
 struct SkelParams {
     int32_t d, n_grid, signed_bound, adaptive, gaussian_velocity, deriv_mode, vectorized;
@@ -25,6 +25,7 @@ struct SkelParams {
     const double *xinit, *vinit, *tparams;
     double *X, *V, *t, *H, *AR, *EV;
     int32_t *EB, *RJ, *HH;
+    uint8_t *IA;       // StickyZigZag: PDMPHistory.is_active, d x n_sk x C bytes, or null
     int32_t *status;   // [0] chains that hit the iteration cap, [1] Q11 guard events, [2] lost hand-offs, [3] chains whose tape ran out
     unsigned long long *stamps;   // diagnostic build only (-DPDMP_STAMP): per-phase cycle sums, else null
     // tape source: replay pre-recorded variates instead of Philox; chain-major, indexed by global chain id

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #else   // runtime compilation of a user potential (user_jit.hip): hiprtc brings the HIP device API, not <stdint.h>
+typedef unsigned char uint8_t;
 typedef signed int int32_t;
 typedef unsigned int uint32_t;
 typedef signed long long int64_t;

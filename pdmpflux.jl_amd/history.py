@@ -41,7 +41,7 @@ def history_from_ensemble(out: dict, c: int) -> PDMPHistory:
     zeros_i = np.zeros(n, np.int32)
     return PDMPHistory(
         X=X, V=out["V"][c].T, t=out["t"][c],
-        is_active=np.ones(X.shape, dtype=bool),                      # trues(d), Composites.jl:95
+        is_active=(out["is_active"][c].T.astype(bool) if "is_active" in out else np.ones(X.shape, dtype=bool)),   # Composites.jl:95,256
         horizon=out.get("horizon", np.zeros((1, n)))[c] if "horizon" in out else np.zeros(n),
         ar=out["ar"][c] if "ar" in out else np.zeros(n),
         errored_bound=out["errored_bound"][c] if "errored_bound" in out else zeros_i,

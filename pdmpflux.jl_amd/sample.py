@@ -63,7 +63,12 @@ def sample_skeleton_ensemble(sampler: AbstractPDMP, n_sk: int, xinit, vinit, *, 
                    rejected=np.empty((Cn, n_sk), np.int32), hitting_horizon=np.empty((Cn, n_sk), np.int32))
         diag = _lib.Diag(out["horizon"].ctypes.data, out["ar"].ctypes.data, out["errored_bound"].ctypes.data,
                          out["error_value_ar"].ctypes.data, out["rejected"].ctypes.data,
-                         out["hitting_horizon"].ctypes.data)
+                         out["hitting_horizon"].ctypes.data, None)
+    if sampler.sampler_id == 6:                              # StickyZigZag: PDMPHistory.is_active (Composites.jl:142)
+        out["is_active"] = np.ones((Cn, n_sk, d), np.uint8)
+        if diag is None:
+            diag = _lib.Diag(None, None, None, None, None, None, None)
+        diag.is_active = out["is_active"].ctypes.data
     L = _lib.lib()
     _lib.check(L.pdmp_sample_skeleton(sampler.handle(), Cn, int(n_sk), int(chain_id_offset), _vp(x), _vp(v),
                                       C.c_uint64(_seed(seed)), _vp(out["X"]), _vp(out["V"]), _vp(out["t"]),

@@ -275,3 +275,36 @@ class RHMC(AbstractPDMP):
 
 def RHMCAD(dim, target, *, AD_backend="ForwardDiff", **kw):                              # RandomizedHamiltonianMonteCarlo.jl:178-182
     return RHMC(dim, target, AD_backend=AD_backend, **kw)
+
+
+class StickyZigZag(AbstractPDMP):
+    """StickyZigZag(dim, grad-U, kappa; refresh_rate=0.0, grid_size=10, tmax=2.0, vectorized_bound=true, signed_bound=true,
+    adaptive=true, AD_backend="FiniteDiff") (StickyZigZagSamplers.jl:59-61) with the sampling loop of src/StickySamplingLoop.jl:
+    a coordinate that reaches 0 sticks there (its velocity is masked out of flows, rates and bounds) and thaws at rate
+    ``kappa[i]``; accepted flips, sticking and thawing are all recorded events, ``PDMPHistory.is_active`` tells which
+    coordinates move.  ``sample_from_skeleton`` interpolates with the plain linear flow on the recorded velocities, as the
+    reference does (sample.jl:499: it does not consult ``is_active``)."""
+    sampler_id = 6
+    name = "StickyZigZag"
+
+    def __init__(self, dim, target, kappa, *, refresh_rate=0.0, grid_size=10, tmax=2.0, vectorized_bound=True,
+                 signed_bound=True, adaptive=True, AD_backend="FiniteDiff", **kw):
+        if signed_bound and not vectorized_bound:                                      # :70-73
+            warnings.warn("Signed bound is not compatible with non-vectorized bound for ZigZag, switching to unsigned bound")
+            signed_bound = False
+        super().__init__(dim, target, grid_size=grid_size, tmax=tmax, refresh_rate=refresh_rate,
+                         vectorized_bound=vectorized_bound, signed_bound=signed_bound, adaptive=adaptive,
+                         AD_backend=AD_backend, **kw)
+        kappa = np.asarray(kappa, dtype=np.float64).ravel()
+        if kappa.size != self.dim:
+            raise DimensionMismatch(f"kappa must have length dim ({self.dim})")
+        self.kappa = kappa
+        base = np.zeros(0) if self._params is None else np.asarray(self._params, dtype=np.float64).ravel()
+        self._params = np.concatenate([base, kappa])                                   # kappa travels as the last dim target_params
+
+
+def StickyZigZagAD(dim, target, kappa, *, refresh_rate=0.0, grid_size=10, tmax=2.0, vectorized_bound=True, signed_bound=True,
+                   adaptive=True, AD_backend="ForwardDiff", **kw):                    # StickyZigZagSamplers.jl:116-126
+    return StickyZigZag(dim, target, kappa, refresh_rate=refresh_rate, grid_size=grid_size, tmax=tmax,
+                        vectorized_bound=vectorized_bound, signed_bound=signed_bound, adaptive=adaptive,
+                        AD_backend=AD_backend, **kw)

@@ -67,3 +67,20 @@ def test_speed_up_zigzag_samples_the_gaussian(oracle):
     assert np.all(np.diff(r["t"], axis=1) > 0)
     smp = oracle.sample_from_skeleton(cfg, 2500, r["X"], r["V"], r["t"]).reshape(-1, d)
     assert np.abs(smp.mean(0)).max() < 0.1 and np.abs(smp.var(0) - 1).max() < 0.15
+
+
+def test_sticky_zigzag_atom_weight_and_frozen_coordinates(oracle):
+    """StickyZigZag (StickySamplingLoop.jl): frozen coordinates sit exactly at 0, time never runs backwards, and the fraction of time
+    a coordinate spends frozen is the weight of the spike in the spike-and-slab target: pi(0)/kappa / (1 + pi(0)/kappa)."""
+    d, C = 3, 24
+    rs = np.random.default_rng(6)
+    x, v = rs.normal(size=(C, d)), rs.choice([-1.0, 1.0], size=(C, d))
+    for kap in (0.5, 2.0):
+        cfg = oracle.Config(sampler=oracle.STICKY, dim=d, target_id=oracle.T_GAUSS_ISO, target_params=np.full(d, kap))
+        r = oracle.sample_skeleton(cfg, 4000, x, v, 3)
+        ia, X, t = r["is_active"], r["X"], r["t"]
+        assert np.all(X[ia == 0] == 0.0) and np.all(np.diff(t, axis=1) >= 0)
+        dt = np.diff(t, axis=1)
+        frozen = ((1 - ia[:, :-1, :]) * dt[:, :, None]).sum(1) / t[:, -1][:, None]
+        w = (0.3989422804 / kap) / (1 + 0.3989422804 / kap)
+        assert abs(frozen.mean() - w) < 0.05        # (the reference's thaw drops the time already moved, :160-161: a small bias at large kappa)
