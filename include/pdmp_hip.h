@@ -72,12 +72,14 @@ typedef struct pdmp_config_t {
     int64_t n_target_params;
     int64_t max_iter_per_event; /* 0 -> 1e6 */
     /* ForwardECMC(dim, grad-U; ran_p = false, mix_p = 0.5, switch = true, positive = true) (ForwardEventChainMonteCarlo.jl:290-292);
-     * ignored by the other samplers.  speed_factor != 1 and normal = true are not implemented. */
+     * ignored by the other samplers.  speed_factor: fe_speed_factor below; normal = true is not implemented (the reference's own
+     * variant takes sqrt of a vector, :228, and cannot run). */
     double  fe_mix_p;
     int32_t fe_ran_p, fe_switch, fe_positive, fe_reserved;
     /* RHMC(dim, grad-U; refresh_rate = 1.0 (or 1 / mean_duration), phi = pi/2, step_size = 0.05, tmax = 10.0, adaptive = false)
      * (RandomizedHamiltonianMonteCarlo.jl:48-57); ignored by the other samplers. */
     double  rh_step_size, rh_phi;
+    double  fe_speed_factor;    /* ForwardECMC(...; speed_factor = 1.0) (:292, jump variant :177-218); 0 -> 1.0 */
 } pdmp_config_t;
 
 typedef struct pdmp_engine *pdmp_handle;

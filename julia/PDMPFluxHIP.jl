@@ -16,6 +16,7 @@ struct Config
     target_params::Ptr{Cdouble}; n_target_params::Int64; max_iter_per_event::Int64
     fe_mix_p::Cdouble; fe_ran_p::Cint; fe_switch::Cint; fe_positive::Cint; fe_reserved::Cint   # ForwardECMC keywords (ABI 3)
     rh_step_size::Cdouble; rh_phi::Cdouble                                                      # RHMC keywords (ABI 4)
+    fe_speed_factor::Cdouble                                                                    # ForwardECMC speed_factor (ABI 5)
 end
 struct Diag   # pdmp_diag_t
     horizon::Ptr{Cdouble}; ar::Ptr{Cdouble}; errored_bound::Ptr{Int32}
@@ -67,7 +68,7 @@ function ZigZagAD(dim::Int, target::Target; refresh_rate=0.0, grid_size=10, tmax
                   signed_bound=true, adaptive=true, AD_backend="ForwardDiff", device=-1)
     p = params(target)
     cfg = Config(0, dim, grid_size, vectorized_bound, signed_bound, adaptive, 0, AD_backend == "FiniteDiff" ? 1 : 0,
-                 target_id(target), device, Float64(tmax), refresh_rate, pointer(p), length(p), 0, 0.5, 0, 1, 1, 0, 0.05, pi / 2)
+                 target_id(target), device, Float64(tmax), refresh_rate, pointer(p), length(p), 0, 0.5, 0, 1, 1, 0, 0.05, pi / 2, 1.0)
     handle = GC.@preserve p create(cfg, target)
     s = HIPSampler(handle, dim, 0)
     finalizer(x -> ccall((:pdmp_destroy, LIB), Cint, (Ptr{Cvoid},), x.handle), s)
@@ -79,7 +80,7 @@ function ForwardECMC(dim::Int, target::Target; grid_size=10, tmax=2.0, signed_bo
                      mix_p=0.5, switch=true, positive=true, AD_backend="ForwardDiff", device=-1)
     p = params(target)
     cfg = Config(3, dim, grid_size, 0, signed_bound, adaptive, 0, AD_backend == "FiniteDiff" ? 1 : 0,
-                 target_id(target), device, Float64(tmax), 0.0, pointer(p), length(p), 0, mix_p, ran_p, switch, positive, 0, 0.05, pi / 2)
+                 target_id(target), device, Float64(tmax), 0.0, pointer(p), length(p), 0, mix_p, ran_p, switch, positive, 0, 0.05, pi / 2, 1.0)
     handle = GC.@preserve p create(cfg, target)
     s = HIPSampler(handle, dim, 3)
     finalizer(x -> ccall((:pdmp_destroy, LIB), Cint, (Ptr{Cvoid},), x.handle), s)
@@ -91,7 +92,7 @@ function SpeedUpZigZag(dim::Int, target::Target; grid_size=10, tmax=2.0, refresh
                        signed_bound=true, adaptive=true, AD_backend="FiniteDiff", device=-1)
     p = params(target)
     cfg = Config(4, dim, grid_size, vectorized_bound, signed_bound, adaptive, 0, AD_backend == "FiniteDiff" ? 1 : 0,
-                 target_id(target), device, Float64(tmax), refresh_rate, pointer(p), length(p), 0, 0.5, 0, 1, 1, 0, 0.05, pi / 2)
+                 target_id(target), device, Float64(tmax), refresh_rate, pointer(p), length(p), 0, 0.5, 0, 1, 1, 0, 0.05, pi / 2, 1.0)
     handle = GC.@preserve p create(cfg, target)
     s = HIPSampler(handle, dim, 4)
     finalizer(x -> ccall((:pdmp_destroy, LIB), Cint, (Ptr{Cvoid},), x.handle), s)

@@ -765,7 +765,8 @@ static int fecmc_jump(const orc_config_t *cfg, ws_t *w, rng_t *rng) {
     double *n = w->gv, *vo = w->fe_vo, *e1 = w->fe_e1, *e2 = w->fe_e2, *z = w->fe_z;
     const double u = rng_uniform(rng);                                       /* :134 */
     const double pw = orc_exp(orc_log(u) * (2.0 / (double)(d - 1)));
-    const double rho = -sqrt(1.0 - pw);                                      /* :135 */
+    const double sf = (cfg->fe_speed_factor == 0.0) ? 1.0 : cfg->fe_speed_factor;   /* _velocity_jump_event_chain_speed_up, :177-218 (1.0: :127-175, same bits) */
+    const double rho = sf * (-sqrt(1.0 - pw));                               /* :135 / :185 */
     const double ng = vnorm(cfg, w, n);                                      /* :143-149 */
     if (ng == 0.0) { for (int i = 0; i < d; ++i) n[i] = 0.0; }
     else for (int i = 0; i < d; ++i) n[i] = n[i] / ng;
@@ -777,7 +778,7 @@ static int fecmc_jump(const orc_config_t *cfg, ws_t *w, rng_t *rng) {
         for (int i = 0; i < d; ++i) vo[i] = vo[i] - dn * n[i];
     }
     const double u2 = rng_uniform(rng);                                      /* :161 */
-    const double sq = sqrt(1.0 - rho * rho);
+    const double sq = sqrt(sf * sf - rho * rho);                             /* :164 / :207 */
     if (u2 >= cfg->fe_mix_p) {                                               /* :162-166 */
         const double nv = vnorm(cfg, w, vo);
         for (int i = 0; i < d; ++i) w->v[i] = vo[i] / nv * sq + rho * n[i];

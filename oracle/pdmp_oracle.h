@@ -69,6 +69,7 @@ typedef struct orc_config_t {
     int32_t rh_reserved;
     /* RHMC keywords (RandomizedHamiltonianMonteCarlo.jl:48-57): step_size = 0.05, phi = pi/2 (refresh_rate = 1, tmax = 10, adaptive = false) */
     double  rh_step_size, rh_phi;
+    double  fe_speed_factor;     /* ForwardECMC speed_factor (ForwardEventChainMonteCarlo.jl:177-218); 0 -> 1.0 */
     uint8_t *is_active_out;      /* StickyZigZag: PDMPHistory.is_active (Composites.jl:142,256), d x n_sk x C bytes, or NULL */
 } orc_config_t;
 

@@ -41,6 +41,7 @@ class Config(C.Structure):
         ("max_iter_per_event", C.c_int64),
         ("fe_mix_p", C.c_double), ("fe_ran_p", C.c_int32), ("fe_switch", C.c_int32), ("fe_positive", C.c_int32),
         ("fe_reserved", C.c_int32), ("rh_step_size", C.c_double), ("rh_phi", C.c_double),
+        ("fe_speed_factor", C.c_double),
     ]
 
 

@@ -306,6 +306,8 @@ int normalize_config(pdmp_config_t &c, bool from_source = false) {
         if (c.dim < 2) return fail(PDMP_ERR_ARGUMENT, "The dimension must be at least 2 to use the ForwardEventChain. Got dimension %d", c.dim);
         if (c.dim == 2) c.fe_mix_p = 0.0;
         c.refresh_rate = 0.0;
+        if (c.fe_speed_factor == 0.0) c.fe_speed_factor = 1.0;
+        if (!std::isfinite(c.fe_speed_factor)) return fail(PDMP_ERR_ARGUMENT, "speed_factor must be finite");
         if (c.target_id == PDMP_T_GAUSS_DENSE) return fail(PDMP_ERR_UNSUPPORTED, "ForwardECMC: no dense-precision target");
         if (c.grid_size != GNG && c.grid_size != 0) return fail(PDMP_ERR_UNSUPPORTED, "ForwardECMC runs on the group kernel: grid_size = 10 (or 0, Brent)");
     }
@@ -544,6 +546,7 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
     p.tmax = c.tmax; p.refresh = c.refresh_rate;
     p.fe_mix_p = c.fe_mix_p; p.fe_ran_p = c.fe_ran_p; p.fe_switch = c.fe_switch; p.fe_positive = c.fe_positive;
     p.rh_step_size = c.rh_step_size; p.rh_phi = c.rh_phi;
+    p.fe_speed = (c.fe_speed_factor == 0.0) ? 1.0 : c.fe_speed_factor;
     p.xinit = xinit; p.vinit = vinit; p.tparams = h->d_tparams;
     p.X = X; p.V = V; p.t = t;
     if (diag) {

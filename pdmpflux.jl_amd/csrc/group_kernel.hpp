@@ -891,7 +891,8 @@ struct GroupChain {
         double *tn = fe_t[0], *tvo = fe_t[1], *t1 = fe_t[2], *t2 = fe_t[3];
         const double u = rng.uniform();                                             // :134
         const double pw = det_exp(det_log(u) * (2.0 / (double)(d - 1)));
-        const double rho = -__dsqrt_rn(1.0 - pw);                                   // :135
+        const double sf = p.fe_speed;                                               // speed_factor (:177-218; 1.0: the default jump, same bits)
+        const double rho = sf * (-__dsqrt_rn(1.0 - pw));                            // :135 / :185
         PDMP_SLOTS(s) {
             const int i = s * G + g;
             tn[s * WAVE + lane] = in_dim(s, i) ? tgt.grad(i, X(s), sh) : 0.0;       // n = copy(grad-U(x)), :143
@@ -912,7 +913,7 @@ struct GroupChain {
             nvo = __dsqrt_rn(tdot(tvo, tvo));
         }
         const double u2 = rng.uniform();                                            // :161
-        const double sq = __dsqrt_rn(1.0 - rho * rho);
+        const double sq = __dsqrt_rn(sf * sf - rho * rho);                          // :164 / :207
         if (u2 >= p.fe_mix_p) {                                                     // :162-166
             PDMP_SLOTS(s) { const int i = s * G + g; if (in_dim(s, i)) V(s) = tvo[s * WAVE + lane] / nvo * sq + rho * tn[s * WAVE + lane]; }
             return false;

@@ -36,6 +36,7 @@ struct SkelParams {
     int32_t fe_ran_p, fe_switch, fe_positive;
     // RHMC keywords (RandomizedHamiltonianMonteCarlo.jl:48-57)
     double rh_step_size, rh_phi;
+    double fe_speed;   // ForwardECMC speed_factor
 };
 
 __device__ __forceinline__ bool uni(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }

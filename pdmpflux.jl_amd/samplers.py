@@ -81,7 +81,8 @@ class AbstractPDMP:
                            self.deriv_mode, self.target.target_id, self.device, self.tmax, self.refresh_rate,
                            p, n, self.max_iter_per_event, float(getattr(self, "mix_p", 0.5)), int(getattr(self, "ran_p", False)),
                            int(getattr(self, "switch", True)), int(getattr(self, "positive", True)), 0,
-                           float(getattr(self, "step_size", 0.05)), float(getattr(self, "phi", math.pi / 2)))
+                           float(getattr(self, "step_size", 0.05)), float(getattr(self, "phi", math.pi / 2)),
+                           float(getattr(self, "speed_factor", 1.0)))
 
     def handle(self):
         if self._handle is None:
@@ -190,8 +191,8 @@ def BoomerangAD(dim, target, *, refresh_rate=0.0, grid_size=10, tmax=2.0, vector
 class ForwardECMC(AbstractPDMP):
     """ForwardECMC(dim, grad-U; grid_size=10, tmax=2.0, signed_bound=true, adaptive=true, ran_p=false, mix_p=0.5,
     switch=true, positive=true, AD_backend="ForwardDiff") (ForwardEventChainMonteCarlo.jl:290-344): the flow, rate and
-    bound of BPS without refreshment and the event-chain velocity jump (:127-175).  ``speed_factor != 1`` and
-    ``normal=True`` select other jump variants of the reference (:177-260) that the engine does not implement."""
+    bound of BPS without refreshment and the event-chain velocity jump (:127-175; ``speed_factor != 1``: :177-218).
+    ``normal=True`` is rejected: that variant of the reference cannot run (it takes the square root of a vector, :228)."""
     sampler_id = 3
     name = "ForwardECMC"
 
@@ -199,12 +200,13 @@ class ForwardECMC(AbstractPDMP):
                  switch=True, positive=True, AD_backend="ForwardDiff", speed_factor=1.0, normal=False, **kw):
         if isinstance(dim, (int, np.integer)) and not isinstance(dim, bool) and 0 < dim < 2:      # :298-300
             raise ArgumentError(f"The dimension must be at least 2 to use the ForwardEventChain. Got dimension {dim}")
-        if float(speed_factor) != 1.0 or normal:
-            raise ArgumentError("ForwardECMC: only the default velocity jump (speed_factor = 1, normal = false) is implemented")
+        if normal:      # the reference's `normal` variant takes sqrt of a vector (ForwardEventChainMonteCarlo.jl:228) and cannot run
+            raise ArgumentError("ForwardECMC: normal = true is not implemented")
         super().__init__(dim, target, grid_size=grid_size, tmax=tmax, refresh_rate=0.0, vectorized_bound=False,
                          signed_bound=signed_bound, adaptive=adaptive, AD_backend=AD_backend, **kw)
         self.mix_p = 0.0 if self.dim == 2 else float(mix_p)                                         # :301-303
         self.ran_p, self.switch, self.positive = bool(ran_p), bool(switch), bool(positive)
+        self.speed_factor = float(speed_factor)
 
 
 def ForwardECMCAD(dim, target, *, grid_size=10, tmax=2.0, signed_bound=True, adaptive=True, AD_backend="ForwardDiff",

@@ -22,6 +22,8 @@ CASES = [
     ("ForwardECMC", 100, "diag", {"tmax": 0.0}),         # G = 8
     ("ForwardECMCAD", 9, "iso", {"grid_size": 0}),       # Brent constant bound
     ("ForwardECMC", 300, "iso", {}),                     # K > 13: G = 32
+    ("ForwardECMC", 11, "banana", {"speed_factor": 1.7}),  # _velocity_jump_event_chain_speed_up, :177-218
+    ("ForwardECMC", 24, "iso", {"speed_factor": 0.6, "ran_p": True}),
 ]
 
 
@@ -50,4 +52,4 @@ def test_forward_ecmc_argument_errors(engine):
     with pytest.raises(engine.ArgumentError):
         engine.ForwardECMC(1, engine.GaussianIso())                                  # ForwardEventChainMonteCarlo.jl:298-300
     with pytest.raises(engine.ArgumentError):
-        engine.ForwardECMC(5, engine.GaussianIso(), speed_factor=2.0)
+        engine.ForwardECMC(5, engine.GaussianIso(), normal=True)
