@@ -832,13 +832,13 @@ struct GroupChain {
     // size h and one of size r = t - n h; chains of a wave take their own numbers of steps (per-lane predicate).
     __device__ __forceinline__ void rhmc_step(double hh) {
         auto sh = shared_state();
+        PDMP_SLOTS(s) {                                   // kick with grad-U of the whole old position first (a potential given as
+            const int i = s * G + g;                      // source reads every coordinate), then the drift
+            if (in_dim(s, i)) V(s) = V(s) - (0.5 * hh) * tgt.grad(i, X(s), sh);
+        }
         PDMP_SLOTS(s) {
             const int i = s * G + g;
-            if (in_dim(s, i)) {
-                const double gi = tgt.grad(i, X(s), sh);
-                V(s) = V(s) - (0.5 * hh) * gi;
-                X(s) = X(s) + hh * V(s);
-            }
+            if (in_dim(s, i)) X(s) = X(s) + hh * V(s);
         }
         sh = shared_state();
         PDMP_SLOTS(s) {

@@ -85,3 +85,14 @@ def test_source_potential_statistics(engine):
     ga = engine.sample_skeleton_ensemble(s, 50, x, v, seed=2)
     gb = engine.sample_skeleton_ensemble(b, 50, x, v, seed=2)
     np.testing.assert_allclose(ga["t"], gb["t"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("kind,kw", [("ForwardECMC", {}), ("RHMC", {"step_size": 0.1}), ("ForwardECMC", {"ran_p": True, "mix_p": 1.0})])
+def test_source_potential_with_the_other_samplers(engine, oracle, kind, kw):
+    """A potential given as source under ForwardECMC and RHMC (their jumps / flows read grad-U at the state itself)."""
+    s, cfg = make_pair(engine, oracle, kind, 8, "src_banana", **kw)
+    C, n_sk = 7, 30
+    x, v = make_init(kind, 8, C, seed=3, target="src_banana")
+    got = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=19, diagnostics=True)
+    ref = oracle.sample_skeleton(cfg, n_sk, x, v, 19, diagnostics=True)
+    assert_bitwise(got, ref)
