@@ -71,6 +71,58 @@ struct pdmp_engine {
 
 namespace {
 
+// ---- flows of the samplers whose flow is not x + v t / a rotation, in the wave layout (lane owns coordinates lane, lane + 64, ...);
+// shared by sample_from_skeleton, the fused moments and the time-horizon cut.
+// SpeedUpZigZag (SpeedUpZigZagSamplers.jl:71-79): x_t = (x - av v) + kv v; dot products in the wave order of the checker.
+__device__ __forceinline__ void suzz_scalars(int d, int lane, const double *x0, const double *v0, double ta, double &av, double &kv) {
+    const double x1 = x0[0], v1 = v0[0], dd = (double)d;
+    av = v1 * x1;
+    double yv = 0.0, yy = 0.0;
+    for (int q = lane; q < d; q += WAVE) { const double y = x0[q] - av * v0[q]; yv += y * v0[q]; yy += y * y; }
+    yv = wave_sum(yv);
+    yy = wave_sum(yy);
+    const double c = v1 * yv, a = (1.0 + yy) / dd - (c * c) / (dd * dd), Y0 = x1 + c / dd;
+    const double bt = (Y0 + __dsqrt_rn(Y0 * Y0 + a)) * det_exp(__dsqrt_rn(dd) * v1 * ta);
+    const double X1 = (bt * bt - a) / (2.0 * bt) - c / dd;
+    kv = v1 * X1;
+}
+// RHMC (RandomizedHamiltonianMonteCarlo.jl:97-130): velocity-Verlet from (x0, v0) by ta; up to 4 coordinates per lane (d <= 256,
+// checked by the host), built-in targets.
+__device__ __forceinline__ void rhmc_integrate(int d, int lane, const double *x0, const double *v0, double ta, double h, int target,
+                                               const double *tparams, double (&xq)[4], double (&vq)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int q = lane + k * WAVE; xq[k] = (q < d) ? x0[q] : 0.0; vq[k] = (q < d) ? v0[q] : 0.0; }
+    auto half_kick = [&](double hh) {                                 // v <- v - (0.5 hh) grad-U(x)
+        double g0 = 0.0, g1 = 0.0;
+        if (target == PDMP_T_BANANA && d >= 2) {                      // test/test_config.jl:33-36, as GTarget<T_BANANA>
+            const double b0 = readlane_d(xq[0], 0), b1 = readlane_d(xq[0], 1);
+            const double sq = b0 * b0, m = sq - 1.0, r = b1 - m, a2 = 2.0 * b0, pr = a2 * r;
+            g0 = b0 - pr; g1 = r;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int q = lane + k * WAVE;
+            if (q < d) {
+                double gq = xq[k];
+                if (target == PDMP_T_GAUSS_DIAG) gq = tparams[d + q] * (xq[k] - tparams[q]);
+                else if (target == PDMP_T_BANANA && d >= 2 && q < 2) gq = (q == 0) ? g0 : g1;
+                vq[k] = vq[k] - (0.5 * hh) * gq;
+            }
+        }
+    };
+    const long long n = (ta == 0.0) ? 0 : (long long)floor(ta / h);
+    const double r = ta - (double)n * h;
+    const long long steps = (ta == 0.0) ? 0 : n + ((r > 0.0) ? 1 : 0);
+    for (long long k2 = 0; k2 < steps; ++k2) {
+        const double hh = (k2 < n) ? h : r;
+        half_kick(hh);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (lane + k * WAVE < d) xq[k] = xq[k] + hh * vq[k];
+        half_kick(hh);
+    }
+}
+
+
 // ---------------------------------------------------------------- sample_from_skeleton, sample.jl:475-513
 // One wave per (chain, tile of 64 output samples): lane s finds the skeleton segment of sample
 // tile*64+s by binary search in t (equivalent to the reference's monotone pointer walk :493-495 for
@@ -109,51 +161,14 @@ __global__ __launch_bounds__(256) void from_skeleton_kernel(int d, int64_t C, in
         double *o = out + ((size_t)c * N + (size_t)(tile * WAVE + s)) * rows;
         double sn = 0.0, cs = 1.0;
         if (BOOMERANG) det_sincos(ta, sn, cs);
-        if (rhmc_target >= 0) {                                       // RHMC: velocity-Verlet from the event's (x, v), RandomizedHamiltonianMonteCarlo.jl:97-130
-            constexpr int KW = 4;                                     // coordinates lane, lane + 64, ...: d <= 256 (checked by the host)
-            double xq[KW], vq[KW];
+        if (rhmc_target >= 0) {                                       // RHMC: velocity-Verlet from the event's (x, v)
+            double xq[4], vq[4];
+            rhmc_integrate(d, lane, x0, v0, ta, rhmc_h, rhmc_target, tparams, xq, vq);
 #pragma unroll
-            for (int k = 0; k < KW; ++k) { const int q = lane + k * WAVE; xq[k] = (q < d) ? x0[q] : 0.0; vq[k] = (q < d) ? v0[q] : 0.0; }
-            auto half_kick = [&](double hh) {                         // v <- v - (0.5 hh) grad-U(x)
-                double g0 = 0.0, g1 = 0.0;
-                if (rhmc_target == PDMP_T_BANANA && d >= 2) {         // test/test_config.jl:33-36, as GTarget<T_BANANA>
-                    const double b0 = readlane_d(xq[0], 0), b1 = readlane_d(xq[0], 1);
-                    const double sq = b0 * b0, m = sq - 1.0, r = b1 - m, a2 = 2.0 * b0, pr = a2 * r;
-                    g0 = b0 - pr; g1 = r;
-                }
-#pragma unroll
-                for (int k = 0; k < KW; ++k) {
-                    const int q = lane + k * WAVE;
-                    if (q < d) {
-                        double gq = xq[k];
-                        if (rhmc_target == PDMP_T_GAUSS_DIAG) gq = tparams[d + q] * (xq[k] - tparams[q]);
-                        else if (rhmc_target == PDMP_T_BANANA && d >= 2 && q < 2) gq = (q == 0) ? g0 : g1;
-                        vq[k] = vq[k] - (0.5 * hh) * gq;
-                    }
-                }
-            };
-            const long long n = (ta == 0.0) ? 0 : (long long)floor(ta / rhmc_h);
-            const double r = ta - (double)n * rhmc_h;
-            const long long steps = (ta == 0.0) ? 0 : n + ((r > 0.0) ? 1 : 0);
-            for (long long k2 = 0; k2 < steps; ++k2) {
-                const double hh = (k2 < n) ? rhmc_h : r;
-                half_kick(hh);
-#pragma unroll
-                for (int k = 0; k < KW; ++k) if (lane + k * WAVE < d) xq[k] = xq[k] + hh * vq[k];
-                half_kick(hh);
-            }
-#pragma unroll
-            for (int k = 0; k < KW; ++k) { const int q = lane + k * WAVE; if (q < d) { o[q] = xq[k]; if (!discard_vt) o[d + q] = vq[k]; } }
+            for (int k = 0; k < 4; ++k) { const int q = lane + k * WAVE; if (q < d) { o[q] = xq[k]; if (!discard_vt) o[d + q] = vq[k]; } }
         } else if (suzz) {                                            // SpeedUpZigZagSamplers.jl:71-79: x_t = y + (v1 X1(t)) v
-            const double x1 = x0[0], v1 = v0[0], av = v1 * x1, dd = (double)d;
-            double yv = 0.0, yy = 0.0;
-            for (int q = lane; q < d; q += WAVE) { const double y = x0[q] - av * v0[q]; yv += y * v0[q]; yy += y * y; }
-            yv = wave_sum(yv);
-            yy = wave_sum(yy);
-            const double c = v1 * yv, a = (1.0 + yy) / dd - (c * c) / (dd * dd), Y0 = x1 + c / dd;
-            const double bt = (Y0 + __dsqrt_rn(Y0 * Y0 + a)) * det_exp(__dsqrt_rn(dd) * v1 * ta);
-            const double X1 = (bt * bt - a) / (2.0 * bt) - c / dd;
-            const double kv = v1 * X1;
+            double av, kv;
+            suzz_scalars(d, lane, x0, v0, ta, av, kv);
             for (int q = lane; q < d; q += WAVE) {
                 const double vq = v0[q], y = x0[q] - av * vq;
                 o[q] = y + kv * vq;
@@ -181,7 +196,8 @@ __global__ __launch_bounds__(256) void from_skeleton_kernel(int d, int64_t C, in
 // small: the caller reruns with a larger n_sk, as _grow_history does, Composites.jl:172-191).  One wave per chain.
 template <bool BOOMERANG>
 __global__ __launch_bounds__(256) void close_at_kernel(int d, int64_t C, int64_t n_sk, double *X, double *V, double *t, double T,
-                                                       int64_t *count) {
+                                                       int64_t *count, int mode = 0, int target = 0, double rhmc_h = 0.0,
+                                                       const double *tparams = nullptr) {
     const int lane = lane_id();
     const int64_t c = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (c >= C) return;
@@ -201,6 +217,16 @@ __global__ __launch_bounds__(256) void close_at_kernel(int d, int64_t C, int64_t
     double *x1 = X + ((size_t)c * n_sk + (size_t)k) * d, *v1 = V + ((size_t)c * n_sk + (size_t)k) * d;
     double sn = 0.0, cs = 1.0;
     if (BOOMERANG) det_sincos(tau, sn, cs);
+    if (mode == 2) {                                                                      // RHMC: velocity-Verlet to T
+        double rx[4], rv[4];
+        rhmc_integrate(d, lane, x0, v0, tau, rhmc_h, target, tparams, rx, rv);
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) { const int q = lane + k2 * WAVE; if (q < d) { x1[q] = rx[k2]; v1[q] = rv[k2]; } }
+    } else if (mode == 1) {                                                               // SpeedUpZigZag
+        double av, kv;
+        suzz_scalars(d, lane, x0, v0, tau, av, kv);
+        for (int q = lane; q < d; q += WAVE) { const double vq = v0[q]; x1[q] = (x0[q] - av * vq) + kv * vq; v1[q] = vq; }
+    } else
     for (int q = lane; q < d; q += WAVE) {
         const double xq = x0[q], vq = v0[q];
         if (BOOMERANG) { x1[q] = xq * cs + vq * sn; v1[q] = (-xq) * sn + vq * cs; }      // BoomerangSamplers.jl:31
@@ -215,7 +241,8 @@ __global__ __launch_bounds__(256) void close_at_kernel(int d, int64_t C, int64_t
 // a sequential sum over the samples of sample_from_skeleton.
 template <bool BOOMERANG>
 __global__ __launch_bounds__(256) void moments_kernel(int d, int64_t C, int64_t n_sk, const double *X, const double *V,
-                                                      const double *t, int64_t N, double *sum_x, double *sum_x2) {
+                                                      const double *t, int64_t N, double *sum_x, double *sum_x2,
+                                                      int mode = 0, int target = 0, double rhmc_h = 0.0, const double *tparams = nullptr) {
     const int lane = lane_id();
     const int64_t c = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (c >= C) return;
@@ -246,12 +273,16 @@ __global__ __launch_bounds__(256) void moments_kernel(int d, int64_t C, int64_t 
                 const double *x0 = X + ((size_t)c * n_sk + (size_t)i) * d, *v0 = V + ((size_t)c * n_sk + (size_t)i) * d;
                 double sn = 0.0, cs = 1.0;
                 if (BOOMERANG) det_sincos(ta, sn, cs);
+                double av = 0.0, kv = 0.0, rx[4] = {0, 0, 0, 0}, rv[4];
+                if (mode == 1) suzz_scalars(d, lane, x0, v0, ta, av, kv);                          // SpeedUpZigZag: the sampler's own flow
+                else if (mode == 2) rhmc_integrate(d, lane, x0, v0, ta, rhmc_h, target, tparams, rx, rv);   // RHMC (d <= 256: q0 == 0)
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
                     const int q = q0 + m * WAVE + lane;
                     if (q < d) {
                         const double xq = x0[q], vq = v0[q];
-                        const double xs = BOOMERANG ? xq * cs + vq * sn : xq + vq * ta;
+                        const double xs = (mode == 1) ? (xq - av * vq) + kv * vq : (mode == 2) ? rx[m]
+                                        : BOOMERANG ? xq * cs + vq * sn : xq + vq * ta;
                         s1[m] += xs;
                         s2[m] += xs * xs;
                     }
@@ -777,7 +808,8 @@ int pdmp_sample_from_skeleton_dt(pdmp_handle h, int64_t C, int64_t n_sk, const d
 int pdmp_close_at_time_device(pdmp_handle h, int64_t C, int64_t n_sk, double *X, double *V, double *t, double T,
                               int64_t *count, void *stream) {
     if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
-    if (h->cfg.sampler == PDMP_SUZZ || h->cfg.sampler == PDMP_RHMC) return fail(PDMP_ERR_UNSUPPORTED, "SpeedUpZigZag / RHMC: not implemented for this entry point (it needs the sampler's own flow)");
+    if (h->cfg.sampler == PDMP_RHMC && (h->cfg.dim > 4 * WAVE || h->cfg.target_id > PDMP_T_BANANA))
+        return fail(PDMP_ERR_UNSUPPORTED, "RHMC: the flow is integrated with up to 4 coordinates per lane (dim <= 256) on the built-in targets");
     if (!(T >= 0.0) || !std::isfinite(T)) return fail(PDMP_ERR_ARGUMENT, "T must be finite and non-negative. Current value: %g", T);   // sample.jl:335-337
     if (n_sk <= 0 || C < 0) return fail(PDMP_ERR_ARGUMENT, "n_sk must be positive and C non-negative");
     if (C == 0) return PDMP_OK;
@@ -786,9 +818,11 @@ int pdmp_close_at_time_device(pdmp_handle h, int64_t C, int64_t n_sk, double *X,
     hipStream_t s = (hipStream_t)stream;
     const dim3 block(256), grid((unsigned)((C + 3) / 4));
     if (h->cfg.sampler == PDMP_BOOMERANG)
-        hipLaunchKernelGGL(close_at_kernel<true>, grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, T, count);
+        hipLaunchKernelGGL(close_at_kernel<true>, grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, T, count, 0, 0, 0.0, (const double *)nullptr);
     else
-        hipLaunchKernelGGL(close_at_kernel<false>, grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, T, count);
+        hipLaunchKernelGGL(close_at_kernel<false>, grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, T, count,
+                           h->cfg.sampler == PDMP_SUZZ ? 1 : (h->cfg.sampler == PDMP_RHMC ? 2 : 0), h->cfg.target_id, h->cfg.rh_step_size,
+                           (const double *)h->d_tparams);
     HIP_TRY(hipGetLastError());
     h->last_stream = s;
     return PDMP_OK;
@@ -797,7 +831,8 @@ int pdmp_close_at_time_device(pdmp_handle h, int64_t C, int64_t n_sk, double *X,
 int pdmp_sample_moments_device(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V, const double *t,
                                int64_t N, double *sum_x, double *sum_x2, void *stream) {
     if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
-    if (h->cfg.sampler == PDMP_SUZZ || h->cfg.sampler == PDMP_RHMC) return fail(PDMP_ERR_UNSUPPORTED, "SpeedUpZigZag / RHMC: not implemented for this entry point (it needs the sampler's own flow)");
+    if (h->cfg.sampler == PDMP_RHMC && (h->cfg.dim > 4 * WAVE || h->cfg.target_id > PDMP_T_BANANA))
+        return fail(PDMP_ERR_UNSUPPORTED, "RHMC: the flow is integrated with up to 4 coordinates per lane (dim <= 256) on the built-in targets");
     if (N <= 0) return fail(PDMP_ERR_ARGUMENT, "N must be positive. Current value: %lld", (long long)N);   // sample.jl:476-478
     if (n_sk <= 0) return fail(PDMP_ERR_ARGUMENT, "empty history");
     if (C < 0) return fail(PDMP_ERR_ARGUMENT, "number of chains must be non-negative");
@@ -810,9 +845,11 @@ int pdmp_sample_moments_device(pdmp_handle h, int64_t C, int64_t n_sk, const dou
     if (int rc = begin_timed(h, s, ev)) return rc;
     const dim3 grid((unsigned)((C + 3) / 4)), block(256);
     if (h->cfg.sampler == PDMP_BOOMERANG)
-        hipLaunchKernelGGL(moments_kernel<true>, grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, N, sum_x, sum_x2);
+        hipLaunchKernelGGL(moments_kernel<true>, grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, N, sum_x, sum_x2, 0, 0, 0.0, (const double *)nullptr);
     else
-        hipLaunchKernelGGL(moments_kernel<false>, grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, N, sum_x, sum_x2);
+        hipLaunchKernelGGL(moments_kernel<false>, grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, N, sum_x, sum_x2,
+                           h->cfg.sampler == PDMP_SUZZ ? 1 : (h->cfg.sampler == PDMP_RHMC ? 2 : 0), h->cfg.target_id, h->cfg.rh_step_size,
+                           (const double *)h->d_tparams);
     HIP_TRY(hipGetLastError());
     return end_timed(h, s, ev);
 }

@@ -220,8 +220,7 @@ class SpeedUpZigZag(AbstractPDMP):
     """SpeedUpZigZag(dim, grad-U; grid_size=10, tmax=2.0, refresh_rate=0.0, vectorized_bound=true, signed_bound=true,
     adaptive=true, AD_backend="FiniteDiff") (SpeedUpZigZagSamplers.jl:56-59): the Zig-Zag loop with the closed-form
     non-linear flow (:71-79) and grad-U_effective = speed grad-U - grad speed, speed(x) = sqrt(1 + |x|^2) (:81-83).
-    ``sample_skeleton`` and ``sample_from_skeleton`` (which interpolates with this flow, sample.jl:499); the fused moment
-    sums and the device-side time-horizon cut are not implemented for it."""
+    ``sample_from_skeleton``, the fused moment sums and the time-horizon cut all interpolate with this flow (sample.jl:499)."""
     sampler_id = 4
     name = "SpeedUpZigZag"
 
@@ -246,8 +245,8 @@ class RHMC(AbstractPDMP):
     """RHMC(dim, grad-U; mean_duration=nothing, refresh_rate=1.0, phi=pi/2, step_size=0.05, tmax=10.0, adaptive=false,
     AD_backend="Undefined") (RandomizedHamiltonianMonteCarlo.jl:48-57): Hamiltonian flow by velocity-Verlet (:97-130), a constant
     Poisson refresh clock (:133, the 2-point BoundBox of :208-218) and Horowitz refreshment v <- cos(phi) v + sin(phi) xi
-    (:144-149).  ``sample_from_skeleton`` integrates the same flow from the last event (built-in targets, dim <= 256); the fused
-    moment sums and the device-side time-horizon cut are not implemented for it."""
+    (:144-149).  ``sample_from_skeleton``, the fused moment sums and the time-horizon cut integrate the same flow from the last
+    event (built-in targets, dim <= 256)."""
     sampler_id = 5
     name = "RHMC"
 

@@ -43,8 +43,36 @@ def test_speed_up_zigzag_samples_use_the_nonlinear_flow(engine, oracle):
     assert np.array_equal(smp, ref)
     flat = smp.reshape(-1, d)
     assert np.abs(flat.mean(0)).max() < 0.05 and np.abs(flat.var(0) - 1).max() < 0.1
-    with pytest.raises(engine.EngineError):                      # the fused moment sums are not implemented for this flow
-        import torch
-        from pdmpflux.jl_amd import ensemble
-        dev = torch.device("cuda:0")
-        ensemble.sample_moments_device(s, 10, torch.from_numpy(sk["X"]).to(dev), torch.from_numpy(sk["V"]).to(dev), torch.from_numpy(sk["t"]).to(dev))
+
+
+@pytest.mark.parametrize("kind,dim,target,kw", [("SpeedUpZigZagAD", 5, "iso", {}), ("RHMC", 7, "banana", {}), ("RHMC", 130, "diag", {"step_size": 0.1})])
+def test_moments_and_time_horizon_use_the_samplers_own_flow(engine, kind, dim, target, kw):
+    """pdmp_sample_moments_device = sequential sums over the samples of sample_from_skeleton, and pdmp_close_at_time_device = the
+    closing point by flow from the last event, both with the non-linear / integrated flow of these samplers."""
+    import torch
+    from pdmpflux.jl_amd import ensemble
+    ctor = getattr(engine, kind)
+    rs = np.random.default_rng(dim)
+    tg = {"iso": engine.GaussianIso(), "banana": engine.Banana(), "diag": engine.GaussianDiag(0.2 * rs.normal(size=dim), np.exp(rs.uniform(-1, 1, size=dim)))}[target]
+    s = ctor(dim, tg, **kw)
+    C, n_sk, N = 9, 60, 50
+    x, v = make_init(kind, dim, C, seed=1, target=target)
+    dev = torch.device("cuda:0")
+    sk = ensemble.sample_skeleton_device(s, n_sk, torch.from_numpy(x).to(dev), torch.from_numpy(v).to(dev), seed=5)
+    smp = ensemble.sample_from_skeleton_device(s, N, sk["X"], sk["V"], sk["t"]).cpu().numpy()
+    s1, s2 = ensemble.sample_moments_device(s, N, sk["X"], sk["V"], sk["t"])
+    r1, r2 = np.zeros((C, dim)), np.zeros((C, dim))
+    for j in range(N):
+        r1 = r1 + smp[:, j]
+        r2 = r2 + smp[:, j] * smp[:, j]
+    assert np.array_equal(s1.cpu().numpy(), r1) and np.array_equal(s2.cpu().numpy(), r2)
+    # time-horizon cut: the closing column equals a sample_from_skeleton point at the same time
+    T = float(sk["t"][:, -1].min()) * 0.61
+    out = ensemble.sample_skeleton_until_device(s, T, torch.from_numpy(x).to(dev), torch.from_numpy(v).to(dev), seed=5, init_capacity=n_sk)
+    cnt = out["count"].cpu().numpy()
+    Xh, Vh, th = sk["X"].cpu().numpy(), sk["V"].cpu().numpy(), sk["t"].cpu().numpy()
+    for c in range(C):
+        k = int(cnt[c])
+        assert out["t"][c, k - 1].item() == T
+        one = engine.sample_from_skeleton_ensemble(s, 1, Xh[c:c + 1], Vh[c:c + 1], th[c:c + 1], discard_vt=False, dt=T)[0, 0]   # the point at 1 * dt = T
+        assert np.array_equal(out["X"][c, k - 1].cpu().numpy(), one[:dim]) and np.array_equal(out["V"][c, k - 1].cpu().numpy(), one[dim:2 * dim])
