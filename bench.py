@@ -247,11 +247,13 @@ def main():
         }
         phases = int(_lib.lib().pdmp_dense_batched_last_phases()) if a.target == "dense" else 0
         if phases > 0:      # dense-precision path: the dominant kernel is the fp64 GEMM P x [requests | velocities] per phase
-            flops = 2.0 * d * d * (2 * C) * phases
+            cols = int(_lib.lib().pdmp_dense_batched_last_columns())   # C per phase, 2C when P v is re-synchronised (every 32nd phase)
+            flops = 2.0 * d * d * cols
             tf = flops / (kernel_ms * 1e-3) / 1e12
             res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6, "traffic": None,
                                "kernel": "rocBLAS dgemm (v_mfma_f64) inside dense_batched", "kernel_ms": kernel_ms, "gemm_phases": phases,
-                               "note": "achieved = 2 d^2 (2C) flop per phase x phases / whole-launch time (GEMMs + step kernels); "
+                               "gemm_columns": cols,
+                               "note": "achieved = 2 d^2 flop per multiplied column x columns / whole-launch time (GEMMs + step kernels); "
                                        "peak = MI355X fp64 matrix spec 78.6 TFLOP/s (datasheet; not in the local guide)"}
         if a.cpu_seconds > 0 and world == 1:                     # CPU baseline: rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(a, sampler)

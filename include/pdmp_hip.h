@@ -194,6 +194,8 @@ int pdmp_reset_timing(pdmp_handle h);
 /* Diagnostics: number of GEMM phases (one d x d by d x 2C fp64 GEMM each) of the last dense-precision batched run
  * on this process (pdmpflux.jl_amd/csrc/dense_batched.hip); 0 if that path has not run. */
 long long pdmp_dense_batched_last_phases(void);
+/* ... and the number of right-hand-side columns those GEMMs multiplied (C per phase, 2C when P v is re-synchronised). */
+long long pdmp_dense_batched_last_columns(void);
 
 /* Test hook: first n variates of stream (seed, chain) produced ON THE DEVICE with the engine's
  * generator; kind 0 uniform, 1 Exp(1), 2 normal vector.  out is a HOST pointer. */

@@ -43,6 +43,7 @@ struct DbParams {
     double *In;                  // d x 2C column-major: [requests | velocities]   (GEMM input)
     double *Out;                 // d x 2C column-major: [P requests | P velocities] (GEMM output)
     double *Gprev;               // C x d: gradient at the left grid time of the cell under construction
+    const double *P;             // d x d column-major precision matrix (for the rank-one update of P v at a flip)
     DbState *st;
     double *X, *V, *t, *H, *AR, *EV;
     int32_t *EB, *RJ, *HH;
@@ -225,6 +226,15 @@ __global__ __launch_bounds__(256) void db_step_kernel(const DbParams p) {
                         carry = carry + readlane_d(inc, WAVE - 1);
                     }
                     if (m < 0) m = d - 1;
+                    // v[m] *= -1, and P v follows by a rank-one update, P (v - 2 v_m e_m) = P v - 2 v_m P[:, m], instead of
+                    // being recomputed by the next GEMM (the host loop re-syncs it with a full product every 32 phases)
+                    const double vm_old = v[m];
+                    {
+                        double *Bv = p.Out + ((size_t)p.C + (size_t)c) * (size_t)d;
+                        const double *Pm = p.P + (size_t)m * (size_t)d;
+                        const double f = 2.0 * vm_old;
+                        for (int i = lane; i < d; i += WAVE) Bv[i] = Bv[i] - f * Pm[i];
+                    }
                     if (lane == (m & (WAVE - 1))) v[m] = -v[m];
                 } else if (lane == 0) {
                     atomicAdd(&p.status[1], 1);                            // Q11 guard
@@ -259,8 +269,9 @@ __global__ __launch_bounds__(256) void db_step_kernel(const DbParams p) {
 
 using namespace pdmp;
 
-static long long g_last_phases = 0;
+static long long g_last_phases = 0, g_last_columns = 0;
 extern "C" long long pdmp_dense_batched_last_phases(void) { return g_last_phases; }   // GEMM phases of the last run (diagnostics)
+extern "C" long long pdmp_dense_batched_last_columns(void) { return g_last_columns; } // right-hand-side columns multiplied over those phases
 
 // Host driver.  Returns hipSuccess-like 0, or a negative code: -3 runtime, -5 unsupported.
 extern "C" int pdmp_dense_batched_run(int device, int d, int signed_bound, int adaptive, double tmax, int64_t cap,
@@ -294,7 +305,7 @@ extern "C" int pdmp_dense_batched_run(int device, int d, int signed_bound, int a
         DbParams p;
         p.d = d; p.signed_bound = signed_bound; p.adaptive = adaptive;
         p.C = C; p.n_sk = n_sk; p.chain0 = chain0; p.cap = cap; p.seed = seed; p.tmax = tmax;
-        p.xinit = xinit; p.vinit = vinit; p.Xs = Xs; p.In = In; p.Out = Out; p.Gprev = Gprev; p.st = st;
+        p.xinit = xinit; p.vinit = vinit; p.Xs = Xs; p.In = In; p.Out = Out; p.Gprev = Gprev; p.st = st; p.P = P_dev;
         p.X = X; p.V = V; p.t = t; p.H = H; p.AR = AR; p.EV = EV; p.EB = EB; p.RJ = RJ; p.HH = HH;
         p.status = status; p.remaining = remaining;
         const dim3 grid((unsigned)((C + 3) / 4)), block(256);
@@ -305,10 +316,14 @@ extern "C" int pdmp_dense_batched_run(int device, int d, int signed_bound, int a
         const int64_t max_phases = 16 * n_sk + 64;
         int32_t live = 1;
         g_last_phases = 0;
+        g_last_columns = 0;
         for (int64_t ph = 0; ph < max_phases && live > 0; ++ph) {
             ++g_last_phases;
-            // Out (d x 2C) = P (d x d) * In (d x 2C): grad-U of every request and P v of every chain
-            DB_BLAS(rocblas_dgemm(handles[device], rocblas_operation_none, rocblas_operation_none, d, (int)(2 * C), d, &one,
+            // Out (d x C) = P (d x d) * requests (d x C): grad-U of every request.  The velocity half, P v of every chain, changes only
+            // at flips, where the step kernel updates it by a rank-one term; a full d x 2C product re-syncs it every 32 phases.
+            const bool full = (ph % 32) == 0 || getenv("PDMP_DENSE_FULL_PV") != nullptr;
+            g_last_columns += full ? 2 * C : C;
+            DB_BLAS(rocblas_dgemm(handles[device], rocblas_operation_none, rocblas_operation_none, d, (int)(full ? 2 * C : C), d, &one,
                                   P_dev, d, In, d, &zero, Out, d));
             hipLaunchKernelGGL(db_step_kernel, grid, block, 0, stream, p);
             if ((ph & 7) == 7) {
