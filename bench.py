@@ -172,26 +172,38 @@ def main():
     out = {"X": torch.empty((C, n_sk, d), dtype=torch.float64, device=dev),
            "V": torch.empty((C, n_sk, d), dtype=torch.float64, device=dev),
            "t": torch.empty((C, n_sk), dtype=torch.float64, device=dev)}
-    end_state = torch.empty((C, 2 * d + 1), dtype=torch.float64, device=dev)
-    gathered = torch.empty((world * C, 2 * d + 1), dtype=torch.float64, device=dev) if world > 1 else None
+    # the exchange is double-buffered: the all-gather of step i runs on RCCL's stream while the kernel of step i+1 runs
+    # (the kernel's work units never wait on a wave that is not already running, so sharing CUs with RCCL cannot stall it)
+    end_state = [torch.empty((C, 2 * d + 1), dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
+    gathered = [torch.empty((world * C, 2 * d + 1), dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
+    pending = [None, None]
     chain0 = rank * C
 
     def step(i):
         ensemble.sample_skeleton_device(sampler, n_sk, x, v, seed=a.seed + i, chain_id_offset=chain0, out=out,
                                         check=False)
         if world > 1:       # the path's only exchange: every rank learns every chain's end state
-            end_state[:, :d] = out["X"][:, -1]
-            end_state[:, d:2 * d] = out["V"][:, -1]
-            end_state[:, 2 * d] = out["t"][:, -1]
+            b = i & 1
+            if pending[b] is not None:          # the gather that last used this buffer pair (two steps ago)
+                pending[b].wait()
+                pending[b] = None
+            es = end_state[b]
+            es[:, :d] = out["X"][:, -1]
+            es[:, d:2 * d] = out["V"][:, -1]
+            es[:, 2 * d] = out["t"][:, -1]
             if rehearsal:
                 parts = [torch.empty((C, 2 * d + 1), dtype=torch.float64) for _ in range(world)]
-                dist.all_gather(parts, end_state.cpu())
-                gathered.copy_(torch.cat(parts, 0))
+                dist.all_gather(parts, es.cpu())
+                gathered[b].copy_(torch.cat(parts, 0))
             else:
-                dist.all_gather_into_tensor(gathered, end_state)
+                pending[b] = dist.all_gather_into_tensor(gathered[b], es, async_op=True)
 
     def fence():
         if world > 1:
+            for b in (0, 1):                    # every gather issued so far is inside the timed region
+                if pending[b] is not None:
+                    pending[b].wait()
+                    pending[b] = None
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -212,6 +224,9 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
+    if world > 1:           # the last gather delivered this rank's own end states to its slot
+        b = (a.warmup + a.steps - 1) & 1
+        assert torch.equal(gathered[b][rank * C:(rank + 1) * C], end_state[b]), "all-gather of end states is inconsistent"
     # sanity inside the bench: strictly increasing event times on a slice, finite outputs
     tt = out["t"][:256]
     assert bool((tt[:, 1:] > tt[:, :-1]).all()) and bool(torch.isfinite(out["X"][:256]).all())
