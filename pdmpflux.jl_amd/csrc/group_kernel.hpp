@@ -133,6 +133,7 @@ template <int TARGET> struct GTarget;
 template <> struct GTarget<T_GAUSS_ISO> {
     static constexpr bool kShared = false, kTile = false, kUser = false;
     static constexpr bool kLinear = true;      // grad-U is affine in x: along a linear flow the rate's slope is the same at every grid time
+    static constexpr int kAffineFrom = 0;      // coordinates i >= kAffineFrom have d grad_i / dx_j = const * delta_ij
     template <class T> using Sh = NoShared;
     __device__ __forceinline__ void init(const double *, int) {}
     template <class T> __device__ __forceinline__ NoShared shared(T, T) const { return {}; }
@@ -141,6 +142,7 @@ template <> struct GTarget<T_GAUSS_ISO> {
 template <> struct GTarget<T_GAUSS_DIAG> {
     static constexpr bool kShared = false, kTile = false, kUser = false;
     static constexpr bool kLinear = true;
+    static constexpr int kAffineFrom = 0;
     template <class T> using Sh = NoShared;
     const double *mu, *prec;            // LDS copies
     __device__ __forceinline__ void init(const double *lds_params, int d) { mu = lds_params; prec = lds_params + d; }
@@ -155,6 +157,7 @@ template <class T> struct BananaSh { T g0, r; };
 template <> struct GTarget<T_BANANA> {          // test/test_config.jl:33-36
     static constexpr bool kShared = true, kTile = false, kUser = false;
     static constexpr bool kLinear = false;
+    static constexpr int kAffineFrom = 2;      // only x_1, x_2 are twisted: every other coordinate is a unit Gaussian
     template <class T> using Sh = BananaSh<T>;
     int d;
     __device__ __forceinline__ void init(const double *, int dim) { d = dim; }
@@ -178,6 +181,7 @@ template <> struct GTarget<T_BANANA> {          // test/test_config.jl:33-36
 template <> struct GTarget<T_USER> {
     static constexpr bool kShared = true, kTile = false, kUser = true;
     static constexpr bool kLinear = false;
+    static constexpr int kAffineFrom = 1 << 30;
     template <class T> using Sh = UserView<T>;
     __device__ __forceinline__ void init(const double *, int) {}
     template <class T> __device__ __forceinline__ T grad(int i, T, const UserView<T> &w) const {
@@ -239,6 +243,16 @@ struct GroupChain {
             return;
         }
         if constexpr (kReg) {
+            if (i < 2 && (G == 4 || G == 2)) {          // lane i of every group by quad_perm: register to register, no LDS crossbar
+                if (G == 4) {
+                    if (i == 0) { x = dpp_d<0x00>(xr[0]); v = dpp_d<0x00>(vr[0]); }      // quad_perm [0,0,0,0]
+                    else { x = dpp_d<0x55>(xr[0]); v = dpp_d<0x55>(vr[0]); }             // quad_perm [1,1,1,1]
+                } else {
+                    if (i == 0) { x = dpp_d<0xA0>(xr[0]); v = dpp_d<0xA0>(vr[0]); }      // quad_perm [0,0,2,2]
+                    else { x = dpp_d<0xF5>(xr[0]); v = dpp_d<0xF5>(vr[0]); }             // quad_perm [1,1,3,3]
+                }
+                return;
+            }
             x = __shfl((s == 0) ? xr[0] : xr[1], l, WAVE);
             v = __shfl((s == 0) ? vr[0] : vr[1], l, WAVE);
         } else {
@@ -495,7 +509,7 @@ struct GroupChain {
                         double v0, g0, v1, g1;
                         eval_vect<SIGNED>(ip, x, v, p0, sh0, v0, g0);
                         eval_vect<SIGNED>(ip, x, v, p1, sh1, v1, g1);
-                        bsum += cell_vect(v0, g0, v1, g1, t0, t1, h);
+                        bsum += cell_vect(v0, g0, v1, g1, t0, t1, h, SAMPLER == S_ZIGZAG && !FD && s * G >= Tgt::kAffineFrom);
                     }
                     b_shf = sh1;
                 } else {                                                               // AD_backend = "FiniteDiff", :223-224
@@ -534,14 +548,17 @@ struct GroupChain {
         return fin;
     }
     // one tangent-intersection cell of one coordinate, UpperBound.jl:229-241 (absolute-time form, Q1)
-    __device__ __forceinline__ static double cell_vect(double v0, double g0, double v1, double g1, double t0, double t1, double h) {
+    __device__ __forceinline__ static double cell_vect(double v0, double g0, double v1, double g1, double t0, double t1, double h,
+                                                       bool affine_slot = false) {
         const double num = fma(-g0, t0, fma(g1, t1, v0 - v1));                         // :229 ((v0-v1) + g1 t1) - g0 t0, fused
         const double den = g1 - g0;
         // Zig-Zag on a potential with affine gradient and forward-mode slopes: slope = (d grad_i/dx_i) v_i^2 at every
         // grid time, the same double each time, so den == 0 exactly for every lane -- known at compile time, no ballot
         // (a convergent operation that would also keep the compiler from overlapping consecutive coordinates).
         constexpr bool always_fast = (SAMPLER == S_ZIGZAG) && Tgt::kLinear && !FD;
-        const bool fast = always_fast ? true : (__ballot(den != 0.0) == 0ull);         // wave-uniform
+        // affine_slot (wave-uniform; a compile-time constant in the register form): every coordinate of this slot has an
+        // affine gradient component (banana: all slots but the first), so den == 0 there too
+        const bool fast = (always_fast || affine_slot) ? true : (__ballot(den != 0.0) == 0ull);   // wave-uniform
         const double q = cell_q(num, den, h, fast);                                    // :234-235
         const double inter = fma(g0, q, v0);                                           // :237
         return fmax(fmax(fmax(v0, v1), inter), 0.0);                                   // :239-241
@@ -1456,6 +1473,7 @@ template <class T> struct DenseSh { const double *g, *b; };
 template <> struct GTarget<T_GAUSS_DENSE> {
     static constexpr bool kShared = true, kTile = true, kUser = false;
     static constexpr bool kLinear = false;     // (it is affine, but its slope lives in an LDS tile: keep the generic path)
+    static constexpr int kAffineFrom = 1 << 30;
     static constexpr int kExtraTiles = 4;          // two gradient tiles, P v, scratch x_t
     template <class T> using Sh = DenseSh<T>;
     const double *P;
@@ -1538,7 +1556,8 @@ __global__ __launch_bounds__(256, GroupOcc<TARGET>::kWaves) void group_kernel(co
 template <int SAMPLER, int TARGET, bool FD> struct RegForm {
     static constexpr bool kSlowZz = SAMPLER == S_ZIGZAG && FD;                       // measured: 88 ms against 73 ms in the LDS form
     static constexpr bool kPartial = !kSlowZz && !(SAMPLER == S_BOOMERANG && TARGET != T_GAUSS_DIAG);   // would spill: Boomerang iso / banana
-    static constexpr bool kFull = !kSlowZz && !GTarget<TARGET>::kShared && !(SAMPLER != S_BPS && TARGET == T_GAUSS_DIAG);   // would spill: banana, Zig-Zag / Boomerang diag
+    static constexpr bool kFull = !kSlowZz && (!GTarget<TARGET>::kShared || (SAMPLER == S_ZIGZAG && TARGET == T_BANANA)) &&
+                                  !(SAMPLER != S_BPS && TARGET == T_GAUSS_DIAG);   // would spill: BPS / Boomerang banana, Zig-Zag / Boomerang diag
     static constexpr bool kAny = (kPartial || kFull) && SAMPLER != S_FECMC;
 };
 
