@@ -1551,14 +1551,13 @@ __global__ __launch_bounds__(256, GroupOcc<TARGET>::kWaves) void group_kernel(co
     group_kernel_body<SAMPLER, TARGET, FD>(gp);
 }
 // Which register-form kernels exist.  kAny: the form is used at all; kPartial: also for K < KC (with the per-slot skips);
-// kFull: a separate instantiation without the skips for K == KC.  Set from the compiler's resource-usage remarks so that no
+// full<GC>(): a separate instantiation without the skips for K == KC.  Set from the compiler's resource-usage remarks so that no
 // instantiation spills a VGPR (see below), and from measurements (Zig-Zag with finite differences: the LDS form is faster).
 template <int SAMPLER, int TARGET, bool FD> struct RegForm {
     static constexpr bool kSlowZz = SAMPLER == S_ZIGZAG && FD;                       // measured: 88 ms against 73 ms in the LDS form
-    static constexpr bool kPartial = !kSlowZz && !(SAMPLER == S_BOOMERANG && TARGET != T_GAUSS_DIAG);   // would spill: Boomerang iso / banana
-    static constexpr bool kFull = !kSlowZz && (!GTarget<TARGET>::kShared || (SAMPLER == S_ZIGZAG && TARGET == T_BANANA)) &&
-                                  !(SAMPLER != S_BPS && TARGET == T_GAUSS_DIAG);   // would spill: BPS / Boomerang banana, Zig-Zag / Boomerang diag
-    static constexpr bool kAny = (kPartial || kFull) && SAMPLER != S_FECMC;
+    static constexpr bool kPartial = !kSlowZz && !(SAMPLER == S_BOOMERANG && TARGET != T_GAUSS_DIAG);   // would spill: Boomerang iso / banana with the skips
+    template <int GC> static constexpr bool full() { return !kSlowZz && !(SAMPLER == S_ZIGZAG && TARGET == T_GAUSS_DIAG && GC == 1); }   // would spill: that one
+    static constexpr bool kAny = !kSlowZz && SAMPLER != S_FECMC;
 };
 
 // register form (x, v in VGPRs, up to KC slots per lane, G fixed at compile time): no LDS tiles; 2 waves per SIMD -- the
@@ -1612,7 +1611,7 @@ hipError_t launch_group_impl(const GroupParams &gp_in, hipStream_t stream) {
     if constexpr (KC > 0) {
         using RF = RegForm<SAMPLER, TARGET, FD>;
         if constexpr (RF::kPartial) kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, false>;
-        if constexpr (RF::kFull) if (gp.K == KC) kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, true>;
+        if constexpr (RF::template full<GC>()) if (gp.K == KC) kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, true>;
     } else kernel = group_kernel<SAMPLER, TARGET, FD>;
     if (!kernel) return hipErrorNotSupported;
     hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
