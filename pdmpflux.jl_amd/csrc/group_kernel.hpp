@@ -199,7 +199,7 @@ template <> struct GTarget<T_USER> {
 // KC = 0: K = ceil(d/G) slots per lane at run time, x and v in LDS tiles.  KC > 0 (register form): up to KC slots, x and v in
 // REGISTERS, every slot loop fully unrolled with a scalar skip of the slots >= K -- no ds_read latency in the loops, no slot
 // addressing.  Same operations in the same order: the two forms agree bit for bit.
-#define PDMP_SLOTS(s) _Pragma("unroll kUnroll") for (int s = 0; s < nk(); ++s) if (!kReg || s < K)
+#define PDMP_SLOTS(s) _Pragma("unroll kUnroll") for (int s = 0; s < nk(); ++s) if (!kReg || s < kmin || s < K)
 template <int SAMPLER, int TARGET, bool FD, int KC = 0>
 struct GroupChain {
     using Tgt = GTarget<TARGET>;
@@ -210,6 +210,9 @@ struct GroupChain {
     static_assert(!kReg || (!Tgt::kTile && !Tgt::kUser && KC >= 2), "register form: separable / banana targets only");
     const SkelParams &p;
     const int G, K, lane, g, base;       // g = lane within the group, base = first lane of the group
+    // register form: the host picks the smallest G with ceil(d/G) <= KREG, so K >= (KREG+1)/2 whenever G >= 2 -- those slots
+    // need no skip (G is a compile-time constant there) and their dependency chains interleave
+    const int kmin;
     double *xs, *vs;                     // this wave's LDS tiles: slot s of lane l at [s*64 + l]
     mutable double xr[kReg ? KC : 1], vr[kReg ? KC : 1];   // register form: slot s of this lane
     double *fe_t[4] = {nullptr, nullptr, nullptr, nullptr};   // ForwardECMC: LDS tiles for n, v_orth, e1 / g1, e2 / g2 / the proposal
@@ -222,7 +225,7 @@ struct GroupChain {
 
     const int cell_budget;               // cells of a lazily built bound per pass of the state machine (bound_advance_vect)
     __device__ __forceinline__ GroupChain(const GroupParams &gp, int l, double *x_tile, double *v_tile)
-        : p(gp.s), G(gp.G), K(gp.K), lane(l), g(l & (gp.G - 1)), base(l & ~(gp.G - 1)), xs(x_tile), vs(v_tile),
+        : p(gp.s), G(gp.G), K(gp.K), lane(l), g(l & (gp.G - 1)), base(l & ~(gp.G - 1)), kmin(gp.G >= 2 ? (KC + 1) / 2 : 1), xs(x_tile), vs(v_tile),
           cell_budget(gp.cell_budget) {}
 
     __device__ __forceinline__ double &X(int s) const { if constexpr (kReg) return xr[s]; else return xs[s * WAVE + lane]; }

@@ -23,7 +23,7 @@ static hipError_t reg_by_lanes(const GroupParams &gp, hipStream_t stream) {
 
 template <int S>
 static hipError_t reg_by_target(int target, bool fd, const GroupParams &gp, hipStream_t stream) {
-    if (gp.K > KREG) return hipErrorNotSupported;
+    if (gp.K > KREG || (gp.G >= 2 && gp.K < (KREG + 1) / 2)) return hipErrorNotSupported;   // (forced lane counts only: the LDS form serves them)
     switch (target) {
     case T_GAUSS_ISO: return fd ? reg_by_lanes<S, T_GAUSS_ISO, true>(gp, stream) : reg_by_lanes<S, T_GAUSS_ISO, false>(gp, stream);
     case T_GAUSS_DIAG: return fd ? reg_by_lanes<S, T_GAUSS_DIAG, true>(gp, stream) : reg_by_lanes<S, T_GAUSS_DIAG, false>(gp, stream);
