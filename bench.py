@@ -239,8 +239,10 @@ def main():
         achieved = C * (n_sk - 1) * bytes_per_event / (kernel_ms * 1e-3) / 1e9
         G = sampler.group_lanes()
         K = (d + G - 1) // G if G > 0 else 0
-        reg_form = G > 0 and sampler.sampler_id == 0 and sampler.deriv_mode == 0 and K <= 13 and G <= 16 and a.target in ("iso", "banana") \
-            and os.environ.get("PDMP_REG", "1") != "0"
+        # mirrors RegForm in csrc/group_kernel.hpp (which register-form instantiations exist)
+        sid, fd = sampler.sampler_id, sampler.deriv_mode != 0
+        reg_form = (G > 0 and sid in (0, 1, 2) and K <= 13 and G <= 16 and (G == 1 or K >= 7) and a.target in ("iso", "banana")
+                    and not (sid == 0 and fd) and not (sid == 2 and K != 13) and os.environ.get("PDMP_REG", "1") != "0")
         kernel = (f"group_kernel_reg<{sampler.name},{a.target}> (G={G} lanes per chain, x and v in registers)" if reg_form else
                   f"group_kernel<{sampler.name},{a.target}> (G={G} lanes per chain)" if G > 0 else
                   f"skeleton_kernel<{sampler.name},{a.target}> (wave per chain)")
@@ -258,7 +260,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(a),
                          "kernel": kernel, "kernel_ms": kernel_ms, "bytes_per_event": bytes_per_event,
                          "note": "fp64 state machine bound by VALU issue (config 2: 115 VALU instructions per event, VALU busy 81 % "
-                                 "at 2 waves/SIMD, profiles/r1/final3_zz_iso_pmc.json); HBM fraction is the requested headline"},
+                                 "at 2 waves/SIMD, profiles/r1/final3_zz_iso_pmc.json; Zig-Zag banana: 142, profiles/r1/zz_banana_r1b_pmc.json; "
+                                 "BPS banana: 404, profiles/r1/bps_banana_r1b_pmc.json); HBM fraction is the requested headline"},
         }
         phases = int(_lib.lib().pdmp_dense_batched_last_phases()) if a.target == "dense" else 0
         if phases > 0:      # dense-precision path: the dominant kernel is the fp64 GEMM P x [requests | velocities] per phase
