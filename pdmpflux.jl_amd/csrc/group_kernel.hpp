@@ -1603,7 +1603,8 @@ inline void group_schedule(int64_t nb, int64_t slots, int64_t n_sk, int force, i
 template <int SAMPLER, int TARGET>
 hipError_t launch_group(const GroupParams &gp, hipStream_t stream);
 
-template <int SAMPLER, int TARGET, bool FD, int KC = 0, int GC = 0>
+// EXACT: only the FULL variant (K == KC) of this KC is instantiated (inst_reg_*_k.hip: one kernel per K = 7..12)
+template <int SAMPLER, int TARGET, bool FD, int KC = 0, int GC = 0, bool EXACT = false>
 hipError_t launch_group_impl(const GroupParams &gp_in, hipStream_t stream) {
     GroupParams gp = gp_in;
     if (KC > 0) gp.tiles = (SAMPLER == S_ZIGZAG) ? 0 : 1;
@@ -1613,7 +1614,7 @@ hipError_t launch_group_impl(const GroupParams &gp_in, hipStream_t stream) {
     void (*kernel)(const GroupParams) = nullptr;
     if constexpr (KC > 0) {
         using RF = RegForm<SAMPLER, TARGET, FD>;
-        if constexpr (RF::kPartial) kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, false>;
+        if constexpr (RF::kPartial && !EXACT) kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, false>;
         if constexpr (RF::template full<GC>()) if (gp.K == KC) kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, true>;
     } else kernel = group_kernel<SAMPLER, TARGET, FD>;
     if (!kernel) return hipErrorNotSupported;

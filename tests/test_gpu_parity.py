@@ -365,6 +365,23 @@ def test_register_and_lds_forms_agree(engine, oracle, monkeypatch, kind, dim, ta
     assert_bitwise(lds, ref)
 
 
+@pytest.mark.parametrize("dim", [14, 30, 70, 160, 22, 48, 96, 183])   # (G, K) = (2,7) (4,8) (8,9) (16,10) (2,11) (4,12) (8,12) (16,12)
+@pytest.mark.parametrize("kind,target", [("ZigZagAD", "iso"), ("ZigZagAD", "diag"), ("ZigZagAD", "banana"),
+                                         ("BPS", "iso"), ("BPS", "diag"), ("BPS", "banana")])
+def test_exact_slot_count_kernels(engine, oracle, monkeypatch, kind, dim, target):
+    """Forward-mode Zig-Zag / BPS with K = ceil(d/G) in 7..12 run a register-form kernel of exactly K slots
+    (inst_reg_*_k.hip); PDMP_REG_EXACT=0 selects the 13-slot kernel with per-slot skips.  Both equal the checker."""
+    s, cfg = make_pair(engine, oracle, kind, dim, target)
+    G = s.group_lanes()
+    assert G >= 2 and 7 <= -(-dim // G) <= 12
+    C, n_sk = 19, 30
+    x, v = make_init(kind, dim, C, seed=31, target=target)
+    ref = oracle.sample_skeleton(cfg, n_sk, x, v, 23, diagnostics=True)
+    assert_bitwise(engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=23, diagnostics=True), ref)
+    monkeypatch.setenv("PDMP_REG_EXACT", "0")
+    assert_bitwise(engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=23, diagnostics=True), ref)
+
+
 @pytest.mark.parametrize("budget", ["1", "2", "5", "8"])
 @pytest.mark.parametrize("kind,dim,target,kw", [
     ("ZigZagAD", 50, "iso", {}), ("ZigZagAD", 50, "banana", {}), ("ZigZag", 20, "banana", {}), ("ZigZagAD", 7, "diag", {"signed_bound": False}),
