@@ -15,8 +15,10 @@ namespace pdmp {
 hipError_t launch_group_reg_zigzag(int target, bool fd, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_bps(int target, bool fd, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_boomerang(int target, bool fd, const GroupParams &gp, hipStream_t stream);
-hipError_t launch_group_reg_zigzag_exact(int target, bool fd, const GroupParams &gp, hipStream_t stream);
-hipError_t launch_group_reg_bps_exact(int target, bool fd, const GroupParams &gp, hipStream_t stream);
+hipError_t launch_group_reg_zigzag_exact(int target, const GroupParams &gp, hipStream_t stream);
+hipError_t launch_group_reg_bps_exact(int target, const GroupParams &gp, hipStream_t stream);
+hipError_t launch_group_reg_boomerang_exact(int target, const GroupParams &gp, hipStream_t stream);
+hipError_t launch_group_reg_boomerang_exact_fd(int target, const GroupParams &gp, hipStream_t stream);
 }
 
 namespace {
@@ -662,8 +664,11 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
             const bool fd = c.deriv_mode != 0;
             const char *ex = getenv("PDMP_REG_EXACT");      // PDMP_REG_EXACT=0: the KREG-slot kernels with per-slot skips (test hook)
             if (!(ex && atoi(ex) == 0))                     // a kernel of exactly K slots where one exists
-                e = c.sampler == PDMP_ZIGZAG ? launch_group_reg_zigzag_exact(c.target_id, fd, gp, s)
-                  : c.sampler == PDMP_BPS    ? launch_group_reg_bps_exact(c.target_id, fd, gp, s) : hipErrorNotSupported;
+                e = c.sampler == PDMP_BOOMERANG    ? (fd ? launch_group_reg_boomerang_exact_fd(c.target_id, gp, s)
+                                                         : launch_group_reg_boomerang_exact(c.target_id, gp, s))
+                  : fd                             ? hipErrorNotSupported
+                  : c.sampler == PDMP_ZIGZAG       ? launch_group_reg_zigzag_exact(c.target_id, gp, s)
+                  : c.sampler == PDMP_BPS          ? launch_group_reg_bps_exact(c.target_id, gp, s) : hipErrorNotSupported;
             if (e == hipErrorNotSupported)
                 e = c.sampler == PDMP_ZIGZAG    ? launch_group_reg_zigzag(c.target_id, fd, gp, s)
                   : c.sampler == PDMP_BPS       ? launch_group_reg_bps(c.target_id, fd, gp, s)

@@ -33,38 +33,37 @@ static hipError_t reg_by_target(int target, bool fd, const GroupParams &gp, hipS
 }
 
 // Exact-K kernels (inst_reg_*_k.hip): the FULL variant for every K = (KREG+1)/2 .. KREG-1 that the lanes-per-chain rule can
-// produce with G >= 2, forward-mode slopes -- no per-slot skips, so the slot bodies interleave (38-41 % faster than the
+// produce with G >= 2 (Zig-Zag, BPS: forward-mode slopes; Boomerang: both slope modes) -- no per-slot skips, so the slot bodies interleave (38-41 % faster than the
 // partial variant of KREG slots where both were measured).
-template <int S, int T, int KC>
+template <int S, int T, bool FD, int KC>
 static hipError_t exact_by_lanes(const GroupParams &gp, hipStream_t stream) {
     switch (gp.G) {
-    case 2: return launch_group_impl<S, T, false, KC, 2, true>(gp, stream);
-    case 4: return launch_group_impl<S, T, false, KC, 4, true>(gp, stream);
-    case 8: return launch_group_impl<S, T, false, KC, 8, true>(gp, stream);
-    case 16: return launch_group_impl<S, T, false, KC, 16, true>(gp, stream);
+    case 2: return launch_group_impl<S, T, FD, KC, 2, true>(gp, stream);
+    case 4: return launch_group_impl<S, T, FD, KC, 4, true>(gp, stream);
+    case 8: return launch_group_impl<S, T, FD, KC, 8, true>(gp, stream);
+    case 16: return launch_group_impl<S, T, FD, KC, 16, true>(gp, stream);
     default: return hipErrorNotSupported;
     }
 }
-template <int S, int T>
+template <int S, int T, bool FD>
 static hipError_t exact_by_slots(const GroupParams &gp, hipStream_t stream) {
     static_assert(KREG == 13, "one case per K below");
     switch (gp.K) {
-    case 7: return exact_by_lanes<S, T, 7>(gp, stream);
-    case 8: return exact_by_lanes<S, T, 8>(gp, stream);
-    case 9: return exact_by_lanes<S, T, 9>(gp, stream);
-    case 10: return exact_by_lanes<S, T, 10>(gp, stream);
-    case 11: return exact_by_lanes<S, T, 11>(gp, stream);
-    case 12: return exact_by_lanes<S, T, 12>(gp, stream);
+    case 7: return exact_by_lanes<S, T, FD, 7>(gp, stream);
+    case 8: return exact_by_lanes<S, T, FD, 8>(gp, stream);
+    case 9: return exact_by_lanes<S, T, FD, 9>(gp, stream);
+    case 10: return exact_by_lanes<S, T, FD, 10>(gp, stream);
+    case 11: return exact_by_lanes<S, T, FD, 11>(gp, stream);
+    case 12: return exact_by_lanes<S, T, FD, 12>(gp, stream);
     default: return hipErrorNotSupported;
     }
 }
-template <int S>
-static hipError_t exact_by_target(int target, bool fd, const GroupParams &gp, hipStream_t stream) {
-    if (fd) return hipErrorNotSupported;
+template <int S, bool FD>       // one translation unit per (sampler, slope mode)
+static hipError_t exact_by_target(int target, const GroupParams &gp, hipStream_t stream) {
     switch (target) {
-    case T_GAUSS_ISO: return exact_by_slots<S, T_GAUSS_ISO>(gp, stream);
-    case T_GAUSS_DIAG: return exact_by_slots<S, T_GAUSS_DIAG>(gp, stream);
-    case T_BANANA: return exact_by_slots<S, T_BANANA>(gp, stream);
+    case T_GAUSS_ISO: return exact_by_slots<S, T_GAUSS_ISO, FD>(gp, stream);
+    case T_GAUSS_DIAG: return exact_by_slots<S, T_GAUSS_DIAG, FD>(gp, stream);
+    case T_BANANA: return exact_by_slots<S, T_BANANA, FD>(gp, stream);
     default: return hipErrorNotSupported;
     }
 }

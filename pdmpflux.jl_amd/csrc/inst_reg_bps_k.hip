@@ -2,5 +2,5 @@
 #include "inst_reg.hpp"
 
 namespace pdmp {
-hipError_t launch_group_reg_bps_exact(int target, bool fd, const GroupParams &gp, hipStream_t stream) { return exact_by_target<S_BPS>(target, fd, gp, stream); }
+hipError_t launch_group_reg_bps_exact(int target, const GroupParams &gp, hipStream_t stream) { return exact_by_target<S_BPS, false>(target, gp, stream); }
 }  // namespace pdmp

@@ -2,5 +2,5 @@
 #include "inst_reg.hpp"
 
 namespace pdmp {
-hipError_t launch_group_reg_zigzag_exact(int target, bool fd, const GroupParams &gp, hipStream_t stream) { return exact_by_target<S_ZIGZAG>(target, fd, gp, stream); }
+hipError_t launch_group_reg_zigzag_exact(int target, const GroupParams &gp, hipStream_t stream) { return exact_by_target<S_ZIGZAG, false>(target, gp, stream); }
 }  // namespace pdmp

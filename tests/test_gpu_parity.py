@@ -367,10 +367,11 @@ def test_register_and_lds_forms_agree(engine, oracle, monkeypatch, kind, dim, ta
 
 @pytest.mark.parametrize("dim", [14, 30, 70, 160, 22, 48, 96, 183])   # (G, K) = (2,7) (4,8) (8,9) (16,10) (2,11) (4,12) (8,12) (16,12)
 @pytest.mark.parametrize("kind,target", [("ZigZagAD", "iso"), ("ZigZagAD", "diag"), ("ZigZagAD", "banana"),
-                                         ("BPS", "iso"), ("BPS", "diag"), ("BPS", "banana")])
+                                         ("BPS", "iso"), ("BPS", "diag"), ("BPS", "banana"),
+                                         ("Boomerang", "iso"), ("Boomerang", "diag"), ("BoomerangAD", "iso"), ("BoomerangAD", "banana")])
 def test_exact_slot_count_kernels(engine, oracle, monkeypatch, kind, dim, target):
-    """Forward-mode Zig-Zag / BPS with K = ceil(d/G) in 7..12 run a register-form kernel of exactly K slots
-    (inst_reg_*_k.hip); PDMP_REG_EXACT=0 selects the 13-slot kernel with per-slot skips.  Both equal the checker."""
+    """Forward-mode Zig-Zag / BPS and Boomerang (both slope modes) with K = ceil(d/G) in 7..12 run a register-form kernel
+    of exactly K slots (inst_reg_*_k.hip, inst_reg_boomerang_kfd.hip); PDMP_REG_EXACT=0 selects the 13-slot kernel with per-slot skips.  Both equal the checker."""
     s, cfg = make_pair(engine, oracle, kind, dim, target)
     G = s.group_lanes()
     assert G >= 2 and 7 <= -(-dim // G) <= 12
