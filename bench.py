@@ -263,6 +263,11 @@ def main():
                                  "at 2 waves/SIMD, profiles/r1/final3_zz_iso_pmc.json; Zig-Zag banana: 142, profiles/r1/zz_banana_r1b_pmc.json; "
                                  "BPS banana: 404, profiles/r1/bps_banana_r1b_pmc.json); HBM fraction is the requested headline"},
         }
+        if a.target == "dense" and int(_lib.lib().pdmp_dense_batched_last_mode()) == 2:
+            res["roofline"]["kernel"] = ("di_segment_kernel (wave per chain; P x and P v kept current by O(d) updates, one rocBLAS dgemm over all "
+                                         "chains per 256 events re-bases them)")
+            res["roofline"]["note"] = ("latency-bound: one chain per wave, 2 waves/SIMD; per event it writes 8(2d+1) B and reads one 8d-byte "
+                                       "column of P (profiles/r1/c4_incr_pmc.json)")
         phases = int(_lib.lib().pdmp_dense_batched_last_phases()) if a.target == "dense" else 0
         if phases > 0:      # dense-precision path: the dominant kernel is the fp64 GEMM P x [requests | velocities] per phase
             cols = int(_lib.lib().pdmp_dense_batched_last_columns())   # C per phase, 2C when P v is re-synchronised (every 32nd phase)

@@ -196,6 +196,9 @@ int pdmp_reset_timing(pdmp_handle h);
 long long pdmp_dense_batched_last_phases(void);
 /* ... and the number of right-hand-side columns those GEMMs multiplied (C per phase, 2C when P v is re-synchronised). */
 long long pdmp_dense_batched_last_columns(void);
+/* ... and which form served it: 0 none yet, 1 one GEMM per phase (d > 1024 or PDMP_DENSE_MODE=gemm), 2 incremental
+ * (P x and P v kept current by O(d) updates, one GEMM per `PDMP_DENSE_RESYNC` = 256 events; last_phases() is 0 then). */
+int pdmp_dense_batched_last_mode(void);
 
 /* Test hook: first n variates of stream (seed, chain) produced ON THE DEVICE with the engine's
  * generator; kind 0 uniform, 1 Exp(1), 2 normal vector.  out is a HOST pointer. */

@@ -60,7 +60,7 @@ SYMBOLS = (
     "pdmp_abi_version", "pdmp_last_error", "pdmp_device_count", "pdmp_create", "pdmp_create_from_source", "pdmp_get_config",
     "pdmp_destroy", "pdmp_get_group_lanes", "pdmp_set_tape", "pdmp_clear_tape", "pdmp_sample_skeleton", "pdmp_sample_skeleton_device", "pdmp_sample_from_skeleton",
     "pdmp_sample_from_skeleton_device", "pdmp_sample_from_skeleton_dt", "pdmp_sample_from_skeleton_dt_device", "pdmp_sample_moments_device", "pdmp_close_at_time_device", "pdmp_check_status", "pdmp_get_timing", "pdmp_reset_timing",
-    "pdmp_debug_rng", "pdmp_dense_batched_last_phases", "pdmp_dense_batched_last_columns",
+    "pdmp_debug_rng", "pdmp_dense_batched_last_phases", "pdmp_dense_batched_last_columns", "pdmp_dense_batched_last_mode",
 )
 
 _lib = None
@@ -108,6 +108,7 @@ def lib():
     L.pdmp_debug_rng.argtypes = [vp, u64, i64, i32, i64, vp]
     L.pdmp_dense_batched_last_phases.restype = C.c_longlong
     L.pdmp_dense_batched_last_columns.restype = C.c_longlong
+    L.pdmp_dense_batched_last_mode.restype = C.c_int
     if L.pdmp_abi_version() != 5:
         raise EngineError(ERR_RUNTIME, "ABI version mismatch")
     _lib = L

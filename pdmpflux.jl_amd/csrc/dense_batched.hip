@@ -265,11 +265,239 @@ __global__ __launch_bounds__(256) void db_step_kernel(const DbParams p) {
     if (lane == 0) p.st[c] = s;
 }
 
+
+// ---------------------------------------------------------------- incremental form (the default for Zig-Zag on a dense precision)
+// grad-U is linear and the Zig-Zag flow is x + v t, so along a chain's trajectory
+//     P (x + v t) = P x + t P v,        a flow by tau:  P x <- P x + tau P v,        a flip of v_m:  P v <- P v - 2 v_m P[:, m],
+// i.e. once gx = P x and gv = P v are known, every gradient the thinning loop asks for -- nine grid times per bound, the
+// proposal -- is an O(d) fma, and an event costs one column of P instead of ~12 products with all of P.  One wave per chain,
+// x, v, gx, gv in registers (coordinate i = s*64 + lane), control flow wave-uniform, the loop of src/SamplingLoopInplace.jl
+// written straight down (same state machine, random-stream order and cell arithmetic as db_step_kernel above).  The recurrences
+// only accumulate rounding (one fma per flow, one per flip), and they are re-based every `resync` events on exact products:
+// the host runs the chains in segments and recomputes [P x | P v] of ALL chains with one fp64 GEMM (matrix cores) between
+// segments.  Checked against the oracle to the same tolerance as the GEMM-per-phase path.
+struct DiState { double t, horizon; unsigned long long rng_n; int32_t dead, pad; };
+
+struct DiParams {
+    int32_t d, signed_bound, adaptive;
+    int64_t C, n_sk, chain0, cap, k_begin, k_end;   // this launch records skeleton columns k_begin .. k_end-1
+    uint64_t seed;
+    double tmax;
+    double *In;                  // d x 2C column-major: [x | v] of every chain (state between segments, GEMM input)
+    const double *Out;           // d x 2C: [P x | P v] (GEMM output)
+    const double *P;
+    DiState *st;
+    double *X, *V, *t, *H, *AR, *EV;
+    int32_t *EB, *RJ, *HH;
+    int32_t *status;             // [0] itercap, [1] guard
+    int32_t *ndead;
+};
+
+// SGN: signed_bound (the constructor default).  There the slope of every coordinate's rate is the same double at both ends of a
+// cell (gv_i v_i), so den == 0 exactly and the tangent intersection needs no division -- as in the group kernel's kLinear path.
+template <int KC, bool SGN>
+__global__ __launch_bounds__(256, SGN ? 2 : 1) void di_segment_kernel(const DiParams p) {
+    const int lane = lane_id();
+    const int64_t c = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (c >= p.C) return;
+    DiState cs;
+    if (p.k_begin == 0) { cs.t = 0.0; cs.horizon = p.tmax; cs.rng_n = 0; cs.dead = 0; cs.pad = 0; }
+    else cs = p.st[c];
+    if (cs.dead) return;
+    const int d = p.d;
+    const bool adaptive = p.adaptive != 0;
+    constexpr bool sgn = SGN;
+    // v, gx = P x, gv = P v in registers; x is only touched by flows and records: it lives in LDS (KC*512 B per wave)
+    __shared__ double x_lds[4][KC * WAVE];
+    double *x = x_lds[threadIdx.x >> 6] + lane;          // slot s at x[s * WAVE]
+    double v[KC], gx[KC], gv[KC];
+    {
+        const double *xin = p.In + (size_t)c * d, *vin = p.In + ((size_t)p.C + (size_t)c) * d;
+        const double *gxin = p.Out + (size_t)c * d, *gvin = p.Out + ((size_t)p.C + (size_t)c) * d;
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+            const int i = s * WAVE + lane;
+            const bool ok = i < d;
+            x[s * WAVE] = ok ? xin[i] : 0.0; v[s] = ok ? vin[i] : 0.0; gx[s] = ok ? gxin[i] : 0.0; gv[s] = ok ? gvin[i] : 0.0;
+        }
+    }
+    ChainRng rng;
+    rng.init(p.seed, (uint64_t)(p.chain0 + c));
+    rng.restore(cs.rng_n);
+    double t = cs.t, horizon = cs.horizon, ts = 0.0, ar = 0.0, E = 0.0, hB = horizon;
+    double ev[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    int errored = 0, rejected = 0, hits = 0, mode = DB_FRESH;
+    int64_t k = p.k_begin, it = 0;
+    bool dead = false;
+
+    auto record = [&](int64_t kk) {
+        const size_t e = (size_t)c * (size_t)p.n_sk + (size_t)kk;
+        double *Xe = p.X + e * (size_t)d, *Ve = p.V + e * (size_t)d;
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+            const int i = s * WAVE + lane;
+            if (i < d) { Xe[i] = x[s * WAVE]; Ve[i] = v[s]; }
+        }
+        if (lane == 0) {
+            p.t[e] = t;
+            if (p.H) p.H[e] = horizon;
+            if (p.AR) p.AR[e] = ar;
+            if (p.EB) p.EB[e] = errored;
+            if (p.RJ) p.RJ[e] = rejected;
+            if (p.HH) p.HH[e] = hits;
+            if (p.EV) for (int q = 0; q < 5; ++q) p.EV[5 * e + q] = ev[q];
+        }
+    };
+    auto flow = [&](double tau) {              // x <- x + v tau (ZigZagSamplers.jl:80) and P x with it
+#pragma unroll
+        for (int s = 0; s < KC; ++s) { x[s * WAVE] = fma(v[s], tau, x[s * WAVE]); gx[s] = fma(tau, gv[s], gx[s]); }
+    };
+
+    if (k == 0) { record(0); k = 1; }          // init_state + record of the initial state (sample.jl:271-272)
+    while (k < p.k_end) {
+        if (++it > p.cap * 4) { dead = true; break; }
+        // ---- bound over [0, harg]: one_step_of_thinning! (:65-85) / erroneous_acceptance_rate! (:131-151) / if_reject! (:188-203)
+        const double harg = (mode == DB_ERR) ? horizon / 2 : ((mode == DB_REUSE) ? hB : horizon);
+        hB = harg;
+        const double h = harg / 9.0;
+        const double e1 = rng.exponential();
+        E = (mode == DB_REUSE) ? E + e1 : e1;
+        double acc = 0.0, cprev = 0.0, tp = __builtin_huge_val(), lb = 0.0;
+        for (int j = 0; j < 9; ++j) {          // cells built lazily in grid order (upper_bound_grid_vect, UpperBound.jl:208-246)
+            const double t0 = (double)j * h, t1 = (j == 8) ? harg : (double)(j + 1) * h;
+            double part = 0.0;
+#pragma unroll
+            for (int s = 0; s < KC; ++s) {
+                const double vi = v[s], g = gv[s] * vi;
+                double v0 = fma(t0, gv[s], gx[s]) * vi, v1 = fma(t1, gv[s], gx[s]) * vi;   // signed_rate_vect at the two grid times
+                double g0 = g, g1 = g;
+                if (!sgn) { g0 = (0.0 < v0) ? g : 0.0; g1 = (0.0 < v1) ? g : 0.0; v0 = fmax(0.0, v0); v1 = fmax(0.0, v1); }
+                const double num = fma(-g0, t0, fma(g1, t1, v0 - v1));         // :229
+                const double den = g1 - g0;
+                const double q = (sgn || den == 0.0) ? ((num > 0.0) ? h : 0.0) : fmin(fmax(num / den, 0.0), h);   // :234-235
+                const double inter = fma(g0, q, v0);                           // :237
+                part += fmax(fmax(fmax(v0, v1), inter), 0.0);                  // :239-241
+            }
+            const double bj = wave_sum(part);                                  // :246
+            acc += bj;
+            const double cj = acc * h;
+            lb = bj;
+            if (!(cj < E)) { tp = t0 + (E - cprev) / (cj - cprev) * h; break; }   // next_event, :264-273
+            cprev = cj;
+        }
+        bool propose;
+        if (mode == DB_ERR) {                                                  // :131-151
+            if (adaptive) horizon = hB;
+            errored++;
+            { const int slot = errored % 5;
+#pragma unroll
+              for (int q = 0; q < 5; ++q) if (q == slot) ev[q] = ar; }
+            propose = tp < horizon;
+        } else if (mode == DB_REUSE) {                                         // :188-203
+            if (adaptive) horizon = horizon / 1.04;
+            rejected++;
+            if (tp > horizon) { flow(horizon); ts += horizon; hits++; }
+            propose = tp < horizon;
+        } else if (tp > horizon) {                                             // move_to_horizon!, :87-101
+            flow(horizon);
+            ts += horizon;
+            hits++;
+            if (adaptive) horizon = horizon * 1.01;
+            propose = false;
+        } else {
+            propose = tp < horizon;
+        }
+        mode = DB_FRESH;
+        if (!propose) continue;
+        // ---- proposal at tp (ac_step!, :113-129): lambda = sum max(0, grad-U(x + v tp) .* v), ZigZagSamplers.jl:83-86
+        double part = 0.0;
+#pragma unroll
+        for (int s = 0; s < KC; ++s) part += fmax(0.0, fma(tp, gv[s], gx[s]) * v[s]);
+        const double lam = wave_sum(part);
+        ar = lam / lb;
+        if (ar > 1.0) { mode = DB_ERR; continue; }
+        const double u = rng.uniform();
+        if (!(u < ar)) { mode = DB_REUSE; continue; }
+        // ---- accepted (if_accept!, :170-186)
+        flow(tp);                                                              // gx becomes exactly the gradient the rate used
+        const double u2 = rng.uniform();
+        if (lam > 0.0) {
+            // velocity_jump (ZigZagSamplers.jl:101-107): Categorical over lambda_i / S as an un-normalised walk against u2*S in
+            // coordinate order; level 1 = slot totals (64 coordinates each), level 2 = one scan inside the slot that was hit
+            const double theta = u2 * lam;
+            int sh = -1;
+            double carry = 0.0, carry_at = 0.0;
+#pragma unroll
+            for (int s = 0; s < KC; ++s) {
+                const double Ts = wave_sum(fmax(0.0, gx[s] * v[s]));
+                if (sh < 0 && (carry + Ts > theta)) { sh = s; carry_at = carry; }
+                carry = carry + Ts;
+            }
+            int m = -1;
+            if (sh >= 0) {
+                double lsel = 0.0;
+#pragma unroll
+                for (int s = 0; s < KC; ++s) if (s == sh) lsel = fmax(0.0, gx[s] * v[s]);
+                const double inc = wave_scan_incl(lsel, lane);
+                const unsigned long long hit = __ballot((sh * WAVE + lane < d) && (carry_at + inc > theta));
+                if (hit != 0ull) m = sh * WAVE + (int)__builtin_ctzll(hit);
+            }
+            if (m < 0) m = d - 1;
+            m = __builtin_amdgcn_readfirstlane(m);
+            // v[m] *= -1 and P v follows by the rank-one term
+            const int ms = m >> 6, ml = m & (WAVE - 1);
+            double vsel = 0.0;
+#pragma unroll
+            for (int s = 0; s < KC; ++s) if (s == ms) vsel = v[s];
+            const double f = 2.0 * readlane_d(vsel, ml);
+            const double *__restrict__ Pm = p.P + (size_t)m * (size_t)d;
+            double pc[KC];                      // column m of P: issued here, consumed after the record's stores (latency overlapped)
+#pragma unroll
+            for (int s = 0; s < KC; ++s) {
+                const int i = s * WAVE + lane;
+                pc[s] = (i < d) ? Pm[i] : 0.0;
+            }
+#pragma unroll
+            for (int s = 0; s < KC; ++s) if (s == ms && lane == ml) v[s] = -v[s];
+            t = t + tp + ts;
+            ts = 0.0;
+            record(k);
+#pragma unroll
+            for (int s = 0; s < KC; ++s) gv[s] = gv[s] - f * pc[s];
+        } else {
+            if (lane == 0) atomicAdd(&p.status[1], 1);                         // Q11 guard
+            t = t + tp + ts;
+            ts = 0.0;
+            record(k);
+        }
+        errored = 0; rejected = 0; hits = 0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) ev[q] = 0.0;
+        it = 0;
+        ++k;
+    }
+    // state for the next segment: x, v back into the GEMM's input, the scalars into st
+    {
+        double *xo = p.In + (size_t)c * d, *vo = p.In + ((size_t)p.C + (size_t)c) * d;
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+            const int i = s * WAVE + lane;
+            if (i < d) { xo[i] = x[s * WAVE]; vo[i] = v[s]; }
+        }
+    }
+    if (lane == 0) {
+        cs.t = t; cs.horizon = horizon; cs.rng_n = rng.n; cs.dead = dead ? 1 : 0;
+        p.st[c] = cs;
+        if (dead) { atomicAdd(&p.status[0], 1); atomicAdd(p.ndead, 1); }
+    }
+}
+
 }  // namespace pdmp
 
 using namespace pdmp;
 
 static long long g_last_phases = 0, g_last_columns = 0;
+static int g_last_mode = 0;
 extern "C" long long pdmp_dense_batched_last_phases(void) { return g_last_phases; }   // GEMM phases of the last run (diagnostics)
 extern "C" long long pdmp_dense_batched_last_columns(void) { return g_last_columns; } // right-hand-side columns multiplied over those phases
 
@@ -317,6 +545,7 @@ extern "C" int pdmp_dense_batched_run(int device, int d, int signed_bound, int a
         int32_t live = 1;
         g_last_phases = 0;
         g_last_columns = 0;
+        g_last_mode = 1;
         for (int64_t ph = 0; ph < max_phases && live > 0; ++ph) {
             ++g_last_phases;
             // Out (d x C) = P (d x d) * requests (d x C): grad-U of every request.  The velocity half, P v of every chain, changes only
@@ -340,6 +569,85 @@ extern "C" int pdmp_dense_batched_run(int device, int d, int signed_bound, int a
 fail:
     (void)hipStreamSynchronize(stream);
     (void)hipFree(Xs); (void)hipFree(In); (void)hipFree(Out); (void)hipFree(Gprev); (void)hipFree(st); (void)hipFree(remaining);
+    return rc;
+#undef DB_TRY
+#undef DB_BLAS
+}
+
+extern "C" int pdmp_dense_batched_last_mode(void) { return g_last_mode; }   // 0 none, 1 GEMM per phase, 2 incremental
+
+static rocblas_handle db_handle(int device) {
+    static rocblas_handle handles[16] = {nullptr};
+    if (device < 0 || device >= 16) return nullptr;
+    if (!handles[device] && rocblas_create_handle(&handles[device]) != rocblas_status_success) handles[device] = nullptr;
+    return handles[device];
+}
+
+// Incremental driver: segments of `resync` events (PDMP_DENSE_RESYNC, default 256); before each segment one fp64 GEMM
+// [P x | P v] = P [x | v] over all chains.  Same return codes as pdmp_dense_batched_run; -5 when d > 1024 (the caller falls back).
+extern "C" int pdmp_dense_incremental_run(int device, int d, int signed_bound, int adaptive, double tmax, int64_t cap,
+                                          const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
+                                          const double *xinit, const double *vinit, double *X, double *V, double *t,
+                                          double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
+                                          int32_t *status, void *stream_v, char *err, int errlen) {
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (d > 16 * WAVE) return -5;
+#define DB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { snprintf(err, errlen, "%s: %s", #expr, hipGetErrorString(e_)); goto fail; } } while (0)
+#define DB_BLAS(expr) do { rocblas_status s_ = (expr); if (s_ != rocblas_status_success) { snprintf(err, errlen, "%s: rocblas status %d", #expr, (int)s_); goto fail; } } while (0)
+    double *In = nullptr, *Out = nullptr;
+    DiState *st = nullptr;
+    int32_t *ndead = nullptr;
+    int rc = -3;
+    {
+        const size_t n = (size_t)C * (size_t)d;
+        int64_t resync = 256;
+        if (const char *e = getenv("PDMP_DENSE_RESYNC")) { const long long r = atoll(e); if (r >= 1) resync = r; }
+        rocblas_handle hb = db_handle(device);
+        if (!hb) { snprintf(err, errlen, "rocblas handle"); goto fail; }
+        DB_TRY(hipMalloc(&In, 2 * n * 8));
+        DB_TRY(hipMalloc(&Out, 2 * n * 8));
+        DB_TRY(hipMalloc(&st, (size_t)C * sizeof(DiState)));
+        DB_TRY(hipMalloc(&ndead, sizeof(int32_t)));
+        DB_TRY(hipMemsetAsync(ndead, 0, sizeof(int32_t), stream));
+        DB_TRY(hipMemcpyAsync(In, xinit, n * 8, hipMemcpyDeviceToDevice, stream));
+        DB_TRY(hipMemcpyAsync(In + n, vinit, n * 8, hipMemcpyDeviceToDevice, stream));
+        DB_BLAS(rocblas_set_stream(hb, stream));
+        DB_BLAS(rocblas_set_pointer_mode(hb, rocblas_pointer_mode_host));
+        DiParams p;
+        p.d = d; p.signed_bound = signed_bound; p.adaptive = adaptive;
+        p.C = C; p.n_sk = n_sk; p.chain0 = chain0; p.cap = cap; p.seed = seed; p.tmax = tmax;
+        p.In = In; p.Out = Out; p.P = P_dev; p.st = st;
+        p.X = X; p.V = V; p.t = t; p.H = H; p.AR = AR; p.EV = EV; p.EB = EB; p.RJ = RJ; p.HH = HH;
+        p.status = status; p.ndead = ndead;
+        const dim3 grid((unsigned)((C + 3) / 4)), block(256);
+        const double one = 1.0, zero = 0.0;
+        g_last_phases = 0; g_last_columns = 0; g_last_mode = 2;
+        for (int64_t k0 = 0; k0 < n_sk;) {
+            const int64_t k1 = (k0 == 0 ? 1 : k0) + resync < n_sk ? (k0 == 0 ? 1 : k0) + resync : n_sk;
+            DB_BLAS(rocblas_dgemm(hb, rocblas_operation_none, rocblas_operation_none, d, (int)(2 * C), d, &one, P_dev, d, In, d, &zero, Out, d));
+            g_last_columns += 2 * C;
+            p.k_begin = k0; p.k_end = k1;
+            if (signed_bound) {
+                if (d <= 4 * WAVE) hipLaunchKernelGGL((di_segment_kernel<4, true>), grid, block, 0, stream, p);
+                else if (d <= 8 * WAVE) hipLaunchKernelGGL((di_segment_kernel<8, true>), grid, block, 0, stream, p);
+                else hipLaunchKernelGGL((di_segment_kernel<16, true>), grid, block, 0, stream, p);
+            } else {
+                if (d <= 4 * WAVE) hipLaunchKernelGGL((di_segment_kernel<4, false>), grid, block, 0, stream, p);
+                else if (d <= 8 * WAVE) hipLaunchKernelGGL((di_segment_kernel<8, false>), grid, block, 0, stream, p);
+                else hipLaunchKernelGGL((di_segment_kernel<16, false>), grid, block, 0, stream, p);
+            }
+            DB_TRY(hipGetLastError());
+            k0 = k1;
+        }
+        int32_t nd = 0;
+        DB_TRY(hipMemcpyAsync(&nd, ndead, sizeof nd, hipMemcpyDeviceToHost, stream));
+        DB_TRY(hipStreamSynchronize(stream));
+        if (nd > 0) { snprintf(err, errlen, "%d chain(s) hit the iteration cap", (int)nd); rc = -4; goto fail; }
+        rc = 0;
+    }
+fail:
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(In); (void)hipFree(Out); (void)hipFree(st); (void)hipFree(ndead);
     return rc;
 #undef DB_TRY
 #undef DB_BLAS

@@ -50,6 +50,11 @@ extern "C" int pdmp_dense_batched_run(int device, int d, int signed_bound, int a
                                       const double *xinit, const double *vinit, double *X, double *V, double *t,
                                       double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
                                       int32_t *status, void *stream, char *err, int errlen);
+extern "C" int pdmp_dense_incremental_run(int device, int d, int signed_bound, int adaptive, double tmax, int64_t cap,
+                                      const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
+                                      const double *xinit, const double *vinit, double *X, double *V, double *t,
+                                      double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
+                                      int32_t *status, void *stream, char *err, int errlen);
 
 extern "C" int pdmp_user_compile(int device, int sampler, int fd, int kind, const char *source, void **fn_out, char *err, int errlen);
 extern "C" int pdmp_user_launch(void *fn, const GroupParams *gp, void *stream);
@@ -641,15 +646,21 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
     if (int rc = begin_timed(h, s, ev)) return rc;
     // Dense-precision Zig-Zag on many chains: grad-U of all chains as one fp64 GEMM per phase (dense_batched.hip);
     // small ensembles and PDMP_DENSE_MODE=matvec keep the bit-exact per-chain mat-vec kernel.
-    const char *dense_mode = getenv("PDMP_DENSE_MODE");
+    const char *dense_mode = getenv("PDMP_DENSE_MODE");       // "incr" | "gemm" | "matvec" (default: incr for >= 64 chains and d <= 1024, gemm beyond)
     const bool batched = c.target_id == PDMP_T_GAUSS_DENSE && c.sampler == PDMP_ZIGZAG && c.vectorized_bound && c.grid_size == GNG &&
                          c.deriv_mode == PDMP_DERIV_FORWARD && !taped && 2 * C < 0x7fffffffLL &&
-                         (dense_mode ? strcmp(dense_mode, "gemm") == 0 : C >= 64);
+                         (dense_mode ? (strcmp(dense_mode, "gemm") == 0 || strcmp(dense_mode, "incr") == 0) : C >= 64);
     if (batched) {
         char msg[256] = "";
-        const int rc = pdmp_dense_batched_run(h->device, c.dim, c.signed_bound, c.adaptive, c.tmax, c.max_iter_per_event, h->d_tparams, C, n_sk,
-                                              chain_id_offset, seed, xinit, vinit, X, V, t, p.H, p.AR, p.EB, p.EV, p.RJ, p.HH,
-                                              h->d_status, stream, msg, (int)sizeof msg);
+        int rc = -5;
+        if (!(dense_mode && strcmp(dense_mode, "gemm") == 0))   // P x, P v kept current incrementally: O(d) per gradient (dense_batched.hip)
+            rc = pdmp_dense_incremental_run(h->device, c.dim, c.signed_bound, c.adaptive, c.tmax, c.max_iter_per_event, h->d_tparams, C, n_sk,
+                                            chain_id_offset, seed, xinit, vinit, X, V, t, p.H, p.AR, p.EB, p.EV, p.RJ, p.HH,
+                                            h->d_status, stream, msg, (int)sizeof msg);
+        if (rc == -5)                                           // d > 1024 (or forced): one GEMM per phase
+            rc = pdmp_dense_batched_run(h->device, c.dim, c.signed_bound, c.adaptive, c.tmax, c.max_iter_per_event, h->d_tparams, C, n_sk,
+                                        chain_id_offset, seed, xinit, vinit, X, V, t, p.H, p.AR, p.EB, p.EV, p.RJ, p.HH,
+                                        h->d_status, stream, msg, (int)sizeof msg);
         if (rc != 0) return fail(rc == -4 ? PDMP_ERR_ITERCAP : PDMP_ERR_RUNTIME, "dense batched path: %s", msg);
         return end_timed(h, s, ev);
     }

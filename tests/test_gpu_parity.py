@@ -320,21 +320,30 @@ def test_tape_replay_bitwise(engine, oracle, kind, dim, target, kw):
     assert np.isfinite(again["t"]).all() and s.group_lanes() > 0
 
 
-@pytest.mark.parametrize("dim,chains,n_sk", [(100, 64, 80), (257, 70, 40)])
-def test_dense_precision_gemm_path_matches_oracle(engine, oracle, monkeypatch, dim, chains, n_sk):
-    """Config-4 path: for >= 64 chains grad-U = P x of ALL chains is one fp64 GEMM per phase on the matrix cores
-    (dense_batched.hip).  rocBLAS' MFMA accumulation order is not the checker's left-to-right row sums, so this path is
-    held to a tolerance -- event times and positions within 1e-9 relative of the reference-order restatement, velocities
-    and counters identical -- while PDMP_DENSE_MODE=matvec (the per-chain mat-vec kernel) stays bit-exact."""
-    s, cfg = make_pair(engine, oracle, "ZigZagAD", dim, "dense", arith=oracle.ARITH_REFERENCE)
+@pytest.mark.parametrize("mode,resync", [("incr", "256"), ("incr", "16"), ("incr", "1"), ("gemm", "256")])
+@pytest.mark.parametrize("dim,chains,n_sk", [(100, 64, 80), (257, 70, 40), (600, 64, 24)])
+def test_dense_precision_batched_paths_match_oracle(engine, oracle, monkeypatch, dim, chains, n_sk, mode, resync):
+    """Config-4 path, >= 64 chains.  Default ("incr"): grad-U is linear and the flow is x + v t, so P x and P v are kept current
+    by O(d) updates (P x += tau P v at a flow, P v -= 2 v_m P[:, m] at a flip) and re-based on exact products by one fp64
+    GEMM over all chains every PDMP_DENSE_RESYNC events.  "gemm" (d > 1024): grad-U = P x of ALL chains as one GEMM per
+    phase (dense_batched.hip).  Neither has the checker's left-to-right row sums (rocBLAS' MFMA accumulation order; the
+    recurrences), so both are held to a tolerance -- event times and positions within 1e-9 relative of the reference-order
+    restatement, velocities and counters identical -- while PDMP_DENSE_MODE=matvec (per-chain mat-vec kernel) is bit-exact."""
+    monkeypatch.setenv("PDMP_DENSE_MODE", mode)
+    monkeypatch.setenv("PDMP_DENSE_RESYNC", resync)
+    kw = {"signed_bound": False} if dim == 257 else {}          # the unsigned bound keeps the division of the tangent intersection
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", dim, "dense", arith=oracle.ARITH_REFERENCE, **kw)
     x, v = make_init("ZigZagAD", dim, chains)
-    got = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=21)
-    ref = oracle.sample_skeleton(cfg, n_sk, x, v, 21)
+    got = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=21, diagnostics=True)
+    from pdmpflux.jl_amd import _lib
+    assert _lib.lib().pdmp_dense_batched_last_mode() == (2 if mode == "incr" else 1)
+    ref = oracle.sample_skeleton(cfg, n_sk, x, v, 21, diagnostics=True)
     assert np.array_equal(got["V"], ref["V"])
     for k in ("rejected", "hitting_horizon", "errored_bound"):
         assert np.array_equal(got[k], ref[k]), k
     assert np.allclose(got["t"], ref["t"], rtol=1e-9, atol=0)
     assert np.allclose(got["X"], ref["X"], rtol=1e-7, atol=1e-9)
+    assert np.allclose(got["horizon"], ref["horizon"], rtol=1e-12) and np.allclose(got["ar"], ref["ar"], rtol=1e-7, atol=1e-12)
     monkeypatch.setenv("PDMP_DENSE_MODE", "matvec")
     s2, cfg2 = make_pair(engine, oracle, "ZigZagAD", dim, "dense")
     got2 = engine.sample_skeleton_ensemble(s2, 12, x[:6], v[:6], seed=21)
