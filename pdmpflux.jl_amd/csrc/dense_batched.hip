@@ -290,7 +290,6 @@ struct DiParams {
     double *X, *V, *t, *H, *AR, *EV;
     int32_t *EB, *RJ, *HH;
     int32_t *status;             // [0] itercap, [1] guard
-    int32_t *ndead;
 };
 
 // SGN: signed_bound (the constructor default).  There the slope of every coordinate's rate is the same double at both ends of a
@@ -488,7 +487,7 @@ __global__ __launch_bounds__(256, SGN ? 2 : 1) void di_segment_kernel(const DiPa
     if (lane == 0) {
         cs.t = t; cs.horizon = horizon; cs.rng_n = rng.n; cs.dead = dead ? 1 : 0;
         p.st[c] = cs;
-        if (dead) { atomicAdd(&p.status[0], 1); atomicAdd(p.ndead, 1); }
+        if (dead) atomicAdd(&p.status[0], 1);
     }
 }
 
@@ -498,6 +497,12 @@ using namespace pdmp;
 
 static long long g_last_phases = 0, g_last_columns = 0;
 static int g_last_mode = 0;
+static rocblas_handle db_handle(int device) {
+    static rocblas_handle handles[16] = {nullptr};
+    if (device < 0 || device >= 16) return nullptr;
+    if (!handles[device] && rocblas_create_handle(&handles[device]) != rocblas_status_success) handles[device] = nullptr;
+    return handles[device];
+}
 extern "C" long long pdmp_dense_batched_last_phases(void) { return g_last_phases; }   // GEMM phases of the last run (diagnostics)
 extern "C" long long pdmp_dense_batched_last_columns(void) { return g_last_columns; } // right-hand-side columns multiplied over those phases
 
@@ -510,7 +515,6 @@ extern "C" int pdmp_dense_batched_run(int device, int d, int signed_bound, int a
     hipStream_t stream = (hipStream_t)stream_v;
 #define DB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { snprintf(err, errlen, "%s: %s", #expr, hipGetErrorString(e_)); goto fail; } } while (0)
 #define DB_BLAS(expr) do { rocblas_status s_ = (expr); if (s_ != rocblas_status_success) { snprintf(err, errlen, "%s: rocblas status %d", #expr, (int)s_); goto fail; } } while (0)
-    static rocblas_handle handles[16] = {nullptr};
     double *Xs = nullptr, *In = nullptr, *Out = nullptr, *Gprev = nullptr;
     DbState *st = nullptr;
     int32_t *remaining = nullptr;
@@ -525,10 +529,10 @@ extern "C" int pdmp_dense_batched_run(int device, int d, int signed_bound, int a
         DB_TRY(hipMalloc(&remaining, sizeof(int32_t)));
         DB_TRY(hipMemsetAsync(remaining, 0, sizeof(int32_t), stream));
         DB_TRY(hipMemsetAsync(Out, 0, 2 * n * 8, stream));
-        if (device < 0 || device >= 16) { snprintf(err, errlen, "device ordinal out of range"); goto fail; }
-        if (!handles[device]) DB_BLAS(rocblas_create_handle(&handles[device]));
-        DB_BLAS(rocblas_set_stream(handles[device], stream));
-        DB_BLAS(rocblas_set_pointer_mode(handles[device], rocblas_pointer_mode_host));
+        rocblas_handle hb = db_handle(device);
+        if (!hb) { snprintf(err, errlen, "rocblas handle (device ordinal %d)", device); goto fail; }
+        DB_BLAS(rocblas_set_stream(hb, stream));
+        DB_BLAS(rocblas_set_pointer_mode(hb, rocblas_pointer_mode_host));
 
         DbParams p;
         p.d = d; p.signed_bound = signed_bound; p.adaptive = adaptive;
@@ -552,7 +556,7 @@ extern "C" int pdmp_dense_batched_run(int device, int d, int signed_bound, int a
             // at flips, where the step kernel updates it by a rank-one term; a full d x 2C product re-syncs it every 32 phases.
             const bool full = (ph % 32) == 0 || getenv("PDMP_DENSE_FULL_PV") != nullptr;
             g_last_columns += full ? 2 * C : C;
-            DB_BLAS(rocblas_dgemm(handles[device], rocblas_operation_none, rocblas_operation_none, d, (int)(full ? 2 * C : C), d, &one,
+            DB_BLAS(rocblas_dgemm(hb, rocblas_operation_none, rocblas_operation_none, d, (int)(full ? 2 * C : C), d, &one,
                                   P_dev, d, In, d, &zero, Out, d));
             hipLaunchKernelGGL(db_step_kernel, grid, block, 0, stream, p);
             if ((ph & 7) == 7) {
@@ -576,79 +580,64 @@ fail:
 
 extern "C" int pdmp_dense_batched_last_mode(void) { return g_last_mode; }   // 0 none, 1 GEMM per phase, 2 incremental
 
-static rocblas_handle db_handle(int device) {
-    static rocblas_handle handles[16] = {nullptr};
-    if (device < 0 || device >= 16) return nullptr;
-    if (!handles[device] && rocblas_create_handle(&handles[device]) != rocblas_status_success) handles[device] = nullptr;
-    return handles[device];
-}
 
 // Incremental driver: segments of `resync` events (PDMP_DENSE_RESYNC, default 256); before each segment one fp64 GEMM
-// [P x | P v] = P [x | v] over all chains.  Same return codes as pdmp_dense_batched_run; -5 when d > 1024 (the caller falls back).
+// [P x | P v] = P [x | v] over all chains.  Asynchronous on `stream` (nothing is read back: a chain that hits the iteration cap
+// is counted in status[0], which pdmp_check_status reports); the workspace (*ws, *ws_cap bytes) belongs to the caller's handle
+// and is grown here on demand.  Returns 0, -3 (runtime error, message in err) or -5 when d > 1024 (the caller falls back).
 extern "C" int pdmp_dense_incremental_run(int device, int d, int signed_bound, int adaptive, double tmax, int64_t cap,
                                           const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
                                           const double *xinit, const double *vinit, double *X, double *V, double *t,
                                           double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
-                                          int32_t *status, void *stream_v, char *err, int errlen) {
+                                          int32_t *status, void *stream_v, void **ws, size_t *ws_cap, char *err, int errlen) {
     hipStream_t stream = (hipStream_t)stream_v;
     if (d > 16 * WAVE) return -5;
-#define DB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { snprintf(err, errlen, "%s: %s", #expr, hipGetErrorString(e_)); goto fail; } } while (0)
-#define DB_BLAS(expr) do { rocblas_status s_ = (expr); if (s_ != rocblas_status_success) { snprintf(err, errlen, "%s: rocblas status %d", #expr, (int)s_); goto fail; } } while (0)
-    double *In = nullptr, *Out = nullptr;
-    DiState *st = nullptr;
-    int32_t *ndead = nullptr;
-    int rc = -3;
-    {
-        const size_t n = (size_t)C * (size_t)d;
-        int64_t resync = 256;
-        if (const char *e = getenv("PDMP_DENSE_RESYNC")) { const long long r = atoll(e); if (r >= 1) resync = r; }
-        rocblas_handle hb = db_handle(device);
-        if (!hb) { snprintf(err, errlen, "rocblas handle"); goto fail; }
-        DB_TRY(hipMalloc(&In, 2 * n * 8));
-        DB_TRY(hipMalloc(&Out, 2 * n * 8));
-        DB_TRY(hipMalloc(&st, (size_t)C * sizeof(DiState)));
-        DB_TRY(hipMalloc(&ndead, sizeof(int32_t)));
-        DB_TRY(hipMemsetAsync(ndead, 0, sizeof(int32_t), stream));
-        DB_TRY(hipMemcpyAsync(In, xinit, n * 8, hipMemcpyDeviceToDevice, stream));
-        DB_TRY(hipMemcpyAsync(In + n, vinit, n * 8, hipMemcpyDeviceToDevice, stream));
-        DB_BLAS(rocblas_set_stream(hb, stream));
-        DB_BLAS(rocblas_set_pointer_mode(hb, rocblas_pointer_mode_host));
-        DiParams p;
-        p.d = d; p.signed_bound = signed_bound; p.adaptive = adaptive;
-        p.C = C; p.n_sk = n_sk; p.chain0 = chain0; p.cap = cap; p.seed = seed; p.tmax = tmax;
-        p.In = In; p.Out = Out; p.P = P_dev; p.st = st;
-        p.X = X; p.V = V; p.t = t; p.H = H; p.AR = AR; p.EV = EV; p.EB = EB; p.RJ = RJ; p.HH = HH;
-        p.status = status; p.ndead = ndead;
-        const dim3 grid((unsigned)((C + 3) / 4)), block(256);
-        const double one = 1.0, zero = 0.0;
-        g_last_phases = 0; g_last_columns = 0; g_last_mode = 2;
-        for (int64_t k0 = 0; k0 < n_sk;) {
-            const int64_t k1 = (k0 == 0 ? 1 : k0) + resync < n_sk ? (k0 == 0 ? 1 : k0) + resync : n_sk;
-            DB_BLAS(rocblas_dgemm(hb, rocblas_operation_none, rocblas_operation_none, d, (int)(2 * C), d, &one, P_dev, d, In, d, &zero, Out, d));
-            g_last_columns += 2 * C;
-            p.k_begin = k0; p.k_end = k1;
-            if (signed_bound) {
-                if (d <= 4 * WAVE) hipLaunchKernelGGL((di_segment_kernel<4, true>), grid, block, 0, stream, p);
-                else if (d <= 8 * WAVE) hipLaunchKernelGGL((di_segment_kernel<8, true>), grid, block, 0, stream, p);
-                else hipLaunchKernelGGL((di_segment_kernel<16, true>), grid, block, 0, stream, p);
-            } else {
-                if (d <= 4 * WAVE) hipLaunchKernelGGL((di_segment_kernel<4, false>), grid, block, 0, stream, p);
-                else if (d <= 8 * WAVE) hipLaunchKernelGGL((di_segment_kernel<8, false>), grid, block, 0, stream, p);
-                else hipLaunchKernelGGL((di_segment_kernel<16, false>), grid, block, 0, stream, p);
-            }
-            DB_TRY(hipGetLastError());
-            k0 = k1;
-        }
-        int32_t nd = 0;
-        DB_TRY(hipMemcpyAsync(&nd, ndead, sizeof nd, hipMemcpyDeviceToHost, stream));
-        DB_TRY(hipStreamSynchronize(stream));
-        if (nd > 0) { snprintf(err, errlen, "%d chain(s) hit the iteration cap", (int)nd); rc = -4; goto fail; }
-        rc = 0;
+#define DB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { snprintf(err, errlen, "%s: %s", #expr, hipGetErrorString(e_)); return -3; } } while (0)
+#define DB_BLAS(expr) do { rocblas_status s_ = (expr); if (s_ != rocblas_status_success) { snprintf(err, errlen, "%s: rocblas status %d", #expr, (int)s_); return -3; } } while (0)
+    const size_t n = (size_t)C * (size_t)d;
+    const size_t need = 4 * n * 8 + (size_t)C * sizeof(DiState);
+    if (need > *ws_cap) {
+        if (*ws) { DB_TRY(hipStreamSynchronize(stream)); DB_TRY(hipFree(*ws)); *ws = nullptr; *ws_cap = 0; }
+        DB_TRY(hipMalloc(ws, need));
+        *ws_cap = need;
     }
-fail:
-    (void)hipStreamSynchronize(stream);
-    (void)hipFree(In); (void)hipFree(Out); (void)hipFree(st); (void)hipFree(ndead);
-    return rc;
+    double *In = (double *)*ws, *Out = In + 2 * n;
+    DiState *st = (DiState *)(Out + 2 * n);
+    int64_t resync = 256;
+    if (const char *e = getenv("PDMP_DENSE_RESYNC")) { const long long r = atoll(e); if (r >= 1) resync = r; }
+    rocblas_handle hb = db_handle(device);
+    if (!hb) { snprintf(err, errlen, "rocblas handle"); return -3; }
+    DB_TRY(hipMemcpyAsync(In, xinit, n * 8, hipMemcpyDeviceToDevice, stream));
+    DB_TRY(hipMemcpyAsync(In + n, vinit, n * 8, hipMemcpyDeviceToDevice, stream));
+    DB_BLAS(rocblas_set_stream(hb, stream));
+    DB_BLAS(rocblas_set_pointer_mode(hb, rocblas_pointer_mode_host));
+    DiParams p;
+    p.d = d; p.signed_bound = signed_bound; p.adaptive = adaptive;
+    p.C = C; p.n_sk = n_sk; p.chain0 = chain0; p.cap = cap; p.seed = seed; p.tmax = tmax;
+    p.In = In; p.Out = Out; p.P = P_dev; p.st = st;
+    p.X = X; p.V = V; p.t = t; p.H = H; p.AR = AR; p.EV = EV; p.EB = EB; p.RJ = RJ; p.HH = HH;
+    p.status = status;
+    const dim3 grid((unsigned)((C + 3) / 4)), block(256);
+    const double one = 1.0, zero = 0.0;
+    g_last_phases = 0; g_last_columns = 0; g_last_mode = 2;
+    for (int64_t k0 = 0; k0 < n_sk;) {
+        const int64_t from = (k0 == 0) ? 1 : k0, k1 = (from + resync < n_sk) ? from + resync : n_sk;
+        DB_BLAS(rocblas_dgemm(hb, rocblas_operation_none, rocblas_operation_none, d, (int)(2 * C), d, &one, P_dev, d, In, d, &zero, Out, d));
+        g_last_columns += 2 * C;
+        p.k_begin = k0; p.k_end = k1;
+        if (signed_bound) {
+            if (d <= 4 * WAVE) hipLaunchKernelGGL((di_segment_kernel<4, true>), grid, block, 0, stream, p);
+            else if (d <= 8 * WAVE) hipLaunchKernelGGL((di_segment_kernel<8, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((di_segment_kernel<16, true>), grid, block, 0, stream, p);
+        } else {
+            if (d <= 4 * WAVE) hipLaunchKernelGGL((di_segment_kernel<4, false>), grid, block, 0, stream, p);
+            else if (d <= 8 * WAVE) hipLaunchKernelGGL((di_segment_kernel<8, false>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((di_segment_kernel<16, false>), grid, block, 0, stream, p);
+        }
+        DB_TRY(hipGetLastError());
+        k0 = k1;
+    }
+    return 0;
 #undef DB_TRY
 #undef DB_BLAS
 }

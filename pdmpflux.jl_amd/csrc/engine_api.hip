@@ -54,7 +54,7 @@ extern "C" int pdmp_dense_incremental_run(int device, int d, int signed_bound, i
                                       const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
                                       const double *xinit, const double *vinit, double *X, double *V, double *t,
                                       double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
-                                      int32_t *status, void *stream, char *err, int errlen);
+                                      int32_t *status, void *stream, void **ws, size_t *ws_cap, char *err, int errlen);
 
 extern "C" int pdmp_user_compile(int device, int sampler, int fd, int kind, const char *source, void **fn_out, char *err, int errlen);
 extern "C" int pdmp_user_launch(void *fn, const GroupParams *gp, void *stream);
@@ -69,6 +69,8 @@ struct pdmp_engine {
     int32_t *d_sched = nullptr;       // group kernel: [0] unit counter, [1..nb] per-batch progress
     size_t sched_cap = 0;
     double *d_state = nullptr;        // group kernel: per-chain hand-off state (2d+4 doubles)
+    void *dense_ws = nullptr;         // incremental dense form: [x | v], [P x | P v], per-chain scalars (dense_batched.hip)
+    size_t dense_ws_cap = 0;
     size_t state_cap = 0;
     double *d_tape[3] = {nullptr, nullptr, nullptr};   // tape source: exp, uni, nrm (chain-major)
     int64_t tape_n[3] = {0, 0, 0}, tape_chains = 0;
@@ -562,6 +564,7 @@ int pdmp_destroy(pdmp_handle h) {
     if (h->d_status) (void)hipFree(h->d_status);
     if (h->d_sched) (void)hipFree(h->d_sched);
     if (h->d_state) (void)hipFree(h->d_state);
+    if (h->dense_ws) (void)hipFree(h->dense_ws);
     for (int q = 0; q < 3; ++q) if (h->d_tape[q]) (void)hipFree(h->d_tape[q]);
     delete h;
     return PDMP_OK;
@@ -656,7 +659,7 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
         if (!(dense_mode && strcmp(dense_mode, "gemm") == 0))   // P x, P v kept current incrementally: O(d) per gradient (dense_batched.hip)
             rc = pdmp_dense_incremental_run(h->device, c.dim, c.signed_bound, c.adaptive, c.tmax, c.max_iter_per_event, h->d_tparams, C, n_sk,
                                             chain_id_offset, seed, xinit, vinit, X, V, t, p.H, p.AR, p.EB, p.EV, p.RJ, p.HH,
-                                            h->d_status, stream, msg, (int)sizeof msg);
+                                            h->d_status, stream, &h->dense_ws, &h->dense_ws_cap, msg, (int)sizeof msg);
         if (rc == -5)                                           // d > 1024 (or forced): one GEMM per phase
             rc = pdmp_dense_batched_run(h->device, c.dim, c.signed_bound, c.adaptive, c.tmax, c.max_iter_per_event, h->d_tparams, C, n_sk,
                                         chain_id_offset, seed, xinit, vinit, X, V, t, p.H, p.AR, p.EB, p.EV, p.RJ, p.HH,
