@@ -283,6 +283,25 @@ def test_iteration_cap_is_reported_not_hung(engine):
         assert np.isfinite(out["t"]).all()
 
 
+@pytest.mark.parametrize("mode", ["incr", "gemm"])
+def test_iteration_cap_on_the_dense_paths(engine, monkeypatch, mode):
+    """The same guarantee on the batched dense-precision paths (dense_batched.hip): a fixed horizon far beyond the event
+    scale makes almost every proposal a rejection, the cap stops the chains and the call reports PDMP_ERR_ITERCAP."""
+    from pdmpflux.jl_amd import _lib
+    monkeypatch.setenv("PDMP_DENSE_MODE", mode)
+    rs = np.random.default_rng(5)
+    A = rs.normal(size=(40, 40))
+    tg = engine.GaussianPrecision(A @ A.T / 40 + np.eye(40))
+    x, v = make_init("ZigZagAD", 40, 64)
+    s = engine.ZigZagAD(40, tg, tmax=40.0, adaptive=False, max_iter_per_event=1)
+    with pytest.raises(engine.EngineError) as e:
+        engine.sample_skeleton_ensemble(s, 50, x, v, seed=3)
+    assert e.value.code == _lib.ERR_ITERCAP
+    ok = engine.ZigZagAD(40, tg)
+    out = engine.sample_skeleton_ensemble(ok, 50, x, v, seed=3)
+    assert np.isfinite(out["t"]).all() and (np.diff(out["t"], axis=1) > 0).all()
+
+
 def test_empty_and_degenerate_ensembles(engine, oracle):
     """Edge cases: no chains, one skeleton point (initial state only), one chain, ragged last wave."""
     s, cfg = make_pair(engine, oracle, "ZigZagAD", 50, "iso")
