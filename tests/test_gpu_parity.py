@@ -283,6 +283,23 @@ def test_iteration_cap_is_reported_not_hung(engine):
         assert np.isfinite(out["t"]).all()
 
 
+@pytest.mark.parametrize("dim,mode", [(3, 2), (64, 2), (256, 2), (512, 2), (513, 2), (1024, 2), (1025, 1)])
+def test_dense_precision_slot_boundaries(engine, oracle, dim, mode):
+    """The incremental kernel is instantiated for 4 / 8 / 16 slots of 64 coordinates (d <= 256 / 512 / 1024); beyond that the
+    GEMM-per-phase form serves the call.  Every boundary against the reference-order restatement, to the tolerance of
+    test_dense_precision_batched_paths_match_oracle."""
+    from pdmpflux.jl_amd import _lib
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", dim, "dense", arith=oracle.ARITH_REFERENCE)
+    C, n_sk = 64, 10
+    x, v = make_init("ZigZagAD", dim, C)
+    got = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=2)
+    assert _lib.lib().pdmp_dense_batched_last_mode() == mode
+    ref = oracle.sample_skeleton(cfg, n_sk, x, v, 2)
+    assert np.array_equal(got["V"], ref["V"])
+    assert np.allclose(got["t"], ref["t"], rtol=1e-9, atol=0)
+    assert np.allclose(got["X"], ref["X"], rtol=1e-7, atol=1e-9)
+
+
 @pytest.mark.parametrize("mode", ["incr", "gemm"])
 def test_iteration_cap_on_the_dense_paths(engine, monkeypatch, mode):
     """The same guarantee on the batched dense-precision paths (dense_batched.hip): a fixed horizon far beyond the event
