@@ -908,7 +908,7 @@ struct GroupChain {
     }
     __device__ __forceinline__ bool fecmc_jump(const typename Tgt::template Sh<double> &sh) {
         const int d = p.d;
-        double *tn = fe_t[0], *tvo = fe_t[1], *t1 = fe_t[2], *t2 = fe_t[3];
+        double *tn = fe_t[0], *tvo = fe_t[1];
         const double u = rng.uniform();                                             // :134
         const double pw = det_exp(det_log(u) * (2.0 / (double)(d - 1)));
         const double sf = p.fe_speed;                                               // speed_factor (:177-218; 1.0: the default jump, same bits)
