@@ -126,6 +126,22 @@ def test_full_machine_schedule_bitwise(engine, oracle):
     assert np.abs(np.linalg.norm(got["V"], axis=2) - np.sqrt(50)).max() < 1e-12   # :172-180 speed conservation
 
 
+@pytest.mark.parametrize("kind,dim,target,C", [("ZigZagAD", 48, "iso", 40000), ("ZigZagAD", 50, "banana", 40000),
+                                               ("BPS", 40, "banana", 40000), ("BPS", 50, "banana", 40000),
+                                               ("BoomerangAD", 90, "iso", 20000), ("Boomerang", 44, "diag", 40000)])
+def test_full_machine_schedule_other_register_kernels(engine, oracle, kind, dim, target, C):
+    """The same multi-segment schedule through the exact-slot-count kernels (K = 12 / 10 / 11) and the FULL banana variants:
+    a strided sample of chains bit for bit against the oracle, event times increasing for every chain."""
+    s, cfg = make_pair(engine, oracle, kind, dim, target)
+    x, v = make_init(kind, dim, C, target=target)
+    got = engine.sample_skeleton_ensemble(s, 64, x, v, seed=78, diagnostics=False)
+    for c in np.arange(0, C, 1999):
+        r1 = oracle.sample_skeleton(cfg, 64, x[c:c + 1], v[c:c + 1], 78, chain_id_offset=int(c), diagnostics=False)
+        for k in ("X", "V", "t"):
+            assert np.array_equal(got[k][c], r1[k][0]), (k, c)
+    assert (np.diff(got["t"], axis=1) > 0).all()
+
+
 def test_group1_sums_in_reference_order(engine, oracle, monkeypatch):
     """With one lane per chain every sum over coordinates runs in the reference's own left-to-right order; only
     cum_sum (cumsum after, not before, the sum over dimensions) can differ in the last bit.  Velocities are
