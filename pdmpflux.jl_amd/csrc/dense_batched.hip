@@ -428,9 +428,11 @@ __global__ __launch_bounds__(256, SGN ? 2 : 1) void di_segment_kernel(const DiPa
             double carry = 0.0, carry_at = 0.0;
 #pragma unroll
             for (int s = 0; s < KC; ++s) {
-                const double Ts = wave_sum(fmax(0.0, gx[s] * v[s]));
-                if (sh < 0 && (carry + Ts > theta)) { sh = s; carry_at = carry; }
-                carry = carry + Ts;
+                if (sh < 0) {                    // wave-uniform: slots after the hit one are not summed
+                    const double Ts = wave_sum(fmax(0.0, gx[s] * v[s]));
+                    if (carry + Ts > theta) { sh = s; carry_at = carry; }
+                    carry = carry + Ts;
+                }
             }
             int m = -1;
             if (sh >= 0) {
