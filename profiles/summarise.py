@@ -5,7 +5,8 @@ import collections, csv, glob, json, os, shutil, sys
 tag, dest = sys.argv[1], sys.argv[2]
 src = f"gpurun_out/prof_{tag}"
 os.makedirs(dest, exist_ok=True)
-stats = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")
+newest = lambda pattern: sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]      # a tag collected twice: the last run counts
+stats = newest(f"{src}/trace/*/*_kernel_stats.csv")
 if stats:
     rows = list(csv.reader(open(stats[0])))
     with open(f"{dest}/{tag}_kernel_stats.csv", "w", newline="") as f:
@@ -14,7 +15,7 @@ if os.path.exists(f"{src}/bench_traced.json"):
     shutil.copy(f"{src}/bench_traced.json", f"{dest}/{tag}_bench_traced.json")
 out = {}
 for d in ("pmc_sq", "pmc_sq2", "pmc_wr", "pmc_rd"):
-    for fcsv in glob.glob(f"{src}/{d}/*/*_counter_collection.csv"):
+    for fcsv in newest(f"{src}/{d}/*/*_counter_collection.csv"):
         agg = collections.defaultdict(float)
         meta = {}
         for r in csv.DictReader(open(fcsv)):
