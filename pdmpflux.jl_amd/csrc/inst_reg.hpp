@@ -33,11 +33,12 @@ static hipError_t reg_by_target(int target, bool fd, const GroupParams &gp, hipS
 }
 
 // Exact-K kernels (inst_reg_*_k.hip): the FULL variant for every K = (KREG+1)/2 .. KREG-1 that the lanes-per-chain rule can
-// produce with G >= 2 (Zig-Zag, BPS: forward-mode slopes; Boomerang: both slope modes) -- no per-slot skips, so the slot bodies interleave (38-41 % faster than the
+// produce with G >= 2, and for K = 2 .. KREG-1 with one lane per chain (d <= 12: the reference's demo regime, 64 chains per wave) (Zig-Zag, BPS: forward-mode slopes; Boomerang: both slope modes) -- no per-slot skips, so the slot bodies interleave (38-41 % faster than the
 // partial variant of KREG slots where both were measured).
 template <int S, int T, bool FD, int KC>
 static hipError_t exact_by_lanes(const GroupParams &gp, hipStream_t stream) {
     switch (gp.G) {
+    case 1: return launch_group_impl<S, T, FD, KC, 1, true>(gp, stream);
     case 2: return launch_group_impl<S, T, FD, KC, 2, true>(gp, stream);
     case 4: return launch_group_impl<S, T, FD, KC, 4, true>(gp, stream);
     case 8: return launch_group_impl<S, T, FD, KC, 8, true>(gp, stream);
@@ -48,7 +49,13 @@ static hipError_t exact_by_lanes(const GroupParams &gp, hipStream_t stream) {
 template <int S, int T, bool FD>
 static hipError_t exact_by_slots(const GroupParams &gp, hipStream_t stream) {
     static_assert(KREG == 13, "one case per K below");
+    if (gp.K < 7 && gp.G != 1) return hipErrorNotSupported;     // K < 7 only arises with one lane per chain (d <= 6)
     switch (gp.K) {
+    case 2: return launch_group_impl<S, T, FD, 2, 1, true>(gp, stream);
+    case 3: return launch_group_impl<S, T, FD, 3, 1, true>(gp, stream);
+    case 4: return launch_group_impl<S, T, FD, 4, 1, true>(gp, stream);
+    case 5: return launch_group_impl<S, T, FD, 5, 1, true>(gp, stream);
+    case 6: return launch_group_impl<S, T, FD, 6, 1, true>(gp, stream);
     case 7: return exact_by_lanes<S, T, FD, 7>(gp, stream);
     case 8: return exact_by_lanes<S, T, FD, 8>(gp, stream);
     case 9: return exact_by_lanes<S, T, FD, 9>(gp, stream);

@@ -431,12 +431,23 @@ def test_register_and_lds_forms_agree(engine, oracle, monkeypatch, kind, dim, ta
                                          ("BPS", "iso"), ("BPS", "diag"), ("BPS", "banana"),
                                          ("Boomerang", "iso"), ("Boomerang", "diag"), ("BoomerangAD", "iso"), ("BoomerangAD", "banana")])
 def test_exact_slot_count_kernels(engine, oracle, monkeypatch, kind, dim, target):
+    _exact_slot_case(engine, oracle, monkeypatch, kind, dim, target)
+
+
+@pytest.mark.parametrize("dim", [2, 3, 5, 6, 7, 10, 12])                  # one lane per chain: K = d
+@pytest.mark.parametrize("kind,target", [("ZigZagAD", "iso"), ("ZigZagAD", "banana"), ("BPS", "diag"), ("BPS", "banana"),
+                                         ("Boomerang", "iso"), ("BoomerangAD", "diag")])
+def test_exact_slot_count_kernels_one_lane_per_chain(engine, oracle, monkeypatch, kind, dim, target):
+    _exact_slot_case(engine, oracle, monkeypatch, kind, dim, target, one_lane=True)
+
+
+def _exact_slot_case(engine, oracle, monkeypatch, kind, dim, target, one_lane=False):
     """Forward-mode Zig-Zag / BPS and Boomerang (both slope modes) with K = ceil(d/G) in 7..12 run a register-form kernel
     of exactly K slots (inst_reg_*_k.hip, inst_reg_boomerang_kfd.hip); PDMP_REG_EXACT=0 selects the 13-slot kernel with per-slot skips.  Both equal the checker."""
     s, cfg = make_pair(engine, oracle, kind, dim, target)
     G = s.group_lanes()
-    assert G >= 2 and 7 <= -(-dim // G) <= 12
-    C, n_sk = 19, 30
+    assert (G == 1 and 2 <= dim <= 12) if one_lane else (G >= 2 and 7 <= -(-dim // G) <= 12)
+    C, n_sk = (70, 30) if one_lane else (19, 30)
     x, v = make_init(kind, dim, C, seed=31, target=target)
     ref = oracle.sample_skeleton(cfg, n_sk, x, v, 23, diagnostics=True)
     assert_bitwise(engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=23, diagnostics=True), ref)
