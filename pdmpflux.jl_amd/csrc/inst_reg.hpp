@@ -46,31 +46,38 @@ static hipError_t exact_by_lanes(const GroupParams &gp, hipStream_t stream) {
     default: return hipErrorNotSupported;
     }
 }
-template <int S, int T, bool FD>
+// HALF splits the instantiations over two translation units per (sampler, slope mode): 0 = K <= 8, 1 = K >= 9 (build time)
+template <int S, int T, bool FD, int HALF>
 static hipError_t exact_by_slots(const GroupParams &gp, hipStream_t stream) {
     static_assert(KREG == 13, "one case per K below");
     if (gp.K < 7 && gp.G != 1) return hipErrorNotSupported;     // K < 7 only arises with one lane per chain (d <= 6)
-    switch (gp.K) {
-    case 2: return launch_group_impl<S, T, FD, 2, 1, true>(gp, stream);
-    case 3: return launch_group_impl<S, T, FD, 3, 1, true>(gp, stream);
-    case 4: return launch_group_impl<S, T, FD, 4, 1, true>(gp, stream);
-    case 5: return launch_group_impl<S, T, FD, 5, 1, true>(gp, stream);
-    case 6: return launch_group_impl<S, T, FD, 6, 1, true>(gp, stream);
-    case 7: return exact_by_lanes<S, T, FD, 7>(gp, stream);
-    case 8: return exact_by_lanes<S, T, FD, 8>(gp, stream);
-    case 9: return exact_by_lanes<S, T, FD, 9>(gp, stream);
-    case 10: return exact_by_lanes<S, T, FD, 10>(gp, stream);
-    case 11: return exact_by_lanes<S, T, FD, 11>(gp, stream);
-    case 12: return exact_by_lanes<S, T, FD, 12>(gp, stream);
-    default: return hipErrorNotSupported;
+    if constexpr (HALF == 0) {
+        switch (gp.K) {
+        case 2: return launch_group_impl<S, T, FD, 2, 1, true>(gp, stream);
+        case 3: return launch_group_impl<S, T, FD, 3, 1, true>(gp, stream);
+        case 4: return launch_group_impl<S, T, FD, 4, 1, true>(gp, stream);
+        case 5: return launch_group_impl<S, T, FD, 5, 1, true>(gp, stream);
+        case 6: return launch_group_impl<S, T, FD, 6, 1, true>(gp, stream);
+        case 7: return exact_by_lanes<S, T, FD, 7>(gp, stream);
+        case 8: return exact_by_lanes<S, T, FD, 8>(gp, stream);
+        default: return hipErrorNotSupported;
+        }
+    } else {
+        switch (gp.K) {
+        case 9: return exact_by_lanes<S, T, FD, 9>(gp, stream);
+        case 10: return exact_by_lanes<S, T, FD, 10>(gp, stream);
+        case 11: return exact_by_lanes<S, T, FD, 11>(gp, stream);
+        case 12: return exact_by_lanes<S, T, FD, 12>(gp, stream);
+        default: return hipErrorNotSupported;
+        }
     }
 }
-template <int S, bool FD>       // one translation unit per (sampler, slope mode)
+template <int S, bool FD, int HALF>       // one translation unit per (sampler, slope mode, half)
 static hipError_t exact_by_target(int target, const GroupParams &gp, hipStream_t stream) {
     switch (target) {
-    case T_GAUSS_ISO: return exact_by_slots<S, T_GAUSS_ISO, FD>(gp, stream);
-    case T_GAUSS_DIAG: return exact_by_slots<S, T_GAUSS_DIAG, FD>(gp, stream);
-    case T_BANANA: return exact_by_slots<S, T_BANANA, FD>(gp, stream);
+    case T_GAUSS_ISO: return exact_by_slots<S, T_GAUSS_ISO, FD, HALF>(gp, stream);
+    case T_GAUSS_DIAG: return exact_by_slots<S, T_GAUSS_DIAG, FD, HALF>(gp, stream);
+    case T_BANANA: return exact_by_slots<S, T_BANANA, FD, HALF>(gp, stream);
     default: return hipErrorNotSupported;
     }
 }

@@ -1,6 +1,10 @@
-// Exact-K register-form kernels (K = 7..12, forward-mode slopes) of the group kernel for sampler S_BPS (see inst_reg.hpp).
+// Exact-K register-form kernels (K = 2..8, forward-mode slopes) of the group kernel for sampler S_BPS (see inst_reg.hpp);
+// K = 9..12 are in inst_reg_bps_k2.hip.
 #include "inst_reg.hpp"
 
 namespace pdmp {
-hipError_t launch_group_reg_bps_exact(int target, const GroupParams &gp, hipStream_t stream) { return exact_by_target<S_BPS, false>(target, gp, stream); }
+hipError_t launch_group_reg_bps_exact_hi(int target, const GroupParams &gp, hipStream_t stream);
+hipError_t launch_group_reg_bps_exact(int target, const GroupParams &gp, hipStream_t stream) {
+    return gp.K >= 9 ? launch_group_reg_bps_exact_hi(target, gp, stream) : exact_by_target<S_BPS, false, 0>(target, gp, stream);
+}
 }  // namespace pdmp
