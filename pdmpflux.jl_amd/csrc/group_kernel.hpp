@@ -682,7 +682,13 @@ struct GroupChain {
         tpo = __builtin_huge_val();
         auto cell = [&](int j, double f1, double s1) {                                 // cell j from grid times j (f0, s0) and j+1
             const double num = fma(s1, h, f0 - f1);                                    // :123 relative form
-            const double q = cell_q(num, s1 - s0, h, false);                           // :124-125
+            // equal slopes at both ends in every lane (affine gradients under the signed bound: the slope is the same sum at
+            // every grid time) -> num / 0 = +-Inf or NaN clamps to h or 0: same bits without the division sequence
+            // (BPS on an affine gradient only: elsewhere the slopes differ and the test costs more than it saves)
+            const double den = s1 - s0;
+            bool fast = false;
+            if constexpr (SAMPLER == S_BPS && Tgt::kLinear) fast = (__ballot(den != 0.0) == 0ull);
+            const double q = cell_q(num, den, h, fast);                                // :124-125
             const double inter = fma(s0, q, f0);                                       // :127
             bj = fmax(fmax(fmax(f0, f1), inter), 0.0);                                 // :128-130
             bj += refresh;                                                             // :131
