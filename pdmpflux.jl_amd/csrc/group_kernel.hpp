@@ -29,6 +29,9 @@
 namespace pdmp {
 
 constexpr int GNG = 10;   // grid_size served by this kernel (the default of every reference constructor)
+#ifndef PDMP_SUZZ_WAVES
+#define PDMP_SUZZ_WAVES 2
+#endif
 constexpr int KREG = 13;  // slots per lane of the register form (x, v in VGPRs): d <= 13 G
 
 struct GroupParams {
@@ -1507,7 +1510,11 @@ __device__ __forceinline__ bool wait_progress(const int32_t *flag, int r) {
 
 // Occupancy target (waves per SIMD): the lazy bound keeps every instantiation under 128 VGPRs, so four
 // waves per SIMD fit the register file; LDS (2*ceil(d/G)*512 B per wave) is what limits residency.
-template <int TARGET> struct GroupOcc { static constexpr int kWaves = (TARGET == T_BANANA) ? 3 : 4; };   // banana + finite differences keeps six shared records: 3 waves avoid spills
+// banana + finite differences keeps six shared records: 3 waves avoid spills; SpeedUpZigZag carries the flow's chain-level
+// scalars and the speed duals on top: at 4 waves (128 VGPRs) it spilled ~250 registers
+template <int TARGET, int SAMPLER = S_ZIGZAG> struct GroupOcc {
+    static constexpr int kWaves = (SAMPLER == S_SUZZ) ? PDMP_SUZZ_WAVES : ((TARGET == T_BANANA) ? 3 : 4);
+};
 
 template <int SAMPLER, int TARGET, bool FD, int KC = 0>
 __device__ __forceinline__ void group_kernel_body(const GroupParams &gp) {
@@ -1556,7 +1563,7 @@ __device__ __forceinline__ void group_kernel_body(const GroupParams &gp) {
 }
 
 template <int SAMPLER, int TARGET, bool FD>
-__global__ __launch_bounds__(256, GroupOcc<TARGET>::kWaves) void group_kernel(const GroupParams gp) {
+__global__ __launch_bounds__(256, (GroupOcc<TARGET, SAMPLER>::kWaves)) void group_kernel(const GroupParams gp) {
     group_kernel_body<SAMPLER, TARGET, FD>(gp);
 }
 // Which register-form kernels exist.  kAny: the form is used at all; kPartial: also for K < KC (with the per-slot skips);
