@@ -593,7 +593,9 @@ extern "C" int pdmp_dense_incremental_run(int device, int d, int signed_bound, i
                                           double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
                                           int32_t *status, void *stream_v, void **ws, size_t *ws_cap, char *err, int errlen) {
     hipStream_t stream = (hipStream_t)stream_v;
-    if (d > 16 * WAVE) return -5;
+    // the unsigned bound keeps the tangent intersection's division: its 16-slot instantiation does not fit the register file
+    // without spilling (and no kernel with lane-dependent branches may spill, see GroupOcc in group_kernel.hpp)
+    if (d > 16 * WAVE || (!signed_bound && d > 8 * WAVE)) return -5;
 #define DB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { snprintf(err, errlen, "%s: %s", #expr, hipGetErrorString(e_)); return -3; } } while (0)
 #define DB_BLAS(expr) do { rocblas_status s_ = (expr); if (s_ != rocblas_status_success) { snprintf(err, errlen, "%s: rocblas status %d", #expr, (int)s_); return -3; } } while (0)
     const size_t n = (size_t)C * (size_t)d;
@@ -633,8 +635,7 @@ extern "C" int pdmp_dense_incremental_run(int device, int d, int signed_bound, i
             else hipLaunchKernelGGL((di_segment_kernel<16, true>), grid, block, 0, stream, p);
         } else {
             if (d <= 4 * WAVE) hipLaunchKernelGGL((di_segment_kernel<4, false>), grid, block, 0, stream, p);
-            else if (d <= 8 * WAVE) hipLaunchKernelGGL((di_segment_kernel<8, false>), grid, block, 0, stream, p);
-            else hipLaunchKernelGGL((di_segment_kernel<16, false>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((di_segment_kernel<8, false>), grid, block, 0, stream, p);
         }
         DB_TRY(hipGetLastError());
         k0 = k1;

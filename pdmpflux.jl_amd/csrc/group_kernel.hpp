@@ -29,9 +29,6 @@
 namespace pdmp {
 
 constexpr int GNG = 10;   // grid_size served by this kernel (the default of every reference constructor)
-#ifndef PDMP_SUZZ_WAVES
-#define PDMP_SUZZ_WAVES 2
-#endif
 constexpr int KREG = 13;  // slots per lane of the register form (x, v in VGPRs): d <= 13 G
 
 struct GroupParams {
@@ -1508,12 +1505,19 @@ __device__ __forceinline__ bool wait_progress(const int32_t *flag, int r) {
     return ok;
 }
 
-// Occupancy target (waves per SIMD): the lazy bound keeps every instantiation under 128 VGPRs, so four
-// waves per SIMD fit the register file; LDS (2*ceil(d/G)*512 B per wave) is what limits residency.
-// banana + finite differences keeps six shared records: 3 waves avoid spills; SpeedUpZigZag carries the flow's chain-level
-// scalars and the speed duals on top: at 4 waves (128 VGPRs) it spilled ~250 registers
-template <int TARGET, int SAMPLER = S_ZIGZAG> struct GroupOcc {
-    static constexpr int kWaves = (SAMPLER == S_SUZZ) ? PDMP_SUZZ_WAVES : ((TARGET == T_BANANA) ? 3 : 4);
+// Occupancy target (waves per SIMD) of the LDS-form group kernel = its register budget (512 / waves VGPRs).  NO instantiation may
+// spill a VGPR: lanes of different chains run different branches, and a register spilled inside a divergent region and reloaded
+// after the join comes back wrong in the lanes that were inactive there (seen twice on the box: an early register-form build
+// faulted at address 0, and StickyZigZag with 2x-unrolled slot loops returned wrong positions until its 12-25 spills were
+// gone).  The table below is set from the compiler's resource-usage remarks and the Makefile fails the build on any spill in
+// any inst_*.hip, so a change that adds register pressure has to lower a number here instead of shipping a spill.
+template <int SAMPLER, int TARGET, bool FD> struct GroupOcc {
+    static constexpr int kWaves =
+        (SAMPLER == S_SUZZ) ? ((TARGET == T_BANANA && !FD) ? 1 : 2)     // the flow's chain-level scalars and the speed duals on top of the Zig-Zag state
+        : (TARGET == T_GAUSS_DENSE || SAMPLER == S_STICKY) ? 2          // the mat-vec's row accumulators; the active mask and the thaw clock
+        : (TARGET == T_BANANA || TARGET == T_USER) ? 3                  // banana + finite differences keeps six shared records
+        : (SAMPLER == S_RHMC || SAMPLER == S_BPS) ? 4
+        : 3;                                                            // Zig-Zag, Boomerang, ForwardECMC on the separable Gaussians
 };
 
 template <int SAMPLER, int TARGET, bool FD, int KC = 0>
@@ -1563,7 +1567,7 @@ __device__ __forceinline__ void group_kernel_body(const GroupParams &gp) {
 }
 
 template <int SAMPLER, int TARGET, bool FD>
-__global__ __launch_bounds__(256, (GroupOcc<TARGET, SAMPLER>::kWaves)) void group_kernel(const GroupParams gp) {
+__global__ __launch_bounds__(256, (GroupOcc<SAMPLER, TARGET, FD>::kWaves)) void group_kernel(const GroupParams gp) {
     group_kernel_body<SAMPLER, TARGET, FD>(gp);
 }
 // Which register-form kernels exist.  kAny: the form is used at all; kPartial: also for K < KC (with the per-slot skips);

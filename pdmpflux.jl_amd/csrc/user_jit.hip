@@ -42,45 +42,61 @@ extern "C" int pdmp_user_compile(int device, int sampler, int fd, int kind, cons
     const auto key = std::make_tuple(device, sampler, fd, kind, std::string(source));
     auto it = g_cache.find(key);
     if (it != g_cache.end()) { *fn_out = (void *)it->second.fn; return 0; }
-    std::string prog;
-    prog += "#define PDMP_USER_KIND " + std::to_string(kind) + "\n";
-    prog += "#include \"wave_math.hpp\"\n#include \"user_ad.hpp\"\n";
-    prog += "namespace pdmp_user {\nusing namespace pdmp;\n#line 1 \"potential\"\n";
-    prog += source;
-    prog += "\n}\n#include \"group_kernel.hpp\"\n";
-    prog += "extern \"C\" __global__ __launch_bounds__(256, 2) void pdmp_user_kernel(const pdmp::GroupParams gp) {\n";
-    prog += "    pdmp::group_kernel_body<" + std::to_string(sampler) + ", pdmp::T_USER, " + (fd ? "true" : "false") + ">(gp);\n}\n";
-    hiprtcProgram p;
-    if (hiprtcCreateProgram(&p, prog.c_str(), "pdmp_user.hip", k_hdr_count, (const char **)k_hdr_src, (const char **)k_hdr_names) != HIPRTC_SUCCESS) {
-        put(err, errlen, "hiprtcCreateProgram failed");
+    // The kernel may not use scratch: a register spilled inside a lane-dependent branch comes back wrong in the lanes that were
+    // inactive there (GroupOcc in group_kernel.hpp).  The static instantiations are checked at build time; here the register
+    // budget is doubled (2 waves per SIMD, then 1) until the compiled kernel is scratch-free, else the potential is refused.
+    // (A potential that indexes a private array dynamically needs scratch as well and is refused with the same message.)
+    Compiled c{};
+    bool ok = false;
+    for (int waves = 2; waves >= 1 && !ok; --waves) {
+        std::string prog;
+        prog += "#define PDMP_USER_KIND " + std::to_string(kind) + "\n";
+        prog += "#include \"wave_math.hpp\"\n#include \"user_ad.hpp\"\n";
+        prog += "namespace pdmp_user {\nusing namespace pdmp;\n#line 1 \"potential\"\n";
+        prog += source;
+        prog += "\n}\n#include \"group_kernel.hpp\"\n";
+        prog += "extern \"C\" __global__ __launch_bounds__(256, " + std::to_string(waves) + ") void pdmp_user_kernel(const pdmp::GroupParams gp) {\n";
+        prog += "    pdmp::group_kernel_body<" + std::to_string(sampler) + ", pdmp::T_USER, " + (fd ? "true" : "false") + ">(gp);\n}\n";
+        hiprtcProgram p;
+        if (hiprtcCreateProgram(&p, prog.c_str(), "pdmp_user.hip", k_hdr_count, (const char **)k_hdr_src, (const char **)k_hdr_names) != HIPRTC_SUCCESS) {
+            put(err, errlen, "hiprtcCreateProgram failed");
+            return -3;
+        }
+        hipDeviceProp_t prop;
+        std::string arch = "--offload-arch=gfx950";
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.gcnArchName[0]) {
+            std::string a(prop.gcnArchName);
+            arch = "--offload-arch=" + a.substr(0, a.find(':'));
+        }
+        const char *opts[] = {arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-w"};   // the arithmetic contract of the static build; -w: the log is for errors
+        const hiprtcResult r = hiprtcCompileProgram(p, 5, opts);
+        if (r != HIPRTC_SUCCESS) {
+            size_t n = 0;
+            hiprtcGetProgramLogSize(p, &n);
+            std::string log(n, '\0');
+            if (n) hiprtcGetProgramLog(p, &log[0]);
+            hiprtcDestroyProgram(&p);
+            put(err, errlen, log);
+            return -1;
+        }
+        size_t cs = 0;
+        hiprtcGetCodeSize(p, &cs);
+        std::vector<char> code(cs);
+        hiprtcGetCode(p, code.data());
+        hiprtcDestroyProgram(&p);
+        hipError_t e = hipModuleLoadData(&c.module, code.data());
+        if (e == hipSuccess) e = hipModuleGetFunction(&c.fn, c.module, "pdmp_user_kernel");
+        if (e != hipSuccess) { put(err, errlen, std::string("loading the compiled potential: ") + hipGetErrorString(e)); return -3; }
+        int scratch = 0;
+        e = hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, c.fn);
+        if (e != hipSuccess) { put(err, errlen, std::string("querying the compiled potential: ") + hipGetErrorString(e)); return -3; }
+        ok = scratch == 0;
+        if (!ok) (void)hipModuleUnload(c.module);
+    }
+    if (!ok) {
+        put(err, errlen, "the compiled potential needs more registers than a wave has (it would spill; see DESIGN.md 4.5): simplify U or lower dim");
         return -3;
     }
-    hipDeviceProp_t prop;
-    std::string arch = "--offload-arch=gfx950";
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.gcnArchName[0]) {
-        std::string a(prop.gcnArchName);
-        arch = "--offload-arch=" + a.substr(0, a.find(':'));
-    }
-    const char *opts[] = {arch.c_str(), "-O3", "-std=c++17", "-ffp-contract=off", "-w"};   // the arithmetic contract of the static build; -w: the log is for errors
-    const hiprtcResult r = hiprtcCompileProgram(p, 5, opts);
-    if (r != HIPRTC_SUCCESS) {
-        size_t n = 0;
-        hiprtcGetProgramLogSize(p, &n);
-        std::string log(n, '\0');
-        if (n) hiprtcGetProgramLog(p, &log[0]);
-        hiprtcDestroyProgram(&p);
-        put(err, errlen, log);
-        return -1;
-    }
-    size_t cs = 0;
-    hiprtcGetCodeSize(p, &cs);
-    std::vector<char> code(cs);
-    hiprtcGetCode(p, code.data());
-    hiprtcDestroyProgram(&p);
-    Compiled c;
-    hipError_t e = hipModuleLoadData(&c.module, code.data());
-    if (e == hipSuccess) e = hipModuleGetFunction(&c.fn, c.module, "pdmp_user_kernel");
-    if (e != hipSuccess) { put(err, errlen, std::string("loading the compiled potential: ") + hipGetErrorString(e)); return -3; }
     g_cache[key] = c;
     *fn_out = (void *)c.fn;
     return 0;
