@@ -206,7 +206,7 @@ struct GroupChain {
     static constexpr bool kReg = KC > 0;
     static constexpr bool kZz = SAMPLER == S_ZIGZAG || SAMPLER == S_SUZZ || SAMPLER == S_STICKY;   // Zig-Zag family: per-coordinate rates, flips
     static constexpr bool kSticky = SAMPLER == S_STICKY;
-    static constexpr int kUnroll = KC > 0 ? KC : 1;   // slot loops: fully unrolled in the register form, left alone otherwise
+    static constexpr int kUnroll = KC > 0 ? KC : 2;   // slot loops: fully unrolled in the register form, by two in the LDS form (RHMC +10 %, the others +0-3 %)
     static_assert(!kReg || (!Tgt::kTile && !Tgt::kUser && KC >= 2), "register form: separable / banana targets only");
     const SkelParams &p;
     const int G, K, lane, g, base;       // g = lane within the group, base = first lane of the group
@@ -1515,8 +1515,8 @@ template <int SAMPLER, int TARGET, bool FD> struct GroupOcc {
     static constexpr int kWaves =
         (SAMPLER == S_SUZZ) ? ((TARGET == T_BANANA && !FD) ? 1 : 2)     // the flow's chain-level scalars and the speed duals on top of the Zig-Zag state
         : (TARGET == T_GAUSS_DENSE || SAMPLER == S_STICKY) ? 2          // the mat-vec's row accumulators; the active mask and the thaw clock
-        : (TARGET == T_BANANA || TARGET == T_USER) ? 3                  // banana + finite differences keeps six shared records
-        : (SAMPLER == S_RHMC || SAMPLER == S_BPS) ? 4
+        : (TARGET == T_BANANA || TARGET == T_USER) ? 2                  // banana + finite differences keeps six shared records
+        : (SAMPLER == S_RHMC) ? 4
         : 3;                                                            // Zig-Zag, Boomerang, ForwardECMC on the separable Gaussians
 };
 
