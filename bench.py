@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--n-sk", type=int, default=1000)
     ap.add_argument("--dim", type=int, default=50)
     ap.add_argument("--sampler", default="ZigZagAD", choices=["ZigZagAD", "ZigZag", "BPS", "BPSAD", "Boomerang", "BoomerangAD", "ForwardECMC", "ForwardECMCAD", "SpeedUpZigZag", "SpeedUpZigZagAD", "RHMC"])
-    ap.add_argument("--target", default="iso", choices=["iso", "banana", "dense", "src_banana"],
+    ap.add_argument("--target", default="iso", choices=["iso", "diag", "banana", "dense", "src_banana"],
                     help="src_banana: U_banana given as source, differentiated by forward mode on the GPU (pdmp_create_from_source)")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time; 0 disables it")
@@ -56,6 +56,10 @@ def dense_precision(a):
 
 
 def make_sampler(P, a):
+    if a.target == "diag":                       # N(mu, diag(1/prec)), prec log-uniform in [1/e, e] (seed 7): a Boomerang that actually bounces
+        import numpy as np
+        rs = np.random.default_rng(7)
+        return getattr(P, a.sampler)(a.dim, P.GaussianDiag(rs.normal(size=a.dim), np.exp(rs.uniform(-1, 1, size=a.dim))))
     tgt = {"iso": P.GaussianIso, "banana": P.Banana, "src_banana": lambda: P.SourcePotential(P.U_BANANA_SOURCE)}.get(a.target)
     tgt = tgt() if tgt else P.GaussianPrecision(dense_precision(a))
     return getattr(P, a.sampler)(a.dim, tgt)
@@ -82,8 +86,11 @@ def cpu_baseline(a, sampler):
     import numpy as np
     from oracle import oracle as O
     cores = min(O.num_threads(), int(os.environ.get("PDMP_CPU_THREADS", "16")))   # CPU share of one GPU slot
-    tid = {"iso": O.T_GAUSS_ISO, "banana": O.T_BANANA, "dense": O.T_GAUSS_DENSE, "src_banana": O.T_AD_BANANA}[a.target]
+    tid = {"iso": O.T_GAUSS_ISO, "diag": O.T_GAUSS_DIAG, "banana": O.T_BANANA, "dense": O.T_GAUSS_DENSE, "src_banana": O.T_AD_BANANA}[a.target]
     tparams = np.asfortranarray(dense_precision(a)).ravel(order="F") if a.target == "dense" else None
+    if a.target == "diag":
+        rs = np.random.default_rng(7)
+        tparams = np.concatenate([rs.normal(size=a.dim), np.exp(rs.uniform(-1, 1, size=a.dim))])
     cfg = O.Config(target_params=tparams, sampler=sampler.sampler_id, dim=a.dim, grid_size=sampler.grid_size, tmax=sampler.tmax,
                    refresh_rate=sampler.refresh_rate, vectorized_bound=sampler.vectorized_bound,
                    signed_bound=sampler.signed_bound, adaptive=sampler.adaptive, deriv_mode=sampler.deriv_mode,
@@ -241,7 +248,7 @@ def main():
         K = (d + G - 1) // G if G > 0 else 0
         # mirrors RegForm in csrc/group_kernel.hpp (which register-form instantiations exist)
         sid, fd = sampler.sampler_id, sampler.deriv_mode != 0
-        reg_form = (G > 0 and sid in (0, 1, 2) and K <= 13 and G <= 16 and (G == 1 or K >= 7) and a.target in ("iso", "banana")
+        reg_form = (G > 0 and sid in (0, 1, 2) and K <= 13 and G <= 16 and (G == 1 or K >= 7) and a.target in ("iso", "diag", "banana")
                     and not (sid == 0 and fd) and not (sid == 2 and K != 13) and os.environ.get("PDMP_REG", "1") != "0")
         kernel = (f"group_kernel_reg<{sampler.name},{a.target}> (G={G} lanes per chain, x and v in registers)" if reg_form else
                   f"group_kernel<{sampler.name},{a.target}> (G={G} lanes per chain)" if G > 0 else
