@@ -21,6 +21,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 
 namespace pdmp {
 
@@ -499,8 +500,10 @@ using namespace pdmp;
 
 static long long g_last_phases = 0, g_last_columns = 0;
 static int g_last_mode = 0;
-static rocblas_handle db_handle(int device) {
+static rocblas_handle db_handle(int device) {                      // one rocBLAS handle per device, created on first use
     static rocblas_handle handles[16] = {nullptr};
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
     if (device < 0 || device >= 16) return nullptr;
     if (!handles[device] && rocblas_create_handle(&handles[device]) != rocblas_status_success) handles[device] = nullptr;
     return handles[device];
