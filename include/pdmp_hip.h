@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PDMP_ABI_VERSION 5   /* 5: + PDMP_STICKY, pdmp_diag_t.is_active; 2: + pdmp_create_from_source, PDMP_T_USER; 3: + PDMP_FECMC and its keywords at the end of pdmp_config_t; 4: + PDMP_SUZZ, PDMP_RHMC and its keywords */
+#define PDMP_ABI_VERSION 6   /* 6: is_active / ragged lengths in sample_from_skeleton*, moments and close_at; + the (N, dt) method, pdmp_compact_*, pdmp_multi_*; 5: + PDMP_STICKY, pdmp_diag_t.is_active; 2: + pdmp_create_from_source, PDMP_T_USER; 3: + PDMP_FECMC and its keywords at the end of pdmp_config_t; 4: + PDMP_SUZZ, PDMP_RHMC and its keywords */
 
 enum { PDMP_OK = 0, PDMP_ERR_ARGUMENT = -1, PDMP_ERR_DIMENSION = -2, PDMP_ERR_RUNTIME = -3,
        PDMP_ERR_ITERCAP = -4, PDMP_ERR_UNSUPPORTED = -5 };
@@ -153,35 +153,92 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
                                 const double *xinit, const double *vinit, uint64_t seed,
                                 double *X, double *V, double *t, const pdmp_diag_t *diag, void *stream);
 
-/* sample_from_skeleton(sampler, N, history; discard_vt)  (src/sample.jl:475-513) for C chains.
- * out: rows x N x C with rows = d (discard_vt) or 2d+1. */
+/* sample_from_skeleton(sampler, N::Int, history; discard_vt)  (src/sample.jl:475-513; the StickyPDMP method :516-561) for C chains.
+ * out: rows x N x C with rows = d (discard_vt) or 2d+1.
+ * is_active: PDMPHistory.is_active, d x n_sk x C bytes (pdmp_diag_t.is_active of the run).  Required for PDMP_STICKY handles,
+ *   whose method flows with v_used = active ? v : 0 (:547-549) -- frozen coordinates stay exactly 0; ignored (may be NULL)
+ *   for the other samplers, as in the reference's generic method.
+ * lens (device forms; may be NULL): lens[c] = number of history columns of chain c (<= n_sk) for the ragged histories of the
+ *   time-horizon variant (count[] of pdmp_close_at_time_device); t_end = t[lens[c]-1]. */
 int pdmp_sample_from_skeleton(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
-                              const double *t, int64_t N, int32_t discard_vt, double *out);
+                              const double *t, const uint8_t *is_active, int64_t N, int32_t discard_vt, double *out);
 int pdmp_sample_from_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, const double *X,
-                                     const double *V, const double *t, int64_t N, int32_t discard_vt,
-                                     double *out, void *stream);
+                                     const double *V, const double *t, const uint8_t *is_active, const int64_t *lens,
+                                     int64_t N, int32_t discard_vt, double *out, void *stream);
 
-/* sample_from_skeleton(sampler, dt::Float64, history; discard_vt) (src/sample.jl:573-646): samples at j*dt,
- * j = 1..N; the caller passes N = floor(t[end]/dt) (:608).  dt == 0 selects the N::Int method above. */
+/* sample_from_skeleton(sampler, dt::Float64, history; discard_vt) (src/sample.jl:573-646; StickyPDMP: use_active, :588-596):
+ * samples at j*dt, j = 1..floor(t_end/dt) (:608).  out is rows x N x C; with counts == NULL the caller passes N = floor(t_end/dt)
+ * (one chain, or chains known to share it); with counts != NULL, N is the capacity per chain, counts[c] = min(N, floor(t_end_c/dt))
+ * columns of chain c are written and the rest is left untouched (host form: zero). */
 int pdmp_sample_from_skeleton_dt(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
-                                 const double *t, int64_t N, double dt, int32_t discard_vt, double *out);
+                                 const double *t, const uint8_t *is_active, int64_t N, double dt, int32_t discard_vt,
+                                 double *out, int64_t *counts);
 int pdmp_sample_from_skeleton_dt_device(pdmp_handle h, int64_t C, int64_t n_sk, const double *X,
-                                        const double *V, const double *t, int64_t N, double dt,
-                                        int32_t discard_vt, double *out, void *stream);
+                                        const double *V, const double *t, const uint8_t *is_active, const int64_t *lens,
+                                        int64_t N, double dt, int32_t discard_vt, double *out, int64_t *counts, void *stream);
+
+/* sample_from_skeleton(sampler, N::Int, dt::Float64, history; discard_vt) (src/sample.jl:649-682): the first n_prefix columns
+ * of the history (:650-653), sample times tm = dt:dt:t[n_prefix], previous index searchsortedfirst(t, tm) - 1 (the last column
+ * with t < tm, :657, clamped to the first), flow with v .* is_active for EVERY sampler (:667; is_active NULL = all active).
+ * out: rows x M x C; counts[c] (may be NULL) = min(M, floor(t[n_prefix-1]/dt)) columns written for chain c.  tm[j] = j*dt
+ * (Julia's range arithmetic is TwicePrecision: same values, the length may differ when t_end/dt is within rounding of an integer). */
+int pdmp_sample_from_skeleton_prefix(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
+                                     const double *t, const uint8_t *is_active, int64_t n_prefix, double dt, int64_t M,
+                                     int32_t discard_vt, double *out, int64_t *counts);
+int pdmp_sample_from_skeleton_prefix_device(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
+                                            const double *t, const uint8_t *is_active, int64_t n_prefix, double dt, int64_t M,
+                                            int32_t discard_vt, double *out, int64_t *counts, void *stream);
 
 /* The step right after the path: per-chain sums of x and x^2 over the N samples that
- * sample_from_skeleton(sampler, N, history) (src/sample.jl:475-513) would return, without writing them:
- * sum_x, sum_x2 are d x C (DEVICE pointers).  mean = sum_x / N, var = sum_x2 / N - mean^2 per chain, or pooled. */
+ * sample_from_skeleton(sampler, N, history) (src/sample.jl:475-513 / :516-561) would return, without writing them:
+ * sum_x, sum_x2 are d x C (DEVICE pointers).  mean = sum_x / N, var = sum_x2 / N - mean^2 per chain, or pooled.
+ * is_active / lens as above (is_active required for PDMP_STICKY). */
 int pdmp_sample_moments_device(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
-                               const double *t, int64_t N, double *sum_x, double *sum_x2, void *stream);
+                               const double *t, const uint8_t *is_active, const int64_t *lens, int64_t N,
+                               double *sum_x, double *sum_x2, void *stream);
 
 /* The cut of the time-horizon variant sample_skeleton(sampler, T::Float64, xinit, vinit) (src/sample.jl:323-439) on a
  * fixed-count skeleton held in HBM (DEVICE pointers; the first events of both variants coincide for one seed): count[c] =
- * number of history columns of chain c -- the events with t <= T (:372) plus one closing column at exactly t = T, written in
- * place over the overshooting event by flow from the last event before T (:385-420).  count[c] < 0: the chain has not passed
- * T within n_sk events (-count[c]-1 events so far); rerun with a larger n_sk (Composites.jl:172-191 doubles). */
-int pdmp_close_at_time_device(pdmp_handle h, int64_t C, int64_t n_sk, double *X, double *V, double *t, double T,
-                              int64_t *count, void *stream);
+ * number of history columns of chain c -- the events with t <= T (:372) plus, unless the last of them sits at exactly t = T,
+ * one closing column at t = T written in place over the overshooting event by flow from the last event before T (:385-420;
+ * StickyPDMP: v_used = active_prev ? v_prev : 0 and is_active = active_prev, :386-401, which needs diag->is_active).  With
+ * diag != NULL the closing column's statistics are those of a non-event point: ar, errored_bound, error_value_ar, rejected,
+ * hitting_horizon = 0 (:402-408); horizon keeps the overshooting state's value (the reference records the same state object).
+ * count[c] < 0: the chain has not passed T within n_sk events (-count[c]-1 events so far); rerun with a larger n_sk
+ * (_grow_history doubles, Composites.jl:172-191). */
+int pdmp_close_at_time_device(pdmp_handle h, int64_t C, int64_t n_sk, double *X, double *V, double *t, const pdmp_diag_t *diag,
+                              double T, int64_t *count, void *stream);
+
+/* _trim_history (src/Composites.jl:198-214) for an ensemble: the ragged histories packed back to back into dense buffers.
+ * pdmp_compact_offsets_device: offsets[c] = sum_{c' < c} max(count[c'], 0), offsets[C] = total columns (C+1 int64, DEVICE;
+ *   wave shuffle scan + cross-wave carry, one block).
+ * pdmp_compact_history_device: column k < count[c] of chain c moves to dense column offsets[c] + k of X_out, V_out (d x total),
+ *   t_out (total) and of every diagnostic array present in both diag and diag_out. */
+int pdmp_compact_offsets_device(pdmp_handle h, int64_t C, const int64_t *count, int64_t *offsets, void *stream);
+int pdmp_compact_history_device(pdmp_handle h, int64_t C, int64_t n_sk, const int64_t *count, const int64_t *offsets,
+                                const double *X, const double *V, const double *t, const pdmp_diag_t *diag,
+                                double *X_out, double *V_out, double *t_out, const pdmp_diag_t *diag_out, void *stream);
+
+/* Multi-device ensembles from ONE host process (SURVEY.md 5 "distributed communication backend", 8(e); the reference is
+ * single-chain, single-thread: its stand-in is the `seed = 42 + i` loop of test/test_property_based.jl:138).  The C chains
+ * shard into contiguous ranges over n_devices GPUs (pdmp_multi_shard_range: sizes differ by at most one); device r runs
+ * pdmp_sample_skeleton_device on its range, on its own stream, with the GLOBAL chain ids (chain_id_offset + lo_r + c), so the
+ * result does not depend on n_devices; nothing is exchanged while sampling.
+ * gather = 0: X[r], V[r], t[r] (DEVICE pointers on device r) receive shard r only (d x n_sk x len_r ...).
+ * gather = 1: X[r], V[r], t[r] are full-size (d x n_sk x C ...) buffers on every device; shard r is written at its chain
+ *   offset and ONE collective per array over RCCL / xGMI (ncclAllGather in place when the shards are equal, else one grouped
+ *   ncclBroadcast per shard = all-gather-v) leaves the whole ensemble on every device -- the north star's final exchange.
+ * xinit, vinit: HOST pointers, d x C (16 d bytes per chain; each shard is copied to its device).  Blocking.
+ * RCCL is loaded on first use (librccl.so.1); n_devices = 1 needs no RCCL. */
+typedef struct pdmp_multi *pdmp_multi_handle;
+int pdmp_multi_shard_range(int64_t C, int32_t rank, int32_t n_ranks, int64_t *lo, int64_t *hi);
+int pdmp_multi_create(const pdmp_config_t *cfg, int32_t n_devices, const int32_t *devices /* NULL: 0..n-1 */, pdmp_multi_handle *out);
+int pdmp_multi_destroy(pdmp_multi_handle m);
+int pdmp_multi_sample_skeleton(pdmp_multi_handle m, int64_t C, int64_t n_sk, int64_t chain_id_offset,
+                               const double *xinit, const double *vinit, uint64_t seed, int32_t gather,
+                               double *const *X, double *const *V, double *const *t);
+/* kernel / exchange time of the last pdmp_multi_sample_skeleton (ms, max over devices; hipEvents on each device's stream) */
+int pdmp_multi_get_timing(pdmp_multi_handle m, double *kernel_ms, double *exchange_ms);
 
 /* Synchronises the handle's last stream and returns PDMP_ERR_ITERCAP if any chain of the launches
  * since the previous check hit the iteration cap (Q11 guard events are counted in *n_guard if non-NULL). */

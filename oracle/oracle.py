@@ -65,6 +65,10 @@ def lib():
                                                C.c_int, dp, C.c_int]
         L.orc_sample_from_skeleton_dt.argtypes = [C.POINTER(_Cfg), C.c_int64, C.c_int64, dp, dp, dp, C.c_int64,
                                                   C.c_double, C.c_int, dp, C.c_int]
+        L.orc_sample_from_skeleton_ex.argtypes = [C.POINTER(_Cfg), C.c_int, C.c_int64, C.c_int64, dp, dp, dp, C.c_void_p, C.c_void_p,
+                                                  C.c_int64, C.c_int64, C.c_double, C.c_int, dp, C.c_void_p, C.c_int]
+        L.orc_sample_skeleton_until.argtypes = [C.POINTER(_Cfg), C.c_int64, C.c_int64, C.c_int64, dp, dp, C.c_uint64, C.c_double,
+                                                dp, dp, dp, dp, dp, ip, dp, ip, ip, C.c_void_p, C.c_int]
         L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
         L.orc_log.argtypes = [C.c_double]; L.orc_log.restype = C.c_double
         L.orc_sincos.argtypes = [C.c_double, dp, dp]
@@ -185,17 +189,57 @@ def sample_skeleton(cfg: Config, n_sk: int, xinit, vinit, seed: int, chain_id_of
     return out
 
 
-def sample_from_skeleton(cfg: Config, N: int, X, V, t, discard_vt: bool = True, n_threads: int = 0, dt: float = 0.0):
+def sample_from_skeleton(cfg: Config, N: int, X, V, t, discard_vt: bool = True, n_threads: int = 0, dt: float = 0.0,
+                         is_active=None, lens=None, n_prefix: int = 0, return_counts: bool = False):
+    """The reference's three sample_from_skeleton methods: ``N::Int`` (dt == 0; sample.jl:475-513, StickyPDMP :516-561),
+    ``dt::Float64`` (dt > 0; :573-646), ``(N, dt)`` (n_prefix > 0 and dt > 0; :649-682: N = capacity of samples per chain)."""
     X = np.ascontiguousarray(X, dtype=np.float64); V = np.ascontiguousarray(V, dtype=np.float64)
     t = np.ascontiguousarray(t, dtype=np.float64)
     if X.ndim == 2:
         X, V, t = X[None], V[None], t[None]
+        if is_active is not None:
+            is_active = np.asarray(is_active)[None]
     Cn, n_sk, d = X.shape
     rows = d if discard_vt else 2 * d + 1
-    out = np.empty((Cn, max(int(N), 0), rows))
+    out = np.zeros((Cn, max(int(N), 0), rows)) if return_counts else np.empty((Cn, max(int(N), 0), rows))
+    ia = None if is_active is None else np.ascontiguousarray(np.asarray(is_active).astype(np.uint8))
+    ln = None if lens is None else np.ascontiguousarray(np.asarray(lens, dtype=np.int64))
+    cnt = np.zeros(Cn, np.int64) if return_counts else None
+    method = 2 if n_prefix > 0 else (1 if dt > 0.0 else 0)
     c = cfg.c()
-    _check(lib().orc_sample_from_skeleton_dt(C.byref(c), Cn, n_sk, _dp(X), _dp(V), _dp(t), int(N), float(dt),
-                                             int(discard_vt), _dp(out), n_threads))
+    vp = lambda a: None if a is None else C.c_void_p(a.ctypes.data)
+    _check(lib().orc_sample_from_skeleton_ex(C.byref(c), method, Cn, n_sk, _dp(X), _dp(V), _dp(t), vp(ia), vp(ln), int(n_prefix), int(N),
+                                             float(dt), int(discard_vt), _dp(out), vp(cnt), n_threads))
+    return (out, cnt) if return_counts else out
+
+
+def sample_skeleton_until(cfg: Config, T: float, xinit, vinit, seed: int, chain_id_offset: int = 0, init_capacity: int = 1024,
+                          n_threads: int = 0) -> dict:
+    """sample_skeleton(sampler, T::Float64, xinit, vinit; seed, init_capacity) (sample.jl:323-439) for C chains: capacity doubles
+    until every chain has reached T (_grow_history, Composites.jl:172-191).  Returns arrays shaped (C, capacity, ...) and ``count``
+    (C,): chain c's history is columns [0, count[c])."""
+    x = np.ascontiguousarray(np.atleast_2d(np.asarray(xinit, dtype=np.float64)))
+    v = np.ascontiguousarray(np.atleast_2d(np.asarray(vinit, dtype=np.float64)))
+    Cn, d = x.shape
+    cap = max(2, int(init_capacity))
+    while True:
+        out = {"X": np.zeros((Cn, cap, d)), "V": np.zeros((Cn, cap, d)), "t": np.zeros((Cn, cap)),
+               "horizon": np.zeros((Cn, cap)), "ar": np.zeros((Cn, cap)), "errored_bound": np.zeros((Cn, cap), np.int32),
+               "error_value_ar": np.zeros((Cn, cap, 5)), "rejected": np.zeros((Cn, cap), np.int32),
+               "hitting_horizon": np.zeros((Cn, cap), np.int32)}
+        c = cfg.c()
+        if cfg.sampler == STICKY:
+            out["is_active"] = np.ones((Cn, cap, d), np.uint8)
+            c.is_active_out = out["is_active"].ctypes.data
+        count = np.zeros(Cn, np.int64)
+        _check(lib().orc_sample_skeleton_until(C.byref(c), Cn, cap, int(chain_id_offset), _dp(x), _dp(v), C.c_uint64(seed & (2**64 - 1)),
+                                               float(T), _dp(out["X"]), _dp(out["V"]), _dp(out["t"]), _dp(out["horizon"]), _dp(out["ar"]),
+                                               _ip(out["errored_bound"]), _dp(out["error_value_ar"]), _ip(out["rejected"]),
+                                               _ip(out["hitting_horizon"]), C.c_void_p(count.ctypes.data), n_threads))
+        if (count > 0).all():
+            break
+        cap *= 2
+    out["count"] = count
     return out
 
 

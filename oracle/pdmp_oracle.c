@@ -943,10 +943,19 @@ static int sticky_thaw_pick(const orc_config_t *cfg, ws_t *w, const double *kapp
 
 /* One chain: sample_skeleton (sample.jl:253-284) = init_state (AbstractPDMP.jl:93-153, the unused
  * first bound of :140 skipped, Q14) + (n_sk-1) x get_event_state! (SamplingLoopInplace.jl:27-39). */
+static void flow_plain(const orc_config_t *cfg, int d, const double *x0, const double *v0, double tau, double *xo, double *vo);
+
+/* T_until < 0: the fixed-count loop of sample.jl:253-284.  T_until >= 0: the time-horizon variant sample_skeleton(sampler,
+ * T::Float64, ...), sample.jl:323-439 -- events are recorded while state.t <= T (:372-378); the first event beyond T is replaced
+ * by ONE closing column at exactly t = T, obtained by the sampler's flow from the previous state (:379-420; StickyPDMP: with
+ * v_used = active_prev ? v_prev : 0 and is_active = active_prev, :386-401) with the statistics of a non-event point (zeros,
+ * :402-408); an event at exactly t == T ends the loop without a closing column (`while state.t < T`, :362).  n_sk is the
+ * capacity: *count_out = number of columns, or -(columns so far) - 1 when the capacity ran out before T (the caller doubles it,
+ * _grow_history, Composites.jl:172-191: same columns, same stream). */
 static int run_chain(const orc_config_t *cfg, ws_t *w, int64_t n_sk, uint64_t seed, uint64_t chain,
                      const double *xinit, const double *vinit,
                      double *X, double *V, double *T, double *H, double *AR, int32_t *EB, double *EV,
-                     int32_t *RJ, int32_t *HH, uint8_t *IA) {
+                     int32_t *RJ, int32_t *HH, uint8_t *IA, double T_until, int64_t *count_out) {
     const int d = w->d, n = w->n;
     const int64_t cap = cfg->max_iter_per_event > 0 ? cfg->max_iter_per_event : 1000000;
     int overrun = 0;
@@ -961,8 +970,17 @@ static int run_chain(const orc_config_t *cfg, ws_t *w, int64_t n_sk, uint64_t se
     for (int i = 0; i < d; ++i) w->actf[i] = 1.0;                              /* is_active = trues(d), Composites.jl:95 */
     double t = 0.0, horizon = cfg->tmax, ts = 0.0, tp = 0.0, E = 0.0, lb = 0.0, ar = 0.0;
     int status = 0;
+    const int until = T_until >= 0.0;
+    double prev_buf[until ? 3 * d : 1];             /* x_prev, v_prev, active_prev (:356-360) */
+    double *x_prev = prev_buf, *v_prev = prev_buf + (until ? d : 0), *a_prev = prev_buf + (until ? 2 * d : 0), t_prev = 0.0;
+    if (until && count_out) *count_out = 0;
     for (int64_t k = 0; k < n_sk; ++k) {
         int32_t errored = 0, rejected = 0, hits = 0; double ev[5] = { 0, 0, 0, 0, 0 };   /* :28-31 */
+        if (until && k > 0) {
+            if (!(t < T_until)) { if (count_out) *count_out = k; return overrun ? -6 : 0; }   /* while state.t < T, :362 (T == 0: :350-353) */
+            memcpy(x_prev, w->x, (size_t)d * 8); memcpy(v_prev, w->v, (size_t)d * 8); memcpy(a_prev, w->actf, (size_t)d * 8);   /* :363-368 */
+            t_prev = t;
+        }
         if (k > 0 && cfg->sampler == ORC_STICKY) {
             /* get_event_state(state, sampler::StickyPDMP), StickySamplingLoop.jl:13-29: an accepted flip, the crossing of an axis
              * (the coordinate sticks) and the thawing of a coordinate are all events. */
@@ -1097,6 +1115,29 @@ static int run_chain(const orc_config_t *cfg, ws_t *w, int64_t n_sk, uint64_t se
                 }
             }
         }
+        if (until && k > 0 && t > T_until) {                                          /* overshoot, :379-420 */
+            const double tau = T_until - t_prev;
+            for (int i = 0; i < d; ++i) {
+                w->actf[i] = a_prev[i];                                               /* :399-401 */
+                v_prev[i] = (cfg->sampler == ORC_STICKY && a_prev[i] == 0.0) ? 0.0 : v_prev[i];   /* v_used, :386-392 */
+            }
+            flow_plain(cfg, d, x_prev, v_prev, tau, w->x, w->v);                      /* xT, vT = sampler.flow(x_prev, v_used, tau), :394-396 */
+            t = T_until;
+            ar = 0.0; errored = 0; rejected = 0; hits = 0;                            /* :402-408 (the local ar is not read again) */
+            for (int q = 0; q < 5; ++q) ev[q] = 0.0;
+            memcpy(X + (size_t)k * d, w->x, (size_t)d * 8);
+            memcpy(V + (size_t)k * d, w->v, (size_t)d * 8);
+            T[k] = t;
+            if (H) H[k] = horizon;
+            if (AR) AR[k] = 0.0;
+            if (EB) EB[k] = 0;
+            if (EV) memcpy(EV + 5 * (size_t)k, ev, 40);
+            if (RJ) RJ[k] = 0;
+            if (HH) HH[k] = 0;
+            if (IA) for (int i = 0; i < d; ++i) IA[(size_t)k * d + i] = (uint8_t)(w->actf[i] != 0.0);
+            if (count_out) *count_out = k + 1;
+            return overrun ? -6 : 0;
+        }
         /* record!, Composites.jl:239-260 */
         memcpy(X + (size_t)k * d, w->x, (size_t)d * 8);
         memcpy(V + (size_t)k * d, w->v, (size_t)d * 8);
@@ -1110,14 +1151,44 @@ static int run_chain(const orc_config_t *cfg, ws_t *w, int64_t n_sk, uint64_t se
         if (IA) for (int i = 0; i < d; ++i) IA[(size_t)k * d + i] = (uint8_t)(w->actf[i] != 0.0);   /* Composites.jl:256 */
     }
     (void)status;
+    if (until) {                                    /* the capacity ran out (or the last column sits at t >= T exactly) */
+        if (count_out) *count_out = (t < T_until) ? -n_sk - 1 : n_sk;
+    }
     return overrun ? -6 : 0;
 }
+
+static int sample_skeleton_impl(const orc_config_t *cfg_in, int64_t C, int64_t n_sk, int64_t chain_id_offset,
+                        const double *xinit, const double *vinit, uint64_t seed,
+                        double *X, double *V, double *t, double *horizon, double *ar,
+                        int32_t *errored_bound, double *error_value_ar, int32_t *rejected,
+                        int32_t *hitting_horizon, int n_threads, double T_until, int64_t *count);
 
 int orc_sample_skeleton(const orc_config_t *cfg_in, int64_t C, int64_t n_sk, int64_t chain_id_offset,
                         const double *xinit, const double *vinit, uint64_t seed,
                         double *X, double *V, double *t, double *horizon, double *ar,
                         int32_t *errored_bound, double *error_value_ar, int32_t *rejected,
                         int32_t *hitting_horizon, int n_threads) {
+    return sample_skeleton_impl(cfg_in, C, n_sk, chain_id_offset, xinit, vinit, seed, X, V, t, horizon, ar, errored_bound,
+                                error_value_ar, rejected, hitting_horizon, n_threads, -1.0, NULL);
+}
+
+/* sample_skeleton(sampler, T::Float64, xinit, vinit), sample.jl:323-439, with `capacity` history columns per chain */
+int orc_sample_skeleton_until(const orc_config_t *cfg_in, int64_t C, int64_t capacity, int64_t chain_id_offset,
+                              const double *xinit, const double *vinit, uint64_t seed, double T_end,
+                              double *X, double *V, double *t, double *horizon, double *ar,
+                              int32_t *errored_bound, double *error_value_ar, int32_t *rejected,
+                              int32_t *hitting_horizon, int64_t *count, int n_threads) {
+    if (!(T_end >= 0.0) || !isfinite(T_end)) FAIL(-1, "T must be finite and non-negative. Current value: %g", T_end);   /* :335-337 */
+    if (!count) FAIL(-1, "null count");
+    return sample_skeleton_impl(cfg_in, C, capacity, chain_id_offset, xinit, vinit, seed, X, V, t, horizon, ar, errored_bound,
+                                error_value_ar, rejected, hitting_horizon, n_threads, T_end, count);
+}
+
+static int sample_skeleton_impl(const orc_config_t *cfg_in, int64_t C, int64_t n_sk, int64_t chain_id_offset,
+                        const double *xinit, const double *vinit, uint64_t seed,
+                        double *X, double *V, double *t, double *horizon, double *ar,
+                        int32_t *errored_bound, double *error_value_ar, int32_t *rejected,
+                        int32_t *hitting_horizon, int n_threads, double T_until, int64_t *count) {
     orc_config_t cfg = *cfg_in;
     if (orc_normalize_config(&cfg)) return -1;
     if (n_sk <= 0) FAIL(-1, "n_sk must be positive. Current value: %lld", (long long)n_sk);   /* sample.jl:262-264 */
@@ -1143,7 +1214,7 @@ int orc_sample_skeleton(const orc_config_t *cfg_in, int64_t C, int64_t n_sk, int
                               errored_bound ? errored_bound + o : NULL,
                               error_value_ar ? error_value_ar + 5 * o : NULL,
                               rejected ? rejected + o : NULL, hitting_horizon ? hitting_horizon + o : NULL,
-                              cfg.is_active_out ? cfg.is_active_out + o * d : NULL);
+                              cfg.is_active_out ? cfg.is_active_out + o * d : NULL, T_until, count ? count + c : NULL);
             if (r) rc = r;
         }
         ws_free(&w);
@@ -1155,11 +1226,105 @@ int orc_sample_skeleton(const orc_config_t *cfg_in, int64_t C, int64_t n_sk, int
     return 0;
 }
 
+/* The sampler's deterministic flow as sample_from_skeleton and the closing point of the time-horizon variant call it
+ * (sampler.flow(x0, v0, tau), sample.jl:499 / :394): plain `x + v * tau` (two roundings, as Julia evaluates it), the rotation for
+ * the Boomerang, the closed form for SpeedUpZigZag (dot products in the engine's wave order), velocity-Verlet for RHMC. */
+static void flow_plain(const orc_config_t *cfg, int d, const double *x0, const double *v0, double tau, double *xo, double *vo) {
+    if (cfg->sampler == ORC_RHMC) {
+        double *xb = malloc((size_t)d * 8 * 5), *vb = xb + d, *xe = vb + d, *g = xe + d, *ge = g + d;
+        for (int q = 0; q < d; ++q) { xb[q] = x0[q]; vb[q] = v0[q]; }
+        rhmc_flow(cfg, xb, vb, d, tau, xe, g, ge);
+        for (int q = 0; q < d; ++q) { xo[q] = xb[q]; if (vo) vo[q] = vb[q]; }
+        free(xb);
+    } else if (cfg->sampler == ORC_SUZZ) {          /* SpeedUpZigZagSamplers.jl:71-79 */
+        double *yb = malloc((size_t)d * 8), *pb = malloc((size_t)d * 8);
+        const double av = v0[0] * x0[0], dd = (double)d;
+        for (int q = 0; q < d; ++q) { yb[q] = x0[q] - av * v0[q]; pb[q] = yb[q] * v0[q]; }
+        const double yv = sum_wave64(pb, d);
+        for (int q = 0; q < d; ++q) pb[q] = yb[q] * yb[q];
+        const double yy = sum_wave64(pb, d);
+        const double c = v0[0] * yv, a = (1.0 + yy) / dd - (c * c) / (dd * dd), Y0 = x0[0] + c / dd;
+        const double bt = (Y0 + sqrt(Y0 * Y0 + a)) * orc_exp(sqrt(dd) * v0[0] * tau);
+        const double X1 = (bt * bt - a) / (2.0 * bt) - c / dd;
+        const double kv = v0[0] * X1;
+        for (int q = 0; q < d; ++q) { const double vq = v0[q]; xo[q] = yb[q] + kv * vq; if (vo) vo[q] = vq; }
+        free(yb); free(pb);
+    } else if (cfg->sampler == ORC_BOOMERANG) {
+        double s, cs; orc_sincos(tau, &s, &cs);
+        for (int q = 0; q < d; ++q) {
+            const double xq = x0[q], vq = v0[q];
+            xo[q] = xq * cs + vq * s;
+            if (vo) vo[q] = (-xq) * s + vq * cs;
+        }
+    } else {
+        for (int q = 0; q < d; ++q) { const double xq = x0[q], vq = v0[q]; xo[q] = xq + vq * tau; if (vo) vo[q] = vq; }
+    }
+}
+
+/* The three sample_from_skeleton methods of the reference, per chain:
+ *   method 0  N::Int                (sample.jl:475-513; StickyPDMP :516-561): N samples, dt = t_end / N
+ *   method 1  dt::Float64           (:573-646; StickyPDMP: use_active):        samples at j dt, j = 1..floor(t_end / dt)
+ *   method 2  (N::Int, dt::Float64) (:649-682): history columns 1..n_prefix, tm = dt:dt:t[n_prefix], previous index
+ *             searchsortedfirst(t, tm) - 1 clamped to 1, flow with v0 .* active for EVERY sampler
+ * is_active: d x n_sk x C bytes or NULL (all active); consulted by the StickyPDMP methods and by method 2.
+ * lens: per-chain number of history columns (ragged histories of the time-horizon variant) or NULL (n_sk).
+ * N: samples per chain (methods 1/2 with counts: the capacity; counts[c] = min(N, floor(t_end_c / dt)) are written). */
+int orc_sample_from_skeleton_ex(const orc_config_t *cfg, int method, int64_t C, int64_t n_sk, const double *X, const double *V,
+                                const double *t, const uint8_t *is_active, const int64_t *lens, int64_t n_prefix, int64_t N,
+                                double dt_in, int discard_vt, double *out, int64_t *counts, int n_threads) {
+    if (N <= 0) FAIL(-1, "N must be positive. Current value: %lld", (long long)N);           /* :476-478 */
+    if (n_sk <= 0) FAIL(-1, "empty history");
+    if (method != 0 && !(dt_in > 0.0)) FAIL(-1, "dt must be positive");
+    if (method == 2 && (n_prefix <= 0 || n_prefix > n_sk)) FAIL(-1, "N out of range of the history");
+    if (cfg->sampler == ORC_STICKY && !is_active) FAIL(-1, "StickyPDMP methods need history.is_active");
+    const int d = cfg->dim;
+    const size_t rows = discard_vt ? (size_t)d : 2 * (size_t)d + 1;                           /* :487 */
+    const int ia_mode = !is_active ? 0 : (method == 2 ? 2 : (cfg->sampler == ORC_STICKY ? 1 : 0));
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+#endif
+#pragma omp parallel for num_threads(n_threads) schedule(static)
+    for (int64_t c = 0; c < C; ++c) {
+        const double *Xc = X + (size_t)c * n_sk * d, *Vc = V + (size_t)c * n_sk * d, *tc = t + (size_t)c * n_sk;
+        const uint8_t *Ac = is_active ? is_active + (size_t)c * n_sk * d : NULL;
+        double *oc = out + (size_t)c * N * rows;
+        double *vu = malloc((size_t)d * 8 * 2), *vn = vu + d;
+        int64_t nh = (method == 2) ? n_prefix : n_sk;                                        /* views 1:N, :650-653 */
+        if (lens && lens[c] > 0 && lens[c] < nh) nh = lens[c];
+        const double dt = method != 0 ? dt_in : tc[nh - 1] / (double)N;                      /* :483-484 */
+        int64_t nmax = N;
+        if (method != 0 && counts) {
+            const double q = floor(tc[nh - 1] / dt_in);                                      /* n_skel = Int(floor(T_end / dt)), :608 */
+            nmax = q < (double)N ? (int64_t)q : N;
+            counts[c] = nmax;
+        }
+        int64_t i = 0;
+        for (int64_t j = 1; j <= nmax; ++j) {
+            const double tm = (double)j * dt;                                                /* :492 */
+            if (method == 2) { while (i < nh - 1 && tc[i + 1] < tm) ++i; }                   /* searchsortedfirst(t, tm) - 1, :657 (i >= 1, :663) */
+            else { while (i < nh - 1 && tc[i + 1] <= tm) ++i; }                              /* :493-495 */
+            const double tau = tm - tc[i];                                                   /* :497 */
+            const double *x0 = Xc + (size_t)i * d, *v0 = Vc + (size_t)i * d;
+            double *o = oc + (size_t)(j - 1) * rows;
+            if (ia_mode) {
+                const uint8_t *a0 = Ac + (size_t)i * d;
+                for (int q = 0; q < d; ++q)
+                    vu[q] = (ia_mode == 2) ? v0[q] * (a0[q] ? 1.0 : 0.0) : (a0[q] ? v0[q] : 0.0);   /* :667 / :547-549 */
+                v0 = vu;
+            }
+            flow_plain(cfg, d, x0, v0, tau, o, discard_vt ? vn : o + d);
+            if (!discard_vt) o[2 * d] = tm;                                                  /* :505-508 */
+        }
+        free(vu);
+    }
+    return 0;
+}
+
 /* sample_from_skeleton(sampler, N, history), sample.jl:475-513 */
 int orc_sample_from_skeleton(const orc_config_t *cfg, int64_t C, int64_t n_sk, const double *X,
                              const double *V, const double *t, int64_t N, int discard_vt, double *out,
                              int n_threads) {
-    return orc_sample_from_skeleton_dt(cfg, C, n_sk, X, V, t, N, 0.0, discard_vt, out, n_threads);
+    return orc_sample_from_skeleton_ex(cfg, 0, C, n_sk, X, V, t, NULL, NULL, 0, N, 0.0, discard_vt, out, NULL, n_threads);
 }
 
 /* dt_in > 0: the `dt::Float64` method (sample.jl:573-646): samples at j*dt_in, j = 1..N (the caller passes
@@ -1167,56 +1332,6 @@ int orc_sample_from_skeleton(const orc_config_t *cfg, int64_t C, int64_t n_sk, c
 int orc_sample_from_skeleton_dt(const orc_config_t *cfg, int64_t C, int64_t n_sk, const double *X,
                                 const double *V, const double *t, int64_t N, double dt_in, int discard_vt, double *out,
                                 int n_threads) {
-    if (N <= 0) FAIL(-1, "N must be positive. Current value: %lld", (long long)N);           /* :476-478 */
-    if (n_sk <= 0) FAIL(-1, "empty history");
-    const int d = cfg->dim;
-    const size_t rows = discard_vt ? (size_t)d : 2 * (size_t)d + 1;                           /* :487 */
-#ifdef _OPENMP
-    if (n_threads <= 0) n_threads = omp_get_max_threads();
-#endif
-#pragma omp parallel for num_threads(n_threads) schedule(static)
-    for (int64_t c = 0; c < C; ++c) {
-        const double *Xc = X + (size_t)c * n_sk * d, *Vc = V + (size_t)c * n_sk * d, *tc = t + (size_t)c * n_sk;
-        double *oc = out + (size_t)c * N * rows;
-        const double dt = dt_in > 0.0 ? dt_in : tc[n_sk - 1] / (double)N;                    /* :483-484 */
-        int64_t i = 0;
-        for (int64_t j = 1; j <= N; ++j) {
-            double tm = (double)j * dt;                                                      /* :492 */
-            while (i < n_sk - 1 && tc[i + 1] <= tm) ++i;                                     /* :493-495 */
-            double tau = tm - tc[i];                                                         /* :497 */
-            const double *x0 = Xc + (size_t)i * d, *v0 = Vc + (size_t)i * d;
-            double *o = oc + (size_t)(j - 1) * rows;
-            if (cfg->sampler == ORC_RHMC) {             /* the sampler's own flow (sample.jl:499): velocity-Verlet from the event's (x, v) */
-                double *xb = malloc((size_t)d * 8 * 5), *vb = xb + d, *xe = vb + d, *g = xe + d, *ge = g + d;
-                for (int q = 0; q < d; ++q) { xb[q] = x0[q]; vb[q] = v0[q]; }
-                rhmc_flow(cfg, xb, vb, d, tau, xe, g, ge);
-                for (int q = 0; q < d; ++q) { o[q] = xb[q]; if (!discard_vt) o[d + q] = vb[q]; }
-                free(xb);
-            } else if (cfg->sampler == ORC_SUZZ) {      /* the sampler's own flow (sample.jl:499), SpeedUpZigZagSamplers.jl:71-79; dot
-                                                         * products in the engine's wave order (lane q sums q, q+64, ...; butterfly) */
-                double *yb = malloc((size_t)d * 8), *pb = malloc((size_t)d * 8);
-                const double av = v0[0] * x0[0], dd = (double)d;
-                for (int q = 0; q < d; ++q) { yb[q] = x0[q] - av * v0[q]; pb[q] = yb[q] * v0[q]; }
-                const double yv = sum_wave64(pb, d);
-                for (int q = 0; q < d; ++q) pb[q] = yb[q] * yb[q];
-                const double yy = sum_wave64(pb, d);
-                const double c = v0[0] * yv, a = (1.0 + yy) / dd - (c * c) / (dd * dd), Y0 = x0[0] + c / dd;
-                const double bt = (Y0 + sqrt(Y0 * Y0 + a)) * orc_exp(sqrt(dd) * v0[0] * tau);
-                const double X1 = (bt * bt - a) / (2.0 * bt) - c / dd;
-                const double kv = v0[0] * X1;
-                for (int q = 0; q < d; ++q) { o[q] = yb[q] + kv * v0[q]; if (!discard_vt) o[d + q] = v0[q]; }
-                free(yb); free(pb);
-            } else if (cfg->sampler == ORC_BOOMERANG) {
-                double s, cs; orc_sincos(tau, &s, &cs);
-                for (int q = 0; q < d; ++q) {
-                    o[q] = x0[q] * cs + v0[q] * s;
-                    if (!discard_vt) o[d + q] = (-x0[q]) * s + v0[q] * cs;
-                }
-            } else {
-                for (int q = 0; q < d; ++q) { o[q] = x0[q] + v0[q] * tau; if (!discard_vt) o[d + q] = v0[q]; }
-            }
-            if (!discard_vt) o[2 * d] = tm;                                                  /* :505-508 */
-        }
-    }
-    return 0;
+    return orc_sample_from_skeleton_ex(cfg, dt_in > 0.0 ? 1 : 0, C, n_sk, X, V, t, NULL, NULL, 0, N, dt_in > 0.0 ? dt_in : 0.0, discard_vt,
+                                       out, NULL, n_threads);
 }

@@ -99,6 +99,21 @@ int orc_sample_from_skeleton_dt(const orc_config_t *cfg, int64_t C, int64_t n_sk
                                 const double *X, const double *V, const double *t,
                                 int64_t N, double dt, int discard_vt, double *out, int n_threads);
 
+/* All three sample_from_skeleton methods (sample.jl:475-513 / :516-561, :573-646, :649-682) with PDMPHistory.is_active and
+ * ragged history lengths; see pdmp_oracle.c. */
+int orc_sample_from_skeleton_ex(const orc_config_t *cfg, int method, int64_t C, int64_t n_sk, const double *X, const double *V,
+                                const double *t, const uint8_t *is_active, const int64_t *lens, int64_t n_prefix, int64_t N,
+                                double dt, int discard_vt, double *out, int64_t *counts, int n_threads);
+
+/* sample_skeleton(sampler, T::Float64, xinit, vinit) (sample.jl:323-439) with `capacity` history columns per chain:
+ * count[c] = columns of chain c (events with t <= T + the closing column at t = T), or -(columns so far) - 1 when the capacity
+ * ran out before T (the caller doubles it, as _grow_history does, Composites.jl:172-191). */
+int orc_sample_skeleton_until(const orc_config_t *cfg, int64_t C, int64_t capacity, int64_t chain_id_offset,
+                              const double *xinit, const double *vinit, uint64_t seed, double T_end,
+                              double *X, double *V, double *t, double *horizon, double *ar,
+                              int32_t *errored_bound, double *error_value_ar, int32_t *rejected,
+                              int32_t *hitting_horizon, int64_t *count, int n_threads);
+
 /* --- pieces exposed for known-answer tests --- */
 void   orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 double orc_log(double x);

@@ -59,7 +59,11 @@ class Timing(C.Structure):
 SYMBOLS = (
     "pdmp_abi_version", "pdmp_last_error", "pdmp_device_count", "pdmp_create", "pdmp_create_from_source", "pdmp_get_config",
     "pdmp_destroy", "pdmp_get_group_lanes", "pdmp_set_tape", "pdmp_clear_tape", "pdmp_sample_skeleton", "pdmp_sample_skeleton_device", "pdmp_sample_from_skeleton",
-    "pdmp_sample_from_skeleton_device", "pdmp_sample_from_skeleton_dt", "pdmp_sample_from_skeleton_dt_device", "pdmp_sample_moments_device", "pdmp_close_at_time_device", "pdmp_check_status", "pdmp_get_timing", "pdmp_reset_timing",
+    "pdmp_sample_from_skeleton_device", "pdmp_sample_from_skeleton_dt", "pdmp_sample_from_skeleton_dt_device",
+    "pdmp_sample_from_skeleton_prefix", "pdmp_sample_from_skeleton_prefix_device", "pdmp_sample_moments_device",
+    "pdmp_close_at_time_device", "pdmp_compact_offsets_device", "pdmp_compact_history_device",
+    "pdmp_multi_shard_range", "pdmp_multi_create", "pdmp_multi_destroy", "pdmp_multi_sample_skeleton", "pdmp_multi_get_timing",
+    "pdmp_check_status", "pdmp_get_timing", "pdmp_reset_timing",
     "pdmp_debug_rng", "pdmp_dense_batched_last_phases", "pdmp_dense_batched_last_columns", "pdmp_dense_batched_last_mode",
 )
 
@@ -96,12 +100,22 @@ def lib():
     L.pdmp_clear_tape.argtypes = [vp]
     L.pdmp_sample_skeleton.argtypes = [vp, i64, i64, i64, vp, vp, u64, vp, vp, vp, C.POINTER(Diag)]
     L.pdmp_sample_skeleton_device.argtypes = [vp, i64, i64, i64, vp, vp, u64, vp, vp, vp, C.POINTER(Diag), vp]
-    L.pdmp_sample_from_skeleton.argtypes = [vp, i64, i64, vp, vp, vp, i64, i32, vp]
-    L.pdmp_sample_from_skeleton_device.argtypes = [vp, i64, i64, vp, vp, vp, i64, i32, vp, vp]
-    L.pdmp_sample_from_skeleton_dt.argtypes = [vp, i64, i64, vp, vp, vp, i64, C.c_double, i32, vp]
-    L.pdmp_sample_from_skeleton_dt_device.argtypes = [vp, i64, i64, vp, vp, vp, i64, C.c_double, i32, vp, vp]
-    L.pdmp_sample_moments_device.argtypes = [vp, i64, i64, vp, vp, vp, i64, vp, vp, vp]
-    L.pdmp_close_at_time_device.argtypes = [vp, i64, i64, vp, vp, vp, C.c_double, vp, vp]
+    f64 = C.c_double
+    L.pdmp_sample_from_skeleton.argtypes = [vp, i64, i64, vp, vp, vp, vp, i64, i32, vp]
+    L.pdmp_sample_from_skeleton_device.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, i64, i32, vp, vp]
+    L.pdmp_sample_from_skeleton_dt.argtypes = [vp, i64, i64, vp, vp, vp, vp, i64, f64, i32, vp, vp]
+    L.pdmp_sample_from_skeleton_dt_device.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, i64, f64, i32, vp, vp, vp]
+    L.pdmp_sample_from_skeleton_prefix.argtypes = [vp, i64, i64, vp, vp, vp, vp, i64, f64, i64, i32, vp, vp]
+    L.pdmp_sample_from_skeleton_prefix_device.argtypes = [vp, i64, i64, vp, vp, vp, vp, i64, f64, i64, i32, vp, vp, vp]
+    L.pdmp_sample_moments_device.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp]
+    L.pdmp_close_at_time_device.argtypes = [vp, i64, i64, vp, vp, vp, C.POINTER(Diag), f64, vp, vp]
+    L.pdmp_compact_offsets_device.argtypes = [vp, i64, vp, vp, vp]
+    L.pdmp_compact_history_device.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, C.POINTER(Diag), vp, vp, vp, C.POINTER(Diag), vp]
+    L.pdmp_multi_shard_range.argtypes = [i64, i32, i32, C.POINTER(i64), C.POINTER(i64)]
+    L.pdmp_multi_create.argtypes = [C.POINTER(Config), i32, C.POINTER(i32), C.POINTER(vp)]
+    L.pdmp_multi_destroy.argtypes = [vp]
+    L.pdmp_multi_sample_skeleton.argtypes = [vp, i64, i64, i64, vp, vp, u64, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.pdmp_multi_get_timing.argtypes = [vp, C.POINTER(f64), C.POINTER(f64)]
     L.pdmp_check_status.argtypes = [vp, C.POINTER(i64)]
     L.pdmp_get_timing.argtypes = [vp, C.POINTER(Timing)]
     L.pdmp_reset_timing.argtypes = [vp]
@@ -109,7 +123,7 @@ def lib():
     L.pdmp_dense_batched_last_phases.restype = C.c_longlong
     L.pdmp_dense_batched_last_columns.restype = C.c_longlong
     L.pdmp_dense_batched_last_mode.restype = C.c_int
-    if L.pdmp_abi_version() != 5:
+    if L.pdmp_abi_version() != 6:
         raise EngineError(ERR_RUNTIME, "ABI version mismatch")
     _lib = L
     return L

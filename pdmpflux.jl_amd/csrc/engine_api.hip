@@ -75,6 +75,8 @@ struct pdmp_engine {
     double *d_tape[3] = {nullptr, nullptr, nullptr};   // tape source: exp, uni, nrm (chain-major)
     int64_t tape_n[3] = {0, 0, 0}, tape_chains = 0;
     hipStream_t last_stream = nullptr;
+    bool launched = false;            // a launch has used the per-handle scheduler / hand-off / status buffers
+    hipEvent_t order_ev = nullptr;    // orders launches of this handle that arrive on different streams (they share those buffers)
     std::vector<EventPair> pending;   // launches not yet folded into `timing`
     std::vector<EventPair> pool;
     pdmp_timing_t timing = {0.0, 0.0, 0};
@@ -139,36 +141,55 @@ __device__ __forceinline__ void rhmc_integrate(int d, int lane, const double *x0
 // tile*64+s by binary search in t (equivalent to the reference's monotone pointer walk :493-495 for
 // non-decreasing t), then the wave writes the 64 samples one after the other, lanes over coordinates
 // (coalesced d*8-byte rows).
+// ia_mode: 0 = velocities as recorded; 1 = StickyPDMP methods (sample.jl:516-561, :588-596 with use_active): v_used = active ? v : 0.0;
+// 2 = the (N, dt) method (:649-682): v0 .* active (a frozen negative velocity becomes -0.0, as in the reference).
+// strict: the (N, dt) method's previous index searchsortedfirst(t, tm) - 1 = last i with t[i] < tm (clamped to the first column)
+// instead of the pointer walk's last i with t[i] <= tm (:493-495).  n_use <= n_sk: only the first n_use columns of every chain
+// are history (the (N, dt) method's views 1:N, :650-653; ragged histories of the time-horizon variant pass count[c] via `lens`).
+// counts != nullptr (dt methods on ensembles): samples of chain c = floor(t_end / dt), at most N; the others are left untouched.
 template <bool BOOMERANG>
 __global__ __launch_bounds__(256) void from_skeleton_kernel(int d, int64_t C, int64_t n_sk, const double *X,
                                                             const double *V, const double *t, int64_t N,
                                                             double dt_in, int discard_vt, double *out, int suzz = 0,
-                                                            int rhmc_target = -1, double rhmc_h = 0.0, const double *tparams = nullptr) {
+                                                            int rhmc_target = -1, double rhmc_h = 0.0, const double *tparams = nullptr,
+                                                            const uint8_t *IA = nullptr, int ia_mode = 0, int strict = 0,
+                                                            int64_t n_use = 0, const int64_t *lens = nullptr, int64_t *counts = nullptr) {
     const int lane = lane_id();
     const int64_t tiles = (N + WAVE - 1) / WAVE;
     const int64_t w = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (w >= C * tiles) return;
     const int64_t c = w / tiles, tile = w % tiles;
     const double *tc = t + (size_t)c * n_sk;
-    const double dt = dt_in > 0.0 ? dt_in : tc[n_sk - 1] / (double)N; // :483-484; dt_in: the dt::Float64 method, :573-646
+    int64_t nh = (n_use > 0 && n_use < n_sk) ? n_use : n_sk;          // history columns of this chain
+    if (lens) { const int64_t l = lens[c]; nh = (l > 0 && l < nh) ? l : nh; }
+    const double dt = dt_in > 0.0 ? dt_in : tc[nh - 1] / (double)N;   // :483-484; dt_in: the dt::Float64 methods, :573-646, :649-682
+    int64_t nmax = N;
+    if (dt_in > 0.0 && counts) {                                      // n_skel = Int(floor(T_end / dt)), :608
+        const double q = floor(tc[nh - 1] / dt_in);
+        nmax = (q < (double)N) ? (int64_t)q : N;
+        if (tile == 0 && lane == 0) counts[c] = nmax;
+    }
     const int64_t j = tile * WAVE + lane + 1;                         // 1-based sample index
     const double tm = (double)j * dt;                                 // :492
-    int64_t lo = 0, hi = n_sk - 1;
-    if (j <= N) {
-        while (lo < hi) {                                             // last index with t[i] <= tm
+    int64_t lo = 0, hi = nh - 1;
+    if (j <= nmax) {
+        while (lo < hi) {                                             // last index with t[i] <= tm (strict: t[i] < tm)
             const int64_t mid = (lo + hi + 1) >> 1;
-            if (tc[mid] <= tm) lo = mid; else hi = mid - 1;
+            const bool le = strict ? (tc[mid] < tm) : (tc[mid] <= tm);
+            if (le) lo = mid; else hi = mid - 1;
         }
     }
     const double tau = tm - tc[lo];                                   // :497
     const int seg_lo = (int)lo, seg_hi = (int)(lo >> 32);
     const size_t rows = discard_vt ? (size_t)d : 2 * (size_t)d + 1;   // :487
-    const int64_t nvalid = (N - tile * WAVE) < WAVE ? (N - tile * WAVE) : WAVE;
+    int64_t nvalid = (nmax - tile * WAVE) < WAVE ? (nmax - tile * WAVE) : WAVE;
+    if (nvalid < 0) nvalid = 0;
     for (int s = 0; s < (int)nvalid; ++s) {
         const int64_t i = ((int64_t)__builtin_amdgcn_readlane(seg_hi, s) << 32) |
                           (uint32_t)__builtin_amdgcn_readlane(seg_lo, s);
         const double ta = readlane_d(tau, s), tms = readlane_d(tm, s);
         const double *x0 = X + ((size_t)c * n_sk + (size_t)i) * d, *v0 = V + ((size_t)c * n_sk + (size_t)i) * d;
+        const uint8_t *a0 = (IA && ia_mode) ? IA + ((size_t)c * n_sk + (size_t)i) * d : nullptr;
         double *o = out + ((size_t)c * N + (size_t)(tile * WAVE + s)) * rows;
         double sn = 0.0, cs = 1.0;
         if (BOOMERANG) det_sincos(ta, sn, cs);
@@ -187,7 +208,9 @@ __global__ __launch_bounds__(256) void from_skeleton_kernel(int d, int64_t C, in
             }
         } else
         for (int q = lane; q < d; q += WAVE) {
-            const double xq = x0[q], vq = v0[q];
+            const double xq = x0[q];
+            double vq = v0[q];
+            if (a0) vq = (ia_mode == 2) ? vq * (a0[q] ? 1.0 : 0.0) : (a0[q] ? vq : 0.0);   // :547-549 / :667
             if (BOOMERANG) {                                          // BoomerangSamplers.jl:31
                 o[q] = xq * cs + vq * sn;
                 if (!discard_vt) o[d + q] = (-xq) * sn + vq * cs;
@@ -208,7 +231,7 @@ __global__ __launch_bounds__(256) void from_skeleton_kernel(int d, int64_t C, in
 template <bool BOOMERANG>
 __global__ __launch_bounds__(256) void close_at_kernel(int d, int64_t C, int64_t n_sk, double *X, double *V, double *t, double T,
                                                        int64_t *count, int mode = 0, int target = 0, double rhmc_h = 0.0,
-                                                       const double *tparams = nullptr) {
+                                                       const double *tparams = nullptr, pdmp_diag_t dg = {}) {
     const int lane = lane_id();
     const int64_t c = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (c >= C) return;
@@ -222,10 +245,13 @@ __global__ __launch_bounds__(256) void close_at_kernel(int d, int64_t C, int64_t
     if (T > 0.0 && lo == n_sk - 1 && tc[lo] <= T) {                   // the chain has not provably passed T within this capacity
         if (tc[lo] < T) { if (lane == 0) count[c] = -k - 1; return; }
     }
-    if (T == 0.0 || tc[lo] == T) { if (lane == 0) count[c] = (T == 0.0) ? 1 : k; return; }
+    if (T == 0.0 || tc[lo] == T) { if (lane == 0) count[c] = (T == 0.0) ? 1 : k; return; }   // `while state.t < T` ends on t == T: no closing column
     const double tau = T - tc[lo];
     const double *x0 = X + ((size_t)c * n_sk + (size_t)lo) * d, *v0 = V + ((size_t)c * n_sk + (size_t)lo) * d;
     double *x1 = X + ((size_t)c * n_sk + (size_t)k) * d, *v1 = V + ((size_t)c * n_sk + (size_t)k) * d;
+    // StickyPDMP: v_used = active_prev ? v_prev : 0 (sample.jl:386-390), is_active of the closing column = active_prev (:399-401)
+    const uint8_t *a0 = (mode == 3 && dg.is_active) ? dg.is_active + ((size_t)c * n_sk + (size_t)lo) * d : nullptr;
+    uint8_t *a1 = a0 ? dg.is_active + ((size_t)c * n_sk + (size_t)k) * d : nullptr;
     double sn = 0.0, cs = 1.0;
     if (BOOMERANG) det_sincos(tau, sn, cs);
     if (mode == 2) {                                                                      // RHMC: velocity-Verlet to T
@@ -239,11 +265,81 @@ __global__ __launch_bounds__(256) void close_at_kernel(int d, int64_t C, int64_t
         for (int q = lane; q < d; q += WAVE) { const double vq = v0[q]; x1[q] = (x0[q] - av * vq) + kv * vq; v1[q] = vq; }
     } else
     for (int q = lane; q < d; q += WAVE) {
-        const double xq = x0[q], vq = v0[q];
+        const double xq = x0[q];
+        double vq = v0[q];
+        if (a0) { const uint8_t a = a0[q]; vq = a ? vq : 0.0; a1[q] = a; }
         if (BOOMERANG) { x1[q] = xq * cs + vq * sn; v1[q] = (-xq) * sn + vq * cs; }      // BoomerangSamplers.jl:31
         else { x1[q] = xq + vq * tau; v1[q] = vq; }                                       // ZigZagSamplers.jl:80
     }
-    if (lane == 0) { tc[k] = T; count[c] = k + 1; }
+    if (lane == 0) {
+        tc[k] = T; count[c] = k + 1;
+        // statistics of a non-event point are zeros (:402-408); horizon stays the overshooting state's (record! of the same state object)
+        const size_t e = (size_t)c * n_sk + (size_t)k;
+        if (dg.ar) dg.ar[e] = 0.0;
+        if (dg.errored_bound) dg.errored_bound[e] = 0;
+        if (dg.rejected) dg.rejected[e] = 0;
+        if (dg.hitting_horizon) dg.hitting_horizon[e] = 0;
+        if (dg.error_value_ar) for (int q = 0; q < 5; ++q) dg.error_value_ar[5 * e + q] = 0.0;
+    }
+}
+
+// _trim_history (Composites.jl:198-214) for an ensemble: the ragged histories (count[c] columns of chain c inside a capacity of
+// n_sk columns) packed back to back.  Pass 1 (one block): offsets[c] = exclusive prefix sum of count -- per wave a shuffle scan,
+// the wave totals combined through LDS, a running carry across 1024-chain tiles.  Pass 2: one wave per (chain, 64-column tile)
+// copies the rows (coalesced on both sides).
+__global__ __launch_bounds__(1024) void compact_offsets_kernel(int64_t C, const int64_t *count, int64_t *offsets) {
+    __shared__ int64_t wsum[16];
+    __shared__ int64_t carry_s;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < C; base += 1024) {
+        const int64_t c = base + threadIdx.x;
+        int64_t v = (c < C) ? count[c] : 0;
+        if (v < 0) v = 0;                                             // an unfinished chain (negative count) contributes nothing
+        int64_t inc = v;
+        for (int off = 1; off < WAVE; off <<= 1) {                    // inclusive scan inside the wave
+            const int64_t o = (int64_t)__shfl_up((long long)inc, off, WAVE);
+            if (lane >= off) inc += o;
+        }
+        if (lane == WAVE - 1) wsum[wave] = inc;
+        __syncthreads();
+        int64_t before = carry_s;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (c < C) offsets[c] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offsets[C] = carry_s;
+}
+__global__ __launch_bounds__(256) void compact_rows_kernel(int d, int64_t C, int64_t n_sk, const int64_t *count, const int64_t *offsets,
+                                                           const double *X, const double *V, const double *t, pdmp_diag_t dg,
+                                                           double *Xo, double *Vo, double *to, pdmp_diag_t og) {
+    const int lane = lane_id();
+    const int64_t tiles = (n_sk + WAVE - 1) / WAVE;
+    const int64_t w = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (w >= C * tiles) return;
+    const int64_t c = w / tiles, k0 = (w % tiles) * WAVE;
+    int64_t n = count[c];
+    if (n < 0) n = 0;
+    if (k0 >= n) return;
+    const int64_t nk = (n - k0) < WAVE ? (n - k0) : WAVE;
+    const size_t src = (size_t)c * n_sk + (size_t)k0, dst = (size_t)offsets[c] + (size_t)k0;
+    const size_t words = (size_t)nk * d;
+    for (size_t q = lane; q < words; q += WAVE) { Xo[dst * d + q] = X[src * d + q]; Vo[dst * d + q] = V[src * d + q]; }
+    if (lane < nk) {
+        to[dst + lane] = t[src + lane];
+        if (dg.horizon && og.horizon) og.horizon[dst + lane] = dg.horizon[src + lane];
+        if (dg.ar && og.ar) og.ar[dst + lane] = dg.ar[src + lane];
+        if (dg.errored_bound && og.errored_bound) og.errored_bound[dst + lane] = dg.errored_bound[src + lane];
+        if (dg.rejected && og.rejected) og.rejected[dst + lane] = dg.rejected[src + lane];
+        if (dg.hitting_horizon && og.hitting_horizon) og.hitting_horizon[dst + lane] = dg.hitting_horizon[src + lane];
+    }
+    if (dg.error_value_ar && og.error_value_ar)
+        for (size_t q = lane; q < (size_t)nk * 5; q += WAVE) og.error_value_ar[dst * 5 + q] = dg.error_value_ar[src * 5 + q];
+    if (dg.is_active && og.is_active)
+        for (size_t q = lane; q < words; q += WAVE) og.is_active[dst * d + q] = dg.is_active[src * d + q];
 }
 
 // Fused sample_from_skeleton + moment sums: per chain the sums of x_j and x_j^2 over the N
@@ -253,12 +349,15 @@ __global__ __launch_bounds__(256) void close_at_kernel(int d, int64_t C, int64_t
 template <bool BOOMERANG>
 __global__ __launch_bounds__(256) void moments_kernel(int d, int64_t C, int64_t n_sk, const double *X, const double *V,
                                                       const double *t, int64_t N, double *sum_x, double *sum_x2,
-                                                      int mode = 0, int target = 0, double rhmc_h = 0.0, const double *tparams = nullptr) {
+                                                      int mode = 0, int target = 0, double rhmc_h = 0.0, const double *tparams = nullptr,
+                                                      const uint8_t *IA = nullptr, const int64_t *lens = nullptr) {
     const int lane = lane_id();
     const int64_t c = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (c >= C) return;
     const double *tc = t + (size_t)c * n_sk;
-    const double dt = tc[n_sk - 1] / (double)N;
+    int64_t nh = n_sk;                                                // history columns of this chain (ragged: the time-horizon variant)
+    if (lens) { const int64_t l = lens[c]; nh = (l > 0 && l < nh) ? l : nh; }
+    const double dt = tc[nh - 1] / (double)N;
     const int64_t tiles = (N + WAVE - 1) / WAVE;
     constexpr int M = 4;
     for (int q0 = 0; q0 < d; q0 += M * WAVE) {
@@ -268,7 +367,7 @@ __global__ __launch_bounds__(256) void moments_kernel(int d, int64_t C, int64_t 
         for (int64_t tile = 0; tile < tiles; ++tile) {
             const int64_t j = tile * WAVE + lane + 1;
             const double tm = (double)j * dt;
-            int64_t lo = 0, hi = n_sk - 1;
+            int64_t lo = 0, hi = nh - 1;
             if (j <= N) {
                 while (lo < hi) {
                     const int64_t mid = (lo + hi + 1) >> 1;
@@ -282,6 +381,7 @@ __global__ __launch_bounds__(256) void moments_kernel(int d, int64_t C, int64_t 
                 const int64_t i = ((int64_t)__builtin_amdgcn_readlane(seg_hi, s) << 32) | (uint32_t)__builtin_amdgcn_readlane(seg_lo, s);
                 const double ta = readlane_d(tau, s);
                 const double *x0 = X + ((size_t)c * n_sk + (size_t)i) * d, *v0 = V + ((size_t)c * n_sk + (size_t)i) * d;
+                const uint8_t *a0 = (IA && mode == 3) ? IA + ((size_t)c * n_sk + (size_t)i) * d : nullptr;   // StickyPDMP, sample.jl:547-549
                 double sn = 0.0, cs = 1.0;
                 if (BOOMERANG) det_sincos(ta, sn, cs);
                 double av = 0.0, kv = 0.0, rx[4] = {0, 0, 0, 0}, rv[4];
@@ -291,7 +391,7 @@ __global__ __launch_bounds__(256) void moments_kernel(int d, int64_t C, int64_t 
                 for (int m = 0; m < M; ++m) {
                     const int q = q0 + m * WAVE + lane;
                     if (q < d) {
-                        const double xq = x0[q], vq = v0[q];
+                        const double xq = x0[q], vq = (a0 && !a0[q]) ? 0.0 : v0[q];
                         const double xs = (mode == 1) ? (xq - av * vq) + kv * vq : (mode == 2) ? rx[m]
                                         : BOOMERANG ? xq * cs + vq * sn : xq + vq * ta;
                         s1[m] += xs;
@@ -386,6 +486,7 @@ launch_fn pick_launcher(int sampler, int target) {
         {launch_skeleton<S_BPS, T_GAUSS_ISO>, launch_skeleton<S_BPS, T_GAUSS_DIAG>, launch_skeleton<S_BPS, T_BANANA>},
         {launch_skeleton<S_BOOMERANG, T_GAUSS_ISO>, launch_skeleton<S_BOOMERANG, T_GAUSS_DIAG>, launch_skeleton<S_BOOMERANG, T_BANANA>},
     };
+    if (sampler < 0 || sampler > 2 || target < 0 || target > 2) return nullptr;   // the wave-per-chain kernel serves the three BASELINE samplers only
     return table[sampler][target];
 }
 
@@ -400,6 +501,7 @@ glaunch_fn pick_group_launcher(int sampler, int target) {
         {launch_group<S_RHMC, T_GAUSS_ISO>, launch_group<S_RHMC, T_GAUSS_DIAG>, launch_group<S_RHMC, T_BANANA>, nullptr},
         {launch_group<S_STICKY, T_GAUSS_ISO>, launch_group<S_STICKY, T_GAUSS_DIAG>, launch_group<S_STICKY, T_BANANA>, nullptr},
     };
+    if (sampler < 0 || sampler > 6 || target < 0 || target > 3) return nullptr;
     return table[sampler][target];
 }
 
@@ -460,6 +562,8 @@ int fold_timing(pdmp_engine *h) {
 extern "C" {
 
 int pdmp_abi_version(void) { return PDMP_ABI_VERSION; }
+// for the library's other translation units (multi_device.hip): one thread-local last-error buffer for the whole ABI
+__attribute__((visibility("hidden"))) int pdmp_set_error_message(int code, const char *msg) { return fail(code, "%s", msg); }
 const char *pdmp_last_error(void) { return g_err; }
 int pdmp_device_count(void) {
     int n = 0;
@@ -492,12 +596,18 @@ static int create_impl(const pdmp_config_t *cfg, const char *source, int32_t kin
     h->device = dev;
     h->cfg.target_params = nullptr;
     h->group_lanes = choose_group_lanes(c);
+#define HIP_TRY_H(expr)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) { pdmp_destroy(h); return fail(PDMP_ERR_RUNTIME, "%s: %s", #expr, hipGetErrorString(e_)); } \
+    } while (0)
     if (c.n_target_params > 0 && c.target_params) {
-        HIP_TRY(hipMalloc(&h->d_tparams, (size_t)c.n_target_params * 8));
-        HIP_TRY(hipMemcpy(h->d_tparams, c.target_params, (size_t)c.n_target_params * 8, hipMemcpyHostToDevice));
+        HIP_TRY_H(hipMalloc(&h->d_tparams, (size_t)c.n_target_params * 8));
+        HIP_TRY_H(hipMemcpy(h->d_tparams, c.target_params, (size_t)c.n_target_params * 8, hipMemcpyHostToDevice));
     }
-    HIP_TRY(hipMalloc(&h->d_status, 4 * sizeof(int32_t)));
-    HIP_TRY(hipMemset(h->d_status, 0, 4 * sizeof(int32_t)));
+    HIP_TRY_H(hipMalloc(&h->d_status, 4 * sizeof(int32_t)));
+    HIP_TRY_H(hipMemset(h->d_status, 0, 4 * sizeof(int32_t)));
+#undef HIP_TRY_H
     if (source) {
         if (h->group_lanes <= 0) { pdmp_destroy(h); return fail(PDMP_ERR_UNSUPPORTED, "potentials given as source: dim too large for the LDS tiles"); }
         static thread_local char log[sizeof g_err];
@@ -537,6 +647,9 @@ int pdmp_set_tape(pdmp_handle h, int64_t C, int64_t n_exp, int64_t n_uni, int64_
     if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
     if (C <= 0 || n_exp <= 0 || n_uni <= 0 || n_nrm <= 0 || !exp_tape || !uni_tape || !nrm_tape)
         return fail(PDMP_ERR_ARGUMENT, "pdmp_set_tape needs C > 0 chains and three non-empty tapes");
+    if (h->cfg.sampler > PDMP_BOOMERANG || h->cfg.target_id > PDMP_T_BANANA || h->cfg.grid_size < 2 || h->cfg.dim > 4 * WAVE)
+        return fail(PDMP_ERR_UNSUPPORTED, "tape replay runs on the wave-per-chain kernel: Zig-Zag / BPS / Boomerang on the built-in "
+                                          "separable / banana targets, grid_size >= 2, dim <= %d", 4 * WAVE);
     if (int rc = pdmp_clear_tape(h)) return rc;
     const double *src[3] = {exp_tape, uni_tape, nrm_tape};
     const int64_t n[3] = {n_exp, n_uni, n_nrm};
@@ -560,6 +673,7 @@ int pdmp_destroy(pdmp_handle h) {
     (void)hipSetDevice(h->device);
     (void)fold_timing(h);
     for (auto &ev : h->pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    if (h->order_ev) (void)hipEventDestroy(h->order_ev);
     if (h->d_tparams) (void)hipFree(h->d_tparams);
     if (h->d_status) (void)hipFree(h->d_status);
     if (h->d_sched) (void)hipFree(h->d_sched);
@@ -603,8 +717,9 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
         if (chain_id_offset < 0 || chain_id_offset + C > h->tape_chains)
             return fail(PDMP_ERR_ARGUMENT, "tape holds %lld chains; requested chains [%lld, %lld)", (long long)h->tape_chains,
                         (long long)chain_id_offset, (long long)(chain_id_offset + C));
-        if (c.grid_size < 2 || c.dim > 4 * WAVE || c.target_id == PDMP_T_GAUSS_DENSE)
-            return fail(PDMP_ERR_UNSUPPORTED, "tape replay runs on the wave-per-chain kernel: grid_size >= 2, dim <= %d, no dense target", 4 * WAVE);
+        if (c.grid_size < 2 || c.dim > 4 * WAVE || c.target_id > PDMP_T_BANANA || c.sampler > PDMP_BOOMERANG)
+            return fail(PDMP_ERR_UNSUPPORTED, "tape replay runs on the wave-per-chain kernel: Zig-Zag / BPS / Boomerang, built-in separable / banana "
+                                              "targets, grid_size >= 2, dim <= %d", 4 * WAVE);
         p.tape_exp = h->d_tape[0]; p.tape_uni = h->d_tape[1]; p.tape_nrm = h->d_tape[2];
         p.tape_n_exp = h->tape_n[0]; p.tape_n_uni = h->tape_n[1]; p.tape_n_nrm = h->tape_n[2];
     }
@@ -616,6 +731,12 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
     g_stamps = d_stamps;
 #endif
     hipStream_t s = (hipStream_t)stream;
+    if (h->launched && s != h->last_stream) {       // the scheduler, hand-off and status buffers belong to the handle: a launch on
+        if (!h->order_ev) HIP_TRY(hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming));   // another stream waits for the previous one
+        HIP_TRY(hipEventRecord(h->order_ev, h->last_stream));
+        HIP_TRY(hipStreamWaitEvent(s, h->order_ev, 0));
+    }
+    h->launched = true;
     GroupParams gp;
     memset(&gp, 0, sizeof gp);
     if (h->group_lanes > 0 && !taped) {
@@ -664,13 +785,13 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
             rc = pdmp_dense_batched_run(h->device, c.dim, c.signed_bound, c.adaptive, c.tmax, c.max_iter_per_event, h->d_tparams, C, n_sk,
                                         chain_id_offset, seed, xinit, vinit, X, V, t, p.H, p.AR, p.EB, p.EV, p.RJ, p.HH,
                                         h->d_status, stream, msg, (int)sizeof msg);
-        if (rc != 0) return fail(rc == -4 ? PDMP_ERR_ITERCAP : PDMP_ERR_RUNTIME, "dense batched path: %s", msg);
+        if (rc != 0) { h->pool.push_back(ev); return fail(rc == -4 ? PDMP_ERR_ITERCAP : PDMP_ERR_RUNTIME, "dense batched path: %s", msg); }
         return end_timed(h, s, ev);
     }
     if (c.target_id == PDMP_T_USER) {
-        if (taped || h->group_lanes <= 0 || !h->user_fn) return fail(PDMP_ERR_UNSUPPORTED, "potentials given as source: no tape replay");
+        if (taped || h->group_lanes <= 0 || !h->user_fn) { h->pool.push_back(ev); return fail(PDMP_ERR_UNSUPPORTED, "potentials given as source: no tape replay"); }
         const int e = pdmp_user_launch(h->user_fn, &gp, s);
-        if (e != 0) return fail(PDMP_ERR_RUNTIME, "launching the compiled potential: %s", hipGetErrorString((hipError_t)e));
+        if (e != 0) { h->pool.push_back(ev); return fail(PDMP_ERR_RUNTIME, "launching the compiled potential: %s", hipGetErrorString((hipError_t)e)); }
     } else if (h->group_lanes > 0 && !taped) {
         hipError_t e = hipErrorNotSupported;
         const char *reg = getenv("PDMP_REG");               // PDMP_REG=0: keep x, v in LDS tiles (test hook)
@@ -689,10 +810,18 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
                   : c.sampler == PDMP_BOOMERANG ? launch_group_reg_boomerang(c.target_id, fd, gp, s)
                                                 : hipErrorNotSupported;
         }
-        if (e == hipErrorNotSupported) e = pick_group_launcher(c.sampler, c.target_id)(gp, s);
-        HIP_TRY(e);
+        if (e == hipErrorNotSupported) {
+            const glaunch_fn f = pick_group_launcher(c.sampler, c.target_id);
+            if (!f) { h->pool.push_back(ev); return fail(PDMP_ERR_UNSUPPORTED, "no group kernel for sampler %d on target %d", c.sampler, c.target_id); }
+            e = f(gp, s);
+        }
+        if (e != hipSuccess) { h->pool.push_back(ev); return fail(PDMP_ERR_RUNTIME, "group kernel launch: %s", hipGetErrorString(e)); }
+    } else {
+        const launch_fn f = pick_launcher(c.sampler, c.target_id);
+        if (!f) { h->pool.push_back(ev); return fail(PDMP_ERR_UNSUPPORTED, "the wave-per-chain kernel serves Zig-Zag / BPS / Boomerang on the built-in separable / banana targets"); }
+        const hipError_t e = f(p, s);
+        if (e != hipSuccess) { h->pool.push_back(ev); return fail(PDMP_ERR_RUNTIME, "wave kernel launch: %s", hipGetErrorString(e)); }
     }
-    else HIP_TRY(pick_launcher(c.sampler, c.target_id)(p, s));
     return end_timed(h, s, ev);
 }
 
@@ -769,45 +898,65 @@ int pdmp_sample_skeleton(pdmp_handle h, int64_t C, int64_t n_sk, int64_t chain_i
     return rc;
 }
 
-int pdmp_sample_from_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
-                                     const double *t, int64_t N, int32_t discard_vt, double *out, void *stream) {
-    return pdmp_sample_from_skeleton_dt_device(h, C, n_sk, X, V, t, N, 0.0, discard_vt, out, stream);
-}
-
-int pdmp_sample_from_skeleton_dt_device(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
-                                        const double *t, int64_t N, double dt, int32_t discard_vt, double *out, void *stream) {
+// ---- sample_from_skeleton: one launcher behind the three reference methods
+// method 0: N::Int (sample.jl:475-513 / StickyPDMP :516-561); 1: dt::Float64 (:573-646); 2: (N::Int, dt::Float64) (:649-682)
+static int from_skeleton_launch(pdmp_handle h, int method, int64_t C, int64_t n_sk, const double *X, const double *V, const double *t,
+                                const uint8_t *is_active, const int64_t *lens, int64_t n_prefix, int64_t N, double dt, int32_t discard_vt,
+                                double *out, int64_t *counts, void *stream) {
     if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
     if (h->cfg.sampler == PDMP_RHMC && (h->cfg.dim > 4 * WAVE || h->cfg.target_id > PDMP_T_BANANA))
         return fail(PDMP_ERR_UNSUPPORTED, "RHMC: sample_from_skeleton integrates the flow with up to 4 coordinates per lane (dim <= 256) on the built-in targets");
-    if (!(dt >= 0.0) || !std::isfinite(dt)) return fail(PDMP_ERR_ARGUMENT, "dt must be finite and non-negative");
+    if (method == 0 && dt != 0.0) return fail(PDMP_ERR_ARGUMENT, "the N::Int method takes no dt");
+    if (method != 0 && (!(dt > 0.0) || !std::isfinite(dt))) return fail(PDMP_ERR_ARGUMENT, "dt must be finite and positive. Current value: %g", dt);
     if (N <= 0) return fail(PDMP_ERR_ARGUMENT, "N must be positive. Current value: %lld", (long long)N);   // sample.jl:476-478
     if (n_sk <= 0) return fail(PDMP_ERR_ARGUMENT, "empty history");
+    if (method == 2 && (n_prefix <= 0 || n_prefix > n_sk)) return fail(PDMP_ERR_ARGUMENT, "the (N, dt) method needs 1 <= N <= length(history). Current value: %lld", (long long)n_prefix);
     if (C < 0) return fail(PDMP_ERR_ARGUMENT, "number of chains must be non-negative");
     if (C == 0) return PDMP_OK;
     if (!X || !V || !t || !out) return fail(PDMP_ERR_ARGUMENT, "null buffer");
+    if (h->cfg.sampler == PDMP_STICKY && !is_active)                                                         // StickyPDMP methods read history.is_active
+        return fail(PDMP_ERR_ARGUMENT, "StickyZigZag: sample_from_skeleton needs PDMPHistory.is_active (sample.jl:516-561)");
     HIP_TRY(hipSetDevice(h->device));
     const int64_t tiles = (N + WAVE - 1) / WAVE, waves = C * tiles, blocks = (waves + 3) / 4;
     if (blocks > 0x7fffffffLL) return fail(PDMP_ERR_UNSUPPORTED, "too many samples for one launch");
+    // is_active is consulted by the StickyPDMP methods (select) and by the (N, dt) method of every sampler (v .* active, :667)
+    const int ia_mode = !is_active ? 0 : (method == 2 ? 2 : (h->cfg.sampler == PDMP_STICKY ? 1 : 0));
     hipStream_t s = (hipStream_t)stream;
     EventPair ev;
     if (int rc = begin_timed(h, s, ev)) return rc;
     if (h->cfg.sampler == PDMP_BOOMERANG)
-        hipLaunchKernelGGL(from_skeleton_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, dt, (int)discard_vt, out, 0);
+        hipLaunchKernelGGL(from_skeleton_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, dt, (int)discard_vt, out, 0,
+                           -1, 0.0, (const double *)nullptr, is_active, ia_mode, (int)(method == 2), n_prefix, lens, counts);
     else
         hipLaunchKernelGGL(from_skeleton_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, dt, (int)discard_vt, out,
                            (int)(h->cfg.sampler == PDMP_SUZZ), h->cfg.sampler == PDMP_RHMC ? h->cfg.target_id : -1, h->cfg.rh_step_size,
-                           (const double *)h->d_tparams);
-    HIP_TRY(hipGetLastError());
+                           (const double *)h->d_tparams, is_active, ia_mode, (int)(method == 2), n_prefix, lens, counts);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) { h->pool.push_back(ev); return fail(PDMP_ERR_RUNTIME, "from_skeleton_kernel: %s", hipGetErrorString(e)); }
     return end_timed(h, s, ev);
 }
 
-int pdmp_sample_from_skeleton(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
-                              const double *t, int64_t N, int32_t discard_vt, double *out) {
-    return pdmp_sample_from_skeleton_dt(h, C, n_sk, X, V, t, N, 0.0, discard_vt, out);
+int pdmp_sample_from_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
+                                     const double *t, const uint8_t *is_active, const int64_t *lens, int64_t N, int32_t discard_vt,
+                                     double *out, void *stream) {
+    return from_skeleton_launch(h, 0, C, n_sk, X, V, t, is_active, lens, 0, N, 0.0, discard_vt, out, nullptr, stream);
 }
 
-int pdmp_sample_from_skeleton_dt(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
-                                 const double *t, int64_t N, double dt, int32_t discard_vt, double *out) {
+int pdmp_sample_from_skeleton_dt_device(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
+                                        const double *t, const uint8_t *is_active, const int64_t *lens, int64_t N, double dt,
+                                        int32_t discard_vt, double *out, int64_t *counts, void *stream) {
+    return from_skeleton_launch(h, 1, C, n_sk, X, V, t, is_active, lens, 0, N, dt, discard_vt, out, counts, stream);
+}
+
+int pdmp_sample_from_skeleton_prefix_device(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
+                                            const double *t, const uint8_t *is_active, int64_t n_prefix, double dt, int64_t M,
+                                            int32_t discard_vt, double *out, int64_t *counts, void *stream) {
+    return from_skeleton_launch(h, 2, C, n_sk, X, V, t, is_active, nullptr, n_prefix, M, dt, discard_vt, out, counts, stream);
+}
+
+// host-pointer forms: stage the history on the device, run the device form, copy the samples back
+static int from_skeleton_host(pdmp_handle h, int method, int64_t C, int64_t n_sk, const double *X, const double *V, const double *t,
+                              const uint8_t *is_active, int64_t n_prefix, int64_t N, double dt, int32_t discard_vt, double *out,
+                              int64_t *counts) {
     if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
     if (N <= 0) return fail(PDMP_ERR_ARGUMENT, "N must be positive. Current value: %lld", (long long)N);
     if (n_sk <= 0) return fail(PDMP_ERR_ARGUMENT, "empty history");
@@ -817,7 +966,9 @@ int pdmp_sample_from_skeleton_dt(pdmp_handle h, int64_t C, int64_t n_sk, const d
     const size_t d = (size_t)h->cfg.dim, ne = (size_t)C * (size_t)n_sk;
     const size_t rows = discard_vt ? d : 2 * d + 1, no = (size_t)C * (size_t)N * rows;
     double *dX = nullptr, *dV = nullptr, *dt_buf = nullptr, *dout = nullptr;
-    auto cleanup = [&]() { (void)hipFree(dX); (void)hipFree(dV); (void)hipFree(dt_buf); (void)hipFree(dout); };
+    uint8_t *dIA = nullptr;
+    int64_t *dcnt = nullptr;
+    auto cleanup = [&]() { (void)hipFree(dX); (void)hipFree(dV); (void)hipFree(dt_buf); (void)hipFree(dout); (void)hipFree(dIA); (void)hipFree(dcnt); };
     TRY_OR_CLEAN(hipMalloc(&dX, ne * d * 8));
     TRY_OR_CLEAN(hipMalloc(&dV, ne * d * 8));
     TRY_OR_CLEAN(hipMalloc(&dt_buf, ne * 8));
@@ -825,14 +976,37 @@ int pdmp_sample_from_skeleton_dt(pdmp_handle h, int64_t C, int64_t n_sk, const d
     TRY_OR_CLEAN(hipMemcpy(dX, X, ne * d * 8, hipMemcpyHostToDevice));
     TRY_OR_CLEAN(hipMemcpy(dV, V, ne * d * 8, hipMemcpyHostToDevice));
     TRY_OR_CLEAN(hipMemcpy(dt_buf, t, ne * 8, hipMemcpyHostToDevice));
-    int rc = pdmp_sample_from_skeleton_dt_device(h, C, n_sk, dX, dV, dt_buf, N, dt, discard_vt, dout, nullptr);
+    if (is_active) { TRY_OR_CLEAN(hipMalloc(&dIA, ne * d)); TRY_OR_CLEAN(hipMemcpy(dIA, is_active, ne * d, hipMemcpyHostToDevice)); }
+    if (counts) {
+        TRY_OR_CLEAN(hipMalloc(&dcnt, (size_t)C * 8));
+        TRY_OR_CLEAN(hipMemset(dout, 0, no * 8));                    // columns beyond a chain's count stay zero
+    }
+    int rc = from_skeleton_launch(h, method, C, n_sk, dX, dV, dt_buf, dIA, nullptr, n_prefix, N, dt, discard_vt, dout, dcnt, nullptr);
     if (rc == PDMP_OK) TRY_OR_CLEAN(hipMemcpy(out, dout, no * 8, hipMemcpyDeviceToHost));
+    if (rc == PDMP_OK && counts) TRY_OR_CLEAN(hipMemcpy(counts, dcnt, (size_t)C * 8, hipMemcpyDeviceToHost));
     cleanup();
     return rc;
 }
 
-int pdmp_close_at_time_device(pdmp_handle h, int64_t C, int64_t n_sk, double *X, double *V, double *t, double T,
-                              int64_t *count, void *stream) {
+int pdmp_sample_from_skeleton(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
+                              const double *t, const uint8_t *is_active, int64_t N, int32_t discard_vt, double *out) {
+    return from_skeleton_host(h, 0, C, n_sk, X, V, t, is_active, 0, N, 0.0, discard_vt, out, nullptr);
+}
+
+int pdmp_sample_from_skeleton_dt(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
+                                 const double *t, const uint8_t *is_active, int64_t N, double dt, int32_t discard_vt, double *out,
+                                 int64_t *counts) {
+    return from_skeleton_host(h, 1, C, n_sk, X, V, t, is_active, 0, N, dt, discard_vt, out, counts);
+}
+
+int pdmp_sample_from_skeleton_prefix(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V,
+                                     const double *t, const uint8_t *is_active, int64_t n_prefix, double dt, int64_t M,
+                                     int32_t discard_vt, double *out, int64_t *counts) {
+    return from_skeleton_host(h, 2, C, n_sk, X, V, t, is_active, n_prefix, M, dt, discard_vt, out, counts);
+}
+
+int pdmp_close_at_time_device(pdmp_handle h, int64_t C, int64_t n_sk, double *X, double *V, double *t, const pdmp_diag_t *diag,
+                              double T, int64_t *count, void *stream) {
     if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
     if (h->cfg.sampler == PDMP_RHMC && (h->cfg.dim > 4 * WAVE || h->cfg.target_id > PDMP_T_BANANA))
         return fail(PDMP_ERR_UNSUPPORTED, "RHMC: the flow is integrated with up to 4 coordinates per lane (dim <= 256) on the built-in targets");
@@ -840,22 +1014,57 @@ int pdmp_close_at_time_device(pdmp_handle h, int64_t C, int64_t n_sk, double *X,
     if (n_sk <= 0 || C < 0) return fail(PDMP_ERR_ARGUMENT, "n_sk must be positive and C non-negative");
     if (C == 0) return PDMP_OK;
     if (!X || !V || !t || !count) return fail(PDMP_ERR_ARGUMENT, "null buffer");
+    if (h->cfg.sampler == PDMP_STICKY && !(diag && diag->is_active))
+        return fail(PDMP_ERR_ARGUMENT, "StickyZigZag: the closing point needs PDMPHistory.is_active (sample.jl:386-392)");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     const dim3 block(256), grid((unsigned)((C + 3) / 4));
+    pdmp_diag_t dg = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (diag) dg = *diag;
     if (h->cfg.sampler == PDMP_BOOMERANG)
-        hipLaunchKernelGGL(close_at_kernel<true>, grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, T, count, 0, 0, 0.0, (const double *)nullptr);
+        hipLaunchKernelGGL(close_at_kernel<true>, grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, T, count, 0, 0, 0.0, (const double *)nullptr, dg);
     else
         hipLaunchKernelGGL(close_at_kernel<false>, grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, T, count,
-                           h->cfg.sampler == PDMP_SUZZ ? 1 : (h->cfg.sampler == PDMP_RHMC ? 2 : 0), h->cfg.target_id, h->cfg.rh_step_size,
-                           (const double *)h->d_tparams);
+                           h->cfg.sampler == PDMP_SUZZ ? 1 : (h->cfg.sampler == PDMP_RHMC ? 2 : (h->cfg.sampler == PDMP_STICKY ? 3 : 0)),
+                           h->cfg.target_id, h->cfg.rh_step_size, (const double *)h->d_tparams, dg);
     HIP_TRY(hipGetLastError());
     h->last_stream = s;
     return PDMP_OK;
 }
 
+int pdmp_compact_offsets_device(pdmp_handle h, int64_t C, const int64_t *count, int64_t *offsets, void *stream) {
+    if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
+    if (C < 0) return fail(PDMP_ERR_ARGUMENT, "number of chains must be non-negative");
+    if (!count || !offsets) return fail(PDMP_ERR_ARGUMENT, "null buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    hipLaunchKernelGGL(compact_offsets_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, C, count, offsets);
+    HIP_TRY(hipGetLastError());
+    h->last_stream = (hipStream_t)stream;
+    return PDMP_OK;
+}
+
+int pdmp_compact_history_device(pdmp_handle h, int64_t C, int64_t n_sk, const int64_t *count, const int64_t *offsets,
+                                const double *X, const double *V, const double *t, const pdmp_diag_t *diag,
+                                double *X_out, double *V_out, double *t_out, const pdmp_diag_t *diag_out, void *stream) {
+    if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
+    if (n_sk <= 0 || C < 0) return fail(PDMP_ERR_ARGUMENT, "n_sk must be positive and C non-negative");
+    if (C == 0) return PDMP_OK;
+    if (!count || !offsets || !X || !V || !t || !X_out || !V_out || !t_out) return fail(PDMP_ERR_ARGUMENT, "null buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    const int64_t tiles = (n_sk + WAVE - 1) / WAVE, blocks = (C * tiles + 3) / 4;
+    if (blocks > 0x7fffffffLL) return fail(PDMP_ERR_UNSUPPORTED, "too many columns for one launch");
+    pdmp_diag_t dg = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, og = dg;
+    if (diag && diag_out) { dg = *diag; og = *diag_out; }
+    hipStream_t s = (hipStream_t)stream;
+    EventPair ev;
+    if (int rc = begin_timed(h, s, ev)) return rc;
+    hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, count, offsets, X, V, t, dg, X_out, V_out, t_out, og);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) { h->pool.push_back(ev); return fail(PDMP_ERR_RUNTIME, "compact_rows_kernel: %s", hipGetErrorString(e)); }
+    return end_timed(h, s, ev);
+}
+
 int pdmp_sample_moments_device(pdmp_handle h, int64_t C, int64_t n_sk, const double *X, const double *V, const double *t,
-                               int64_t N, double *sum_x, double *sum_x2, void *stream) {
+                               const uint8_t *is_active, const int64_t *lens, int64_t N, double *sum_x, double *sum_x2, void *stream) {
     if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
     if (h->cfg.sampler == PDMP_RHMC && (h->cfg.dim > 4 * WAVE || h->cfg.target_id > PDMP_T_BANANA))
         return fail(PDMP_ERR_UNSUPPORTED, "RHMC: the flow is integrated with up to 4 coordinates per lane (dim <= 256) on the built-in targets");
@@ -864,6 +1073,8 @@ int pdmp_sample_moments_device(pdmp_handle h, int64_t C, int64_t n_sk, const dou
     if (C < 0) return fail(PDMP_ERR_ARGUMENT, "number of chains must be non-negative");
     if (C == 0) return PDMP_OK;
     if (!X || !V || !t || !sum_x || !sum_x2) return fail(PDMP_ERR_ARGUMENT, "null buffer");
+    if (h->cfg.sampler == PDMP_STICKY && !is_active)
+        return fail(PDMP_ERR_ARGUMENT, "StickyZigZag: the samples need PDMPHistory.is_active (sample.jl:516-561)");
     if ((C + 3) / 4 > 0x7fffffffLL) return fail(PDMP_ERR_UNSUPPORTED, "too many chains for one launch");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
@@ -871,12 +1082,13 @@ int pdmp_sample_moments_device(pdmp_handle h, int64_t C, int64_t n_sk, const dou
     if (int rc = begin_timed(h, s, ev)) return rc;
     const dim3 grid((unsigned)((C + 3) / 4)), block(256);
     if (h->cfg.sampler == PDMP_BOOMERANG)
-        hipLaunchKernelGGL(moments_kernel<true>, grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, N, sum_x, sum_x2, 0, 0, 0.0, (const double *)nullptr);
+        hipLaunchKernelGGL(moments_kernel<true>, grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, N, sum_x, sum_x2, 0, 0, 0.0, (const double *)nullptr,
+                           (const uint8_t *)nullptr, lens);
     else
         hipLaunchKernelGGL(moments_kernel<false>, grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, N, sum_x, sum_x2,
-                           h->cfg.sampler == PDMP_SUZZ ? 1 : (h->cfg.sampler == PDMP_RHMC ? 2 : 0), h->cfg.target_id, h->cfg.rh_step_size,
-                           (const double *)h->d_tparams);
-    HIP_TRY(hipGetLastError());
+                           h->cfg.sampler == PDMP_SUZZ ? 1 : (h->cfg.sampler == PDMP_RHMC ? 2 : (h->cfg.sampler == PDMP_STICKY ? 3 : 0)),
+                           h->cfg.target_id, h->cfg.rh_step_size, (const double *)h->d_tparams, is_active, lens);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) { h->pool.push_back(ev); return fail(PDMP_ERR_RUNTIME, "moments_kernel: %s", hipGetErrorString(e)); }
     return end_timed(h, s, ev);
 }
 

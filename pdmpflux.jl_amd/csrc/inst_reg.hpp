@@ -23,7 +23,7 @@ static hipError_t reg_by_lanes(const GroupParams &gp, hipStream_t stream) {
 
 template <int S>
 static hipError_t reg_by_target(int target, bool fd, const GroupParams &gp, hipStream_t stream) {
-    if (gp.K > KREG || (gp.G >= 2 && gp.K < (KREG + 1) / 2)) return hipErrorNotSupported;   // (forced lane counts only: the LDS form serves them)
+    if (gp.K > KREG || (gp.G >= 2 && gp.K < (KREG + 1) / 2)) return hipErrorNotSupported;   // (the exact-K kernels or the LDS form serve them)
     switch (target) {
     case T_GAUSS_ISO: return fd ? reg_by_lanes<S, T_GAUSS_ISO, true>(gp, stream) : reg_by_lanes<S, T_GAUSS_ISO, false>(gp, stream);
     case T_GAUSS_DIAG: return fd ? reg_by_lanes<S, T_GAUSS_DIAG, true>(gp, stream) : reg_by_lanes<S, T_GAUSS_DIAG, false>(gp, stream);
@@ -46,11 +46,24 @@ static hipError_t exact_by_lanes(const GroupParams &gp, hipStream_t stream) {
     default: return hipErrorNotSupported;
     }
 }
-// HALF splits the instantiations over two translation units per (sampler, slope mode): 0 = K <= 8, 1 = K >= 9 (build time)
+// HALF splits the instantiations over translation units per (sampler, slope mode): 0 = K <= 8, 1 = K >= 9 (build time);
+// 2 = K = 2..6 with G >= 2 lanes per chain -- the layouts the occupancy rule picks when a launch has too few chains to fill the
+// machine at the default G (pdmp_suggest_group_lanes: d = 50 on a 12 500-chain shard runs G = 16, K = 4)
 template <int S, int T, bool FD, int HALF>
 static hipError_t exact_by_slots(const GroupParams &gp, hipStream_t stream) {
     static_assert(KREG == 13, "one case per K below");
-    if (gp.K < 7 && gp.G != 1) return hipErrorNotSupported;     // K < 7 only arises with one lane per chain (d <= 6)
+    if constexpr (HALF == 2) {
+        if (gp.G < 2) return hipErrorNotSupported;
+        switch (gp.K) {
+        case 2: return exact_by_lanes<S, T, FD, 2>(gp, stream);
+        case 3: return exact_by_lanes<S, T, FD, 3>(gp, stream);
+        case 4: return exact_by_lanes<S, T, FD, 4>(gp, stream);
+        case 5: return exact_by_lanes<S, T, FD, 5>(gp, stream);
+        case 6: return exact_by_lanes<S, T, FD, 6>(gp, stream);
+        default: return hipErrorNotSupported;
+        }
+    } else
+    if (gp.K < 7 && gp.G != 1) return hipErrorNotSupported;     // (K < 7 with G >= 2: HALF 2, where that translation unit exists)
     if constexpr (HALF == 0) {
         switch (gp.K) {
         case 2: return launch_group_impl<S, T, FD, 2, 1, true>(gp, stream);

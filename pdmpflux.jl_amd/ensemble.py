@@ -29,8 +29,8 @@ def _stream_ptr(stream):
 
 def _need_cuda(*ts):
     for t in ts:
-        if t is not None and (not t.is_cuda or t.dtype not in (torch.float64, torch.int32) or not t.is_contiguous()):
-            raise ArgumentError("device entry points need contiguous float64/int32 CUDA tensors "
+        if t is not None and (not t.is_cuda or t.dtype not in (torch.float64, torch.int32, torch.int64, torch.uint8) or not t.is_contiguous()):
+            raise ArgumentError("device entry points need contiguous float64 / int32 / int64 / uint8 CUDA tensors "
                                 "(the engine has no CPU fallback)")
 
 
@@ -61,7 +61,11 @@ def sample_skeleton_device(sampler: AbstractPDMP, n_sk: int, xinit: torch.Tensor
                          buf("errored_bound", (Cn, n_sk), torch.int32).data_ptr(),
                          buf("error_value_ar", (Cn, n_sk, 5)).data_ptr(),
                          buf("rejected", (Cn, n_sk), torch.int32).data_ptr(),
-                         buf("hitting_horizon", (Cn, n_sk), torch.int32).data_ptr())
+                         buf("hitting_horizon", (Cn, n_sk), torch.int32).data_ptr(), None)
+    if sampler.sampler_id == 6:                              # StickyZigZag: PDMPHistory.is_active (Composites.jl:142,256)
+        if diag is None:
+            diag = _lib.Diag(None, None, None, None, None, None, None)
+        diag.is_active = buf("is_active", (Cn, n_sk, d), torch.uint8).data_ptr()
     L = _lib.lib()
     with torch.cuda.device(dev):
         _lib.check(L.pdmp_sample_skeleton_device(sampler.handle(), Cn, int(n_sk), int(chain_id_offset), _ptr(xinit),
@@ -72,12 +76,22 @@ def sample_skeleton_device(sampler: AbstractPDMP, n_sk: int, xinit: torch.Tensor
     return o
 
 
+def _diag_of(out: dict):
+    """pdmp_diag_t over whichever diagnostic tensors ``out`` holds (None when it holds none)."""
+    keys = ("horizon", "ar", "errored_bound", "error_value_ar", "rejected", "hitting_horizon", "is_active")
+    if not any(k in out for k in keys):
+        return None
+    return _lib.Diag(*[out[k].data_ptr() if k in out else None for k in keys])
+
+
 def sample_from_skeleton_device(sampler: AbstractPDMP, N: int, X: torch.Tensor, V: torch.Tensor, t: torch.Tensor, *,
-                                discard_vt: bool = True, out: torch.Tensor | None = None, stream=None):
-    """pdmp_sample_from_skeleton_device: returns ``(C, N, rows)`` on the device."""
+                                discard_vt: bool = True, out: torch.Tensor | None = None, stream=None,
+                                is_active: torch.Tensor | None = None, lens: torch.Tensor | None = None):
+    """pdmp_sample_from_skeleton_device: returns ``(C, N, rows)`` on the device.  ``is_active`` (uint8, like X): required for
+    StickyZigZag (sample.jl:516-561); ``lens`` (int64, (C,)): ragged history lengths of the time-horizon variant."""
     if N <= 0:
         raise ArgumentError(f"N must be positive. Current value: {N}")
-    _need_cuda(X, V, t)
+    _need_cuda(X, V, t, is_active, lens)
     Cn, n_sk, d = X.shape
     if d != sampler.dim or V.shape != X.shape or tuple(t.shape) != (Cn, n_sk):
         raise DimensionMismatch("history tensors do not match the sampler dimension")
@@ -87,36 +101,66 @@ def sample_from_skeleton_device(sampler: AbstractPDMP, N: int, X: torch.Tensor, 
     _need_cuda(out)
     with torch.cuda.device(X.device):
         _lib.check(_lib.lib().pdmp_sample_from_skeleton_device(sampler.handle(), Cn, n_sk, _ptr(X), _ptr(V), _ptr(t),
-                                                               int(N), int(bool(discard_vt)), _ptr(out),
-                                                               _stream_ptr(stream)))
+                                                               _ptr(is_active), _ptr(lens), int(N), int(bool(discard_vt)),
+                                                               _ptr(out), _stream_ptr(stream)))
     return out
 
 
-def sample_moments_device(sampler: AbstractPDMP, N: int, X: torch.Tensor, V: torch.Tensor, t: torch.Tensor, *, stream=None):
+def sample_moments_device(sampler: AbstractPDMP, N: int, X: torch.Tensor, V: torch.Tensor, t: torch.Tensor, *, stream=None,
+                          is_active: torch.Tensor | None = None, lens: torch.Tensor | None = None):
     """pdmp_sample_moments_device: per-chain sums of x and x^2 over the N samples sample_from_skeleton would
     return (never materialised).  Returns (sum_x, sum_x2), each ``(C, d)`` on the device."""
     if N <= 0:
         raise ArgumentError(f"N must be positive. Current value: {N}")
-    _need_cuda(X, V, t)
+    _need_cuda(X, V, t, is_active, lens)
     Cn, n_sk, d = X.shape
     if d != sampler.dim or V.shape != X.shape or tuple(t.shape) != (Cn, n_sk):
         raise DimensionMismatch("history tensors do not match the sampler dimension")
     s1 = torch.empty((Cn, d), dtype=torch.float64, device=X.device)
     s2 = torch.empty((Cn, d), dtype=torch.float64, device=X.device)
     with torch.cuda.device(X.device):
-        _lib.check(_lib.lib().pdmp_sample_moments_device(sampler.handle(), Cn, n_sk, _ptr(X), _ptr(V), _ptr(t), int(N),
-                                                         _ptr(s1), _ptr(s2), _stream_ptr(stream)))
+        _lib.check(_lib.lib().pdmp_sample_moments_device(sampler.handle(), Cn, n_sk, _ptr(X), _ptr(V), _ptr(t), _ptr(is_active),
+                                                         _ptr(lens), int(N), _ptr(s1), _ptr(s2), _stream_ptr(stream)))
     return s1, s2
+
+
+def compact_history_device(sampler: AbstractPDMP, out: dict, count: torch.Tensor, *, stream=None) -> dict:
+    """``_trim_history`` (Composites.jl:198-214) for an ensemble on the device: the ragged histories ``[0, count[c])`` of ``out``
+    (tensors shaped ``(C, n_sk, ...)``) packed back to back.  Returns ``offsets`` ``(C+1,)`` int64 (wave prefix scan,
+    pdmp_compact_offsets_device) and dense tensors ``X, V (total, d)``, ``t (total,)`` + the diagnostics ``out`` holds."""
+    _need_cuda(count)
+    Cn, n_sk, d = out["X"].shape
+    dev = out["X"].device
+    L = _lib.lib()
+    offsets = torch.empty((Cn + 1,), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.pdmp_compact_offsets_device(sampler.handle(), Cn, _ptr(count), _ptr(offsets), _stream_ptr(stream)))
+        total = int(offsets[-1].item())
+        res = {"offsets": offsets, "count": count,
+               "X": torch.empty((total, d), dtype=torch.float64, device=dev), "V": torch.empty((total, d), dtype=torch.float64, device=dev),
+               "t": torch.empty((total,), dtype=torch.float64, device=dev)}
+        for k, shape in (("horizon", (total,)), ("ar", (total,)), ("errored_bound", (total,)), ("error_value_ar", (total, 5)),
+                         ("rejected", (total,)), ("hitting_horizon", (total,)), ("is_active", (total, d))):
+            if k in out:
+                res[k] = torch.empty(shape, dtype=out[k].dtype, device=dev)
+        din, dout = _diag_of(out), _diag_of(res)
+        _lib.check(L.pdmp_compact_history_device(sampler.handle(), Cn, n_sk, _ptr(count), _ptr(offsets), _ptr(out["X"]), _ptr(out["V"]),
+                                                 _ptr(out["t"]), C.byref(din) if din is not None else None, _ptr(res["X"]),
+                                                 _ptr(res["V"]), _ptr(res["t"]), C.byref(dout) if dout is not None else None,
+                                                 _stream_ptr(stream)))
+    return res
 
 
 def sample_skeleton_until_device(sampler: AbstractPDMP, T: float, xinit: torch.Tensor, vinit: torch.Tensor, *, seed=None,
                                  chain_id_offset: int = 0, diagnostics: bool = False, init_capacity: int = 1024,
-                                 stream=None) -> dict:
+                                 stream=None, compact: bool = False) -> dict:
     """Time-horizon variant ``sample_skeleton(sampler, T::Float64, xinit, vinit)`` (src/sample.jl:323-439) for an ensemble
     held on the device: the fixed-count kernel runs with a capacity that doubles (``_grow_history``, Composites.jl:172-191)
     until every chain has passed ``T``; ``pdmp_close_at_time_device`` then writes each chain's closing column at ``t == T``
-    in place (:385-420) and returns the ragged lengths.  Returns the skeleton tensors plus ``count`` ``(C,)`` int64: chain c's
-    history is columns ``[0, count[c])``; columns beyond are the discarded overshoot."""
+    in place (:385-420; the sampler's own flow, the Sticky mask :386-392, zeroed statistics :402-408) and returns the ragged
+    lengths.  Returns the skeleton tensors plus ``count`` ``(C,)`` int64: chain c's history is columns ``[0, count[c])``;
+    columns beyond are the discarded overshoot.  ``compact=True``: the histories trimmed and packed back to back instead
+    (``compact_history_device``: dense ``(total, ...)`` tensors + ``offsets``)."""
     import math
     T = float(T)
     if not math.isfinite(T) or T < 0:
@@ -128,22 +172,16 @@ def sample_skeleton_until_device(sampler: AbstractPDMP, T: float, xinit: torch.T
                                      diagnostics=diagnostics, stream=stream)
         Cn = xinit.shape[0]
         count = torch.empty((Cn,), dtype=torch.int64, device=xinit.device)
+        dg = _diag_of(out)
         with torch.cuda.device(xinit.device):
             _lib.check(_lib.lib().pdmp_close_at_time_device(sampler.handle(), Cn, cap, _ptr(out["X"]), _ptr(out["V"]), _ptr(out["t"]),
-                                                            C.c_double(T), C.c_void_p(count.data_ptr()), _stream_ptr(stream)))
+                                                            C.byref(dg) if dg is not None else None, C.c_double(T),
+                                                            C.c_void_p(count.data_ptr()), _stream_ptr(stream)))
         if bool((count > 0).all()):
             break
         cap *= 2                                                                          # newcap = 2 * size, :375-377
-    if diagnostics:                                     # statistics of the closing column are those of a non-event point (:402-408)
-        closed = out["t"].gather(1, (count - 1).unsqueeze(1)).squeeze(1) == T
-        prev_t = out["t"].gather(1, (count - 2).clamp(min=0).unsqueeze(1)).squeeze(1)
-        closed &= (count >= 2) & (prev_t < T)
-        idx = (count - 1)[closed]
-        rows = torch.nonzero(closed).squeeze(1)
-        out["ar"][rows, idx] = 0.0
-        for key in ("errored_bound", "rejected", "hitting_horizon"):
-            out[key][rows, idx] = 0
-        out["error_value_ar"][rows, idx] = 0.0
+    if compact:
+        return compact_history_device(sampler, out, count, stream=stream)
     out["count"] = count
     return out
 
@@ -223,12 +261,13 @@ def sample_skeleton_sharded(sampler: AbstractPDMP, n_sk: int, xinit: torch.Tenso
         raise ArgumentError(f"N must be positive. Current value: {N_samples}")
     if gather == "moments" and compute is None:
         # fused on the device: the d x N x C samples are never written (pdmp_sample_moments_device)
-        s1, s2 = sample_moments_device(sampler, N_samples, res["X"], res["V"], res["t"])
+        s1, s2 = sample_moments_device(sampler, N_samples, res["X"], res["V"], res["t"], is_active=res.get("is_active"))
         d = s1.shape[-1]
         m = torch.cat([s1.sum(0), s2.sum(0), s1.new_tensor([float(s1.shape[0] * N_samples)])])
         smp = None
     else:
-        smp = sample_from_skeleton_device(sampler, N_samples, res["X"], res["V"], res["t"]) if compute is None else res["samples"]
+        smp = (sample_from_skeleton_device(sampler, N_samples, res["X"], res["V"], res["t"], is_active=res.get("is_active"))
+               if compute is None else res["samples"])
     if gather == "samples":
         res["samples"] = _all_gather_rows(smp, C_total, world, group) if world > 1 else smp
         return res

@@ -76,51 +76,36 @@ def sample_skeleton_ensemble(sampler: AbstractPDMP, n_sk: int, xinit, vinit, *, 
     return out
 
 
-def _flow_host(sampler: AbstractPDMP, x, v, tau):
-    """Deterministic flow of one state on the host (ZigZagSamplers.jl:80, BouncyParticleSamplers.jl:32,
-    BoomerangSamplers.jl:31) -- only used for the single closing point of the time-horizon variant."""
-    if sampler.sampler_id == 2:
-        c, s_ = math.cos(tau), math.sin(tau)
-        return x * c + v * s_, (-x) * s_ + v * c
-    return x + v * tau, v.copy()
-
-
 def sample_skeleton_until(sampler: AbstractPDMP, T: float, xinit, vinit, *, seed=None, verbose: bool = True,
                           init_capacity: int = 1024):
     """Time-horizon variant ``sample_skeleton(sampler, T::Float64, xinit, vinit; seed, init_capacity)``
     (src/sample.jl:323-439): advance every chain to time ``T``; the history ends with one closing point at
-    exactly ``t == T`` obtained by deterministic flow from the last event before ``T`` (:385-420).
+    exactly ``t == T`` obtained by the sampler's own deterministic flow from the last event before ``T`` (:385-420).
 
     The events before ``T`` are, by construction of the reference loop, the first events of the fixed-count
-    skeleton for the same seed, so the engine's fixed-count kernel is run with a capacity that doubles
-    (as ``_grow_history`` does, Composites.jl:172-191) until every chain has passed ``T``; the closing point
-    and the trimming (``_trim_history``, :198-214) happen on the host.  Returns a PDMPHistory for vector
-    inputs, a list of PDMPHistory (one per chain, ragged lengths) for ``(C, d)`` inputs."""
+    skeleton for the same seed, so the engine's fixed-count kernel runs with a capacity that doubles
+    (as ``_grow_history`` does, Composites.jl:172-191) until every chain has passed ``T``; the closing point is
+    written on the device (``pdmp_close_at_time_device``: every sampler's flow, the Sticky mask, zeroed statistics)
+    and the ragged histories are packed by ``pdmp_compact_history_device`` (``_trim_history``, :198-214).
+    Returns a PDMPHistory for vector inputs, a list of PDMPHistory (one per chain, ragged lengths) for ``(C, d)`` inputs."""
+    import torch
+    from . import ensemble
     T = float(T)
     if not math.isfinite(T) or T < 0:
         raise ArgumentError(f"T must be finite and non-negative. Current value: {T}")      # sample.jl:335-337
     x, v, single = _as_init(sampler, xinit, vinit)
-    seed = _seed(seed)
-    cap = max(2, int(init_capacity))
-    while True:
-        out = sample_skeleton_ensemble(sampler, cap, x, v, seed=seed)
-        if T == 0.0 or bool((out["t"][:, -1] > T).all()):
-            break
-        cap *= 2                                                                          # newcap = 2 * size, :375-377
+    if not torch.cuda.is_available():
+        raise _lib.EngineError(_lib.ERR_RUNTIME, "no HIP device visible: the PDMP engine has no CPU fallback")
+    dev = torch.device("cuda", sampler.device if sampler.device >= 0 else torch.cuda.current_device())
+    res = ensemble.sample_skeleton_until_device(sampler, T, torch.from_numpy(x).to(dev), torch.from_numpy(v).to(dev), seed=_seed(seed),
+                                                diagnostics=True, init_capacity=init_capacity, compact=True)
+    off = res["offsets"].cpu().numpy()
+    host = {k: res[k].cpu().numpy() for k in ("X", "V", "t", "horizon", "ar", "errored_bound", "error_value_ar", "rejected",
+                                              "hitting_horizon") + (("is_active",) if "is_active" in res else ())}
     hists = []
     for c in range(x.shape[0]):
-        t = out["t"][c]
-        k = 1 if T == 0.0 else int(np.searchsorted(t, T, side="right"))                   # events with t <= T are recorded (:372)
-        h = history_from_ensemble({key: val[c:c + 1, :k] for key, val in out.items()}, 0)
-        if T > 0.0 and t[k - 1] < T:                                                      # overshoot: closing point at t = T (:385-420)
-            xT, vT = _flow_host(sampler, out["X"][c, k - 1], out["V"][c, k - 1], T - t[k - 1])
-            app = lambda a, val: np.concatenate([a, np.asarray(val, dtype=a.dtype).reshape(a.shape[:-1] + (1,))], axis=-1)
-            h = PDMPHistory(
-                X=app(h.X, xT), V=app(h.V, vT), t=app(h.t, T), is_active=np.ones((h.X.shape[0], k + 1), dtype=bool),
-                horizon=app(h.horizon, out["horizon"][c, k]),        # the state object keeps the overshooting event's horizon
-                ar=app(h.ar, 0.0), errored_bound=app(h.errored_bound, 0), error_value_ar=app(h.error_value_ar, np.zeros(5)),
-                rejected=app(h.rejected, 0), hitting_horizon=app(h.hitting_horizon, 0))
-        hists.append(h)
+        sl = slice(int(off[c]), int(off[c + 1]))
+        hists.append(history_from_ensemble({k: a[None, sl] for k, a in host.items()}, 0))
     if single:
         sampler.state = hists[0]
         return hists[0]
@@ -144,9 +129,12 @@ def sample_skeleton(sampler: AbstractPDMP, n_sk, xinit, vinit, *, seed=None, ver
     return hist
 
 
-def sample_from_skeleton_ensemble(sampler: AbstractPDMP, N: int, X, V, t, *, discard_vt: bool = True, dt: float = 0.0):
-    """X, V: (C, n_sk, d); t: (C, n_sk).  Returns (C, N, rows) with rows = d or 2d+1.  ``dt > 0``: samples at
-    ``j*dt`` (the ``dt::Float64`` method); the caller guarantees ``N*dt <= t[:, -1]``."""
+def sample_from_skeleton_ensemble(sampler: AbstractPDMP, N: int, X, V, t, *, discard_vt: bool = True, dt: float = 0.0,
+                                  is_active=None, n_prefix: int = 0, return_counts: bool = False):
+    """X, V: (C, n_sk, d); t: (C, n_sk); is_active: (C, n_sk, d) uint8 / bool (PDMPHistory.is_active; required for StickyZigZag).
+    Returns (C, N, rows) with rows = d or 2d+1.  ``dt > 0``: samples at ``j*dt`` (the ``dt::Float64`` method); ``n_prefix > 0``
+    with ``dt``: the ``(N, dt)`` method on the first ``n_prefix`` columns.  ``return_counts``: also the per-chain number of
+    samples ``floor(t_end/dt)`` (columns beyond it are zero)."""
     if N <= 0:
         raise ArgumentError(f"N must be positive. Current value: {N}")          # sample.jl:476-478
     X = np.ascontiguousarray(X, dtype=np.float64); V = np.ascontiguousarray(V, dtype=np.float64)
@@ -154,18 +142,57 @@ def sample_from_skeleton_ensemble(sampler: AbstractPDMP, N: int, X, V, t, *, dis
     Cn, n_sk, d = X.shape
     if d != sampler.dim or V.shape != X.shape or t.shape != (Cn, n_sk):
         raise DimensionMismatch("history arrays do not match the sampler dimension")
+    ia = None
+    if is_active is not None:
+        ia = np.ascontiguousarray(np.asarray(is_active).astype(np.uint8))
+        if ia.shape != X.shape:
+            raise DimensionMismatch("is_active does not match the history")
     rows = d if discard_vt else 2 * d + 1
-    out = np.empty((Cn, N, rows))
-    _lib.check(_lib.lib().pdmp_sample_from_skeleton_dt(sampler.handle(), Cn, n_sk, _vp(X), _vp(V), _vp(t), int(N),
-                                                       float(dt), int(bool(discard_vt)), _vp(out)))
-    return out
+    out = np.zeros((Cn, N, rows)) if return_counts else np.empty((Cn, N, rows))
+    counts = np.zeros(Cn, np.int64) if return_counts else None
+    L = _lib.lib()
+    if n_prefix > 0:
+        _lib.check(L.pdmp_sample_from_skeleton_prefix(sampler.handle(), Cn, n_sk, _vp(X), _vp(V), _vp(t), _vp(ia), int(n_prefix),
+                                                      float(dt), int(N), int(bool(discard_vt)), _vp(out), _vp(counts)))
+    elif dt > 0.0:
+        _lib.check(L.pdmp_sample_from_skeleton_dt(sampler.handle(), Cn, n_sk, _vp(X), _vp(V), _vp(t), _vp(ia), int(N),
+                                                  float(dt), int(bool(discard_vt)), _vp(out), _vp(counts)))
+    else:
+        _lib.check(L.pdmp_sample_from_skeleton(sampler.handle(), Cn, n_sk, _vp(X), _vp(V), _vp(t), _vp(ia), int(N),
+                                               int(bool(discard_vt)), _vp(out)))
+    return (out, counts) if return_counts else out
 
 
-def sample_from_skeleton(sampler: AbstractPDMP, N, history, *, discard_vt: bool = True):
-    """``N::Int``: sample.jl:475-513 (N equispaced samples, dt = t[end]/N).  ``dt::Float64``: :573-646
-    (samples at j*dt, j = 1..floor(t[end]/dt)) -- dispatch on the type of the second argument, as Julia does.
-    ``history`` is a PDMPHistory (-> ``rows x N`` matrix, Fortran-ordered view) or, for the Int method, an
-    ensemble dict (-> (C, N, rows))."""
+def _history_arrays(history):
+    X = np.ascontiguousarray(history.X.T)[None]
+    V = np.ascontiguousarray(history.V.T)[None]
+    t = np.ascontiguousarray(history.t)[None]
+    ia = np.ascontiguousarray(np.asarray(history.is_active).T.astype(np.uint8))[None]
+    return X, V, t, ia
+
+
+def sample_from_skeleton(sampler: AbstractPDMP, N, history, dt=None, *, discard_vt: bool = True):
+    """``N::Int``: sample.jl:475-513 (N equispaced samples, dt = t[end]/N; StickyPDMP: :516-561).  ``dt::Float64``: :573-646
+    (samples at j*dt, j = 1..floor(t[end]/dt)).  ``(N::Int, dt::Float64, history)``: :649-682 (the first N history columns,
+    samples at dt:dt:t[N]) -- written ``sample_from_skeleton(sampler, N, dt, history)`` as in Julia, or with ``dt=`` as a
+    keyword.  Dispatch on the types of the arguments, as Julia does.  ``history`` is a PDMPHistory (-> ``rows x N`` matrix,
+    Fortran-ordered view) or, for the Int method, an ensemble dict (-> (C, N, rows))."""
+    if isinstance(history, float) and not isinstance(dt, float) and dt is not None:      # Julia's positional order (sampler, N, dt, history)
+        history, dt = dt, history
+    if dt is not None:                                                                   # the (N, dt) method, :649-682
+        if isinstance(history, dict):
+            raise ArgumentError("the (N, dt) method takes one PDMPHistory")
+        n_pre, dt = int(N), float(dt)
+        if not (dt > 0.0) or not math.isfinite(dt):
+            raise ArgumentError(f"dt must be positive and finite. Current value: {dt}")
+        if n_pre < 1 or n_pre > len(history):
+            raise ArgumentError(f"N must be in 1..length(history) = {len(history)}. Current value: {N}")   # BoundsError in Julia
+        M = int(math.floor(history.t[n_pre - 1] / dt))                                   # length(dt:dt:t[end])
+        rows = history.X.shape[0] if discard_vt else 2 * history.X.shape[0] + 1
+        if M <= 0:
+            return np.empty((rows, 0))
+        X, V, t, ia = _history_arrays(history)
+        return sample_from_skeleton_ensemble(sampler, M, X, V, t, discard_vt=discard_vt, dt=dt, is_active=ia, n_prefix=n_pre)[0].T
     if isinstance(N, float):
         dt = N
         if isinstance(history, dict):
@@ -176,19 +203,15 @@ def sample_from_skeleton(sampler: AbstractPDMP, N, history, *, discard_vt: bool 
         rows = history.X.shape[0] if discard_vt else 2 * history.X.shape[0] + 1
         if n <= 0:
             return np.empty((rows, 0))
-        X = np.ascontiguousarray(history.X.T)[None]
-        V = np.ascontiguousarray(history.V.T)[None]
-        t = np.ascontiguousarray(history.t)[None]
-        return sample_from_skeleton_ensemble(sampler, n, X, V, t, discard_vt=discard_vt, dt=dt)[0].T
+        X, V, t, ia = _history_arrays(history)
+        return sample_from_skeleton_ensemble(sampler, n, X, V, t, discard_vt=discard_vt, dt=dt, is_active=ia)[0].T
     if N <= 0:
         raise ArgumentError(f"N must be positive. Current value: {N}")
     if isinstance(history, dict):
         return sample_from_skeleton_ensemble(sampler, N, history["X"], history["V"], history["t"],
-                                             discard_vt=discard_vt)
-    X = np.ascontiguousarray(history.X.T)[None]
-    V = np.ascontiguousarray(history.V.T)[None]
-    t = np.ascontiguousarray(history.t)[None]
-    return sample_from_skeleton_ensemble(sampler, N, X, V, t, discard_vt=discard_vt)[0].T
+                                             discard_vt=discard_vt, is_active=history.get("is_active"))
+    X, V, t, ia = _history_arrays(history)
+    return sample_from_skeleton_ensemble(sampler, N, X, V, t, discard_vt=discard_vt, is_active=ia)[0].T
 
 
 def sample(sampler: AbstractPDMP, N_sk: int, N_samples: int, xinit, vinit, *, seed=None, verbose: bool = True,

@@ -14,7 +14,7 @@ import warnings
 import numpy as np
 
 from . import _lib
-from ._lib import ArgumentError
+from ._lib import ArgumentError, DimensionMismatch
 
 ZIGZAG, BPS_ID, BOOMERANG = 0, 1, 2
 DERIV_FORWARD, DERIV_FINITE_DIFF = 0, 1
@@ -283,8 +283,8 @@ class StickyZigZag(AbstractPDMP):
     adaptive=true, AD_backend="FiniteDiff") (StickyZigZagSamplers.jl:59-61) with the sampling loop of src/StickySamplingLoop.jl:
     a coordinate that reaches 0 sticks there (its velocity is masked out of flows, rates and bounds) and thaws at rate
     ``kappa[i]``; accepted flips, sticking and thawing are all recorded events, ``PDMPHistory.is_active`` tells which
-    coordinates move.  ``sample_from_skeleton`` interpolates with the plain linear flow on the recorded velocities, as the
-    reference does (sample.jl:499: it does not consult ``is_active``)."""
+    coordinates move.  ``sample_from_skeleton`` dispatches to the reference's ``StickyPDMP`` methods (sample.jl:516-561, :588-596):
+    the flow uses ``v_used = is_active ? v : 0``, so a frozen coordinate stays exactly 0 between its sticking and thawing events."""
     sampler_id = 6
     name = "StickyZigZag"
 

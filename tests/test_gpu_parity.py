@@ -472,37 +472,6 @@ def test_bound_instalments_do_not_change_results(engine, oracle, monkeypatch, bu
     assert_bitwise(got, ref)
 
 
-@pytest.mark.parametrize("kind,dim,target", [("ZigZagAD", 10, "iso"), ("BPS", 8, "banana"), ("Boomerang", 12, "iso")])
-def test_time_horizon_on_the_device_matches_the_host_variant(engine, kind, dim, target):
-    """pdmp_close_at_time_device (closing column at t = T written in place, sample.jl:385-420) against the host
-    implementation of the same variant (sample_skeleton_until)."""
-    import torch
-    from pdmpflux.jl_amd import ensemble
-    ctor = getattr(engine, kind)
-    tg = engine.GaussianIso() if target == "iso" else engine.Banana()
-    s = ctor(dim, tg)
-    C, T = 13, 3.7
-    x, v = make_init(kind, dim, C, seed=2, target=target)
-    dev = torch.device("cuda:0")
-    out = ensemble.sample_skeleton_until_device(s, T, torch.from_numpy(x).to(dev), torch.from_numpy(v).to(dev), seed=9,
-                                                diagnostics=True, init_capacity=16)
-    hists = engine.sample_skeleton(s, T, x, v, seed=9, init_capacity=16)
-    cnt = out["count"].cpu().numpy()
-    for c in range(C):
-        h, k = hists[c], int(cnt[c])
-        assert k == h.t.shape[0]
-        assert np.array_equal(out["t"][c, :k].cpu().numpy(), h.t) and h.t[-1] == T
-        Xd, Vd = out["X"][c, :k].cpu().numpy().T, out["V"][c, :k].cpu().numpy().T
-        assert np.array_equal(Xd[:, :-1], h.X[:, :-1]) and np.array_equal(Vd[:, :-1], h.V[:, :-1])
-        if kind == "Boomerang":     # the host variant rotates the closing point with libm's sin/cos, the device with the engine's
-            np.testing.assert_allclose(Xd[:, -1], h.X[:, -1], rtol=1e-13, atol=1e-15)
-            np.testing.assert_allclose(Vd[:, -1], h.V[:, -1], rtol=1e-13, atol=1e-15)
-        else:
-            assert np.array_equal(Xd[:, -1], h.X[:, -1]) and np.array_equal(Vd[:, -1], h.V[:, -1])
-        assert np.array_equal(out["ar"][c, :k].cpu().numpy(), h.ar)
-        assert np.array_equal(out["rejected"][c, :k].cpu().numpy(), h.rejected)
-
-
 def _random_cases(n, seed):
     rs = np.random.default_rng(seed)
     cases = []

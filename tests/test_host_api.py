@@ -109,7 +109,7 @@ def test_library_exports_every_declared_symbol(engine):
     for sym in decl:
         assert hasattr(L, sym), f"{sym} declared in include/pdmp_hip.h but not exported"
     assert sorted(_lib.SYMBOLS) == decl, "python binding table and header disagree"
-    assert _lib.lib().pdmp_abi_version() == 5
+    assert _lib.lib().pdmp_abi_version() == 6
 
 
 def test_fails_loudly_without_gpu(engine):
@@ -156,3 +156,23 @@ def test_shard_ranges(engine):
         assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
         sizes = [b - a for a, b in parts]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_multi_device_partition_equals_shard_range(engine):
+    """pdmp_multi_shard_range (the partition pdmp_multi_sample_skeleton uses inside the library) = ensemble.shard_range (the
+    partition of the one-process-per-GPU driver): a chain lands on the same rank either way."""
+    from pdmpflux.jl_amd import _lib
+    from pdmpflux.jl_amd.ensemble import shard_range
+    L = _lib.lib()
+    for C_total, world in ((100000, 8), (100000, 3), (10, 3), (7, 8), (0, 4), (5, 1), (12500, 7)):
+        for r in range(world):
+            lo, hi = C.c_int64(), C.c_int64()
+            assert L.pdmp_multi_shard_range(C_total, r, world, C.byref(lo), C.byref(hi)) == 0
+            assert (lo.value, hi.value) == shard_range(C_total, r, world)
+    lo, hi = C.c_int64(), C.c_int64()
+    assert L.pdmp_multi_shard_range(10, 3, 3, C.byref(lo), C.byref(hi)) == _lib.ERR_ARGUMENT
+
+
+def test_sticky_kappa_length_is_checked(engine):
+    with pytest.raises(engine.DimensionMismatch):
+        engine.StickyZigZag(3, engine.GaussianIso(), [0.5, 0.5])
