@@ -1,21 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- skeleton-events/sec of the sample_skeleton() hot path on MI355X.
 
-Workload at N=1 (BASELINE.json configs[1]): Zig-Zag, d=50 standard Gaussian, 10^5 chains per GPU,
-n_sk=1000 skeleton points per chain (9.99e7 events per step), synthetic stationary starts
-(x ~ N(0,I), v = +-1), defaults of ZigZagAD (grid_size=10, tmax=2, signed vectorised bound,
-adaptive, forward-mode slopes).  One "step" = one sample_skeleton() pass over the whole ensemble,
-inputs and outputs resident in HBM.  With N>1 (torchrun, one rank per GPU) every rank runs its own
-10^5 chains (weak scaling; chain ids are global) and each step ends with one RCCL all-gather of the
-chains' end states.
+Default workload (BASELINE.json configs[1], the configuration the metric is quoted on): Zig-Zag, d=50 standard Gaussian,
+ONE ensemble of 10^5 chains, n_sk=1000 skeleton points per chain (9.99e7 events per step), synthetic stationary starts
+(x ~ N(0,I), v = +-1), defaults of ZigZagAD (grid_size=10, tmax=2, signed vectorised bound, adaptive, forward-mode slopes).
+One "step" = one sample_skeleton() pass over the whole ensemble, inputs and outputs resident in HBM.
+
+With N>1 (torchrun, one rank per GPU) the SAME ensemble is sharded over the ranks (strong scaling: rank r takes the contiguous
+chain range shard_range(chains, r, N), chain ids stay global) and every step ends, inside the timed region, with the north
+star's exchange: one RCCL all-gather each for the X, V and t shards, after which every GPU holds the whole skeleton
+(`ensemble.sample_skeleton_sharded(gather="skeleton")`, in place in preallocated full-size buffers).  `--gather none` times
+the sharded kernels alone.  The lanes-per-chain layout is chosen from the shard size (`--lanes auto`,
+pdmp_suggest_group_lanes): a 12 500-chain shard does not fill the GPU at the default layout.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (HBM, algorithmic
-bytes 8(2d+1) per event over hipEvent-timed kernel durations) and `cpu_baseline` (the CPU oracle on
-the host cores of the same box, bounded sample).
+bytes 8(2d+1) per event over hipEvent-timed kernel durations; `roofline.valu`: the VALU-issue ceiling that actually binds)
+and `cpu_baseline` (the CPU oracle on all host cores of the same box, bounded sample).
 """
 import argparse
 import json
@@ -35,10 +39,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--chains", type=int, default=100_000, help="chains per GPU")
+    ap.add_argument("--chains", type=int, default=100_000, help="chains of the ensemble (sharded over the GPUs)")
+    ap.add_argument("--gather", default="skeleton", choices=["skeleton", "none"],
+                    help="N > 1: the exchange that ends every step (skeleton: all-gather of X, V, t -- the north star's)")
+    ap.add_argument("--lanes", default="auto", help="lanes per chain: auto (from the shard size), default, or a power of two")
     ap.add_argument("--n-sk", type=int, default=1000)
     ap.add_argument("--dim", type=int, default=50)
     ap.add_argument("--sampler", default="ZigZagAD", choices=["ZigZagAD", "ZigZag", "BPS", "BPSAD", "Boomerang", "BoomerangAD", "ForwardECMC", "ForwardECMCAD", "SpeedUpZigZag", "SpeedUpZigZagAD", "RHMC"])
+    ap.add_argument("--refresh-rate", type=float, default=None, help="BPS / Boomerang refresh_rate (default: the constructor's)")
     ap.add_argument("--target", default="iso", choices=["iso", "diag", "banana", "dense", "src_banana"],
                     help="src_banana: U_banana given as source, differentiated by forward mode on the GPU (pdmp_create_from_source)")
     ap.add_argument("--seed", type=int, default=2024)
@@ -62,12 +70,14 @@ def make_sampler(P, a):
         return getattr(P, a.sampler)(a.dim, P.GaussianDiag(rs.normal(size=a.dim), np.exp(rs.uniform(-1, 1, size=a.dim))))
     tgt = {"iso": P.GaussianIso, "banana": P.Banana, "src_banana": lambda: P.SourcePotential(P.U_BANANA_SOURCE)}.get(a.target)
     tgt = tgt() if tgt else P.GaussianPrecision(dense_precision(a))
-    return getattr(P, a.sampler)(a.dim, tgt)
+    kw = {} if a.refresh_rate is None else {"refresh_rate": a.refresh_rate}
+    return getattr(P, a.sampler)(a.dim, tgt, **kw)
 
 
-def make_inputs(torch, a, dev, rank):
+def make_inputs(torch, a, dev):
+    """The WHOLE ensemble's initial states on every rank (16 d bytes per chain; same generator seed everywhere)."""
     g = torch.Generator(device=dev)
-    g.manual_seed(a.seed * 1000 + rank)
+    g.manual_seed(a.seed * 1000)
     x = torch.randn((a.chains, a.dim), dtype=torch.float64, device=dev, generator=g)
     if a.target in ("banana", "src_banana"):
         x = 1.0 + 0.1 * x
@@ -81,11 +91,17 @@ def make_inputs(torch, a, dev, rank):
 
 
 def cpu_baseline(a, sampler):
-    """Oracle ('port' of the reference algorithm, reference summation order) on the host cores: a bounded
-    sample of the same workload -- same d, n_sk, sampler and target, fewer chains."""
+    """Oracle ('port' of the reference algorithm, reference summation order) on ALL host cores of this box: a bounded
+    sample of the same workload -- same d, n_sk, sampler and target, fewer chains.  Each OpenMP thread runs a contiguous slab
+    of chains into its own part of the output (first touched by that thread), see oracle/pdmp_oracle.c."""
     import numpy as np
     from oracle import oracle as O
-    cores = min(O.num_threads(), int(os.environ.get("PDMP_CPU_THREADS", "16")))   # CPU share of one GPU slot
+    nproc = os.cpu_count() or 1
+    try:
+        nproc = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    cores = int(os.environ.get("PDMP_CPU_THREADS", "0")) or min(O.num_threads(), nproc)
     tid = {"iso": O.T_GAUSS_ISO, "diag": O.T_GAUSS_DIAG, "banana": O.T_BANANA, "dense": O.T_GAUSS_DENSE, "src_banana": O.T_AD_BANANA}[a.target]
     tparams = np.asfortranarray(dense_precision(a)).ravel(order="F") if a.target == "dense" else None
     if a.target == "diag":
@@ -100,7 +116,12 @@ def cpu_baseline(a, sampler):
     rs = np.random.default_rng(a.seed)
     n_sk = min(a.n_sk, 1000)
 
+    bufs = {}
+
     def run(C, off):
+        if not bufs or bufs["t"].shape[0] < C:       # output buffers allocated and touched once, reused by every timed run
+            bufs.update(X=np.zeros((C, n_sk, a.dim)), V=np.zeros((C, n_sk, a.dim)), t=np.zeros((C, n_sk)))
+        out = {k: bufs[k][:C] for k in ("X", "V", "t")}
         x = rs.normal(size=(C, a.dim))
         if a.target in ("banana", "src_banana"):
             x = 1.0 + 0.1 * x
@@ -110,37 +131,56 @@ def cpu_baseline(a, sampler):
             v = rs.normal(size=(C, a.dim))
             v /= np.linalg.norm(v, axis=1, keepdims=True)
         t0 = time.perf_counter()
-        O.sample_skeleton(cfg, n_sk, x, v, a.seed, chain_id_offset=off, diagnostics=False, n_threads=cores)
+        O.sample_skeleton(cfg, n_sk, x, v, a.seed, chain_id_offset=off, diagnostics=False, n_threads=cores, out=out)
         return time.perf_counter() - t0
 
     C0 = 4 * cores
-    dt = run(C0, 0)                                            # calibration (also warms the threads)
+    cap = max(C0, int(3e9 // (n_sk * 8 * (2 * a.dim + 1))))    # keep the host buffers under ~3 GB
+    cap -= cap % cores
+    run(cap if cap * n_sk * a.dim < 4e7 else C0, 0)            # warms the threads (and sizes the buffers when that is cheap)
+    dt = run(C0, 0)                                            # calibration
     per_chain = dt / C0
-    cap = max(C0, int(1.5e9 // (n_sk * 8 * (2 * a.dim + 1))))  # keep the host buffers under ~1.5 GB
     total = max(C0, int(a.cpu_seconds / per_chain))
+    total = min(total, 40 * cap)
     done, spent, off = 0, 0.0, C0
     while done < total and spent < 2 * a.cpu_seconds:
         c = min(cap, total - done)
+        c = max(cores, c - c % cores)                          # equal slabs
         spent += run(c, off)
         done += c
         off += c
     events = done * (n_sk - 1)
-    return {"value": events / spent, "unit": "events/s", "cores": cores, "kind": "port",
+    return {"value": events / spent, "unit": "events/s", "cores": cores, "nproc": nproc, "kind": "port",
+            "label": "CPU restatement of PDMPFlux.jl's algorithm (oracle/pdmp_oracle.c), not the Julia package itself",
             "sample": f"{done} chains x n_sk={n_sk} of the same workload ({events} events, {spent:.1f} s, "
-                      f"OpenMP over chains, -O2 no fast-math, reference summation order)"}
+                      f"OpenMP over chains on {cores} of {nproc} hardware threads, static slabs, -O2 no fast-math, reference summation order)"}
 
 
-def measured_traffic(a):
-    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (WRITE_SIZE exact, FETCH_SIZE x2
-    on gfx950; collected by profiles/collect.sh in separate --pmc runs and committed as profiles/traffic.json).
-    PMC counters cannot be read from inside this process, so the figure is the committed measurement of the
-    identical workload, or null when none exists for it."""
+def measured_counters(a, C_local, G):
+    """HBM bytes per launch and VALU instruction counts of the dominant kernel from the rocprofv3 PMC passes (WRITE_SIZE exact,
+    FETCH_SIZE x2 on gfx950; collected by profiles/collect.sh in separate --pmc runs and committed as profiles/traffic.json).
+    PMC counters cannot be read from inside this process, so the figures are the COMMITTED measurement of the identical
+    workload and layout (the entry names its source file), or None when none exists for it."""
     try:
         table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except (OSError, ValueError):
         return None
-    key = f"{a.sampler}|{a.target}|d={a.dim}|C={a.chains}|n_sk={a.n_sk}"
-    return table.get(key, {}).get("hbm_bytes_per_launch")
+    key = f"{a.sampler}|{a.target}|d={a.dim}|C={C_local}|n_sk={a.n_sk}"
+    e = table.get(key + f"|G={G}") or table.get(key)
+    return e
+
+
+def workload_label(a, sampler, world, C_local):
+    rr = f", refresh_rate={sampler.refresh_rate}" if a.sampler.startswith(("BPS", "Boomerang", "RHMC")) else ""
+    slopes = "forward-mode slopes" if sampler.deriv_mode == 0 else "finite-difference slopes"
+    base = {("ZigZagAD", "iso", 50, 100_000, 1000): " = BASELINE configs[1]",
+            ("BPS", "banana", 50, 100_000, 1000): " = BASELINE configs[2]",
+            ("BPSAD", "banana", 50, 100_000, 1000): " = BASELINE configs[2]",
+            ("ZigZagAD", "dense", 1000, 10_000, 200): " = BASELINE configs[3] at n_sk=200",
+            ("Boomerang", "iso", 100, 100_000, 1000): " = BASELINE configs[4]"}.get((a.sampler, a.target, a.dim, a.chains, a.n_sk), "")
+    shard = "" if world == 1 else f", sharded over {world} GPUs ({C_local} chains on rank 0)"
+    return (f"{a.sampler} d={a.dim} {a.target} target, one ensemble of {a.chains} chains x n_sk={a.n_sk}{base}{shard}; "
+            f"grid_size={sampler.grid_size}, tmax={sampler.tmax}, {'adaptive' if sampler.adaptive else 'fixed horizon'}, {slopes}{rr}")
 
 
 def main():
@@ -174,43 +214,32 @@ def main():
 
     sampler = make_sampler(P, a)
     sampler.device = local
-    x, v = make_inputs(torch, a, dev, rank)
-    C, d, n_sk = a.chains, a.dim, a.n_sk
-    out = {"X": torch.empty((C, n_sk, d), dtype=torch.float64, device=dev),
-           "V": torch.empty((C, n_sk, d), dtype=torch.float64, device=dev),
-           "t": torch.empty((C, n_sk), dtype=torch.float64, device=dev)}
-    # the exchange is double-buffered: the all-gather of step i runs on RCCL's stream while the kernel of step i+1 runs
-    # (the kernel's work units never wait on a wave that is not already running, so sharing CUs with RCCL cannot stall it)
-    end_state = [torch.empty((C, 2 * d + 1), dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
-    gathered = [torch.empty((world * C, 2 * d + 1), dtype=torch.float64, device=dev) for _ in range(2)] if world > 1 else None
-    pending = [None, None]
-    chain0 = rank * C
+    x, v = make_inputs(torch, a, dev)
+    C_total, d, n_sk = a.chains, a.dim, a.n_sk
+    lo, hi = ensemble.shard_range(C_total, rank, world)
+    C_max = ensemble.shard_range(C_total, 0, world)[1]                 # the largest shard (rank 0)
+    # ONE layout for all ranks (the order of the sums over coordinates depends on it): from the largest shard
+    if a.lanes == "auto":
+        sampler.set_group_lanes(sampler.suggest_group_lanes(C_max))
+    elif a.lanes != "default":
+        sampler.set_group_lanes(int(a.lanes))
+    gather = a.gather if world > 1 else "none"
+    # full-size buffers, allocated once: the shard is sampled straight into its chain range and gathered in place
+    rows = C_total if gather == "skeleton" else hi - lo
+    full = {"X": torch.empty((rows, n_sk, d), dtype=torch.float64, device=dev),
+            "V": torch.empty((rows, n_sk, d), dtype=torch.float64, device=dev),
+            "t": torch.empty((rows, n_sk), dtype=torch.float64, device=dev)}
 
     def step(i):
-        ensemble.sample_skeleton_device(sampler, n_sk, x, v, seed=a.seed + i, chain_id_offset=chain0, out=out,
-                                        check=False)
-        if world > 1:       # the path's only exchange: every rank learns every chain's end state
-            b = i & 1
-            if pending[b] is not None:          # the gather that last used this buffer pair (two steps ago)
-                pending[b].wait()
-                pending[b] = None
-            es = end_state[b]
-            es[:, :d] = out["X"][:, -1]
-            es[:, d:2 * d] = out["V"][:, -1]
-            es[:, 2 * d] = out["t"][:, -1]
-            if rehearsal:
-                parts = [torch.empty((C, 2 * d + 1), dtype=torch.float64) for _ in range(world)]
-                dist.all_gather(parts, es.cpu())
-                gathered[b].copy_(torch.cat(parts, 0))
-            else:
-                pending[b] = dist.all_gather_into_tensor(gathered[b], es, async_op=True)
+        if world == 1:
+            ensemble.sample_skeleton_device(sampler, n_sk, x, v, seed=a.seed + i, out=full, check=False)
+        else:       # rank r samples chains [lo_r, hi_r); gather="skeleton": then one all-gather each for X, V, t
+            ensemble.sample_skeleton_sharded(sampler, n_sk, x, v, seed=a.seed + i, gather=gather, out_full=full, check=False,
+                                             via_host=rehearsal)
 
     def fence():
+        torch.cuda.synchronize()
         if world > 1:
-            for b in (0, 1):                    # every gather issued so far is inside the timed region
-                if pending[b] is not None:
-                    pending[b].wait()
-                    pending[b] = None
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -226,49 +255,68 @@ def main():
     from pdmpflux.jl_amd import _lib
     _lib.check(_lib.lib().pdmp_check_status(sampler.handle(), None))
     tm = ensemble.kernel_timing(sampler)
+    kernel_ms = tm["kernel_ms_total"] / max(tm["launches"], 1)
+    kernel_ms_max = kernel_ms
     if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        te = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+        elapsed, kernel_ms_max = float(te[0].item()), float(te[1].item())
 
-    if world > 1:           # the last gather delivered this rank's own end states to its slot
-        b = (a.warmup + a.steps - 1) & 1
-        assert torch.equal(gathered[b][rank * C:(rank + 1) * C], end_state[b]), "all-gather of end states is inconsistent"
-    # sanity inside the bench: strictly increasing event times on a slice, finite outputs
-    tt = out["t"][:256]
-    assert bool((tt[:, 1:] > tt[:, :-1]).all()) and bool(torch.isfinite(out["X"][:256]).all())
+    # sanity inside the bench: strictly increasing event times on a slice, finite outputs; after the exchange every rank holds
+    # every rank's chains: the block of the LAST rank must be what a checksum of that rank says
+    own = full["t"][lo:hi] if gather == "skeleton" else full["t"]
+    tt = own[:256]
+    assert bool((tt[:, 1:] > tt[:, :-1]).all()) and bool(torch.isfinite(full["X"][:256]).all())
+    if gather == "skeleton":
+        cdev = "cpu" if rehearsal else dev
+        mine = torch.stack([full["t"][lo:hi].sum(), full["X"][lo:hi, -1].sum(), full["V"][lo:hi, -1].sum()]).to(cdev)
+        sums = [torch.zeros(3, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(sums, mine)
+        for r in range(world):
+            l2, h2 = ensemble.shard_range(C_total, r, world)
+            got = torch.stack([full["t"][l2:h2].sum(), full["X"][l2:h2, -1].sum(), full["V"][l2:h2, -1].sum()]).cpu()
+            assert torch.equal(got, sums[r].cpu()), f"rank {rank}: the gathered block of rank {r} differs from what that rank computed"
 
     if rank == 0:
-        events_step = world * C * (n_sk - 1)
+        events_step = C_total * (n_sk - 1)
         value = events_step * a.steps / elapsed
         bytes_per_event = 8 * (2 * d + 1)                         # X, V, t of one event
-        kernel_ms = tm["kernel_ms_total"] / max(tm["launches"], 1)
-        achieved = C * (n_sk - 1) * bytes_per_event / (kernel_ms * 1e-3) / 1e9
+        C_local = hi - lo
+        achieved = C_local * (n_sk - 1) * bytes_per_event / (kernel_ms * 1e-3) / 1e9
         G = sampler.group_lanes()
         K = (d + G - 1) // G if G > 0 else 0
         # mirrors RegForm in csrc/group_kernel.hpp (which register-form instantiations exist)
         sid, fd = sampler.sampler_id, sampler.deriv_mode != 0
-        reg_form = (G > 0 and sid in (0, 1, 2) and K <= 13 and G <= 16 and (G == 1 or K >= 7) and a.target in ("iso", "diag", "banana")
-                    and not (sid == 0 and fd) and not (sid == 2 and K != 13) and os.environ.get("PDMP_REG", "1") != "0")
-        kernel = (f"group_kernel_reg<{sampler.name},{a.target}> (G={G} lanes per chain, x and v in registers)" if reg_form else
+        small_k = (G >= 2 and K < 7)
+        reg_form = (G > 0 and sid in (0, 1, 2) and K <= 13 and G <= 16 and K >= 2 and a.target in ("iso", "diag", "banana")
+                    and not (sid == 0 and fd) and not (sid == 2 and K != 13 and K < 7) and not (small_k and (fd or sid == 2))
+                    and os.environ.get("PDMP_REG", "1") != "0")
+        kernel = (f"group_kernel_reg<{sampler.name},{a.target}> (G={G} lanes per chain, K={K} slots, x and v in registers)" if reg_form else
                   f"group_kernel<{sampler.name},{a.target}> (G={G} lanes per chain)" if G > 0 else
                   f"skeleton_kernel<{sampler.name},{a.target}> (wave per chain)")
+        cnt = measured_counters(a, C_local, G)
+        xbytes = 0 if gather != "skeleton" else (C_total - C_local) * n_sk * bytes_per_event
         res = {
-            "metric": "skeleton-events/sec (whole node), Zig-Zag d=50, 10^5 chains",
+            "metric": f"skeleton-events/sec (whole node), {a.sampler} d={d} {a.target}, {C_total} chains",
             "value": value, "unit": "events/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{a.sampler} d={d} {a.target} target, {C} chains/GPU x n_sk={n_sk} "
-                                   f"(BASELINE configs[1]), grid_size={sampler.grid_size}, tmax={sampler.tmax}, "
-                                   f"adaptive, forward-mode slopes", "chains_per_gpu": C, "n_sk": n_sk, "dim": d,
-                       "events_per_step": events_step,
-                       "exchange": "none" if world == 1 else "all-gather of chain end states (2d+1 doubles per chain)"},
+            "config": {"workload": workload_label(a, sampler, world, C_local), "chains": C_total, "chains_rank0": C_local,
+                       "n_sk": n_sk, "dim": d, "events_per_step": events_step, "lanes_per_chain": G,
+                       "exchange": "none" if gather != "skeleton" else
+                                   f"one all-gather each of the X, V, t shards per step (RCCL, in place): {xbytes} bytes received per GPU per step",
+                       "exchange_bytes_per_gpu": xbytes,
+                       "kernel_ms_max_over_ranks": kernel_ms_max,
+                       "kernel_only_events_per_s": events_step / (kernel_ms_max * 1e-3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(a),
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": cnt.get("hbm_bytes_per_launch") if cnt else None,
+                         "traffic_source": (cnt.get("source", "profiles/traffic.json") + " -- committed rocprofv3 measurement of this workload, not read in this run") if cnt else None,
                          "kernel": kernel, "kernel_ms": kernel_ms, "bytes_per_event": bytes_per_event,
-                         "note": "fp64 state machine bound by VALU issue (config 2: 115 VALU instructions per event, VALU busy 81 % "
-                                 "at 2 waves/SIMD, profiles/r1/final3_zz_iso_pmc.json; Zig-Zag banana: 142, profiles/r1/zz_banana_r1b_pmc.json; "
-                                 "BPS banana: 404, profiles/r1/bps_banana_r1b_pmc.json); HBM fraction is the requested headline"},
+                         "valu": ({"instr_per_event": cnt.get("valu_instr_per_event"), "busy": cnt.get("valu_busy"),
+                                   "source": cnt.get("valu_source")} if cnt and cnt.get("valu_instr_per_event") else None),
+                         "note": "the kernel is bound by fp64 VALU issue, not by HBM (roofline.valu: wave-instructions per event and the share of "
+                                 "SIMD cycles the VALUs are busy, from the committed PMC pass); the HBM fraction is the requested headline"},
         }
         if a.target == "dense" and int(_lib.lib().pdmp_dense_batched_last_mode()) == 2:
             res["roofline"]["kernel"] = ("di_segment_kernel (wave per chain; P x and P v kept current by O(d) updates, one rocBLAS dgemm over all "

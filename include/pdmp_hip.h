@@ -128,6 +128,14 @@ int pdmp_destroy(pdmp_handle h);
  * (sums run in the "GROUP(G)" order of DESIGN.md; G = 1 is the reference's left-to-right order), or
  * 0 when the wave-per-chain kernel ("WAVE64" order) serves it.  Lets a checker pick the matching order. */
 int pdmp_get_group_lanes(pdmp_handle h);
+/* Lanes per chain of the following launches.  pdmp_suggest_group_lanes(h, C) is the layout the engine recommends for launches of
+ * C chains: the default G (the smallest with ceil(dim/G) <= 13 coordinate slots per lane) for every C -- measured on MI355X, more
+ * lanes per chain do not speed up launches that are too small to fill the GPU (such a launch is bound by the latency
+ * of one wave's sequential event loop, which is per-chain scalar work).  pdmp_set_group_lanes pins another power of two (0 = back to
+ * the default).  G fixes the order of the sums over coordinates ("GROUP(G)"): results are bit-identical across shardings for equal
+ * G, which is why a sharded run (pdmp_multi_*, the Python driver) uses ONE G for all shards. */
+int pdmp_suggest_group_lanes(pdmp_handle h, int64_t C);
+int pdmp_set_group_lanes(pdmp_handle h, int32_t G);
 
 /* Tape source: replace the built-in Philox stream (the engine's stand-in for Julia's
  * MersenneTwister, AbstractPDMP.jl:100) by pre-recorded variates, one tape per kind in consumption order --

@@ -162,7 +162,7 @@ def normalize(cfg: Config) -> Config:
 
 
 def sample_skeleton(cfg: Config, n_sk: int, xinit, vinit, seed: int, chain_id_offset: int = 0,
-                    diagnostics: bool = True, n_threads: int = 0) -> dict:
+                    diagnostics: bool = True, n_threads: int = 0, out: dict | None = None) -> dict:
     """xinit, vinit: (C, d) arrays (row c = chain c; memory layout equals the reference's d x C
     column-major).  Returns dict of arrays: X, V (C, n_sk, d), t (C, n_sk), + diagnostics."""
     x = np.ascontiguousarray(np.atleast_2d(np.asarray(xinit, dtype=np.float64)))
@@ -171,7 +171,10 @@ def sample_skeleton(cfg: Config, n_sk: int, xinit, vinit, seed: int, chain_id_of
         raise OracleError(-2, f"xinit and vinit must have the same dimension as dim ({cfg.dim})")
     Cn, d = x.shape
     n = max(int(n_sk), 0)
-    out = {"X": np.empty((Cn, n, d)), "V": np.empty((Cn, n, d)), "t": np.empty((Cn, n))}
+    if out is not None:                 # caller-owned (already touched) buffers: bench.py's cpu_baseline times the loop, not page faults
+        assert not diagnostics and all(out[k].flags.c_contiguous and out[k].shape[:2] == (Cn, n) for k in ("X", "V", "t"))
+    else:
+        out = {"X": np.empty((Cn, n, d)), "V": np.empty((Cn, n, d)), "t": np.empty((Cn, n))}
     if diagnostics:
         out.update(horizon=np.empty((Cn, n)), ar=np.empty((Cn, n)),
                    errored_bound=np.empty((Cn, n), np.int32), error_value_ar=np.empty((Cn, n, 5)),

@@ -580,12 +580,26 @@ static void upper_bound(const orc_config_t *cfg, ws_t *w, const double *x, const
             }
         }
         if (cfg->arith == ORC_ARITH_REFERENCE) memset(w->cum, 0, (size_t)n * 8);
+        /* coordinates i >= affine_from have d grad_i / dx_j = const * delta_ij (isotropic / diagonal Gaussian: all; banana: i >= 2);
+         * the engine decides per slot of G coordinates, hence the rounding to a multiple of G below */
+        const int affine_cells = cfg->arith == ORC_ARITH_GROUP && cfg->sampler == ORC_ZIGZAG && cfg->signed_bound &&
+                                 cfg->deriv_mode == ORC_DERIV_FORWARD;
+        const int affine_from = (cfg->target_id == ORC_T_GAUSS_ISO || cfg->target_id == ORC_T_GAUSS_DIAG) ? 0
+                              : (cfg->target_id == ORC_T_BANANA ? 2 : (1 << 30));
         double *run = w->fa;                       /* per-dimension running cumsum (:243-244) */
         for (int i = 0; i < d; ++i) run[i] = 0.0;
         for (int j = 0; j + 1 < n; ++j) {
             const double *v0 = w->vals + (size_t)j * d, *v1 = v0 + d, *g0 = w->slps + (size_t)j * d, *g1 = g0 + d;
             for (int i = 0; i < d; ++i) {
                 /* :229  absolute-time tangent intersection (Q1) */
+                if (affine_cells && (i / cfg->group_lanes) * cfg->group_lanes >= affine_from) {
+                    /* GROUP order, engine-order choice "affine cell" (DESIGN.md): forward-mode Zig-Zag under the signed bound on a
+                     * coordinate whose gradient component is affine in that coordinate -- the slope is the same double at both
+                     * ends, so the reference's tangent intersection degenerates (num / 0 -> clamp -> p = h or 0) and `inter` is
+                     * v0 or v0 + g h = v1 up to rounding: the cell maximum is max(v0, v1, 0), taken without the detour. */
+                    w->cell[i] = pmax(pmax(v0[i], v1[i]), 0.0);
+                    continue;
+                }
                 double num = FUSED(cfg) ? fma(-g0[i], t[j], fma(g1[i], t[j + 1], v0[i] - v1[i]))
                                         : ((v0[i] - v1[i]) + g1[i] * t[j + 1]) - g0[i] * t[j];
                 double p = num / (g1[i] - g0[i]);
@@ -1203,7 +1217,7 @@ static int sample_skeleton_impl(const orc_config_t *cfg_in, int64_t C, int64_t n
 #pragma omp parallel num_threads(n_threads)
     {
         ws_t w; int ok = ws_init(&w, d, cfg.grid_size == 0 ? 2 : cfg.grid_size) == 0;
-#pragma omp for schedule(dynamic, 4)
+#pragma omp for schedule(static)        /* contiguous slabs: a thread first-touches and fills its own part of the outputs */
         for (int64_t c = 0; c < C; ++c) {
             if (!ok) { rc = -1; continue; }
             size_t o = (size_t)c * (size_t)n_sk;

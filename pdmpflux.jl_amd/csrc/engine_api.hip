@@ -633,6 +633,36 @@ int pdmp_create_from_source(const pdmp_config_t *cfg, const char *source, int32_
 
 int pdmp_get_group_lanes(pdmp_handle h) { return h ? (h->tape_chains > 0 ? 0 : h->group_lanes) : -1; }
 
+// Lanes per chain for launches of C chains.  Round 2 measured the obvious idea -- more lanes per chain when a launch cannot fill
+// the 2 048 resident wave slots (a 12 500-chain shard of the 8-GPU run is 782 waves at G = 4) -- and it does not pay: Zig-Zag d = 50,
+// 12 500 chains x 1000 events: G = 4 / 8 / 16 -> 4.88 / 5.19 / 7.27 ms (25 000 chains: 9.1 / 8.5 ms; 50 000: 14.0 / 16.5 ms).
+// An under-filled launch is bound by the latency of ONE wave's event loop (n_sk sequential events), and that is dominated by the
+// per-chain scalar work (random stream, log, bound inversion, Categorical scan), which more lanes per chain replicate instead of
+// shrinking.  So the suggestion is the default layout for every C; pdmp_set_group_lanes stays as the explicit knob.
+int pdmp_suggest_group_lanes(pdmp_handle h, int64_t C) {
+    if (!h) return -1;
+    (void)C;
+    return choose_group_lanes(h->cfg);
+}
+
+int pdmp_set_group_lanes(pdmp_handle h, int32_t G) {
+    if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
+    const pdmp_config_t &c = h->cfg;
+    const int def = choose_group_lanes(c);
+    if (G == 0) { h->group_lanes = def; return PDMP_OK; }
+    if (def <= 0 || c.target_id == PDMP_T_GAUSS_DENSE)
+        return fail(PDMP_ERR_UNSUPPORTED, "this configuration does not run on the group kernel with a free lane count");
+    if (G < 1 || G > WAVE || (G & (G - 1)) != 0) return fail(PDMP_ERR_ARGUMENT, "lanes per chain must be a power of two in 1..64. Current value: %d", (int)G);
+    const int tiles = (c.sampler == PDMP_FECMC) ? 6 : 2;
+    const int tpar = ((c.target_id == PDMP_T_GAUSS_DIAG) ? 2 * c.dim : 0) + ((c.sampler == PDMP_STICKY) ? c.dim : 0);
+    if (group_waves_per_block((c.dim + G - 1) / G, tpar, tiles) < 1)
+        return fail(PDMP_ERR_UNSUPPORTED, "dim %d with %d lanes per chain does not fit the LDS tiles", c.dim, (int)G);
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->launched) HIP_TRY(hipStreamSynchronize(h->last_stream));
+    h->group_lanes = G;
+    return PDMP_OK;
+}
+
 int pdmp_clear_tape(pdmp_handle h) {
     if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
     HIP_TRY(hipSetDevice(h->device));
@@ -795,7 +825,9 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
     } else if (h->group_lanes > 0 && !taped) {
         hipError_t e = hipErrorNotSupported;
         const char *reg = getenv("PDMP_REG");               // PDMP_REG=0: keep x, v in LDS tiles (test hook)
-        if (!(reg && atoi(reg) == 0)) {
+        // register form: the default bound flags only (grid_size = 10; Zig-Zag: vectorized signed bound) -- GroupChain::brent() etc.
+        const bool reg_flags = c.grid_size == GNG && (c.sampler != PDMP_ZIGZAG || (c.vectorized_bound && c.signed_bound));
+        if (!(reg && atoi(reg) == 0) && reg_flags) {
             const bool fd = c.deriv_mode != 0;
             const char *ex = getenv("PDMP_REG_EXACT");      // PDMP_REG_EXACT=0: the KREG-slot kernels with per-slot skips (test hook)
             if (!(ex && atoi(ex) == 0))                     // a kernel of exactly K slots where one exists

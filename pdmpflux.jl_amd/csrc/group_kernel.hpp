@@ -134,6 +134,7 @@ template <> struct GTarget<T_GAUSS_ISO> {
     static constexpr bool kShared = false, kTile = false, kUser = false;
     static constexpr bool kLinear = true;      // grad-U is affine in x: along a linear flow the rate's slope is the same at every grid time
     static constexpr int kAffineFrom = 0;      // coordinates i >= kAffineFrom have d grad_i / dx_j = const * delta_ij
+    static constexpr bool kMonotone = true;    // ... with const >= 0: the Zig-Zag rate (x_i + v_i t) v_i of such a coordinate never decreases in t
     template <class T> using Sh = NoShared;
     __device__ __forceinline__ void init(const double *, int) {}
     template <class T> __device__ __forceinline__ NoShared shared(T, T) const { return {}; }
@@ -143,6 +144,7 @@ template <> struct GTarget<T_GAUSS_DIAG> {
     static constexpr bool kShared = false, kTile = false, kUser = false;
     static constexpr bool kLinear = true;
     static constexpr int kAffineFrom = 0;
+    static constexpr bool kMonotone = false;   // a precision may be negative
     template <class T> using Sh = NoShared;
     const double *mu, *prec;            // LDS copies
     __device__ __forceinline__ void init(const double *lds_params, int d) { mu = lds_params; prec = lds_params + d; }
@@ -158,6 +160,7 @@ template <> struct GTarget<T_BANANA> {          // test/test_config.jl:33-36
     static constexpr bool kShared = true, kTile = false, kUser = false;
     static constexpr bool kLinear = false;
     static constexpr int kAffineFrom = 2;      // only x_1, x_2 are twisted: every other coordinate is a unit Gaussian
+    static constexpr bool kMonotone = true;
     template <class T> using Sh = BananaSh<T>;
     int d;
     __device__ __forceinline__ void init(const double *, int dim) { d = dim; }
@@ -182,6 +185,7 @@ template <> struct GTarget<T_USER> {
     static constexpr bool kShared = true, kTile = false, kUser = true;
     static constexpr bool kLinear = false;
     static constexpr int kAffineFrom = 1 << 30;
+    static constexpr bool kMonotone = false;
     template <class T> using Sh = UserView<T>;
     __device__ __forceinline__ void init(const double *, int) {}
     template <class T> __device__ __forceinline__ T grad(int i, T, const UserView<T> &w) const {
@@ -217,6 +221,12 @@ struct GroupChain {
     mutable double xr[kReg ? KC : 1], vr[kReg ? KC : 1];   // register form: slot s of this lane
     double *fe_t[4] = {nullptr, nullptr, nullptr, nullptr};   // ForwardECMC: LDS tiles for n, v_orth, e1 / g1, e2 / g2 / the proposal
     __device__ __forceinline__ int nk() const { if constexpr (kReg) return KC; else return K; }
+    // The register form serves the constructors' DEFAULT bound flags only -- grid_size = 10 and, for Zig-Zag, the vectorized signed
+    // bound (the host routes every other combination to the LDS form): the unsigned / non-vectorized / Brent code is not compiled into
+    // these kernels at all, which is what keeps them inside 2 waves per SIMD without spills.
+    __device__ __forceinline__ bool brent() const { if constexpr (kReg) return false; else return p.n_grid == 0; }
+    __device__ __forceinline__ bool vectorized() const { if constexpr (kReg) return true; else return p.vectorized != 0; }
+    __device__ __forceinline__ bool zz_signed() const { if constexpr (kReg) return true; else return p.signed_bound != 0; }
     // coordinate i = s*G + g exists (i < d): only the last slot K-1 can be partly padded (register form: a scalar test for the others)
     __device__ __forceinline__ bool in_dim(int s, int i) const { if constexpr (kReg) return s < K - 1 || i < p.d; else return i < p.d; }
     Tgt tgt;
@@ -509,10 +519,23 @@ struct GroupChain {
                         const int i = s * G + g;
                         const int ip = (in_dim(s, i)) ? i : 0;
                         const double x = X(s), v = VU(s);
-                        double v0, g0, v1, g1;
-                        eval_vect<SIGNED>(ip, x, v, p0, sh0, v0, g0);
-                        eval_vect<SIGNED>(ip, x, v, p1, sh1, v1, g1);
-                        bsum += cell_vect(v0, g0, v1, g1, t0, t1, h, SAMPLER == S_ZIGZAG && !FD && s * G >= Tgt::kAffineFrom);
+                        // "Affine cell" (arithmetic contract, GROUP order; mirrored by the checker): forward-mode Zig-Zag under the signed
+                        // bound, slot of coordinates whose gradient component is affine in its own coordinate -- the rate is linear in t,
+                        // its slope the same double at both ends of the cell, so the reference's tangent intersection (UpperBound.jl:229-237)
+                        // divides by zero, clamps to h or 0 and yields v0 or v0 + g h = v1 up to rounding: the cell maximum (:239-241) is
+                        // max(v0, v1, 0).  No slopes, no intersection; with a non-negative slope v1 >= v0 exactly (rounding is monotone),
+                        // so only the right end is evaluated.  4 instead of 15 fp64 operations per coordinate and cell on the Gaussians.
+                        if (SIGNED && SAMPLER == S_ZIGZAG && s * G >= Tgt::kAffineFrom) {      // wave-uniform; a constant in the register form
+                            const typename Tgt::template Sh<double> nosh{};                        // (an affine component reads no other coordinate)
+                            const double v1 = fval_vect<true>(ip, x, v, p1, nosh);
+                            if constexpr (Tgt::kMonotone) bsum += fmax(v1, 0.0);
+                            else bsum += fmax(fmax(fval_vect<true>(ip, x, v, p0, nosh), v1), 0.0);
+                        } else {
+                            double v0, g0, v1, g1;
+                            eval_vect<SIGNED>(ip, x, v, p0, sh0, v0, g0);
+                            eval_vect<SIGNED>(ip, x, v, p1, sh1, v1, g1);
+                            bsum += cell_vect(v0, g0, v1, g1, t0, t1, h);
+                        }
                     }
                     b_shf = sh1;
                 } else {                                                               // AD_backend = "FiniteDiff", :223-224
@@ -551,17 +574,10 @@ struct GroupChain {
         return fin;
     }
     // one tangent-intersection cell of one coordinate, UpperBound.jl:229-241 (absolute-time form, Q1)
-    __device__ __forceinline__ static double cell_vect(double v0, double g0, double v1, double g1, double t0, double t1, double h,
-                                                       bool affine_slot = false) {
+    __device__ __forceinline__ static double cell_vect(double v0, double g0, double v1, double g1, double t0, double t1, double h) {
         const double num = fma(-g0, t0, fma(g1, t1, v0 - v1));                         // :229 ((v0-v1) + g1 t1) - g0 t0, fused
         const double den = g1 - g0;
-        // Zig-Zag on a potential with affine gradient and forward-mode slopes: slope = (d grad_i/dx_i) v_i^2 at every
-        // grid time, the same double each time, so den == 0 exactly for every lane -- known at compile time, no ballot
-        // (a convergent operation that would also keep the compiler from overlapping consecutive coordinates).
-        constexpr bool always_fast = (SAMPLER == S_ZIGZAG) && Tgt::kLinear && !FD;
-        // affine_slot (wave-uniform; a compile-time constant in the register form): every coordinate of this slot has an
-        // affine gradient component (banana: all slots but the first), so den == 0 there too
-        const bool fast = (always_fast || affine_slot) ? true : (__ballot(den != 0.0) == 0ull);   // wave-uniform
+        const bool fast = __ballot(den != 0.0) == 0ull;                                // wave-uniform: no lane divides (cell_q)
         const double q = cell_q(num, den, h, fast);                                    // :234-235
         const double inter = fma(g0, q, v0);                                           // :237
         return fmax(fmax(fmax(v0, v1), inter), 0.0);                                   // :239-241
@@ -810,12 +826,14 @@ struct GroupChain {
             tp = (c1 < E) ? __builtin_huge_val() : 0.0 + (E - 0.0) / (c1 - 0.0) * (harg - 0.0);
             return true;
         }
-        if (p.n_grid == 0) { bound_constant(harg, E, tp, lb); return true; }
+        if (brent()) { bound_constant(harg, E, tp, lb); return true; }
         if constexpr (kZz) {
-            if (p.vectorized)
-                return p.signed_bound ? bound_advance_vect<true, FD>(harg, E, tp, lb, budget) : bound_advance_vect<false, FD>(harg, E, tp, lb, budget);
+            if (vectorized()) {
+                if constexpr (kReg) return bound_advance_vect<true, FD>(harg, E, tp, lb, budget);
+                else return zz_signed() ? bound_advance_vect<true, FD>(harg, E, tp, lb, budget) : bound_advance_vect<false, FD>(harg, E, tp, lb, budget);
+            }
         }
-        bound_invert_scalar<FD>(harg, E, tp, lb);
+        if constexpr (!(kReg && kZz)) bound_invert_scalar<FD>(harg, E, tp, lb);
         return true;
     }
 
@@ -1064,7 +1082,9 @@ struct GroupChain {
                 const double T = group_sum(lam, G);
                 if (ms_hit < 0 && (carry + T > theta)) { ms_hit = s; carry_at = carry; lam_hit = lam; }
                 carry = carry + T;
-                if (__ballot(ms_hit < 0) == 0ull) break;
+                // LDS form: stop once every chain of the wave has its slot.  Register form: straight-line code -- with 64/G chains per
+                // wave the last hit slot is nearly always one of the last, and without the ballot + branch the K slot totals interleave
+                if constexpr (!kReg) { if (__ballot(ms_hit < 0) == 0ull) break; }
             }
             int m = -1;
             {
@@ -1331,7 +1351,7 @@ struct GroupChain {
         int mode = FRESH;
         double hB = horizon;
         const int budget = (G == WAVE) ? GNG : cell_budget;               // one chain per wave: nobody to wait for
-        const bool resumable = kZz && p.vectorized && p.n_grid != 0 && !Tgt::kTile;   // bounds built by bound_advance_vect
+        const bool resumable = kZz && vectorized() && !brent() && !Tgt::kTile;   // bounds built by bound_advance_vect
 #ifdef PDMP_STAMP
         unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
 #define STAMP(k) do { unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[k] += now_ - st_last; st_last = now_; } while (0)
@@ -1483,6 +1503,7 @@ template <> struct GTarget<T_GAUSS_DENSE> {
     static constexpr bool kShared = true, kTile = true, kUser = false;
     static constexpr bool kLinear = false;     // (it is affine, but its slope lives in an LDS tile: keep the generic path)
     static constexpr int kAffineFrom = 1 << 30;
+    static constexpr bool kMonotone = false;
     static constexpr int kExtraTiles = 4;          // two gradient tiles, P v, scratch x_t
     template <class T> using Sh = DenseSh<T>;
     const double *P;

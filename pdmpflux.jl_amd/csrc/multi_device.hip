@@ -163,6 +163,9 @@ int pdmp_multi_sample_skeleton(pdmp_multi_handle m, int64_t C, int64_t n_sk, int
         if (hi[r] - lo[r] != hi[0] - lo[0]) equal = false;
         if (!X[r] || !V[r] || !t[r]) return failf(PDMP_ERR_ARGUMENT, "null per-device buffer");
     }
+    // ONE layout for every shard (results must not depend on which device a chain lands on): the occupancy choice for the largest shard
+    const int G = pdmp_suggest_group_lanes(m->h[0], hi[0] - lo[0]);
+    for (int r = 0; r < n; ++r) if (G > 0) { if (int rc = pdmp_set_group_lanes(m->h[r], G)) return rc; }
     const bool exchange = gather != 0 && n > 1;
     if (exchange && m->comm.empty()) {
         if (int rc = load_rccl()) return rc;

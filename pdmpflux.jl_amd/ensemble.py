@@ -222,8 +222,42 @@ def _all_gather_rows(local: torch.Tensor, C_total: int, world: int, group) -> to
     return torch.cat(parts, 0) if pad or world > 1 else full
 
 
+def _gather_in_place(full: torch.Tensor, C_total: int, rank: int, world: int, group, via_host: bool = False) -> None:
+    """The all-gather of one output array, in place: ``full`` holds ``C_total`` rows on every rank, rank r has filled rows
+    ``shard_range(C_total, r, world)``.  Equal shards: ONE all_gather_into_tensor whose input is this rank's slice of the output
+    (RCCL's in-place form: no staging copy; one direct exchange per xGMI peer link).  Unequal shards: one broadcast per shard
+    (all-gather-v).  ``via_host`` (rehearsals of GPU ranks under gloo) / CPU tensors: through a copy, gloo does not alias."""
+    import torch.distributed as dist
+    ranges = [shard_range(C_total, r, world) for r in range(world)]
+    lo, hi = ranges[rank]
+    equal = len({b - a for a, b in ranges}) == 1
+    if via_host or not full.is_cuda:
+        mine = full[lo:hi].cpu().clone()
+        if equal:
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine, group=group)
+        else:
+            parts = []
+            for r, (a, b) in enumerate(ranges):
+                buf = mine if r == rank else torch.empty((b - a,) + tuple(full.shape[1:]), dtype=full.dtype)
+                dist.broadcast(buf, src=dist.get_global_rank(group, r) if group is not None else r, group=group)
+                parts.append(buf)
+        for r, (a, b) in enumerate(ranges):
+            if r != rank:
+                full[a:b].copy_(parts[r])
+        return
+    if equal:
+        dist.all_gather_into_tensor(full, full[lo:hi], group=group)
+    else:
+        for r, (a, b) in enumerate(ranges):
+            if b > a:
+                dist.broadcast(full[a:b], src=dist.get_global_rank(group, r) if group is not None else r, group=group)
+
+
 def sample_skeleton_sharded(sampler: AbstractPDMP, n_sk: int, xinit: torch.Tensor, vinit: torch.Tensor, *, seed,
-                            gather: str = "none", N_samples: int | None = None, group=None, compute=None) -> dict:
+                            gather: str = "none", N_samples: int | None = None, group=None, compute=None,
+                            out_full: dict | None = None, check: bool = True, via_host: bool = False,
+                            lanes: str | int | None = None) -> dict:
     """Ensemble over all ranks of ``group``.  ``xinit``/``vinit`` hold ALL ``C_total`` chains on every
     rank (cheap: 16 d bytes per chain); this rank samples its contiguous shard.
 
@@ -232,6 +266,10 @@ def sample_skeleton_sharded(sampler: AbstractPDMP, n_sk: int, xinit: torch.Tenso
              "samples"   run sample_from_skeleton(N_samples) locally and all-gather the (C, N, d) samples
              "moments"   all-reduce sum(x), sum(x^2), count of the local samples (2d+1 doubles)
 
+    ``out_full`` (gather "none" / "skeleton"): preallocated tensors ``X, V (C_total, n_sk, d)``, ``t (C_total, n_sk)`` (for
+    "none": shard-sized); the shard is sampled straight into its rows and the gather runs in place (``_gather_in_place``).
+    ``lanes``: "auto" picks the lanes-per-chain layout from the largest shard (pdmp_suggest_group_lanes), an int pins it;
+    None leaves the handle as it is.  One layout for all ranks -- results are bit-identical across shardings for equal layouts.
     ``compute`` (tests only) replaces the HIP engine by a callable
     ``(x_shard, v_shard, chain0) -> {"X","V","t"}`` so the sharding logic can run under gloo on CPU.
     """
@@ -243,16 +281,36 @@ def sample_skeleton_sharded(sampler: AbstractPDMP, n_sk: int, xinit: torch.Tenso
     C_total = xinit.shape[0]
     lo, hi = shard_range(C_total, rank, world)
     xs, vs = xinit[lo:hi].contiguous(), vinit[lo:hi].contiguous()
+    if lanes is not None and compute is None:
+        G = sampler.suggest_group_lanes(shard_range(C_total, 0, world)[1]) if lanes == "auto" else int(lanes)
+        sampler.set_group_lanes(G)
+    local_out = None
+    if out_full is not None:
+        if gather not in ("none", "skeleton"):
+            raise ArgumentError("out_full serves gather = 'none' / 'skeleton'")
+        want = C_total if gather == "skeleton" else hi - lo
+        if any(out_full[k].shape[0] != want for k in ("X", "V", "t")):
+            raise DimensionMismatch(f"out_full tensors must hold {want} chains")
+        local_out = {k: (out_full[k][lo:hi] if gather == "skeleton" else out_full[k]) for k in ("X", "V", "t")}
     if compute is None:
-        res = sample_skeleton_device(sampler, n_sk, xs, vs, seed=seed, chain_id_offset=lo)
+        res = sample_skeleton_device(sampler, n_sk, xs, vs, seed=seed, chain_id_offset=lo, out=local_out, check=check)
     else:
         res = compute(xs, vs, lo)
+        if local_out is not None:
+            for k in ("X", "V", "t"):
+                local_out[k].copy_(res[k])
     res = dict(res)
     res["chain_range"] = (lo, hi)
     if gather == "none":
         return res
     if gather == "skeleton":
-        if world > 1:
+        if out_full is not None:
+            if world > 1:
+                for k in ("X", "V", "t"):
+                    _gather_in_place(out_full[k], C_total, rank, world, group, via_host=via_host)
+            for k in ("X", "V", "t"):
+                res[k] = out_full[k]
+        elif world > 1:
             for k in ("X", "V", "t"):
                 res[k] = _all_gather_rows(res[k], C_total, world, group)
         res["chain_range"] = (0, C_total)

@@ -101,6 +101,15 @@ class AbstractPDMP:
         G of the group kernel, or 0 for the wave-per-chain kernel."""
         return int(_lib.lib().pdmp_get_group_lanes(self.handle()))
 
+    def suggest_group_lanes(self, C: int) -> int:
+        """Lanes per chain that fill the GPU for launches of ``C`` chains (pdmp_suggest_group_lanes)."""
+        return int(_lib.lib().pdmp_suggest_group_lanes(self.handle(), int(C)))
+
+    def set_group_lanes(self, G: int) -> None:
+        """Select the lanes per chain of the following launches (pdmp_set_group_lanes; 0 = the default).  Changes the order of
+        the sums over coordinates: compare with a checker in ``ARITH_GROUP(G)`` of the same G."""
+        _lib.check(_lib.lib().pdmp_set_group_lanes(self.handle(), int(G)))
+
     def set_tape(self, exp_tape, uni_tape, nrm_tape):
         """Replay pre-recorded Exp(1) / U(0,1) / N(0,1) variates (arrays of shape ``(C, n_kind)``, row c = chain c,
         each kind in consumption order) instead of the Philox stream (pdmp_set_tape)."""

@@ -49,6 +49,14 @@ def _worker(rank, world, port, outdir):
     for mode in ("none", "skeleton", "samples", "moments"):
         r = ensemble.sample_skeleton_sharded(sampler, N_SK, x, v, seed=SEED, gather=mode, N_samples=N_SMP, compute=compute)
         res[mode] = {k: (val.numpy() if torch.is_tensor(val) else val) for k, val in r.items()}
+    # the path bench.py --gpus N runs every step: preallocated full-size buffers, shard sampled into its rows, gathered in place;
+    # ragged shards (7 chains: one broadcast per shard) and equal shards (the first 6 chains: one all-gather per array)
+    for tag, n in (("inplace_ragged", C_TOTAL), ("inplace_equal", 6)):
+        full = {"X": torch.zeros((n, N_SK, D), dtype=torch.float64), "V": torch.zeros((n, N_SK, D), dtype=torch.float64),
+                "t": torch.zeros((n, N_SK), dtype=torch.float64)}
+        r = ensemble.sample_skeleton_sharded(sampler, N_SK, x[:n], v[:n], seed=SEED, gather="skeleton", compute=compute, out_full=full)
+        assert r["X"] is full["X"] and r["chain_range"] == (0, n)
+        res[tag] = {k: full[k].numpy().copy() for k in ("X", "V", "t")}
     np.save(os.path.join(outdir, f"rank{rank}.npy"), np.array([res], dtype=object), allow_pickle=True)
     dist.barrier()
     dist.destroy_process_group()
@@ -71,6 +79,8 @@ def test_sharded_ensemble_world2(tmp_path, oracle):
         for k in ("X", "V", "t"):
             assert np.array_equal(res["none"][k], full[k][lo:hi]), (rank, k)           # shard = slice of the global run
             assert np.array_equal(res["skeleton"][k], full[k]), (rank, k)              # all-gather: everyone has everything
+            assert np.array_equal(res["inplace_ragged"][k], full[k]), (rank, k)        # bench.py's in-place exchange, ragged shards
+            assert np.array_equal(res["inplace_equal"][k], full[k][:6]), (rank, k)     # ... and equal shards
         assert np.array_equal(res["samples"]["samples"], full_s)
         flat = full_s.reshape(-1, D)
         np.testing.assert_allclose(res["moments"]["mean"], flat.mean(0), rtol=1e-12, atol=1e-14)
