@@ -384,6 +384,7 @@ typedef struct {
     double *fe_vo, *fe_e1, *fe_e2, *fe_z, *fe_g;   /* ForwardECMC velocity jump: d, d, d, d, 2d */
     double *vu, *actf;                     /* StickyZigZag: v .* is_active (PDMPState.v_active) and is_active as 0.0 / 1.0 */
     double step;
+    double lr_raw;                         /* affine-tail order (BPS, GROUP): the accepted proposal's g.v, reused by the bounce */
 } ws_t;
 
 static int ws_init(ws_t *w, int d, int n) {
@@ -524,9 +525,91 @@ static void fd_points(double t, double horizon, double *tm, double *tp) {
     *tp = (horizon < t + h) ? horizon : t + h;      /* min(horizon, x+h) */
 }
 
+/* "Affine tail" (GROUP order only; engine-order choice): BPS with forward-mode slopes on a potential whose gradient
+ * components i >= aff are affine in their own coordinate (isotropic / diagonal Gaussian: aff = 0; banana: aff = 2).  Along the
+ * linear flow the bounded function g(x + v t).v of BouncyParticleSamplers.jl:39-47 is then  head(t) + A + B t  with
+ *   A = sum_{i >= aff} g_i(x) v_i,   B = sum_{i >= aff} (dg_i/dx_i v_i) v_i   (one pass over the coordinates per state, summed in the
+ *   GROUP order: per lane left to right over i = g, g+G, ..., then the butterfly), and
+ *   head(t) = sum_{i < aff} g_i(x_t) v_i on forward-mode numbers -- two coordinates for the banana, evaluated in full at every time.
+ * Value and t-derivative at a grid time: f = head.v + fma(B, t, A), f' = head.e + B.  The reference evaluates all d coordinates
+ * at every grid time; the two agree up to the rounding of the sums (1e-5 tolerance test, tests/test_gpu_reference_order.py). */
+static int lr_mode(const orc_config_t *cfg) {
+    return cfg->arith == ORC_ARITH_GROUP && cfg->sampler == ORC_BPS && cfg->deriv_mode == ORC_DERIV_FORWARD &&
+           (cfg->target_id == ORC_T_GAUSS_ISO || cfg->target_id == ORC_T_GAUSS_DIAG || cfg->target_id == ORC_T_BANANA);
+}
+static int lr_aff(const orc_config_t *cfg) { return (cfg->target_id == ORC_T_BANANA && cfg->dim >= 2) ? 2 : 0; }
+static void lr_coeffs(const orc_config_t *cfg, ws_t *w, const double *x, const double *v, double *A, double *B) {
+    const int d = w->d, aff = lr_aff(cfg);
+    grad_dual(cfg, x, v, w->gv, w->ge);                     /* g_i(x) and dg_i/dx_i v_i of the affine components (head entries unused) */
+    for (int i = 0; i < d; ++i) {
+        w->tmp[i] = (i >= aff) ? w->gv[i] * v[i] : 0.0;
+        w->tmp2[i] = (i >= aff) ? w->ge[i] * v[i] : 0.0;
+    }
+    *A = sum_group(w->tmp, d, cfg->group_lanes);
+    *B = sum_group(w->tmp2, d, cfg->group_lanes);
+}
+static double lr_func(const orc_config_t *cfg, const double *x, const double *v, double A, double B, double t, double *slp) {
+    double fv = fma(B, t, A), fe = B;
+    if (lr_aff(cfg)) {                                      /* banana head: coordinates 0 and 1 (test/test_config.jl:33-36) */
+        const double x0v = fma(v[0], t, x[0]), x0e = v[0], x1v = fma(v[1], t, x[1]), x1e = v[1];
+        double sq_v = x0v * x0v, sq_e = x0e * x0v + x0v * x0e;
+        double m_v = sq_v - 1.0, m_e = sq_e;
+        double r_v = x1v - m_v, r_e = x1e - m_e;
+        double a_v = 2.0 * x0v, a_e = 2.0 * x0e;
+        double pr_v = a_v * r_v, pr_e = a_e * r_v + a_v * r_e;
+        const double g0v = x0v - pr_v, g0e = x0e - pr_e;
+        const double hv = (0.0 + g0v * v[0]) + r_v * v[1], he = (0.0 + g0e * v[0]) + r_e * v[1];
+        fv = hv + fv; fe = he + fe;
+    }
+    if (slp) *slp = fe;
+    return fv;
+}
+
+/* "Quadratic form" (GROUP order only; engine-order choice): Boomerang on the isotropic Gaussian.  Along the rotation
+ * x_t = x cos t + v sin t, v_t = -x sin t + v cos t (BoomerangSamplers.jl:31) the bounded function grad-U(x_t).v_t = x_t.v_t of
+ * :38-46 is  XV (c^2 - s^2) + (VV - XX) s c  with the three dot products XX = x.x, XV = x.v, VV = v.v of the state (GROUP order:
+ * per lane left to right, then the butterfly), its t-derivative  XV (-4 s c) + (VV - XX) (c^2 - s^2).  One pass over the
+ * coordinates per state instead of one per grid time (and per finite-difference point: 30 per bound with AD_backend="FiniteDiff"). */
+static int lrb_mode(const orc_config_t *cfg) {
+    return cfg->arith == ORC_ARITH_GROUP && cfg->sampler == ORC_BOOMERANG && cfg->target_id == ORC_T_GAUSS_ISO;
+}
+static void lrb_coeffs(const orc_config_t *cfg, ws_t *w, const double *x, const double *v, double *XX, double *XV, double *VV) {
+    const int d = w->d, G = cfg->group_lanes;
+    for (int i = 0; i < d; ++i) w->tmp[i] = x[i] * x[i];
+    *XX = sum_group(w->tmp, d, G);
+    for (int i = 0; i < d; ++i) w->tmp[i] = x[i] * v[i];
+    *XV = sum_group(w->tmp, d, G);
+    for (int i = 0; i < d; ++i) w->tmp[i] = v[i] * v[i];
+    *VV = sum_group(w->tmp, d, G);
+}
+static double lrb_raw(double XX, double XV, double VV, double t, double *de) {
+    double sn, cs; orc_sincos(t, &sn, &cs);
+    const double cc = cs * cs, ss = sn * sn, sc = sn * cs, dq = VV - XX;
+    if (de) *de = XV * (-4.0 * sc) + dq * (cc - ss);
+    return XV * (cc - ss) + dq * sc;
+}
+/* the scalar bounded function of the bound (signed_rate / rate incl. refresh_rate, BoomerangSamplers.jl:38-46; Q2) */
+static double lrb_sc(const orc_config_t *cfg, double XX, double XV, double VV, double t, double *slp) {
+    double de, dv = lrb_raw(XX, XV, VV, t, &de);
+    if (cfg->signed_bound) { if (slp) *slp = de; return dv + cfg->refresh_rate; }
+    if (slp) *slp = (0.0 < dv) ? de : 0.0;
+    return pmax(0.0, dv) + cfg->refresh_rate;
+}
+
 /* The unsigned total rate used by the accept test (always `sampler.rate`, SamplingLoopInplace.jl:116; Q3) */
 static double true_rate(const orc_config_t *cfg, ws_t *w, double t) {
     if (cfg->sampler == ORC_RHMC) return cfg->refresh_rate;          /* rate = (_x0, _v0, _t) -> refresh_rate, :133 */
+    if (lrb_mode(cfg)) {
+        double XX, XV, VV;
+        lrb_coeffs(cfg, w, w->x, w->v, &XX, &XV, &VV);
+        return pmax(0.0, lrb_raw(XX, XV, VV, t, NULL)) + cfg->refresh_rate;
+    }
+    if (lr_mode(cfg)) {
+        double A, B;
+        lr_coeffs(cfg, w, w->x, w->v, &A, &B);
+        w->lr_raw = lr_func(cfg, w->x, w->v, A, B, t, NULL);
+        return pmax(0.0, w->lr_raw) + cfg->refresh_rate;
+    }
     flow_dual(cfg, w, w->x, w->v, t);
     grad_dual(cfg, w->xv, w->xe, w->gv, w->ge);
     if (cfg->sampler == ORC_SUZZ) suzz_effective(cfg, w, w->xv, w->xe, w->gv, w->ge);
@@ -624,8 +707,26 @@ static void upper_bound(const orc_config_t *cfg, ws_t *w, const double *x, const
     /* scalar grid bound, :92-137 */
     double *val = w->vals, *slp = w->slps;
     const double refresh = cfg->signed_bound ? cfg->refresh_rate : 0.0;    /* AbstractPDMP.jl:104-112 */
+    double lrA = 0.0, lrB = 0.0, qXX = 0.0, qXV = 0.0, qVV = 0.0;
+    if (lr_mode(cfg)) lr_coeffs(cfg, w, x, v, &lrA, &lrB);
+    if (lrb_mode(cfg)) lrb_coeffs(cfg, w, x, v, &qXX, &qXV, &qVV);
     for (int j = 0; j < n; ++j) {
-        if (cfg->deriv_mode == ORC_DERIV_FORWARD) {
+        if (lrb_mode(cfg)) {                                                  /* quadratic-form order: both slope modes */
+            if (cfg->deriv_mode == ORC_DERIV_FORWARD) { val[j] = lrb_sc(cfg, qXX, qXV, qVV, t[j], &slp[j]); continue; }
+            val[j] = lrb_sc(cfg, qXX, qXV, qVV, t[j], NULL);
+            double tm, tp; fd_points(t[j], horizon, &tm, &tp);
+            if (tp == tm) slp[j] = val[j] - val[j];
+            else if (tm == t[j]) slp[j] = (lrb_sc(cfg, qXX, qXV, qVV, tp, NULL) - val[j]) / (tp - t[j]);
+            else if (tp == t[j]) slp[j] = (val[j] - lrb_sc(cfg, qXX, qXV, qVV, tm, NULL)) / (t[j] - tm);
+            else { double fp = lrb_sc(cfg, qXX, qXV, qVV, tp, NULL), fm = lrb_sc(cfg, qXX, qXV, qVV, tm, NULL);
+                slp[j] = (fp - fm) / (tp - tm); }
+            continue;
+        }
+        if (lr_mode(cfg)) {                                                   /* affine-tail order: same function, O(1) per grid time */
+            double de, dv = lr_func(cfg, x, v, lrA, lrB, t[j], &de);
+            if (cfg->signed_bound) { val[j] = dv + cfg->refresh_rate; slp[j] = de; }
+            else { val[j] = pmax(0.0, dv) + cfg->refresh_rate; slp[j] = (0.0 < dv) ? de : 0.0; }
+        } else if (cfg->deriv_mode == ORC_DERIV_FORWARD) {
             val[j] = sc_func_dual(cfg, w, x, v, t[j], &slp[j]);               /* :97,:102 */
         } else {
             val[j] = sc_func_dual(cfg, w, x, v, t[j], NULL);
@@ -867,6 +968,7 @@ static int velocity_jump(const orc_config_t *cfg, ws_t *w, rng_t *rng) {
     if (cfg->sampler == ORC_BOOMERANG) for (int i = 0; i < d; ++i) g[i] = g[i] - w->x[i];   /* :51-52 (Q8) */
     for (int i = 0; i < d; ++i) w->tmp[i] = g[i] * w->v[i];
     double gv_dot = vsum(cfg, w->tmp, d);
+    if (lr_mode(cfg)) gv_dot = w->lr_raw;                     /* the engine reuses the accepted proposal's g.v (same point, same state) */
     double bounce = pmax(0.0, gv_dot);
     double prob = bounce / (bounce + cfg->refresh_rate);      /* NaN when both are 0 (Q9) */
     double u = rng_uniform(rng);

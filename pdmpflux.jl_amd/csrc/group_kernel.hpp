@@ -410,6 +410,79 @@ struct GroupChain {
         else return gd.e * vt.v;
     }
 
+    // ---- "Affine tail" (arithmetic contract, GROUP order; mirrored by the checker's lr_* functions): BPS with forward-mode slopes on a
+    // potential whose gradient components i >= aff are affine in their own coordinate (Gaussians: aff = 0; banana: aff = 2).  Along the
+    // linear flow the bounded function g(x + v t).v (BouncyParticleSamplers.jl:39-47) is  head(t) + A + B t  with
+    //   A = sum_{i >= aff} g_i(x) v_i,  B = sum_{i >= aff} (dg_i/dx_i v_i) v_i  -- ONE pass over the coordinates per state (x, v) --
+    //   head(t) = sum_{i < aff} g_i(x_t) v_i on forward-mode numbers (the banana's two twisted coordinates, evaluated by every lane of
+    //   the chain's group from broadcast copies: no cross-lane sum per grid time).
+    // Every grid time of every bound and the proposal's rate then cost O(1) instead of a pass over d coordinates and two butterflies:
+    // BPS on the banana went from 404 to ~100 VALU instructions per event.
+    static constexpr bool kLowRank = SAMPLER == S_BPS && !FD && !Tgt::kTile && !Tgt::kUser;
+    double lr_A = 0.0, lr_B = 0.0, lr_x0 = 0.0, lr_v0 = 0.0, lr_x1 = 0.0, lr_v1 = 0.0;
+    mutable bool lr_ok = false;                  // (lr_A, lr_B, head copies) belong to the current (x, v)
+    __device__ __forceinline__ int lr_aff() const { return (Tgt::kAffineFrom > 0 && Tgt::kAffineFrom < (1 << 30) && p.d >= 2) ? Tgt::kAffineFrom : 0; }
+    __device__ __forceinline__ void lr_prepare() {
+        if (__ballot(!lr_ok) == 0ull) return;
+        const int aff = lr_aff();
+        double a = 0.0, b = 0.0;
+        const typename Tgt::template Sh<Dual> nosh{};                      // (an affine component reads no other coordinate)
+        PDMP_SLOTS(s) {
+            const int i = s * G + g;
+            const bool tail = in_dim(s, i) && i >= aff;
+            const Dual gd = tgt.grad(in_dim(s, i) ? i : 0, Dual{X(s), V(s)}, nosh);
+            const double ta = gd.v * V(s), tb = gd.e * V(s);
+            a += tail ? ta : 0.0;
+            b += tail ? tb : 0.0;
+        }
+        a = group_sum(a, G);
+        b = group_sum(b, G);
+        double x0 = 0.0, v0 = 0.0, x1 = 0.0, v1 = 0.0;
+        if (aff > 0) { coord(0, x0, v0); coord(1, x1, v1); }
+        if (!lr_ok) { lr_A = a; lr_B = b; lr_x0 = x0; lr_v0 = v0; lr_x1 = x1; lr_v1 = v1; lr_ok = true; }
+    }
+    // value (and t-derivative) of g(x_t).v at time t from the prepared coefficients
+    __device__ __forceinline__ void lr_eval(double t, double &fv, double &fe) const {
+        fv = fma(lr_B, t, lr_A);
+        fe = lr_B;
+        if constexpr (Tgt::kShared && !Tgt::kTile && !Tgt::kUser) {        // a twisted head: the banana's coordinates 0 and 1
+            if (lr_aff() > 0) {
+                const Dual a{fma(lr_v0, t, lr_x0), lr_v0}, b{fma(lr_v1, t, lr_x1), lr_v1};
+                const auto sh = tgt.template shared<Dual>(a, b);           // {g_0, g_1}
+                const double hv = (0.0 + sh.g0.v * lr_v0) + sh.r.v * lr_v1, he = (0.0 + sh.g0.e * lr_v0) + sh.r.e * lr_v1;
+                fv = hv + fv;
+                fe = he + fe;
+            }
+        }
+    }
+
+    // ---- "Quadratic form" (arithmetic contract, GROUP order; mirrored by the checker's lrb_* functions): Boomerang on the isotropic
+    // Gaussian.  Along the rotation (BoomerangSamplers.jl:31) the bounded function x_t . v_t of :38-46 is
+    //   XV (c^2 - s^2) + (VV - XX) s c,   d/dt = XV (-4 s c) + (VV - XX) (c^2 - s^2),   XX = x.x, XV = x.v, VV = v.v of the state:
+    // one pass over the coordinates per state instead of one per grid time and finite-difference point (30 per bound with the
+    // constructor's default AD_backend = "FiniteDiff"); what remains per point is its sin / cos.
+    static constexpr bool kQuad = SAMPLER == S_BOOMERANG && TARGET == T_GAUSS_ISO;
+    double q_xx = 0.0, q_xv = 0.0, q_vv = 0.0;
+    __device__ __forceinline__ void q_prepare() {
+        if (__ballot(!lr_ok) == 0ull) return;
+        double a = 0.0, b = 0.0, c = 0.0;
+        PDMP_SLOTS(s) { const double x = X(s), v = V(s); a += x * x; b += x * v; c += v * v; }    // (padded coordinates hold zeros)
+        a = group_sum(a, G); b = group_sum(b, G); c = group_sum(c, G);
+        if (!lr_ok) { q_xx = a; q_xv = b; q_vv = c; lr_ok = true; }
+    }
+    __device__ __forceinline__ double q_raw(const TimePt &tp, double *de) const {
+        const double cc = tp.c * tp.c, ss = tp.s * tp.s, sc = tp.s * tp.c, dq = q_vv - q_xx;
+        if (de) *de = q_xv * (-4.0 * sc) + dq * (cc - ss);
+        return q_xv * (cc - ss) + dq * sc;
+    }
+    __device__ __forceinline__ double q_bounded(const TimePt &tp, double *slp) const {     // signed_rate / rate incl. refresh_rate (Q2)
+        double de;
+        const double dv = q_raw(tp, &de);
+        const bool sgn = p.signed_bound != 0;
+        if (slp) *slp = sgn ? de : ((0.0 < dv) ? de : 0.0);
+        return (sgn ? dv : fmax(0.0, dv)) + p.refresh;
+    }
+
     // ---- tangent-intersection cell, UpperBound.jl:229-241 (absolute-time form, Q1) / :123-130
     // den == 0 (every Gaussian coordinate) gives num/0 = +-Inf or NaN, which the reference's
     // NaN->0 + clamp turns into h or 0: same bits as the division path, no v_div sequence.
@@ -719,6 +792,45 @@ struct GroupChain {
             f0 = f1;
             s0 = s1;
         };
+        if constexpr (kQuad) {
+            q_prepare();
+            auto point = [&](double t, double &val, double &slp) {
+                if constexpr (!FDM) {
+                    TimePt tq;
+                    time_pt(t, tq);
+                    val = q_bounded(tq, &slp);                                         // :97, :102
+                } else {                                                               // :117-118, finite differences :50-76
+                    FdPt P;
+                    fd_point(t, harg, P);
+                    val = q_bounded(P.c, nullptr);
+                    slp = fd_slope(P, val, q_bounded(P.m, nullptr), q_bounded(P.pl, nullptr));
+                }
+            };
+            point(0.0, f0, s0);
+            for (int j = 0; j < GNG - 1; ++j) {
+                double f1, s1;
+                point((j == GNG - 2) ? harg : (double)(j + 1) * h, f1, s1);
+                cell(j, f1, s1);
+                if (__ballot(!found) == 0ull) break;
+            }
+        } else
+        if constexpr (kLowRank && !FDM) {
+            lr_prepare();
+            const bool sgn = p.signed_bound != 0;
+            auto point = [&](double t, double &val, double &slp) {
+                double dv, de;
+                lr_eval(t, dv, de);
+                val = (sgn ? dv : fmax(0.0, dv)) + p.refresh;                          // includes refresh_rate (Q2)
+                slp = sgn ? de : ((0.0 < dv) ? de : 0.0);
+            };
+            point(0.0, f0, s0);
+            for (int j = 0; j < GNG - 1; ++j) {                                        // lazy, cell by cell: a grid time is O(1) now
+                double f1, s1;
+                point((j == GNG - 2) ? harg : (double)(j + 1) * h, f1, s1);
+                cell(j, f1, s1);
+                if (__ballot(!found) == 0ull) break;
+            }
+        } else
         if constexpr (!FDM && !Tgt::kTile) {
             // lazy in batches of three cells: grid times {0,1,2,3}, {4,5,6}, {7,8,9}, one coordinate pass per batch
             {
@@ -843,6 +955,19 @@ struct GroupChain {
     // sum(lambda) (Zig-Zag) / dot(grad-U, v) (BPS) is this very number and is not recomputed.
     __device__ __forceinline__ double true_rate(double t, double &raw) {
         if constexpr (SAMPLER == S_RHMC) { raw = 0.0; return p.refresh; }      // rate = (_x0, _v0, _t) -> refresh_rate, :133
+        if constexpr (kQuad) {
+            q_prepare();
+            TimePt tq;
+            time_pt(t, tq);
+            raw = q_raw(tq, nullptr);
+            return fmax(0.0, raw) + p.refresh;                                  // Boomerang :38-41
+        }
+        if constexpr (kLowRank) {
+            lr_prepare();                                                       // (already prepared by the bound on the grid path)
+            double fe;
+            lr_eval(t, raw, fe);
+            return fmax(0.0, raw) + p.refresh;                                  // BPS :39-42
+        }
         TimePt tp;
         time_pt(t, tp);
         const auto sh = shared_at<double>(tp);
@@ -917,6 +1042,7 @@ struct GroupChain {
             if constexpr (SAMPLER == S_BOOMERANG) V(s) = vt;
         }
         sz_ok = false;
+        lr_ok = false;
     }
 
     // ---- velocity_jump: ZigZagSamplers.jl:101-107, BouncyParticleSamplers.jl:50-74, BoomerangSamplers.jl:49-67
@@ -1046,6 +1172,7 @@ struct GroupChain {
     // returns true when the chain asks for a velocity refresh: the normals are drawn by refresh_velocities(), outside the
     // divergent accept branch, with all 64 lanes of the wave
     __device__ __forceinline__ bool velocity_jump(double raw) {
+        lr_ok = false;
         TimePt t0;
         t0.t = 0.0; t0.s = 0.0; t0.c = 1.0; t0.sp = 1.0; t0.spe = 0.0;
         if constexpr (SAMPLER == S_SUZZ) suzz_speed(t0, true);          // speed(x) of the state itself, SpeedUpZigZagSamplers.jl:104
@@ -1201,6 +1328,7 @@ struct GroupChain {
             }
         }
         if (mine) {
+            lr_ok = false;
             rng.normals_done(d);
             if constexpr (kReg) { PDMP_SLOTS(s) vr[s] = in_dim(s, s * G + g) ? vs[s * WAVE + lane] : 0.0; }   // register form: vs is an exchange tile only
             double acc = 0.0;
@@ -1331,6 +1459,7 @@ struct GroupChain {
         rng.init_lane(p.seed, (uint64_t)(p.chain0 + c));
         rng.restore(n0);
         amask = 0xffffffffu;                                              // is_active = trues(d), Composites.jl:95 (StickyZigZag runs in one segment)
+        lr_ok = false;
         if constexpr (Tgt::kTile) tgt.b_valid = false;
         double ts = 0.0, tp = 0.0, E = 0.0, lb = 0.0;
         int32_t errored = 0, rejected = 0, hits = 0;
@@ -1605,7 +1734,10 @@ template <int SAMPLER, int TARGET, bool FD> struct RegForm {
 // instantiations must stay free of VGPR spills (a spill under a partial exec mask loses the inactive lanes' values, and
 // lanes of different chains run different branches here): `make check-spills`
 template <int SAMPLER, int TARGET, bool FD, int KC, int GC, bool FULL>
-__global__ __launch_bounds__(256, 2) void group_kernel_reg(const GroupParams gp_in) {
+#ifndef PDMP_REG_WAVES
+#define PDMP_REG_WAVES 2
+#endif
+__global__ __launch_bounds__(256, PDMP_REG_WAVES) void group_kernel_reg(const GroupParams gp_in) {
     GroupParams gp = gp_in;
     gp.G = GC;                 // the host launches this instantiation only for G == GC, K <= KC: folds every use of G
     if (FULL) gp.K = KC;       // ... and the FULL one only for K == KC: the per-slot skips fold away too

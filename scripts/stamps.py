@@ -2,7 +2,7 @@ import sys, os, shutil, ctypes as C
 sys.path.insert(0, '.')
 # diagnostic build: swap the library in a scratch copy of the package dir is not needed -- load it by path
 import pdmpflux.jl_amd._lib as L
-L.LIB_PATH = os.path.abspath("scratch/libpdmphip_stamp.so")   # make -C pdmpflux.jl_amd/csrc stamp
+L.LIB_PATH = os.path.abspath("pdmpflux.jl_amd/libpdmphip_stamp.so")   # make -C pdmpflux.jl_amd/csrc stamp (git-ignored; travels with gpurun)
 import torch
 import pdmpflux.jl_amd as P
 from pdmpflux.jl_amd import ensemble
