@@ -239,7 +239,9 @@ def main():
     C_max = ensemble.shard_range(C_total, 0, world)[1]                 # the largest shard (rank 0)
     # ONE layout for all ranks (the order of the sums over coordinates depends on it): from the largest shard
     if a.lanes == "auto":
-        sampler.set_group_lanes(sampler.suggest_group_lanes(C_max))
+        G_auto = sampler.suggest_group_lanes(C_max)
+        if G_auto != sampler.group_lanes():
+            sampler.set_group_lanes(G_auto)
     elif a.lanes != "default":
         sampler.set_group_lanes(int(a.lanes))
     gather = a.gather if world > 1 else "none"

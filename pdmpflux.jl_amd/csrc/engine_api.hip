@@ -223,6 +223,91 @@ __global__ __launch_bounds__(256) void from_skeleton_kernel(int d, int64_t C, in
     }
 }
 
+// The same samples, streamed: the common case (linear flow or Boomerang rotation) as a flat copy-like kernel.  One wave per (chain,
+// tile of 64 samples) as above, but instead of 64 serial row copies the tile's 64 x rows output elements are walked in memory
+// order -- element e = 64 k + lane belongs to sample e / rows, row entry e % rows -- so every store instruction writes 512
+// contiguous bytes and every lane works (a d = 50 row fills 50 of 64 lanes in the row-per-iteration form); the per-sample segment
+// index, residual time and sin / cos sit in LDS.  Four elements per lane in flight.  HBM-bound: 8(2d+1) B read per touched event +
+// 8 rows B written per sample.
+template <bool BOOMERANG>
+__global__ __launch_bounds__(256) void from_skeleton_flat_kernel(int d, int64_t C, int64_t n_sk, const double *X, const double *V,
+                                                                 const double *t, int64_t N, double dt_in, int discard_vt, double *out,
+                                                                 const uint8_t *IA, int ia_mode, int strict, int64_t n_use,
+                                                                 const int64_t *lens, int64_t *counts) {
+    __shared__ int seg_s[4][WAVE];
+    __shared__ double tau_s[4][WAVE], tm_s[4][WAVE], sn_s[4][WAVE], cs_s[4][WAVE];
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const int64_t tiles = (N + WAVE - 1) / WAVE;
+    const int64_t w = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wv);
+    if (w >= C * tiles) return;
+    const int64_t c = w / tiles, tile = w % tiles;
+    const double *tc = t + (size_t)c * n_sk;
+    int64_t nh = (n_use > 0 && n_use < n_sk) ? n_use : n_sk;
+    if (lens) { const int64_t l = lens[c]; nh = (l > 0 && l < nh) ? l : nh; }
+    const double dt = dt_in > 0.0 ? dt_in : tc[nh - 1] / (double)N;   // :483-484
+    int64_t nmax = N;
+    if (dt_in > 0.0 && counts) {                                      // n_skel = Int(floor(T_end / dt)), :608
+        const double q = floor(tc[nh - 1] / dt_in);
+        nmax = (q < (double)N) ? (int64_t)q : N;
+        if (tile == 0 && lane == 0) counts[c] = nmax;
+    }
+    const int64_t j = tile * WAVE + lane + 1;                         // 1-based sample index
+    const double tm = (double)j * dt;                                 // :492
+    int lo = 0, hi = (int)nh - 1;
+    if (j <= nmax) {
+        while (lo < hi) {                                             // last index with t[i] <= tm (strict: t[i] < tm)
+            const int mid = (lo + hi + 1) >> 1;
+            const bool le = strict ? (tc[mid] < tm) : (tc[mid] <= tm);
+            if (le) lo = mid; else hi = mid - 1;
+        }
+    }
+    const double tau = tm - tc[lo];                                   // :497
+    double sn = 0.0, cs = 1.0;
+    if (BOOMERANG) det_sincos(tau, sn, cs);
+    seg_s[wv][lane] = lo; tau_s[wv][lane] = tau; tm_s[wv][lane] = tm; sn_s[wv][lane] = sn; cs_s[wv][lane] = cs;
+    __builtin_amdgcn_wave_barrier();                                  // (LDS traffic of one wave is ordered; the barrier only stops reordering by the compiler)
+    int64_t nvalid = (nmax - tile * WAVE) < WAVE ? (nmax - tile * WAVE) : WAVE;
+    if (nvalid <= 0) return;
+    const int rows = discard_vt ? d : 2 * d + 1;                      // :487
+    const int total = (int)nvalid * rows;
+    const double *Xc = X + (size_t)c * n_sk * d, *Vc = V + (size_t)c * n_sk * d;
+    const uint8_t *Ac = (IA && ia_mode) ? IA + (size_t)c * n_sk * d : nullptr;
+    double *o = out + ((size_t)c * N + (size_t)tile * WAVE) * rows;
+    const unsigned long long magic = 0x100000000ull / (unsigned)rows;        // floor(2^32 / rows): (e * magic) >> 32 is e / rows or one less
+    constexpr int U = 4;
+    for (int e0 = lane; e0 < total; e0 += U * WAVE) {
+        double xv[U], vv[U], ta[U], s1[U], c1[U], tmv[U];
+        int r[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * WAVE;
+            ok[u] = e < total;
+            const int ee = ok[u] ? e : 0;
+            int smp = (int)(((unsigned long long)(unsigned)ee * magic) >> 32);   // (rows = 1: magic = 2^32, exact)
+            if ((smp + 1) * rows <= ee) ++smp;
+            r[u] = ee - smp * rows;
+            const int q = r[u] < d ? r[u] : (r[u] < 2 * d ? r[u] - d : 0);
+            const size_t off = (size_t)seg_s[wv][smp] * d + q;
+            xv[u] = Xc[off];
+            double vq = Vc[off];
+            if (Ac) { const uint8_t a = Ac[off]; vq = (ia_mode == 2) ? vq * (a ? 1.0 : 0.0) : (a ? vq : 0.0); }   // :547-549 / :667
+            vv[u] = vq;
+            ta[u] = tau_s[wv][smp]; tmv[u] = tm_s[wv][smp];
+            s1[u] = sn_s[wv][smp]; c1[u] = cs_s[wv][smp];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            double val;
+            if (r[u] < d) val = BOOMERANG ? xv[u] * c1[u] + vv[u] * s1[u] : xv[u] + vv[u] * ta[u];             // BoomerangSamplers.jl:31 / ZigZagSamplers.jl:80
+            else if (r[u] < 2 * d) val = BOOMERANG ? (-xv[u]) * s1[u] + vv[u] * c1[u] : vv[u];
+            else val = tmv[u];                                                                                      // :505-508
+            o[e0 + u * WAVE] = val;
+        }
+    }
+}
+
 // Closing point of the time-horizon variant sample_skeleton(sampler, T::Float64, ...) (src/sample.jl:323-439), on the device:
 // per chain, count[c] = number of history columns once the chain is cut at T -- the events with t <= T (:372) plus, when the
 // last of them lies strictly before T, one closing column at exactly t = T obtained by flow from it (:385-420), which
@@ -649,7 +734,7 @@ int pdmp_set_group_lanes(pdmp_handle h, int32_t G) {
     if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
     const pdmp_config_t &c = h->cfg;
     const int def = choose_group_lanes(c);
-    if (G == 0) { h->group_lanes = def; return PDMP_OK; }
+    if (G == 0 || G == def) { h->group_lanes = def; return PDMP_OK; }
     if (def <= 0 || c.target_id == PDMP_T_GAUSS_DENSE)
         return fail(PDMP_ERR_UNSUPPORTED, "this configuration does not run on the group kernel with a free lane count");
     if (G < 1 || G > WAVE || (G & (G - 1)) != 0) return fail(PDMP_ERR_ARGUMENT, "lanes per chain must be a power of two in 1..64. Current value: %d", (int)G);
@@ -956,7 +1041,15 @@ static int from_skeleton_launch(pdmp_handle h, int method, int64_t C, int64_t n_
     hipStream_t s = (hipStream_t)stream;
     EventPair ev;
     if (int rc = begin_timed(h, s, ev)) return rc;
-    if (h->cfg.sampler == PDMP_BOOMERANG)
+    const bool flat = h->cfg.sampler != PDMP_SUZZ && h->cfg.sampler != PDMP_RHMC && (2 * (int64_t)h->cfg.dim + 1) * WAVE < (1ll << 31) / (2 * (int64_t)h->cfg.dim + 1) &&
+                      !getenv("PDMP_FROM_SKELETON_ROWS");            // (env: the row-per-iteration kernel, for A/B runs)
+    if (flat && h->cfg.sampler == PDMP_BOOMERANG)
+        hipLaunchKernelGGL(from_skeleton_flat_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, dt, (int)discard_vt, out,
+                           is_active, ia_mode, (int)(method == 2), n_prefix, lens, counts);
+    else if (flat)
+        hipLaunchKernelGGL(from_skeleton_flat_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, dt, (int)discard_vt, out,
+                           is_active, ia_mode, (int)(method == 2), n_prefix, lens, counts);
+    else if (h->cfg.sampler == PDMP_BOOMERANG)
         hipLaunchKernelGGL(from_skeleton_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, dt, (int)discard_vt, out, 0,
                            -1, 0.0, (const double *)nullptr, is_active, ia_mode, (int)(method == 2), n_prefix, lens, counts);
     else

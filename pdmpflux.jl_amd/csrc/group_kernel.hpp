@@ -558,7 +558,7 @@ struct GroupChain {
     template <bool SIGNED, bool FDM>
     __device__ __forceinline__ bool bound_advance_vect(double harg, double E, double &tpo, double &lbo, int budget) {
         const double h = harg / (double)(GNG - 1);
-        bool found = false;
+        bool found = false, found_now = false;
 #ifdef PDMP_STAMP
         if (lane == 0 && p.stamps) atomicAdd(&p.stamps[7], 1ull);
 #endif
@@ -633,7 +633,7 @@ struct GroupChain {
                 const double cj = b_acc * h;
                 if (!(cj < E)) {                                                       // searchsortedfirst, :265
                     found = true;
-                    tpo = t0 + (E - b_cprev) / (cj - b_cprev) * h;                     // :269
+                    found_now = true;                                                  // the division of :269 follows the loop: once per pass
                     lbo = bj;                                                          // :270
                 }
                 b_cbefore = b_cprev;
@@ -642,6 +642,8 @@ struct GroupChain {
                 b_next = j + 1;
             }
         }
+        // next_event, :269, for the chains that found their cell in this pass: cell b_next - 1, cum_sum b_cbefore before and b_cprev after it
+        if (found_now) tpo = (double)(b_next - 1) * h + (E - b_cbefore) / (b_cprev - b_cbefore) * h;
         const bool fin = found || b_next >= GNG - 1;
         if (fin && !found) lbo = b_last;                                               // box_max[end], :270
         return fin;
@@ -769,6 +771,8 @@ struct GroupChain {
         double acc = 0.0, cprev = 0.0, bj = 0.0, f0, s0;
         bool found = false;
         tpo = __builtin_huge_val();
+        int inv_j = 0;
+        double inv_c0 = 0.0, inv_c1 = 1.0;
         auto cell = [&](int j, double f1, double s1) {                                 // cell j from grid times j (f0, s0) and j+1
             const double num = fma(s1, h, f0 - f1);                                    // :123 relative form
             // equal slopes at both ends in every lane (affine gradients under the signed bound: the slope is the same sum at
@@ -783,15 +787,16 @@ struct GroupChain {
             bj += refresh;                                                             // :131
             acc += bj;
             const double cj = acc * h;                                                 // :133-134
-            if (!found && !(cj < E)) {
-                found = true;
-                tpo = (double)j * h + (E - cprev) / (cj - cprev) * h;
+            if (!found && !(cj < E)) {                                                 // searchsortedfirst, :265 -- the inversion's division
+                found = true;                                                          // (:269) is done ONCE after the loop (inv_*), not in
+                inv_j = j; inv_c0 = cprev; inv_c1 = cj;                                // every cell some chain of the wave finishes in
                 lbo = bj;
             }
             cprev = cj;
             f0 = f1;
             s0 = s1;
         };
+
         if constexpr (kQuad) {
             q_prepare();
             auto point = [&](double t, double &val, double &slp) {
@@ -861,7 +866,8 @@ struct GroupChain {
                 if (__ballot(!found) == 0ull) break;
             }
         }
-        if (!found) lbo = bj;
+        if (found) tpo = (double)inv_j * h + (E - inv_c0) / (inv_c1 - inv_c0) * h;     // next_event, :269
+        else lbo = bj;
     }
     // ---- upper_bound_constant (UpperBound.jl:18-36) + next_event for grid_size == 0: the UNSIGNED rate
     // (AbstractPDMP.jl:121-125) is maximised over [0, harg] by Brent's method -- Optim.jl's univariate Brent()
@@ -1310,19 +1316,48 @@ struct GroupChain {
     // same arithmetic: the normals are those of the chain-local loop.
     __device__ __forceinline__ void refresh_velocities(bool mine) {
         const int d = p.d, logG = __builtin_ctz(G);
-        unsigned long long todo = __ballot(mine && g == 0);
-        while (todo != 0ull) {
-            const int L = (int)__builtin_ctzll(todo);                     // first lane of the chain
-            todo &= todo - 1ull;
-            ChainRng r = rng;                                             // seed words are the same in every lane
-            r.c2 = (uint32_t)__builtin_amdgcn_readlane((int)rng.c2, L);
-            r.c3 = (uint32_t)__builtin_amdgcn_readlane((int)rng.c3, L);
-            r.n = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rng.n >> 32), L) << 32) |
-                  (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rng.n, L);
-            for (int P = lane; 2 * P < d; P += WAVE) {
+        const int P = (d + 1) >> 1;                                       // Box-Muller pairs per chain
+        const unsigned long long todo = __ballot(mine && g == 0);        // first lanes of the refreshing chains
+        const int R = (int)__builtin_popcountll(todo);
+        // The pairs of ALL refreshing chains of the wave, back to back over the 64 lanes: lane l of pass q0 takes flat pair q0 + l =
+        // (refreshing chain r, pair q - r P) -- d = 50: two chains per pass, d = 100 with eight chains: 6.25 passes instead of 8.
+        if (2 * P > WAVE) {                                               // fewer than two chains per pass (d = 100: measured slower when packed):
+            unsigned long long rest = todo;                               // one chain at a time, its stream counters in SGPRs
+            while (rest != 0ull) {
+                const int L = (int)__builtin_ctzll(rest);
+                rest &= rest - 1ull;
+                ChainRng r = rng;
+                r.c2 = (uint32_t)__builtin_amdgcn_readlane((int)rng.c2, L);
+                r.c3 = (uint32_t)__builtin_amdgcn_readlane((int)rng.c3, L);
+                r.n = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rng.n >> 32), L) << 32) |
+                      (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rng.n, L);
+                for (int pr = lane; pr < P; pr += WAVE) {
+                    double z0, z1;
+                    r.normal_pair(pr, z0, z1);
+                    const int i0 = 2 * pr, i1 = 2 * pr + 1;
+                    vs[(i0 >> logG) * WAVE + L + (i0 & (G - 1))] = z0;
+                    if (i1 < d) vs[(i1 >> logG) * WAVE + L + (i1 & (G - 1))] = z1;
+                }
+            }
+        } else
+        for (int q0 = 0; q0 < R * P; q0 += WAVE) {
+            const int q = q0 + lane;
+            const bool act = q < R * P;
+            int L = 0, pr = 0;                                            // first lane of my pair's chain, pair index inside it
+            unsigned long long rest = todo;
+            for (int r = 0; r < R; ++r) {                                 // R <= 64 / G iterations of two compares
+                const int Lr = (int)__builtin_ctzll(rest);
+                rest &= rest - 1ull;
+                if (q >= r * P && q < (r + 1) * P) { L = Lr; pr = q - r * P; }
+            }
+            ChainRng r2 = rng;                                            // seed words are the same in every lane; counters of lane L
+            r2.c2 = (uint32_t)__shfl((int)rng.c2, L, WAVE);
+            r2.c3 = (uint32_t)__shfl((int)rng.c3, L, WAVE);
+            r2.n = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(rng.n >> 32), L, WAVE) << 32) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)rng.n, L, WAVE);
+            if (act) {
                 double z0, z1;
-                r.normal_pair(P, z0, z1);
-                const int i0 = 2 * P, i1 = 2 * P + 1;
+                r2.normal_pair(pr, z0, z1);
+                const int i0 = 2 * pr, i1 = 2 * pr + 1;
                 vs[(i0 >> logG) * WAVE + L + (i0 & (G - 1))] = z0;
                 if (i1 < d) vs[(i1 >> logG) * WAVE + L + (i1 & (G - 1))] = z1;
             }

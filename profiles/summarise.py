@@ -3,6 +3,7 @@
 import collections, csv, glob, json, os, shutil, sys
 
 tag, dest = sys.argv[1], sys.argv[2]
+pat = sys.argv[3] if len(sys.argv) > 3 else "pdmp::"          # which kernels count (substring of the kernel name)
 src = f"gpurun_out/prof_{tag}"
 os.makedirs(dest, exist_ok=True)
 newest = lambda pattern: sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]      # a tag collected twice: the last run counts
@@ -10,7 +11,7 @@ stats = newest(f"{src}/trace/*/*_kernel_stats.csv")
 if stats:
     rows = list(csv.reader(open(stats[0])))
     with open(f"{dest}/{tag}_kernel_stats.csv", "w", newline="") as f:
-        csv.writer(f).writerows([rows[0]] + [r for r in rows[1:] if "pdmp::" in r[0]])
+        csv.writer(f).writerows([rows[0]] + [r for r in rows[1:] if pat in r[0]])
 if os.path.exists(f"{src}/bench_traced.json"):
     shutil.copy(f"{src}/bench_traced.json", f"{dest}/{tag}_bench_traced.json")
 out = {}
@@ -19,7 +20,7 @@ for d in ("pmc_sq", "pmc_sq2", "pmc_wr", "pmc_rd"):
         agg = collections.defaultdict(float)
         meta = {}
         for r in csv.DictReader(open(fcsv)):
-            if "pdmp::" in r["Kernel_Name"]:
+            if pat in r["Kernel_Name"]:
                 agg[r["Counter_Name"]] += float(r["Counter_Value"])
                 meta = {k: r[k] for k in ("Kernel_Name", "VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size") if k in r}
         out.update(agg)

@@ -130,9 +130,14 @@ def test_config5_boomerang_d100(engine, oracle):
         ref = oracle.sample_skeleton(cfg, n_sk, xh[c:c + 1], vh[c:c + 1], 5, chain_id_offset=87_500 + int(c), diagnostics=False)
         assert np.array_equal(t[c].cpu().numpy(), ref["t"][0]), c
         assert np.array_equal(out["X"][c].cpu().numpy(), ref["X"][0]), c
-    # the Boomerang preserves the reference measure N(0, I) exactly on this target: moments of the event positions
+    # moments of the event positions against a reference-order run of the checker.  (They are NOT those of N(0, I): the reference's
+    # Boomerang takes its event rate from grad-U . v but its jump from grad-U - x, SURVEY quirk Q8, so on the standard Gaussian every
+    # event is a velocity refresh at rate max(0, x.v) + refresh_rate and Var x settles near 0.77 -- reproduced, not corrected.)
     Xs = out["X"][:, 200:]
-    assert abs(float(Xs.mean())) < 0.01 and abs(float(Xs.var()) - 1) < 0.02
+    refcfg = oracle.Config(**{**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__ if k != "_keep"}, "arith": oracle.ARITH_REFERENCE})
+    r = oracle.sample_skeleton(refcfg, n_sk, xh[:48], vh[:48], 99, diagnostics=False)
+    want = r["X"][:, 200:].var()
+    assert abs(float(Xs.mean())) < 0.01 and abs(float(Xs.var()) / want - 1) < 0.03 and 0.7 < want < 0.85
 
 
 def test_config4_dense_precision_1e4_chains(engine, oracle, monkeypatch):
