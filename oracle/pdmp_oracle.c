@@ -582,8 +582,19 @@ static void lrb_coeffs(const orc_config_t *cfg, ws_t *w, const double *x, const 
     for (int i = 0; i < d; ++i) w->tmp[i] = v[i] * v[i];
     *VV = sum_group(w->tmp, d, G);
 }
+static double lrb_form(double XX, double XV, double VV, double sn, double cs, double *de);
 static double lrb_raw(double XX, double XV, double VV, double t, double *de) {
     double sn, cs; orc_sincos(t, &sn, &cs);
+    return lrb_form(XX, XV, VV, sn, cs, de);
+}
+/* finite-difference neighbours t + delta of a grid time (|delta| <= 1.5e-8 max(1, t), UpperBound.jl:58-61): sin / cos by the
+ * angle-addition formulas from those of t, with sin(delta) = delta, cos(delta) = 1 - delta^2/2 (exact to the last bit at that size) */
+static double lrb_raw_shifted(double XX, double XV, double VV, double t, double tt) {
+    double sn, cs; orc_sincos(t, &sn, &cs);
+    const double dl = tt - t, cd = 1.0 - 0.5 * (dl * dl);
+    return lrb_form(XX, XV, VV, sn * cd + cs * dl, cs * cd - sn * dl, NULL);
+}
+static double lrb_form(double XX, double XV, double VV, double sn, double cs, double *de) {
     const double cc = cs * cs, ss = sn * sn, sc = sn * cs, dq = VV - XX;
     if (de) *de = XV * (-4.0 * sc) + dq * (cc - ss);
     return XV * (cc - ss) + dq * sc;
@@ -715,11 +726,14 @@ static void upper_bound(const orc_config_t *cfg, ws_t *w, const double *x, const
             if (cfg->deriv_mode == ORC_DERIV_FORWARD) { val[j] = lrb_sc(cfg, qXX, qXV, qVV, t[j], &slp[j]); continue; }
             val[j] = lrb_sc(cfg, qXX, qXV, qVV, t[j], NULL);
             double tm, tp; fd_points(t[j], horizon, &tm, &tp);
+#define LRB_NB(tt) (cfg->signed_bound ? lrb_raw_shifted(qXX, qXV, qVV, t[j], (tt)) + cfg->refresh_rate \
+                                      : pmax(0.0, lrb_raw_shifted(qXX, qXV, qVV, t[j], (tt))) + cfg->refresh_rate)
             if (tp == tm) slp[j] = val[j] - val[j];
-            else if (tm == t[j]) slp[j] = (lrb_sc(cfg, qXX, qXV, qVV, tp, NULL) - val[j]) / (tp - t[j]);
-            else if (tp == t[j]) slp[j] = (val[j] - lrb_sc(cfg, qXX, qXV, qVV, tm, NULL)) / (t[j] - tm);
-            else { double fp = lrb_sc(cfg, qXX, qXV, qVV, tp, NULL), fm = lrb_sc(cfg, qXX, qXV, qVV, tm, NULL);
+            else if (tm == t[j]) slp[j] = (LRB_NB(tp) - val[j]) / (tp - t[j]);
+            else if (tp == t[j]) slp[j] = (val[j] - LRB_NB(tm)) / (t[j] - tm);
+            else { double fp = LRB_NB(tp), fm = LRB_NB(tm);
                 slp[j] = (fp - fm) / (tp - tm); }
+#undef LRB_NB
             continue;
         }
         if (lr_mode(cfg)) {                                                   /* affine-tail order: same function, O(1) per grid time */

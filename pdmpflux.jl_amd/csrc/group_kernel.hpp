@@ -520,7 +520,21 @@ struct GroupChain {
     __device__ __forceinline__ void fd_point(double t, double horizon, FdPt &P) const {
         const double hh = 1.4901161193847656e-08 * fmax(1.0, fabs(t));               // sqrt(eps) * max(1, |t|), :58
         const double tm = fmax(0.0, t - hh), tq = (horizon < t + hh) ? horizon : t + hh;   // :60-61
-        time_pt(t, P.c); time_pt(tm, P.m); time_pt(tq, P.pl);
+        if constexpr (SAMPLER == S_BOOMERANG && TARGET == T_GAUSS_ISO) {
+            // quadratic-form order: sin / cos of the two neighbours t + delta (|delta| <= 1.5e-8 max(1, t)) by the angle-addition
+            // formulas from sin / cos of t -- sin(delta) = delta and cos(delta) = 1 - delta^2 / 2 to the last bit at that size; delta is
+            // the exact difference of the rounded points (Sterbenz).  One range reduction per grid time instead of three.
+            time_pt(t, P.c);
+            auto shifted = [&](double tt, TimePt &o) {
+                const double dl = tt - t, cd = 1.0 - 0.5 * (dl * dl);
+                o = P.c;
+                o.t = tt;
+                o.s = P.c.s * cd + P.c.c * dl;
+                o.c = P.c.c * cd - P.c.s * dl;
+            };
+            shifted(tm, P.m);
+            shifted(tq, P.pl);
+        } else { time_pt(t, P.c); time_pt(tm, P.m); time_pt(tq, P.pl); }
         P.kind = (tq == tm) ? 3 : ((tm == t) ? 1 : ((tq == t) ? 2 : 0));              // :64-75
         P.den = (P.kind == 1) ? tq - t : ((P.kind == 2) ? t - tm : tq - tm);
     }
@@ -1321,8 +1335,8 @@ struct GroupChain {
         const int R = (int)__builtin_popcountll(todo);
         // The pairs of ALL refreshing chains of the wave, back to back over the 64 lanes: lane l of pass q0 takes flat pair q0 + l =
         // (refreshing chain r, pair q - r P) -- d = 50: two chains per pass, d = 100 with eight chains: 6.25 passes instead of 8.
-        if (2 * P > WAVE) {                                               // fewer than two chains per pass (d = 100: measured slower when packed):
-            unsigned long long rest = todo;                               // one chain at a time, its stream counters in SGPRs
+        if constexpr (SAMPLER == S_BOOMERANG) {                           // Boomerang (d = 100, config 5: 50 pairs per chain): measured slower when
+            unsigned long long rest = todo;                               // packed -- one chain at a time, its stream counters in SGPRs
             while (rest != 0ull) {
                 const int L = (int)__builtin_ctzll(rest);
                 rest &= rest - 1ull;

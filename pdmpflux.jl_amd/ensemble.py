@@ -247,7 +247,10 @@ def _gather_in_place(full: torch.Tensor, C_total: int, rank: int, world: int, gr
                 full[a:b].copy_(parts[r])
         return
     if equal:
-        dist.all_gather_into_tensor(full, full[lo:hi], group=group)
+        try:
+            dist.all_gather_into_tensor(full, full[lo:hi], group=group)          # in place: input = this rank's slice of the output
+        except (RuntimeError, ValueError):                                        # a backend that refuses aliased buffers (argument check:
+            dist.all_gather_into_tensor(full, full[lo:hi].clone(), group=group)   # every rank takes the same branch)
     else:
         for r, (a, b) in enumerate(ranges):
             if b > a:
