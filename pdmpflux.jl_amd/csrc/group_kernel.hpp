@@ -232,6 +232,55 @@ struct GroupChain {
     Tgt tgt;
     ChainRng rng;
     int32_t guard = 0;
+    // ---- random stream, prefetched per pass of the state machine.  A pass draws at most three variates of a chain -- the bound's
+    // exponential, the acceptance uniform, the jump's uniform: stream positions n, n+1, n+2 = Philox blocks n>>1 and (n>>1)+1.
+    // Drawn one by one (ChainRng::uniform) each draw runs the ten Philox rounds whenever ANY of the wave's chains starts a new block,
+    // i.e. three times per pass although a chain consumes 1.5 blocks.  With G >= 2 lanes per chain the even lanes of a chain compute
+    // block n>>1 and the odd lanes block (n>>1)+1 in ONE execution at the top of the pass; a draw then picks its half and fetches it
+    // from the even or odd neighbour by quad_perm DPP.  Same variates at the same stream positions (the stream is counter-based).
+    // Register form only (G is a compile-time constant there; the LDS-form and the runtime-compiled kernels draw one variate at a time:
+    // a runtime-compiled Boomerang kernel -- 256 VGPRs + 32 AGPRs at one wave per SIMD -- misbehaved with the six more live registers).
+#ifdef PDMP_NO_PREFETCH          // A/B builds (scripts/ab.sh)
+    static constexpr bool kPrefetch = false;
+#else
+    static constexpr bool kPrefetch = kReg && (SAMPLER == S_ZIGZAG || SAMPLER == S_BPS || SAMPLER == S_BOOMERANG);
+#endif
+    uint32_t pf_w0 = 0, pf_w1 = 0, pf_w2 = 0, pf_w3 = 0;
+    uint64_t pf_n = 0;
+    __device__ __forceinline__ void rng_prefetch() {
+        if constexpr (kPrefetch) {
+            if (G >= 2) {
+                pf_n = rng.n;
+                uint32_t w[4];
+                rng.block_at((pf_n >> 1) + (uint64_t)(g & 1), w);
+                pf_w0 = w[0]; pf_w1 = w[1]; pf_w2 = w[2]; pf_w3 = w[3];
+            }
+        }
+    }
+    __device__ __forceinline__ double draw_uniform() {
+        if constexpr (kPrefetch) {
+            if (G >= 2) {
+                const uint64_t idx = rng.n;
+                const uint32_t sel = (uint32_t)((idx >> 1) - (pf_n >> 1));           // 0: the even lanes' block, 1: the odd lanes'
+                const bool half = (idx & 1ull) != 0ull;
+                const int lo_own = (int)(half ? pf_w2 : pf_w0), hi_own = (int)(half ? pf_w3 : pf_w1);
+                const int lo_e = __builtin_amdgcn_update_dpp(0, lo_own, 0xA0, 0xF, 0xF, true);   // quad_perm [0,0,2,2]: the pair's even lane
+                const int hi_e = __builtin_amdgcn_update_dpp(0, hi_own, 0xA0, 0xF, 0xF, true);
+                const int lo_o = __builtin_amdgcn_update_dpp(0, lo_own, 0xF5, 0xF, 0xF, true);   // quad_perm [1,1,3,3]: the odd lane
+                const int hi_o = __builtin_amdgcn_update_dpp(0, hi_own, 0xF5, 0xF, 0xF, true);
+                uint32_t lo = (uint32_t)(sel ? lo_o : lo_e), hi = (uint32_t)(sel ? hi_o : hi_e);
+                if (__ballot(sel > 1u) != 0ull) {                                    // a fourth draw in one pass (no sampler of this family
+                    uint32_t w[4];                                                   // makes one): its block directly
+                    rng.block_at(idx >> 1, w);
+                    if (sel > 1u) { lo = half ? w[2] : w[0]; hi = half ? w[3] : w[1]; }
+                }
+                ++rng.n;
+                return bits_to_u(lo, hi);
+            }
+        }
+        return rng.uniform();
+    }
+    __device__ __forceinline__ double draw_exponential() { return -det_log(draw_uniform()); }
 
     const int cell_budget;               // cells of a lazily built bound per pass of the state machine (bound_advance_vect)
     __device__ __forceinline__ GroupChain(const GroupParams &gp, int l, double *x_tile, double *v_tile)
@@ -1213,7 +1262,7 @@ struct GroupChain {
                 PDMP_SLOTS(s) { const int i = s * G + g; a += (in_dim(s, i)) ? fmax(0.0, eff(tgt.grad(i, X(s), sh), X(s), t0) * V(s)) : 0.0; }
                 S = group_sum(a, G);
             }
-            const double u = rng.uniform();                              // Categorical draw
+            const double u = draw_uniform();                             // Categorical draw
             if (!(S > 0.0)) { guard++; return false; }                         // Q11
             // Categorical(lambda / S) (ZigZagSamplers.jl:102-104): the reference walks cp += lambda_i / S until
             // cp > u; the engine walks the un-normalised cumulative rate against theta = u * S (same index up
@@ -1283,7 +1332,7 @@ struct GroupChain {
             }
             const double bounce = fmax(0.0, gv);
             const double prob = bounce / (bounce + p.refresh);           // NaN if both 0 (Q9)
-            const double u = rng.uniform();
+            const double u = draw_uniform();
             if (u < prob) {
                 acc = 0.0;
                 PDMP_SLOTS(s) {
@@ -1539,13 +1588,14 @@ struct GroupChain {
 #endif
         while (__ballot(!done) != 0ull) {
             STAMP(5);
+            rng_prefetch();
             bool accepted = false, refresh = false, proposed = false, event_out = false;   // event_out: a StickyZigZag stick / thaw event
             if (!done && !propose) {
                 // one_step_of_thinning! (:65-85), erroneous_acceptance_rate! (:131-151) or if_reject! (:188-203)
                 if (!brun) {
                     const double harg = (mode == ERR) ? horizon / 2 : ((mode == REUSE) ? hB : horizon);
                     hB = harg;
-                    const double e1 = rng.exponential();
+                    const double e1 = draw_exponential();
                     E = (mode == REUSE) ? E + e1 : e1;                    // cumulative only after a rejection (:190)
                     if (mode == REUSE && resumable) bound_resume(tp); else bound_begin(tp);
                     brun = true;
@@ -1612,7 +1662,7 @@ struct GroupChain {
                 if (ar > 1.0) {
                     mode = ERR;
                 } else {                                                  // ac_step_with_proxy!, :153-168
-                    const double u = rng.uniform();
+                    const double u = draw_uniform();
                     if (u < ar) {                                         // if_accept!, :170-186
                         flow_state(tp);
                         STAMP(2);

@@ -268,6 +268,10 @@ struct ChainRng {
         return bits_to_u(lo, hi);
     }
     __device__ __forceinline__ double exponential() { return -det_log(uniform()); }
+    // the four words of block `blk` of this stream (variates 2 blk and 2 blk + 1), stateless
+    __device__ __forceinline__ void block_at(uint64_t blk, uint32_t (&w)[4]) const {
+        philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), c2, c3, k0, k1, w);
+    }
     // standard normal for coordinate i of a d-vector; call normals_done(d) once afterwards
     __device__ __forceinline__ double normal_coord(int i) const {
         const uint64_t blk = ((n + 1) >> 1) + (uint64_t)(i >> 1);
