@@ -204,7 +204,7 @@ template <> struct GTarget<T_USER> {
 // REGISTERS, every slot loop fully unrolled with a scalar skip of the slots >= K -- no ds_read latency in the loops, no slot
 // addressing.  Same operations in the same order: the two forms agree bit for bit.
 #define PDMP_SLOTS(s) _Pragma("unroll kUnroll") for (int s = 0; s < nk(); ++s) if (!kReg || s < kmin || s < K)
-template <int SAMPLER, int TARGET, bool FD, int KC = 0>
+template <int SAMPLER, int TARGET, bool FD, int KC = 0, int GC = 0>      // GC: lanes per chain when it is a compile-time constant (register form)
 struct GroupChain {
     using Tgt = GTarget<TARGET>;
     static constexpr bool kReg = KC > 0;
@@ -860,6 +860,67 @@ struct GroupChain {
             s0 = s1;
         };
 
+        // ---- Grid times across the lanes of the chain (register form, G >= 2, bounded functions that cost O(1) per time point: the
+        // affine tail and the quadratic form).  The ten grid times are independent, so lane g of the chain's G evaluates times g, g+G, ...
+        // and cells g, g+G, ... (its right neighbour's values come by lane shuffle); the nine cell maxima are then gathered to every
+        // lane, which runs the reference's cumulative sum and search in grid order.  Same arithmetic per point and per cell, same order
+        // of the cumulative sum: bit-identical to the sequential loop below -- but ceil(10/G) steps instead of up to nine, which is what
+        // the wave paid whenever ONE of its chains ran to the horizon (0.9 of BPS's 2.1 bounds per event do).
+        if constexpr (kReg && GC >= 2 && GC <= 16 && (kQuad || (kLowRank && !FDM))) {
+            constexpr int M = (GNG + GC - 1) / GC;                                     // time points per lane
+            if constexpr (kQuad) q_prepare(); else lr_prepare();
+            const bool sgn = p.signed_bound != 0;
+            double pf[M + 1], ps[M + 1], bj[M];
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const int j = g + GC * m;
+                const double tj = (j >= GNG - 1) ? harg : (double)j * h;               // (lanes beyond the grid evaluate the horizon again: unused)
+                if constexpr (kQuad) {
+                    if constexpr (!FDM) { TimePt tq; time_pt(tj, tq); pf[m] = q_bounded(tq, &ps[m]); }
+                    else {
+                        FdPt P;
+                        fd_point(tj, harg, P);
+                        pf[m] = q_bounded(P.c, nullptr);
+                        ps[m] = fd_slope(P, pf[m], q_bounded(P.m, nullptr), q_bounded(P.pl, nullptr));
+                    }
+                } else {
+                    double dv, de;
+                    lr_eval(tj, dv, de);
+                    pf[m] = (sgn ? dv : fmax(0.0, dv)) + p.refresh;                    // includes refresh_rate (Q2)
+                    ps[m] = sgn ? de : ((0.0 < dv) ? de : 0.0);
+                }
+            }
+            pf[M] = 0.0; ps[M] = 0.0;
+            const int nxt = base + ((g + 1) & (GC - 1));                               // the lane that holds the next grid time
+#pragma unroll
+            for (int m = 0; m < M; ++m) {                                              // cell j = g + G m from times j and j + 1
+                const double a_f = __shfl(pf[m], nxt, WAVE), a_s = __shfl(ps[m], nxt, WAVE);
+                const double b_f = __shfl(pf[m + 1], nxt, WAVE), b_s = __shfl(ps[m + 1], nxt, WAVE);
+                const bool wrap = g == GC - 1;                                         // time j + 1 sits in lane 0's next slot
+                const double f1 = wrap ? b_f : a_f, s1 = wrap ? b_s : a_s, fz = pf[m], sz = ps[m];
+                const double num = fma(s1, h, fz - f1);                                // :123 relative form
+                const double den = s1 - sz;
+                bool fast = false;
+                if constexpr (SAMPLER == S_BPS && Tgt::kLinear) fast = (__ballot(den != 0.0) == 0ull);
+                const double q = cell_q(num, den, h, fast);                            // :124-125
+                const double inter = fma(sz, q, fz);                                   // :127
+                bj[m] = fmax(fmax(fmax(fz, f1), inter), 0.0) + refresh;                // :128-131
+            }
+            int inv_jj = 0;
+            double c0 = 0.0, c1 = 1.0, last = 0.0;
+#pragma unroll
+            for (int j = 0; j < GNG - 1; ++j) {                                        // cum_sum and searchsortedfirst in grid order, :133-134, :265
+                const double b = __shfl(bj[j / GC], base + (j % GC), WAVE);
+                acc += b;
+                const double cj = acc * h;
+                if (!found && !(cj < E)) { found = true; inv_jj = j; c0 = cprev; c1 = cj; lbo = b; }
+                cprev = cj;
+                last = b;
+            }
+            if (found) tpo = (double)inv_jj * h + (E - c0) / (c1 - c0) * h;            // next_event, :269
+            else lbo = last;                                                           // box_max[end], :270
+            return;
+        }
         if constexpr (kQuad) {
             q_prepare();
             auto point = [&](double t, double &val, double &slp) {
@@ -1769,7 +1830,7 @@ template <int SAMPLER, int TARGET, bool FD> struct GroupOcc {
         : 3;                                                            // Zig-Zag, Boomerang, ForwardECMC on the separable Gaussians
 };
 
-template <int SAMPLER, int TARGET, bool FD, int KC = 0>
+template <int SAMPLER, int TARGET, bool FD, int KC = 0, int GC = 0>
 __device__ __forceinline__ void group_kernel_body(const GroupParams &gp) {
     extern __shared__ double smem[];
     const int lane = lane_id();
@@ -1781,7 +1842,7 @@ __device__ __forceinline__ void group_kernel_body(const GroupParams &gp) {
     double *tile = smem + gp.tpar + (size_t)wave * gp.tiles * tsz;
     const int cpw = WAVE / gp.G;
     // register form: no x tile; one K*64-double tile per wave only where refreshed velocities are exchanged between lanes
-    GroupChain<SAMPLER, TARGET, FD, KC> chain(gp, lane, tile, KC > 0 ? tile : tile + tsz);
+    GroupChain<SAMPLER, TARGET, FD, KC, GC> chain(gp, lane, tile, KC > 0 ? tile : tile + tsz);
     chain.tgt.init(smem, gp.s.d);
     if constexpr (SAMPLER == S_FECMC) {
         for (int q = 0; q < 4; ++q) chain.fe_t[q] = tile + (2 + q) * tsz;
@@ -1840,7 +1901,7 @@ __global__ __launch_bounds__(256, PDMP_REG_WAVES) void group_kernel_reg(const Gr
     GroupParams gp = gp_in;
     gp.G = GC;                 // the host launches this instantiation only for G == GC, K <= KC: folds every use of G
     if (FULL) gp.K = KC;       // ... and the FULL one only for K == KC: the per-slot skips fold away too
-    group_kernel_body<SAMPLER, TARGET, FD, KC>(gp);
+    group_kernel_body<SAMPLER, TARGET, FD, KC, GC>(gp);
 }
 
 #ifndef __HIPCC_RTC__   // host side (not part of a runtime-compiled user kernel)
