@@ -368,8 +368,16 @@ __global__ __launch_bounds__(256, SGN ? 2 : 1) void di_segment_kernel(const DiPa
             double part = 0.0;
 #pragma unroll
             for (int s = 0; s < KC; ++s) {
-                const double vi = v[s], g = gv[s] * vi;
+                const double vi = v[s];
                 double v0 = fma(t0, gv[s], gx[s]) * vi, v1 = fma(t1, gv[s], gx[s]) * vi;   // signed_rate_vect at the two grid times
+                if constexpr (sgn) {
+                    // "affine cell" (DESIGN.md 2): under the signed bound every coordinate's rate is linear in t with the same slope double
+                    // gv_i v_i at both ends, the reference's tangent intersection divides by zero and clamps to h or 0, `inter` is v0 or
+                    // v0 + g h = v1 up to rounding: the cell maximum is max(v0, v1, 0) (the slope may have either sign here)
+                    part += fmax(fmax(v0, v1), 0.0);
+                    continue;
+                }
+                const double g = gv[s] * vi;
                 double g0 = g, g1 = g;
                 if (!sgn) { g0 = (0.0 < v0) ? g : 0.0; g1 = (0.0 < v1) ? g : 0.0; v0 = fmax(0.0, v0); v1 = fmax(0.0, v1); }
                 const double num = fma(-g0, t0, fma(g1, t1, v0 - v1));         // :229
