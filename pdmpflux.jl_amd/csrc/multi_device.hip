@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -166,7 +167,9 @@ int pdmp_multi_sample_skeleton(pdmp_multi_handle m, int64_t C, int64_t n_sk, int
     // ONE layout for every shard (results must not depend on which device a chain lands on): the occupancy choice for the largest shard
     const int G = pdmp_suggest_group_lanes(m->h[0], hi[0] - lo[0]);
     for (int r = 0; r < n; ++r) if (G > 0) { if (int rc = pdmp_set_group_lanes(m->h[r], G)) return rc; }
-    const bool exchange = gather != 0 && n > 1;
+    // (PDMP_MULTI_FORCE_RCCL: test hook -- run the collective with one device too, which exercises the run-time binding of librccl,
+    // the communicator and the grouped in-place all-gather on a one-GPU box)
+    const bool exchange = gather != 0 && (n > 1 || getenv("PDMP_MULTI_FORCE_RCCL") != nullptr);
     if (exchange && m->comm.empty()) {
         if (int rc = load_rccl()) return rc;
         m->comm.assign(n, nullptr);

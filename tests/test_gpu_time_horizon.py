@@ -255,6 +255,35 @@ def test_sample_from_skeleton_prefix_method(engine, oracle, kind, dim, target):
         engine.sample_from_skeleton(s, 1000, dt, h)
 
 
+def test_multi_device_collective_through_rccl_with_one_rank(engine, monkeypatch):
+    """PDMP_MULTI_FORCE_RCCL: the library binds librccl at run time, builds a one-rank communicator (ncclCommInitAll) and runs the
+    grouped in-place ncclAllGather of X, V, t -- all that a one-GPU box can exercise of the exchange; the result must be untouched."""
+    import ctypes as C
+    import torch
+    from pdmpflux.jl_amd import _lib, ensemble
+    monkeypatch.setenv("PDMP_MULTI_FORCE_RCCL", "1")
+    L = _lib.lib()
+    s = engine.ZigZagAD(20, engine.GaussianIso())
+    Cn, n_sk, d = 37, 30, 20
+    x, v = make_init("ZigZagAD", d, Cn, seed=8)
+    dev = torch.device("cuda:0")
+    single = ensemble.sample_skeleton_device(s, n_sk, torch.from_numpy(x).to(dev), torch.from_numpy(v).to(dev), seed=3)
+    m = C.c_void_p()
+    conf = s._config()
+    _lib.check(L.pdmp_multi_create(C.byref(conf), 1, None, C.byref(m)))
+    try:
+        X = torch.zeros((Cn, n_sk, d), dtype=torch.float64, device=dev); V = torch.zeros_like(X)
+        t = torch.zeros((Cn, n_sk), dtype=torch.float64, device=dev)
+        arr = lambda tt: (C.c_void_p * 1)(tt.data_ptr())
+        _lib.check(L.pdmp_multi_sample_skeleton(m, Cn, n_sk, 0, C.c_void_p(x.ctypes.data), C.c_void_p(v.ctypes.data), C.c_uint64(3), 1, arr(X), arr(V), arr(t)))
+        assert torch.equal(X, single["X"]) and torch.equal(V, single["V"]) and torch.equal(t, single["t"])
+        km, xm = C.c_double(), C.c_double()
+        _lib.check(L.pdmp_multi_get_timing(m, C.byref(km), C.byref(xm)))
+        assert xm.value >= 0.0
+    finally:
+        L.pdmp_multi_destroy(m)
+
+
 def test_multi_device_entry_with_one_device(engine, oracle):
     """pdmp_multi_* (one host process, n devices; include/pdmp_hip.h) with n_devices = 1 equals pdmp_sample_skeleton_device,
     with and without the gather flag, and the checker."""
