@@ -534,7 +534,7 @@ static void fd_points(double t, double horizon, double *tm, double *tp) {
  * Value and t-derivative at a grid time: f = head.v + fma(B, t, A), f' = head.e + B.  The reference evaluates all d coordinates
  * at every grid time; the two agree up to the rounding of the sums (1e-5 tolerance test, tests/test_gpu_reference_order.py). */
 static int lr_mode(const orc_config_t *cfg) {
-    return cfg->arith == ORC_ARITH_GROUP && cfg->sampler == ORC_BPS && cfg->deriv_mode == ORC_DERIV_FORWARD &&
+    return cfg->arith == ORC_ARITH_GROUP && (cfg->sampler == ORC_BPS || cfg->sampler == ORC_FECMC) && cfg->deriv_mode == ORC_DERIV_FORWARD &&
            (cfg->target_id == ORC_T_GAUSS_ISO || cfg->target_id == ORC_T_GAUSS_DIAG || cfg->target_id == ORC_T_BANANA);
 }
 static int lr_aff(const orc_config_t *cfg) { return (cfg->target_id == ORC_T_BANANA && cfg->dim >= 2) ? 2 : 0; }

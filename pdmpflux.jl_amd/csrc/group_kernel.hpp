@@ -467,7 +467,7 @@ struct GroupChain {
     //   the chain's group from broadcast copies: no cross-lane sum per grid time).
     // Every grid time of every bound and the proposal's rate then cost O(1) instead of a pass over d coordinates and two butterflies:
     // BPS on the banana went from 404 to ~100 VALU instructions per event.
-    static constexpr bool kLowRank = SAMPLER == S_BPS && !FD && !Tgt::kTile && !Tgt::kUser;
+    static constexpr bool kLowRank = (SAMPLER == S_BPS || SAMPLER == S_FECMC) && !FD && !Tgt::kTile && !Tgt::kUser;   // (ForwardECMC bounds BPS's rate, ForwardEventChainMonteCarlo.jl:19-43)
     double lr_A = 0.0, lr_B = 0.0, lr_x0 = 0.0, lr_v0 = 0.0, lr_x1 = 0.0, lr_v1 = 0.0;
     mutable bool lr_ok = false;                  // (lr_A, lr_B, head copies) belong to the current (x, v)
     __device__ __forceinline__ int lr_aff() const { return (Tgt::kAffineFrom > 0 && Tgt::kAffineFrom < (1 << 30) && p.d >= 2) ? Tgt::kAffineFrom : 0; }
