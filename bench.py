@@ -189,6 +189,19 @@ def measured_counters(a, C_local, G):
     return e
 
 
+def metric_label(a, sampler, C_total):
+    """BASELINE.json's metric wording, built from the arguments: the default run reads 'skeleton-events/sec (whole node), Zig-Zag d=50,
+    10^5 chains'; any other sampler / target / slope mode / size says so."""
+    family = "Zig-Zag" if a.sampler.startswith("ZigZag") else ("Boomerang" if a.sampler.startswith("Boomerang") else
+             ("BPS" if a.sampler.startswith("BPS") else a.sampler))
+    extra = "" if a.target == "iso" else f" {a.target}"
+    if sampler.deriv_mode != 0:
+        extra += " (finite-difference slopes)"
+    chains = "10^5" if C_total == 100_000 else ("10^4" if C_total == 10_000 else str(C_total))
+    nsk = "" if a.n_sk == 1000 else f", n_sk={a.n_sk}"
+    return f"skeleton-events/sec (whole node), {family} d={a.dim}{extra}, {chains} chains{nsk}"
+
+
 def workload_label(a, sampler, world, C_local):
     rr = f", refresh_rate={sampler.refresh_rate}" if a.sampler.startswith(("BPS", "Boomerang", "RHMC")) else ""
     slopes = "forward-mode slopes" if sampler.deriv_mode == 0 else "finite-difference slopes"
@@ -318,7 +331,7 @@ def main():
         cnt = measured_counters(a, C_local, G)
         xbytes = 0 if gather != "skeleton" else (C_total - C_local) * n_sk * bytes_per_event
         res = {
-            "metric": f"skeleton-events/sec (whole node), {a.sampler} d={d} {a.target}, {C_total} chains",
+            "metric": metric_label(a, sampler, C_total),
             "value": value, "unit": "events/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
