@@ -12,6 +12,8 @@
 
 using namespace pdmp;
 namespace pdmp {
+hipError_t launch_lane_zigzag(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);   // lane_kernel.hpp
+hipError_t launch_lane_check(const double *vinit, int64_t n, int32_t *flag, hipStream_t stream);
 hipError_t launch_group_reg_zigzag(int target, bool fd, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_bps(int target, bool fd, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_boomerang(int target, bool fd, const GroupParams &gp, hipStream_t stream);
@@ -690,8 +692,8 @@ static int create_impl(const pdmp_config_t *cfg, const char *source, int32_t kin
         HIP_TRY_H(hipMalloc(&h->d_tparams, (size_t)c.n_target_params * 8));
         HIP_TRY_H(hipMemcpy(h->d_tparams, c.target_params, (size_t)c.n_target_params * 8, hipMemcpyHostToDevice));
     }
-    HIP_TRY_H(hipMalloc(&h->d_status, 4 * sizeof(int32_t)));
-    HIP_TRY_H(hipMemset(h->d_status, 0, 4 * sizeof(int32_t)));
+    HIP_TRY_H(hipMalloc(&h->d_status, 8 * sizeof(int32_t)));      // [4]: the lane kernel's unit-speed flag
+    HIP_TRY_H(hipMemset(h->d_status, 0, 8 * sizeof(int32_t)));
 #undef HIP_TRY_H
     if (source) {
         if (h->group_lanes <= 0) { pdmp_destroy(h); return fail(PDMP_ERR_UNSUPPORTED, "potentials given as source: dim too large for the LDS tiles"); }
@@ -863,7 +865,7 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
         gp.cell_budget = 3;
         if (const char *e = getenv("PDMP_CELL_BUDGET")) { const int b = atoi(e); if (b >= 1 && b <= GNG - 1) gp.cell_budget = b; }   // tuning / tests
         const int64_t nb = (C + WAVE / gp.G - 1) / (WAVE / gp.G);
-        const size_t need_sched = (size_t)nb + 1, need_state = (size_t)C * (size_t)(2 * c.dim + 4);
+        const size_t need_sched = (size_t)nb + 1, need_state = (size_t)((C + WAVE - 1) / WAVE * WAVE) * (size_t)(2 * c.dim + 4);   // (whole batches of 64: lane_kernel.hpp)
         if (need_sched > h->sched_cap) {
             if (h->d_sched) { HIP_TRY(hipStreamSynchronize(h->last_stream)); HIP_TRY(hipFree(h->d_sched)); h->d_sched = nullptr; h->sched_cap = 0; }
             HIP_TRY(hipMalloc(&h->d_sched, need_sched * sizeof(int32_t)));
@@ -914,6 +916,24 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
         const bool reg_flags = c.grid_size == GNG && (c.sampler != PDMP_ZIGZAG || (c.vectorized_bound && c.signed_bound));
         if (!(reg && atoi(reg) == 0) && reg_flags) {
             const bool fd = c.deriv_mode != 0;
+            // Large Zig-Zag ensembles at d = 49..52 on the isotropic Gaussian / banana: one LANE per chain (lane_kernel.hpp), bit-identical
+            // to the G = 4 group kernel.  It needs unit speeds: a check kernel raises a device flag otherwise, the lane kernel then
+            // returns at once and the group kernel below (which returns at once while the flag is 0) does the launch's work.
+            const char *lane_env = getenv("PDMP_LANE");     // 0: never, 1: whenever the configuration allows (tests), unset: from the chain count
+            const char *lane_min = getenv("PDMP_LANE_MIN_CHAINS");
+            const int64_t lane_from = lane_min ? atoll(lane_min) : 49152;
+            const bool lane_ok = c.sampler == PDMP_ZIGZAG && !fd && (c.target_id == PDMP_T_GAUSS_ISO || c.target_id == PDMP_T_BANANA) &&
+                                 c.dim >= 49 && c.dim <= 52 && gp.G == 4 && (int64_t)WAVE * n_sk * c.dim * 8 < 0x7fffffffLL;   // (a batch's window of X: 31-bit byte offsets)
+            if (lane_ok && !(lane_env && atoi(lane_env) == 0) && ((lane_env && atoi(lane_env) == 1) || C >= lane_from)) {
+                int32_t *flag = h->d_status + 4;
+                hipError_t le = hipMemsetAsync(flag, 0, sizeof(int32_t), s);
+                if (le == hipSuccess) le = launch_lane_check(vinit, C * (int64_t)c.dim, flag, s);
+                int rounds = 8;
+                if (const char *r = getenv("PDMP_LANE_ROUNDS")) { const int v = atoi(r); if (v >= 1 && v <= 64) rounds = v; }
+                if (le == hipSuccess) le = launch_lane_zigzag(c.target_id, gp, flag, rounds, s);
+                if (le != hipSuccess) { h->pool.push_back(ev); return fail(PDMP_ERR_RUNTIME, "lane kernel launch: %s", hipGetErrorString(le)); }
+                gp.only_if = flag;
+            }
             const char *ex = getenv("PDMP_REG_EXACT");      // PDMP_REG_EXACT=0: the KREG-slot kernels with per-slot skips (test hook)
             if (!(ex && atoi(ex) == 0))                     // a kernel of exactly K slots where one exists
                 e = c.sampler == PDMP_BOOMERANG    ? (fd ? launch_group_reg_boomerang_exact_fd(c.target_id, gp, s)

@@ -45,6 +45,7 @@ struct GroupParams {
     int32_t *ctr;         // unit counter (zeroed before the launch)
     int32_t *progress;    // progress[b] = segments of batch b completed (zeroed before the launch)
     double *state;        // per chain: x[d], v[d], t, horizon, ar, rng counter  (stride 2d+4 doubles)
+    const int32_t *only_if;   // null, or a device flag: the register-form kernels return at once while it is 0 (lane_kernel.hpp ran instead)
 };
 
 // ---------------------------------------------------------------- group-of-lanes primitives (G uniform)
@@ -1898,6 +1899,7 @@ template <int SAMPLER, int TARGET, bool FD, int KC, int GC, bool FULL>
 #define PDMP_REG_WAVES 2
 #endif
 __global__ __launch_bounds__(256, PDMP_REG_WAVES) void group_kernel_reg(const GroupParams gp_in) {
+    if (gp_in.only_if && __hip_atomic_load(gp_in.only_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     GroupParams gp = gp_in;
     gp.G = GC;                 // the host launches this instantiation only for G == GC, K <= KC: folds every use of G
     if (FULL) gp.K = KC;       // ... and the FULL one only for K == KC: the per-slot skips fold away too

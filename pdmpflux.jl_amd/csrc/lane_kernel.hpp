@@ -1,0 +1,519 @@
+// lane_kernel.hpp -- ONE LANE PER CHAIN: the large-ensemble form of the Zig-Zag hot path (sample_skeleton, src/sample.jl:253-284) for the
+// constructors' default bound (grid_size = 10, vectorized signed bound, forward-mode slopes) on the isotropic Gaussian and the banana,
+// unit speeds (|v_i| = 1, the reference's initial velocities), 49 <= d <= 52.
+//
+// Why (profiles/r2): the group kernel (G = 4 lanes per chain, 16 chains per wave) is bound by fp64 VALU issue -- 81 wave-instructions
+// per event at config 2 -- and two thirds of those are per-CHAIN scalar work (random stream, log, cumulative sums, inversion, the
+// Categorical's bookkeeping, the state machine) that the four lanes of a chain execute redundantly.  With one chain per lane that work
+// is shared by 64 chains per instruction and no sum over coordinates crosses lanes any more (no DPP butterflies, no ballots in the
+// Categorical walk).
+//
+// State ("signed positions"): with v_i = +-1 the Zig-Zag dynamics only ever needs  y_i = x_i v_i:
+//   rate_i(t) = max(0, (x_i + v_i t) v_i) = max(0, y_i + t),   flow: y_i <- y_i + t,   flip of coordinate m: y_m <- -y_m
+// -- in IEEE arithmetic, not only on paper: multiplying by +-1 is exact and rounding to nearest is symmetric, so fl(x - t) (-1) =
+// fl(-x + t).  A lane holds y_i in VGPRs (52 doubles) and the signs of v packed in two words; x_i = y_i v_i and v_i are rebuilt (sign-bit
+// xor) where they are needed: in record!, and for the banana's two twisted coordinates.  The only visible difference to carrying x and
+// v: when x_i + v_i t cancels to exactly 0 with v_i = -1 the zero's sign differs (an event of probability ~2^-52 per operation).
+//
+// Arithmetic: BIT-IDENTICAL to the group kernel with G = 4 (the "GROUP(4)" order of the checker).  A lane keeps four partial sums --
+// coordinate i = 4 s + g goes to partial g, slots s in ascending order -- and combines them as ((p0 + p1) + (p2 + p3)), which is what the
+// xor-1 / xor-2 butterfly over the four lanes computes; the Kogge-Stone scan inside the Categorical's hit slot is written out for four
+// elements; every other expression is GroupChain's (group_kernel.hpp), operation for operation.  So the choice between the two
+// kernels -- made per launch from the number of chains -- cannot be seen in the results (tests/test_gpu_lane_kernel.py compares them,
+// and both with the checker), and sharding invariance holds across it.
+//
+// record! (Composites.jl:239-260) transposes X and V rows through an LDS tile so that a store instruction writes 16 consecutive
+// doubles of each of four chains (a lane's own row lies n_sk d 8 bytes from its neighbour's).
+#pragma once
+#include "group_kernel.hpp"
+
+namespace pdmp {
+
+constexpr int LK = 13;            // slots of the emulated G = 4 layout: d <= 52
+constexpr int LD = 4 * LK;        // coordinate registers per lane
+constexpr int LT = 17;            // LDS transpose tile: 64 chains x 16 coordinates, rows padded to 17 doubles
+constexpr int LANE_DMIN = LD - 3; // the last slot may be partly padding, no other
+constexpr int LANE_LDS_PER_WAVE = WAVE * LT + WAVE;   // doubles: transpose tile + row indices
+
+// Slot loops run slot by slot: without this the scheduler hoists the 52 independent terms of a sum in front of their
+// additions (104 more live registers, spills); with it a slot's four terms are in flight at a time -- still four independent
+// dependency chains, and the SIMD's other wave fills the rest.
+#ifdef LANE_MARKS
+#define LANE_MARK(n) asm volatile("; LANEMARK " #n ::: "memory")
+#else
+#define LANE_MARK(n)
+#endif
+#define LANE_SLOT_FENCE(a, tt) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(tt))
+
+template <int TARGET>
+struct LaneChain {
+    static_assert(TARGET == T_GAUSS_ISO || TARGET == T_BANANA, "lane kernel: isotropic Gaussian and banana");
+    static constexpr bool kBanana = TARGET == T_BANANA;
+    using Tgt = GTarget<TARGET>;
+    const SkelParams &p;
+    const int lane, d;
+    Tgt tgt;
+    double y[LD];                 // y_i = x_i v_i
+    uint32_t sg0 = 0, sg1 = 0;    // bit i of (sg1:sg0) set <=> v_i = -1
+    ChainRng rng;
+    int32_t guard = 0;
+    double *tile;                 // this wave's LDS transpose tile (64 x LT doubles) followed by 64 row indices
+
+    __device__ __forceinline__ LaneChain(const SkelParams &sp, int l, double *t_) : p(sp), lane(l), d(sp.d), tile(t_) { tgt.init(nullptr, sp.d); }
+
+    __device__ __forceinline__ static double sgn(double a, uint32_t s) {          // a * v for v = +-1 (exact): flip the sign bit
+        return __hiloint2double(__double2hiint(a) ^ (int)s, __double2loint(a));
+    }
+    __device__ __forceinline__ uint32_t sw(int i) const {                         // sign word of v_i: 0 or 0x80000000 (i is a constant after unrolling)
+        const uint32_t w = (i < 32) ? sg0 : sg1;
+        const int b = i & 31;
+        return (b == 31) ? (w & 0x80000000u) : ((w << (31 - b)) & 0x80000000u);
+    }
+    __device__ __forceinline__ double X(int i) const { return sgn(y[i], sw(i)); }
+    __device__ __forceinline__ double V(int i) const { return __hiloint2double((int)(0x3ff00000u | sw(i)), 0); }
+    __device__ __forceinline__ bool in_dim(int i) const { return i < LANE_DMIN || i < d; }
+    __device__ __forceinline__ static double gsum4(const double (&a)[4]) { return (a[0] + a[1]) + (a[2] + a[3]); }   // the xor-1, xor-2 butterfly
+
+    // ---- the lazily built vectorized bound, GroupChain::bound_advance_vect<true, false> for this chain
+    int b_next = 0;
+    double b_acc = 0.0, b_cprev = 0.0, b_last = 0.0, b_cbefore = 0.0;
+    bool b_recheck = false;
+    BananaSh<Dual> b_shf{};
+    __device__ __forceinline__ void bound_begin(double &tpo) {
+        b_next = 0; b_acc = 0.0; b_cprev = 0.0; b_last = 0.0; b_cbefore = 0.0; b_recheck = false;
+        tpo = __builtin_huge_val();
+    }
+    __device__ __forceinline__ void bound_resume(double &tpo) { b_recheck = true; tpo = __builtin_huge_val(); }
+
+    __device__ __forceinline__ BananaSh<Dual> head_dual(double t) const {         // GroupChain::shared_at<Dual>: x_0, x_1 flowed, on duals in t
+        const double v0 = V(0), v1 = V(1);
+        const Dual a{fma(v0, t, X(0)), v0}, b{fma(v1, t, X(1)), v1};
+        return tgt.template shared<Dual>(a, b);
+    }
+    // one general tangent-intersection cell of coordinate i (the banana's slot 0), GroupChain::eval_vect<true> + cell_vect
+    __device__ __forceinline__ double cell_general(int i, double t0, double t1, double h, const BananaSh<Dual> &sh0, const BananaSh<Dual> &sh1) const {
+        const double v = V(i), x = X(i);
+        const Dual xt0{fma(v, t0, x), v}, xt1{fma(v, t1, x), v};
+        const Dual gd0 = tgt.grad(i, xt0, sh0), gd1 = tgt.grad(i, xt1, sh1);
+        const double v0 = gd0.v * v, g0 = gd0.e * v, v1 = gd1.v * v, g1 = gd1.e * v;
+        const double num = fma(-g0, t0, fma(g1, t1, v0 - v1));
+        const double den = g1 - g0;
+        const double q = (den != 0.0) ? fmin(fmax(num / den, 0.0), h) : ((num > 0.0) ? h : 0.0);   // cell_q: the clamp of num / 0 without the division
+        const double inter = fma(g0, q, v0);
+        return fmax(fmax(fmax(v0, v1), inter), 0.0);
+    }
+    __device__ __forceinline__ bool bound_advance(double harg, double E, double &tpo, double &lbo, int budget) {
+        const double h = harg / (double)(GNG - 1);
+        bool found = false, found_now = false;
+#ifdef LANE_NO_BOUND
+        tpo = E * h; lbo = y[7]; return true;
+#endif
+        if (b_recheck) {
+            b_recheck = false;
+            if (b_next > 0 && !(b_cprev < E)) {
+                found = true;
+                tpo = (double)(b_next - 1) * h + (E - b_cbefore) / (b_cprev - b_cbefore) * h;
+                lbo = b_last;
+            }
+        }
+        for (int pass = 0; pass < budget; ++pass) {
+            const bool act = !found && b_next < GNG - 1;
+            if (__ballot(act) == 0ull) break;
+            if (act) {
+                const int j = b_next;
+                const double t0 = (double)j * h;
+                double t1 = (j == GNG - 2) ? harg : (double)(j + 1) * h;
+                double part[4] = {0.0, 0.0, 0.0, 0.0};
+                if constexpr (kBanana) {                                          // slot 0: x_0, x_1 twisted (and x_2, x_3 with them, as the group kernel's slot)
+                    if (j == 0) b_shf = head_dual(t0);
+                    const BananaSh<Dual> sh0 = b_shf, sh1 = head_dual(t1);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) part[g] += cell_general(g, t0, t1, h, sh0, sh1);
+                    b_shf = sh1;
+                }
+#pragma unroll
+                for (int s = kBanana ? 1 : 0; s < LK; ++s) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int i = 4 * s + g;
+                        if (in_dim(i)) part[g] += fmax(y[i] + t1, 0.0);           // affine cell, monotone: max(v0, v1, 0) = max(v1, 0), v1 = (x + v t1) v
+                    }
+                    LANE_SLOT_FENCE(part, t1);
+                }
+                const double bj = gsum4(part);
+                b_acc += bj;
+                const double cj = b_acc * h;
+                if (!(cj < E)) { found = true; found_now = true; lbo = bj; }
+                b_cbefore = b_cprev;
+                b_cprev = cj;
+                b_last = bj;
+                b_next = j + 1;
+            }
+        }
+        if (found_now) tpo = (double)(b_next - 1) * h + (E - b_cbefore) / (b_cprev - b_cbefore) * h;
+        const bool fin = found || b_next >= GNG - 1;
+        if (fin && !found) lbo = b_last;
+        return fin;
+    }
+
+    // ---- GroupChain::true_rate for Zig-Zag: sum max(0, grad-U(x + v t) .* v) in the GROUP(4) order
+    __device__ __forceinline__ double true_rate(double t) const {
+        double part[4] = {0.0, 0.0, 0.0, 0.0};
+        BananaSh<double> sh{};
+        if constexpr (kBanana) sh = tgt.template shared<double>(fma(V(0), t, X(0)), fma(V(1), t, X(1)));
+#pragma unroll
+        for (int s = 0; s < LK; ++s) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int i = 4 * s + g;
+                if (in_dim(i)) {
+                    double gv = y[i] + t;                                         // (x + v t) v
+                    if constexpr (kBanana) { if (i < 2) gv = sgn(i == 0 ? sh.g0 : sh.r, sw(i)); }
+                    part[g] += fmax(0.0, gv);
+                }
+            }
+            LANE_SLOT_FENCE(part, t);
+        }
+        return gsum4(part);
+    }
+    // The state is written in ONE place per pass of the state machine, outside every divergent region (no phi webs over the 104
+    // registers of y): flow by tf -- the horizon, the accepted proposal's time, or -0.0 for a lane that does not move (y + (-0.0) = y
+    // for every double, zeros included) -- and flip of coordinate m (-1: none).
+    __device__ __forceinline__ void flow_and_flip(double tf, int m) {
+        const uint32_t bit = 1u << (m & 31);                                      // v[m] *= -1
+        sg0 ^= (m >= 0 && m < 32) ? bit : 0u;
+        sg1 ^= (m >= 32) ? bit : 0u;
+#pragma unroll
+        for (int i = 0; i < LD; ++i) {                                            // padded coordinates are never read
+            asm volatile("v_add_f64 %0, %0, %1" : "+v"(y[i]) : "v"(tf));          // y_i + tf in place (a plain IEEE addition)
+            y[i] = sgn(y[i], (i == m) ? 0x80000000u : 0u);
+        }
+    }
+    // ---- GroupChain::velocity_jump for Zig-Zag (ZigZagSamplers.jl:101-107): Categorical over the un-normalised rates, slots of four
+    // Returns the coordinate to flip (-1: Q11 guard, no flip); reads the state flowed by t (y_i + t: the very doubles flow_and_flip stores).
+    __device__ __forceinline__ int velocity_jump(double S, double t) {
+        BananaSh<double> sh{};
+        if constexpr (kBanana) sh = tgt.template shared<double>(fma(V(0), t, X(0)), fma(V(1), t, X(1)));
+        const double u = rng.uniform();
+        if (!(S > 0.0)) { guard++; return -1; }                                   // Q11
+#ifdef LANE_NO_WALK
+        return (int)(u * 50.0);
+#endif
+        const double theta = u * S;
+        double carry = 0.0, carry_at = 0.0, lh[4] = {0.0, 0.0, 0.0, 0.0};
+        int ms_hit = -1;
+#pragma unroll
+        for (int s = 0; s < LK; ++s) {
+            double l[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int i = 4 * s + g;
+                double gv = y[i] + t;                                             // x v at the accepted point
+                if constexpr (kBanana) { if (i < 2) gv = sgn(i == 0 ? sh.g0 : sh.r, sw(i)); }
+                l[g] = in_dim(i) ? fmax(0.0, gv) : 0.0;
+            }
+            const double T = gsum4(l);
+            if (ms_hit < 0 && (carry + T > theta)) { ms_hit = s; carry_at = carry; lh[0] = l[0]; lh[1] = l[1]; lh[2] = l[2]; lh[3] = l[3]; }
+            carry = carry + T;
+            LANE_SLOT_FENCE(lh, t);
+            asm volatile("" : "+v"(carry), "+v"(carry_at), "+v"(ms_hit));
+        }
+        int m = -1;
+        if (ms_hit >= 0) {                                                        // Kogge-Stone inclusive scan of the hit slot, written out
+            const double a1 = lh[1] + lh[0], a2 = lh[2] + lh[1], a3 = lh[3] + lh[2];
+            const double inc[4] = {lh[0], a1, a2 + lh[0], a3 + a1};
+#pragma unroll
+            for (int g = 3; g >= 0; --g) if ((4 * ms_hit + g < d) && (carry_at + inc[g] > theta)) m = 4 * ms_hit + g;
+        }
+        if (m < 0) m = d - 1;
+        return m;
+    }
+
+    // ---- record!, Composites.jl:239-260, for the lanes with `rec`: X and V rows through the LDS transpose tile.
+    // A lane writes its y row (16 coordinates at a time), its sign words and the byte offset of its event row inside the wave's
+    // window of X / V (64 consecutive chains: 64 n_sk d 8 bytes, < 2^31 -- the host checks) to LDS; then lane (quad = lane / 16,
+    // sub = lane % 16) of store (q, r) reads y of coordinate q + sub of chain 4 r + quad, applies that chain's sign bit -- x = y v,
+    // v = +-1 -- and stores both through buffer descriptors of the window: a chain that does not record publishes an offset beyond
+    // the window and the hardware drops its lanes (no exec masks, no branches in the store loop).  The last four coordinates
+    // (48..51) go out as 16 chains x 4 coordinates per store.
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    static constexpr uint32_t kNoRow = 0x80000000u;
+    __amdgpu_buffer_rsrc_t rsX, rsV;                                              // this unit's windows of p.X and p.V
+    __device__ __forceinline__ void open_window(int64_t b) {
+        const size_t first = (size_t)b * WAVE * (size_t)p.n_sk * (size_t)d;
+        int64_t chains = p.C - b * WAVE;
+        if (chains > WAVE) chains = WAVE;
+        const int bytes = (int)(chains * p.n_sk * d * 8);
+        rsX = __builtin_amdgcn_make_buffer_rsrc(p.X + first, 0, bytes, 0x00020000);
+        rsV = __builtin_amdgcn_make_buffer_rsrc(p.V + first, 0, bytes, 0x00020000);
+    }
+    template <int W, int NR>          // W coordinates x 64 / W chains per store, NR = W stores per tile
+    __device__ __forceinline__ void store_tile(int q, int l) {                    // l = lane (opaque copy: see record)
+        const int sub = l & (W - 1), grp = l / W;
+        const uint32_t sh = (uint32_t)(31 - ((q + sub) & 31));                    // the sign bit of coordinate q + sub, moved to bit 31
+        const bool col_ok = in_dim(q + sub);
+        // one base address per array; the chain of store r lies a constant further on (folds into the DS instruction's offset)
+        const double *tb = tile + grp * LT + sub;
+        const uint32_t *sb = (const uint32_t *)(tile + grp * LT + (LT - 1)) + (q >= 32 ? 1 : 0);
+        const uint32_t *rb = (const uint32_t *)(tile + WAVE * LT) + grp;
+        const uint32_t col = (uint32_t)(q + sub) * 8u;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            constexpr int CH = WAVE / W;                                          // chains per store: store r covers chains CH r .. CH r + CH - 1
+            uint32_t off = rb[CH * r];
+            off = col_ok ? off + col : kNoRow;
+            const double yv = tb[CH * r * LT];
+            const uint32_t w = sb[CH * r * 2 * LT];
+            const uint32_t s31 = (w << sh) & 0x80000000u;
+            u32x2 xv, vv;
+            xv.x = (uint32_t)__double2loint(yv); xv.y = (uint32_t)__double2hiint(yv) ^ s31;
+            vv.x = 0u; vv.y = 0x3ff00000u | s31;
+            __builtin_amdgcn_raw_buffer_store_b64(xv, rsX, (int)off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(vv, rsV, (int)off, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void record(bool rec, int64_t c, int32_t k, double t, double horizon, double ar, int32_t errored,
+                                           const double (&ev)[5], int32_t rejected, int32_t hits) {
+#ifdef LANE_NO_RECORD
+        if (rec) { p.t[(size_t)c * (size_t)p.n_sk + (size_t)k] = t + y[3]; } return;
+#endif
+        int l = lane;
+        asm volatile("" : "+v"(l));               // LDS addresses are rebuilt here from an opaque copy of the lane id: hoisted out of the
+                                                  // event loop they would occupy ~50 registers for the whole launch
+        uint32_t *roff = (uint32_t *)(tile + WAVE * LT);                          // 64 row offsets after the tile
+        double *trow = tile + l * LT;                                             // my tile row; column 16: my two sign words
+        __builtin_amdgcn_wave_barrier();
+        roff[l] = rec ? ((uint32_t)l * (uint32_t)p.n_sk + (uint32_t)k) * (uint32_t)d * 8u : kNoRow;
+        trow[LT - 1] = __longlong_as_double((long long)(((uint64_t)sg1 << 32) | (uint64_t)sg0));
+#pragma unroll
+        for (int q = 0; q < LD; q += 16) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { if (q + j < LD) trow[j] = y[q + j]; }
+            __builtin_amdgcn_wave_barrier();
+            if (q + 16 <= LD) store_tile<16, 16>(q, l);
+            else store_tile<4, 4>(q, l);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (rec) {
+            const size_t e = (size_t)c * (size_t)p.n_sk + (size_t)k;
+            p.t[e] = t;
+            if (p.H) p.H[e] = horizon;
+            if (p.AR) p.AR[e] = ar;
+            if (p.EB) p.EB[e] = errored;
+            if (p.RJ) p.RJ[e] = rejected;
+            if (p.HH) p.HH[e] = hits;
+            if (p.EV) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q) p.EV[5 * e + q] = ev[q];
+            }
+        }
+    }
+
+    // ---- GroupChain::run_segment for the 64 chains of this wave.  Hand-off state of batch b (private to this kernel): word w of
+    // the chain in lane l at state[(b (2d+4) + w) 64 + l] -- y_0..y_{d-1}, the sign words, t, horizon, ar, the stream position.
+    __device__ __forceinline__ void run_segment(int64_t b, int64_t c, bool chain_ok, int r, int64_t seg_len, double *state, int budget) {
+        const int64_t k_begin = 1 + (int64_t)r * seg_len;
+        int64_t k_end = k_begin + seg_len;
+        if (k_end > p.n_sk) k_end = p.n_sk;
+        double *st = state + (size_t)b * (size_t)(2 * d + 4) * WAVE + lane;
+        open_window(b);
+        double t = 0.0, horizon = p.tmax, ar = 0.0;
+        uint64_t n0 = 0;
+        sg0 = 0; sg1 = 0;
+        if (r > 0) {
+#pragma unroll
+            for (int i = 0; i < LD; ++i) y[i] = in_dim(i) ? st[(size_t)i * WAVE] : 0.0;
+            const uint64_t sgw = (uint64_t)__double_as_longlong(st[(size_t)d * WAVE]);
+            sg0 = (uint32_t)sgw; sg1 = (uint32_t)(sgw >> 32);
+            t = st[(size_t)(d + 1) * WAVE]; horizon = st[(size_t)(d + 2) * WAVE]; ar = st[(size_t)(d + 3) * WAVE];
+            n0 = (uint64_t)__double_as_longlong(st[(size_t)(d + 4) * WAVE]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < LD; ++i) {
+                const bool ok = chain_ok && in_dim(i);
+                const double xi = ok ? p.xinit[(size_t)c * d + i] : 0.0;
+                const double vi = ok ? p.vinit[(size_t)c * d + i] : 1.0;
+                const uint32_t s = (uint32_t)__double2hiint(vi) & 0x80000000u;
+                y[i] = sgn(xi, s);
+                if (i < 32) sg0 |= (s >> 31) << (i & 31); else sg1 |= (s >> 31) << (i & 31);
+            }
+        }
+        rng.init_lane(p.seed, (uint64_t)(p.chain0 + c));
+        rng.restore(n0);
+        double ts = 0.0, tp = 0.0, E = 0.0, lb = 0.0;
+        int32_t errored = 0, rejected = 0, hits = 0;
+        double ev[5] = {0, 0, 0, 0, 0};
+        const bool adaptive = p.adaptive != 0;
+        bool done = !chain_ok;
+        if (r == 0) record(!done, c, 0, t, horizon, ar, 0, ev, 0, 0);             // sample.jl:272 (whole wave: the transpose is cooperative)
+        int32_t k = (int32_t)k_begin, it = 0;
+        const int32_t cap = (int32_t)p.cap, kend = (int32_t)k_end;
+        if (k >= kend) done = true;
+        enum : int { FRESH = 0, ERR = 1, REUSE = 2 };
+        bool propose = false, brun = false;
+        int mode = FRESH;
+        double hB = horizon;
+        while (__ballot(!done) != 0ull) {
+            bool accepted = false, proposed = false;
+            double tf = -0.0;
+            int m = -1;
+            LANE_MARK(0);
+            if (!done && !propose) {
+                if (!brun) {
+                    const double harg = (mode == ERR) ? horizon / 2 : ((mode == REUSE) ? hB : horizon);
+                    hB = harg;
+                    const double e1 = rng.exponential();
+                    E = (mode == REUSE) ? E + e1 : e1;
+                    if (mode == REUSE) bound_resume(tp); else bound_begin(tp);
+                    brun = true;
+                }
+                LANE_MARK(1);
+                if (bound_advance(hB, E, tp, lb, budget)) {
+                    LANE_MARK(2);
+                    const double harg = hB;
+                    brun = false;
+                    if (mode == ERR) {
+                        if (adaptive) horizon = harg;
+                        errored++;
+                        const int slot = errored % 5;
+#pragma unroll
+                        for (int q = 0; q < 5; ++q) if (q == slot) ev[q] = ar;
+                        propose = tp < horizon;
+                    } else if (mode == REUSE) {
+                        if (adaptive) horizon = horizon / 1.04;
+                        rejected++;
+                        if (tp > horizon) { tf = horizon; ts += horizon; hits++; }
+                        propose = tp < horizon;
+                    } else if (tp > horizon) {
+                        tf = horizon;
+                        ts += horizon;
+                        hits++;
+                        if (adaptive) horizon = horizon * 1.01;
+                    } else {
+                        propose = tp < horizon;
+                    }
+                    mode = FRESH;
+                    if (++it > cap) { done = true; atomicAdd(&p.status[0], 1); }
+                }
+            }
+            LANE_MARK(3);
+            if (!done && propose) {
+                const double lam = true_rate(tp);
+                LANE_MARK(4);
+                ar = lam / lb;
+                propose = false;
+                if (ar > 1.0) {
+                    mode = ERR;
+                } else {
+                    const double u = rng.uniform();
+                    if (u < ar) {
+                        tf = tp;
+                        m = velocity_jump(lam, tp);
+                        accepted = true;
+                    } else {
+                        mode = REUSE;
+                    }
+                }
+                proposed = true;
+            }
+            LANE_MARK(5);
+            flow_and_flip(tf, m);
+            LANE_MARK(6);
+            if (accepted) { t = t + tp + ts; ts = 0.0; tp = 0.0; }
+            if (__ballot(accepted) != 0ull) record(accepted, c, k, t, horizon, ar, errored, ev, rejected, hits);
+            if (accepted) {
+                errored = 0; rejected = 0; hits = 0;
+#pragma unroll
+                for (int q = 0; q < 5; ++q) ev[q] = 0.0;
+                it = 0;
+                if (++k >= kend) done = true;
+            }
+            LANE_MARK(7);
+            if (proposed && ++it > cap && !done) { done = true; atomicAdd(&p.status[0], 1); }
+        }
+        LANE_MARK(8);
+        // hand-off state (write-through stores, as the group kernel's; padding lanes write their own column too: it is theirs)
+#pragma unroll
+        for (int i = 0; i < LD; ++i) if (in_dim(i)) publish(st + (size_t)i * WAVE, y[i]);
+        publish(st + (size_t)d * WAVE, __longlong_as_double((long long)(((uint64_t)sg1 << 32) | (uint64_t)sg0)));
+        publish(st + (size_t)(d + 1) * WAVE, t); publish(st + (size_t)(d + 2) * WAVE, horizon); publish(st + (size_t)(d + 3) * WAVE, ar);
+        publish(st + (size_t)(d + 4) * WAVE, __longlong_as_double((long long)rng.n));
+        if (guard) { atomicAdd(&p.status[1], guard); guard = 0; }
+    }
+};
+
+// flag[0] != 0 after this kernel: some |v_i| != 1 -- the lane kernel leaves the launch to the group kernel (GroupParams::only_if)
+__global__ __launch_bounds__(256) void lane_check_kernel(const double *vinit, int64_t n, int32_t *flag) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool bad = i < n && fabs(vinit[i]) != 1.0;
+    if (__ballot(bad) != 0ull && lane_id() == 0) atomicOr(flag, 1);
+}
+
+template <int TARGET>
+__global__ __launch_bounds__(256, LANE_WAVES) void lane_kernel(const GroupParams gp, const int32_t *flag) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;      // not unit speeds: the group kernel runs instead
+    extern __shared__ double smem[];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    double *tile = smem + (size_t)wave * LANE_LDS_PER_WAVE;
+    LaneChain<TARGET> chain(gp.s, lane, tile);
+    const int nb = (int)gp.nb, n_units = nb * gp.nseg;
+    bool lost = false;
+    for (int pulled = 0; pulled <= n_units && !lost; ++pulled) {
+        int u = 0;
+        if (lane == 0) u = atomicAdd(gp.ctr, 1);
+        u = __builtin_amdgcn_readfirstlane(u);
+        if (u >= n_units) break;
+        const int r = u / nb, b = u - r * nb;
+        if (r > 0) lost = !wait_progress(gp.progress + b, r);
+        if (!lost) {
+            const int64_t c = (int64_t)b * WAVE + lane;
+            chain.run_segment(b, c, c < gp.s.C, r, gp.seg_len, gp.state, gp.cell_budget);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&gp.progress[b], r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (lost && lane == 0) atomicAdd(&gp.s.status[2], 1);
+}
+
+#ifndef __HIPCC_RTC__
+// segments per chain: ~`rounds` work units per resident wave slot (the units of a launch differ in length; 10^5 chains are 1 563
+// batches for 2 048 slots, so one unit per batch would leave a quarter of the SIMDs with half the work of the others)
+inline void lane_schedule(int64_t nb, int64_t slots, int64_t n_sk, int force, int rounds, int32_t &nseg, int64_t &seg_len) {
+    const int64_t events = n_sk > 1 ? n_sk - 1 : 1;
+    int64_t want = (rounds * slots + nb - 1) / nb;
+    if (force > 0) want = force;
+    const int64_t max_seg = events / 16 > 0 ? events / 16 : 1;
+    if (force <= 0 && want > max_seg) want = max_seg;
+    if (want > events) want = events;
+    if (want < 1) want = 1;
+    seg_len = (events + want - 1) / want;
+    nseg = (int32_t)((events + seg_len - 1) / seg_len);
+}
+
+template <int TARGET>
+inline hipError_t launch_lane(const GroupParams &gp_in, const int32_t *flag, int rounds, hipStream_t stream) {
+    GroupParams gp = gp_in;
+    constexpr int wpb = 4;
+    const size_t lds = (size_t)wpb * LANE_LDS_PER_WAVE * sizeof(double);
+    void (*kernel)(const GroupParams, const int32_t *) = lane_kernel<TARGET>;
+    int per_cu = 0, dev = 0, cus = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE * wpb, lds);
+    if (e != hipSuccess) return e;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (per_cu < 1) per_cu = 1;
+    if (cus < 1) cus = 256;
+    gp.nb = (gp.s.C + WAVE - 1) / WAVE;
+    const int64_t slots = (int64_t)cus * per_cu * wpb;
+    lane_schedule(gp.nb, slots, gp.s.n_sk, gp.nseg, rounds, gp.nseg, gp.seg_len);
+    int64_t blocks = (gp.nb * gp.nseg + wpb - 1) / wpb;
+    if (blocks > (int64_t)cus * per_cu) blocks = (int64_t)cus * per_cu;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(WAVE * wpb), lds, stream, gp, flag);
+    return hipGetLastError();
+}
+hipError_t launch_lane_zigzag(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);
+hipError_t launch_lane_check(const double *vinit, int64_t n, int32_t *flag, hipStream_t stream);
+#endif
+
+}  // namespace pdmp

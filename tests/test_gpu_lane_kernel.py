@@ -1,0 +1,97 @@
+"""The one-lane-per-chain kernel (csrc/lane_kernel.hpp) -- large Zig-Zag ensembles at d = 49..52 on the isotropic Gaussian and the
+banana -- against the checker in the GROUP(4) order and against the group kernel it replaces: bit for bit, every array, every
+diagnostic; hand-off between segments, ragged batches, bound instalments, the fall-back for speeds that are not +-1."""
+import numpy as np
+import pytest
+
+from helpers import assert_bitwise, make_init, make_pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def lane(monkeypatch):
+    monkeypatch.setenv("PDMP_LANE", "1")      # take the lane kernel whatever the number of chains
+    return monkeypatch
+
+
+def _run(engine, oracle, dim, target, C, n_sk, seed=3, init_seed=0, diagnostics=True, **kw):
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", dim, target, **kw)
+    assert s.group_lanes() == 4
+    x, v = make_init("ZigZagAD", dim, C, seed=init_seed, target=target)
+    got = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=seed, diagnostics=diagnostics)
+    return s, cfg, x, v, got
+
+
+@pytest.mark.parametrize("dim", [49, 50, 51, 52])
+@pytest.mark.parametrize("target", ["iso", "banana"])
+def test_lane_kernel_matches_checker(engine, oracle, lane, dim, target):
+    s, cfg, x, v, got = _run(engine, oracle, dim, target, 150, 120)          # 150 chains: two full batches and a ragged one
+    ref = oracle.sample_skeleton(cfg, 120, x, v, 3, diagnostics=True)
+    assert_bitwise(got, ref)
+
+
+@pytest.mark.parametrize("target", ["iso", "banana"])
+def test_lane_kernel_equals_group_kernel(engine, oracle, monkeypatch, target):
+    """The choice between the two kernels -- made per launch from the number of chains -- cannot be seen in the results."""
+    monkeypatch.setenv("PDMP_LANE", "0")
+    _, _, _, _, a = _run(engine, oracle, 50, target, 333, 200, seed=11)
+    monkeypatch.setenv("PDMP_LANE", "1")
+    _, _, _, _, b = _run(engine, oracle, 50, target, 333, 200, seed=11)
+    assert_bitwise(b, a)
+
+
+@pytest.mark.parametrize("segments", [2, 7, 1000])
+@pytest.mark.parametrize("target", ["iso", "banana"])
+def test_lane_kernel_segment_handoff(engine, oracle, lane, segments, target):
+    lane.setenv("PDMP_FORCE_SEGMENTS", str(segments))
+    s, cfg, x, v, got = _run(engine, oracle, 50, target, 70, 90)
+    assert_bitwise(got, oracle.sample_skeleton(cfg, 90, x, v, 3, diagnostics=True))
+
+
+@pytest.mark.parametrize("budget", ["1", "2", "5", "9"])
+def test_lane_kernel_bound_instalments(engine, oracle, lane, budget):
+    lane.setenv("PDMP_CELL_BUDGET", budget)
+    s, cfg, x, v, got = _run(engine, oracle, 50, "banana", 70, 60)
+    assert_bitwise(got, oracle.sample_skeleton(cfg, 60, x, v, 3, diagnostics=True))
+
+
+@pytest.mark.parametrize("kw", [{"tmax": 0.0}, {"tmax": 0.05}, {"tmax": 20.0}, {"adaptive": False, "tmax": 0.4}])
+def test_lane_kernel_horizons(engine, oracle, lane, kw):
+    """Fixed and extreme horizons: bounds that run to the horizon (all nine cells), rejections, erroneous bounds."""
+    s, cfg, x, v, got = _run(engine, oracle, 50, "banana", 70, 60, **kw)
+    assert_bitwise(got, oracle.sample_skeleton(cfg, 60, x, v, 3, diagnostics=True))
+
+
+def test_lane_kernel_zero_start(engine, oracle, lane):
+    """x = 0 exactly with both signs of v: y = x v starts at +-0."""
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", 50, "iso")
+    x = np.zeros((64, 50))
+    v = np.where(np.random.default_rng(5).random((64, 50)) < 0.5, -1.0, 1.0)
+    got = engine.sample_skeleton_ensemble(s, 40, x, v, seed=9, diagnostics=True)
+    assert_bitwise(got, oracle.sample_skeleton(cfg, 40, x, v, 9, diagnostics=True))
+
+
+def test_lane_kernel_leaves_other_speeds_to_the_group_kernel(engine, oracle, lane):
+    """|v_i| != 1 somewhere in the ensemble: the check kernel raises the flag and the group kernel does the launch's work."""
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", 50, "iso")
+    x, v = make_init("ZigZagAD", 50, 130)
+    v[77, 13] = 0.5
+    got = engine.sample_skeleton_ensemble(s, 50, x, v, seed=2, diagnostics=True)
+    assert_bitwise(got, oracle.sample_skeleton(cfg, 50, x, v, 2, diagnostics=True))
+
+
+def test_lane_kernel_full_machine(engine, oracle, monkeypatch):
+    """Default selection (no environment): 65 600 chains take the lane kernel, more batches than resident waves, several segments per
+    chain; a strided sample of chains bit for bit against the checker, global chain ids, invariants on every chain."""
+    monkeypatch.delenv("PDMP_LANE", raising=False)
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", 50, "banana")
+    C = 65600
+    x, v = make_init("ZigZagAD", 50, C, target="banana")
+    got = engine.sample_skeleton_ensemble(s, 96, x, v, seed=77, diagnostics=False)
+    for c in np.arange(0, C, 1291):
+        r1 = oracle.sample_skeleton(cfg, 96, x[c:c + 1], v[c:c + 1], 77, chain_id_offset=int(c), diagnostics=False)
+        for k in ("X", "V", "t"):
+            assert np.array_equal(got[k][c], r1[k][0]), (k, c)
+    assert (np.diff(got["t"], axis=1) > 0).all()
+    assert (np.abs(got["V"]) == 1.0).all()
