@@ -175,7 +175,7 @@ def cpu_baseline(a, sampler):
                       f"OpenMP over chains on {cores} threads (hardware threads visible: {nproc}, CPU share of this process: {share}), static slabs, -O2 no fast-math, reference summation order)"}
 
 
-def measured_counters(a, C_local, G):
+def measured_counters(a, C_local, G, form=0):
     """HBM bytes per launch and VALU instruction counts of the dominant kernel from the rocprofv3 PMC passes (WRITE_SIZE exact,
     FETCH_SIZE x2 on gfx950; collected by profiles/collect.sh in separate --pmc runs and committed as profiles/traffic.json).
     PMC counters cannot be read from inside this process, so the figures are the COMMITTED measurement of the identical
@@ -185,6 +185,8 @@ def measured_counters(a, C_local, G):
     except (OSError, ValueError):
         return None
     key = f"{a.sampler}|{a.target}|d={a.dim}|C={C_local}|n_sk={a.n_sk}"
+    if form == 4:                                                # the one-lane-per-chain kernel has its own measurements
+        return table.get(key + "|lane")
     e = table.get(key + f"|G={G}") or table.get(key)
     return e
 
@@ -328,7 +330,11 @@ def main():
         kernel = (f"group_kernel_reg<{sampler.name},{a.target}> (G={G} lanes per chain, K={K} slots, x and v in registers)" if reg_form else
                   f"group_kernel<{sampler.name},{a.target}> (G={G} lanes per chain)" if G > 0 else
                   f"skeleton_kernel<{sampler.name},{a.target}> (wave per chain)")
-        cnt = measured_counters(a, C_local, G)
+        form = sampler.last_launch_form()                        # which kernel form served the timed launches (pdmp_last_launch_form)
+        if form == 4:
+            kernel = (f"lane_kernel<{a.target}> (one lane per chain, 64 chains per wave; signed positions y = x v in registers, "
+                      "events stored as whole 64-byte lines)")
+        cnt = measured_counters(a, C_local, G, form)
         xbytes = 0 if gather != "skeleton" else (C_total - C_local) * n_sk * bytes_per_event
         res = {
             "metric": metric_label(a, sampler, C_total),
@@ -349,8 +355,11 @@ def main():
                          "kernel": kernel, "kernel_ms": kernel_ms, "bytes_per_event": bytes_per_event,
                          "valu": ({"instr_per_event": cnt.get("valu_instr_per_event"), "busy": cnt.get("valu_busy"),
                                    "source": cnt.get("valu_source")} if cnt and cnt.get("valu_instr_per_event") else None),
-                         "note": "the kernel is bound by fp64 VALU issue, not by HBM (roofline.valu: wave-instructions per event and the share of "
-                                 "SIMD cycles the VALUs are busy, from the committed PMC pass); the HBM fraction is the requested headline"},
+                         "note": ("HBM-write bound: roofline.traffic / kernel_ms is the write rate the launch sustains (a plain fill of this GPU "
+                                  "reaches ~5.6 TB/s); roofline.valu = wave-instructions per event and the share of SIMD cycles the VALUs are busy"
+                                  if form == 4 else
+                                  "the kernel is bound by fp64 VALU issue, not by HBM (roofline.valu: wave-instructions per event and the share of "
+                                  "SIMD cycles the VALUs are busy, from the committed PMC pass); the HBM fraction is the requested headline")},
         }
         if a.target == "dense" and int(_lib.lib().pdmp_dense_batched_last_mode()) == 2:
             res["roofline"]["kernel"] = ("di_segment_kernel (wave per chain; P x and P v kept current by O(d) updates, one rocBLAS dgemm over all "

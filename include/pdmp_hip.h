@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PDMP_ABI_VERSION 6   /* 6: is_active / ragged lengths in sample_from_skeleton*, moments and close_at; + the (N, dt) method, pdmp_compact_*, pdmp_multi_*; 5: + PDMP_STICKY, pdmp_diag_t.is_active; 2: + pdmp_create_from_source, PDMP_T_USER; 3: + PDMP_FECMC and its keywords at the end of pdmp_config_t; 4: + PDMP_SUZZ, PDMP_RHMC and its keywords */
+#define PDMP_ABI_VERSION 7   /* 7: + pdmp_last_launch_form; 6: is_active / ragged lengths in sample_from_skeleton*, moments and close_at; + the (N, dt) method, pdmp_compact_*, pdmp_multi_*; 5: + PDMP_STICKY, pdmp_diag_t.is_active; 2: + pdmp_create_from_source, PDMP_T_USER; 3: + PDMP_FECMC and its keywords at the end of pdmp_config_t; 4: + PDMP_SUZZ, PDMP_RHMC and its keywords */
 
 enum { PDMP_OK = 0, PDMP_ERR_ARGUMENT = -1, PDMP_ERR_DIMENSION = -2, PDMP_ERR_RUNTIME = -3,
        PDMP_ERR_ITERCAP = -4, PDMP_ERR_UNSUPPORTED = -5 };
@@ -136,6 +136,11 @@ int pdmp_get_group_lanes(pdmp_handle h);
  * G, which is why a sharded run (pdmp_multi_*, the Python driver) uses ONE G for all shards. */
 int pdmp_suggest_group_lanes(pdmp_handle h, int64_t C);
 int pdmp_set_group_lanes(pdmp_handle h, int32_t G);
+/* Which kernel form served the handle's last pdmp_sample_skeleton* launch (waits for it to finish): a diagnostic for benchmarks and
+ * tests, results do not depend on it.  PDMP_FORM_LANE: one lane per chain (csrc/lane_kernel.hpp; large Zig-Zag ensembles at
+ * dim 49..52 with unit speeds on the isotropic Gaussian / banana -- bit-identical to the group kernel with G = 4). */
+enum { PDMP_FORM_NONE = 0, PDMP_FORM_WAVE = 1, PDMP_FORM_GROUP = 2, PDMP_FORM_GROUP_REG = 3, PDMP_FORM_LANE = 4, PDMP_FORM_DENSE = 5, PDMP_FORM_USER = 6 };
+int pdmp_last_launch_form(pdmp_handle h);
 
 /* Tape source: replace the built-in Philox stream (the engine's stand-in for Julia's
  * MersenneTwister, AbstractPDMP.jl:100) by pre-recorded variates, one tape per kind in consumption order --

@@ -19,7 +19,7 @@ using PDMPFlux: AbstractPDMP, PDMPHistory
 import PDMPFlux: sample, sample_skeleton, sample_from_skeleton
 
 const LIB = get(ENV, "PDMPHIP_LIB", "libpdmphip.so")
-const ABI_VERSION = 6
+const ABI_VERSION = 7
 
 # ---------------------------------------------------------------------------------------------- C structs (include/pdmp_hip.h)
 struct Config   # pdmp_config_t

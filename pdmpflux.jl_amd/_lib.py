@@ -58,7 +58,7 @@ class Timing(C.Structure):
 # every symbol include/pdmp_hip.h declares; tests check that the library exports all of them
 SYMBOLS = (
     "pdmp_abi_version", "pdmp_last_error", "pdmp_device_count", "pdmp_create", "pdmp_create_from_source", "pdmp_get_config",
-    "pdmp_destroy", "pdmp_get_group_lanes", "pdmp_suggest_group_lanes", "pdmp_set_group_lanes", "pdmp_set_tape", "pdmp_clear_tape", "pdmp_sample_skeleton", "pdmp_sample_skeleton_device", "pdmp_sample_from_skeleton",
+    "pdmp_destroy", "pdmp_get_group_lanes", "pdmp_suggest_group_lanes", "pdmp_set_group_lanes", "pdmp_last_launch_form", "pdmp_set_tape", "pdmp_clear_tape", "pdmp_sample_skeleton", "pdmp_sample_skeleton_device", "pdmp_sample_from_skeleton",
     "pdmp_sample_from_skeleton_device", "pdmp_sample_from_skeleton_dt", "pdmp_sample_from_skeleton_dt_device",
     "pdmp_sample_from_skeleton_prefix", "pdmp_sample_from_skeleton_prefix_device", "pdmp_sample_moments_device",
     "pdmp_close_at_time_device", "pdmp_compact_offsets_device", "pdmp_compact_history_device",
@@ -96,6 +96,8 @@ def lib():
     L.pdmp_destroy.argtypes = [vp]
     L.pdmp_get_group_lanes.argtypes = [vp]
     L.pdmp_get_group_lanes.restype = C.c_int
+    L.pdmp_last_launch_form.argtypes = [vp]
+    L.pdmp_last_launch_form.restype = C.c_int
     L.pdmp_suggest_group_lanes.argtypes = [vp, i64]
     L.pdmp_suggest_group_lanes.restype = C.c_int
     L.pdmp_set_group_lanes.argtypes = [vp, i32]
@@ -126,7 +128,7 @@ def lib():
     L.pdmp_dense_batched_last_phases.restype = C.c_longlong
     L.pdmp_dense_batched_last_columns.restype = C.c_longlong
     L.pdmp_dense_batched_last_mode.restype = C.c_int
-    if L.pdmp_abi_version() != 6:
+    if L.pdmp_abi_version() != 7:
         raise EngineError(ERR_RUNTIME, "ABI version mismatch")
     _lib = L
     return L

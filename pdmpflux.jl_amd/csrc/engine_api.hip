@@ -65,6 +65,7 @@ struct pdmp_engine {
     pdmp_config_t cfg;
     void *user_fn = nullptr;          // PDMP_T_USER: the runtime-compiled group kernel (user_jit.hip)
     int group_lanes = 0;              // 0: wave-per-chain kernel; else lanes per chain of the group kernel
+    int last_form = 0;                // PDMP_FORM_* of the last launch (PDMP_FORM_LANE: provided the unit-speed flag stayed 0)
     int device = 0;
     double *d_tparams = nullptr;
     int32_t *d_status = nullptr;      // [0] itercap chains, [1] guard events, [2] lost hand-offs, [3] spare
@@ -718,6 +719,15 @@ int pdmp_create_from_source(const pdmp_config_t *cfg, const char *source, int32_
     return create_impl(cfg, source, kind, out);
 }
 
+int pdmp_last_launch_form(pdmp_handle h) {
+    if (!h) return -1;
+    if (h->last_form != PDMP_FORM_LANE) return h->last_form;
+    int32_t flag = 0;                              // the lane kernel ran unless the check kernel found a speed other than +-1
+    if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->last_stream) != hipSuccess ||
+        hipMemcpy(&flag, h->d_status + 4, sizeof flag, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return flag == 0 ? PDMP_FORM_LANE : PDMP_FORM_GROUP_REG;
+}
+
 int pdmp_get_group_lanes(pdmp_handle h) { return h ? (h->tape_chains > 0 ? 0 : h->group_lanes) : -1; }
 
 // Lanes per chain for launches of C chains.  Round 2 measured the obvious idea -- more lanes per chain when a launch cannot fill
@@ -903,14 +913,17 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
                                         chain_id_offset, seed, xinit, vinit, X, V, t, p.H, p.AR, p.EB, p.EV, p.RJ, p.HH,
                                         h->d_status, stream, msg, (int)sizeof msg);
         if (rc != 0) { h->pool.push_back(ev); return fail(rc == -4 ? PDMP_ERR_ITERCAP : PDMP_ERR_RUNTIME, "dense batched path: %s", msg); }
+        h->last_form = PDMP_FORM_DENSE;
         return end_timed(h, s, ev);
     }
     if (c.target_id == PDMP_T_USER) {
         if (taped || h->group_lanes <= 0 || !h->user_fn) { h->pool.push_back(ev); return fail(PDMP_ERR_UNSUPPORTED, "potentials given as source: no tape replay"); }
+        h->last_form = PDMP_FORM_USER;
         const int e = pdmp_user_launch(h->user_fn, &gp, s);
         if (e != 0) { h->pool.push_back(ev); return fail(PDMP_ERR_RUNTIME, "launching the compiled potential: %s", hipGetErrorString((hipError_t)e)); }
     } else if (h->group_lanes > 0 && !taped) {
         hipError_t e = hipErrorNotSupported;
+        h->last_form = PDMP_FORM_GROUP_REG;
         const char *reg = getenv("PDMP_REG");               // PDMP_REG=0: keep x, v in LDS tiles (test hook)
         // register form: the default bound flags only (grid_size = 10; Zig-Zag: vectorized signed bound) -- GroupChain::brent() etc.
         const bool reg_flags = c.grid_size == GNG && (c.sampler != PDMP_ZIGZAG || (c.vectorized_bound && c.signed_bound));
@@ -921,18 +934,23 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
             // returns at once and the group kernel below (which returns at once while the flag is 0) does the launch's work.
             const char *lane_env = getenv("PDMP_LANE");     // 0: never, 1: whenever the configuration allows (tests), unset: from the chain count
             const char *lane_min = getenv("PDMP_LANE_MIN_CHAINS");
-            const int64_t lane_from = lane_min ? atoll(lane_min) : 49152;
+            // measured (one MI355X, n_sk = 1000): up to 65 536 chains the lane kernel takes 10.9 ms (Gaussian) / 13.1 ms (banana) whatever the
+            // count -- one wave per SIMD walks its 64 chains' events one after the other -- and the group kernel 0.3 / 0.25 ms per 1 000 chains
+            const int64_t lane_from = lane_min ? atoll(lane_min) : (c.target_id == PDMP_T_BANANA ? 56000 : 40000);
             const bool lane_ok = c.sampler == PDMP_ZIGZAG && !fd && (c.target_id == PDMP_T_GAUSS_ISO || c.target_id == PDMP_T_BANANA) &&
                                  c.dim >= 49 && c.dim <= 52 && gp.G == 4 && (int64_t)WAVE * n_sk * c.dim * 8 < 0x7fffffffLL;   // (a batch's window of X: 31-bit byte offsets)
             if (lane_ok && !(lane_env && atoi(lane_env) == 0) && ((lane_env && atoi(lane_env) == 1) || C >= lane_from)) {
                 int32_t *flag = h->d_status + 4;
                 hipError_t le = hipMemsetAsync(flag, 0, sizeof(int32_t), s);
                 if (le == hipSuccess) le = launch_lane_check(vinit, C * (int64_t)c.dim, flag, s);
-                int rounds = 8;
+                int rounds = 24;                             // work units per resident wave (measured: 8 -> 24: 18.2 -> 16.8 ms at config 2)
                 if (const char *r = getenv("PDMP_LANE_ROUNDS")) { const int v = atoi(r); if (v >= 1 && v <= 64) rounds = v; }
-                if (le == hipSuccess) le = launch_lane_zigzag(c.target_id, gp, flag, rounds, s);
+                GroupParams lp = gp;
+                if (!getenv("PDMP_CELL_BUDGET")) lp.cell_budget = 5;   // a pass of 64 chains costs ~2 000 instructions, a cell 240: wait for more cells
+                if (le == hipSuccess) le = launch_lane_zigzag(c.target_id, lp, flag, rounds, s);
                 if (le != hipSuccess) { h->pool.push_back(ev); return fail(PDMP_ERR_RUNTIME, "lane kernel launch: %s", hipGetErrorString(le)); }
                 gp.only_if = flag;
+                h->last_form = PDMP_FORM_LANE;
             }
             const char *ex = getenv("PDMP_REG_EXACT");      // PDMP_REG_EXACT=0: the KREG-slot kernels with per-slot skips (test hook)
             if (!(ex && atoi(ex) == 0))                     // a kernel of exactly K slots where one exists
@@ -948,12 +966,14 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
                                                 : hipErrorNotSupported;
         }
         if (e == hipErrorNotSupported) {
+            h->last_form = PDMP_FORM_GROUP;
             const glaunch_fn f = pick_group_launcher(c.sampler, c.target_id);
             if (!f) { h->pool.push_back(ev); return fail(PDMP_ERR_UNSUPPORTED, "no group kernel for sampler %d on target %d", c.sampler, c.target_id); }
             e = f(gp, s);
         }
         if (e != hipSuccess) { h->pool.push_back(ev); return fail(PDMP_ERR_RUNTIME, "group kernel launch: %s", hipGetErrorString(e)); }
     } else {
+        h->last_form = PDMP_FORM_WAVE;
         const launch_fn f = pick_launcher(c.sampler, c.target_id);
         if (!f) { h->pool.push_back(ev); return fail(PDMP_ERR_UNSUPPORTED, "the wave-per-chain kernel serves Zig-Zag / BPS / Boomerang on the built-in separable / banana targets"); }
         const hipError_t e = f(p, s);

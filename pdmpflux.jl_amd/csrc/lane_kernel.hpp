@@ -27,13 +27,20 @@
 #pragma once
 #include "group_kernel.hpp"
 
+#ifndef LANE_WAVES
+#define LANE_WAVES 1          // waves per SIMD the kernel is compiled for (512 registers per lane at 1)
+#endif
+#ifndef LANE_STORE_AUX
+#define LANE_STORE_AUX 2      // nt: streaming stores (measured 16.8 -> 16.5 ms); cache-policy bits of the event stores (buffer_store ... sc0 = 1 / nt = 2 / sc1 = 16)
+#endif
+
 namespace pdmp {
 
 constexpr int LK = 13;            // slots of the emulated G = 4 layout: d <= 52
 constexpr int LD = 4 * LK;        // coordinate registers per lane
-constexpr int LT = 17;            // LDS transpose tile: 64 chains x 16 coordinates, rows padded to 17 doubles
+constexpr int LR = 61;            // LDS row of a chain: up to 7 carried doubles + 52 coordinates, padded to an odd stride
 constexpr int LANE_DMIN = LD - 3; // the last slot may be partly padding, no other
-constexpr int LANE_LDS_PER_WAVE = WAVE * LT + WAVE;   // doubles: transpose tile + row indices
+constexpr int LANE_LDS_PER_WAVE = WAVE * LR + 2 * WAVE + 8 * WAVE;   // doubles: 64 rows + 16 bytes of store parameters per chain + 8 event times per chain
 
 // Slot loops run slot by slot: without this the scheduler hoists the 52 independent terms of a sum in front of their
 // additions (104 more live registers, spills); with it a slot's four terms are in flight at a time -- still four independent
@@ -57,7 +64,7 @@ struct LaneChain {
     uint32_t sg0 = 0, sg1 = 0;    // bit i of (sg1:sg0) set <=> v_i = -1
     ChainRng rng;
     int32_t guard = 0;
-    double *tile;                 // this wave's LDS transpose tile (64 x LT doubles) followed by 64 row indices
+    double *tile;                 // this wave's LDS: 64 rows of LR doubles, then 64 x (sign bits, window offset, valid range)
 
     __device__ __forceinline__ LaneChain(const SkelParams &sp, int l, double *t_) : p(sp), lane(l), d(sp.d), tile(t_) { tgt.init(nullptr, sp.d); }
 
@@ -73,6 +80,32 @@ struct LaneChain {
     __device__ __forceinline__ double V(int i) const { return __hiloint2double((int)(0x3ff00000u | sw(i)), 0); }
     __device__ __forceinline__ bool in_dim(int i) const { return i < LANE_DMIN || i < d; }
     __device__ __forceinline__ static double gsum4(const double (&a)[4]) { return (a[0] + a[1]) + (a[2] + a[3]); }   // the xor-1, xor-2 butterfly
+
+    // ---- random stream, prefetched per pass of the state machine (as GroupChain's, without the lane pairing): a pass draws at most three
+    // variates of a chain -- the bound's exponential, the acceptance uniform, the jump's uniform: stream positions n, n+1, n+2 = Philox
+    // blocks n >> 1 and (n >> 1) + 1.  Drawn one by one each draw would run the ten Philox rounds whenever ANY of the 64 chains starts a
+    // new block, i.e. three times per pass; here both blocks are computed once at the top of the pass and a draw picks its two words.
+    // (The eight words are locals of run_segment, not members: a select between members turns into a dynamic address into this object
+    // and keeps all of it -- y included -- in scratch memory.)
+    struct Prefetch { uint32_t a0, a1, a2, a3, b0, b1, b2, b3; uint64_t blk; };
+    __device__ __forceinline__ Prefetch rng_prefetch() const {
+        Prefetch f;
+        f.blk = rng.n >> 1;
+        uint32_t w[4];
+        rng.block_at(f.blk, w);
+        f.a0 = w[0]; f.a1 = w[1]; f.a2 = w[2]; f.a3 = w[3];
+        uint32_t v[4];
+        rng.block_at(f.blk + 1, v);
+        f.b0 = v[0]; f.b1 = v[1]; f.b2 = v[2]; f.b3 = v[3];
+        return f;
+    }
+    __device__ __forceinline__ double draw_uniform(const Prefetch &f) {
+        const uint32_t idx = (uint32_t)(rng.n - 2 * f.blk);                       // 0..3: the first three draws of a pass (a fourth would repeat idx 3: none is made)
+        const bool hi2 = (idx & 2u) != 0u, odd = (idx & 1u) != 0u;
+        const uint32_t lo_a = odd ? f.a2 : f.a0, hi_a = odd ? f.a3 : f.a1, lo_b = odd ? f.b2 : f.b0, hi_b = odd ? f.b3 : f.b1;
+        ++rng.n;
+        return bits_to_u(hi2 ? lo_b : lo_a, hi2 ? hi_b : hi_a);
+    }
 
     // ---- the lazily built vectorized bound, GroupChain::bound_advance_vect<true, false> for this chain
     int b_next = 0;
@@ -183,18 +216,21 @@ struct LaneChain {
         const uint32_t bit = 1u << (m & 31);                                      // v[m] *= -1
         sg0 ^= (m >= 0 && m < 32) ? bit : 0u;
         sg1 ^= (m >= 32) ? bit : 0u;
+        // the flip: one compare per slot of four, then per coordinate a select of the lane's word for g = m % 4 and the xor
+        const int ms = m >> 2, mg = m & 3;                                        // (m = -1: slot -1, no slot matches)
+        const uint32_t x0 = (mg == 0) ? 0x80000000u : 0u, x1 = (mg == 1) ? 0x80000000u : 0u, x2 = (mg == 2) ? 0x80000000u : 0u,
+                       x3 = (mg == 3) ? 0x80000000u : 0u;
 #pragma unroll
         for (int i = 0; i < LD; ++i) {                                            // padded coordinates are never read
             asm volatile("v_add_f64 %0, %0, %1" : "+v"(y[i]) : "v"(tf));          // y_i + tf in place (a plain IEEE addition)
-            y[i] = sgn(y[i], (i == m) ? 0x80000000u : 0u);
+            const uint32_t xg = (i & 3) == 0 ? x0 : ((i & 3) == 1 ? x1 : ((i & 3) == 2 ? x2 : x3));
+            y[i] = sgn(y[i], (ms == (i >> 2)) ? xg : 0u);
         }
     }
-    // ---- GroupChain::velocity_jump for Zig-Zag (ZigZagSamplers.jl:101-107): Categorical over the un-normalised rates, slots of four
     // Returns the coordinate to flip (-1: Q11 guard, no flip); reads the state flowed by t (y_i + t: the very doubles flow_and_flip stores).
-    __device__ __forceinline__ int velocity_jump(double S, double t) {
+    __device__ __forceinline__ int velocity_jump(double S, double t, double u) {           // u: the Categorical's uniform
         BananaSh<double> sh{};
         if constexpr (kBanana) sh = tgt.template shared<double>(fma(V(0), t, X(0)), fma(V(1), t, X(1)));
-        const double u = rng.uniform();
         if (!(S > 0.0)) { guard++; return -1; }                                   // Q11
 #ifdef LANE_NO_WALK
         return (int)(u * 50.0);
@@ -229,47 +265,75 @@ struct LaneChain {
         return m;
     }
 
-    // ---- record!, Composites.jl:239-260, for the lanes with `rec`: X and V rows through the LDS transpose tile.
-    // A lane writes its y row (16 coordinates at a time), its sign words and the byte offset of its event row inside the wave's
-    // window of X / V (64 consecutive chains: 64 n_sk d 8 bytes, < 2^31 -- the host checks) to LDS; then lane (quad = lane / 16,
-    // sub = lane % 16) of store (q, r) reads y of coordinate q + sub of chain 4 r + quad, applies that chain's sign bit -- x = y v,
-    // v = +-1 -- and stores both through buffer descriptors of the window: a chain that does not record publishes an offset beyond
-    // the window and the hardware drops its lanes (no exec masks, no branches in the store loop).  The last four coordinates
-    // (48..51) go out as 16 chains x 4 coordinates per store.
+    // ---- record!, Composites.jl:239-260, for the lanes with `rec`: X and V rows through LDS, stored as WHOLE 64-byte lines.
+    // X[c, k, :] of consecutive events of a chain are contiguous in memory (d doubles each), so a chain writes one continuous
+    // stream per array.  An event row of 400 bytes straddles lines; written as it comes, the straddled lines leave the L2 half
+    // written and are written twice (profiles: 93.6 GB for 80.7 GB of events).  Here the tail of a row that does not complete
+    // a line stays in the chain's LDS row -- the "carry", `cl` doubles -- and goes out in front of the next event's row:
+    //   LDS row = [carry | y_0 .. y_{d-1}] = stream positions A .. A + cl + d - 1, A a multiple of 8 doubles;
+    //   the first nfull = 8 floor((cl + d) / 8) doubles are stored (lines A / 8 ...), the rest becomes the next carry.
+    // Values are kept as (y, sign bit): x = y with the sign flipped where the bit is set, v = +-1 from the same bit; bit i of
+    // the chain's 64-bit word S belongs to row position i (carried positions keep the bits they were recorded with).
+    // Store (q, r): lane (grp = lane / W, sub = lane % W) handles position q + sub of chain (64 / W) r + grp through buffer
+    // descriptors of the wave's window of X / V (64 consecutive chains, < 2^31 bytes -- the host checks); a chain that does not
+    // record publishes an offset beyond the window and the hardware drops its lanes: no exec masks, no branches in the loop.
+    // At the end of a segment the carry is flushed as a partial line; the next segment starts mid-line (`skip`).
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     static constexpr uint32_t kNoRow = 0x80000000u;
     __amdgpu_buffer_rsrc_t rsX, rsV;                                              // this unit's windows of p.X and p.V
-    __device__ __forceinline__ void open_window(int64_t b) {
+    int cl = 0, skip = 0;                                                         // carried doubles; leading row positions that are not mine (segment start)
+    uint32_t Sc0 = 0, Sc1 = 0;                                                    // sign bits of the carried doubles
+    __device__ __forceinline__ void open_window(int64_t b, int64_t c, int64_t k_first) {
         const size_t first = (size_t)b * WAVE * (size_t)p.n_sk * (size_t)d;
         int64_t chains = p.C - b * WAVE;
         if (chains > WAVE) chains = WAVE;
         const int bytes = (int)(chains * p.n_sk * d * 8);
         rsX = __builtin_amdgcn_make_buffer_rsrc(p.X + first, 0, bytes, 0x00020000);
         rsV = __builtin_amdgcn_make_buffer_rsrc(p.V + first, 0, bytes, 0x00020000);
+        // my stream starts this far into a 64-byte line of memory
+        cl = skip = (int)(((uintptr_t)(p.X + ((size_t)c * (size_t)p.n_sk + (size_t)k_first) * (size_t)d) >> 3) & 7);
+        Sc0 = Sc1 = 0;
+        tfirst = (int)(((uintptr_t)(p.t + (size_t)c * (size_t)p.n_sk + (size_t)k_first) >> 3) & 7);
+        tlast = -1;
     }
-    template <int W, int NR>          // W coordinates x 64 / W chains per store, NR = W stores per tile
+    // Event times: 8 bytes per event, eight events of a chain per 64-byte line -- stored one by one each would leave the L2 as a
+    // partial line.  They wait in LDS (slot = the time's position in its line, [slot][lane]) until the line is complete.
+    int tfirst = 0, tlast = -1;                                                   // first valid slot of the line being filled; last slot filled (-1: nothing waits)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    __device__ __forceinline__ void store_times(double *line, const double *ring, int lo, int hi) {   // slots lo..hi of my line
+        if (lo == 0 && hi == 7) {
+            d2 *dst = (d2 *)line;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { d2 v; v.x = ring[(2 * j) * WAVE]; v.y = ring[(2 * j + 1) * WAVE]; dst[j] = v; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (j >= lo && j <= hi) line[j] = ring[j * WAVE];
+        }
+    }
+    // store parameters of a chain, 16 bytes: S (two words), window offset of row position 0 (kNoRow: nothing to store), skip | nfull << 8
+    template <int W, int NR, bool LO, bool HI>      // W positions x 64 / W chains per store, NR stores; LO / HI: check position >= skip / < nfull
     __device__ __forceinline__ void store_tile(int q, int l) {                    // l = lane (opaque copy: see record)
+        constexpr int CH = WAVE / W;                                              // chains per store: store r covers chains CH r .. CH r + CH - 1
         const int sub = l & (W - 1), grp = l / W;
-        const uint32_t sh = (uint32_t)(31 - ((q + sub) & 31));                    // the sign bit of coordinate q + sub, moved to bit 31
-        const bool col_ok = in_dim(q + sub);
-        // one base address per array; the chain of store r lies a constant further on (folds into the DS instruction's offset)
-        const double *tb = tile + grp * LT + sub;
-        const uint32_t *sb = (const uint32_t *)(tile + grp * LT + (LT - 1)) + (q >= 32 ? 1 : 0);
-        const uint32_t *rb = (const uint32_t *)(tile + WAVE * LT) + grp;
-        const uint32_t col = (uint32_t)(q + sub) * 8u;
+        const uint32_t pos = (uint32_t)(q + sub);
+        const uint32_t sh = 31u - (pos & 31u);                                    // the sign bit of position q + sub, moved to bit 31
+        const double *tb = tile + grp * LR + pos;                                 // one base address per array; the chain of store r lies a
+        const u32x4 *mb = (const u32x4 *)(tile + WAVE * LR) + grp;                // constant further on (folds into the DS offset)
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            constexpr int CH = WAVE / W;                                          // chains per store: store r covers chains CH r .. CH r + CH - 1
-            uint32_t off = rb[CH * r];
-            off = col_ok ? off + col : kNoRow;
-            const double yv = tb[CH * r * LT];
-            const uint32_t w = sb[CH * r * 2 * LT];
+            const u32x4 m = mb[CH * r];
+            const double yv = tb[CH * r * LR];
+            uint32_t off = m.z + pos * 8u;
+            if constexpr (LO) off = (pos >= (m.w & 0xffu)) ? off : kNoRow;
+            if constexpr (HI) off = (pos < (m.w >> 8)) ? off : kNoRow;
+            const uint32_t w = (q >= 32) ? m.y : m.x;
             const uint32_t s31 = (w << sh) & 0x80000000u;
             u32x2 xv, vv;
             xv.x = (uint32_t)__double2loint(yv); xv.y = (uint32_t)__double2hiint(yv) ^ s31;
             vv.x = 0u; vv.y = 0x3ff00000u | s31;
-            __builtin_amdgcn_raw_buffer_store_b64(xv, rsX, (int)off, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(vv, rsV, (int)off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(xv, rsX, (int)off, 0, LANE_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(vv, rsV, (int)off, 0, LANE_STORE_AUX);
         }
     }
     __device__ __forceinline__ void record(bool rec, int64_t c, int32_t k, double t, double horizon, double ar, int32_t errored,
@@ -280,24 +344,42 @@ struct LaneChain {
         int l = lane;
         asm volatile("" : "+v"(l));               // LDS addresses are rebuilt here from an opaque copy of the lane id: hoisted out of the
                                                   // event loop they would occupy ~50 registers for the whole launch
-        uint32_t *roff = (uint32_t *)(tile + WAVE * LT);                          // 64 row offsets after the tile
-        double *trow = tile + l * LT;                                             // my tile row; column 16: my two sign words
+        double *myrow = tile + l * LR;
+        u32x4 *meta = (u32x4 *)(tile + WAVE * LR) + l;
+        const int total = cl + d, nfull = total & ~7;
+        const uint64_t S = (((uint64_t)Sc1 << 32) | Sc0) | ((((uint64_t)sg1 << 32) | sg0) << cl);
+        u32x4 m;
+        m.x = (uint32_t)S; m.y = (uint32_t)(S >> 32);
+        m.z = rec ? (((uint32_t)l * (uint32_t)p.n_sk + (uint32_t)k) * (uint32_t)d - (uint32_t)cl) * 8u : kNoRow;
+        m.w = (uint32_t)skip | ((uint32_t)nfull << 8);
         __builtin_amdgcn_wave_barrier();
-        roff[l] = rec ? ((uint32_t)l * (uint32_t)p.n_sk + (uint32_t)k) * (uint32_t)d * 8u : kNoRow;
-        trow[LT - 1] = __longlong_as_double((long long)(((uint64_t)sg1 << 32) | (uint64_t)sg0));
+        *meta = m;
+        double *wrow = myrow + cl;
 #pragma unroll
-        for (int q = 0; q < LD; q += 16) {
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { if (q + j < LD) trow[j] = y[q + j]; }
-            __builtin_amdgcn_wave_barrier();
-            if (q + 16 <= LD) store_tile<16, 16>(q, l);
-            else store_tile<4, 4>(q, l);
-        }
+        for (int j = 0; j < LD; ++j) wrow[j] = y[j];
+        __builtin_amdgcn_wave_barrier();
+        store_tile<16, 16, true, false>(0, l);                                    // nfull >= 48, skip <= 7: positions 16..47 need no check
+        store_tile<16, 16, false, false>(16, l);
+        store_tile<16, 16, false, false>(32, l);
+        store_tile<8, 8, false, true>(48, l);                                     // nfull = 48 or 56
         __builtin_amdgcn_wave_barrier();
         if (rec) {
+            const double *from = myrow + nfull;                                   // the row's tail that completes no line: the next carry
+            double mv[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) mv[j] = from[j];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) myrow[j] = mv[j];
+            const uint64_t Sn = S >> nfull;
+            Sc0 = (uint32_t)Sn; Sc1 = (uint32_t)(Sn >> 32);
+            cl = total - nfull;
+            skip = 0;
             const size_t e = (size_t)c * (size_t)p.n_sk + (size_t)k;
-            p.t[e] = t;
+            double *ring = tile + WAVE * LR + 2 * WAVE + l;
+            const int slot = (int)(((uintptr_t)(p.t + e) >> 3) & 7);
+            ring[slot * WAVE] = t;
+            tlast = slot;
+            if (slot == 7) { store_times(p.t + e - 7, ring, tfirst, 7); tfirst = 0; tlast = -1; }
             if (p.H) p.H[e] = horizon;
             if (p.AR) p.AR[e] = ar;
             if (p.EB) p.EB[e] = errored;
@@ -309,6 +391,24 @@ struct LaneChain {
             }
         }
     }
+    // end of a segment: the carried doubles [skip, cl) go out as the head of a line whose rest the next segment writes; k = the next event
+    __device__ __forceinline__ void flush_carry(bool mine, int64_t c, int32_t k) {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        u32x4 m;
+        m.x = Sc0; m.y = Sc1;
+        m.z = (mine && cl > skip) ? (((uint32_t)l * (uint32_t)p.n_sk + (uint32_t)k) * (uint32_t)d - (uint32_t)cl) * 8u : kNoRow;
+        m.w = (uint32_t)skip | ((uint32_t)cl << 8);
+        __builtin_amdgcn_wave_barrier();
+        *((u32x4 *)(tile + WAVE * LR) + l) = m;
+        __builtin_amdgcn_wave_barrier();
+        store_tile<8, 8, true, true>(0, l);
+        __builtin_amdgcn_wave_barrier();
+        cl = 0; skip = 0;
+        if (mine && tlast >= 0)                                                   // the event times of an incomplete line; k - 1 = my last event, in slot tlast
+            store_times(p.t + ((size_t)c * (size_t)p.n_sk + (size_t)k - 1 - (size_t)tlast), tile + WAVE * LR + 2 * WAVE + l, tfirst, tlast);
+        tlast = -1;
+    }
 
     // ---- GroupChain::run_segment for the 64 chains of this wave.  Hand-off state of batch b (private to this kernel): word w of
     // the chain in lane l at state[(b (2d+4) + w) 64 + l] -- y_0..y_{d-1}, the sign words, t, horizon, ar, the stream position.
@@ -317,7 +417,6 @@ struct LaneChain {
         int64_t k_end = k_begin + seg_len;
         if (k_end > p.n_sk) k_end = p.n_sk;
         double *st = state + (size_t)b * (size_t)(2 * d + 4) * WAVE + lane;
-        open_window(b);
         double t = 0.0, horizon = p.tmax, ar = 0.0;
         uint64_t n0 = 0;
         sg0 = 0; sg1 = 0;
@@ -339,6 +438,7 @@ struct LaneChain {
                 if (i < 32) sg0 |= (s >> 31) << (i & 31); else sg1 |= (s >> 31) << (i & 31);
             }
         }
+        open_window(b, c, r == 0 ? 0 : k_begin);
         rng.init_lane(p.seed, (uint64_t)(p.chain0 + c));
         rng.restore(n0);
         double ts = 0.0, tp = 0.0, E = 0.0, lb = 0.0;
@@ -358,12 +458,13 @@ struct LaneChain {
             bool accepted = false, proposed = false;
             double tf = -0.0;
             int m = -1;
+            const Prefetch pf = rng_prefetch();
             LANE_MARK(0);
             if (!done && !propose) {
                 if (!brun) {
                     const double harg = (mode == ERR) ? horizon / 2 : ((mode == REUSE) ? hB : horizon);
                     hB = harg;
-                    const double e1 = rng.exponential();
+                    const double e1 = -det_log(draw_uniform(pf));
                     E = (mode == REUSE) ? E + e1 : e1;
                     if (mode == REUSE) bound_resume(tp); else bound_begin(tp);
                     brun = true;
@@ -406,10 +507,10 @@ struct LaneChain {
                 if (ar > 1.0) {
                     mode = ERR;
                 } else {
-                    const double u = rng.uniform();
+                    const double u = draw_uniform(pf);
                     if (u < ar) {
                         tf = tp;
-                        m = velocity_jump(lam, tp);
+                        m = velocity_jump(lam, tp, draw_uniform(pf));
                         accepted = true;
                     } else {
                         mode = REUSE;
@@ -433,6 +534,7 @@ struct LaneChain {
             if (proposed && ++it > cap && !done) { done = true; atomicAdd(&p.status[0], 1); }
         }
         LANE_MARK(8);
+        flush_carry(chain_ok, c, k);
         // hand-off state (write-through stores, as the group kernel's; padding lanes write their own column too: it is theirs)
 #pragma unroll
         for (int i = 0; i < LD; ++i) if (in_dim(i)) publish(st + (size_t)i * WAVE, y[i]);
@@ -498,7 +600,9 @@ inline hipError_t launch_lane(const GroupParams &gp_in, const int32_t *flag, int
     const size_t lds = (size_t)wpb * LANE_LDS_PER_WAVE * sizeof(double);
     void (*kernel)(const GroupParams, const int32_t *) = lane_kernel<TARGET>;
     int per_cu = 0, dev = 0, cus = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE * wpb, lds);
+    hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE * wpb, lds);
     if (e != hipSuccess) return e;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

@@ -101,6 +101,11 @@ class AbstractPDMP:
         G of the group kernel, or 0 for the wave-per-chain kernel."""
         return int(_lib.lib().pdmp_get_group_lanes(self.handle()))
 
+    def last_launch_form(self) -> int:
+        """Kernel form of the last launch (pdmp_last_launch_form): 1 wave per chain, 2 group (LDS), 3 group (registers), 4 one lane
+        per chain, 5 dense-precision path, 6 potential given as source."""
+        return int(_lib.lib().pdmp_last_launch_form(self.handle()))
+
     def suggest_group_lanes(self, C: int) -> int:
         """Lanes per chain that fill the GPU for launches of ``C`` chains (pdmp_suggest_group_lanes)."""
         return int(_lib.lib().pdmp_suggest_group_lanes(self.handle(), int(C)))
