@@ -51,7 +51,48 @@ def parse():
                     help="src_banana: U_banana given as source, differentiated by forward mode on the GPU (pdmp_create_from_source)")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time; 0 disables it")
+    ap.add_argument("--pmc", default="auto", choices=["auto", "off"],
+                    help="auto (N = 1): measure roofline.traffic live -- child runs of this command (one launch each) under rocprofv3 --pmc "
+                         "WRITE_SIZE, FETCH_SIZE and the VALU counters, before this process touches the GPU; off: quote profiles/traffic.json")
     return ap.parse_args()
+
+
+def live_counters(a):
+    """HBM bytes and VALU counters of ONE launch of this very workload on this GPU: three child processes `rocprofv3 --pmc ... --
+    python3 bench.py --steps 1 --warmup 0 --pmc off <same workload>` (each counter group in its own run, kernel trace off, as
+    MI355X_MICROARCH.md prescribes; WRITE_SIZE / FETCH_SIZE in KiB, FETCH_SIZE x2 on gfx950), run BEFORE this process initialises the
+    GPU.  Returns None when rocprofv3 is missing or a pass fails: the line then quotes the committed measurement instead."""
+    import csv, glob, shutil, subprocess, tempfile
+    if shutil.which("rocprofv3") is None or os.environ.get("PDMP_BENCH_PMC") == "0":
+        return None
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None                                              # this run is itself being profiled: no nested profiler
+    args = ["--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--pmc", "off", "--chains", str(a.chains), "--n-sk", str(a.n_sk),
+            "--dim", str(a.dim), "--sampler", a.sampler, "--target", a.target, "--seed", str(a.seed), "--lanes", a.lanes]
+    if a.refresh_rate is not None:
+        args += ["--refresh-rate", str(a.refresh_rate)]
+    out, env = {}, dict(os.environ, TMPDIR="/tmp")
+    for group in (["WRITE_SIZE"], ["FETCH_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"]):
+        tmp = tempfile.mkdtemp(prefix="pdmp_pmc_", dir="/tmp")
+        try:
+            cmd = ["rocprofv3", "--pmc", *group, "--output-format", "csv", "-d", tmp, "--", "python3", os.path.join(ROOT, "bench.py"), *args]
+            r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+            files = glob.glob(os.path.join(tmp, "**", "*_counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            names = set()
+            for row in csv.DictReader(open(files[0])):
+                if "pdmp::" in row["Kernel_Name"]:
+                    out[row["Counter_Name"]] = out.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                    names.add(row["Kernel_Name"].split("(")[0])
+            out["kernels"] = sorted(names)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    if "WRITE_SIZE" not in out or "FETCH_SIZE" not in out:
+        return None
+    return out
 
 
 def dense_precision(a):
@@ -219,6 +260,7 @@ def workload_label(a, sampler, world, C_local):
 
 def main():
     a = parse()
+    live = live_counters(a) if (a.pmc == "auto" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.gpus == 1) else None
     import torch
     import pdmpflux.jl_amd as P
     from pdmpflux.jl_amd import ensemble
@@ -335,6 +377,17 @@ def main():
             kernel = (f"lane_kernel<{a.target}> (one lane per chain, 64 chains per wave; signed positions y = x v in registers, "
                       "events stored as whole 64-byte lines)")
         cnt = measured_counters(a, C_local, G, form)
+        if live:                                                  # measured now, on this GPU, for this workload
+            events_launch = C_local * (n_sk - 1)
+            cnt = {"hbm_bytes_per_launch": live["WRITE_SIZE"] * 1024 + live["FETCH_SIZE"] * 1024 * 2,
+                   "write_bytes": live["WRITE_SIZE"] * 1024, "read_bytes_corrected": live["FETCH_SIZE"] * 1024 * 2,
+                   "source": "LIVE: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE (KiB; FETCH_SIZE x2 on gfx950) around one launch of this workload in child "
+                             "processes of this run, each counter in its own pass; kernels " + ", ".join(live.get("kernels", []))}
+            if live.get("SQ_INSTS_VALU") and live.get("GRBM_GUI_ACTIVE"):
+                cnt.update({"valu_instr_per_event": live["SQ_INSTS_VALU"] / events_launch,
+                            "salu_instr_per_event": live.get("SQ_INSTS_SALU", 0.0) / events_launch,
+                            "valu_busy": 4 * live["SQ_ACTIVE_INST_VALU"] / (live["GRBM_GUI_ACTIVE"] / 8 * 1024),
+                            "valu_source": "LIVE: SQ_INSTS_VALU / events of one launch; busy = 4 SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)"})
         xbytes = 0 if gather != "skeleton" else (C_total - C_local) * n_sk * bytes_per_event
         res = {
             "metric": metric_label(a, sampler, C_total),
@@ -351,9 +404,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": cnt.get("hbm_bytes_per_launch") if cnt else None,
-                         "traffic_source": (cnt.get("source", "profiles/traffic.json") + " -- committed rocprofv3 measurement of this workload, not read in this run") if cnt else None,
+                         "traffic_source": (cnt.get("source", "profiles/traffic.json") + ("" if live else " -- committed rocprofv3 measurement of this workload, not read in this run")) if cnt else None,
+                         "traffic_write": cnt.get("write_bytes") if cnt else None, "traffic_read": cnt.get("read_bytes_corrected") if cnt else None,
                          "kernel": kernel, "kernel_ms": kernel_ms, "bytes_per_event": bytes_per_event,
-                         "valu": ({"instr_per_event": cnt.get("valu_instr_per_event"), "busy": cnt.get("valu_busy"),
+                         "valu": ({"instr_per_event": cnt.get("valu_instr_per_event"), "salu_instr_per_event": cnt.get("salu_instr_per_event"), "busy": cnt.get("valu_busy"),
                                    "source": cnt.get("valu_source")} if cnt and cnt.get("valu_instr_per_event") else None),
                          "note": ("HBM-write bound: roofline.traffic / kernel_ms is the write rate the launch sustains (a plain fill of this GPU "
                                   "reaches ~5.6 TB/s); roofline.valu = wave-instructions per event and the share of SIMD cycles the VALUs are busy"

@@ -131,7 +131,9 @@ struct LaneChain {
         const double v0 = gd0.v * v, g0 = gd0.e * v, v1 = gd1.v * v, g1 = gd1.e * v;
         const double num = fma(-g0, t0, fma(g1, t1, v0 - v1));
         const double den = g1 - g0;
-        const double q = (den != 0.0) ? fmin(fmax(num / den, 0.0), h) : ((num > 0.0) ? h : 0.0);   // cell_q: the clamp of num / 0 without the division
+        // cell_q: the clamp of num / 0 without the division; coordinates 2, 3 are affine with slope v v = 1 at both ends -- den is 0.0
+        // whatever the state, so their division is not even compiled
+        const double q = (i < 2 && den != 0.0) ? fmin(fmax(num / den, 0.0), h) : ((num > 0.0) ? h : 0.0);
         const double inter = fma(g0, q, v0);
         return fmax(fmax(fmax(v0, v1), inter), 0.0);
     }

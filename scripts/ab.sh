@@ -6,7 +6,7 @@ cp pdmpflux.jl_amd/libpdmphip.so /tmp/lib_orig.so
 for rep in 1 2 3; do
   for v in A B; do
     if [ $v = A ]; then cp $A pdmpflux.jl_amd/libpdmphip.so; else cp $B pdmpflux.jl_amd/libpdmphip.so; fi
-    r=$(timeout -k 10 200 python bench.py --steps 5 --warmup 1 --cpu-seconds 0 "$@" 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.read()); print(r['ms_per_step'])")
+    r=$(timeout -k 10 200 python bench.py --steps 5 --warmup 1 --cpu-seconds 0 --pmc off "$@" 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.read()); print(r['ms_per_step'])")
     echo "$v $r"
   done
 done

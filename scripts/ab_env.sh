@@ -3,8 +3,8 @@
 # Alternates default / VAR three times on the SAME GPU (boxes of the pool differ by several %).
 E=$1; shift
 for rep in 1 2 3; do
-  r=$(timeout -k 10 200 python bench.py --steps 5 --warmup 1 --cpu-seconds 0 "$@" 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.read()); print(r['ms_per_step'])")
+  r=$(timeout -k 10 200 python bench.py --steps 5 --warmup 1 --cpu-seconds 0 --pmc off "$@" 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.read()); print(r['ms_per_step'])")
   echo "default $r"
-  r=$(env $E timeout -k 10 200 python bench.py --steps 5 --warmup 1 --cpu-seconds 0 "$@" 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.read()); print(r['ms_per_step'])")
+  r=$(env $E timeout -k 10 200 python bench.py --steps 5 --warmup 1 --cpu-seconds 0 --pmc off "$@" 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.read()); print(r['ms_per_step'])")
   echo "$E $r"
 done

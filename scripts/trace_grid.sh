@@ -3,7 +3,7 @@
 TAG=$1; shift
 OUT=gpurun_out/prof_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 "$@" > $OUT/bench.json 2> $OUT/log.txt
+rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 --pmc off "$@" > $OUT/bench.json 2> $OUT/log.txt
 python3 - "$OUT" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
