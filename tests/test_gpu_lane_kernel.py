@@ -95,3 +95,49 @@ def test_lane_kernel_full_machine(engine, oracle, monkeypatch):
             assert np.array_equal(got[k][c], r1[k][0]), (k, c)
     assert (np.diff(got["t"], axis=1) > 0).all()
     assert (np.abs(got["V"]) == 1.0).all()
+
+
+@pytest.mark.parametrize("offs", [(1, 5, 2), (3, 3, 7), (6, 0, 1)])
+@pytest.mark.parametrize("n_sk,dim", [(37, 50), (40, 51)])
+def test_lane_kernel_unaligned_outputs(engine, oracle, lane, offs, n_sk, dim):
+    """Output arrays that start anywhere inside a 64-byte line (views into larger buffers, as a sharded run's in-place exchange
+    produces them), with different misalignments for X, V and t and row lengths that are no multiple of a line: the line-exact
+    stores (carried row tails, staged event times, partial lines at both ends of every chain and segment) must write exactly
+    the bytes of the arrays -- the guard words around them stay untouched -- and the same values."""
+    import torch
+    lane.setenv("PDMP_FORCE_SEGMENTS", "3")
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", dim, "banana")
+    C = 70
+    x, v = make_init("ZigZagAD", dim, C, seed=4, target="banana")
+    dev = torch.device("cuda:0")
+    guard = -12345.678
+    bufs, out = {}, {}
+    for name, shape, off in (("X", (C, n_sk, dim), offs[0]), ("V", (C, n_sk, dim), offs[1]), ("t", (C, n_sk), offs[2])):
+        n = int(np.prod(shape))
+        b = torch.full((n + 16,), guard, dtype=torch.float64, device=dev)
+        bufs[name] = (b, off, n)
+        out[name] = b[off:off + n].view(shape)
+    from pdmpflux.jl_amd import ensemble
+    got = ensemble.sample_skeleton_device(s, n_sk, torch.from_numpy(x).to(dev), torch.from_numpy(v).to(dev), seed=6, out=out)
+    assert s.last_launch_form() == 4
+    ref = oracle.sample_skeleton(cfg, n_sk, x, v, 6, diagnostics=False)
+    for name in ("X", "V", "t"):
+        b, off, n = bufs[name]
+        assert got[name].data_ptr() == b.data_ptr() + 8 * off                    # the engine wrote into the view it was given
+        assert np.array_equal(got[name].cpu().numpy(), ref[name]), name
+        assert bool((b[:off] == guard).all()) and bool((b[off + n:] == guard).all()), name
+
+
+def test_lane_kernel_is_what_ran(engine, oracle, monkeypatch):
+    """pdmp_last_launch_form: 4 (one lane per chain) for a large unit-speed ensemble, 3 (group kernel, registers) when the check
+    kernel finds another speed or the ensemble is small."""
+    monkeypatch.delenv("PDMP_LANE", raising=False)
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", 50, "iso")
+    x, v = make_init("ZigZagAD", 50, 41000)
+    engine.sample_skeleton_ensemble(s, 8, x, v, seed=1, diagnostics=False)
+    assert s.last_launch_form() == 4
+    v[5, 5] = 2.0
+    engine.sample_skeleton_ensemble(s, 8, x, v, seed=1, diagnostics=False)
+    assert s.last_launch_form() == 3
+    engine.sample_skeleton_ensemble(s, 8, x[:100], np.sign(v[:100]), seed=1, diagnostics=False)
+    assert s.last_launch_form() == 3
