@@ -30,6 +30,9 @@
 #ifndef LANE_WAVES
 #define LANE_WAVES 1          // waves per SIMD the kernel is compiled for (512 registers per lane at 1)
 #endif
+#ifndef LANE_BATCH
+#define LANE_BATCH 8          // stores whose LDS reads are in flight together (record)
+#endif
 #ifndef LANE_STORE_AUX
 #define LANE_STORE_AUX 2      // nt: streaming stores (measured 16.8 -> 16.5 ms); cache-policy bits of the event stores (buffer_store ... sc0 = 1 / nt = 2 / sc1 = 16)
 #endif
@@ -45,7 +48,9 @@ constexpr int LANE_LDS_PER_WAVE = WAVE * LR + 2 * WAVE + 8 * WAVE;   // doubles:
 // Slot loops run slot by slot: without this the scheduler hoists the 52 independent terms of a sum in front of their
 // additions (104 more live registers, spills); with it a slot's four terms are in flight at a time -- still four independent
 // dependency chains, and the SIMD's other wave fills the rest.
-#ifdef LANE_MARKS
+#if defined(PDMP_STAMP)        // diagnostic build (make stamp): wave cycles per phase of the state machine, summed into p.stamps
+#define LANE_MARK(n) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[st_cur] += now_ - st_last; st_last = now_; st_cur = n; } while (0)
+#elif defined(LANE_MARKS)
 #define LANE_MARK(n) asm volatile("; LANEMARK " #n ::: "memory")
 #else
 #define LANE_MARK(n)
@@ -322,20 +327,30 @@ struct LaneChain {
         const uint32_t sh = 31u - (pos & 31u);                                    // the sign bit of position q + sub, moved to bit 31
         const double *tb = tile + grp * LR + pos;                                 // one base address per array; the chain of store r lies a
         const u32x4 *mb = (const u32x4 *)(tile + WAVE * LR) + grp;                // constant further on (folds into the DS offset)
+        // LDS reads of LANE_BATCH stores are issued together, then their stores: one wave per SIMD runs in order, and a read that
+        // is waited for before every store costs its ~100-cycle round trip 56 times per event row
+        constexpr int NB = NR < LANE_BATCH ? NR : LANE_BATCH;
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const u32x4 m = mb[CH * r];
-            const double yv = tb[CH * r * LR];
-            uint32_t off = m.z + pos * 8u;
-            if constexpr (LO) off = (pos >= (m.w & 0xffu)) ? off : kNoRow;
-            if constexpr (HI) off = (pos < (m.w >> 8)) ? off : kNoRow;
-            const uint32_t w = (q >= 32) ? m.y : m.x;
-            const uint32_t s31 = (w << sh) & 0x80000000u;
-            u32x2 xv, vv;
-            xv.x = (uint32_t)__double2loint(yv); xv.y = (uint32_t)__double2hiint(yv) ^ s31;
-            vv.x = 0u; vv.y = 0x3ff00000u | s31;
-            __builtin_amdgcn_raw_buffer_store_b64(xv, rsX, (int)off, 0, LANE_STORE_AUX);
-            __builtin_amdgcn_raw_buffer_store_b64(vv, rsV, (int)off, 0, LANE_STORE_AUX);
+        for (int r0 = 0; r0 < NR; r0 += NB) {
+            u32x4 m[NB];
+            double yv[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) { m[b] = mb[CH * (r0 + b)]; yv[b] = tb[CH * (r0 + b) * LR]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                uint32_t off = m[b].z + pos * 8u;
+                if constexpr (LO) off = (pos >= (m[b].w & 0xffu)) ? off : kNoRow;
+                if constexpr (HI) off = (pos < (m[b].w >> 8)) ? off : kNoRow;
+                const uint32_t w = (q >= 32) ? m[b].y : m[b].x;
+                const uint32_t s31 = (w << sh) & 0x80000000u;
+                u32x2 xv, vv;
+                xv.x = (uint32_t)__double2loint(yv[b]); xv.y = (uint32_t)__double2hiint(yv[b]) ^ s31;
+                vv.x = 0u; vv.y = 0x3ff00000u | s31;
+                __builtin_amdgcn_raw_buffer_store_b64(xv, rsX, (int)off, 0, LANE_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64(vv, rsV, (int)off, 0, LANE_STORE_AUX);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __device__ __forceinline__ void record(bool rec, int64_t c, int32_t k, double t, double horizon, double ar, int32_t errored,
@@ -456,10 +471,15 @@ struct LaneChain {
         bool propose = false, brun = false;
         int mode = FRESH;
         double hB = horizon;
+#ifdef PDMP_STAMP
+        unsigned long long st_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+        int st_cur = 8;
+#endif
         while (__ballot(!done) != 0ull) {
             bool accepted = false, proposed = false;
             double tf = -0.0;
             int m = -1;
+            LANE_MARK(8);
             const Prefetch pf = rng_prefetch();
             LANE_MARK(0);
             if (!done && !propose) {
@@ -536,6 +556,13 @@ struct LaneChain {
             if (proposed && ++it > cap && !done) { done = true; atomicAdd(&p.status[0], 1); }
         }
         LANE_MARK(8);
+#ifdef PDMP_STAMP
+        // slots: 0 E draw, 1 bound cells, 2 bound epilogue, 3 -> true_rate, 4 ar / accept / walk, 5 flow + flip, 6 record, 7 loop tail, 8 prefetch
+        if (lane == 0 && p.stamps) {
+            atomicAdd(&p.stamps[0], st_acc[0] + st_acc[8]); atomicAdd(&p.stamps[1], st_acc[1] + st_acc[2]); atomicAdd(&p.stamps[2], st_acc[3]);
+            atomicAdd(&p.stamps[3], st_acc[4]); atomicAdd(&p.stamps[4], st_acc[5]); atomicAdd(&p.stamps[5], st_acc[6] + st_acc[7]);
+        }
+#endif
         flush_carry(chain_ok, c, k);
         // hand-off state (write-through stores, as the group kernel's; padding lanes write their own column too: it is theirs)
 #pragma unroll

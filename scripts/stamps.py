@@ -7,7 +7,7 @@ import torch
 import pdmpflux.jl_amd as P
 from pdmpflux.jl_amd import ensemble
 dev = torch.device("cuda:0")
-C_, d, n_sk = 100000, 50, 1000
+C_, d, n_sk = int(sys.argv[2]) if len(sys.argv) > 2 else 100000, 50, 1000
 g = torch.Generator(device=dev); g.manual_seed(1)
 x = torch.randn((C_, d), dtype=torch.float64, device=dev, generator=g)
 v = torch.randint(0, 2, (C_, d), device=dev, generator=g).to(torch.float64) * 2 - 1
@@ -16,6 +16,11 @@ if kind == "bps":
     x = 1.0 + 0.1 * x
     v = torch.randn((C_, d), dtype=torch.float64, device=dev, generator=g); v = (v / v.norm(dim=1, keepdim=True)).contiguous()
     s = P.BPS(d, P.Banana())
+elif kind == "boom":
+    C_, d = (int(sys.argv[2]) if len(sys.argv) > 2 else 50000), 100
+    x = torch.randn((C_, d), dtype=torch.float64, device=dev, generator=g)
+    v = torch.randn((C_, d), dtype=torch.float64, device=dev, generator=g)
+    s = P.Boomerang(d, P.GaussianIso())
 else:
     s = P.ZigZagAD(d, P.GaussianIso())
 out = ensemble.sample_skeleton_device(s, n_sk, x, v, seed=1)
@@ -27,5 +32,7 @@ print("rc", lib.pdmp_debug_stamps(buf))
 vals = list(buf)[:6]; print("cells", buf[6], "wave-bounds", buf[7], "cells per wave-bound", buf[6]/max(buf[7],1))
 tot = sum(vals)
 names = ["BOUND(exp+cells+inversion)", "true_rate+ar", "uniform+flow_state", "velocity_jump", "record", "loop top/other"]
+if s.last_launch_form() == 4:       # lane kernel (csrc/lane_kernel.hpp, LANE_MARK)
+    names = ["prefetch + E draw", "bound cells + epilogue", "true_rate", "ar + accept + walk", "flow + flip", "record + loop tail"]
 for n, v_ in zip(names, vals):
     print(f"{n:32s} {v_:>16d}  {100*v_/tot:5.1f}%")
