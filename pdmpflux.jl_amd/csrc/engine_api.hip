@@ -948,9 +948,10 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
                 GroupParams lp = gp;
                 if (!getenv("PDMP_CELL_BUDGET")) lp.cell_budget = 5;   // a pass of 64 chains costs ~2 000 instructions, a cell 240: wait for more cells
                 if (le == hipSuccess) le = launch_lane_zigzag(c.target_id, lp, flag, rounds, s);
-                if (le != hipSuccess) { h->pool.push_back(ev); return fail(PDMP_ERR_RUNTIME, "lane kernel launch: %s", hipGetErrorString(le)); }
-                gp.only_if = flag;
-                h->last_form = PDMP_FORM_LANE;
+                if (le == hipSuccess) {                      // (a lane kernel that cannot be launched -- it asks for 145 KB of LDS per block --
+                    gp.only_if = flag;                       //  leaves the launch to the group kernel below)
+                    h->last_form = PDMP_FORM_LANE;
+                } else (void)hipGetLastError();
             }
             const char *ex = getenv("PDMP_REG_EXACT");      // PDMP_REG_EXACT=0: the KREG-slot kernels with per-slot skips (test hook)
             if (!(ex && atoi(ex) == 0))                     // a kernel of exactly K slots where one exists

@@ -45,17 +45,41 @@ constexpr int LR = 61;            // LDS row of a chain: up to 7 carried doubles
 constexpr int LANE_DMIN = LD - 3; // the last slot may be partly padding, no other
 constexpr int LANE_LDS_PER_WAVE = WAVE * LR + 2 * WAVE + 8 * WAVE;   // doubles: 64 rows + 16 bytes of store parameters per chain + 8 event times per chain
 
-// Slot loops run slot by slot: without this the scheduler hoists the 52 independent terms of a sum in front of their
-// additions (104 more live registers, spills); with it a slot's four terms are in flight at a time -- still four independent
-// dependency chains, and the SIMD's other wave fills the rest.
+// Two waves per SIMD (256 registers): slot loops run slot by slot -- without this the scheduler hoists the 52 independent terms of a sum
+// in front of their additions (104 more live registers, spills).  One wave per SIMD (512 registers, the build that ships): no fence, the
+// terms of all slots are in flight together (banana 17.2 -> 16.7 ms).
+#if LANE_WAVES == 1 && !defined(LANE_FENCE)
+#define LANE_NO_FENCE
+#endif
 #if defined(PDMP_STAMP)        // diagnostic build (make stamp): wave cycles per phase of the state machine, summed into p.stamps
-#define LANE_MARK(n) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[st_cur] += now_ - st_last; st_last = now_; st_cur = n; } while (0)
-#elif defined(LANE_MARKS)
+#define LANE_MARK(n) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[LANE_PREV_##n] += now_ - st_last; st_last = now_; } while (0)
+// the phase that ENDS at mark n (static: the marks are passed in program order; 8 = loop top)
+#define LANE_PREV_0 8
+#define LANE_PREV_1 0
+#define LANE_PREV_2 1
+#define LANE_PREV_3 2
+#define LANE_PREV_4 3
+#define LANE_PREV_5 4
+#define LANE_PREV_6 5
+#define LANE_PREV_7 15
+#define LANE_PREV_8 7
+#define LANE_PREV_9 6
+#define LANE_PREV_10 9
+#define LANE_PREV_11 10
+#define LANE_PREV_12 11
+#define LANE_PREV_13 12
+#define LANE_PREV_14 13
+#define LANE_PREV_15 14
+#elif defined(LANE_MARKS)      // static instruction counts per phase: markers in the assembly
 #define LANE_MARK(n) asm volatile("; LANEMARK " #n ::: "memory")
 #else
 #define LANE_MARK(n)
 #endif
+#ifdef LANE_NO_FENCE
+#define LANE_SLOT_FENCE(a, tt)
+#else
 #define LANE_SLOT_FENCE(a, tt) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(tt))
+#endif
 
 template <int TARGET>
 struct LaneChain {
@@ -259,7 +283,9 @@ struct LaneChain {
             if (ms_hit < 0 && (carry + T > theta)) { ms_hit = s; carry_at = carry; lh[0] = l[0]; lh[1] = l[1]; lh[2] = l[2]; lh[3] = l[3]; }
             carry = carry + T;
             LANE_SLOT_FENCE(lh, t);
+#ifndef LANE_NO_FENCE
             asm volatile("" : "+v"(carry), "+v"(carry_at), "+v"(ms_hit));
+#endif
         }
         int m = -1;
         if (ms_hit >= 0) {                                                        // Kogge-Stone inclusive scan of the hit slot, written out
@@ -289,6 +315,11 @@ struct LaneChain {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     static constexpr uint32_t kNoRow = 0x80000000u;
     __amdgpu_buffer_rsrc_t rsX, rsV;                                              // this unit's windows of p.X and p.V
+    uint32_t dbg_acc = 0;
+#ifdef PDMP_STAMP
+    unsigned long long st_acc[16], st_last = 0;
+    int st_cur = 8;
+#endif
     int cl = 0, skip = 0;                                                         // carried doubles; leading row positions that are not mine (segment start)
     uint32_t Sc0 = 0, Sc1 = 0;                                                    // sign bits of the carried doubles
     __device__ __forceinline__ void open_window(int64_t b, int64_t c, int64_t k_first) {
@@ -347,8 +378,12 @@ struct LaneChain {
                 u32x2 xv, vv;
                 xv.x = (uint32_t)__double2loint(yv[b]); xv.y = (uint32_t)__double2hiint(yv[b]) ^ s31;
                 vv.x = 0u; vv.y = 0x3ff00000u | s31;
+#ifdef LANE_DBG_NOSTORE            // experiment: the reads and the arithmetic without the stores (results are wrong)
+                dbg_acc ^= xv.y ^ vv.y ^ off ^ xv.x;
+#else
                 __builtin_amdgcn_raw_buffer_store_b64(xv, rsX, (int)off, 0, LANE_STORE_AUX);
                 __builtin_amdgcn_raw_buffer_store_b64(vv, rsV, (int)off, 0, LANE_STORE_AUX);
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -370,16 +405,22 @@ struct LaneChain {
         m.z = rec ? (((uint32_t)l * (uint32_t)p.n_sk + (uint32_t)k) * (uint32_t)d - (uint32_t)cl) * 8u : kNoRow;
         m.w = (uint32_t)skip | ((uint32_t)nfull << 8);
         __builtin_amdgcn_wave_barrier();
+        LANE_MARK(9);
         *meta = m;
         double *wrow = myrow + cl;
 #pragma unroll
         for (int j = 0; j < LD; ++j) wrow[j] = y[j];
         __builtin_amdgcn_wave_barrier();
+        LANE_MARK(10);
         store_tile<16, 16, true, false>(0, l);                                    // nfull >= 48, skip <= 7: positions 16..47 need no check
+        LANE_MARK(11);
         store_tile<16, 16, false, false>(16, l);
+        LANE_MARK(12);
         store_tile<16, 16, false, false>(32, l);
+        LANE_MARK(13);
         store_tile<8, 8, false, true>(48, l);                                     // nfull = 48 or 56
         __builtin_amdgcn_wave_barrier();
+        LANE_MARK(14);
         if (rec) {
             const double *from = myrow + nfull;                                   // the row's tail that completes no line: the next carry
             double mv[7];
@@ -407,6 +448,7 @@ struct LaneChain {
                 for (int q = 0; q < 5; ++q) p.EV[5 * e + q] = ev[q];
             }
         }
+        LANE_MARK(15);
     }
     // end of a segment: the carried doubles [skip, cl) go out as the head of a line whose rest the next segment writes; k = the next event
     __device__ __forceinline__ void flush_carry(bool mine, int64_t c, int32_t k) {
@@ -472,8 +514,9 @@ struct LaneChain {
         int mode = FRESH;
         double hB = horizon;
 #ifdef PDMP_STAMP
-        unsigned long long st_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
-        int st_cur = 8;
+        for (int q = 0; q < 16; ++q) st_acc[q] = 0;
+        st_last = __builtin_amdgcn_s_memtime();
+        st_cur = 8;
 #endif
         while (__ballot(!done) != 0ull) {
             bool accepted = false, proposed = false;
@@ -559,8 +602,14 @@ struct LaneChain {
 #ifdef PDMP_STAMP
         // slots: 0 E draw, 1 bound cells, 2 bound epilogue, 3 -> true_rate, 4 ar / accept / walk, 5 flow + flip, 6 record, 7 loop tail, 8 prefetch
         if (lane == 0 && p.stamps) {
-            atomicAdd(&p.stamps[0], st_acc[0] + st_acc[8]); atomicAdd(&p.stamps[1], st_acc[1] + st_acc[2]); atomicAdd(&p.stamps[2], st_acc[3]);
-            atomicAdd(&p.stamps[3], st_acc[4]); atomicAdd(&p.stamps[4], st_acc[5]); atomicAdd(&p.stamps[5], st_acc[6] + st_acc[7]);
+            atomicAdd(&p.stamps[0], st_acc[8] + st_acc[0]);                            // Philox prefetch + exponential
+            atomicAdd(&p.stamps[1], st_acc[1] + st_acc[2]);                            // bound cells + epilogue
+            atomicAdd(&p.stamps[2], st_acc[3] + st_acc[4]);                            // true rate, ar, accept, Categorical walk
+            atomicAdd(&p.stamps[3], st_acc[5]);                                        // flow + flip
+            atomicAdd(&p.stamps[4], st_acc[6] + st_acc[9]);                            // record: row and parameters to LDS
+            atomicAdd(&p.stamps[5], st_acc[10] + st_acc[11] + st_acc[12] + st_acc[13]); // record: the four tiles (LDS reads, stores)
+            atomicAdd(&p.stamps[6], st_acc[14]);                                       // record: carry, event times, diagnostics
+            atomicAdd(&p.stamps[7], st_acc[15] + st_acc[7]);                           // loop tail
         }
 #endif
         flush_carry(chain_ok, c, k);
@@ -571,6 +620,9 @@ struct LaneChain {
         publish(st + (size_t)(d + 1) * WAVE, t); publish(st + (size_t)(d + 2) * WAVE, horizon); publish(st + (size_t)(d + 3) * WAVE, ar);
         publish(st + (size_t)(d + 4) * WAVE, __longlong_as_double((long long)rng.n));
         if (guard) { atomicAdd(&p.status[1], guard); guard = 0; }
+#ifdef LANE_DBG_NOSTORE
+        if (dbg_acc == 0x12345u) atomicAdd(&p.status[1], 1);
+#endif
     }
 };
 

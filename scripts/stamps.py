@@ -31,8 +31,11 @@ lib.pdmp_debug_stamps.argtypes = [C.POINTER(C.c_ulonglong)]
 print("rc", lib.pdmp_debug_stamps(buf))
 vals = list(buf)[:6]; print("cells", buf[6], "wave-bounds", buf[7], "cells per wave-bound", buf[6]/max(buf[7],1))
 tot = sum(vals)
+
 names = ["BOUND(exp+cells+inversion)", "true_rate+ar", "uniform+flow_state", "velocity_jump", "record", "loop top/other"]
 if s.last_launch_form() == 4:       # lane kernel (csrc/lane_kernel.hpp, LANE_MARK)
-    names = ["prefetch + E draw", "bound cells + epilogue", "true_rate", "ar + accept + walk", "flow + flip", "record + loop tail"]
+    names = ["prefetch + E draw", "bound cells + epilogue", "rate + accept + walk", "flow + flip", "record: row to LDS", "record: tiles (reads, stores)",
+             "record: carry, times, diag", "loop tail"]
+    vals = list(buf)[:8]; tot = sum(vals)
 for n, v_ in zip(names, vals):
     print(f"{n:32s} {v_:>16d}  {100*v_/tot:5.1f}%")
