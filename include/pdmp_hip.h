@@ -138,7 +138,7 @@ int pdmp_suggest_group_lanes(pdmp_handle h, int64_t C);
 int pdmp_set_group_lanes(pdmp_handle h, int32_t G);
 /* Which kernel form served the handle's last pdmp_sample_skeleton* launch (waits for it to finish): a diagnostic for benchmarks and
  * tests, results do not depend on it.  PDMP_FORM_LANE: one lane per chain (csrc/lane_kernel.hpp; large Zig-Zag ensembles at
- * dim 49..52 with unit speeds on the isotropic Gaussian / banana -- bit-identical to the group kernel with G = 4). */
+ * dim 27..52 with unit speeds on the isotropic Gaussian / banana -- bit-identical to the group kernel with G = 4). */
 enum { PDMP_FORM_NONE = 0, PDMP_FORM_WAVE = 1, PDMP_FORM_GROUP = 2, PDMP_FORM_GROUP_REG = 3, PDMP_FORM_LANE = 4, PDMP_FORM_DENSE = 5, PDMP_FORM_USER = 6 };
 int pdmp_last_launch_form(pdmp_handle h);
 

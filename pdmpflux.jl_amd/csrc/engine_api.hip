@@ -12,7 +12,9 @@
 
 using namespace pdmp;
 namespace pdmp {
-hipError_t launch_lane_zigzag(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);   // lane_kernel.hpp
+hipError_t launch_lane_zigzag(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);   // lane_kernel.hpp: d = 49 .. 52
+hipError_t launch_lane_zigzag_a(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream); // d = 25 .. 36
+hipError_t launch_lane_zigzag_b(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream); // d = 37 .. 48
 hipError_t launch_lane_check(const double *vinit, int64_t n, int32_t *flag, hipStream_t stream);
 hipError_t launch_group_reg_zigzag(int target, bool fd, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_bps(int target, bool fd, const GroupParams &gp, hipStream_t stream);
@@ -938,7 +940,7 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
             // count -- one wave per SIMD walks its 64 chains' events one after the other -- and the group kernel 0.3 / 0.25 ms per 1 000 chains
             const int64_t lane_from = lane_min ? atoll(lane_min) : (c.target_id == PDMP_T_BANANA ? 56000 : 40000);
             const bool lane_ok = c.sampler == PDMP_ZIGZAG && !fd && (c.target_id == PDMP_T_GAUSS_ISO || c.target_id == PDMP_T_BANANA) &&
-                                 c.dim >= 49 && c.dim <= 52 && gp.G == 4 && (int64_t)WAVE * n_sk * c.dim * 8 < 0x7fffffffLL;   // (a batch's window of X: 31-bit byte offsets)
+                                 c.dim >= 25 && c.dim <= 52 && gp.G == 4 && (int64_t)WAVE * n_sk * c.dim * 8 < 0x7fffffffLL;   // (a batch's window of X: 31-bit byte offsets)
             if (lane_ok && !(lane_env && atoi(lane_env) == 0) && ((lane_env && atoi(lane_env) == 1) || C >= lane_from)) {
                 int32_t *flag = h->d_status + 4;
                 hipError_t le = hipMemsetAsync(flag, 0, sizeof(int32_t), s);
@@ -947,7 +949,8 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
                 if (const char *r = getenv("PDMP_LANE_ROUNDS")) { const int v = atoi(r); if (v >= 1 && v <= 64) rounds = v; }
                 GroupParams lp = gp;
                 if (!getenv("PDMP_CELL_BUDGET")) lp.cell_budget = 5;   // a pass of 64 chains costs ~2 000 instructions, a cell 240: wait for more cells
-                if (le == hipSuccess) le = launch_lane_zigzag(c.target_id, lp, flag, rounds, s);
+                if (le == hipSuccess) le = c.dim > 48 ? launch_lane_zigzag(c.target_id, lp, flag, rounds, s)
+                                      : c.dim > 36 ? launch_lane_zigzag_b(c.target_id, lp, flag, rounds, s) : launch_lane_zigzag_a(c.target_id, lp, flag, rounds, s);
                 if (le == hipSuccess) {                      // (a lane kernel that cannot be launched -- it asks for 145 KB of LDS per block --
                     gp.only_if = flag;                       //  leaves the launch to the group kernel below)
                     h->last_form = PDMP_FORM_LANE;

@@ -1,6 +1,7 @@
 // lane_kernel.hpp -- ONE LANE PER CHAIN: the large-ensemble form of the Zig-Zag hot path (sample_skeleton, src/sample.jl:253-284) for the
 // constructors' default bound (grid_size = 10, vectorized signed bound, forward-mode slopes) on the isotropic Gaussian and the banana,
-// unit speeds (|v_i| = 1, the reference's initial velocities), 49 <= d <= 52.
+// unit speeds (|v_i| = 1, the reference's initial velocities), 27 <= d <= 52 (the dimensions the engine runs with G = 4 lanes per chain
+// otherwise; one instantiation per number of four-coordinate slots).
 //
 // Why (profiles/r2): the group kernel (G = 4 lanes per chain, 16 chains per wave) is bound by fp64 VALU issue -- 81 wave-instructions
 // per event at config 2 -- and two thirds of those are per-CHAIN scalar work (random stream, log, cumulative sums, inversion, the
@@ -39,11 +40,11 @@
 
 namespace pdmp {
 
-constexpr int LK = 13;            // slots of the emulated G = 4 layout: d <= 52
-constexpr int LD = 4 * LK;        // coordinate registers per lane
-constexpr int LR = 61;            // LDS row of a chain: up to 7 carried doubles + 52 coordinates, padded to an odd stride
-constexpr int LANE_DMIN = LD - 3; // the last slot may be partly padding, no other
-constexpr int LANE_LDS_PER_WAVE = WAVE * LR + 2 * WAVE + 8 * WAVE;   // doubles: 64 rows + 16 bytes of store parameters per chain + 8 event times per chain
+// LK = slots of the emulated G = 4 layout: one instantiation per LK = 7 .. 13 serves d = 4 LK - 3 .. 4 LK (25 .. 52; the engine's default
+// layout is G = 4 from d = 27 on)
+constexpr int LANE_LK_MIN = 7, LANE_LK_MAX = 13;
+constexpr int lane_row_stride(int lk) { return (7 + 4 * lk) | 1; }   // LDS row: up to 7 carried doubles + 4 LK coordinates, odd stride
+constexpr int lane_lds_per_wave(int lk) { return WAVE * lane_row_stride(lk) + 2 * WAVE + 8 * WAVE; } // doubles: 64 rows + 16 bytes of store parameters per chain + 8 event times per chain
 
 // Two waves per SIMD (256 registers): slot loops run slot by slot -- without this the scheduler hoists the 52 independent terms of a sum
 // in front of their additions (104 more live registers, spills).  One wave per SIMD (512 registers, the build that ships): no fence, the
@@ -81,9 +82,13 @@ constexpr int LANE_LDS_PER_WAVE = WAVE * LR + 2 * WAVE + 8 * WAVE;   // doubles:
 #define LANE_SLOT_FENCE(a, tt) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(tt))
 #endif
 
-template <int TARGET>
+template <int TARGET, int LK>
 struct LaneChain {
     static_assert(TARGET == T_GAUSS_ISO || TARGET == T_BANANA, "lane kernel: isotropic Gaussian and banana");
+    static_assert(LK >= LANE_LK_MIN && LK <= LANE_LK_MAX, "lane kernel: 7 .. 13 slots of four coordinates");
+    static constexpr int LD = 4 * LK;                    // coordinate registers per lane
+    static constexpr int LR = lane_row_stride(LK);       // LDS row stride
+    static constexpr int LANE_DMIN = LD - 3;             // the last slot may be partly padding, no other
     static constexpr bool kBanana = TARGET == T_BANANA;
     using Tgt = GTarget<TARGET>;
     const SkelParams &p;
@@ -169,9 +174,6 @@ struct LaneChain {
     __device__ __forceinline__ bool bound_advance(double harg, double E, double &tpo, double &lbo, int budget) {
         const double h = harg / (double)(GNG - 1);
         bool found = false, found_now = false;
-#ifdef LANE_NO_BOUND
-        tpo = E * h; lbo = y[7]; return true;
-#endif
         if (b_recheck) {
             b_recheck = false;
             if (b_next > 0 && !(b_cprev < E)) {
@@ -263,9 +265,6 @@ struct LaneChain {
         BananaSh<double> sh{};
         if constexpr (kBanana) sh = tgt.template shared<double>(fma(V(0), t, X(0)), fma(V(1), t, X(1)));
         if (!(S > 0.0)) { guard++; return -1; }                                   // Q11
-#ifdef LANE_NO_WALK
-        return (int)(u * 50.0);
-#endif
         const double theta = u * S;
         double carry = 0.0, carry_at = 0.0, lh[4] = {0.0, 0.0, 0.0, 0.0};
         int ms_hit = -1;
@@ -315,7 +314,6 @@ struct LaneChain {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     static constexpr uint32_t kNoRow = 0x80000000u;
     __amdgpu_buffer_rsrc_t rsX, rsV;                                              // this unit's windows of p.X and p.V
-    uint32_t dbg_acc = 0;
 #ifdef PDMP_STAMP
     unsigned long long st_acc[16], st_last = 0;
     int st_cur = 8;
@@ -378,21 +376,14 @@ struct LaneChain {
                 u32x2 xv, vv;
                 xv.x = (uint32_t)__double2loint(yv[b]); xv.y = (uint32_t)__double2hiint(yv[b]) ^ s31;
                 vv.x = 0u; vv.y = 0x3ff00000u | s31;
-#ifdef LANE_DBG_NOSTORE            // experiment: the reads and the arithmetic without the stores (results are wrong)
-                dbg_acc ^= xv.y ^ vv.y ^ off ^ xv.x;
-#else
                 __builtin_amdgcn_raw_buffer_store_b64(xv, rsX, (int)off, 0, LANE_STORE_AUX);
                 __builtin_amdgcn_raw_buffer_store_b64(vv, rsV, (int)off, 0, LANE_STORE_AUX);
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     __device__ __forceinline__ void record(bool rec, int64_t c, int32_t k, double t, double horizon, double ar, int32_t errored,
                                            const double (&ev)[5], int32_t rejected, int32_t hits) {
-#ifdef LANE_NO_RECORD
-        if (rec) { p.t[(size_t)c * (size_t)p.n_sk + (size_t)k] = t + y[3]; } return;
-#endif
         int l = lane;
         asm volatile("" : "+v"(l));               // LDS addresses are rebuilt here from an opaque copy of the lane id: hoisted out of the
                                                   // event loop they would occupy ~50 registers for the whole launch
@@ -412,13 +403,16 @@ struct LaneChain {
         for (int j = 0; j < LD; ++j) wrow[j] = y[j];
         __builtin_amdgcn_wave_barrier();
         LANE_MARK(10);
-        store_tile<16, 16, true, false>(0, l);                                    // nfull >= 48, skip <= 7: positions 16..47 need no check
+        // nfull = 8 floor((cl + d) / 8) lies in [NF_MIN, NF_MAX]; skip <= 7: whole tiles of 16 positions below NF_MIN need no upper check,
+        // only the first one the lower check; the rest goes out as tiles of 8 positions x 8 chains with the upper check
+        constexpr int NF_MIN = LANE_DMIN & ~7, NF_MAX = (LD + 7) & ~7, Q0 = NF_MIN & ~15;
+        store_tile<16, 16, true, false>(0, l);
         LANE_MARK(11);
-        store_tile<16, 16, false, false>(16, l);
-        LANE_MARK(12);
-        store_tile<16, 16, false, false>(32, l);
+#pragma unroll
+        for (int q = 16; q < Q0; q += 16) store_tile<16, 16, false, false>(q, l);
         LANE_MARK(13);
-        store_tile<8, 8, false, true>(48, l);                                     // nfull = 48 or 56
+#pragma unroll
+        for (int q = Q0; q < NF_MAX; q += 8) store_tile<8, 8, false, true>(q, l);
         __builtin_amdgcn_wave_barrier();
         LANE_MARK(14);
         if (rec) {
@@ -620,26 +614,16 @@ struct LaneChain {
         publish(st + (size_t)(d + 1) * WAVE, t); publish(st + (size_t)(d + 2) * WAVE, horizon); publish(st + (size_t)(d + 3) * WAVE, ar);
         publish(st + (size_t)(d + 4) * WAVE, __longlong_as_double((long long)rng.n));
         if (guard) { atomicAdd(&p.status[1], guard); guard = 0; }
-#ifdef LANE_DBG_NOSTORE
-        if (dbg_acc == 0x12345u) atomicAdd(&p.status[1], 1);
-#endif
     }
 };
 
-// flag[0] != 0 after this kernel: some |v_i| != 1 -- the lane kernel leaves the launch to the group kernel (GroupParams::only_if)
-__global__ __launch_bounds__(256) void lane_check_kernel(const double *vinit, int64_t n, int32_t *flag) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool bad = i < n && fabs(vinit[i]) != 1.0;
-    if (__ballot(bad) != 0ull && lane_id() == 0) atomicOr(flag, 1);
-}
-
-template <int TARGET>
+template <int TARGET, int LK>
 __global__ __launch_bounds__(256, LANE_WAVES) void lane_kernel(const GroupParams gp, const int32_t *flag) {
     if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;      // not unit speeds: the group kernel runs instead
     extern __shared__ double smem[];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
-    double *tile = smem + (size_t)wave * LANE_LDS_PER_WAVE;
-    LaneChain<TARGET> chain(gp.s, lane, tile);
+    double *tile = smem + (size_t)wave * lane_lds_per_wave(LK);
+    LaneChain<TARGET, LK> chain(gp.s, lane, tile);
     const int nb = (int)gp.nb, n_units = nb * gp.nseg;
     bool lost = false;
     for (int pulled = 0; pulled <= n_units && !lost; ++pulled) {
@@ -674,12 +658,12 @@ inline void lane_schedule(int64_t nb, int64_t slots, int64_t n_sk, int force, in
     nseg = (int32_t)((events + seg_len - 1) / seg_len);
 }
 
-template <int TARGET>
+template <int TARGET, int LK>
 inline hipError_t launch_lane(const GroupParams &gp_in, const int32_t *flag, int rounds, hipStream_t stream) {
     GroupParams gp = gp_in;
     constexpr int wpb = 4;
-    const size_t lds = (size_t)wpb * LANE_LDS_PER_WAVE * sizeof(double);
-    void (*kernel)(const GroupParams, const int32_t *) = lane_kernel<TARGET>;
+    const size_t lds = (size_t)wpb * lane_lds_per_wave(LK) * sizeof(double);
+    void (*kernel)(const GroupParams, const int32_t *) = lane_kernel<TARGET, LK>;
     int per_cu = 0, dev = 0, cus = 0;
     hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -697,7 +681,24 @@ inline hipError_t launch_lane(const GroupParams &gp_in, const int32_t *flag, int
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(WAVE * wpb), lds, stream, gp, flag);
     return hipGetLastError();
 }
-hipError_t launch_lane_zigzag(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);
+// one translation unit per range of LK (inst_lane_zigzag*.hip); hipErrorNotSupported: not this unit's LK
+template <int TARGET, int LK0, int LK1>
+inline hipError_t launch_lane_by_slots(int lk, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream) {
+    if constexpr (LK0 > LK1) return hipErrorNotSupported;
+    else return lk == LK0 ? launch_lane<TARGET, LK0>(gp, flag, rounds, stream) : launch_lane_by_slots<TARGET, LK0 + 1, LK1>(lk, gp, flag, rounds, stream);
+}
+template <int LK0, int LK1>
+inline hipError_t launch_lane_range(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream) {
+    const int lk = (gp.s.d + 3) / 4;
+    switch (target) {
+    case T_GAUSS_ISO: return launch_lane_by_slots<T_GAUSS_ISO, LK0, LK1>(lk, gp, flag, rounds, stream);
+    case T_BANANA: return launch_lane_by_slots<T_BANANA, LK0, LK1>(lk, gp, flag, rounds, stream);
+    default: return hipErrorNotSupported;
+    }
+}
+hipError_t launch_lane_zigzag(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);       // LK = 13
+hipError_t launch_lane_zigzag_a(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);     // LK = 7 .. 9
+hipError_t launch_lane_zigzag_b(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);     // LK = 10 .. 12
 hipError_t launch_lane_check(const double *vinit, int64_t n, int32_t *flag, hipStream_t stream);
 #endif
 

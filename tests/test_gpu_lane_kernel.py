@@ -1,4 +1,4 @@
-"""The one-lane-per-chain kernel (csrc/lane_kernel.hpp) -- large Zig-Zag ensembles at d = 49..52 on the isotropic Gaussian and the
+"""The one-lane-per-chain kernel (csrc/lane_kernel.hpp) -- large Zig-Zag ensembles at d = 27..52 on the isotropic Gaussian and the
 banana -- against the checker in the GROUP(4) order and against the group kernel it replaces: bit for bit, every array, every
 diagnostic; hand-off between segments, ragged batches, bound instalments, the fall-back for speeds that are not +-1."""
 import numpy as np
@@ -23,10 +23,11 @@ def _run(engine, oracle, dim, target, C, n_sk, seed=3, init_seed=0, diagnostics=
     return s, cfg, x, v, got
 
 
-@pytest.mark.parametrize("dim", [49, 50, 51, 52])
+@pytest.mark.parametrize("dim", [27, 28, 29, 32, 33, 36, 37, 40, 41, 44, 45, 47, 48, 49, 50, 51, 52])
 @pytest.mark.parametrize("target", ["iso", "banana"])
 def test_lane_kernel_matches_checker(engine, oracle, lane, dim, target):
     s, cfg, x, v, got = _run(engine, oracle, dim, target, 150, 120)          # 150 chains: two full batches and a ragged one
+    assert s.last_launch_form() == 4
     ref = oracle.sample_skeleton(cfg, 120, x, v, 3, diagnostics=True)
     assert_bitwise(got, ref)
 
@@ -42,10 +43,10 @@ def test_lane_kernel_equals_group_kernel(engine, oracle, monkeypatch, target):
 
 
 @pytest.mark.parametrize("segments", [2, 7, 1000])
-@pytest.mark.parametrize("target", ["iso", "banana"])
-def test_lane_kernel_segment_handoff(engine, oracle, lane, segments, target):
+@pytest.mark.parametrize("target,dim", [("iso", 50), ("banana", 50), ("banana", 31), ("iso", 46)])
+def test_lane_kernel_segment_handoff(engine, oracle, lane, segments, target, dim):
     lane.setenv("PDMP_FORCE_SEGMENTS", str(segments))
-    s, cfg, x, v, got = _run(engine, oracle, 50, target, 70, 90)
+    s, cfg, x, v, got = _run(engine, oracle, dim, target, 70, 90)
     assert_bitwise(got, oracle.sample_skeleton(cfg, 90, x, v, 3, diagnostics=True))
 
 
@@ -98,7 +99,7 @@ def test_lane_kernel_full_machine(engine, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("offs", [(1, 5, 2), (3, 3, 7), (6, 0, 1)])
-@pytest.mark.parametrize("n_sk,dim", [(37, 50), (40, 51)])
+@pytest.mark.parametrize("n_sk,dim", [(37, 50), (40, 51), (33, 27), (29, 38), (31, 45)])
 def test_lane_kernel_unaligned_outputs(engine, oracle, lane, offs, n_sk, dim):
     """Output arrays that start anywhere inside a 64-byte line (views into larger buffers, as a sharded run's in-place exchange
     produces them), with different misalignments for X, V and t and row lengths that are no multiple of a line: the line-exact
