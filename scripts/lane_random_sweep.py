@@ -1,0 +1,47 @@
+"""One-off random sweep of the one-lane-per-chain kernel (not part of the suite): random dimension 27..52, target, horizon settings, number
+of chains / events, hand-off segments and bound instalments, every case against the checker bit for bit (PDMP_LANE=1 forces the lane
+kernel).  Usage (GPU box): python scripts/lane_random_sweep.py <n_cases> <seed>; prints mismatches, exit code 1 on any."""
+import os, sys
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+os.environ["PDMP_LANE"] = "1"
+import numpy as np
+import pdmpflux.jl_amd as P
+from oracle import oracle as O
+from helpers import make_pair, make_init, assert_bitwise
+
+n, seed0 = int(sys.argv[1]), int(sys.argv[2])
+rs = np.random.default_rng(seed0)
+bad = done = 0
+for q in range(n):
+    dim = int(rs.integers(27, 53))
+    target = ["iso", "banana"][rs.integers(2)]
+    kw = {}
+    if rs.random() < 0.4:
+        kw["tmax"] = float(rs.choice([0.0, 0.02, 0.3, 1.0, 5.0, 50.0]))
+    if rs.random() < 0.25:
+        kw["adaptive"] = False
+    C = int(rs.choice([1, 5, 63, 64, 65, 100, 129, 200, 300]))
+    n_sk = int(rs.choice([1, 2, 3, 9, 17, 40, 64, 100, 150]))
+    seg = int(rs.choice([0, 0, 1, 2, 3, 5, 1000]))
+    budget = int(rs.choice([0, 0, 1, 2, 3, 9]))
+    for k, val in (("PDMP_FORCE_SEGMENTS", seg), ("PDMP_CELL_BUDGET", budget)):
+        if val: os.environ[k] = str(val)
+        else: os.environ.pop(k, None)
+    seed = int(rs.integers(1, 10**6))
+    try:
+        s, cfg = make_pair(P, O, "ZigZagAD", dim, target, **kw)
+        x, v = make_init("ZigZagAD", dim, C, seed=seed % 1000, target=target)
+        if rs.random() < 0.2:
+            x[:] = 0.0                                  # exact zeros: y = x v starts at +-0
+        got = P.sample_skeleton_ensemble(s, n_sk, x, v, seed=seed, diagnostics=True)
+        assert s.last_launch_form() == 4, "the lane kernel did not run"
+        ref = O.sample_skeleton(cfg, n_sk, x, v, seed, diagnostics=True)
+        assert_bitwise(got, ref)
+        done += 1
+    except Exception as e:
+        bad += 1
+        print("MISMATCH", dim, target, kw, C, n_sk, seg, budget, seed, "->", repr(e)[:300], flush=True)
+    if (done + bad) % 100 == 0:
+        print("progress", done, bad, flush=True)
+print("checked", done, "failed", bad)
+sys.exit(1 if bad else 0)
