@@ -23,8 +23,9 @@
 // kernels -- made per launch from the number of chains -- cannot be seen in the results (tests/test_gpu_lane_kernel.py compares them,
 // and both with the checker), and sharding invariance holds across it.
 //
-// record! (Composites.jl:239-260) transposes X and V rows through an LDS tile so that a store instruction writes 16 consecutive
-// doubles of each of four chains (a lane's own row lies n_sk d 8 bytes from its neighbour's).
+// record! (Composites.jl:239-260) goes through the chain's LDS row so that a store instruction writes 16 consecutive doubles of each of
+// four chains (a lane's own row lies n_sk d 8 bytes from its neighbour's), and only WHOLE 64-byte lines: see `record` below.
+// One wave per SIMD (512 registers per lane); the launch is bound by the rate at which the events can be written.
 #pragma once
 #include "group_kernel.hpp"
 
@@ -35,7 +36,7 @@
 #define LANE_BATCH 8          // stores whose LDS reads are in flight together (record)
 #endif
 #ifndef LANE_STORE_AUX
-#define LANE_STORE_AUX 2      // nt: streaming stores (measured 16.8 -> 16.5 ms); cache-policy bits of the event stores (buffer_store ... sc0 = 1 / nt = 2 / sc1 = 16)
+#define LANE_STORE_AUX 2      // nt: streaming stores (measured 16.6 -> 15.1 ms at config 2); cache-policy bits of the event stores (buffer_store ... sc0 = 1 / nt = 2 / sc1 = 16)
 #endif
 
 namespace pdmp {
