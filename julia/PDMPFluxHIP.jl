@@ -313,6 +313,9 @@ function sample_skeleton_device!(s::HIPSampler, X, V, t, xinit, vinit; seed::Int
     return nothing
 end
 check_status(s::HIPSampler) = check(ccall((:pdmp_check_status, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}), s.handle, C_NULL))
+# which kernel form served the last launch (diagnostic; waits for the launch): 1 wave per chain, 2 group (LDS), 3 group (registers),
+# 4 one lane per chain (large Zig-Zag ensembles, d = 27..52, unit speeds), 5 dense-precision path, 6 potential given as source
+last_launch_form(s::HIPSampler) = Int(ccall((:pdmp_last_launch_form, LIB), Cint, (Ptr{Cvoid},), s.handle))
 
 # One Julia process, n GPUs (pdmp_multi_*): the C chains shard into contiguous ranges over the devices; with gather = true one RCCL
 # collective per output array leaves the whole skeleton on every device (the final exchange of a multi-GPU run).
