@@ -936,9 +936,10 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
             // returns at once and the group kernel below (which returns at once while the flag is 0) does the launch's work.
             const char *lane_env = getenv("PDMP_LANE");     // 0: never, 1: whenever the configuration allows (tests), unset: from the chain count
             const char *lane_min = getenv("PDMP_LANE_MIN_CHAINS");
-            // measured (one MI355X, n_sk = 1000): up to 65 536 chains the lane kernel takes 10.9 ms (Gaussian) / 13.1 ms (banana) whatever the
-            // count -- one wave per SIMD walks its 64 chains' events one after the other -- and the group kernel 0.3 / 0.25 ms per 1 000 chains
-            const int64_t lane_from = lane_min ? atoll(lane_min) : (c.target_id == PDMP_T_BANANA ? 56000 : 40000);
+            // measured (one MI355X, n_sk = 1000): up to 65 536 chains the lane kernel takes 9.6 ms (d = 50 Gaussian) / 11.0 ms (banana) / 7.8 ms
+            // (d = 32) whatever the count -- one wave per SIMD walks its 64 chains' events one after the other -- while the group kernel grows
+            // with the count: it wins below ~41 000 chains at d = 50 (9.4 ms at 40 000, 12.8 ms at 45 000) and below ~48 000 at d = 32
+            const int64_t lane_from = lane_min ? atoll(lane_min) : (c.dim >= 45 ? 42000 : 48000);
             const bool lane_ok = c.sampler == PDMP_ZIGZAG && !fd && (c.target_id == PDMP_T_GAUSS_ISO || c.target_id == PDMP_T_BANANA) &&
                                  c.dim >= 25 && c.dim <= 52 && gp.G == 4 && (int64_t)WAVE * n_sk * c.dim * 8 < 0x7fffffffLL;   // (a batch's window of X: 31-bit byte offsets)
             if (lane_ok && !(lane_env && atoi(lane_env) == 0) && ((lane_env && atoi(lane_env) == 1) || C >= lane_from)) {

@@ -134,7 +134,7 @@ def test_lane_kernel_is_what_ran(engine, oracle, monkeypatch):
     kernel finds another speed or the ensemble is small."""
     monkeypatch.delenv("PDMP_LANE", raising=False)
     s, cfg = make_pair(engine, oracle, "ZigZagAD", 50, "iso")
-    x, v = make_init("ZigZagAD", 50, 41000)
+    x, v = make_init("ZigZagAD", 50, 43000)
     engine.sample_skeleton_ensemble(s, 8, x, v, seed=1, diagnostics=False)
     assert s.last_launch_form() == 4
     v[5, 5] = 2.0
