@@ -28,6 +28,11 @@
 
 namespace pdmp {
 
+#ifdef PDMP_NO_DPP_BOUND        // A/B builds
+constexpr bool defined_no_dpp_bound = true;
+#else
+constexpr bool defined_no_dpp_bound = false;
+#endif
 constexpr int GNG = 10;   // grid_size served by this kernel (the default of every reference constructor)
 constexpr int KREG = 13;  // slots per lane of the register form (x, v in VGPRs): d <= 13 G
 
@@ -895,8 +900,13 @@ struct GroupChain {
             const int nxt = base + ((g + 1) & (GC - 1));                               // the lane that holds the next grid time
 #pragma unroll
             for (int m = 0; m < M; ++m) {                                              // cell j = g + G m from times j and j + 1
-                const double a_f = __shfl(pf[m], nxt, WAVE), a_s = __shfl(ps[m], nxt, WAVE);
-                const double b_f = __shfl(pf[m + 1], nxt, WAVE), b_s = __shfl(ps[m + 1], nxt, WAVE);
+                double a_f, a_s, b_f, b_s;
+                if constexpr (GC == 4 && !defined_no_dpp_bound) {                      // the next lane of the quad by DPP (quad_perm [1,2,3,0]): no LDS round trip
+                    a_f = dpp_d<0x39>(pf[m]); a_s = dpp_d<0x39>(ps[m]); b_f = dpp_d<0x39>(pf[m + 1]); b_s = dpp_d<0x39>(ps[m + 1]);
+                } else {                                                               // (G = 8: row_shl:1 / row_shr:7 + a select measured no faster than the shuffle)
+                    a_f = __shfl(pf[m], nxt, WAVE); a_s = __shfl(ps[m], nxt, WAVE);
+                    b_f = __shfl(pf[m + 1], nxt, WAVE); b_s = __shfl(ps[m + 1], nxt, WAVE);
+                }
                 const bool wrap = g == GC - 1;                                         // time j + 1 sits in lane 0's next slot
                 const double f1 = wrap ? b_f : a_f, s1 = wrap ? b_s : a_s, fz = pf[m], sz = ps[m];
                 const double num = fma(s1, h, fz - f1);                                // :123 relative form
@@ -911,7 +921,11 @@ struct GroupChain {
             double c0 = 0.0, c1 = 1.0, last = 0.0;
 #pragma unroll
             for (int j = 0; j < GNG - 1; ++j) {                                        // cum_sum and searchsortedfirst in grid order, :133-134, :265
-                const double b = __shfl(bj[j / GC], base + (j % GC), WAVE);
+                double b;
+                if constexpr (GC == 4 && !defined_no_dpp_bound) {                      // lane j % 4 of the quad, broadcast by DPP
+                    const double src = bj[j / GC];
+                    b = (j % 4 == 0) ? dpp_d<0x00>(src) : (j % 4 == 1) ? dpp_d<0x55>(src) : (j % 4 == 2) ? dpp_d<0xAA>(src) : dpp_d<0xFF>(src);
+                } else b = __shfl(bj[j / GC], base + (j % GC), WAVE);
                 acc += b;
                 const double cj = acc * h;
                 if (!found && !(cj < E)) { found = true; inv_jj = j; c0 = cprev; c1 = cj; lbo = b; }
