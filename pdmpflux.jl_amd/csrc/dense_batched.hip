@@ -295,6 +295,11 @@ struct DiParams {
 
 // SGN: signed_bound (the constructor default).  There the slope of every coordinate's rate is the same double at both ends of a
 // cell (gv_i v_i), so den == 0 exactly and the tangent intersection needs no division -- as in the group kernel's kLinear path.
+#ifdef PDMP_DENSE_PLAIN_STORES     // A/B builds
+#define PDMP_ROW_STORE(ptr, val) (*(ptr) = (val))
+#else
+#define PDMP_ROW_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#endif
 template <int KC, bool SGN>
 __global__ __launch_bounds__(256, SGN ? 2 : 1) void di_segment_kernel(const DiParams p) {
     const int lane = lane_id();
@@ -336,7 +341,9 @@ __global__ __launch_bounds__(256, SGN ? 2 : 1) void di_segment_kernel(const DiPa
 #pragma unroll
         for (int s = 0; s < KC; ++s) {
             const int i = s * WAVE + lane;
-            if (i < d) { Xe[i] = x[s * WAVE]; Ve[i] = v[s]; }
+            // whole 64-byte lines (a row is 8 d bytes, d = 1000: 125 lines), written once and not read again by this launch: streaming
+            // stores keep them from displacing the columns of P in the L2
+            if (i < d) { PDMP_ROW_STORE(&Xe[i], x[s * WAVE]); PDMP_ROW_STORE(&Ve[i], v[s]); }
         }
         if (lane == 0) {
             p.t[e] = t;
