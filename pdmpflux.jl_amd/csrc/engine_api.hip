@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void from_skeleton_flat_kernel(int d, int64_t 
             r[u] = ee - smp * rows;
             const int q = r[u] < d ? r[u] : (r[u] < 2 * d ? r[u] - d : 0);
             const size_t off = (size_t)seg_s[wv][smp] * d + q;
-            xv[u] = Xc[off];
+            xv[u] = Xc[off];                                         // (plain loads: a row is read by ~1.6 samples; streaming loads measured 10 % slower)
             double vq = Vc[off];
             if (Ac) { const uint8_t a = Ac[off]; vq = (ia_mode == 2) ? vq * (a ? 1.0 : 0.0) : (a ? vq : 0.0); }   // :547-549 / :667
             vv[u] = vq;
@@ -308,7 +308,11 @@ __global__ __launch_bounds__(256) void from_skeleton_flat_kernel(int d, int64_t 
             if (r[u] < d) val = BOOMERANG ? xv[u] * c1[u] + vv[u] * s1[u] : xv[u] + vv[u] * ta[u];             // BoomerangSamplers.jl:31 / ZigZagSamplers.jl:80
             else if (r[u] < 2 * d) val = BOOMERANG ? (-xv[u]) * s1[u] + vv[u] * c1[u] : vv[u];
             else val = tmv[u];                                                                                      // :505-508
+#ifdef PDMP_FS_PLAIN_STORES        // A/B builds
             o[e0 + u * WAVE] = val;
+#else
+            __builtin_nontemporal_store(val, &o[e0 + u * WAVE]);      // samples: consecutive lanes, consecutive doubles, written once -- streaming stores leave the L2 to the skeleton rows
+#endif
         }
     }
 }
