@@ -72,6 +72,8 @@ def live_counters(a):
     if a.refresh_rate is not None:
         args += ["--refresh-rate", str(a.refresh_rate)]
     out, env = {}, dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)                                         # the children are plain single-process runs
     for group in (["WRITE_SIZE"], ["FETCH_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"]):
         tmp = tempfile.mkdtemp(prefix="pdmp_pmc_", dir="/tmp")
         try:
