@@ -383,6 +383,41 @@ struct LaneChain {
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    // The same with TWO consecutive positions per lane and 16-byte stores (half the store instructions): tiles that need no lower
+    // check -- a pair of positions (even, odd) lies on one side of nfull, a multiple of 8, but `skip` may be odd.  W positions per
+    // tile, W / 2 lanes per chain, 128 / W chains per store, W / 2 stores.
+    template <int W, bool HI>
+    __device__ __forceinline__ void store_tile2(int q, int l) {
+        constexpr int LPC = W / 2, CH = WAVE / LPC, NR = WAVE / CH;               // lanes per chain, chains per store, stores per tile
+        const int sub = l & (LPC - 1), grp = l / LPC;
+        const uint32_t pos = (uint32_t)(q + 2 * sub);                             // even; pos and pos + 1 share a sign word
+        const uint32_t sh = 31u - (pos & 31u);
+        const double *tb = tile + grp * LR + pos;
+        const u32x4 *mb = (const u32x4 *)(tile + WAVE * LR) + grp;
+        constexpr int NB = NR < LANE_BATCH ? NR : LANE_BATCH;
+#pragma unroll
+        for (int r0 = 0; r0 < NR; r0 += NB) {
+            u32x4 m[NB];
+            double ya[NB], yb[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) { m[b] = mb[CH * (r0 + b)]; ya[b] = tb[CH * (r0 + b) * LR]; yb[b] = tb[CH * (r0 + b) * LR + 1]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                uint32_t off = m[b].z + pos * 8u;
+                if constexpr (HI) off = (pos < (m[b].w >> 8)) ? off : kNoRow;
+                const uint32_t w = (q >= 32) ? m[b].y : m[b].x;
+                const uint32_t sa = (w << sh) & 0x80000000u, sb = (w << (sh - 1u)) & 0x80000000u;
+                u32x4 xv, vv;
+                xv.x = (uint32_t)__double2loint(ya[b]); xv.y = (uint32_t)__double2hiint(ya[b]) ^ sa;
+                xv.z = (uint32_t)__double2loint(yb[b]); xv.w = (uint32_t)__double2hiint(yb[b]) ^ sb;
+                vv.x = 0u; vv.y = 0x3ff00000u | sa; vv.z = 0u; vv.w = 0x3ff00000u | sb;
+                __builtin_amdgcn_raw_buffer_store_b128(xv, rsX, (int)off, 0, LANE_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(vv, rsV, (int)off, 0, LANE_STORE_AUX);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
     __device__ __forceinline__ void record(bool rec, int64_t c, int32_t k, double t, double horizon, double ar, int32_t errored,
                                            const double (&ev)[5], int32_t rejected, int32_t hits) {
         int l = lane;
@@ -409,11 +444,19 @@ struct LaneChain {
         constexpr int NF_MIN = LANE_DMIN & ~7, NF_MAX = (LD + 7) & ~7, Q0 = NF_MIN & ~15;
         store_tile<16, 16, true, false>(0, l);
         LANE_MARK(11);
+#ifdef LANE_STORE_B64              // A/B builds: 8-byte stores everywhere
 #pragma unroll
         for (int q = 16; q < Q0; q += 16) store_tile<16, 16, false, false>(q, l);
         LANE_MARK(13);
 #pragma unroll
         for (int q = Q0; q < NF_MAX; q += 8) store_tile<8, 8, false, true>(q, l);
+#else
+#pragma unroll
+        for (int q = 16; q < Q0; q += 16) store_tile2<16, false>(q, l);
+        LANE_MARK(13);
+#pragma unroll
+        for (int q = Q0; q < NF_MAX; q += 8) store_tile2<8, true>(q, l);
+#endif
         __builtin_amdgcn_wave_barrier();
         LANE_MARK(14);
         if (rec) {
