@@ -945,7 +945,8 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
             // with the count: it wins below ~41 000 chains at d = 50 (9.4 ms at 40 000, 12.8 ms at 45 000) and below ~48 000 at d = 32
             const int64_t lane_from = lane_min ? atoll(lane_min) : (c.dim >= 45 ? 42000 : 48000);
             const bool lane_ok = c.sampler == PDMP_ZIGZAG && !fd && (c.target_id == PDMP_T_GAUSS_ISO || c.target_id == PDMP_T_BANANA) &&
-                                 c.dim >= 25 && c.dim <= 52 && gp.G == 4 && (int64_t)WAVE * n_sk * c.dim * 8 < 0x7fffffffLL;   // (a batch's window of X: 31-bit byte offsets)
+                                 c.dim >= 25 && c.dim <= 52 && gp.G == 4 && (int64_t)WAVE * n_sk * c.dim * 8 < 0x7fffffffLL &&   // (a batch's window of X: 31-bit byte offsets)
+                                 ((uintptr_t)X & 63u) == 0 && (n_sk * (int64_t)c.dim) % 8 == 0;   // (every chain's row stream starts on a 64-byte line: lane_kernel.hpp, open_window)
             if (lane_ok && !(lane_env && atoi(lane_env) == 0) && ((lane_env && atoi(lane_env) == 1) || C >= lane_from)) {
                 int32_t *flag = h->d_status + 4;
                 hipError_t le = hipMemsetAsync(flag, 0, sizeof(int32_t), s);

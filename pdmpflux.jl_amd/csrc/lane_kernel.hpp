@@ -310,7 +310,7 @@ struct LaneChain {
     // Store (q, r): lane (grp = lane / W, sub = lane % W) handles position q + sub of chain (64 / W) r + grp through buffer
     // descriptors of the wave's window of X / V (64 consecutive chains, < 2^31 bytes -- the host checks); a chain that does not
     // record publishes an offset beyond the window and the hardware drops its lanes: no exec masks, no branches in the loop.
-    // At the end of a segment the carry is flushed as a partial line; the next segment starts mid-line (`skip`).
+    // At the end of a segment the carry is flushed as a partial line; the next segment rebuilds it from the hand-off state.
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     static constexpr uint32_t kNoRow = 0x80000000u;
@@ -319,8 +319,13 @@ struct LaneChain {
     unsigned long long st_acc[16], st_last = 0;
     int st_cur = 8;
 #endif
-    int cl = 0, skip = 0;                                                         // carried doubles; leading row positions that are not mine (segment start)
+    int cl = 0;                                                                   // carried doubles (row positions 0 .. cl - 1 of my LDS row)
     uint32_t Sc0 = 0, Sc1 = 0;                                                    // sign bits of the carried doubles
+    // The host takes this kernel only when X is 64-byte aligned and n_sk d is a multiple of 8 doubles: every chain's stream then starts
+    // on a line, and a segment that starts at event k_first starts a = (k_first d) mod 8 doubles into one -- the same for all chains of
+    // the wave.  Those a doubles in front of it are the tail of the previous event's row, i.e. of the very state the segment starts
+    // from (the hand-off state IS the last recorded event): the carry is rebuilt from it and the line is written whole again (the
+    // previous segment's flush wrote the same bytes), so no row position ever has to be skipped.  Called with y, sg loaded.
     __device__ __forceinline__ void open_window(int64_t b, int64_t c, int64_t k_first) {
         const size_t first = (size_t)b * WAVE * (size_t)p.n_sk * (size_t)d;
         int64_t chains = p.C - b * WAVE;
@@ -328,9 +333,27 @@ struct LaneChain {
         const int bytes = (int)(chains * p.n_sk * d * 8);
         rsX = __builtin_amdgcn_make_buffer_rsrc(p.X + first, 0, bytes, 0x00020000);
         rsV = __builtin_amdgcn_make_buffer_rsrc(p.V + first, 0, bytes, 0x00020000);
-        // my stream starts this far into a 64-byte line of memory
-        cl = skip = (int)(((uintptr_t)(p.X + ((size_t)c * (size_t)p.n_sk + (size_t)k_first) * (size_t)d) >> 3) & 7);
+        const int a = (int)(((uint64_t)k_first * (uint64_t)d) & 7u);              // wave-uniform
+        cl = a;
         Sc0 = Sc1 = 0;
+        if (a > 0) {                                                              // (k_first > 0: a later segment)
+            int l = lane;
+            asm volatile("" : "+v"(l));
+            double *myrow = tile + l * LR;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < LD; ++j) myrow[7 + j] = y[j];                     // the state's coordinates at row positions 7 .. 7 + LD - 1
+            __builtin_amdgcn_wave_barrier();
+            const double *from = myrow + 7 + (d - a);                             // its last a coordinates
+            double mv[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) mv[j] = from[j];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 7; ++j) myrow[j] = mv[j];                         // (positions >= a are overwritten by the next row)
+            const uint64_t Sn = ((((uint64_t)sg1 << 32) | sg0) >> (d - a)) & ((1ull << a) - 1ull);
+            Sc0 = (uint32_t)Sn; Sc1 = (uint32_t)(Sn >> 32);
+        }
         tfirst = (int)(((uintptr_t)(p.t + (size_t)c * (size_t)p.n_sk + (size_t)k_first) >> 3) & 7);
         tlast = -1;
     }
@@ -348,7 +371,7 @@ struct LaneChain {
             for (int j = 0; j < 8; ++j) if (j >= lo && j <= hi) line[j] = ring[j * WAVE];
         }
     }
-    // store parameters of a chain, 16 bytes: S (two words), window offset of row position 0 (kNoRow: nothing to store), skip | nfull << 8
+    // store parameters of a chain, 16 bytes: S (two words), window offset of row position 0 (kNoRow: nothing to store), nfull << 8
     template <int W, int NR, bool LO, bool HI>      // W positions x 64 / W chains per store, NR stores; LO / HI: check position >= skip / < nfull
     __device__ __forceinline__ void store_tile(int q, int l) {                    // l = lane (opaque copy: see record)
         constexpr int CH = WAVE / W;                                              // chains per store: store r covers chains CH r .. CH r + CH - 1
@@ -384,7 +407,7 @@ struct LaneChain {
         }
     }
     // The same with TWO consecutive positions per lane and 16-byte stores (half the store instructions): tiles that need no lower
-    // check -- a pair of positions (even, odd) lies on one side of nfull, a multiple of 8, but `skip` may be odd.  W positions per
+    // (a pair of positions (even, odd) lies on one side of nfull, a multiple of 8).  W positions per
     // tile, W / 2 lanes per chain, 128 / W chains per store, W / 2 stores.
     template <int W, bool HI>
     __device__ __forceinline__ void store_tile2(int q, int l) {
@@ -430,7 +453,7 @@ struct LaneChain {
         u32x4 m;
         m.x = (uint32_t)S; m.y = (uint32_t)(S >> 32);
         m.z = rec ? (((uint32_t)l * (uint32_t)p.n_sk + (uint32_t)k) * (uint32_t)d - (uint32_t)cl) * 8u : kNoRow;
-        m.w = (uint32_t)skip | ((uint32_t)nfull << 8);
+        m.w = (uint32_t)nfull << 8;
         __builtin_amdgcn_wave_barrier();
         LANE_MARK(9);
         *meta = m;
@@ -439,20 +462,18 @@ struct LaneChain {
         for (int j = 0; j < LD; ++j) wrow[j] = y[j];
         __builtin_amdgcn_wave_barrier();
         LANE_MARK(10);
-        // nfull = 8 floor((cl + d) / 8) lies in [NF_MIN, NF_MAX]; skip <= 7: whole tiles of 16 positions below NF_MIN need no upper check,
-        // only the first one the lower check; the rest goes out as tiles of 8 positions x 8 chains with the upper check
+        // nfull = 8 floor((cl + d) / 8) lies in [NF_MIN, NF_MAX]: whole tiles of 16 positions below NF_MIN need no check, the rest goes out as
+        // tiles of 8 positions checked against nfull
         constexpr int NF_MIN = LANE_DMIN & ~7, NF_MAX = (LD + 7) & ~7, Q0 = NF_MIN & ~15;
-        store_tile<16, 16, true, false>(0, l);
-        LANE_MARK(11);
-#ifdef LANE_STORE_B64              // A/B builds: 8-byte stores everywhere
+#ifdef LANE_STORE_B64              // A/B builds: 8-byte stores
 #pragma unroll
-        for (int q = 16; q < Q0; q += 16) store_tile<16, 16, false, false>(q, l);
+        for (int q = 0; q < Q0; q += 16) store_tile<16, 16, false, false>(q, l);
         LANE_MARK(13);
 #pragma unroll
         for (int q = Q0; q < NF_MAX; q += 8) store_tile<8, 8, false, true>(q, l);
 #else
 #pragma unroll
-        for (int q = 16; q < Q0; q += 16) store_tile2<16, false>(q, l);
+        for (int q = 0; q < Q0; q += 16) store_tile2<16, false>(q, l);
         LANE_MARK(13);
 #pragma unroll
         for (int q = Q0; q < NF_MAX; q += 8) store_tile2<8, true>(q, l);
@@ -469,7 +490,6 @@ struct LaneChain {
             const uint64_t Sn = S >> nfull;
             Sc0 = (uint32_t)Sn; Sc1 = (uint32_t)(Sn >> 32);
             cl = total - nfull;
-            skip = 0;
             const size_t e = (size_t)c * (size_t)p.n_sk + (size_t)k;
             double *ring = tile + WAVE * LR + 2 * WAVE + l;
             const int slot = (int)(((uintptr_t)(p.t + e) >> 3) & 7);
@@ -488,20 +508,20 @@ struct LaneChain {
         }
         LANE_MARK(15);
     }
-    // end of a segment: the carried doubles [skip, cl) go out as the head of a line whose rest the next segment writes; k = the next event
+    // end of a segment: the carried doubles go out as the head of a line (the next segment writes that line whole again); k = the next event
     __device__ __forceinline__ void flush_carry(bool mine, int64_t c, int32_t k) {
         int l = lane;
         asm volatile("" : "+v"(l));
         u32x4 m;
         m.x = Sc0; m.y = Sc1;
-        m.z = (mine && cl > skip) ? (((uint32_t)l * (uint32_t)p.n_sk + (uint32_t)k) * (uint32_t)d - (uint32_t)cl) * 8u : kNoRow;
-        m.w = (uint32_t)skip | ((uint32_t)cl << 8);
+        m.z = (mine && cl > 0) ? (((uint32_t)l * (uint32_t)p.n_sk + (uint32_t)k) * (uint32_t)d - (uint32_t)cl) * 8u : kNoRow;
+        m.w = (uint32_t)cl << 8;
         __builtin_amdgcn_wave_barrier();
         *((u32x4 *)(tile + WAVE * LR) + l) = m;
         __builtin_amdgcn_wave_barrier();
-        store_tile<8, 8, true, true>(0, l);
+        store_tile<8, 8, false, true>(0, l);
         __builtin_amdgcn_wave_barrier();
-        cl = 0; skip = 0;
+        cl = 0;
         if (mine && tlast >= 0)                                                   // the event times of an incomplete line; k - 1 = my last event, in slot tlast
             store_times(p.t + ((size_t)c * (size_t)p.n_sk + (size_t)k - 1 - (size_t)tlast), tile + WAVE * LR + 2 * WAVE + l, tfirst, tlast);
         tlast = -1;

@@ -34,7 +34,7 @@ for q in range(n):
         if rs.random() < 0.2:
             x[:] = 0.0                                  # exact zeros: y = x v starts at +-0
         got = P.sample_skeleton_ensemble(s, n_sk, x, v, seed=seed, diagnostics=True)
-        assert s.last_launch_form() == 4, "the lane kernel did not run"
+        assert s.last_launch_form() == (4 if (n_sk * dim) % 8 == 0 else 3), "unexpected kernel form"
         ref = O.sample_skeleton(cfg, n_sk, x, v, seed, diagnostics=True)
         assert_bitwise(got, ref)
         done += 1
