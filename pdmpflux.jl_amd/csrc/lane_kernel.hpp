@@ -83,7 +83,9 @@ constexpr int lane_lds_per_wave(int lk) { return WAVE * lane_row_stride(lk) + 2 
 #define LANE_SLOT_FENCE(a, tt) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(tt))
 #endif
 
-template <int TARGET, int LK>
+// DIAG: the launch records PDMPHistory's diagnostic arrays (horizon, ar, errored_bound, error_value_ar, rejected, hitting_horizon);
+// without them (the throughput case) their pointers, counters and the five-slot ring of error values are not compiled in at all.
+template <int TARGET, int LK, bool DIAG>
 struct LaneChain {
     static_assert(TARGET == T_GAUSS_ISO || TARGET == T_BANANA, "lane kernel: isotropic Gaussian and banana");
     static_assert(LK >= LANE_LK_MIN && LK <= LANE_LK_MAX, "lane kernel: 7 .. 13 slots of four coordinates");
@@ -496,14 +498,16 @@ struct LaneChain {
             ring[slot * WAVE] = t;
             tlast = slot;
             if (slot == 7) { store_times(p.t + e - 7, ring, tfirst, 7); tfirst = 0; tlast = -1; }
-            if (p.H) p.H[e] = horizon;
-            if (p.AR) p.AR[e] = ar;
-            if (p.EB) p.EB[e] = errored;
-            if (p.RJ) p.RJ[e] = rejected;
-            if (p.HH) p.HH[e] = hits;
-            if (p.EV) {
+            if constexpr (DIAG) {
+                if (p.H) p.H[e] = horizon;
+                if (p.AR) p.AR[e] = ar;
+                if (p.EB) p.EB[e] = errored;
+                if (p.RJ) p.RJ[e] = rejected;
+                if (p.HH) p.HH[e] = hits;
+                if (p.EV) {
 #pragma unroll
-                for (int q = 0; q < 5; ++q) p.EV[5 * e + q] = ev[q];
+                    for (int q = 0; q < 5; ++q) p.EV[5 * e + q] = ev[q];
+                }
             }
         }
         LANE_MARK(15);
@@ -681,13 +685,13 @@ struct LaneChain {
     }
 };
 
-template <int TARGET, int LK>
+template <int TARGET, int LK, bool DIAG>
 __global__ __launch_bounds__(256, LANE_WAVES) void lane_kernel(const GroupParams gp, const int32_t *flag) {
     if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;      // not unit speeds: the group kernel runs instead
     extern __shared__ double smem[];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     double *tile = smem + (size_t)wave * lane_lds_per_wave(LK);
-    LaneChain<TARGET, LK> chain(gp.s, lane, tile);
+    LaneChain<TARGET, LK, DIAG> chain(gp.s, lane, tile);
     const int nb = (int)gp.nb, n_units = nb * gp.nseg;
     bool lost = false;
     for (int pulled = 0; pulled <= n_units && !lost; ++pulled) {
@@ -722,12 +726,12 @@ inline void lane_schedule(int64_t nb, int64_t slots, int64_t n_sk, int force, in
     nseg = (int32_t)((events + seg_len - 1) / seg_len);
 }
 
-template <int TARGET, int LK>
+template <int TARGET, int LK, bool DIAG>
 inline hipError_t launch_lane(const GroupParams &gp_in, const int32_t *flag, int rounds, hipStream_t stream) {
     GroupParams gp = gp_in;
     constexpr int wpb = 4;
     const size_t lds = (size_t)wpb * lane_lds_per_wave(LK) * sizeof(double);
-    void (*kernel)(const GroupParams, const int32_t *) = lane_kernel<TARGET, LK>;
+    void (*kernel)(const GroupParams, const int32_t *) = lane_kernel<TARGET, LK, DIAG>;
     int per_cu = 0, dev = 0, cus = 0;
     hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -749,7 +753,11 @@ inline hipError_t launch_lane(const GroupParams &gp_in, const int32_t *flag, int
 template <int TARGET, int LK0, int LK1>
 inline hipError_t launch_lane_by_slots(int lk, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream) {
     if constexpr (LK0 > LK1) return hipErrorNotSupported;
-    else return lk == LK0 ? launch_lane<TARGET, LK0>(gp, flag, rounds, stream) : launch_lane_by_slots<TARGET, LK0 + 1, LK1>(lk, gp, flag, rounds, stream);
+    else {
+        const bool diag = gp.s.H || gp.s.AR || gp.s.EB || gp.s.RJ || gp.s.HH || gp.s.EV;
+        return lk != LK0 ? launch_lane_by_slots<TARGET, LK0 + 1, LK1>(lk, gp, flag, rounds, stream)
+                         : (diag ? launch_lane<TARGET, LK0, true>(gp, flag, rounds, stream) : launch_lane<TARGET, LK0, false>(gp, flag, rounds, stream));
+    }
 }
 template <int LK0, int LK1>
 inline hipError_t launch_lane_range(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream) {
