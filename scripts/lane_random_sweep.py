@@ -33,10 +33,11 @@ for q in range(n):
         x, v = make_init("ZigZagAD", dim, C, seed=seed % 1000, target=target)
         if rs.random() < 0.2:
             x[:] = 0.0                                  # exact zeros: y = x v starts at +-0
-        got = P.sample_skeleton_ensemble(s, n_sk, x, v, seed=seed, diagnostics=True)
+        diag = bool(rs.random() < 0.5)              # without diagnostics the kernel instantiation is another one (DIAG = false)
+        got = P.sample_skeleton_ensemble(s, n_sk, x, v, seed=seed, diagnostics=diag)
         assert s.last_launch_form() == (4 if (n_sk * dim) % 8 == 0 else 3), "unexpected kernel form"
-        ref = O.sample_skeleton(cfg, n_sk, x, v, seed, diagnostics=True)
-        assert_bitwise(got, ref)
+        ref = O.sample_skeleton(cfg, n_sk, x, v, seed, diagnostics=diag)
+        assert_bitwise(got, ref) if diag else assert_bitwise(got, ref, keys=("X", "V", "t"))
         done += 1
     except Exception as e:
         bad += 1

@@ -53,6 +53,15 @@ def test_lane_kernel_segment_handoff(engine, oracle, lane, segments, target, dim
     assert_bitwise(got, oracle.sample_skeleton(cfg, 96, x, v, 3, diagnostics=True))
 
 
+@pytest.mark.parametrize("dim", [27, 34, 41, 50, 52])
+@pytest.mark.parametrize("target", ["iso", "banana"])
+def test_lane_kernel_without_diagnostics(engine, oracle, lane, dim, target):
+    """Launches that record no diagnostic arrays run another instantiation of the kernel (counters and error ring compiled out)."""
+    lane.setenv("PDMP_FORCE_SEGMENTS", "4")
+    s, cfg, x, v, got = _run(engine, oracle, dim, target, 131, 72, seed=17, diagnostics=False)
+    assert_bitwise(got, oracle.sample_skeleton(cfg, 72, x, v, 17, diagnostics=False), keys=("X", "V", "t"))
+
+
 @pytest.mark.parametrize("budget", ["1", "2", "5", "9"])
 def test_lane_kernel_bound_instalments(engine, oracle, lane, budget):
     lane.setenv("PDMP_CELL_BUDGET", budget)
