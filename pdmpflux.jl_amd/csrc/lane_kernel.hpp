@@ -309,9 +309,10 @@ struct LaneChain {
     //   the first nfull = 8 floor((cl + d) / 8) doubles are stored (lines A / 8 ...), the rest becomes the next carry.
     // Values are kept as (y, sign bit): x = y with the sign flipped where the bit is set, v = +-1 from the same bit; bit i of
     // the chain's 64-bit word S belongs to row position i (carried positions keep the bits they were recorded with).
-    // Store (q, r): lane (grp = lane / W, sub = lane % W) handles position q + sub of chain (64 / W) r + grp through buffer
-    // descriptors of the wave's window of X / V (64 consecutive chains, < 2^31 bytes -- the host checks); a chain that does not
-    // record publishes an offset beyond the window and the hardware drops its lanes: no exec masks, no branches in the loop.
+    // Store (q, r) of a tile of W row positions: lane (grp = lane / (W / 2), sub = lane % (W / 2)) handles the two positions
+    // q + 2 sub, + 1 of chain (128 / W) r + grp in one 16-byte store (store_tile2; store_tile: one position, 8 bytes -- the flush)
+    // through buffer descriptors of the wave's window of X / V (64 consecutive chains, < 2^31 bytes -- the host checks); a chain that
+    // does not record publishes an offset beyond the window and the hardware drops its lanes: no exec masks, no branches in the loop.
     // At the end of a segment the carry is flushed as a partial line; the next segment rebuilds it from the hand-off state.
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
