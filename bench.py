@@ -10,8 +10,12 @@ With N>1 (torchrun, one rank per GPU) the SAME ensemble is sharded over the rank
 chain range shard_range(chains, r, N), chain ids stay global) and every step ends, inside the timed region, with the north
 star's exchange: one RCCL all-gather each for the X, V and t shards, after which every GPU holds the whole skeleton
 (`ensemble.sample_skeleton_sharded(gather="skeleton")`, in place in preallocated full-size buffers).  `--gather none` times
-the sharded kernels alone.  The lanes-per-chain layout is chosen from the shard size (`--lanes auto`,
-pdmp_suggest_group_lanes): a 12 500-chain shard does not fill the GPU at the default layout.
+the sharded kernels alone.  The lanes-per-chain layout is ONE for all ranks (`--lanes auto` = pdmp_suggest_group_lanes, which returns
+the default layout for every shard size: more lanes per chain were measured and do not shorten a small shard's launch).
+
+`--driver multi` runs the same sharded step through the library's own multi-device entry (`pdmp_multi_sample_skeleton`,
+csrc/multi_device.hip: ONE process, one stream per device, grouped in-place ncclAllGather) -- the entry a Julia host uses -- instead
+of one process per GPU over torch.distributed: `python bench.py --gpus N --driver multi` (no torchrun).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -42,7 +46,10 @@ def parse():
     ap.add_argument("--chains", type=int, default=100_000, help="chains of the ensemble (sharded over the GPUs)")
     ap.add_argument("--gather", default="skeleton", choices=["skeleton", "none"],
                     help="N > 1: the exchange that ends every step (skeleton: all-gather of X, V, t -- the north star's)")
-    ap.add_argument("--lanes", default="auto", help="lanes per chain: auto (from the shard size), default, or a power of two")
+    ap.add_argument("--lanes", default="auto", help="lanes per chain: auto (pdmp_suggest_group_lanes: the default layout for every shard size), default, or a power of two")
+    ap.add_argument("--driver", default="ranks", choices=["ranks", "multi"],
+                    help="ranks: one process per GPU over torch.distributed (what the round driver launches); multi: ONE process, "
+                         "pdmp_multi_sample_skeleton over --gpus devices (the library's own RCCL path)")
     ap.add_argument("--n-sk", type=int, default=1000)
     ap.add_argument("--dim", type=int, default=50)
     ap.add_argument("--sampler", default="ZigZagAD", choices=["ZigZagAD", "ZigZag", "BPS", "BPSAD", "Boomerang", "BoomerangAD", "ForwardECMC", "ForwardECMCAD", "SpeedUpZigZag", "SpeedUpZigZagAD", "RHMC"])
@@ -77,10 +84,22 @@ def live_counters(a):
     for group in (["WRITE_SIZE"], ["FETCH_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"]):
         tmp = tempfile.mkdtemp(prefix="pdmp_pmc_", dir="/tmp")
         try:
-            cmd = ["rocprofv3", "--pmc", *group, "--output-format", "csv", "-d", tmp, "--", "python3", os.path.join(ROOT, "bench.py"), *args]
-            r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+            # the interpreter itself after `--` (no env / launcher hop: the profiler has initialised the GPU before the program starts);
+            # its own session, so that a timeout ends the profiled grandchild too instead of leaving it on the GPU
+            cmd = ["rocprofv3", "--pmc", *group, "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.join(ROOT, "bench.py"), *args]
+            proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=120)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
+                return None
             files = glob.glob(os.path.join(tmp, "**", "*_counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
+            if rc != 0 or not files:
                 return None
             names = set()
             for row in csv.DictReader(open(files[0])):
@@ -260,8 +279,76 @@ def workload_label(a, sampler, world, C_local):
             f"grid_size={sampler.grid_size}, tmax={sampler.tmax}, {'adaptive' if sampler.adaptive else 'fixed horizon'}, {slopes}{rr}")
 
 
+def main_multi(a):
+    """`--driver multi`: the sharded step through pdmp_multi_sample_skeleton -- one process, one engine handle and stream per device,
+    the final exchange by grouped in-place ncclAllGather inside the library (csrc/multi_device.hip).  Same workload, same JSON line."""
+    import ctypes as C
+    import torch
+    import pdmpflux.jl_amd as P
+    from pdmpflux.jl_amd import _lib, ensemble
+    n = a.gpus
+    assert torch.cuda.is_available() and torch.cuda.device_count() >= n, f"--driver multi --gpus {n}: {torch.cuda.device_count()} device(s) visible"
+    sampler = make_sampler(P, a)
+    x, v = make_inputs(torch, a, torch.device("cuda", 0))
+    xh, vh = x.cpu().numpy(), v.cpu().numpy()                  # the entry takes host inits (a Julia host's arrays) and stages each shard
+    C_total, d, n_sk = a.chains, a.dim, a.n_sk
+    gather = 1 if (a.gather == "skeleton" and n > 1) else 0
+    L = _lib.lib()
+    cfg = sampler._config()
+    m = C.c_void_p()
+    _lib.check(L.pdmp_multi_create(C.byref(cfg), n, None, C.byref(m)))
+    bufs = []
+    for r in range(n):
+        lo, hi = ensemble.shard_range(C_total, r, n)
+        rows = C_total if gather else hi - lo
+        dev = torch.device("cuda", r)
+        bufs.append({"X": torch.empty((rows, n_sk, d), dtype=torch.float64, device=dev), "V": torch.empty((rows, n_sk, d), dtype=torch.float64, device=dev),
+                     "t": torch.empty((rows, n_sk), dtype=torch.float64, device=dev)})
+    arr = lambda k: (C.c_void_p * n)(*[b[k].data_ptr() for b in bufs])
+    AX, AV, At = arr("X"), arr("V"), arr("t")
+
+    def step(i):
+        _lib.check(L.pdmp_multi_sample_skeleton(m, C_total, n_sk, 0, C.c_void_p(xh.ctypes.data), C.c_void_p(vh.ctypes.data), C.c_uint64(a.seed + i),
+                                                gather, AX, AV, At))
+    for i in range(a.warmup):
+        step(i)
+    k_ms, x_ms = [], []
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)                                      # returns after every device's stream has drained
+        km, xm = C.c_double(), C.c_double()
+        _lib.check(L.pdmp_multi_get_timing(m, C.byref(km), C.byref(xm)))
+        k_ms.append(km.value); x_ms.append(xm.value)
+    elapsed = time.perf_counter() - t0
+    tt = bufs[0]["t"][:256]
+    assert bool((tt[:, 1:] > tt[:, :-1]).all()) and bool(torch.isfinite(bufs[0]["X"][:256]).all())
+    if gather:                                                  # every device holds every shard: compare device n-1's copy with device 0's
+        assert torch.equal(bufs[0]["t"].cpu(), bufs[n - 1]["t"].cpu())
+    L.pdmp_multi_destroy(m)
+    events_step = C_total * (n_sk - 1)
+    bytes_per_event = 8 * (2 * d + 1)
+    lo0, hi0 = ensemble.shard_range(C_total, 0, n)
+    kernel_ms = sum(k_ms) / len(k_ms)                           # staging of the shard's inits (host -> device) + the shard kernel, max over devices
+    achieved = (hi0 - lo0) * (n_sk - 1) * bytes_per_event / (kernel_ms * 1e-3) / 1e9
+    xbytes = (C_total - (hi0 - lo0)) * n_sk * bytes_per_event if gather else 0
+    res = {"metric": metric_label(a, sampler, C_total), "value": events_step * a.steps / elapsed, "unit": "events/s", "n_gpus": n, "steps": a.steps,
+           "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": workload_label(a, sampler, n, hi0 - lo0), "driver": "multi: one process, pdmp_multi_sample_skeleton (csrc/multi_device.hip)",
+                      "chains": C_total, "chains_rank0": hi0 - lo0, "n_sk": n_sk, "dim": d, "events_per_step": events_step,
+                      "exchange": "none" if not gather else f"grouped in-place ncclAllGather of X, V, t inside the library: {xbytes} bytes received per GPU per step",
+                      "exchange_bytes_per_gpu": xbytes, "kernel_ms_max_over_devices": kernel_ms, "exchange_ms_max_over_devices": sum(x_ms) / len(x_ms),
+                      "host_inits": "xinit / vinit are host arrays, staged per step (16 d bytes per chain)"},
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "kernel_ms": kernel_ms, "bytes_per_event": bytes_per_event,
+                        "note": "kernel_ms here includes the host -> device staging of the shard's initial states (hipEvents around both)"}}
+    print(json.dumps(res), flush=True)
+
+
 def main():
     a = parse()
+    if a.driver == "multi":
+        return main_multi(a)
     live = live_counters(a) if (a.pmc == "auto" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.gpus == 1) else None
     import torch
     import pdmpflux.jl_amd as P
@@ -417,6 +504,17 @@ def main():
                                   "the kernel is bound by fp64 VALU issue, not by HBM (roofline.valu: wave-instructions per event and the share of "
                                   "SIMD cycles the VALUs are busy, from the committed PMC pass); the HBM fraction is the requested headline")},
         }
+        # The ceiling that binds the VALU-bound workloads (BPS, Boomerang, small shards): fp64 vector issue.  Every VALU wave-instruction
+        # occupies its SIMD's 16 fp64 lanes for 4 cycles whatever it computes, so SQ_INSTS_VALU x 64 lanes x 2 flop (an FMA per lane and
+        # issue slot) is the flop-equivalent of the issue slots the launch used; against the 78.6 TFLOP/s fp64 vector peak
+        # (256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz) that is the share of all VALU issue slots of the chip at its top clock.
+        if cnt and cnt.get("valu_instr_per_event"):
+            slots = cnt["valu_instr_per_event"] * C_local * (n_sk - 1) * 64 * 2 / (kernel_ms * 1e-3) / 1e12
+            res["roofline_valu"] = {"bound": "valu-f64", "achieved": slots, "peak": 78.6, "unit": "TFLOP/s", "frac": slots / 78.6,
+                                    "instr_per_event": cnt["valu_instr_per_event"], "busy": cnt.get("valu_busy"),
+                                    "note": "achieved = SQ_INSTS_VALU x 64 lanes x 2 flop / kernel time: the fp64-FMA equivalent of the VALU issue slots used "
+                                            "(not all of them hold fp64 arithmetic); peak = fp64 vector peak at 2.4 GHz; `busy` is the same share against the "
+                                            "clock the chip actually held (4 SQ_ACTIVE_INST_VALU / SIMD cycles)"}
         if a.target == "dense" and int(_lib.lib().pdmp_dense_batched_last_mode()) == 2:
             res["roofline"]["kernel"] = ("di_segment_kernel (wave per chain; P x and P v kept current by O(d) updates, one rocBLAS dgemm over all "
                                          "chains per 256 events re-bases them)")

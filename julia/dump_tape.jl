@@ -10,6 +10,8 @@
 #     randexp(rng)                 SamplingLoopInplace.jl:70,136,190        -> exp.f64
 #     rand(rng) / Categorical      SamplingLoopInplace.jl:154, ZigZagSamplers.jl:104, BouncyParticleSamplers.jl:54, BoomerangSamplers.jl:55 -> uni.f64
 #     randn!(rng, v)               BouncyParticleSamplers.jl:67             -> nrm.f64
+#     rand(key), randn(key, 2, dim), randn(key, dim)   ForwardEventChainMonteCarlo.jl:62,79,107,138,160,164 -> uni.f64 / nrm.f64
+#                                  (randn(key, dims...) fills an array through randn!: logged column-major, i.e. g[1,j], g[2,j] adjacent)
 # and writes the tapes and the resulting PDMPHistory as raw little-endian arrays plus a meta.json.  The engine (pdmp_set_tape) and
 # the checker (orc_config_t.tape_*) replay the tapes draw for draw; tests/test_julia_fixtures.py compares their skeletons with the
 # dumped history at the north-star tolerance.  (Boomerang's refresh draws `randn(dim)` from the GLOBAL rng, BoomerangSamplers.jl:65,
@@ -63,6 +65,11 @@ function cases()
         ("bps_banana_d50", BPS, grad_banana, 50, (;), "banana", Float64[]),
         ("bps_errorpath_d2", BPS, grad_banana, 2, (; tmax=20.0, adaptive=false), "banana", Float64[]),
         ("boomerang_diag_d6_norefresh", Boomerang, grad_diag6, 6, (; refresh_rate=0.0), "diag", vcat(mu6, prec6)),
+        # ForwardECMC: the reference's most-tested grid-path sampler (test/test_integration.jl:41-65, test/test_diagnostics.jl:128)
+        ("forwardecmc_iso_d6", ForwardECMC, x -> x, 6, (;), "iso", Float64[]),
+        ("forwardecmcad_banana_d6", ForwardECMCAD, U_banana, 6, (;), "banana", Float64[]),
+        ("forwardecmc_iso_d50_ranp", ForwardECMC, x -> x, 50, (; ran_p=true), "iso", Float64[]),
+        ("forwardecmc_diag_d6_fullrefresh", ForwardECMC, grad_diag6, 6, (; switch=false), "diag", vcat(mu6, prec6)),
     ]
 end
 
@@ -70,7 +77,7 @@ function dump_case(outdir, name, ctor, pot, d, kw, target, tparams; n_sk=400, se
     sampler = ctor(d, pot; kw...)
     rs = MersenneTwister(sum(Int, collect(name)))
     xinit = target == "banana" ? 1 .+ 0.1 .* randn(rs, d) : randn(rs, d)
-    vinit = ctor in (ZigZag, ZigZagAD) ? rand(rs, [-1.0, 1.0], d) : (v = randn(rs, d); ctor === BPS ? v ./ sqrt(sum(v .^ 2)) : v)
+    vinit = ctor in (ZigZag, ZigZagAD) ? rand(rs, [-1.0, 1.0], d) : (v = randn(rs, d); ctor in (BPS, ForwardECMC, ForwardECMCAD) ? v ./ sqrt(sum(v .^ 2)) : v)
     x0, v0 = copy(xinit), copy(vinit)                      # init_state aliases its arguments (AbstractPDMP.jl:141-149)
     state = init_state(sampler, xinit, vinit, seed)
     tape = TapeRNG(seed)

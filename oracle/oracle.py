@@ -34,7 +34,7 @@ class _Cfg(C.Structure):
         ("tape_exp", C.POINTER(C.c_double)), ("tape_uni", C.POINTER(C.c_double)), ("tape_nrm", C.POINTER(C.c_double)),
         ("tape_n_exp", C.c_int64), ("tape_n_uni", C.c_int64), ("tape_n_nrm", C.c_int64),
         ("fe_mix_p", C.c_double), ("fe_ran_p", C.c_int32), ("fe_switch", C.c_int32), ("fe_positive", C.c_int32),
-        ("rh_reserved", C.c_int32), ("rh_step_size", C.c_double), ("rh_phi", C.c_double),
+        ("no_identities", C.c_int32), ("rh_step_size", C.c_double), ("rh_phi", C.c_double),
         ("fe_speed_factor", C.c_double), ("is_active_out", C.c_void_p),
     ]
 
@@ -124,6 +124,7 @@ class Config:
     step_size: float = 0.05            # RHMC keywords (RandomizedHamiltonianMonteCarlo.jl:48-57)
     phi: float = 1.5707963267948966
     speed_factor: float = 1.0          # ForwardECMC
+    no_identities: bool = False        # GROUP order without the engine order's three algebraic identities (checker-side comparisons only)
     is_active_out: int | None = None   # StickyZigZag: address of a (C, n_sk, d) uint8 array receiving PDMPHistory.is_active
     _keep: list = field(default_factory=list, repr=False)
 
@@ -143,7 +144,7 @@ class Config:
         return _Cfg(self.sampler, self.dim, self.grid_size, int(self.vectorized_bound), int(self.signed_bound),
                     int(self.adaptive), int(self.gaussian_velocity), self.deriv_mode, self.target_id, self.arith,
                     float(self.tmax), float(self.refresh_rate), p, n, self.max_iter_per_event, self.group_lanes,
-                    te, tu, tn, ne, nu, nn, float(self.mix_p), int(self.ran_p), int(self.switch), int(self.positive), 0,
+                    te, tu, tn, ne, nu, nn, float(self.mix_p), int(self.ran_p), int(self.switch), int(self.positive), int(self.no_identities),
                     float(self.step_size), float(self.phi), float(self.speed_factor), self.is_active_out)
 
 

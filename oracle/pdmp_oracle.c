@@ -534,7 +534,7 @@ static void fd_points(double t, double horizon, double *tm, double *tp) {
  * Value and t-derivative at a grid time: f = head.v + fma(B, t, A), f' = head.e + B.  The reference evaluates all d coordinates
  * at every grid time; the two agree up to the rounding of the sums (1e-5 tolerance test, tests/test_gpu_reference_order.py). */
 static int lr_mode(const orc_config_t *cfg) {
-    return cfg->arith == ORC_ARITH_GROUP && (cfg->sampler == ORC_BPS || cfg->sampler == ORC_FECMC) && cfg->deriv_mode == ORC_DERIV_FORWARD &&
+    return cfg->arith == ORC_ARITH_GROUP && !cfg->no_identities && (cfg->sampler == ORC_BPS || cfg->sampler == ORC_FECMC) && cfg->deriv_mode == ORC_DERIV_FORWARD &&
            (cfg->target_id == ORC_T_GAUSS_ISO || cfg->target_id == ORC_T_GAUSS_DIAG || cfg->target_id == ORC_T_BANANA);
 }
 static int lr_aff(const orc_config_t *cfg) { return (cfg->target_id == ORC_T_BANANA && cfg->dim >= 2) ? 2 : 0; }
@@ -571,7 +571,7 @@ static double lr_func(const orc_config_t *cfg, const double *x, const double *v,
  * per lane left to right, then the butterfly), its t-derivative  XV (-4 s c) + (VV - XX) (c^2 - s^2).  One pass over the
  * coordinates per state instead of one per grid time (and per finite-difference point: 30 per bound with AD_backend="FiniteDiff"). */
 static int lrb_mode(const orc_config_t *cfg) {
-    return cfg->arith == ORC_ARITH_GROUP && cfg->sampler == ORC_BOOMERANG && cfg->target_id == ORC_T_GAUSS_ISO;
+    return cfg->arith == ORC_ARITH_GROUP && !cfg->no_identities && cfg->sampler == ORC_BOOMERANG && cfg->target_id == ORC_T_GAUSS_ISO;
 }
 static void lrb_coeffs(const orc_config_t *cfg, ws_t *w, const double *x, const double *v, double *XX, double *XV, double *VV) {
     const int d = w->d, G = cfg->group_lanes;
@@ -676,7 +676,7 @@ static void upper_bound(const orc_config_t *cfg, ws_t *w, const double *x, const
         if (cfg->arith == ORC_ARITH_REFERENCE) memset(w->cum, 0, (size_t)n * 8);
         /* coordinates i >= affine_from have d grad_i / dx_j = const * delta_ij (isotropic / diagonal Gaussian: all; banana: i >= 2);
          * the engine decides per slot of G coordinates, hence the rounding to a multiple of G below */
-        const int affine_cells = cfg->arith == ORC_ARITH_GROUP && cfg->sampler == ORC_ZIGZAG && cfg->signed_bound &&
+        const int affine_cells = cfg->arith == ORC_ARITH_GROUP && !cfg->no_identities && cfg->sampler == ORC_ZIGZAG && cfg->signed_bound &&
                                  cfg->deriv_mode == ORC_DERIV_FORWARD;
         const int affine_from = (cfg->target_id == ORC_T_GAUSS_ISO || cfg->target_id == ORC_T_GAUSS_DIAG) ? 0
                               : (cfg->target_id == ORC_T_BANANA ? 2 : (1 << 30));

@@ -66,7 +66,9 @@ typedef struct orc_config_t {
     /* ForwardECMC keywords (ForwardEventChainMonteCarlo.jl:290-292): mix_p = 0.5, ran_p = false, switch = true, positive = true */
     double  fe_mix_p;
     int32_t fe_ran_p, fe_switch, fe_positive;
-    int32_t rh_reserved;
+    int32_t no_identities;       /* GROUP order only, checker-side switch (tests/test_oracle_identities.py): 1 = evaluate the reference's full
+                                  * formulas in the GROUP summation order, WITHOUT the three algebraic identities the engine order takes
+                                  * (affine cell, affine tail, quadratic form) -- what those identities are compared against */
     /* RHMC keywords (RandomizedHamiltonianMonteCarlo.jl:48-57): step_size = 0.05, phi = pi/2 (refresh_rate = 1, tmax = 10, adaptive = false) */
     double  rh_step_size, rh_phi;
     double  fe_speed_factor;     /* ForwardECMC speed_factor (ForwardEventChainMonteCarlo.jl:177-218); 0 -> 1.0 */

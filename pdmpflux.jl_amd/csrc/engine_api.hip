@@ -23,6 +23,11 @@ hipError_t launch_group_reg_zigzag_exact(int target, const GroupParams &gp, hipS
 hipError_t launch_group_reg_bps_exact(int target, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_boomerang_exact(int target, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_boomerang_exact_fd(int target, const GroupParams &gp, hipStream_t stream);
+// tape replay (pdmp_set_tape): the same kernel forms with the tapes as random source (inst_tape_*.hip)
+hipError_t launch_lane_zigzag_tape(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);
+hipError_t launch_group_reg_tape_zigzag(int target, bool fd, const GroupParams &gp, hipStream_t stream);
+hipError_t launch_group_reg_tape_bps(int target, bool fd, const GroupParams &gp, hipStream_t stream);
+hipError_t launch_group_reg_tape_boomerang(int target, bool fd, const GroupParams &gp, hipStream_t stream);
 }
 
 namespace {
@@ -599,6 +604,20 @@ glaunch_fn pick_group_launcher(int sampler, int target) {
     return table[sampler][target];
 }
 
+glaunch_fn pick_group_tape_launcher(int sampler, int target) {
+    static const glaunch_fn table[7][3] = {
+        {launch_group_tape<S_ZIGZAG, T_GAUSS_ISO>, launch_group_tape<S_ZIGZAG, T_GAUSS_DIAG>, launch_group_tape<S_ZIGZAG, T_BANANA>},
+        {launch_group_tape<S_BPS, T_GAUSS_ISO>, launch_group_tape<S_BPS, T_GAUSS_DIAG>, launch_group_tape<S_BPS, T_BANANA>},
+        {launch_group_tape<S_BOOMERANG, T_GAUSS_ISO>, launch_group_tape<S_BOOMERANG, T_GAUSS_DIAG>, launch_group_tape<S_BOOMERANG, T_BANANA>},
+        {launch_group_tape<S_FECMC, T_GAUSS_ISO>, launch_group_tape<S_FECMC, T_GAUSS_DIAG>, launch_group_tape<S_FECMC, T_BANANA>},
+        {launch_group_tape<S_SUZZ, T_GAUSS_ISO>, launch_group_tape<S_SUZZ, T_GAUSS_DIAG>, launch_group_tape<S_SUZZ, T_BANANA>},
+        {launch_group_tape<S_RHMC, T_GAUSS_ISO>, launch_group_tape<S_RHMC, T_GAUSS_DIAG>, launch_group_tape<S_RHMC, T_BANANA>},
+        {launch_group_tape<S_STICKY, T_GAUSS_ISO>, launch_group_tape<S_STICKY, T_GAUSS_DIAG>, launch_group_tape<S_STICKY, T_BANANA>},
+    };
+    if (sampler < 0 || sampler > 6 || target < 0 || target > 2) return nullptr;
+    return table[sampler][target];
+}
+
 // Lanes per chain for the group kernel: the smallest power of two that keeps a wave's LDS tile
 // (2 * ceil(d/G) * 512 B) within `budget` bytes, i.e. at least 160 KiB / (4 * budget) blocks of four
 // waves per CU.  0 = the configuration is served by the wave-per-chain kernel instead.
@@ -623,6 +642,16 @@ int choose_group_lanes(const pdmp_config_t &c) {
         if (2 * K * WAVE * sizeof(double) <= budget) return G;
     }
     return 0;
+}
+
+// Which kernel family replays a tape for this handle: the group family (LDS form, register form, one lane per chain -- whichever
+// the same launch would run with the Philox stream) for every sampler on the built-in separable / banana targets, else the
+// wave-per-chain kernel (grid sizes other than 10: Zig-Zag / BPS / Boomerang), else none.
+bool tape_on_group(const pdmp_engine *h) {
+    return h->group_lanes > 0 && h->cfg.target_id <= PDMP_T_BANANA && !(getenv("PDMP_TAPE_WAVE") && atoi(getenv("PDMP_TAPE_WAVE")) == 1);
+}
+bool tape_on_wave(const pdmp_engine *h) {
+    return h->cfg.sampler <= PDMP_BOOMERANG && h->cfg.target_id <= PDMP_T_BANANA && h->cfg.grid_size >= 2 && h->cfg.dim <= 4 * WAVE;
 }
 
 int begin_timed(pdmp_engine *h, hipStream_t s, EventPair &ev) {
@@ -734,7 +763,7 @@ int pdmp_last_launch_form(pdmp_handle h) {
     return flag == 0 ? PDMP_FORM_LANE : PDMP_FORM_GROUP_REG;
 }
 
-int pdmp_get_group_lanes(pdmp_handle h) { return h ? (h->tape_chains > 0 ? 0 : h->group_lanes) : -1; }
+int pdmp_get_group_lanes(pdmp_handle h) { return h ? ((h->tape_chains > 0 && !tape_on_group(h)) ? 0 : h->group_lanes) : -1; }
 
 // Lanes per chain for launches of C chains.  Round 2 measured the obvious idea -- more lanes per chain when a launch cannot fill
 // the 2 048 resident wave slots (a 12 500-chain shard of the 8-GPU run is 782 waves at G = 4) -- and it does not pay: Zig-Zag d = 50,
@@ -780,9 +809,9 @@ int pdmp_set_tape(pdmp_handle h, int64_t C, int64_t n_exp, int64_t n_uni, int64_
     if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
     if (C <= 0 || n_exp <= 0 || n_uni <= 0 || n_nrm <= 0 || !exp_tape || !uni_tape || !nrm_tape)
         return fail(PDMP_ERR_ARGUMENT, "pdmp_set_tape needs C > 0 chains and three non-empty tapes");
-    if (h->cfg.sampler > PDMP_BOOMERANG || h->cfg.target_id > PDMP_T_BANANA || h->cfg.grid_size < 2 || h->cfg.dim > 4 * WAVE)
-        return fail(PDMP_ERR_UNSUPPORTED, "tape replay runs on the wave-per-chain kernel: Zig-Zag / BPS / Boomerang on the built-in "
-                                          "separable / banana targets, grid_size >= 2, dim <= %d", 4 * WAVE);
+    if (!tape_on_group(h) && !tape_on_wave(h))
+        return fail(PDMP_ERR_UNSUPPORTED, "tape replay: the built-in separable / banana targets (group kernels: every sampler, grid_size = 10 or 0; "
+                                          "wave-per-chain kernel: Zig-Zag / BPS / Boomerang, grid_size >= 2, dim <= %d)", 4 * WAVE);
     if (int rc = pdmp_clear_tape(h)) return rc;
     const double *src[3] = {exp_tape, uni_tape, nrm_tape};
     const int64_t n[3] = {n_exp, n_uni, n_nrm};
@@ -850,9 +879,8 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
         if (chain_id_offset < 0 || chain_id_offset + C > h->tape_chains)
             return fail(PDMP_ERR_ARGUMENT, "tape holds %lld chains; requested chains [%lld, %lld)", (long long)h->tape_chains,
                         (long long)chain_id_offset, (long long)(chain_id_offset + C));
-        if (c.grid_size < 2 || c.dim > 4 * WAVE || c.target_id > PDMP_T_BANANA || c.sampler > PDMP_BOOMERANG)
-            return fail(PDMP_ERR_UNSUPPORTED, "tape replay runs on the wave-per-chain kernel: Zig-Zag / BPS / Boomerang, built-in separable / banana "
-                                              "targets, grid_size >= 2, dim <= %d", 4 * WAVE);
+        if (!tape_on_group(h) && !tape_on_wave(h))
+            return fail(PDMP_ERR_UNSUPPORTED, "tape replay: built-in separable / banana targets only");
         p.tape_exp = h->d_tape[0]; p.tape_uni = h->d_tape[1]; p.tape_nrm = h->d_tape[2];
         p.tape_n_exp = h->tape_n[0]; p.tape_n_uni = h->tape_n[1]; p.tape_n_nrm = h->tape_n[2];
     }
@@ -872,7 +900,8 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
     h->launched = true;
     GroupParams gp;
     memset(&gp, 0, sizeof gp);
-    if (h->group_lanes > 0 && !taped) {
+    const bool tgroup = taped && tape_on_group(h);           // a replay on the group family: same forms, tapes as random source
+    if (h->group_lanes > 0 && (!taped || tgroup)) {
         gp.s = p;
         gp.G = h->group_lanes;
         gp.K = (c.dim + gp.G - 1) / gp.G;
@@ -894,7 +923,7 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
         }
         HIP_TRY(hipMemsetAsync(h->d_sched, 0, need_sched * sizeof(int32_t), s));
         if (const char *e = getenv("PDMP_FORCE_SEGMENTS")) gp.nseg = atoi(e);   // test hook, see group_schedule
-        if (c.sampler == PDMP_STICKY) gp.nseg = 1;                              // the hand-off state does not carry is_active
+        if (c.sampler == PDMP_STICKY || tgroup) gp.nseg = 1;                    // the hand-off state carries neither is_active nor tape positions
         gp.ctr = h->d_sched;
         gp.progress = h->d_sched + 1;
         gp.state = h->d_state;
@@ -927,7 +956,7 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
         h->last_form = PDMP_FORM_USER;
         const int e = pdmp_user_launch(h->user_fn, &gp, s);
         if (e != 0) { h->pool.push_back(ev); return fail(PDMP_ERR_RUNTIME, "launching the compiled potential: %s", hipGetErrorString((hipError_t)e)); }
-    } else if (h->group_lanes > 0 && !taped) {
+    } else if (h->group_lanes > 0 && (!taped || tgroup)) {
         hipError_t e = hipErrorNotSupported;
         h->last_form = PDMP_FORM_GROUP_REG;
         const char *reg = getenv("PDMP_REG");               // PDMP_REG=0: keep x, v in LDS tiles (test hook)
@@ -955,7 +984,9 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
                 if (const char *r = getenv("PDMP_LANE_ROUNDS")) { const int v = atoi(r); if (v >= 1 && v <= 64) rounds = v; }
                 GroupParams lp = gp;
                 if (!getenv("PDMP_CELL_BUDGET")) lp.cell_budget = 5;   // a pass of 64 chains costs ~2 000 instructions, a cell 240: wait for more cells
-                if (le == hipSuccess) le = c.dim > 48 ? launch_lane_zigzag(c.target_id, lp, flag, rounds, s)
+                if (tgroup) lp.nseg = 1;                     // (lane_schedule: a forced segment count)
+                if (le == hipSuccess) le = tgroup ? launch_lane_zigzag_tape(c.target_id, lp, flag, rounds, s)   // (d = 49 .. 52; else the group kernel below replays)
+                                      : c.dim > 48 ? launch_lane_zigzag(c.target_id, lp, flag, rounds, s)
                                       : c.dim > 36 ? launch_lane_zigzag_b(c.target_id, lp, flag, rounds, s) : launch_lane_zigzag_a(c.target_id, lp, flag, rounds, s);
                 if (le == hipSuccess) {                      // (a lane kernel that cannot be launched -- it asks for 145 KB of LDS per block --
                     gp.only_if = flag;                       //  leaves the launch to the group kernel below)
@@ -963,13 +994,18 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
                 } else (void)hipGetLastError();
             }
             const char *ex = getenv("PDMP_REG_EXACT");      // PDMP_REG_EXACT=0: the KREG-slot kernels with per-slot skips (test hook)
-            if (!(ex && atoi(ex) == 0))                     // a kernel of exactly K slots where one exists
+            if (tgroup)                                     // a replay: the 13-slot register kernels with the tapes as random source
+                e = c.sampler == PDMP_ZIGZAG    ? (fd ? hipErrorNotSupported : launch_group_reg_tape_zigzag(c.target_id, fd, gp, s))
+                  : c.sampler == PDMP_BPS       ? launch_group_reg_tape_bps(c.target_id, fd, gp, s)
+                  : c.sampler == PDMP_BOOMERANG ? launch_group_reg_tape_boomerang(c.target_id, fd, gp, s)
+                                                : hipErrorNotSupported;
+            else if (!(ex && atoi(ex) == 0))                // a kernel of exactly K slots where one exists
                 e = c.sampler == PDMP_BOOMERANG    ? (fd ? launch_group_reg_boomerang_exact_fd(c.target_id, gp, s)
                                                          : launch_group_reg_boomerang_exact(c.target_id, gp, s))
                   : fd                             ? hipErrorNotSupported
                   : c.sampler == PDMP_ZIGZAG       ? launch_group_reg_zigzag_exact(c.target_id, gp, s)
                   : c.sampler == PDMP_BPS          ? launch_group_reg_bps_exact(c.target_id, gp, s) : hipErrorNotSupported;
-            if (e == hipErrorNotSupported)
+            if (e == hipErrorNotSupported && !tgroup)
                 e = c.sampler == PDMP_ZIGZAG    ? launch_group_reg_zigzag(c.target_id, fd, gp, s)
                   : c.sampler == PDMP_BPS       ? launch_group_reg_bps(c.target_id, fd, gp, s)
                   : c.sampler == PDMP_BOOMERANG ? launch_group_reg_boomerang(c.target_id, fd, gp, s)
@@ -977,7 +1013,7 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
         }
         if (e == hipErrorNotSupported) {
             h->last_form = PDMP_FORM_GROUP;
-            const glaunch_fn f = pick_group_launcher(c.sampler, c.target_id);
+            const glaunch_fn f = tgroup ? pick_group_tape_launcher(c.sampler, c.target_id) : pick_group_launcher(c.sampler, c.target_id);
             if (!f) { h->pool.push_back(ev); return fail(PDMP_ERR_UNSUPPORTED, "no group kernel for sampler %d on target %d", c.sampler, c.target_id); }
             e = f(gp, s);
         }

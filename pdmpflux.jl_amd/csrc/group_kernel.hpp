@@ -210,7 +210,9 @@ template <> struct GTarget<T_USER> {
 // REGISTERS, every slot loop fully unrolled with a scalar skip of the slots >= K -- no ds_read latency in the loops, no slot
 // addressing.  Same operations in the same order: the two forms agree bit for bit.
 #define PDMP_SLOTS(s) _Pragma("unroll kUnroll") for (int s = 0; s < nk(); ++s) if (!kReg || s < kmin || s < K)
-template <int SAMPLER, int TARGET, bool FD, int KC = 0, int GC = 0>      // GC: lanes per chain when it is a compile-time constant (register form)
+// TAPE: the random source is a set of pre-recorded tapes instead of the Philox stream (pdmp_set_tape) -- separate
+// instantiations (inst_tape_*.hip), so the kernels that serve the Philox stream are compiled from exactly the code they had before.
+template <int SAMPLER, int TARGET, bool FD, int KC = 0, int GC = 0, bool TAPE = false>      // GC: lanes per chain when it is a compile-time constant (register form)
 struct GroupChain {
     using Tgt = GTarget<TARGET>;
     static constexpr bool kReg = KC > 0;
@@ -249,8 +251,73 @@ struct GroupChain {
 #ifdef PDMP_NO_PREFETCH          // A/B builds (scripts/ab.sh)
     static constexpr bool kPrefetch = false;
 #else
-    static constexpr bool kPrefetch = kReg && (SAMPLER == S_ZIGZAG || SAMPLER == S_BPS || SAMPLER == S_BOOMERANG);
+    static constexpr bool kPrefetch = kReg && !TAPE && (SAMPLER == S_ZIGZAG || SAMPLER == S_BPS || SAMPLER == S_BOOMERANG);
 #endif
+    // ---- tape source: one tape per kind of variate (Exp(1), U(0,1), N(0,1)), each in consumption order, chain-major by GLOBAL
+    // chain id -- the format of julia/dump_tape.jl, of the wave-per-chain kernel (skeleton_kernel.hpp: r_exp / r_uni / r_normal) and
+    // of the checker.  An exhausted tape yields 1.0 / 0.5 / 0.0, flags the launch (status[3]) and
+    // stops the chain.  A taped launch runs in ONE segment (the hand-off state carries one stream position, a tape has three).
+    const double *tp_e = nullptr, *tp_u = nullptr, *tp_n = nullptr;
+    int32_t tp_ie = 0, tp_iu = 0, tp_in = 0;
+    bool tp_over = false;
+    __device__ __forceinline__ void tape_open(int64_t c) {
+        if constexpr (TAPE) {
+            const size_t gc = (size_t)(p.chain0 + c);
+            tp_e = p.tape_exp + gc * (size_t)p.tape_n_exp;
+            tp_u = p.tape_uni + gc * (size_t)p.tape_n_uni;
+            tp_n = p.tape_nrm + gc * (size_t)p.tape_n_nrm;
+            tp_ie = 0; tp_iu = 0; tp_in = 0; tp_over = false;
+        }
+    }
+    // the chain's next uniform / exponential outside the prefetched stream positions (and every draw of a taped launch)
+    __device__ __forceinline__ double r_uniform() {
+        if constexpr (TAPE) { if (tp_iu < p.tape_n_uni) return tp_u[tp_iu++]; tp_over = true; return 0.5; }
+        else return rng.uniform();
+    }
+    __device__ __forceinline__ double r_exponential() {
+        if constexpr (TAPE) { if (tp_ie < p.tape_n_exp) return tp_e[tp_ie++]; tp_over = true; return 1.0; }
+        else return rng.exponential();
+    }
+    // coordinate i of the chain's next vector of normals (call r_normals_done(count) once afterwards)
+    __device__ __forceinline__ double r_normal_coord(int i) const {
+        if constexpr (TAPE) return (tp_in + i < p.tape_n_nrm) ? tp_n[tp_in + i] : 0.0;
+        else return rng.normal_coord(i);
+    }
+    __device__ __forceinline__ void r_normal_pair(int P, double &z0, double &z1) const {     // normals 2P, 2P + 1 of that vector
+        if constexpr (TAPE) { z0 = r_normal_coord(2 * P); z1 = r_normal_coord(2 * P + 1); }
+        else rng.normal_pair(P, z0, z1);
+    }
+    __device__ __forceinline__ void r_normals_done(int n) {
+        if constexpr (TAPE) { if (tp_in + n > p.tape_n_nrm) tp_over = true; tp_in += n; }
+        else rng.normals_done(n);
+    }
+    // The normals of ANOTHER chain of this wave (the one whose first lane is L), for the wave-cooperative refreshes: its stream
+    // counters (Philox) or its tape position, fetched from lane L.
+    struct NormalSrc { ChainRng r; const double *tn; int left; };
+    template <bool UNIFORM_L> __device__ __forceinline__ NormalSrc normal_src(int L) const {
+        NormalSrc o;
+        o.r = rng; o.tn = nullptr; o.left = 0;                                     // seed words are the same in every lane
+        if constexpr (TAPE) {
+            const unsigned long long a = (unsigned long long)(uintptr_t)(tp_n + tp_in);
+            const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)a, L, WAVE), hi = (uint32_t)__shfl((int)(uint32_t)(a >> 32), L, WAVE);
+            o.tn = (const double *)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+            o.left = __shfl((int)(p.tape_n_nrm - tp_in), L, WAVE);
+        } else if constexpr (UNIFORM_L) {                                          // L wave-uniform: the counters come as scalars
+            o.r.c2 = (uint32_t)__builtin_amdgcn_readlane((int)rng.c2, L);
+            o.r.c3 = (uint32_t)__builtin_amdgcn_readlane((int)rng.c3, L);
+            o.r.n = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rng.n >> 32), L) << 32) |
+                    (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rng.n, L);
+        } else {
+            o.r.c2 = (uint32_t)__shfl((int)rng.c2, L, WAVE);
+            o.r.c3 = (uint32_t)__shfl((int)rng.c3, L, WAVE);
+            o.r.n = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(rng.n >> 32), L, WAVE) << 32) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)rng.n, L, WAVE);
+        }
+        return o;
+    }
+    __device__ __forceinline__ static void src_pair(const NormalSrc &o, int P, double &z0, double &z1) {
+        if constexpr (TAPE) { z0 = (2 * P < o.left) ? o.tn[2 * P] : 0.0; z1 = (2 * P + 1 < o.left) ? o.tn[2 * P + 1] : 0.0; }
+        else o.r.normal_pair(P, z0, z1);
+    }
     uint32_t pf_w0 = 0, pf_w1 = 0, pf_w2 = 0, pf_w3 = 0;
     uint64_t pf_n = 0;
     __device__ __forceinline__ void rng_prefetch() {
@@ -264,6 +331,7 @@ struct GroupChain {
         }
     }
     __device__ __forceinline__ double draw_uniform() {
+        if constexpr (TAPE) return r_uniform();
         if constexpr (kPrefetch) {
             if (G >= 2) {
                 const uint64_t idx = rng.n;
@@ -286,7 +354,10 @@ struct GroupChain {
         }
         return rng.uniform();
     }
-    __device__ __forceinline__ double draw_exponential() { return -det_log(draw_uniform()); }
+    __device__ __forceinline__ double draw_exponential() {
+        if constexpr (TAPE) return r_exponential();
+        else return -det_log(draw_uniform());
+    }
 
     const int cell_budget;               // cells of a lazily built bound per pass of the state machine (bound_advance_vect)
     __device__ __forceinline__ GroupChain(const GroupParams &gp, int l, double *x_tile, double *v_tile)
@@ -1204,7 +1275,7 @@ struct GroupChain {
     __device__ __forceinline__ bool fecmc_jump(const typename Tgt::template Sh<double> &sh) {
         const int d = p.d;
         double *tn = fe_t[0], *tvo = fe_t[1];
-        const double u = rng.uniform();                                             // :134
+        const double u = r_uniform();                                               // :134
         const double pw = det_exp(det_log(u) * (2.0 / (double)(d - 1)));
         const double sf = p.fe_speed;                                               // speed_factor (:177-218; 1.0: the default jump, same bits)
         const double rho = sf * (-__dsqrt_rn(1.0 - pw));                            // :135 / :185
@@ -1221,13 +1292,13 @@ struct GroupChain {
         PDMP_SLOTS(s) { const double vp = vn * tn[s * WAVE + lane]; tvo[s * WAVE + lane] = V(s) - vp; }   // :152-153
         double nvo = __dsqrt_rn(tdot(tvo, tvo));
         if (nvo < 1e-10) {                                                          // :156-159
-            PDMP_SLOTS(s) { const int i = s * G + g; tvo[s * WAVE + lane] = in_dim(s, i) ? rng.normal_coord(i) : 0.0; }
-            rng.normals_done(d);
+            PDMP_SLOTS(s) { const int i = s * G + g; tvo[s * WAVE + lane] = in_dim(s, i) ? r_normal_coord(i) : 0.0; }
+            r_normals_done(d);
             const double dn = tdot(tvo, tn);
             PDMP_SLOTS(s) tvo[s * WAVE + lane] = tvo[s * WAVE + lane] - dn * tn[s * WAVE + lane];
             nvo = __dsqrt_rn(tdot(tvo, tvo));
         }
-        const double u2 = rng.uniform();                                            // :161
+        const double u2 = r_uniform();                                              // :161
         const double sq = __dsqrt_rn(sf * sf - rho * rho);                          // :164 / :207
         if (u2 >= p.fe_mix_p) {                                                     // :162-166
             PDMP_SLOTS(s) { const int i = s * G + g; if (in_dim(s, i)) V(s) = tvo[s * WAVE + lane] / nvo * sq + rho * tn[s * WAVE + lane]; }
@@ -1248,15 +1319,11 @@ struct GroupChain {
         while (todo != 0ull) {
             const int L = (int)__builtin_ctzll(todo);                               // first lane of the chain
             todo &= todo - 1ull;
-            ChainRng r = rng;                                                       // seed words are the same in every lane
-            r.c2 = (uint32_t)__builtin_amdgcn_readlane((int)rng.c2, L);
-            r.c3 = (uint32_t)__builtin_amdgcn_readlane((int)rng.c3, L);
-            r.n = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rng.n >> 32), L) << 32) |
-                  (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rng.n, L);
+            const NormalSrc r = normal_src<true>(L);
             if (p.fe_switch) {                                                      // g1[P], g2[P] = pair P
                 for (int P = lane; P < d; P += WAVE) {
                     double z0, z1;
-                    r.normal_pair(P, z0, z1);
+                    src_pair(r, P, z0, z1);
                     const int o = (P >> logG) * WAVE + L + (P & (G - 1));
                     t1[o] = z0;
                     t2[o] = z1;
@@ -1264,7 +1331,7 @@ struct GroupChain {
             } else {                                                                // z[2P], z[2P+1] = pair P
                 for (int P = lane; 2 * P < d; P += WAVE) {
                     double z0, z1;
-                    r.normal_pair(P, z0, z1);
+                    src_pair(r, P, z0, z1);
                     const int i0 = 2 * P, i1 = 2 * P + 1;
                     t2[(i0 >> logG) * WAVE + L + (i0 & (G - 1))] = z0;
                     if (i1 < d) t2[(i1 >> logG) * WAVE + L + (i1 & (G - 1))] = z1;
@@ -1275,7 +1342,7 @@ struct GroupChain {
         const double rho = fe_rho, sq = fe_sq;
         PDMP_SLOTS(s) { const int i = s * G + g; if (!in_dim(s, i)) { t1[s * WAVE + lane] = 0.0; t2[s * WAVE + lane] = 0.0; } }
         if (p.fe_switch) {                                                          // _orthogonal_switch, :60-91
-            rng.normals_done(2 * d);
+            r_normals_done(2 * d);
             const double d1 = tdot(t1, tn);
             PDMP_SLOTS(s) t1[s * WAVE + lane] = t1[s * WAVE + lane] - d1 * tn[s * WAVE + lane];        // :67
             const double d2 = tdot(t2, tn);
@@ -1288,7 +1355,7 @@ struct GroupChain {
             PDMP_SLOTS(s) t2[s * WAVE + lane] = t2[s * WAVE + lane] / n2;                              // :73
             const double a = tdot(tvo, t1), b = tdot(tvo, t2);
             double sn = 0.0, cs = 0.0;
-            if (p.fe_ran_p) { const double ut = rng.uniform(); det_sincos_2pi(ut, sn, cs); }           // theta = rand * 2pi, :79
+            if (p.fe_ran_p) { const double ut = r_uniform(); det_sincos_2pi(ut, sn, cs); }             // theta = rand * 2pi, :79
             double acc = 0.0;
             PDMP_SLOTS(s) {
                 const double vo = tvo[s * WAVE + lane], e1 = t1[s * WAVE + lane], e2 = t2[s * WAVE + lane];
@@ -1304,7 +1371,7 @@ struct GroupChain {
                 PDMP_SLOTS(s) t2[s * WAVE + lane] = t2[s * WAVE + lane] * sg;
             }
         } else {                                                                    // _full_refresh, :108-117
-            rng.normals_done(d);
+            r_normals_done(d);
             const double nz = __dsqrt_rn(tdot(t2, t2));
             PDMP_SLOTS(s) t2[s * WAVE + lane] = t2[s * WAVE + lane] / nz;
             const double dn = tdot(t2, tn);
@@ -1383,13 +1450,13 @@ struct GroupChain {
             const int logG = __builtin_ctz(G);
             for (int P = g; 2 * P < d; P += G) {
                 double z0, z1;
-                rng.normal_pair(P, z0, z1);
+                r_normal_pair(P, z0, z1);
                 const int i0 = 2 * P, i1 = 2 * P + 1;
                 const int o0 = (i0 >> logG) * WAVE + base + (i0 & (G - 1)), o1 = (i1 >> logG) * WAVE + base + (i1 & (G - 1));
                 vs[o0] = cphi * vs[o0] + sphi * z0;
                 if (i1 < d) vs[o1] = cphi * vs[o1] + sphi * z1;
             }
-            rng.normals_done(d);
+            r_normals_done(d);
             return false;
         } else if constexpr (SAMPLER == S_FECMC) {
             return fecmc_jump(sh);
@@ -1465,14 +1532,10 @@ struct GroupChain {
             while (rest != 0ull) {
                 const int L = (int)__builtin_ctzll(rest);
                 rest &= rest - 1ull;
-                ChainRng r = rng;
-                r.c2 = (uint32_t)__builtin_amdgcn_readlane((int)rng.c2, L);
-                r.c3 = (uint32_t)__builtin_amdgcn_readlane((int)rng.c3, L);
-                r.n = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(rng.n >> 32), L) << 32) |
-                      (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)rng.n, L);
+                const NormalSrc r = normal_src<true>(L);
                 for (int pr = lane; pr < P; pr += WAVE) {
                     double z0, z1;
-                    r.normal_pair(pr, z0, z1);
+                    src_pair(r, pr, z0, z1);
                     const int i0 = 2 * pr, i1 = 2 * pr + 1;
                     vs[(i0 >> logG) * WAVE + L + (i0 & (G - 1))] = z0;
                     if (i1 < d) vs[(i1 >> logG) * WAVE + L + (i1 & (G - 1))] = z1;
@@ -1489,13 +1552,10 @@ struct GroupChain {
                 rest &= rest - 1ull;
                 if (q >= r * P && q < (r + 1) * P) { L = Lr; pr = q - r * P; }
             }
-            ChainRng r2 = rng;                                            // seed words are the same in every lane; counters of lane L
-            r2.c2 = (uint32_t)__shfl((int)rng.c2, L, WAVE);
-            r2.c3 = (uint32_t)__shfl((int)rng.c3, L, WAVE);
-            r2.n = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(rng.n >> 32), L, WAVE) << 32) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)rng.n, L, WAVE);
+            const NormalSrc r2 = normal_src<false>(L);                    // counters (or the tape position) of lane L
             if (act) {
                 double z0, z1;
-                r2.normal_pair(pr, z0, z1);
+                src_pair(r2, pr, z0, z1);
                 const int i0 = 2 * pr, i1 = 2 * pr + 1;
                 vs[(i0 >> logG) * WAVE + L + (i0 & (G - 1))] = z0;
                 if (i1 < d) vs[(i1 >> logG) * WAVE + L + (i1 & (G - 1))] = z1;
@@ -1503,7 +1563,7 @@ struct GroupChain {
         }
         if (mine) {
             lr_ok = false;
-            rng.normals_done(d);
+            r_normals_done(d);
             if constexpr (kReg) { PDMP_SLOTS(s) vr[s] = in_dim(s, s * G + g) ? vs[s * WAVE + lane] : 0.0; }   // register form: vs is an exchange tile only
             double acc = 0.0;
             PDMP_SLOTS(s) {
@@ -1558,7 +1618,7 @@ struct GroupChain {
     // with an inclusive scan inside the slot (GROUP order of the checker)
     __device__ __forceinline__ void sticky_thaw() {
         flow_state_closed(tt);
-        const double u = rng.uniform() * thaw_rate;
+        const double u = r_uniform() * thaw_rate;
         double carry = 0.0;
         int pick = -1, last = -1;
         PDMP_SLOTS(s) {
@@ -1632,6 +1692,7 @@ struct GroupChain {
         }
         rng.init_lane(p.seed, (uint64_t)(p.chain0 + c));
         rng.restore(n0);
+        if (chain_ok) tape_open(c);
         amask = 0xffffffffu;                                              // is_active = trues(d), Composites.jl:95 (StickyZigZag runs in one segment)
         lr_ok = false;
         if constexpr (Tgt::kTile) tgt.b_valid = false;
@@ -1664,6 +1725,7 @@ struct GroupChain {
 #endif
         while (__ballot(!done) != 0ull) {
             STAMP(5);
+            if constexpr (TAPE) { if (tp_over) done = true; }             // tape exhausted: stop this chain (reported below)
             rng_prefetch();
             bool accepted = false, refresh = false, proposed = false, event_out = false;   // event_out: a StickyZigZag stick / thaw event
             if (!done && !propose) {
@@ -1683,7 +1745,7 @@ struct GroupChain {
                         if (mode == FRESH) {                              // one_step_of_thinning_or_sticking_or_thawing, StickySamplingLoop.jl:40-46
                             thaw_rate = sticky_thaw_rate();
                             tt = __builtin_huge_val();
-                            if (thaw_rate != 0.0) tt = rng.exponential() / thaw_rate;
+                            if (thaw_rate != 0.0) tt = r_exponential() / thaw_rate;
                         }
                     }
                     const double tnext = kSticky ? ((tp < tt) ? tp : tt) : tp;   // min(tp, tt); tt = Inf for the other samplers (Composites.jl:100)
@@ -1786,6 +1848,7 @@ struct GroupChain {
             }
         }
         if (guard && g == 0) { atomicAdd(&p.status[1], guard); guard = 0; }
+        if constexpr (TAPE) { if (tp_over && g == 0) atomicAdd(&p.status[3], 1); }
     }
 };
 
@@ -1845,7 +1908,7 @@ template <int SAMPLER, int TARGET, bool FD> struct GroupOcc {
         : 3;                                                            // Zig-Zag, Boomerang, ForwardECMC on the separable Gaussians
 };
 
-template <int SAMPLER, int TARGET, bool FD, int KC = 0, int GC = 0>
+template <int SAMPLER, int TARGET, bool FD, int KC = 0, int GC = 0, bool TAPE = false>
 __device__ __forceinline__ void group_kernel_body(const GroupParams &gp) {
     extern __shared__ double smem[];
     const int lane = lane_id();
@@ -1857,7 +1920,7 @@ __device__ __forceinline__ void group_kernel_body(const GroupParams &gp) {
     double *tile = smem + gp.tpar + (size_t)wave * gp.tiles * tsz;
     const int cpw = WAVE / gp.G;
     // register form: no x tile; one K*64-double tile per wave only where refreshed velocities are exchanged between lanes
-    GroupChain<SAMPLER, TARGET, FD, KC, GC> chain(gp, lane, tile, KC > 0 ? tile : tile + tsz);
+    GroupChain<SAMPLER, TARGET, FD, KC, GC, TAPE> chain(gp, lane, tile, KC > 0 ? tile : tile + tsz);
     chain.tgt.init(smem, gp.s.d);
     if constexpr (SAMPLER == S_FECMC) {
         for (int q = 0; q < 4; ++q) chain.fe_t[q] = tile + (2 + q) * tsz;
@@ -1891,9 +1954,31 @@ __device__ __forceinline__ void group_kernel_body(const GroupParams &gp) {
     if (lost && lane == 0) atomicAdd(&gp.s.status[2], 1);         // predecessor lost: report, never hang
 }
 
+// A launch that another kernel form serves (the lane kernel was enqueued and its unit-speed flag stayed 0): EVERY entry point of
+// the group family returns at once, so that two forms can never both write the outputs and the shared scheduler / hand-off state.
+__device__ __forceinline__ bool served_elsewhere(const GroupParams &gp) {
+    return gp.only_if && __hip_atomic_load(gp.only_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+}
+
 template <int SAMPLER, int TARGET, bool FD>
 __global__ __launch_bounds__(256, (GroupOcc<SAMPLER, TARGET, FD>::kWaves)) void group_kernel(const GroupParams gp) {
+    if (served_elsewhere(gp)) return;
     group_kernel_body<SAMPLER, TARGET, FD>(gp);
+}
+// tape replay (inst_tape_*.hip): the same code with the tapes as random source; one wave per SIMD (512 registers: the tape
+// pointers and positions can never cause a spill, and a replay is a parity run, not a throughput run)
+template <int SAMPLER, int TARGET, bool FD>
+__global__ __launch_bounds__(256, 1) void group_kernel_tape(const GroupParams gp) {
+    if (served_elsewhere(gp)) return;
+    group_kernel_body<SAMPLER, TARGET, FD, 0, 0, true>(gp);
+}
+template <int SAMPLER, int TARGET, bool FD, int KC, int GC, bool FULL>
+__global__ __launch_bounds__(256, 1) void group_kernel_reg_tape(const GroupParams gp_in) {
+    if (served_elsewhere(gp_in)) return;
+    GroupParams gp = gp_in;
+    gp.G = GC;
+    if (FULL) gp.K = KC;
+    group_kernel_body<SAMPLER, TARGET, FD, KC, GC, true>(gp);
 }
 // Which register-form kernels exist.  kAny: the form is used at all; kPartial: also for K < KC (with the per-slot skips);
 // full<GC>(): a separate instantiation without the skips for K == KC.  Set from the compiler's resource-usage remarks so that no
@@ -1949,8 +2034,11 @@ inline void group_schedule(int64_t nb, int64_t slots, int64_t n_sk, int force, i
 template <int SAMPLER, int TARGET>
 hipError_t launch_group(const GroupParams &gp, hipStream_t stream);
 
+template <int SAMPLER, int TARGET>
+hipError_t launch_group_tape(const GroupParams &gp, hipStream_t stream);       // LDS form with the tapes as random source (inst_tape_lds*.hip)
+
 // EXACT: only the FULL variant (K == KC) of this KC is instantiated (inst_reg_*_k.hip: one kernel per K = 7..12)
-template <int SAMPLER, int TARGET, bool FD, int KC = 0, int GC = 0, bool EXACT = false>
+template <int SAMPLER, int TARGET, bool FD, int KC = 0, int GC = 0, bool EXACT = false, bool TAPE = false>
 hipError_t launch_group_impl(const GroupParams &gp_in, hipStream_t stream) {
     GroupParams gp = gp_in;
     if (KC > 0) gp.tiles = (SAMPLER == S_ZIGZAG) ? 0 : 1;
@@ -1960,9 +2048,15 @@ hipError_t launch_group_impl(const GroupParams &gp_in, hipStream_t stream) {
     void (*kernel)(const GroupParams) = nullptr;
     if constexpr (KC > 0) {
         using RF = RegForm<SAMPLER, TARGET, FD>;
-        if constexpr (RF::kPartial && !EXACT) kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, false>;
-        if constexpr (RF::template full<GC>()) if (gp.K == KC) kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, true>;
-    } else kernel = group_kernel<SAMPLER, TARGET, FD>;
+        if constexpr (TAPE) {                       // (one wave per SIMD: no instantiation can spill, so every one exists)
+            if constexpr (!EXACT) kernel = group_kernel_reg_tape<SAMPLER, TARGET, FD, KC, GC, false>;
+            if (gp.K == KC) kernel = group_kernel_reg_tape<SAMPLER, TARGET, FD, KC, GC, true>;
+        } else {
+            if constexpr (RF::kPartial && !EXACT) kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, false>;
+            if constexpr (RF::template full<GC>()) if (gp.K == KC) kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, true>;
+        }
+    } else if constexpr (TAPE) kernel = group_kernel_tape<SAMPLER, TARGET, FD>;
+    else kernel = group_kernel<SAMPLER, TARGET, FD>;
     if (!kernel) return hipErrorNotSupported;
     hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -1981,6 +2075,13 @@ hipError_t launch_group_impl(const GroupParams &gp_in, hipStream_t stream) {
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(WAVE * wpb), lds, stream, gp);
     return hipGetLastError();
 }
+
+#define PDMP_DEFINE_GROUP_TAPE_LAUNCHER(S, T)                                                       \
+    template <>                                                                                     \
+    hipError_t launch_group_tape<S, T>(const GroupParams &gp, hipStream_t stream) {                 \
+        return gp.s.deriv_mode != 0 ? launch_group_impl<S, T, true, 0, 0, false, true>(gp, stream)  \
+                                    : launch_group_impl<S, T, false, 0, 0, false, true>(gp, stream); \
+    }
 
 #define PDMP_DEFINE_GROUP_LAUNCHER(S, T)                                                            \
     template <>                                                                                     \

@@ -6,28 +6,30 @@
 
 namespace pdmp {
 
-template <int S, int T, bool FD>
+// TAPE: the tape-replay instantiations (inst_tape_reg_*.hip; group_kernel_reg_tape, one wave per SIMD).  A replay runs the
+// 13-slot kernels (with the per-slot skips where K < 13) for every configuration the register form serves with the Philox stream.
+template <int S, int T, bool FD, bool TAPE = false>
 static hipError_t reg_by_lanes(const GroupParams &gp, hipStream_t stream) {
     if constexpr (!RegForm<S, T, FD>::kAny) return hipErrorNotSupported;
     else {
         switch (gp.G) {
-        case 1: return launch_group_impl<S, T, FD, KREG, 1>(gp, stream);
-        case 2: return launch_group_impl<S, T, FD, KREG, 2>(gp, stream);
-        case 4: return launch_group_impl<S, T, FD, KREG, 4>(gp, stream);
-        case 8: return launch_group_impl<S, T, FD, KREG, 8>(gp, stream);
-        case 16: return launch_group_impl<S, T, FD, KREG, 16>(gp, stream);
+        case 1: return launch_group_impl<S, T, FD, KREG, 1, false, TAPE>(gp, stream);
+        case 2: return launch_group_impl<S, T, FD, KREG, 2, false, TAPE>(gp, stream);
+        case 4: return launch_group_impl<S, T, FD, KREG, 4, false, TAPE>(gp, stream);
+        case 8: return launch_group_impl<S, T, FD, KREG, 8, false, TAPE>(gp, stream);
+        case 16: return launch_group_impl<S, T, FD, KREG, 16, false, TAPE>(gp, stream);
         default: return hipErrorNotSupported;
         }
     }
 }
 
-template <int S>
+template <int S, bool TAPE = false>
 static hipError_t reg_by_target(int target, bool fd, const GroupParams &gp, hipStream_t stream) {
-    if (gp.K > KREG || (gp.G >= 2 && gp.K < (KREG + 1) / 2)) return hipErrorNotSupported;   // (the exact-K kernels or the LDS form serve them)
+    if (gp.K > KREG || (!TAPE && gp.G >= 2 && gp.K < (KREG + 1) / 2)) return hipErrorNotSupported;   // (the exact-K kernels or the LDS form serve them)
     switch (target) {
-    case T_GAUSS_ISO: return fd ? reg_by_lanes<S, T_GAUSS_ISO, true>(gp, stream) : reg_by_lanes<S, T_GAUSS_ISO, false>(gp, stream);
-    case T_GAUSS_DIAG: return fd ? reg_by_lanes<S, T_GAUSS_DIAG, true>(gp, stream) : reg_by_lanes<S, T_GAUSS_DIAG, false>(gp, stream);
-    case T_BANANA: return fd ? reg_by_lanes<S, T_BANANA, true>(gp, stream) : reg_by_lanes<S, T_BANANA, false>(gp, stream);
+    case T_GAUSS_ISO: return fd ? reg_by_lanes<S, T_GAUSS_ISO, true, TAPE>(gp, stream) : reg_by_lanes<S, T_GAUSS_ISO, false, TAPE>(gp, stream);
+    case T_GAUSS_DIAG: return fd ? reg_by_lanes<S, T_GAUSS_DIAG, true, TAPE>(gp, stream) : reg_by_lanes<S, T_GAUSS_DIAG, false, TAPE>(gp, stream);
+    case T_BANANA: return fd ? reg_by_lanes<S, T_BANANA, true, TAPE>(gp, stream) : reg_by_lanes<S, T_BANANA, false, TAPE>(gp, stream);
     default: return hipErrorNotSupported;
     }
 }

@@ -85,7 +85,9 @@ constexpr int lane_lds_per_wave(int lk) { return WAVE * lane_row_stride(lk) + 2 
 
 // DIAG: the launch records PDMPHistory's diagnostic arrays (horizon, ar, errored_bound, error_value_ar, rejected, hitting_horizon);
 // without them (the throughput case) their pointers, counters and the five-slot ring of error values are not compiled in at all.
-template <int TARGET, int LK, bool DIAG>
+// TAPE: pre-recorded variates instead of the Philox stream (pdmp_set_tape; GroupChain's tape source, same format) -- separate
+// instantiations (inst_tape_lane.hip), one segment per chain.
+template <int TARGET, int LK, bool DIAG, bool TAPE = false>
 struct LaneChain {
     static_assert(TARGET == T_GAUSS_ISO || TARGET == T_BANANA, "lane kernel: isotropic Gaussian and banana");
     static_assert(LK >= LANE_LK_MIN && LK <= LANE_LK_MAX, "lane kernel: 7 .. 13 slots of four coordinates");
@@ -125,8 +127,14 @@ struct LaneChain {
     // (The eight words are locals of run_segment, not members: a select between members turns into a dynamic address into this object
     // and keeps all of it -- y included -- in scratch memory.)
     struct Prefetch { uint32_t a0, a1, a2, a3, b0, b1, b2, b3; uint64_t blk; };
+    const double *tp_e = nullptr, *tp_u = nullptr;       // tape source (TAPE instantiations): this chain's Exp(1) and U(0,1) tapes
+    int32_t tp_ie = 0, tp_iu = 0;
+    bool tp_over = false;
+    __device__ __forceinline__ double tape_uniform() { if (tp_iu < p.tape_n_uni) return tp_u[tp_iu++]; tp_over = true; return 0.5; }
+    __device__ __forceinline__ double tape_exponential() { if (tp_ie < p.tape_n_exp) return tp_e[tp_ie++]; tp_over = true; return 1.0; }
     __device__ __forceinline__ Prefetch rng_prefetch() const {
         Prefetch f;
+        if constexpr (TAPE) { f.a0 = f.a1 = f.a2 = f.a3 = f.b0 = f.b1 = f.b2 = f.b3 = 0u; f.blk = 0; return f; }
         f.blk = rng.n >> 1;
         uint32_t w[4];
         rng.block_at(f.blk, w);
@@ -137,6 +145,7 @@ struct LaneChain {
         return f;
     }
     __device__ __forceinline__ double draw_uniform(const Prefetch &f) {
+        if constexpr (TAPE) return tape_uniform();
         const uint32_t idx = (uint32_t)(rng.n - 2 * f.blk);                       // 0..3: the first three draws of a pass (a fourth would repeat idx 3: none is made)
         const bool hi2 = (idx & 2u) != 0u, odd = (idx & 1u) != 0u;
         const uint32_t lo_a = odd ? f.a2 : f.a0, hi_a = odd ? f.a3 : f.a1, lo_b = odd ? f.b2 : f.b0, hi_b = odd ? f.b3 : f.b1;
@@ -563,6 +572,12 @@ struct LaneChain {
         open_window(b, c, r == 0 ? 0 : k_begin);
         rng.init_lane(p.seed, (uint64_t)(p.chain0 + c));
         rng.restore(n0);
+        if constexpr (TAPE) {
+            const size_t gc = (size_t)(p.chain0 + (chain_ok ? c : 0));
+            tp_e = p.tape_exp + gc * (size_t)p.tape_n_exp;
+            tp_u = p.tape_uni + gc * (size_t)p.tape_n_uni;
+            tp_ie = 0; tp_iu = 0; tp_over = false;
+        }
         double ts = 0.0, tp = 0.0, E = 0.0, lb = 0.0;
         int32_t errored = 0, rejected = 0, hits = 0;
         double ev[5] = {0, 0, 0, 0, 0};
@@ -586,13 +601,15 @@ struct LaneChain {
             double tf = -0.0;
             int m = -1;
             LANE_MARK(8);
+            if constexpr (TAPE) { if (tp_over) done = true; }                     // tape exhausted: stop this chain (status[3] below)
             const Prefetch pf = rng_prefetch();
             LANE_MARK(0);
             if (!done && !propose) {
                 if (!brun) {
                     const double harg = (mode == ERR) ? horizon / 2 : ((mode == REUSE) ? hB : horizon);
                     hB = harg;
-                    const double e1 = -det_log(draw_uniform(pf));
+                    double e1;
+                    if constexpr (TAPE) e1 = tape_exponential(); else e1 = -det_log(draw_uniform(pf));
                     E = (mode == REUSE) ? E + e1 : e1;
                     if (mode == REUSE) bound_resume(tp); else bound_begin(tp);
                     brun = true;
@@ -683,16 +700,17 @@ struct LaneChain {
         publish(st + (size_t)(d + 1) * WAVE, t); publish(st + (size_t)(d + 2) * WAVE, horizon); publish(st + (size_t)(d + 3) * WAVE, ar);
         publish(st + (size_t)(d + 4) * WAVE, __longlong_as_double((long long)rng.n));
         if (guard) { atomicAdd(&p.status[1], guard); guard = 0; }
+        if constexpr (TAPE) { if (tp_over && chain_ok) atomicAdd(&p.status[3], 1); }
     }
 };
 
-template <int TARGET, int LK, bool DIAG>
+template <int TARGET, int LK, bool DIAG, bool TAPE = false>
 __global__ __launch_bounds__(256, LANE_WAVES) void lane_kernel(const GroupParams gp, const int32_t *flag) {
     if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;      // not unit speeds: the group kernel runs instead
     extern __shared__ double smem[];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     double *tile = smem + (size_t)wave * lane_lds_per_wave(LK);
-    LaneChain<TARGET, LK, DIAG> chain(gp.s, lane, tile);
+    LaneChain<TARGET, LK, DIAG, TAPE> chain(gp.s, lane, tile);
     const int nb = (int)gp.nb, n_units = nb * gp.nseg;
     bool lost = false;
     for (int pulled = 0; pulled <= n_units && !lost; ++pulled) {
@@ -727,12 +745,12 @@ inline void lane_schedule(int64_t nb, int64_t slots, int64_t n_sk, int force, in
     nseg = (int32_t)((events + seg_len - 1) / seg_len);
 }
 
-template <int TARGET, int LK, bool DIAG>
+template <int TARGET, int LK, bool DIAG, bool TAPE = false>
 inline hipError_t launch_lane(const GroupParams &gp_in, const int32_t *flag, int rounds, hipStream_t stream) {
     GroupParams gp = gp_in;
     constexpr int wpb = 4;
     const size_t lds = (size_t)wpb * lane_lds_per_wave(LK) * sizeof(double);
-    void (*kernel)(const GroupParams, const int32_t *) = lane_kernel<TARGET, LK, DIAG>;
+    void (*kernel)(const GroupParams, const int32_t *) = lane_kernel<TARGET, LK, DIAG, TAPE>;
     int per_cu = 0, dev = 0, cus = 0;
     hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -772,6 +790,7 @@ inline hipError_t launch_lane_range(int target, const GroupParams &gp, const int
 hipError_t launch_lane_zigzag(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);       // LK = 13
 hipError_t launch_lane_zigzag_a(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);     // LK = 7 .. 9
 hipError_t launch_lane_zigzag_b(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);     // LK = 10 .. 12
+hipError_t launch_lane_zigzag_tape(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);  // LK = 13, tape source
 hipError_t launch_lane_check(const double *vinit, int64_t n, int32_t *flag, hipStream_t stream);
 #endif
 

@@ -98,7 +98,8 @@ int pdmp_multi_shard_range(int64_t C, int32_t rank, int32_t n_ranks, int64_t *lo
 
 int pdmp_multi_destroy(pdmp_multi_handle m) {
     if (!m) return PDMP_OK;
-    for (int r = 0; r < m->n; ++r) {
+    const int nd = (int)m->dev.size();               // (not m->n: a create that failed while validating the device list has fewer)
+    for (int r = 0; r < nd; ++r) {
         (void)hipSetDevice(m->dev[r]);
         if (r < (int)m->comm.size() && m->comm[r] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(m->comm[r]);
         if (r < (int)m->h.size() && m->h[r]) (void)pdmp_destroy(m->h[r]);
@@ -120,13 +121,13 @@ int pdmp_multi_create(const pdmp_config_t *cfg, int32_t n_devices, const int32_t
         return failf(PDMP_ERR_ARGUMENT, "n_devices must be in 1..%s visible devices. Current value: %s", b, a);
     }
     pdmp_multi *m = new pdmp_multi();
-    m->n = n_devices;
     for (int r = 0; r < n_devices; ++r) {
         const int d = devices ? devices[r] : r;
         for (int q = 0; q < r; ++q) if (m->dev[q] == d) { pdmp_multi_destroy(m); return failf(PDMP_ERR_ARGUMENT, "duplicate device in the device list"); }
         if (d < 0 || d >= visible) { pdmp_multi_destroy(m); return failf(PDMP_ERR_ARGUMENT, "device ordinal out of range"); }
         m->dev.push_back(d);
     }
+    m->n = n_devices;                                // only now: the device list is complete and valid
     m->h.assign(n_devices, nullptr); m->stream.assign(n_devices, nullptr);
     m->dx.assign(n_devices, nullptr); m->dv.assign(n_devices, nullptr); m->init_cap.assign(n_devices, 0);
     for (int r = 0; r < n_devices; ++r) {
@@ -173,7 +174,10 @@ int pdmp_multi_sample_skeleton(pdmp_multi_handle m, int64_t C, int64_t n_sk, int
     if (exchange && m->comm.empty()) {
         if (int rc = load_rccl()) return rc;
         m->comm.assign(n, nullptr);
-        R_TRY(g_rccl.CommInitAll(m->comm.data(), n, m->dev.data()));
+        if (const int r_ = g_rccl.CommInitAll(m->comm.data(), n, m->dev.data())) {
+            m->comm.clear();                         // the next gathering call tries again instead of using null communicators
+            return failf(PDMP_ERR_RUNTIME, "ncclCommInitAll: %s", g_rccl.GetErrorString(r_));
+        }
     }
     // 1. every device: stage its shard of the inits, launch its kernel on its stream (asynchronous)
     for (int r = 0; r < n; ++r) {
@@ -204,20 +208,23 @@ int pdmp_multi_sample_skeleton(pdmp_multi_handle m, int64_t C, int64_t n_sk, int
         for (int a = 0; a < 3; ++a) {
             double *const *buf = (a == 0) ? X : (a == 1 ? V : t);
             R_TRY(g_rccl.GroupStart());
-            for (int r = 0; r < n; ++r) {
+            int gerr = 0;                            // an error inside the group: close the group before returning (never leave it open)
+            for (int r = 0; r < n && !gerr; ++r) {
                 if (equal) {
                     const size_t cnt = (size_t)(hi[0] - lo[0]) * per_chain[a];
-                    R_TRY(g_rccl.AllGather(buf[r] + (size_t)r * cnt, buf[r], cnt, kRcclFloat64, m->comm[r], m->stream[r]));   // in place
+                    gerr = g_rccl.AllGather(buf[r] + (size_t)r * cnt, buf[r], cnt, kRcclFloat64, m->comm[r], m->stream[r]);   // in place
                 } else {
-                    for (int root = 0; root < n; ++root) {
+                    for (int root = 0; root < n && !gerr; ++root) {
                         const size_t cnt = (size_t)(hi[root] - lo[root]) * per_chain[a];
                         if (cnt == 0) continue;
                         double *p = buf[r] + (size_t)lo[root] * per_chain[a];
-                        R_TRY(g_rccl.Broadcast(p, p, cnt, kRcclFloat64, root, m->comm[r], m->stream[r]));
+                        gerr = g_rccl.Broadcast(p, p, cnt, kRcclFloat64, root, m->comm[r], m->stream[r]);
                     }
                 }
             }
-            R_TRY(g_rccl.GroupEnd());
+            const int gend = g_rccl.GroupEnd();
+            if (gerr) return failf(PDMP_ERR_RUNTIME, "RCCL collective inside the group: %s", g_rccl.GetErrorString(gerr));
+            R_TRY(gend);
         }
     }
     // 3. wait, fold the timings, check every device's chain status

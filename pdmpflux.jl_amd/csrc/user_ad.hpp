@@ -35,7 +35,7 @@ template <class T> __device__ __forceinline__ Fwd<T> operator/(Fwd<T> a, double 
 template <class T> __device__ __forceinline__ Fwd<T> operator/(double a, Fwd<T> b) { const T q = a / b.v; return {q, (-(q * b.e)) / b.v}; }
 
 // ---- elementary functions on double, Dual and Fwd<T> (same rule at every level):
-//   sq(a) = a*a (Julia's x^2, literal_pow)   sqrt' = 1/(2 sqrt)   log' = 1/a   sin' = cos   cos' = -sin
+//   sq(a) = a*a (Julia's x^2, literal_pow)   sqrt' = 1/(2 sqrt)   log' = 1/a   exp' = exp   sin' = cos   cos' = -sin
 __device__ __forceinline__ double sq(double a) { return a * a; }
 __device__ __forceinline__ Dual sq(Dual a) { return a * a; }
 template <class T> __device__ __forceinline__ Fwd<T> sq(Fwd<T> a) { return a * a; }
@@ -47,6 +47,12 @@ template <class T> __device__ __forceinline__ Fwd<T> sqrt_(Fwd<T> a) { const T r
 __device__ __forceinline__ double log_(double a) { return (a > 0.0) ? det_log(a) : __builtin_nan(""); }   // normal positive arguments
 __device__ __forceinline__ Dual log_(Dual a) { return {log_(a.v), a.e / a.v}; }
 template <class T> __device__ __forceinline__ Fwd<T> log_(Fwd<T> a) { return {log_(a.v), a.e / a.v}; }
+
+// exp' = exp (round 3: the reference's own test potentials need it -- U_Mixture of test/test_integration.jl:67-75 is a log of a sum of
+// exponentials, the strict gradient of test/test_samplers.jl:142 is tanh(x/2) = (e^x - 1) / (e^x + 1))
+__device__ __forceinline__ double exp_(double a) { return det_exp(a); }
+__device__ __forceinline__ Dual exp_(Dual a) { const double r = det_exp(a.v); return {r, a.e * r}; }
+template <class T> __device__ __forceinline__ Fwd<T> exp_(Fwd<T> a) { const T r = exp_(a.v); return {r, a.e * r}; }
 
 __device__ __forceinline__ void sincos_(double a, double &s, double &c) { det_sincos(a, s, c); }
 __device__ __forceinline__ void sincos_(Dual a, Dual &s, Dual &c) {

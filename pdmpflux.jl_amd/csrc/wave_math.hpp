@@ -15,6 +15,7 @@ typedef unsigned int uint32_t;
 typedef signed long long int64_t;
 typedef unsigned long long uint64_t;
 typedef unsigned long size_t;
+typedef unsigned long uintptr_t;
 #endif
 
 namespace pdmp {

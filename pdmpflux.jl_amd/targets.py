@@ -90,7 +90,7 @@ class SourcePotential:
                 return s / 2.0;
             }''')
 
-    Available on every number type the engine differentiates with: ``+ - * /``, ``sq``, ``sqrt_``, ``log_``, ``sin_``, ``cos_``.
+    Available on every number type the engine differentiates with: ``+ - * /``, ``sq``, ``sqrt_``, ``log_``, ``exp_``, ``sin_``, ``cos_``.
     """
     source: str
     kind: int = SRC_POTENTIAL

@@ -23,11 +23,14 @@ def load(meta_path):
 
 def oracle_config(O, fx, arith):
     m = fx["meta"]
-    sid = {"ZigZag": O.ZIGZAG, "ZigZagAD": O.ZIGZAG, "BPS": O.BPS, "BPSAD": O.BPS, "Boomerang": O.BOOMERANG, "BoomerangAD": O.BOOMERANG}[m["ctor"]]
+    sid = {"ZigZag": O.ZIGZAG, "ZigZagAD": O.ZIGZAG, "BPS": O.BPS, "BPSAD": O.BPS, "Boomerang": O.BOOMERANG, "BoomerangAD": O.BOOMERANG,
+           "ForwardECMC": O.FECMC, "ForwardECMCAD": O.FECMC}[m["ctor"]]
     dflt = {"ZigZag": dict(tmax=2.0, refresh_rate=0.0, vectorized_bound=True, deriv_mode=O.DERIV_FINITE_DIFF),
             "ZigZagAD": dict(tmax=2.0, refresh_rate=0.0, vectorized_bound=True, deriv_mode=O.DERIV_FORWARD),
             "BPS": dict(tmax=1.0, refresh_rate=0.1, vectorized_bound=False, deriv_mode=O.DERIV_FORWARD),
-            "Boomerang": dict(tmax=1.0, refresh_rate=0.1, vectorized_bound=False, deriv_mode=O.DERIV_FINITE_DIFF)}[m["ctor"]]
+            "Boomerang": dict(tmax=1.0, refresh_rate=0.1, vectorized_bound=False, deriv_mode=O.DERIV_FINITE_DIFF),
+            "ForwardECMC": dict(tmax=2.0, refresh_rate=0.0, vectorized_bound=False, deriv_mode=O.DERIV_FORWARD),       # ForwardEventChainMonteCarlo.jl:290-292
+            "ForwardECMCAD": dict(tmax=2.0, refresh_rate=0.0, vectorized_bound=False, deriv_mode=O.DERIV_FORWARD)}[m["ctor"]]
     dflt.update({k: v for k, v in m["kwargs"].items()})
     tid = {"iso": O.T_GAUSS_ISO, "diag": O.T_GAUSS_DIAG, "banana": O.T_BANANA}[m["target"]]
     tp = np.asarray(m["target_params"], dtype=np.float64)

@@ -351,9 +351,11 @@ def test_empty_and_degenerate_ensembles(engine, oracle):
 
 @pytest.mark.parametrize("kind,dim,target,kw", [("ZigZagAD", 50, "iso", {}), ("BPS", 20, "banana", {"refresh_rate": 0.5}),
                                                 ("Boomerang", 9, "diag", {})])
-def test_tape_replay_bitwise(engine, oracle, kind, dim, target, kw):
+def test_tape_replay_bitwise(engine, oracle, monkeypatch, kind, dim, target, kw):
     """Tape source: both sides replay the same externally generated variates (numpy's generators here,
-    a Julia dump in the intended use) instead of Philox; trajectories must still agree bit for bit."""
+    a Julia dump in the intended use) instead of Philox; trajectories must still agree bit for bit.  Here on the wave-per-chain
+    kernel (PDMP_TAPE_WAVE=1; round 1's only replaying form); every other kernel form: tests/test_gpu_tape_replay.py."""
+    monkeypatch.setenv("PDMP_TAPE_WAVE", "1")
     rs = np.random.default_rng(5)
     C_ = 6
     tape = (rs.exponential(size=(C_, 3000)), rs.random(size=(C_, 3000)), rs.normal(size=(C_, 6000)))

@@ -22,11 +22,15 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-5          # north star: "event times/positions within 1e-5 rel fp64"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-# (id, ctor, dim, target, kwargs, chains for the moments check)
+# (id, ctor, dim, target, kwargs, chains for the moments check); ids ending in _lane run the one-lane-per-chain kernel (PDMP_LANE=1) --
+# the kernel that produces the headline numbers at full size -- so that it is held to the reference order DIRECTLY, not through
+# its bit-identity with the group kernel
 WORKLOADS = [
     ("config1_zigzagad_d10_iso", "ZigZagAD", 10, "iso", {}, 10_000),
     ("config2_zigzagad_d50_iso", "ZigZagAD", 50, "iso", {}, 10_000),
+    ("config2_zigzagad_d50_iso_lane", "ZigZagAD", 50, "iso", {}, 10_000),
     ("metric2_zigzagad_d50_banana", "ZigZagAD", 50, "banana", {}, 10_000),
+    ("metric2_zigzagad_d50_banana_lane", "ZigZagAD", 50, "banana", {}, 10_000),
     ("config3_bps_d50_banana", "BPS", 50, "banana", {}, 4_000),
     ("config5_boomerang_d100_fd", "Boomerang", 100, "iso", {"refresh_rate": 0.5}, 2_000),
     ("config5_boomerangad_d100", "BoomerangAD", 100, "iso", {"refresh_rate": 0.5}, 2_000),
@@ -64,11 +68,15 @@ def _record(name, stats):
 
 
 @pytest.mark.parametrize("name,kind,dim,target,kw,_cm", WORKLOADS, ids=[w[0] for w in WORKLOADS])
-def test_reference_order_within_tolerance(engine, oracle, name, kind, dim, target, kw, _cm):
+def test_reference_order_within_tolerance(engine, oracle, monkeypatch, name, kind, dim, target, kw, _cm):
+    lane = name.endswith("_lane")
+    if lane:
+        monkeypatch.setenv("PDMP_LANE", "1")
     s, cfg = make_pair(engine, oracle, kind, dim, target, arith=oracle.ARITH_REFERENCE, **kw)
-    C, n_sk = 64, 1000
+    C, n_sk = (200, 1000) if lane else (64, 1000)                 # lane kernel: four batches of 64 chains, the last one ragged
     x, v = make_init(kind, dim, C, seed=12, target=target)
     got = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=77, diagnostics=True)
+    assert (s.last_launch_form() == 4) == lane, "the workload did not run on the kernel form it names"
     ref = oracle.sample_skeleton(cfg, n_sk, x, v, 77, diagnostics=True)
     zigzag = kind.startswith("ZigZag")
     forks, kinds = [], []
@@ -84,7 +92,7 @@ def test_reference_order_within_tolerance(engine, oracle, name, kind, dim, targe
     stats = {"chains": C, "events_per_chain": n_sk, "fork_fraction": frac, "median_fork_index": (float(np.median(forks)) if forks else None),
              "forks_on_a_recorded_discrete_field": kinds.count("discrete"), "forks_on_an_unrecorded_decision": kinds.count("continuous"),
              "events_compared_within_1e-5": int(events_before), "forks_per_event": len(forks) / max(events_before, 1),
-             "lanes_per_chain": s.group_lanes()}
+             "lanes_per_chain": s.group_lanes(), "kernel_form": s.last_launch_form()}
     _record(name, stats)
     # how often may a 1-ulp difference flip a decision?  a comparison u < ar (or cum_sum >= E) with operands that differ by ~1e-15
     # relative flips with probability ~1e-15 per decision; exact ties are the exception: tp == horizon-type comparisons of values that
@@ -101,16 +109,20 @@ def test_reference_order_within_tolerance(engine, oracle, name, kind, dim, targe
 
 
 @pytest.mark.parametrize("name,kind,dim,target,kw,C", WORKLOADS, ids=[w[0] for w in WORKLOADS])
-def test_engine_and_reference_order_moments_agree(engine, oracle, name, kind, dim, target, kw, C):
+def test_engine_and_reference_order_moments_agree(engine, oracle, monkeypatch, name, kind, dim, target, kw, C):
     """Pooled moments of the samples of an engine-order run and of a reference-order run (different streams: seeds differ, so the
     two are independent) agree within Monte Carlo error: |mean difference| < 5 standard errors per coordinate (Bonferroni-safe)."""
     import torch
     from pdmpflux.jl_amd import ensemble
+    if name.endswith("_lane"):
+        monkeypatch.setenv("PDMP_LANE", "1")
     s, cfg = make_pair(engine, oracle, kind, dim, target, arith=oracle.ARITH_REFERENCE, **kw)
     n_sk, N = 150, 60
     x, v = make_init(kind, dim, C, seed=5, target=target)
     dev = torch.device("cuda:0")
     sk = ensemble.sample_skeleton_device(s, n_sk, torch.from_numpy(x).to(dev), torch.from_numpy(v).to(dev), seed=1001)
+    torch.cuda.synchronize()
+    assert (s.last_launch_form() == 4) == name.endswith("_lane")
     a = ensemble.sample_from_skeleton_device(s, N, sk["X"], sk["V"], sk["t"]).cpu().numpy()
     r = oracle.sample_skeleton(cfg, n_sk, x, v, 2002, diagnostics=False)
     b = oracle.sample_from_skeleton(cfg, N, r["X"], r["V"], r["t"])

@@ -34,8 +34,15 @@ def test_oracle_replays_julia_fixture(oracle, meta):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["default", "lane", "lds", "wave"])
 @pytest.mark.parametrize("meta", CASES, ids=[os.path.basename(os.path.dirname(p)) for p in CASES])
-def test_engine_replays_julia_fixture(engine, meta):
+def test_engine_replays_julia_fixture(engine, monkeypatch, meta, form):
+    """The replay runs on the kernel form the same launch uses with the Philox stream (`default`: register-form group kernel where
+    one exists), and on every other form that can serve the case: one lane per chain (Zig-Zag, d = 49..52), LDS-form group
+    kernel, wave per chain."""
+    env = {"lane": ("PDMP_LANE", "1"), "lds": ("PDMP_REG", "0"), "wave": ("PDMP_TAPE_WAVE", "1")}.get(form)
+    if env:
+        monkeypatch.setenv(*env)
     fx = load(meta)
     m = fx["meta"]
     P = engine
@@ -43,6 +50,13 @@ def test_engine_replays_julia_fixture(engine, meta):
     tp = np.asarray(m["target_params"], dtype=np.float64)
     target = {"iso": P.GaussianIso, "banana": P.Banana}.get(m["target"], lambda: P.GaussianDiag(tp[:d], tp[d:]))()
     s = getattr(P, m["ctor"])(d, target, **m["kwargs"])
+    if form == "lane" and not (m["ctor"] == "ZigZagAD" and 49 <= d <= 52 and m["target"] in ("iso", "banana")):
+        pytest.skip("the lane kernel's replay serves Zig-Zag at d = 49..52 on the isotropic Gaussian / banana")
+    if form == "wave" and m["ctor"].startswith("ForwardECMC"):
+        pytest.skip("the wave-per-chain kernel serves Zig-Zag / BPS / Boomerang")
     s.set_tape(*fx["tape"])
     got = P.sample_skeleton_ensemble(s, int(m["n_sk"]), fx["xinit"][None], fx["vinit"][None], seed=0, diagnostics=True)
-    compare(got, fx, "engine (tape replay, wave-per-chain kernel)")
+    kernel = {1: "wave per chain", 2: "group kernel, LDS form", 3: "group kernel, register form", 4: "one lane per chain"}[s.last_launch_form()]
+    if form == "lane":
+        assert s.last_launch_form() == 4
+    compare(got, fx, f"engine (tape replay, {kernel})")
