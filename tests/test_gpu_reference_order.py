@@ -117,7 +117,7 @@ def test_engine_and_reference_order_moments_agree(engine, oracle, monkeypatch, n
     if name.endswith("_lane"):
         monkeypatch.setenv("PDMP_LANE", "1")
     s, cfg = make_pair(engine, oracle, kind, dim, target, arith=oracle.ARITH_REFERENCE, **kw)
-    n_sk, N = 150, 60
+    n_sk, N = 152, 60
     x, v = make_init(kind, dim, C, seed=5, target=target)
     dev = torch.device("cuda:0")
     sk = ensemble.sample_skeleton_device(s, n_sk, torch.from_numpy(x).to(dev), torch.from_numpy(v).to(dev), seed=1001)
