@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PDMP_ABI_VERSION 7   /* 7: + pdmp_last_launch_form; 6: is_active / ragged lengths in sample_from_skeleton*, moments and close_at; + the (N, dt) method, pdmp_compact_*, pdmp_multi_*; 5: + PDMP_STICKY, pdmp_diag_t.is_active; 2: + pdmp_create_from_source, PDMP_T_USER; 3: + PDMP_FECMC and its keywords at the end of pdmp_config_t; 4: + PDMP_SUZZ, PDMP_RHMC and its keywords */
+#define PDMP_ABI_VERSION 8   /* 8: + the time horizon as a kernel feature (pdmp_sample_skeleton_until_device, pdmp_close_chunk_device, pdmp_until_advance_device, pdmp_compact_chunk_device); tape replay on every kernel form; 7: + pdmp_last_launch_form; 6: is_active / ragged lengths in sample_from_skeleton*, moments and close_at; + the (N, dt) method, pdmp_compact_*, pdmp_multi_*; 5: + PDMP_STICKY, pdmp_diag_t.is_active; 2: + pdmp_create_from_source, PDMP_T_USER; 3: + PDMP_FECMC and its keywords at the end of pdmp_config_t; 4: + PDMP_SUZZ, PDMP_RHMC and its keywords */
 
 enum { PDMP_OK = 0, PDMP_ERR_ARGUMENT = -1, PDMP_ERR_DIMENSION = -2, PDMP_ERR_RUNTIME = -3,
        PDMP_ERR_ITERCAP = -4, PDMP_ERR_UNSUPPORTED = -5 };
@@ -115,7 +115,7 @@ int pdmp_create(const pdmp_config_t *cfg, pdmp_handle *out);
  * run time (hiprtc) into the same kernel as the built-in potentials:
  *   PDMP_SRC_POTENTIAL:  template <class X> __device__ auto U(const X &x, int d)              x[j] = coordinate j (0-based)
  *   PDMP_SRC_GRADIENT:   template <class X> __device__ auto grad_i(int i, const X &x, int d)   coordinate i of grad-U
- * written with + - * /, sq (= x^2), sqrt_, log_, sin_, cos_ so that it runs on doubles, on forward-mode numbers in time
+ * written with + - * /, sq (= x^2), sqrt_, log_, exp_, sin_, cos_ so that it runs on doubles, on forward-mode numbers in time
  * (the slope of the rate along the flow, UpperBound.jl:102,210) and -- for a potential -- on the nested forward-mode
  * numbers that yield grad-U (one partial per pass; pdmpflux.jl_amd/csrc/user_ad.hpp states every rule).  cfg->target_id
  * and target_params are ignored.  A source that does not compile returns PDMP_ERR_ARGUMENT with the compiler's log in
@@ -146,8 +146,12 @@ int pdmp_last_launch_form(pdmp_handle h);
  * MersenneTwister, AbstractPDMP.jl:100) by pre-recorded variates, one tape per kind in consumption order --
  * randexp (SamplingLoopInplace.jl:70,136,190), rand (:154 and the samplers' jumps), randn (BouncyParticleSamplers.jl:67)
  * -- so that a run of ANY generator (e.g. a dump from Julia) can be replayed draw for draw.  HOST pointers, C x n_*
- * doubles, chain-major, indexed by the global chain id; copied.  While a tape is set, seeds are ignored and the
- * wave-per-chain kernel runs ("WAVE64" order; pdmp_get_group_lanes() returns 0).  An exhausted tape fails the call. */
+ * doubles, chain-major, indexed by the global chain id; copied.  While a tape is set, seeds are ignored.  The replay runs on the
+ * kernel form the same launch uses with the Philox stream -- LDS-form / register-form group kernel, one lane per chain (dim 49..52),
+ * every sampler on the built-in separable / banana targets, as separate instantiations of the same code with the tapes as random
+ * source (csrc/inst_tape_*.hip), in ONE segment per chain; pdmp_get_group_lanes() keeps returning the layout, i.e. the order of
+ * the sums.  Grid sizes other than 10 / 0 (Zig-Zag, BPS, Boomerang): the wave-per-chain kernel ("WAVE64" order,
+ * pdmp_get_group_lanes() = 0).  An exhausted tape fails the call (ForwardECMC's randn(key, 2, dim) is logged column-major). */
 int pdmp_set_tape(pdmp_handle h, int64_t C, int64_t n_exp, int64_t n_uni, int64_t n_nrm,
                   const double *exp_tape, const double *uni_tape, const double *nrm_tape);
 int pdmp_clear_tape(pdmp_handle h);
@@ -221,6 +225,47 @@ int pdmp_sample_moments_device(pdmp_handle h, int64_t C, int64_t n_sk, const dou
  * (_grow_history doubles, Composites.jl:172-191). */
 int pdmp_close_at_time_device(pdmp_handle h, int64_t C, int64_t n_sk, double *X, double *V, double *t, const pdmp_diag_t *diag,
                               double T, int64_t *count, void *stream);
+
+/* ---- sample_skeleton(sampler, T::Float64, xinit, vinit; seed, init_capacity) (src/sample.jl:323-439) as a kernel feature.
+ * The reference grows ONE chain's history in place (`while state.t < T`, :372; _grow_history doubles the capacity, :375-377,
+ * Composites.jl:172-191).  For an ensemble the history is produced in CHUNKS: a chunk is one launch over the chains that have not
+ * reached T yet, `capacity` columns each; a chain stops inside the kernel after recording its first event with t >= T, the others
+ * use the whole capacity and RESUME in the next chunk from their hand-off state (x, v, t, horizon, ar, stream position -- the last
+ * recorded event), which the next chunk records again as its column 0.  Finished chains cost nothing; memory is the sum of the
+ * chunks, O(sum of the history lengths), never chains x longest history.
+ *
+ * pdmp_sample_skeleton_until_device: one chunk.  DEVICE pointers, asynchronous on `stream`.
+ *   resume = 0: the first chunk, C chains from xinit / vinit (d x C), streams (seed, chain_id_offset + c); chain_map must be NULL.
+ *   resume = 1: C = the number of chains still running; chain_map[c] (int64, DEVICE) = the index of launch chain c in the FIRST
+ *     chunk's ensemble -- its state slot and its random stream; xinit / vinit are ignored (may be NULL).  seed and
+ *     chain_id_offset must be the first chunk's.  X, V, t (and diag) are this chunk's own buffers, d x capacity x C etc.
+ *   n_recorded[c] (int64, DEVICE) = columns chain c recorded in this chunk (capacity, or fewer when it reached T).
+ *   Runs on the group / lane kernels: every sampler except StickyZigZag, built-in and source-given targets except the
+ *   dense-precision one, grid_size = 10 or 0, no tape; PDMP_ERR_UNSUPPORTED otherwise (use the fixed-count path + pdmp_close_at_time_device
+ *   with a doubled capacity).  A chunk of a handle whose first chunk ran one lane per chain needs 64-byte aligned X and
+ *   capacity * dim a multiple of 8 (any capacity that is a multiple of 8).
+ * pdmp_close_chunk_device: pdmp_close_at_time_device restricted to the recorded columns of a chunk (stride = capacity):
+ *   count[c] >= 0: the chain's history ends in this chunk with count[c] columns, the last one at exactly t = T (the closing
+ *   column written in place over the overshooting event, :385-420; none when an event sits at exactly T);
+ *   count[c] < 0: not finished, -count[c]-1 = n_recorded[c] columns, all of them events.
+ * pdmp_until_advance_device: the bookkeeping between chunks, on the device (one block; ballot + prefix sums):
+ *   for launch chain c with original index o = map_in ? map_in[c] : c:  start[c] = total[o];  total[o] += |columns of c| - skip
+ *   (skip = 0 for the first chunk, 1 for a resumed one: its column 0 repeats the previous chunk's last event); the chains with
+ *   count[c] < 0 are appended, in order, to map_out (their original indices) and *n_active (DEVICE int64) receives their number.
+ *   total is C_first int64, zeroed by the caller before the first chunk; after the last chunk it holds every chain's history
+ *   length, and pdmp_compact_offsets_device(total) the dense offsets.
+ * pdmp_compact_chunk_device: columns [skip, |count[c]|) of every chain of one chunk into dense buffers (_trim_history for an
+ *   ensemble): column k of launch chain c goes to dense column offsets[o] + start[c] + (k - skip). */
+int pdmp_sample_skeleton_until_device(pdmp_handle h, int64_t C, int64_t capacity, int64_t chain_id_offset, const double *xinit,
+                                      const double *vinit, uint64_t seed, double T, int32_t resume, const int64_t *chain_map,
+                                      double *X, double *V, double *t, const pdmp_diag_t *diag, int64_t *n_recorded, void *stream);
+int pdmp_close_chunk_device(pdmp_handle h, int64_t C, int64_t capacity, double *X, double *V, double *t, const pdmp_diag_t *diag,
+                            double T, const int64_t *n_recorded, int64_t *count, void *stream);
+int pdmp_until_advance_device(pdmp_handle h, int64_t C, const int64_t *count, int64_t skip, const int64_t *map_in, int64_t *total,
+                              int64_t *start, int64_t *map_out, int64_t *n_active, void *stream);
+int pdmp_compact_chunk_device(pdmp_handle h, int64_t C, int64_t capacity, const int64_t *count, int64_t skip, const int64_t *chain_map,
+                              const int64_t *start, const int64_t *offsets, const double *X, const double *V, const double *t,
+                              const pdmp_diag_t *diag, double *X_out, double *V_out, double *t_out, const pdmp_diag_t *diag_out, void *stream);
 
 /* _trim_history (src/Composites.jl:198-214) for an ensemble: the ragged histories packed back to back into dense buffers.
  * pdmp_compact_offsets_device: offsets[c] = sum_{c' < c} max(count[c'], 0), offsets[C] = total columns (C+1 int64, DEVICE;

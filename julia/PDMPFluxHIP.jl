@@ -1,5 +1,5 @@
 # PDMPFluxHIP.jl -- the reference-side binding a PDMPFlux.jl maintainer would add (see INTEGRATION.md).
-# NOT executed anywhere in this pipeline (no Julia toolchain in the image); the same ABI (include/pdmp_hip.h, version 6) is
+# NOT executed anywhere in this pipeline (no Julia toolchain in the image); the same ABI (include/pdmp_hip.h, version 8) is
 # exercised through ctypes by tests/ and bench.py.  Struct layouts mirror the header field for field.
 #
 # Every constructor of the reference has a method here that takes a TARGET DESCRIPTOR in place of the closure `∇U` / `U`
@@ -19,7 +19,7 @@ using PDMPFlux: AbstractPDMP, PDMPHistory
 import PDMPFlux: sample, sample_skeleton, sample_from_skeleton
 
 const LIB = get(ENV, "PDMPHIP_LIB", "libpdmphip.so")
-const ABI_VERSION = 7
+const ABI_VERSION = 8
 
 # ---------------------------------------------------------------------------------------------- C structs (include/pdmp_hip.h)
 struct Config   # pdmp_config_t

@@ -62,6 +62,7 @@ SYMBOLS = (
     "pdmp_sample_from_skeleton_device", "pdmp_sample_from_skeleton_dt", "pdmp_sample_from_skeleton_dt_device",
     "pdmp_sample_from_skeleton_prefix", "pdmp_sample_from_skeleton_prefix_device", "pdmp_sample_moments_device",
     "pdmp_close_at_time_device", "pdmp_compact_offsets_device", "pdmp_compact_history_device",
+    "pdmp_sample_skeleton_until_device", "pdmp_close_chunk_device", "pdmp_until_advance_device", "pdmp_compact_chunk_device",
     "pdmp_multi_shard_range", "pdmp_multi_create", "pdmp_multi_destroy", "pdmp_multi_sample_skeleton", "pdmp_multi_get_timing",
     "pdmp_check_status", "pdmp_get_timing", "pdmp_reset_timing",
     "pdmp_debug_rng", "pdmp_dense_batched_last_phases", "pdmp_dense_batched_last_columns", "pdmp_dense_batched_last_mode",
@@ -116,6 +117,10 @@ def lib():
     L.pdmp_close_at_time_device.argtypes = [vp, i64, i64, vp, vp, vp, C.POINTER(Diag), f64, vp, vp]
     L.pdmp_compact_offsets_device.argtypes = [vp, i64, vp, vp, vp]
     L.pdmp_compact_history_device.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, C.POINTER(Diag), vp, vp, vp, C.POINTER(Diag), vp]
+    L.pdmp_sample_skeleton_until_device.argtypes = [vp, i64, i64, i64, vp, vp, u64, f64, i32, vp, vp, vp, vp, C.POINTER(Diag), vp, vp]
+    L.pdmp_close_chunk_device.argtypes = [vp, i64, i64, vp, vp, vp, C.POINTER(Diag), f64, vp, vp, vp]
+    L.pdmp_until_advance_device.argtypes = [vp, i64, vp, i64, vp, vp, vp, vp, vp, vp]
+    L.pdmp_compact_chunk_device.argtypes = [vp, i64, i64, vp, i64, vp, vp, vp, vp, vp, vp, C.POINTER(Diag), vp, vp, vp, C.POINTER(Diag), vp]
     L.pdmp_multi_shard_range.argtypes = [i64, i32, i32, C.POINTER(i64), C.POINTER(i64)]
     L.pdmp_multi_create.argtypes = [C.POINTER(Config), i32, C.POINTER(i32), C.POINTER(vp)]
     L.pdmp_multi_destroy.argtypes = [vp]
@@ -128,7 +133,7 @@ def lib():
     L.pdmp_dense_batched_last_phases.restype = C.c_longlong
     L.pdmp_dense_batched_last_columns.restype = C.c_longlong
     L.pdmp_dense_batched_last_mode.restype = C.c_int
-    if L.pdmp_abi_version() != 7:
+    if L.pdmp_abi_version() != 8:
         raise EngineError(ERR_RUNTIME, "ABI version mismatch")
     _lib = L
     return L

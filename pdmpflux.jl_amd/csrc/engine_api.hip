@@ -85,6 +85,8 @@ struct pdmp_engine {
     double *d_tape[3] = {nullptr, nullptr, nullptr};   // tape source: exp, uni, nrm (chain-major)
     int64_t tape_n[3] = {0, 0, 0}, tape_chains = 0;
     hipStream_t last_stream = nullptr;
+    bool until_valid = false;         // d_state holds the hand-off states of a first chunk of `until_chains` chains (time-horizon variant)
+    int64_t until_chains = 0;
     bool launched = false;            // a launch has used the per-handle scheduler / hand-off / status buffers
     hipEvent_t order_ev = nullptr;    // orders launches of this handle that arrive on different streams (they share those buffers)
     std::vector<EventPair> pending;   // launches not yet folded into `timing`
@@ -328,14 +330,17 @@ __global__ __launch_bounds__(256) void from_skeleton_flat_kernel(int d, int64_t 
 // overwrites the overshooting event in place; count[c] = -(events) - 1 when the chain has not passed T yet (capacity too
 // small: the caller reruns with a larger n_sk, as _grow_history does, Composites.jl:172-191).  One wave per chain.
 template <bool BOOMERANG>
-__global__ __launch_bounds__(256) void close_at_kernel(int d, int64_t C, int64_t n_sk, double *X, double *V, double *t, double T,
+__global__ __launch_bounds__(256) void close_at_kernel(int d, int64_t C, int64_t n_sk_cap, double *X, double *V, double *t, double T,
                                                        int64_t *count, int mode = 0, int target = 0, double rhmc_h = 0.0,
-                                                       const double *tparams = nullptr, pdmp_diag_t dg = {}) {
+                                                       const double *tparams = nullptr, pdmp_diag_t dg = {}, const int64_t *valid = nullptr) {
     const int lane = lane_id();
     const int64_t c = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (c >= C) return;
-    double *tc = t + (size_t)c * n_sk;
-    int64_t lo = 0, hi = n_sk - 1;                                    // last index with t[i] <= T (t[0] = 0 <= T)
+    double *tc = t + (size_t)c * n_sk_cap;
+    // valid: the columns chain c recorded (a launch that stops chains at T leaves the rest of the capacity unwritten); the column
+    // stride stays the capacity
+    const int64_t n_sk = valid ? valid[c] : n_sk_cap;
+    int64_t lo = 0, hi = n_sk - 1;                                    // last index with t[i] <= T (t[0] <= T: a chunk starts before T)
     while (lo < hi) {
         const int64_t mid = (lo + hi + 1) >> 1;
         if (tc[mid] <= T) lo = mid; else hi = mid - 1;
@@ -346,11 +351,11 @@ __global__ __launch_bounds__(256) void close_at_kernel(int d, int64_t C, int64_t
     }
     if (T == 0.0 || tc[lo] == T) { if (lane == 0) count[c] = (T == 0.0) ? 1 : k; return; }   // `while state.t < T` ends on t == T: no closing column
     const double tau = T - tc[lo];
-    const double *x0 = X + ((size_t)c * n_sk + (size_t)lo) * d, *v0 = V + ((size_t)c * n_sk + (size_t)lo) * d;
-    double *x1 = X + ((size_t)c * n_sk + (size_t)k) * d, *v1 = V + ((size_t)c * n_sk + (size_t)k) * d;
+    const double *x0 = X + ((size_t)c * n_sk_cap + (size_t)lo) * d, *v0 = V + ((size_t)c * n_sk_cap + (size_t)lo) * d;
+    double *x1 = X + ((size_t)c * n_sk_cap + (size_t)k) * d, *v1 = V + ((size_t)c * n_sk_cap + (size_t)k) * d;
     // StickyPDMP: v_used = active_prev ? v_prev : 0 (sample.jl:386-390), is_active of the closing column = active_prev (:399-401)
-    const uint8_t *a0 = (mode == 3 && dg.is_active) ? dg.is_active + ((size_t)c * n_sk + (size_t)lo) * d : nullptr;
-    uint8_t *a1 = a0 ? dg.is_active + ((size_t)c * n_sk + (size_t)k) * d : nullptr;
+    const uint8_t *a0 = (mode == 3 && dg.is_active) ? dg.is_active + ((size_t)c * n_sk_cap + (size_t)lo) * d : nullptr;
+    uint8_t *a1 = a0 ? dg.is_active + ((size_t)c * n_sk_cap + (size_t)k) * d : nullptr;
     double sn = 0.0, cs = 1.0;
     if (BOOMERANG) det_sincos(tau, sn, cs);
     if (mode == 2) {                                                                      // RHMC: velocity-Verlet to T
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(256) void close_at_kernel(int d, int64_t C, int64_t
     if (lane == 0) {
         tc[k] = T; count[c] = k + 1;
         // statistics of a non-event point are zeros (:402-408); horizon stays the overshooting state's (record! of the same state object)
-        const size_t e = (size_t)c * n_sk + (size_t)k;
+        const size_t e = (size_t)c * n_sk_cap + (size_t)k;
         if (dg.ar) dg.ar[e] = 0.0;
         if (dg.errored_bound) dg.errored_bound[e] = 0;
         if (dg.rejected) dg.rejected[e] = 0;
@@ -425,6 +430,81 @@ __global__ __launch_bounds__(256) void compact_rows_kernel(int d, int64_t C, int
     if (k0 >= n) return;
     const int64_t nk = (n - k0) < WAVE ? (n - k0) : WAVE;
     const size_t src = (size_t)c * n_sk + (size_t)k0, dst = (size_t)offsets[c] + (size_t)k0;
+    const size_t words = (size_t)nk * d;
+    for (size_t q = lane; q < words; q += WAVE) { Xo[dst * d + q] = X[src * d + q]; Vo[dst * d + q] = V[src * d + q]; }
+    if (lane < nk) {
+        to[dst + lane] = t[src + lane];
+        if (dg.horizon && og.horizon) og.horizon[dst + lane] = dg.horizon[src + lane];
+        if (dg.ar && og.ar) og.ar[dst + lane] = dg.ar[src + lane];
+        if (dg.errored_bound && og.errored_bound) og.errored_bound[dst + lane] = dg.errored_bound[src + lane];
+        if (dg.rejected && og.rejected) og.rejected[dst + lane] = dg.rejected[src + lane];
+        if (dg.hitting_horizon && og.hitting_horizon) og.hitting_horizon[dst + lane] = dg.hitting_horizon[src + lane];
+    }
+    if (dg.error_value_ar && og.error_value_ar)
+        for (size_t q = lane; q < (size_t)nk * 5; q += WAVE) og.error_value_ar[dst * 5 + q] = dg.error_value_ar[src * 5 + q];
+    if (dg.is_active && og.is_active)
+        for (size_t q = lane; q < words; q += WAVE) og.is_active[dst * d + q] = dg.is_active[src * d + q];
+}
+
+// ---- Time-horizon variant as a kernel feature (pdmp_sample_skeleton_until_device): bookkeeping between chunks.
+// After a chunk has been sampled and closed, for every launch chain c (original chain o = map_in ? map_in[c] : c):
+//   kept = the columns of this chunk that belong to the chain's history = |count[c]| columns (count >= 0: finished, the closing
+//          column included; count < 0: -count - 1 columns, all events) minus `skip` (1 for a resumed chunk: its column 0 repeats
+//          the previous chunk's last event);
+//   start[c] = total[o] (the chain's history length so far = where this chunk's columns go), total[o] += kept;
+//   the chains that have not reached T are appended to map_out in launch order -- the north star's "wavefront ballot / prefix-sum to
+//   compact the branchy stream": per wave a ballot + popcount rank, wave totals through LDS, a running carry across tiles of 1024.
+__global__ __launch_bounds__(1024) void until_advance_kernel(int64_t C, const int64_t *count, int64_t skip, const int64_t *map_in,
+                                                             int64_t *total, int64_t *start, int64_t *map_out, int64_t *n_active) {
+    __shared__ int wsum[16];
+    __shared__ int64_t carry_s;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < C; base += 1024) {
+        const int64_t c = base + threadIdx.x;
+        bool act = false;
+        int64_t o = 0;
+        if (c < C) {
+            const int64_t cnt = count[c];
+            o = map_in ? map_in[c] : c;
+            const int64_t cols = cnt >= 0 ? cnt : -cnt - 1;
+            const int64_t kept = cols > skip ? cols - skip : 0;
+            const int64_t before = total[o];
+            start[c] = before;
+            total[o] = before + kept;
+            act = cnt < 0;
+        }
+        const unsigned long long ball = __ballot(act);
+        const int rank = __builtin_popcountll(ball & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __builtin_popcountll(ball);
+        __syncthreads();
+        int64_t before = carry_s;
+        int tile_total = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wave) before += wsum[w]; tile_total += wsum[w]; }
+        if (act) map_out[before + rank] = o;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s += tile_total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_active = carry_s;
+}
+// One chunk's columns [skip, |count[c]|) of every launch chain into the dense buffers: column k of launch chain c (original chain o)
+// goes to dense column offsets[o] + start[c] + (k - skip).  One wave per (chain, 64-column tile), coalesced on both sides.
+__global__ __launch_bounds__(256) void compact_chunk_kernel(int d, int64_t C, int64_t cap, const int64_t *count, int64_t skip,
+                                                            const int64_t *map, const int64_t *start, const int64_t *offsets,
+                                                            const double *X, const double *V, const double *t, pdmp_diag_t dg,
+                                                            double *Xo, double *Vo, double *to, pdmp_diag_t og) {
+    const int lane = lane_id();
+    const int64_t tiles = (cap + WAVE - 1) / WAVE;
+    const int64_t w = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (w >= C * tiles) return;
+    const int64_t c = w / tiles, k0 = skip + (w % tiles) * WAVE;
+    const int64_t cnt = count[c], n = cnt >= 0 ? cnt : -cnt - 1;
+    if (k0 >= n) return;
+    const int64_t nk = (n - k0) < WAVE ? (n - k0) : WAVE;
+    const int64_t o = map ? map[c] : c;
+    const size_t src = (size_t)c * cap + (size_t)k0, dst = (size_t)(offsets[o] + start[c] + (k0 - skip));
     const size_t words = (size_t)nk * d;
     for (size_t q = lane; q < words; q += WAVE) { Xo[dst * d + q] = X[src * d + q]; Vo[dst * d + q] = V[src * d + q]; }
     if (lane < nk) {
@@ -846,14 +926,18 @@ int pdmp_destroy(pdmp_handle h) {
     return PDMP_OK;
 }
 
-int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t chain_id_offset,
-                                const double *xinit, const double *vinit, uint64_t seed, double *X, double *V,
-                                double *t, const pdmp_diag_t *diag, void *stream) {
+// the time-horizon variant's launch arguments (pdmp_sample_skeleton_until_device); null: the fixed-count path
+struct UntilArgs { double T; int resume; const int64_t *chain_map; int64_t *count; int form; };
+
+static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_t chain_id_offset,
+                                  const double *xinit, const double *vinit, uint64_t seed, double *X, double *V,
+                                  double *t, const pdmp_diag_t *diag, void *stream, const UntilArgs *until) {
     if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
     if (n_sk <= 0) return fail(PDMP_ERR_ARGUMENT, "n_sk must be positive. Current value: %lld", (long long)n_sk);   // sample.jl:262-264
     if (C < 0) return fail(PDMP_ERR_ARGUMENT, "number of chains must be non-negative");
     if (C == 0) return PDMP_OK;
-    if (!xinit || !vinit || !X || !V || !t) return fail(PDMP_ERR_ARGUMENT, "null buffer");
+    const bool resuming = until && until->resume;
+    if ((!resuming && (!xinit || !vinit)) || !X || !V || !t) return fail(PDMP_ERR_ARGUMENT, "null buffer");
     if (n_sk > 0x7fffffffLL || (C + 3) / 4 > 0x7fffffffLL || C * (n_sk / 16 + 1) > 0x7fffffffLL) return fail(PDMP_ERR_UNSUPPORTED, "too many chains x events for one launch");
     HIP_TRY(hipSetDevice(h->device));
     SkelParams p;
@@ -874,6 +958,8 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
         p.IA = diag->is_active;
     }
     p.status = h->d_status;
+    p.t_stop = __builtin_huge_val();
+    if (until) { p.t_stop = until->T; p.resume = until->resume; p.chain_map = until->chain_map; p.count = until->count; }
     const bool taped = h->tape_chains > 0;
     if (taped) {
         if (chain_id_offset < 0 || chain_id_offset + C > h->tape_chains)
@@ -911,6 +997,9 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
         if (const char *e = getenv("PDMP_CELL_BUDGET")) { const int b = atoi(e); if (b >= 1 && b <= GNG - 1) gp.cell_budget = b; }   // tuning / tests
         const int64_t nb = (C + WAVE / gp.G - 1) / (WAVE / gp.G);
         const size_t need_sched = (size_t)nb + 1, need_state = (size_t)((C + WAVE - 1) / WAVE * WAVE) * (size_t)(2 * c.dim + 4);   // (whole batches of 64: lane_kernel.hpp)
+        if (resuming && (!h->until_valid || !h->d_state || need_state > h->state_cap || C > h->until_chains))
+            return fail(PDMP_ERR_ARGUMENT, "resume: this handle holds no hand-off state of a first chunk of at least %lld chains", (long long)C);
+        if (!resuming) { h->until_valid = until != nullptr; h->until_chains = C; }
         if (need_sched > h->sched_cap) {
             if (h->d_sched) { HIP_TRY(hipStreamSynchronize(h->last_stream)); HIP_TRY(hipFree(h->d_sched)); h->d_sched = nullptr; h->sched_cap = 0; }
             HIP_TRY(hipMalloc(&h->d_sched, need_sched * sizeof(int32_t)));
@@ -933,6 +1022,11 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
     // Dense-precision Zig-Zag on many chains: grad-U of all chains as one fp64 GEMM per phase (dense_batched.hip);
     // small ensembles and PDMP_DENSE_MODE=matvec keep the bit-exact per-chain mat-vec kernel.
     const char *dense_mode = getenv("PDMP_DENSE_MODE");       // "incr" | "gemm" | "matvec" (default: incr for >= 64 chains and d <= 1024, gemm beyond)
+    if (until && (taped || h->group_lanes <= 0 || c.target_id == PDMP_T_GAUSS_DENSE || c.sampler == PDMP_STICKY)) {
+        h->pool.push_back(ev);
+        return fail(PDMP_ERR_UNSUPPORTED, "the in-kernel time horizon runs on the group / lane kernels (grid_size = 10 or 0; not StickyZigZag, whose hand-off "
+                                          "state does not carry is_active; not the dense-precision target; no tape): rerun the fixed-count path with a doubled capacity instead");
+    }
     const bool batched = c.target_id == PDMP_T_GAUSS_DENSE && c.sampler == PDMP_ZIGZAG && c.vectorized_bound && c.grid_size == GNG &&
                          c.deriv_mode == PDMP_DERIV_FORWARD && !taped && 2 * C < 0x7fffffffLL &&
                          (dense_mode ? (strcmp(dense_mode, "gemm") == 0 || strcmp(dense_mode, "incr") == 0) : C >= 64);
@@ -976,10 +1070,17 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
             const bool lane_ok = c.sampler == PDMP_ZIGZAG && !fd && (c.target_id == PDMP_T_GAUSS_ISO || c.target_id == PDMP_T_BANANA) &&
                                  c.dim >= 25 && c.dim <= 52 && gp.G == 4 && (int64_t)WAVE * n_sk * c.dim * 8 < 0x7fffffffLL &&   // (a batch's window of X: 31-bit byte offsets)
                                  ((uintptr_t)X & 63u) == 0 && (n_sk * (int64_t)c.dim) % 8 == 0;   // (every chain's row stream starts on a 64-byte line: lane_kernel.hpp, open_window)
-            if (lane_ok && !(lane_env && atoi(lane_env) == 0) && ((lane_env && atoi(lane_env) == 1) || C >= lane_from)) {
+            // a resumed chunk continues in the form whose state layout its first chunk left behind (until->form), whatever its size
+            const bool lane_wanted = resuming ? until->form == PDMP_FORM_LANE
+                                              : (!(lane_env && atoi(lane_env) == 0) && ((lane_env && atoi(lane_env) == 1) || C >= lane_from));
+            if (resuming && lane_wanted && !lane_ok) {
+                h->pool.push_back(ev);
+                return fail(PDMP_ERR_ARGUMENT, "resume: the first chunk ran one lane per chain; its chunks need 64-byte aligned X and capacity * dim a multiple of 8");
+            }
+            if (lane_ok && lane_wanted) {
                 int32_t *flag = h->d_status + 4;
                 hipError_t le = hipMemsetAsync(flag, 0, sizeof(int32_t), s);
-                if (le == hipSuccess) le = launch_lane_check(vinit, C * (int64_t)c.dim, flag, s);
+                if (le == hipSuccess && !resuming) le = launch_lane_check(vinit, C * (int64_t)c.dim, flag, s);   // (a resumed chunk: the first chunk's check stands)
                 int rounds = 24;                             // work units per resident wave (measured: 8 -> 24: 18.2 -> 16.8 ms at config 2)
                 if (const char *r = getenv("PDMP_LANE_ROUNDS")) { const int v = atoi(r); if (v >= 1 && v <= 64) rounds = v; }
                 GroupParams lp = gp;
@@ -1025,6 +1126,88 @@ int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t 
         const hipError_t e = f(p, s);
         if (e != hipSuccess) { h->pool.push_back(ev); return fail(PDMP_ERR_RUNTIME, "wave kernel launch: %s", hipGetErrorString(e)); }
     }
+    return end_timed(h, s, ev);
+}
+
+int pdmp_sample_skeleton_device(pdmp_handle h, int64_t C, int64_t n_sk, int64_t chain_id_offset,
+                                const double *xinit, const double *vinit, uint64_t seed, double *X, double *V,
+                                double *t, const pdmp_diag_t *diag, void *stream) {
+    return sample_skeleton_launch(h, C, n_sk, chain_id_offset, xinit, vinit, seed, X, V, t, diag, stream, nullptr);
+}
+
+// ---- sample_skeleton(sampler, T::Float64, ...) (src/sample.jl:323-439) as a kernel feature: one chunk of the history.
+int pdmp_sample_skeleton_until_device(pdmp_handle h, int64_t C, int64_t capacity, int64_t chain_id_offset, const double *xinit,
+                                      const double *vinit, uint64_t seed, double T, int32_t resume, const int64_t *chain_map,
+                                      double *X, double *V, double *t, const pdmp_diag_t *diag, int64_t *n_recorded, void *stream) {
+    if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
+    if (!(T >= 0.0) || !std::isfinite(T)) return fail(PDMP_ERR_ARGUMENT, "T must be finite and non-negative. Current value: %g", T);   // sample.jl:335-337
+    if (capacity < 2) return fail(PDMP_ERR_ARGUMENT, "a chunk needs a capacity of at least 2 columns. Current value: %lld", (long long)capacity);
+    if (!n_recorded) return fail(PDMP_ERR_ARGUMENT, "null buffer");
+    if (!resume && chain_map) return fail(PDMP_ERR_ARGUMENT, "a chain map belongs to a resumed chunk");
+    UntilArgs u = {T, resume ? 1 : 0, chain_map, n_recorded, 0};
+    // a resumed chunk continues in the kernel form whose state layout the previous chunk left behind: the lane kernel's, unless its
+    // unit-speed check sent that launch to the group kernel (known once it has run: pdmp_last_launch_form waits for it -- the host
+    // has waited for the previous chunk anyway, to learn how many chains are left)
+    if (resume) u.form = pdmp_last_launch_form(h);
+    const int rc = sample_skeleton_launch(h, C, capacity, chain_id_offset, xinit, vinit, seed, X, V, t, diag, stream, &u);
+    return rc;
+}
+
+int pdmp_close_chunk_device(pdmp_handle h, int64_t C, int64_t capacity, double *X, double *V, double *t, const pdmp_diag_t *diag,
+                            double T, const int64_t *n_recorded, int64_t *count, void *stream) {
+    if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
+    if (h->cfg.sampler == PDMP_RHMC && (h->cfg.dim > 4 * WAVE || h->cfg.target_id > PDMP_T_BANANA))
+        return fail(PDMP_ERR_UNSUPPORTED, "RHMC: the flow is integrated with up to 4 coordinates per lane (dim <= 256) on the built-in targets");
+    if (!(T >= 0.0) || !std::isfinite(T)) return fail(PDMP_ERR_ARGUMENT, "T must be finite and non-negative. Current value: %g", T);
+    if (capacity <= 0 || C < 0) return fail(PDMP_ERR_ARGUMENT, "capacity must be positive and C non-negative");
+    if (C == 0) return PDMP_OK;
+    if (!X || !V || !t || !count || !n_recorded) return fail(PDMP_ERR_ARGUMENT, "null buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 block(256), grid((unsigned)((C + 3) / 4));
+    pdmp_diag_t dg = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (diag) dg = *diag;
+    if (h->cfg.sampler == PDMP_BOOMERANG)
+        hipLaunchKernelGGL(close_at_kernel<true>, grid, block, 0, s, h->cfg.dim, C, capacity, X, V, t, T, count, 0, 0, 0.0, (const double *)nullptr, dg, n_recorded);
+    else
+        hipLaunchKernelGGL(close_at_kernel<false>, grid, block, 0, s, h->cfg.dim, C, capacity, X, V, t, T, count,
+                           h->cfg.sampler == PDMP_SUZZ ? 1 : (h->cfg.sampler == PDMP_RHMC ? 2 : (h->cfg.sampler == PDMP_STICKY ? 3 : 0)),
+                           h->cfg.target_id, h->cfg.rh_step_size, (const double *)h->d_tparams, dg, n_recorded);
+    HIP_TRY(hipGetLastError());
+    h->last_stream = s;
+    return PDMP_OK;
+}
+
+int pdmp_until_advance_device(pdmp_handle h, int64_t C, const int64_t *count, int64_t skip, const int64_t *map_in, int64_t *total,
+                              int64_t *start, int64_t *map_out, int64_t *n_active, void *stream) {
+    if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
+    if (C < 0 || skip < 0) return fail(PDMP_ERR_ARGUMENT, "C and skip must be non-negative");
+    if (!count || !total || !start || !map_out || !n_active) return fail(PDMP_ERR_ARGUMENT, "null buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    hipLaunchKernelGGL(until_advance_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, C, count, skip, map_in, total, start, map_out, n_active);
+    HIP_TRY(hipGetLastError());
+    h->last_stream = (hipStream_t)stream;
+    return PDMP_OK;
+}
+
+int pdmp_compact_chunk_device(pdmp_handle h, int64_t C, int64_t capacity, const int64_t *count, int64_t skip, const int64_t *chain_map,
+                              const int64_t *start, const int64_t *offsets, const double *X, const double *V, const double *t,
+                              const pdmp_diag_t *diag, double *X_out, double *V_out, double *t_out, const pdmp_diag_t *diag_out, void *stream) {
+    if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
+    if (capacity <= 0 || C < 0 || skip < 0) return fail(PDMP_ERR_ARGUMENT, "capacity must be positive, C and skip non-negative");
+    if (C == 0) return PDMP_OK;
+    if (!count || !start || !offsets || !X || !V || !t || !X_out || !V_out || !t_out) return fail(PDMP_ERR_ARGUMENT, "null buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    const int64_t tiles = (capacity + WAVE - 1) / WAVE, blocks = (C * tiles + 3) / 4;
+    if (blocks > 0x7fffffffLL) return fail(PDMP_ERR_UNSUPPORTED, "too many columns for one launch");
+    pdmp_diag_t dg = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, og = dg;
+    if (diag && diag_out) { dg = *diag; og = *diag_out; }
+    hipStream_t s = (hipStream_t)stream;
+    EventPair ev;
+    if (int rc = begin_timed(h, s, ev)) return rc;
+    hipLaunchKernelGGL(compact_chunk_kernel, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, capacity, count, skip, chain_map, start, offsets,
+                       X, V, t, dg, X_out, V_out, t_out, og);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) { h->pool.push_back(ev); return fail(PDMP_ERR_RUNTIME, "compact_chunk_kernel: %s", hipGetErrorString(e)); }
     return end_timed(h, s, ev);
 }
 

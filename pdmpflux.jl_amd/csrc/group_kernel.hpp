@@ -1667,32 +1667,35 @@ struct GroupChain {
     // Segments end right after an accepted event, where the thinning state is just
     // (x, v, t, horizon, ar, rng counter): every other field of PDMPState is reset or rebuilt
     // (SamplingLoopInplace.jl:28-31,69-76,181-183), so the hand-off between segments is 2d+4 doubles.
-    __device__ __forceinline__ void run_segment(int64_t c, bool chain_ok, int r, int64_t seg_len, double *state) {
+    __device__ __forceinline__ void run_segment(int64_t c, bool chain_ok, int r, int64_t seg_len, double *state, int nseg = 1) {
         const int d = p.d;
         const int64_t k_begin = 1 + (int64_t)r * seg_len;
         int64_t k_end = k_begin + seg_len;
         if (k_end > p.n_sk) k_end = p.n_sk;
-        double *st = state + (size_t)(chain_ok ? c : 0) * (size_t)(2 * d + 4);
+        // cs: the chain's index in the ORIGINAL ensemble (state slot, initial state, random stream); c: its index in this launch (outputs)
+        const int64_t cs = (p.chain_map && chain_ok) ? p.chain_map[c] : (chain_ok ? c : 0);
+        double *st = state + (size_t)cs * (size_t)(2 * d + 4);
         double t = 0.0, horizon = p.tmax, ar = 0.0;
         uint64_t n0 = 0;
-        if (r > 0 && chain_ok) {
+        const bool from_state = r > 0 || p.resume != 0;                   // (wave-uniform)
+        if (from_state && chain_ok) {
             t = st[2 * d]; horizon = st[2 * d + 1]; ar = st[2 * d + 2];
             n0 = (uint64_t)__double_as_longlong(st[2 * d + 3]);
         }
         PDMP_SLOTS(s) {
             const int i = s * G + g;
             const bool ok = chain_ok && in_dim(s, i);
-            if (r == 0) {
-                X(s) = ok ? p.xinit[(size_t)c * d + i] : 0.0;            // copies: inputs are never mutated (Q7)
-                V(s) = ok ? p.vinit[(size_t)c * d + i] : 0.0;
+            if (!from_state) {
+                X(s) = ok ? p.xinit[(size_t)cs * d + i] : 0.0;           // copies: inputs are never mutated (Q7)
+                V(s) = ok ? p.vinit[(size_t)cs * d + i] : 0.0;
             } else {
                 X(s) = ok ? st[i] : 0.0;
                 V(s) = ok ? st[d + i] : 0.0;
             }
         }
-        rng.init_lane(p.seed, (uint64_t)(p.chain0 + c));
+        rng.init_lane(p.seed, (uint64_t)(p.chain0 + cs));
         rng.restore(n0);
-        if (chain_ok) tape_open(c);
+        if (chain_ok) tape_open(cs);
         amask = 0xffffffffu;                                              // is_active = trues(d), Composites.jl:95 (StickyZigZag runs in one segment)
         lr_ok = false;
         if constexpr (Tgt::kTile) tgt.b_valid = false;
@@ -1701,9 +1704,14 @@ struct GroupChain {
         double ev[5] = {0, 0, 0, 0, 0};
         const bool adaptive = p.adaptive != 0;
         bool done = !chain_ok;
-        if (!done && r == 0) record(c, 0, t, horizon, ar, 0, ev, 0, 0);   // sample.jl:272
+        if (!done && r == 0) record(c, 0, t, horizon, ar, 0, ev, 0, 0);   // sample.jl:272 (a resumed chunk: the previous chunk's last event again)
         int32_t k = (int32_t)k_begin, it = 0;                             // host guarantees n_sk, cap < 2^31
         const int32_t cap = (int32_t)p.cap, kend = (int32_t)k_end;
+        // time-horizon variant: `while state.t < T` (sample.jl:372) -- a chain that has reached t_stop (in an earlier segment, or with
+        // T = 0 at its initial state) records nothing more; t_stop = +Inf otherwise
+        const bool fin_before = !(t < p.t_stop);
+        bool stopped = false;
+        if (fin_before) done = true;
         if (k >= kend) done = true;
         // Per-lane phase: BOUND (mode FRESH / ERR / REUSE) or PROPOSE.  The BoundBox is never kept across
         // loop iterations: after a rejection the reference re-inverts the SAME bound with a larger
@@ -1830,6 +1838,7 @@ struct GroupChain {
                 for (int q = 0; q < 5; ++q) ev[q] = 0.0;
                 it = 0;
                 if (++k >= kend) done = true;
+                if (!(t < p.t_stop)) { done = true; stopped = true; }     // the event that passed T is recorded, then the loop ends (:372-384)
             }
             STAMP(4);
             if (proposed && ++it > cap && !done) { done = true; if (g == 0) atomicAdd(&p.status[0], 1); }
@@ -1849,6 +1858,9 @@ struct GroupChain {
         }
         if (guard && g == 0) { atomicAdd(&p.status[1], guard); guard = 0; }
         if constexpr (TAPE) { if (tp_over && g == 0) atomicAdd(&p.status[3], 1); }
+        // columns this chain recorded in this launch: written by the segment it stopped in, else by its last segment
+        if (p.count && chain_ok && g == 0 && !fin_before && (stopped || r == nseg - 1)) p.count[c] = (int64_t)k;
+        if (p.count && chain_ok && g == 0 && fin_before && r == 0) p.count[c] = 1;      // T = 0: the initial point alone (:350-353)
     }
 };
 
@@ -1943,7 +1955,7 @@ __device__ __forceinline__ void group_kernel_body(const GroupParams &gp) {
         if (r > 0) lost = !wait_progress(gp.progress + b, r);
         if (!lost) {
             const int64_t c = (int64_t)b * cpw + lane / gp.G;
-            chain.run_segment(c, c < gp.s.C, r, gp.seg_len, gp.state);
+            chain.run_segment(c, c < gp.s.C, r, gp.seg_len, gp.state, gp.nseg);
             // no agent-scope release here: it is a buffer_wbl2, a write-back of the XCD's whole L2, which the event stores of
             // every wave keep full of dirty lines (measured: 35 -> 52 ms when the segments were made 3x shorter); the
             // hand-off state went out write-through instead, and the drain below covers it
@@ -1986,7 +1998,9 @@ __global__ __launch_bounds__(256, 1) void group_kernel_reg_tape(const GroupParam
 template <int SAMPLER, int TARGET, bool FD> struct RegForm {
     static constexpr bool kSlowZz = SAMPLER == S_ZIGZAG && FD;                       // measured: 88 ms against 73 ms in the LDS form
     static constexpr bool kPartial = !kSlowZz && !(SAMPLER == S_BOOMERANG && TARGET != T_GAUSS_DIAG);   // would spill: Boomerang iso / banana with the skips
-    template <int GC> static constexpr bool full() { return !kSlowZz && !(SAMPLER == S_ZIGZAG && TARGET == T_GAUSS_DIAG && GC == 1); }   // would spill: that one
+    template <int GC> static constexpr bool full() {        // would spill: Zig-Zag and (since the time-horizon stop of round 3) Boomerang on the diagonal Gaussian at one lane per chain
+        return !kSlowZz && !((SAMPLER == S_ZIGZAG || SAMPLER == S_BOOMERANG) && TARGET == T_GAUSS_DIAG && GC == 1);
+    }
     static constexpr bool kAny = !kSlowZz && SAMPLER != S_FECMC;
 };
 

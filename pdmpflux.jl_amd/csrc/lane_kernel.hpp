@@ -543,15 +543,23 @@ struct LaneChain {
 
     // ---- GroupChain::run_segment for the 64 chains of this wave.  Hand-off state of batch b (private to this kernel): word w of
     // the chain in lane l at state[(b (2d+4) + w) 64 + l] -- y_0..y_{d-1}, the sign words, t, horizon, ar, the stream position.
-    __device__ __forceinline__ void run_segment(int64_t b, int64_t c, bool chain_ok, int r, int64_t seg_len, double *state, int budget) {
+    __device__ __forceinline__ void run_segment(int64_t b, int64_t c, bool chain_ok, int r, int64_t seg_len, double *state, int budget, int nseg = 1) {
         const int64_t k_begin = 1 + (int64_t)r * seg_len;
         int64_t k_end = k_begin + seg_len;
         if (k_end > p.n_sk) k_end = p.n_sk;
-        double *st = state + (size_t)b * (size_t)(2 * d + 4) * WAVE + lane;
+        // cs: the chain's index in the ORIGINAL ensemble (state slot: batch cs / 64, lane cs % 64; initial state; random stream);
+        // c = 64 b + lane: its index in this launch (outputs).  A padding lane of a ragged batch uses its own launch slot.
+        // (The time-horizon features -- chain map, resume, stop at t_stop, column counts -- live in the DIAG instantiations only: the
+        // throughput kernels keep the registers and instructions they had; the host routes every such launch to a DIAG kernel.)
+        int64_t cs = c;
+        if constexpr (DIAG) { if (p.chain_map && chain_ok) cs = p.chain_map[c]; }
+        double *st = state + (size_t)(cs >> 6) * (size_t)(2 * d + 4) * WAVE + (size_t)(cs & 63);
         double t = 0.0, horizon = p.tmax, ar = 0.0;
         uint64_t n0 = 0;
         sg0 = 0; sg1 = 0;
-        if (r > 0) {
+        bool from_state = r > 0;
+        if constexpr (DIAG) from_state = from_state || p.resume != 0;
+        if (from_state) {
 #pragma unroll
             for (int i = 0; i < LD; ++i) y[i] = in_dim(i) ? st[(size_t)i * WAVE] : 0.0;
             const uint64_t sgw = (uint64_t)__double_as_longlong(st[(size_t)d * WAVE]);
@@ -562,18 +570,18 @@ struct LaneChain {
 #pragma unroll
             for (int i = 0; i < LD; ++i) {
                 const bool ok = chain_ok && in_dim(i);
-                const double xi = ok ? p.xinit[(size_t)c * d + i] : 0.0;
-                const double vi = ok ? p.vinit[(size_t)c * d + i] : 1.0;
+                const double xi = ok ? p.xinit[(size_t)cs * d + i] : 0.0;
+                const double vi = ok ? p.vinit[(size_t)cs * d + i] : 1.0;
                 const uint32_t s = (uint32_t)__double2hiint(vi) & 0x80000000u;
                 y[i] = sgn(xi, s);
                 if (i < 32) sg0 |= (s >> 31) << (i & 31); else sg1 |= (s >> 31) << (i & 31);
             }
         }
         open_window(b, c, r == 0 ? 0 : k_begin);
-        rng.init_lane(p.seed, (uint64_t)(p.chain0 + c));
+        rng.init_lane(p.seed, (uint64_t)(p.chain0 + cs));
         rng.restore(n0);
         if constexpr (TAPE) {
-            const size_t gc = (size_t)(p.chain0 + (chain_ok ? c : 0));
+            const size_t gc = (size_t)(p.chain0 + (chain_ok ? cs : 0));
             tp_e = p.tape_exp + gc * (size_t)p.tape_n_exp;
             tp_u = p.tape_uni + gc * (size_t)p.tape_n_uni;
             tp_ie = 0; tp_iu = 0; tp_over = false;
@@ -586,6 +594,8 @@ struct LaneChain {
         if (r == 0) record(!done, c, 0, t, horizon, ar, 0, ev, 0, 0);             // sample.jl:272 (whole wave: the transpose is cooperative)
         int32_t k = (int32_t)k_begin, it = 0;
         const int32_t cap = (int32_t)p.cap, kend = (int32_t)k_end;
+        bool fin_before = false, stopped = false;                                 // time-horizon variant: `while state.t < T`, sample.jl:372 (as GroupChain)
+        if constexpr (DIAG) { fin_before = !(t < p.t_stop); if (fin_before) done = true; }
         if (k >= kend) done = true;
         enum : int { FRESH = 0, ERR = 1, REUSE = 2 };
         bool propose = false, brun = false;
@@ -674,6 +684,7 @@ struct LaneChain {
                 for (int q = 0; q < 5; ++q) ev[q] = 0.0;
                 it = 0;
                 if (++k >= kend) done = true;
+                if constexpr (DIAG) { if (!(t < p.t_stop)) { done = true; stopped = true; } }
             }
             LANE_MARK(7);
             if (proposed && ++it > cap && !done) { done = true; atomicAdd(&p.status[0], 1); }
@@ -693,14 +704,21 @@ struct LaneChain {
         }
 #endif
         flush_carry(chain_ok, c, k);
-        // hand-off state (write-through stores, as the group kernel's; padding lanes write their own column too: it is theirs)
+        // hand-off state (write-through stores, as the group kernel's).  Real chains only: with a chain map the slot a padding lane
+        // would address belongs to another chain of the original ensemble.
+        if (chain_ok) {
 #pragma unroll
-        for (int i = 0; i < LD; ++i) if (in_dim(i)) publish(st + (size_t)i * WAVE, y[i]);
-        publish(st + (size_t)d * WAVE, __longlong_as_double((long long)(((uint64_t)sg1 << 32) | (uint64_t)sg0)));
-        publish(st + (size_t)(d + 1) * WAVE, t); publish(st + (size_t)(d + 2) * WAVE, horizon); publish(st + (size_t)(d + 3) * WAVE, ar);
-        publish(st + (size_t)(d + 4) * WAVE, __longlong_as_double((long long)rng.n));
+            for (int i = 0; i < LD; ++i) if (in_dim(i)) publish(st + (size_t)i * WAVE, y[i]);
+            publish(st + (size_t)d * WAVE, __longlong_as_double((long long)(((uint64_t)sg1 << 32) | (uint64_t)sg0)));
+            publish(st + (size_t)(d + 1) * WAVE, t); publish(st + (size_t)(d + 2) * WAVE, horizon); publish(st + (size_t)(d + 3) * WAVE, ar);
+            publish(st + (size_t)(d + 4) * WAVE, __longlong_as_double((long long)rng.n));
+        }
         if (guard) { atomicAdd(&p.status[1], guard); guard = 0; }
         if constexpr (TAPE) { if (tp_over && chain_ok) atomicAdd(&p.status[3], 1); }
+        if constexpr (DIAG) {
+            if (p.count && chain_ok && !fin_before && (stopped || r == nseg - 1)) p.count[c] = (int64_t)k;
+            if (p.count && chain_ok && fin_before && r == 0) p.count[c] = 1;
+        }
     }
 };
 
@@ -722,7 +740,7 @@ __global__ __launch_bounds__(256, LANE_WAVES) void lane_kernel(const GroupParams
         if (r > 0) lost = !wait_progress(gp.progress + b, r);
         if (!lost) {
             const int64_t c = (int64_t)b * WAVE + lane;
-            chain.run_segment(b, c, c < gp.s.C, r, gp.seg_len, gp.state, gp.cell_budget);
+            chain.run_segment(b, c, c < gp.s.C, r, gp.seg_len, gp.state, gp.cell_budget, gp.nseg);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(&gp.progress[b], r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -773,7 +791,8 @@ template <int TARGET, int LK0, int LK1>
 inline hipError_t launch_lane_by_slots(int lk, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream) {
     if constexpr (LK0 > LK1) return hipErrorNotSupported;
     else {
-        const bool diag = gp.s.H || gp.s.AR || gp.s.EB || gp.s.RJ || gp.s.HH || gp.s.EV;
+        const bool diag = gp.s.H || gp.s.AR || gp.s.EB || gp.s.RJ || gp.s.HH || gp.s.EV ||
+                          gp.s.count || gp.s.chain_map || gp.s.resume || gp.s.t_stop < __builtin_huge_val();   // (the time-horizon features: DIAG kernels)
         return lk != LK0 ? launch_lane_by_slots<TARGET, LK0 + 1, LK1>(lk, gp, flag, rounds, stream)
                          : (diag ? launch_lane<TARGET, LK0, true>(gp, flag, rounds, stream) : launch_lane<TARGET, LK0, false>(gp, flag, rounds, stream));
     }

@@ -37,6 +37,17 @@ struct SkelParams {
     // RHMC keywords (RandomizedHamiltonianMonteCarlo.jl:48-57)
     double rh_step_size, rh_phi;
     double fe_speed;   // ForwardECMC speed_factor
+    // Time-horizon variant sample_skeleton(sampler, T::Float64, ...) (src/sample.jl:323-439) as a kernel feature (group / lane kernels):
+    //   t_stop   a chain stops after recording its first event with t >= t_stop (`while state.t < T`, :372); +Inf: fixed count
+    //   resume   != 0: every chain starts from its hand-off state (x, v, t, horizon, ar, stream position: the last event of the
+    //            previous chunk, recorded again as column 0 of this one) instead of (xinit, vinit, 0, tmax, 0, 0)
+    //   chain_map  null, or chain_map[c] = index of launch chain c in the ORIGINAL ensemble: its state slot, its xinit / vinit row
+    //            and (+ chain0) its random stream; outputs are indexed by the launch's own c (dense over the active chains)
+    //   count    null, or count[c] = columns chain c recorded in this launch (n_sk when it used the whole capacity)
+    double t_stop;
+    int32_t resume, until_pad;
+    const int64_t *chain_map;
+    int64_t *count;
 };
 
 __device__ __forceinline__ bool uni(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }

@@ -151,6 +151,144 @@ def compact_history_device(sampler: AbstractPDMP, out: dict, count: torch.Tensor
     return res
 
 
+_DIAG_SPECS = (("horizon", torch.float64, ()), ("ar", torch.float64, ()), ("errored_bound", torch.int32, ()),
+               ("error_value_ar", torch.float64, (5,)), ("rejected", torch.int32, ()), ("hitting_horizon", torch.int32, ()))
+
+
+def sample_skeleton_until_chunked_device(sampler: AbstractPDMP, T: float, xinit: torch.Tensor, vinit: torch.Tensor, *, seed=None,
+                                         chain_id_offset: int = 0, diagnostics: bool = False, init_capacity: int = 1024,
+                                         stream=None, stats: dict | None = None, compact: bool = True) -> dict:
+    """Time-horizon variant ``sample_skeleton(sampler, T::Float64, xinit, vinit; seed, init_capacity)`` (src/sample.jl:323-439) for an
+    ensemble, with the time horizon as a KERNEL feature (include/pdmp_hip.h, ABI 8): the history is produced in chunks -- one launch
+    over the chains that have not reached ``T`` yet; a chain stops inside the kernel after its first event with ``t >= T``
+    (``while state.t < T``, :372), the others use the chunk's whole capacity and resume in the next chunk from their hand-off
+    state; finished chains cost nothing.  Between chunks, on the device: the closing column at exactly ``t == T`` (:385-420,
+    ``pdmp_close_chunk_device``), the per-chain history lengths and the compacted list of the chains still running (ballot +
+    prefix sums, ``pdmp_until_advance_device``); the host learns ONE number per chunk, how many chains are left.  Memory is the
+    sum of the chunks -- O(sum of the history lengths) -- plus the dense result, never chains x longest history.
+
+    Chunk capacities: the first is ``init_capacity`` (the reference's keyword; rounded up to a multiple of 8 so that a chunk's rows
+    start on 64-byte lines); the reference then doubles its one chain's buffer (:375-377, Composites.jl:172-191) -- here a later
+    chunk is sized from what the chains still running have left: the 90 % quantile of (T - t) x their event rate so far, with 10 % + 8
+    columns of slack (at most four times the capacity so far); stragglers take one more, small chunk.
+
+    Returns the histories trimmed and packed back to back (``_trim_history``, Composites.jl:198-214): ``X, V (total, d)``, ``t
+    (total,)`` (+ diagnostics), ``offsets (C+1,)``, ``count (C,)``: chain c = rows ``offsets[c] : offsets[c+1]``.
+    ``compact=False`` skips that copy (it reads and writes every event once more -- at config-2 size twice the time of the
+    sampling itself): when ONE chunk held every chain (a first capacity above the longest history) the result is that chunk as it
+    is, ``X, V (C, capacity, d)``, ``t (C, capacity)`` + ``count`` -- the ragged layout ``sample_from_skeleton_device(lens=count)``
+    and the fused moments read directly; otherwise ``{"chunks": [...], "count": ...}``: per chunk its tensors, ``count`` (columns;
+    negative: -n-1 for a chain that continues), ``start`` (where they go in the chain's history), ``map`` (launch chain ->
+    chain, None: identity) and ``skip`` (1: column 0 repeats the previous chunk's last event).
+    Raises EngineError(UNSUPPORTED) for configurations the in-kernel horizon does not serve (StickyZigZag, dense precision, the
+    wave-per-chain kernel, tape replay): ``sample_skeleton_until_device`` falls back to the capacity-doubling re-run for those."""
+    import math
+    T = float(T)
+    if not math.isfinite(T) or T < 0:
+        raise ArgumentError(f"T must be finite and non-negative. Current value: {T}")      # sample.jl:335-337
+    if xinit.dim() != 2 or xinit.shape != vinit.shape or xinit.shape[1] != sampler.dim:
+        raise DimensionMismatch(f"xinit and vinit must be (C, {sampler.dim})")
+    _need_cuda(xinit, vinit)
+    Cn, d = xinit.shape
+    dev = xinit.device
+    seed = _seed(seed)
+    L = _lib.lib()
+    h = sampler.handle()
+    sp = _stream_ptr(stream)
+    cap = -(-max(2, int(init_capacity)) // 8) * 8
+    total = torch.zeros((Cn,), dtype=torch.int64, device=dev)
+    chunks, cmap, C_l, cap_sum, allocated = [], None, Cn, 0, 0
+    prof = [] if (stats is not None and stats.get("profile")) else None
+
+    def mark(what):                                  # diagnostic: wall time of each step, synchronised (stats={"profile": True})
+        if prof is not None:
+            import time
+            torch.cuda.synchronize()
+            prof.append((what, time.perf_counter()))
+    with torch.cuda.device(dev):
+        while True:
+            mark("chunk begin")
+            bufs = {"X": torch.empty((C_l, cap, d), dtype=torch.float64, device=dev), "V": torch.empty((C_l, cap, d), dtype=torch.float64, device=dev),
+                    "t": torch.empty((C_l, cap), dtype=torch.float64, device=dev)}
+            if diagnostics:
+                for k, dt_, tail in _DIAG_SPECS:
+                    bufs[k] = torch.empty((C_l, cap) + tail, dtype=dt_, device=dev)
+            allocated += sum(b.numel() * b.element_size() for b in bufs.values())
+            dg = _diag_of(bufs)
+            nrec = torch.empty((C_l,), dtype=torch.int64, device=dev)
+            count = torch.empty((C_l,), dtype=torch.int64, device=dev)
+            start = torch.empty((C_l,), dtype=torch.int64, device=dev)
+            nxt = torch.empty((C_l,), dtype=torch.int64, device=dev)
+            n_act = torch.zeros((1,), dtype=torch.int64, device=dev)
+            resume = 0 if cmap is None else 1
+            mark("allocated")
+            _lib.check(L.pdmp_sample_skeleton_until_device(h, C_l, cap, int(chain_id_offset), _ptr(xinit), _ptr(vinit), C.c_uint64(seed),
+                                                           C.c_double(T), resume, _ptr(cmap), _ptr(bufs["X"]), _ptr(bufs["V"]), _ptr(bufs["t"]),
+                                                           C.byref(dg) if dg is not None else None, _ptr(nrec), sp))
+            mark("sampled")
+            _lib.check(L.pdmp_close_chunk_device(h, C_l, cap, _ptr(bufs["X"]), _ptr(bufs["V"]), _ptr(bufs["t"]),
+                                                 C.byref(dg) if dg is not None else None, C.c_double(T), _ptr(nrec), _ptr(count), sp))
+            mark("closed")
+            _lib.check(L.pdmp_until_advance_device(h, C_l, _ptr(count), resume, _ptr(cmap), _ptr(total), _ptr(start), _ptr(nxt), _ptr(n_act), sp))
+            mark("advanced")
+            _lib.check(L.pdmp_check_status(h, None))                           # (waits for the chunk; iteration cap / lost hand-off -> error)
+            chunks.append({"bufs": bufs, "count": count, "start": start, "map": cmap, "cap": cap, "skip": resume, "C": C_l})
+            cap_sum += cap
+            n = int(n_act.item())
+            if n == 0:
+                break
+            # the chains still running: history so far, time reached -> columns they still need
+            cmap = nxt[:n].clone()
+            unfinished = count < 0
+            t_reached = bufs["t"][:, cap - 1][unfinished]
+            done_cols = total[cmap].to(torch.float64)
+            need = (T - t_reached) * (done_cols / t_reached.clamp_min(1e-300))
+            # a chunk's capacity is one number for all its chains: sized for the 90 % quantile (+ 10 % + 8 columns) -- the stragglers take
+            # one more small chunk, which costs less than giving every chain the capacity of the slowest
+            # (below 8192 chains a chunk is small whatever its capacity: sized for the slowest chain, no further chunk)
+            if not bool(torch.isfinite(need).all()):
+                want = float(cap_sum)
+            elif n >= 8192:
+                want = float(torch.quantile(need, 0.9).item()) * 1.1 + 8.0
+            else:
+                want = float(need.max().item()) * 1.25 + 16.0
+            cap = int(min(max(16.0, want), float(max(4 * cap_sum, 1024))))   # (an estimate gone wild costs chunks or memory, never correctness)
+            cap = -(-cap // 8) * 8
+            C_l = n
+        mark("chunks done")
+        if prof is not None:
+            stats["profile_ms"] = [(b[0], round((b[1] - a[1]) * 1e3, 3)) for a, b in zip(prof, prof[1:])]
+        if stats is not None:
+            stats.update(chunks=len(chunks), capacities=[ch["cap"] for ch in chunks], chains=[ch["C"] for ch in chunks], chunk_bytes=allocated)
+        if not compact:
+            if len(chunks) == 1:
+                out = dict(chunks[0]["bufs"])
+                out["count"] = total
+                return out
+            return {"chunks": [{**ch["bufs"], "count": ch["count"], "start": ch["start"], "map": ch["map"], "skip": ch["skip"]} for ch in chunks],
+                    "count": total}
+        offsets = torch.empty((Cn + 1,), dtype=torch.int64, device=dev)
+        _lib.check(L.pdmp_compact_offsets_device(h, Cn, _ptr(total), _ptr(offsets), sp))
+        tot = int(offsets[-1].item())
+        res = {"offsets": offsets, "count": total, "X": torch.empty((tot, d), dtype=torch.float64, device=dev),
+               "V": torch.empty((tot, d), dtype=torch.float64, device=dev), "t": torch.empty((tot,), dtype=torch.float64, device=dev)}
+        if diagnostics:
+            for k, dt_, tail in _DIAG_SPECS:
+                res[k] = torch.empty((tot,) + tail, dtype=dt_, device=dev)
+        dout = _diag_of(res)
+        dense_bytes = sum(res[k].numel() * res[k].element_size() for k in res if k not in ("offsets", "count"))
+        for ch in chunks:
+            b = ch["bufs"]
+            din = _diag_of(b)
+            _lib.check(L.pdmp_compact_chunk_device(h, ch["C"], ch["cap"], _ptr(ch["count"]), ch["skip"], _ptr(ch["map"]), _ptr(ch["start"]),
+                                                   _ptr(offsets), _ptr(b["X"]), _ptr(b["V"]), _ptr(b["t"]), C.byref(din) if din is not None else None,
+                                                   _ptr(res["X"]), _ptr(res["V"]), _ptr(res["t"]), C.byref(dout) if dout is not None else None, sp))
+        torch.cuda.current_stream().synchronize() if stream is None else stream.synchronize()   # the chunks are released on return
+    if stats is not None:
+        stats.update(dense_bytes=dense_bytes)
+    return res
+
+
 def sample_skeleton_until_device(sampler: AbstractPDMP, T: float, xinit: torch.Tensor, vinit: torch.Tensor, *, seed=None,
                                  chain_id_offset: int = 0, diagnostics: bool = False, init_capacity: int = 1024,
                                  stream=None, compact: bool = False) -> dict:
@@ -165,6 +303,13 @@ def sample_skeleton_until_device(sampler: AbstractPDMP, T: float, xinit: torch.T
     T = float(T)
     if not math.isfinite(T) or T < 0:
         raise ArgumentError(f"T must be finite and non-negative. Current value: {T}")      # sample.jl:335-337
+    if compact:                              # packed result: the time horizon inside the kernel, chunked history (memory O(sum of lengths))
+        try:
+            return sample_skeleton_until_chunked_device(sampler, T, xinit, vinit, seed=seed, chain_id_offset=chain_id_offset,
+                                                        diagnostics=diagnostics, init_capacity=init_capacity, stream=stream)
+        except _lib.EngineError as e:
+            if e.code != _lib.ERR_UNSUPPORTED:
+                raise                        # (StickyZigZag, dense precision, wave-per-chain kernel, tape replay: the re-run below)
     cap = max(2, int(init_capacity))
     seed = _seed(seed)
     while True:

@@ -1,0 +1,124 @@
+"""The time horizon as a KERNEL feature (ABI 8: pdmp_sample_skeleton_until_device + pdmp_close_chunk_device +
+pdmp_until_advance_device + pdmp_compact_chunk_device; host loop: ensemble.sample_skeleton_until_chunked_device) against the
+checker's restatement of `sample_skeleton(sampler, T::Float64, ...)` (src/sample.jl:323-439, orc_sample_skeleton_until): chains stop
+inside the kernel at their first event with t >= T, the others resume from their hand-off state in the next chunk, finished
+chains cost nothing, memory is the sum of the chunks.  Every chain's packed history must equal the checker's, bit for bit,
+whatever the chunking (tiny capacities force many chunks and many resumes), on the group kernels and on the lane kernel."""
+import numpy as np
+import pytest
+
+from helpers import DIAG_KEYS, make_init, make_pair
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("ZigZagAD", 10, "iso", {}, 3.7), ("ZigZagAD", 50, "banana", {}, 2.2), ("ZigZag", 6, "diag", {}, 5.0),
+    ("BPS", 8, "banana", {}, 3.1), ("BPSAD", 50, "iso", {}, 4.0),
+    ("Boomerang", 12, "iso", {"refresh_rate": 0.5}, 6.3), ("BoomerangAD", 20, "diag", {"refresh_rate": 0.3}, 4.4),
+    ("SpeedUpZigZagAD", 5, "iso", {}, 2.0), ("RHMC", 6, "banana", {}, 4.5), ("ForwardECMC", 9, "diag", {}, 3.3),
+    ("ZigZagAD", 8, "iso", {"grid_size": 0}, 3.0),                       # Brent constant bound
+    ("ZigZagAD", 300, "iso", {}, 0.4),                                   # LDS form, G = 32
+]
+
+
+def _run(engine, oracle, s, cfg, x, v, T, seed, cap, stats=None, lo=0):
+    import torch
+    from pdmpflux.jl_amd import ensemble
+    dev = torch.device("cuda:0")
+    got = ensemble.sample_skeleton_until_chunked_device(s, T, torch.from_numpy(x).to(dev), torch.from_numpy(v).to(dev), seed=seed,
+                                                        diagnostics=True, init_capacity=cap, stats=stats, chain_id_offset=lo)
+    ref = oracle.sample_skeleton_until(cfg, T, x, v, seed, init_capacity=max(cap, 64), chain_id_offset=lo)
+    off = got["offsets"].cpu().numpy()
+    cnt = got["count"].cpu().numpy()
+    assert np.array_equal(cnt, ref["count"]), (cnt[:8], ref["count"][:8])
+    assert off[0] == 0 and np.array_equal(off[1:], np.cumsum(cnt))
+    host = {k: got[k].cpu().numpy() for k in ("X", "V", "t") + DIAG_KEYS}
+    for c in range(x.shape[0]):
+        k = int(cnt[c])
+        for key in ("X", "V", "t") + DIAG_KEYS:
+            a, b = host[key][off[c]:off[c + 1]], ref[key][c, :k]
+            same = (a == b) | (np.isnan(a) & np.isnan(b))
+            assert same.all(), f"chain {c} {key}: first mismatch at {np.argwhere(~same)[0]} of {k} columns"
+        assert host["t"][off[c + 1] - 1] == T or T == 0.0                # t[end] == T exactly (test/test_samplers.jl:56-62)
+    return got, ref, cnt
+
+
+@pytest.mark.parametrize("cap", [8, 64])
+@pytest.mark.parametrize("kind,dim,target,kw,T", CASES, ids=[f"{c[0]}-d{c[1]}-{c[2]}-T{c[4]}" for c in CASES])
+def test_chunked_time_horizon_matches_checker(engine, oracle, kind, dim, target, kw, T, cap):
+    s, cfg = make_pair(engine, oracle, kind, dim, target, **kw)
+    C = 21
+    x, v = make_init(kind, dim, C, seed=2, target=target)
+    stats = {}
+    got, ref, cnt = _run(engine, oracle, s, cfg, x, v, T, 9, cap, stats)
+    assert len(set(cnt.tolist())) > 1                                    # ragged
+    if cap == 8 and cnt.max() > 9:
+        assert stats["chunks"] >= 2 and stats["chains"][-1] <= C         # several resumes, fewer and fewer chains
+    assert stats["chains"] == sorted(stats["chains"], reverse=True)
+
+
+@pytest.mark.parametrize("target", ["iso", "banana"])
+def test_chunked_time_horizon_on_the_lane_kernel(engine, oracle, monkeypatch, target):
+    """PDMP_LANE=1: the first chunk runs one lane per chain; the resumed chunks -- a handful of chains -- must continue in the SAME
+    form (the hand-off state has that kernel's layout: signed positions, sign words, batch-major)."""
+    monkeypatch.setenv("PDMP_LANE", "1")
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", 50, target)
+    C, T = 150, 1.6                                                      # three batches of 64 chains, the last one ragged
+    x, v = make_init("ZigZagAD", 50, C, seed=5, target=target)
+    stats = {}
+    _run(engine, oracle, s, cfg, x, v, T, 4, 16, stats, lo=7)            # chain_id_offset: streams keyed by the global chain id
+    assert s.last_launch_form() == 4 and stats["chunks"] >= 2
+
+
+def test_chunked_time_horizon_segment_handoff(engine, oracle, monkeypatch):
+    """Several segments per chunk (PDMP_FORCE_SEGMENTS): a chain that reaches T in an early segment records nothing in the later ones."""
+    monkeypatch.setenv("PDMP_FORCE_SEGMENTS", "5")
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", 50, "iso")
+    x, v = make_init("ZigZagAD", 50, 40, seed=8)
+    stats = {}
+    _run(engine, oracle, s, cfg, x, v, 1.1, 3, 200, stats)               # ~25 events per chain in a capacity of 200: one chunk, five segments
+    assert stats["chunks"] == 1
+
+
+def test_chunked_time_horizon_edge_cases(engine, oracle):
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", 3, "iso")
+    x, v = np.zeros((5, 3)), np.ones((5, 3))
+    got, ref, cnt = _run(engine, oracle, s, cfg, x, v, 0.0, 1, 8)        # T == 0: the initial point alone (sample.jl:350-353)
+    assert (cnt == 1).all()
+    # an event at exactly t == T ends the loop without a closing column: replay a run with T = one of its event times
+    fixed = engine.sample_skeleton_ensemble(s, 30, x[:1] + 0.1, v[:1], seed=5)
+    T = float(fixed["t"][0, 17])
+    got, ref, cnt = _run(engine, oracle, s, cfg, x[:1] + 0.1, v[:1], T, 5, 8)
+    assert cnt[0] == 18 and got["t"][-1].item() == T
+    import torch
+    from pdmpflux.jl_amd import ensemble
+    with pytest.raises(engine.ArgumentError):
+        ensemble.sample_skeleton_until_chunked_device(s, -1.0, torch.zeros((2, 3), dtype=torch.float64, device="cuda"),
+                                                      torch.ones((2, 3), dtype=torch.float64, device="cuda"), seed=1)
+
+
+def test_chunked_path_memory_and_fallback(engine, oracle):
+    """Memory is the sum of the chunks: 4000 chains x T for ~130 events each from a first capacity of 64 -- the padded re-run needs
+    chains x 256 columns, the chunks a fraction more than the histories themselves.  StickyZigZag is not served in-kernel (its
+    hand-off state carries no is_active): the device entry says UNSUPPORTED and the host falls back to the re-run."""
+    import torch
+    from pdmpflux.jl_amd import ensemble, _lib
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", 10, "iso")
+    C, T = 4000, 33.0
+    x, v = make_init("ZigZagAD", 10, C, seed=1)
+    stats = {}
+    dev = torch.device("cuda:0")
+    got = ensemble.sample_skeleton_until_chunked_device(s, T, torch.from_numpy(x).to(dev), torch.from_numpy(v).to(dev), seed=2, init_capacity=64, stats=stats)
+    cnt = got["count"].cpu().numpy()
+    ref = oracle.sample_skeleton_until(cfg, T, x[:30], v[:30], 2, init_capacity=64)
+    assert np.array_equal(cnt[:30], ref["count"])
+    assert stats["chunk_bytes"] < 1.6 * stats["dense_bytes"], stats      # vs (C x max count) = what the re-run allocates last
+    assert stats["chains"][0] == C and stats["chunks"] <= 5, stats      # the later chunks are sized from the chains' own event rates
+    from test_gpu_time_horizon import sticky_pair
+    st, _ = sticky_pair(engine, oracle, 6)
+    xs, vs = make_init("ZigZag", 6, 4, seed=1)
+    with pytest.raises(_lib.EngineError) as e:
+        ensemble.sample_skeleton_until_chunked_device(st, 2.0, torch.from_numpy(xs).to(dev), torch.from_numpy(vs).to(dev), seed=1)
+    assert e.value.code == _lib.ERR_UNSUPPORTED
+    packed = ensemble.sample_skeleton_until_device(st, 2.0, torch.from_numpy(xs).to(dev), torch.from_numpy(vs).to(dev), seed=1, compact=True)
+    assert packed["offsets"].shape[0] == 5 and packed["t"][-1].item() == 2.0
