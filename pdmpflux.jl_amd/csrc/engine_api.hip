@@ -1068,14 +1068,14 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
             // with the count: it wins below ~41 000 chains at d = 50 (9.4 ms at 40 000, 12.8 ms at 45 000) and below ~48 000 at d = 32
             const int64_t lane_from = lane_min ? atoll(lane_min) : (c.dim >= 45 ? 42000 : 48000);
             const bool lane_ok = c.sampler == PDMP_ZIGZAG && !fd && (c.target_id == PDMP_T_GAUSS_ISO || c.target_id == PDMP_T_BANANA) &&
-                                 c.dim >= 25 && c.dim <= 52 && gp.G == 4 && (int64_t)WAVE * n_sk * c.dim * 8 < 0x7fffffffLL &&   // (a batch's window of X: 31-bit byte offsets)
-                                 ((uintptr_t)X & 63u) == 0 && (n_sk * (int64_t)c.dim) % 8 == 0;   // (every chain's row stream starts on a 64-byte line: lane_kernel.hpp, open_window)
+                                 c.dim >= 25 && c.dim <= 52 && gp.G == 4 && (int64_t)WAVE * n_sk * c.dim * 8 < 0x7fffffffLL;   // (a batch's window of X: 31-bit byte offsets)
+            // (round 3: no alignment preconditions any more -- a chain's rows may start anywhere inside a 64-byte line, lane_kernel.hpp: open_window)
             // a resumed chunk continues in the form whose state layout its first chunk left behind (until->form), whatever its size
             const bool lane_wanted = resuming ? until->form == PDMP_FORM_LANE
                                               : (!(lane_env && atoi(lane_env) == 0) && ((lane_env && atoi(lane_env) == 1) || C >= lane_from));
             if (resuming && lane_wanted && !lane_ok) {
                 h->pool.push_back(ev);
-                return fail(PDMP_ERR_ARGUMENT, "resume: the first chunk ran one lane per chain; its chunks need 64-byte aligned X and capacity * dim a multiple of 8");
+                return fail(PDMP_ERR_ARGUMENT, "resume: the first chunk ran one lane per chain; a chunk's capacity must keep 64 * capacity * dim * 8 below 2^31 bytes");
             }
             if (lane_ok && lane_wanted) {
                 int32_t *flag = h->d_status + 4;

@@ -333,11 +333,14 @@ struct LaneChain {
 #endif
     int cl = 0;                                                                   // carried doubles (row positions 0 .. cl - 1 of my LDS row)
     uint32_t Sc0 = 0, Sc1 = 0;                                                    // sign bits of the carried doubles
-    // The host takes this kernel only when X is 64-byte aligned and n_sk d is a multiple of 8 doubles: every chain's stream then starts
-    // on a line, and a segment that starts at event k_first starts a = (k_first d) mod 8 doubles into one -- the same for all chains of
-    // the wave.  Those a doubles in front of it are the tail of the previous event's row, i.e. of the very state the segment starts
-    // from (the hand-off state IS the last recorded event): the carry is rebuilt from it and the line is written whole again (the
-    // previous segment's flush wrote the same bytes), so no row position ever has to be skipped.  Called with y, sg loaded.
+    // A segment that starts at event k_first >= 1 of chain c starts a = (address of X[c, k_first, 0] / 8) mod 8 doubles into a 64-byte
+    // line -- per chain: round 3 dropped the preconditions "X on a line, n_sk d a multiple of 8" under which a was the same for the
+    // whole wave.  Those a doubles in front of it are the tail of the previous event's row, i.e. of the very state the segment starts
+    // from (the hand-off state IS the last recorded event; a <= 7 < d): the carry is rebuilt from it and the line is written whole
+    // again (the previous segment's flush, or record_initial, wrote the same bytes), so no row position ever has to be skipped.  The
+    // one row whose head may share a line with something that is not the chain's -- column 0 -- never comes through here
+    // (record_initial); the chain's last line goes out as a partial line (flush_carry).  V uses the same offsets from its own base: it
+    // is line-exact when it has X's phase inside a line, correct anywhere.  Called with y, sg loaded, k_first >= 1.
     __device__ __forceinline__ void open_window(int64_t b, int64_t c, int64_t k_first) {
         const size_t first = (size_t)b * WAVE * (size_t)p.n_sk * (size_t)d;
         int64_t chains = p.C - b * WAVE;
@@ -345,10 +348,10 @@ struct LaneChain {
         const int bytes = (int)(chains * p.n_sk * d * 8);
         rsX = __builtin_amdgcn_make_buffer_rsrc(p.X + first, 0, bytes, 0x00020000);
         rsV = __builtin_amdgcn_make_buffer_rsrc(p.V + first, 0, bytes, 0x00020000);
-        const int a = (int)(((uint64_t)k_first * (uint64_t)d) & 7u);              // wave-uniform
+        const int a = (int)(((uintptr_t)(p.X + ((size_t)c * (size_t)p.n_sk + (size_t)k_first) * (size_t)d) >> 3) & 7u);   // per chain
         cl = a;
         Sc0 = Sc1 = 0;
-        if (a > 0) {                                                              // (k_first > 0: a later segment)
+        {                                                                         // (all lanes: a = 0 moves nothing that is read)
             int l = lane;
             asm volatile("" : "+v"(l));
             double *myrow = tile + l * LR;
@@ -522,6 +525,28 @@ struct LaneChain {
         }
         LANE_MARK(15);
     }
+    // Column 0 (sample.jl:272; a resumed chunk: the previous chunk's last event again): each lane its own row, straight from the
+    // registers -- once per chain, and the only row whose head can share a 64-byte line with bytes that are not the chain's (the
+    // previous chain's last row, or whatever precedes X): nothing but the row itself is written.
+    __device__ __forceinline__ void record_initial(bool rec, int64_t c, double t, double horizon, double ar) {
+        if (!rec) return;
+        const size_t e = (size_t)c * (size_t)p.n_sk;
+        double *Xe = p.X + e * (size_t)d, *Ve = p.V + e * (size_t)d;
+#pragma unroll
+        for (int i = 0; i < LD; ++i) if (in_dim(i)) { Xe[i] = X(i); Ve[i] = V(i); }
+        p.t[e] = t;
+        if constexpr (DIAG) {
+            if (p.H) p.H[e] = horizon;
+            if (p.AR) p.AR[e] = ar;
+            if (p.EB) p.EB[e] = 0;
+            if (p.RJ) p.RJ[e] = 0;
+            if (p.HH) p.HH[e] = 0;
+            if (p.EV) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q) p.EV[5 * e + q] = 0.0;
+            }
+        }
+    }
     // end of a segment: the carried doubles go out as the head of a line (the next segment writes that line whole again); k = the next event
     __device__ __forceinline__ void flush_carry(bool mine, int64_t c, int32_t k) {
         int l = lane;
@@ -577,7 +602,8 @@ struct LaneChain {
                 if (i < 32) sg0 |= (s >> 31) << (i & 31); else sg1 |= (s >> 31) << (i & 31);
             }
         }
-        open_window(b, c, r == 0 ? 0 : k_begin);
+        if (r == 0) record_initial(chain_ok, c, t, horizon, ar);                  // (k_begin = 1: the segment's window opens behind column 0)
+        open_window(b, c, k_begin);
         rng.init_lane(p.seed, (uint64_t)(p.chain0 + cs));
         rng.restore(n0);
         if constexpr (TAPE) {
@@ -591,7 +617,6 @@ struct LaneChain {
         double ev[5] = {0, 0, 0, 0, 0};
         const bool adaptive = p.adaptive != 0;
         bool done = !chain_ok;
-        if (r == 0) record(!done, c, 0, t, horizon, ar, 0, ev, 0, 0);             // sample.jl:272 (whole wave: the transpose is cooperative)
         int32_t k = (int32_t)k_begin, it = 0;
         const int32_t cap = (int32_t)p.cap, kend = (int32_t)k_end;
         bool fin_before = false, stopped = false;                                 // time-horizon variant: `while state.t < T`, sample.jl:372 (as GroupChain)

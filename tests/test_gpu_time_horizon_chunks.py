@@ -98,13 +98,13 @@ def test_chunked_time_horizon_edge_cases(engine, oracle):
 
 
 def test_chunked_path_memory_and_fallback(engine, oracle):
-    """Memory is the sum of the chunks: 4000 chains x T for ~130 events each from a first capacity of 64 -- the padded re-run needs
+    """Memory is the sum of the chunks: 12 000 chains x T for ~130 events each from a first capacity of 64 -- the padded re-run needs
     chains x 256 columns, the chunks a fraction more than the histories themselves.  StickyZigZag is not served in-kernel (its
     hand-off state carries no is_active): the device entry says UNSUPPORTED and the host falls back to the re-run."""
     import torch
     from pdmpflux.jl_amd import ensemble, _lib
     s, cfg = make_pair(engine, oracle, "ZigZagAD", 10, "iso")
-    C, T = 4000, 33.0
+    C, T = 12000, 33.0
     x, v = make_init("ZigZagAD", 10, C, seed=1)
     stats = {}
     dev = torch.device("cuda:0")
@@ -112,7 +112,7 @@ def test_chunked_path_memory_and_fallback(engine, oracle):
     cnt = got["count"].cpu().numpy()
     ref = oracle.sample_skeleton_until(cfg, T, x[:30], v[:30], 2, init_capacity=64)
     assert np.array_equal(cnt[:30], ref["count"])
-    assert stats["chunk_bytes"] < 1.6 * stats["dense_bytes"], stats      # vs (C x max count) = what the re-run allocates last
+    assert stats["chunk_bytes"] < 1.4 * stats["dense_bytes"], stats      # (the re-run's last attempt alone: C x 256 columns = 2 x the histories)
     assert stats["chains"][0] == C and stats["chunks"] <= 5, stats      # the later chunks are sized from the chains' own event rates
     from test_gpu_time_horizon import sticky_pair
     st, _ = sticky_pair(engine, oracle, 6)
