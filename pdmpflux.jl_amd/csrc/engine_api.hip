@@ -23,6 +23,9 @@ hipError_t launch_group_reg_zigzag_exact(int target, const GroupParams &gp, hipS
 hipError_t launch_group_reg_bps_exact(int target, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_boomerang_exact(int target, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_boomerang_exact_fd(int target, const GroupParams &gp, hipStream_t stream);
+hipError_t launch_lane_bps_13(int target, const GroupParams &gp, int rounds, hipStream_t stream);       // lane_bps_kernel.hpp: d = 49 .. 52
+hipError_t launch_lane_bps_a(int target, const GroupParams &gp, int rounds, hipStream_t stream);        // d = 25 .. 36
+hipError_t launch_lane_bps_b(int target, const GroupParams &gp, int rounds, hipStream_t stream);        // d = 37 .. 48
 // tape replay (pdmp_set_tape): the same kernel forms with the tapes as random source (inst_tape_*.hip)
 hipError_t launch_lane_zigzag_tape(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);
 hipError_t launch_group_reg_tape_zigzag(int target, bool fd, const GroupParams &gp, hipStream_t stream);
@@ -1094,8 +1097,29 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
                     h->last_form = PDMP_FORM_LANE;
                 } else (void)hipGetLastError();
             }
+            // BPS at d = 27 .. 52 on the isotropic Gaussian / banana, forward-mode slopes, with one LANE per chain (lane_bps_kernel.hpp;
+            // bit-identical to the G = 4 group kernel).  MEASURED SLOWER than the group kernel (config 3: 58.7 ms against 40.3 ms; 131
+            // instead of 194 VALU instructions per event, but VALU busy 37 % instead of 83 %: one wave per SIMD cannot hide the long
+            // dependent chains of the per-chain scalar work -- log, divisions, Box-Muller) and therefore OFF unless PDMP_LANE_BPS=1
+            // asks for it (tests, profiles).  Its hand-off state has its own layout: a resumed chunk of the time-horizon variant stays in it.
+            bool lane_bps_ran = false;
+            {
+                const char *bps_env = getenv("PDMP_LANE_BPS");
+                const bool bps_ok = c.sampler == PDMP_BPS && !fd && !tgroup && (c.target_id == PDMP_T_GAUSS_ISO || c.target_id == PDMP_T_BANANA) &&
+                                    c.dim >= 27 && c.dim <= 52 && gp.G == 4;
+                const bool bps_wanted = resuming ? until->form == PDMP_FORM_LANE : (bps_env && atoi(bps_env) == 1);
+                if (bps_ok && bps_wanted) {
+                    int rounds = 24;
+                    if (const char *r = getenv("PDMP_LANE_ROUNDS")) { const int v = atoi(r); if (v >= 1 && v <= 64) rounds = v; }
+                    hipError_t le = c.dim > 48 ? launch_lane_bps_13(c.target_id, gp, rounds, s)
+                                  : c.dim > 36 ? launch_lane_bps_b(c.target_id, gp, rounds, s) : launch_lane_bps_a(c.target_id, gp, rounds, s);
+                    if (le == hipSuccess) { lane_bps_ran = true; h->last_form = PDMP_FORM_LANE; e = hipSuccess; }
+                    else (void)hipGetLastError();
+                }
+            }
             const char *ex = getenv("PDMP_REG_EXACT");      // PDMP_REG_EXACT=0: the KREG-slot kernels with per-slot skips (test hook)
-            if (tgroup)                                     // a replay: the 13-slot register kernels with the tapes as random source
+            if (lane_bps_ran) {}                            // (the launch is done)
+            else if (tgroup)                                     // a replay: the 13-slot register kernels with the tapes as random source
                 e = c.sampler == PDMP_ZIGZAG    ? (fd ? hipErrorNotSupported : launch_group_reg_tape_zigzag(c.target_id, fd, gp, s))
                   : c.sampler == PDMP_BPS       ? launch_group_reg_tape_bps(c.target_id, fd, gp, s)
                   : c.sampler == PDMP_BOOMERANG ? launch_group_reg_tape_boomerang(c.target_id, fd, gp, s)
