@@ -347,9 +347,59 @@ function sample_skeleton!(m::MultiSampler, X::Vector, V::Vector, t::Vector, xini
     return nothing
 end
 
+# ---------------------------------------------------------------------------------------------- time horizon for an ensemble (ABI 8)
+# sample_skeleton(sampler, T::Float64, xinit, vinit; seed, init_capacity) (src/sample.jl:323-439) for C chains held in HBM, with the time
+# horizon inside the kernel: the history comes in chunks -- `init_capacity` columns for every chain, then smaller chunks for the chains
+# that have not reached T, which resume from their hand-off state; finished chains cost nothing, memory is the sum of the history
+# lengths.  `A` = the device array type (AMDGPU.ROCArray); xinit, vinit: d x C device arrays.  Returns the packed `_trim_history`
+# layout (Composites.jl:198-214): X, V (d x total), t (total), offsets (C + 1; chain c = columns offsets[c]+1 : offsets[c+1]), count (C).
+# PDMP_ERR_UNSUPPORTED (-5: StickyZigZag, the dense-precision target, tape replays) -> use the single-chain method above per chain.
+function sample_skeleton_until(s::HIPSampler, T::Float64, xinit, vinit, A; seed::Int, chain_id_offset::Int=0, init_capacity::Int=1024, stream=C_NULL)
+    (isfinite(T) && T >= 0) || throw(ArgumentError("T must be finite and non-negative. Current value: $T"))   # :335-337
+    d, C = size(xinit)
+    cap = 8 * cld(max(2, init_capacity), 8)
+    total = A(zeros(Int64, C))
+    chunks = NamedTuple[]
+    cmap, Cl, skip = nothing, C, 0
+    while true
+        X, V, t = A{Float64}(undef, d, cap, Cl), A{Float64}(undef, d, cap, Cl), A{Float64}(undef, cap, Cl)
+        nrec, count, start, nxt, nact = A{Int64}(undef, Cl), A{Int64}(undef, Cl), A{Int64}(undef, Cl), A{Int64}(undef, Cl), A(zeros(Int64, 1))
+        pmap = cmap === nothing ? Ptr{Cvoid}(C_NULL) : Ptr{Cvoid}(pointer(cmap))
+        check(ccall((:pdmp_sample_skeleton_until_device, LIB), Cint,
+                    (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, UInt64, Cdouble, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                    s.handle, Cl, cap, chain_id_offset, pointer(xinit), pointer(vinit), seed_word(seed), T, skip, pmap, pointer(X), pointer(V), pointer(t), C_NULL, pointer(nrec), stream))
+        check(ccall((:pdmp_close_chunk_device, LIB), Cint,
+                    (Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                    s.handle, Cl, cap, pointer(X), pointer(V), pointer(t), C_NULL, T, pointer(nrec), pointer(count), stream))
+        check(ccall((:pdmp_until_advance_device, LIB), Cint,
+                    (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                    s.handle, Cl, pointer(count), skip, pmap, pointer(total), pointer(start), pointer(nxt), pointer(nact), stream))
+        check_status(s)                                                          # waits for the chunk
+        push!(chunks, (X=X, V=V, t=t, count=count, start=start, map=cmap, cap=cap, skip=skip, C=Cl))
+        n = Array(nact)[1]
+        n == 0 && break
+        cmap, Cl, skip = nxt[1:n], n, 1                                          # the chains still running, in launch order
+        cap = 8 * cld(max(16, min(cap, 2 * cap)), 8)                             # (the Python mirror sizes later chunks from the chains' event rates)
+    end
+    offsets = A{Int64}(undef, C + 1)
+    check(ccall((:pdmp_compact_offsets_device, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), s.handle, C, pointer(total), pointer(offsets), stream))
+    tot = Array(offsets)[end]
+    Xo, Vo, to = A{Float64}(undef, d, tot), A{Float64}(undef, d, tot), A{Float64}(undef, tot)
+    for ch in chunks
+        pmap = ch.map === nothing ? Ptr{Cvoid}(C_NULL) : Ptr{Cvoid}(pointer(ch.map))
+        check(ccall((:pdmp_compact_chunk_device, LIB), Cint,
+                    (Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                    s.handle, ch.C, ch.cap, pointer(ch.count), ch.skip, pmap, pointer(ch.start), pointer(offsets), pointer(ch.X), pointer(ch.V), pointer(ch.t), C_NULL,
+                    pointer(Xo), pointer(Vo), pointer(to), C_NULL, stream))
+    end
+    check_status(s)
+    return (X=Xo, V=Vo, t=to, offsets=offsets, count=total)
+end
+
 # ---------------------------------------------------------------------------------------------- tape replay (julia/dump_tape.jl)
 # Replace the engine's Philox stream by pre-recorded variates (one tape per kind, in consumption order): a dump of MersenneTwister's
-# randexp / rand / randn calls made by the reference replays draw for draw.
+# randexp / rand / randn calls made by the reference replays draw for draw, on whichever kernel form the launch uses otherwise
+# (group kernels, one lane per chain; every sampler, ForwardECMC included).
 function set_tape!(s::HIPSampler, exp_tape::Matrix{Float64}, uni_tape::Matrix{Float64}, nrm_tape::Matrix{Float64})   # columns = chains
     C = size(exp_tape, 2)
     GC.@preserve exp_tape uni_tape nrm_tape check(ccall((:pdmp_set_tape, LIB), Cint,
