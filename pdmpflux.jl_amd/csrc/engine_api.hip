@@ -1074,7 +1074,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
                                  c.dim >= 25 && c.dim <= 52 && gp.G == 4 && (int64_t)WAVE * n_sk * c.dim * 8 < 0x7fffffffLL;   // (a batch's window of X: 31-bit byte offsets)
             // (round 3: no alignment preconditions any more -- a chain's rows may start anywhere inside a 64-byte line, lane_kernel.hpp: open_window)
             // a resumed chunk continues in the form whose state layout its first chunk left behind (until->form), whatever its size
-            const bool lane_wanted = resuming ? until->form == PDMP_FORM_LANE
+            const bool lane_wanted = resuming ? (until->form == PDMP_FORM_LANE && c.sampler == PDMP_ZIGZAG)   // (BPS: its own lane form, below)
                                               : (!(lane_env && atoi(lane_env) == 0) && ((lane_env && atoi(lane_env) == 1) || C >= lane_from));
             if (resuming && lane_wanted && !lane_ok) {
                 h->pool.push_back(ev);

@@ -1736,6 +1736,11 @@ struct GroupChain {
             if constexpr (TAPE) { if (tp_over) done = true; }             // tape exhausted: stop this chain (reported below)
             rng_prefetch();
             bool accepted = false, refresh = false, proposed = false, event_out = false;   // event_out: a StickyZigZag stick / thaw event
+            // The flow of a pass -- to the horizon (move_to_horizon!, move_to_horizon2!) or to the accepted proposal (if_accept!) -- happens
+            // in ONE place, behind the propose phase: a lane does at most one of the three per pass, and one call site instead of three
+            // keeps the state registers free of copies at the joins of the divergent regions (round 3: 189 v_mov_b64 in the event loop).
+            bool moves = false;
+            double tflow = 0.0, raw = 0.0;
             if (!done && !propose) {
                 // one_step_of_thinning! (:65-85), erroneous_acceptance_rate! (:131-151) or if_reject! (:188-203)
                 if (!brun) {
@@ -1768,7 +1773,7 @@ struct GroupChain {
                         if (adaptive) horizon = horizon / 1.04;           // :194
                         rejected++;
                         if (tnext > horizon) {                            // move_to_horizon2!, :205-217 (SamplingLoopInplace.jl:163)
-                            flow_state(horizon);
+                            moves = true; tflow = horizon;
                             ts += horizon;
                             hits++;
                         }
@@ -1779,7 +1784,7 @@ struct GroupChain {
                         ts = 0.0;
                         event_out = true;
                     } else if (tnext > horizon) {                         // move_to_horizon!, :87-101
-                        flow_state(horizon);
+                        moves = true; tflow = horizon;
                         ts += horizon;
                         hits++;
                         if (adaptive) horizon = horizon * 1.01;
@@ -1800,7 +1805,6 @@ struct GroupChain {
                 proposed = true;
             }
             if (!done && propose) {
-                double raw;
                 const double lam = true_rate(tp, raw);                    // ac_step!, :113-129
                 ar = lam / lb;
                 STAMP(1);
@@ -1810,9 +1814,7 @@ struct GroupChain {
                 } else {                                                  // ac_step_with_proxy!, :153-168
                     const double u = draw_uniform();
                     if (u < ar) {                                         // if_accept!, :170-186
-                        flow_state(tp);
-                        STAMP(2);
-                        refresh = velocity_jump(raw);
+                        moves = true; tflow = tp;
                         accepted = true;
                     } else {
                         mode = REUSE;                                     // if_reject! continues in the BOUND phase
@@ -1820,6 +1822,9 @@ struct GroupChain {
                 }
                 proposed = true;
             }
+            if (moves) flow_state(tflow);
+            STAMP(2);
+            if (accepted) refresh = velocity_jump(raw);
             if constexpr (SAMPLER == S_BPS || SAMPLER == S_BOOMERANG) {   // the whole wave draws the normals of its refreshing chains
                 if (__ballot(refresh) != 0ull) refresh_velocities(refresh);
             } else if constexpr (SAMPLER == S_FECMC) {
