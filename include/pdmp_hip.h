@@ -240,10 +240,9 @@ int pdmp_close_at_time_device(pdmp_handle h, int64_t C, int64_t n_sk, double *X,
  *     chunk's ensemble -- its state slot and its random stream; xinit / vinit are ignored (may be NULL).  seed and
  *     chain_id_offset must be the first chunk's.  X, V, t (and diag) are this chunk's own buffers, d x capacity x C etc.
  *   n_recorded[c] (int64, DEVICE) = columns chain c recorded in this chunk (capacity, or fewer when it reached T).
- *   Runs on the group / lane kernels: every sampler except StickyZigZag, built-in and source-given targets except the
- *   dense-precision one, grid_size = 10 or 0, no tape; PDMP_ERR_UNSUPPORTED otherwise (use the fixed-count path + pdmp_close_at_time_device
- *   with a doubled capacity).  A chunk of a handle whose first chunk ran one lane per chain needs 64-byte aligned X and
- *   capacity * dim a multiple of 8 (any capacity that is a multiple of 8).
+ *   Runs on the group / lane kernels: every sampler (StickyZigZag: the hand-off state carries the active masks; pass diag->is_active),
+ *   built-in and source-given targets except the dense-precision one, grid_size = 10 or 0, no tape; PDMP_ERR_UNSUPPORTED otherwise
+ *   (use the fixed-count path + pdmp_close_at_time_device with a doubled capacity).
  * pdmp_close_chunk_device: pdmp_close_at_time_device restricted to the recorded columns of a chunk (stride = capacity):
  *   count[c] >= 0: the chain's history ends in this chunk with count[c] columns, the last one at exactly t = T (the closing
  *   column written in place over the overshooting event, :385-420; none when an event sits at exactly T);

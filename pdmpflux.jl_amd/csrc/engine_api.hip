@@ -999,7 +999,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
         gp.cell_budget = 3;
         if (const char *e = getenv("PDMP_CELL_BUDGET")) { const int b = atoi(e); if (b >= 1 && b <= GNG - 1) gp.cell_budget = b; }   // tuning / tests
         const int64_t nb = (C + WAVE / gp.G - 1) / (WAVE / gp.G);
-        const size_t need_sched = (size_t)nb + 1, need_state = (size_t)((C + WAVE - 1) / WAVE * WAVE) * (size_t)(2 * c.dim + 4);   // (whole batches of 64: lane_kernel.hpp)
+        const size_t need_sched = (size_t)nb + 1, need_state = (size_t)((C + WAVE - 1) / WAVE * WAVE) * ((size_t)(2 * c.dim + 4) + (c.sampler == PDMP_STICKY ? (size_t)gp.G : 0));   // (whole batches of 64: lane_kernel.hpp; StickyZigZag: + the active masks of a chain's lanes)
         if (resuming && (!h->until_valid || !h->d_state || need_state > h->state_cap || C > h->until_chains))
             return fail(PDMP_ERR_ARGUMENT, "resume: this handle holds no hand-off state of a first chunk of at least %lld chains", (long long)C);
         if (!resuming) { h->until_valid = until != nullptr; h->until_chains = C; }
@@ -1015,7 +1015,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
         }
         HIP_TRY(hipMemsetAsync(h->d_sched, 0, need_sched * sizeof(int32_t), s));
         if (const char *e = getenv("PDMP_FORCE_SEGMENTS")) gp.nseg = atoi(e);   // test hook, see group_schedule
-        if (c.sampler == PDMP_STICKY || tgroup) gp.nseg = 1;                    // the hand-off state carries neither is_active nor tape positions
+        if (tgroup) gp.nseg = 1;                                                // the hand-off state does not carry tape positions
         gp.ctr = h->d_sched;
         gp.progress = h->d_sched + 1;
         gp.state = h->d_state;
@@ -1025,10 +1025,10 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
     // Dense-precision Zig-Zag on many chains: grad-U of all chains as one fp64 GEMM per phase (dense_batched.hip);
     // small ensembles and PDMP_DENSE_MODE=matvec keep the bit-exact per-chain mat-vec kernel.
     const char *dense_mode = getenv("PDMP_DENSE_MODE");       // "incr" | "gemm" | "matvec" (default: incr for >= 64 chains and d <= 1024, gemm beyond)
-    if (until && (taped || h->group_lanes <= 0 || c.target_id == PDMP_T_GAUSS_DENSE || c.sampler == PDMP_STICKY)) {
+    if (until && (taped || h->group_lanes <= 0 || c.target_id == PDMP_T_GAUSS_DENSE)) {
         h->pool.push_back(ev);
-        return fail(PDMP_ERR_UNSUPPORTED, "the in-kernel time horizon runs on the group / lane kernels (grid_size = 10 or 0; not StickyZigZag, whose hand-off "
-                                          "state does not carry is_active; not the dense-precision target; no tape): rerun the fixed-count path with a doubled capacity instead");
+        return fail(PDMP_ERR_UNSUPPORTED, "the in-kernel time horizon runs on the group / lane kernels (grid_size = 10 or 0; not the dense-precision target; "
+                                          "no tape): rerun the fixed-count path with a doubled capacity instead");
     }
     const bool batched = c.target_id == PDMP_T_GAUSS_DENSE && c.sampler == PDMP_ZIGZAG && c.vectorized_bound && c.grid_size == GNG &&
                          c.deriv_mode == PDMP_DERIV_FORWARD && !taped && 2 * C < 0x7fffffffLL &&

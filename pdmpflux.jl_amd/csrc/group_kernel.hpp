@@ -1674,7 +1674,10 @@ struct GroupChain {
         if (k_end > p.n_sk) k_end = p.n_sk;
         // cs: the chain's index in the ORIGINAL ensemble (state slot, initial state, random stream); c: its index in this launch (outputs)
         const int64_t cs = (p.chain_map && chain_ok) ? p.chain_map[c] : (chain_ok ? c : 0);
-        double *st = state + (size_t)cs * (size_t)(2 * d + 4);
+        // hand-off state of a chain: x[d], v[d], t, horizon, ar, stream position -- and, for StickyZigZag (round 3), the active masks of the
+        // chain's G lanes (one word each: bit s = the coordinate of slot s moves), so that sticky chains too run in segments and resume
+        const size_t stride = (size_t)(2 * d + 4) + (kSticky ? (size_t)G : 0);
+        double *st = state + (size_t)cs * stride;
         double t = 0.0, horizon = p.tmax, ar = 0.0;
         uint64_t n0 = 0;
         const bool from_state = r > 0 || p.resume != 0;                   // (wave-uniform)
@@ -1696,7 +1699,8 @@ struct GroupChain {
         rng.init_lane(p.seed, (uint64_t)(p.chain0 + cs));
         rng.restore(n0);
         if (chain_ok) tape_open(cs);
-        amask = 0xffffffffu;                                              // is_active = trues(d), Composites.jl:95 (StickyZigZag runs in one segment)
+        amask = 0xffffffffu;                                              // is_active = trues(d), Composites.jl:95
+        if constexpr (kSticky) { if (from_state && chain_ok) amask = (uint32_t)__double_as_longlong(st[2 * d + 4 + g]); }
         lr_ok = false;
         if constexpr (Tgt::kTile) tgt.b_valid = false;
         double ts = 0.0, tp = 0.0, E = 0.0, lb = 0.0;
@@ -1860,6 +1864,7 @@ struct GroupChain {
                 publish(st + 2 * d, t); publish(st + 2 * d + 1, horizon); publish(st + 2 * d + 2, ar);
                 publish(st + 2 * d + 3, __longlong_as_double((long long)rng.n));
             }
+            if constexpr (kSticky) publish(st + 2 * d + 4 + g, __longlong_as_double((long long)amask));
         }
         if (guard && g == 0) { atomicAdd(&p.status[1], guard); guard = 0; }
         if constexpr (TAPE) { if (tp_over && g == 0) atomicAdd(&p.status[3], 1); }

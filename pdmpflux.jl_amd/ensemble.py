@@ -180,8 +180,8 @@ def sample_skeleton_until_chunked_device(sampler: AbstractPDMP, T: float, xinit:
     and the fused moments read directly; otherwise ``{"chunks": [...], "count": ...}``: per chunk its tensors, ``count`` (columns;
     negative: -n-1 for a chain that continues), ``start`` (where they go in the chain's history), ``map`` (launch chain ->
     chain, None: identity) and ``skip`` (1: column 0 repeats the previous chunk's last event).
-    Raises EngineError(UNSUPPORTED) for configurations the in-kernel horizon does not serve (StickyZigZag, dense precision, the
-    wave-per-chain kernel, tape replay): ``sample_skeleton_until_device`` falls back to the capacity-doubling re-run for those."""
+    Raises EngineError(UNSUPPORTED) for configurations the in-kernel horizon does not serve (dense precision, the wave-per-chain
+    kernel, tape replay): ``sample_skeleton_until_device`` falls back to the capacity-doubling re-run for those."""
     import math
     T = float(T)
     if not math.isfinite(T) or T < 0:
@@ -213,6 +213,8 @@ def sample_skeleton_until_chunked_device(sampler: AbstractPDMP, T: float, xinit:
             if diagnostics:
                 for k, dt_, tail in _DIAG_SPECS:
                     bufs[k] = torch.empty((C_l, cap) + tail, dtype=dt_, device=dev)
+            if sampler.sampler_id == 6:                          # StickyZigZag: PDMPHistory.is_active (Composites.jl:142,256)
+                bufs["is_active"] = torch.empty((C_l, cap, d), dtype=torch.uint8, device=dev)
             allocated += sum(b.numel() * b.element_size() for b in bufs.values())
             dg = _diag_of(bufs)
             nrec = torch.empty((C_l,), dtype=torch.int64, device=dev)
@@ -275,6 +277,8 @@ def sample_skeleton_until_chunked_device(sampler: AbstractPDMP, T: float, xinit:
         if diagnostics:
             for k, dt_, tail in _DIAG_SPECS:
                 res[k] = torch.empty((tot,) + tail, dtype=dt_, device=dev)
+        if sampler.sampler_id == 6:
+            res["is_active"] = torch.empty((tot, d), dtype=torch.uint8, device=dev)
         dout = _diag_of(res)
         dense_bytes = sum(res[k].numel() * res[k].element_size() for k in res if k not in ("offsets", "count"))
         for ch in chunks:
@@ -309,7 +313,7 @@ def sample_skeleton_until_device(sampler: AbstractPDMP, T: float, xinit: torch.T
                                                         diagnostics=diagnostics, init_capacity=init_capacity, stream=stream)
         except _lib.EngineError as e:
             if e.code != _lib.ERR_UNSUPPORTED:
-                raise                        # (StickyZigZag, dense precision, wave-per-chain kernel, tape replay: the re-run below)
+                raise                        # (dense precision, wave-per-chain kernel, tape replay: the re-run below)
     cap = max(2, int(init_capacity))
     seed = _seed(seed)
     while True:

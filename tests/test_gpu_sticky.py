@@ -65,3 +65,19 @@ def test_sticky_zigzag_freezes_at_zero_and_thaws(engine):
     assert abs(frozen.mean() - w) < 0.03
     h = engine.sample_skeleton(s, 50, np.zeros(d) + 0.3, np.ones(d), seed=4)
     assert h.is_active.shape == (d, 50) and h.is_active.dtype == bool
+
+
+@pytest.mark.parametrize("segments", [3, 7])
+@pytest.mark.parametrize("dim,target", [(5, "iso"), (50, "iso"), (20, "banana")])
+def test_sticky_zigzag_segment_handoff(engine, oracle, monkeypatch, segments, dim, target):
+    """Round 3: the hand-off state carries the active masks of a chain's lanes, so StickyZigZag runs in segments (the dynamic
+    schedule of large ensembles) like every other sampler: a coordinate frozen at the end of a segment is still frozen -- and thaws
+    at the same event -- in the next one."""
+    monkeypatch.setenv("PDMP_FORCE_SEGMENTS", str(segments))
+    s, cfg = pair(engine, oracle, "StickyZigZagAD", dim, target, 0.5)
+    C, n_sk = 41, 120
+    x, v = make_init("ZigZag", dim, C, seed=9, target=target)
+    got = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=51, diagnostics=True)
+    ref = oracle.sample_skeleton(cfg, n_sk, x, v, 51, diagnostics=True)
+    assert_bitwise(got, ref, keys=("X", "V", "t", "is_active") + DIAG_KEYS)
+    assert (ref["is_active"] == 0).any()

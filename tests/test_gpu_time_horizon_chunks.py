@@ -99,8 +99,8 @@ def test_chunked_time_horizon_edge_cases(engine, oracle):
 
 def test_chunked_path_memory_and_fallback(engine, oracle):
     """Memory is the sum of the chunks: 12 000 chains x T for ~130 events each from a first capacity of 64 -- the padded re-run needs
-    chains x 256 columns, the chunks a fraction more than the histories themselves.  StickyZigZag is not served in-kernel (its
-    hand-off state carries no is_active): the device entry says UNSUPPORTED and the host falls back to the re-run."""
+    chains x 256 columns, the chunks a fraction more than the histories themselves.  The dense-precision target is not served in-kernel: the
+    device entry says UNSUPPORTED and the host falls back to the re-run."""
     import torch
     from pdmpflux.jl_amd import ensemble, _lib
     s, cfg = make_pair(engine, oracle, "ZigZagAD", 10, "iso")
@@ -114,11 +114,34 @@ def test_chunked_path_memory_and_fallback(engine, oracle):
     assert np.array_equal(cnt[:30], ref["count"])
     assert stats["chunk_bytes"] < 1.4 * stats["dense_bytes"], stats      # (the re-run's last attempt alone: C x 256 columns = 2 x the histories)
     assert stats["chains"][0] == C and stats["chunks"] <= 5, stats      # the later chunks are sized from the chains' own event rates
-    from test_gpu_time_horizon import sticky_pair
-    st, _ = sticky_pair(engine, oracle, 6)
-    xs, vs = make_init("ZigZag", 6, 4, seed=1)
+    dn, _ = make_pair(engine, oracle, "ZigZagAD", 70, "dense")           # the dense-precision target is not served in-kernel
+    xs, vs = make_init("ZigZagAD", 70, 4, seed=1)
     with pytest.raises(_lib.EngineError) as e:
-        ensemble.sample_skeleton_until_chunked_device(st, 2.0, torch.from_numpy(xs).to(dev), torch.from_numpy(vs).to(dev), seed=1)
+        ensemble.sample_skeleton_until_chunked_device(dn, 0.5, torch.from_numpy(xs).to(dev), torch.from_numpy(vs).to(dev), seed=1)
     assert e.value.code == _lib.ERR_UNSUPPORTED
-    packed = ensemble.sample_skeleton_until_device(st, 2.0, torch.from_numpy(xs).to(dev), torch.from_numpy(vs).to(dev), seed=1, compact=True)
-    assert packed["offsets"].shape[0] == 5 and packed["t"][-1].item() == 2.0
+    packed = ensemble.sample_skeleton_until_device(dn, 0.5, torch.from_numpy(xs).to(dev), torch.from_numpy(vs).to(dev), seed=1, compact=True)
+    assert packed["offsets"].shape[0] == 5 and packed["t"][-1].item() == 0.5
+
+
+@pytest.mark.parametrize("dim,target,kap,T,cap", [(4, "iso", 0.5, 6.0, 8), (13, "diag", 0.3, 4.0, 16), (50, "iso", 0.7, 2.5, 24), (20, "banana", 0.5, 3.0, 8)])
+def test_chunked_time_horizon_sticky(engine, oracle, dim, target, kap, T, cap):
+    """StickyZigZag in chunks (round 3: the hand-off state carries the active masks): the resumed chunk starts with the frozen
+    coordinates still frozen; is_active of every column and the closing column's masked flow (sample.jl:386-401) as the checker's."""
+    import torch
+    from pdmpflux.jl_amd import ensemble
+    from test_gpu_time_horizon import sticky_pair
+    s, cfg = sticky_pair(engine, oracle, dim, target, kap)
+    C = 33
+    x, v = make_init("ZigZag", dim, C, seed=4, target=target)
+    dev = torch.device("cuda:0")
+    stats = {}
+    got = ensemble.sample_skeleton_until_chunked_device(s, T, torch.from_numpy(x).to(dev), torch.from_numpy(v).to(dev), seed=17, diagnostics=True,
+                                                        init_capacity=cap, stats=stats)
+    ref = oracle.sample_skeleton_until(cfg, T, x, v, 17, init_capacity=64)
+    cnt, off = got["count"].cpu().numpy(), got["offsets"].cpu().numpy()
+    assert np.array_equal(cnt, ref["count"]) and stats["chunks"] >= 2
+    for key in ("X", "V", "t", "is_active") + DIAG_KEYS:
+        a = got[key].cpu().numpy()
+        for c in range(C):
+            assert np.array_equal(a[off[c]:off[c + 1]], ref[key][c, :cnt[c]], equal_nan=True), (key, c)
+    assert (got["is_active"] == 0).any()
