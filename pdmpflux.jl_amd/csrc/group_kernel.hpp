@@ -212,7 +212,11 @@ template <> struct GTarget<T_USER> {
 #define PDMP_SLOTS(s) _Pragma("unroll kUnroll") for (int s = 0; s < nk(); ++s) if (!kReg || s < kmin || s < K)
 // TAPE: the random source is a set of pre-recorded tapes instead of the Philox stream (pdmp_set_tape) -- separate
 // instantiations (inst_tape_*.hip), so the kernels that serve the Philox stream are compiled from exactly the code they had before.
-template <int SAMPLER, int TARGET, bool FD, int KC = 0, int GC = 0, bool TAPE = false>      // GC: lanes per chain when it is a compile-time constant (register form)
+// LEAN: the throughput instantiation of a FULL 13-slot register kernel (round 3, as the lane kernels' DIAG = false): a launch that
+// records no diagnostic array and uses none of the time-horizon features (t_stop, resume, chain map, column counts) runs a kernel that
+// does not contain them -- their pointers, counters and the five-slot error ring cost scalar registers (spilled to VGPR lanes and
+// read back with v_readlane in the event loop) and instructions in kernels that are bound by VALU issue.
+template <int SAMPLER, int TARGET, bool FD, int KC = 0, int GC = 0, bool TAPE = false, bool LEAN = false>      // GC: lanes per chain when it is a compile-time constant (register form)
 struct GroupChain {
     using Tgt = GTarget<TARGET>;
     static constexpr bool kReg = KC > 0;
@@ -1651,14 +1655,16 @@ struct GroupChain {
         }
         if (g == 0) {
             p.t[e] = t;
-            if (p.H) p.H[e] = horizon;
-            if (p.AR) p.AR[e] = ar;
-            if (p.EB) p.EB[e] = errored;
-            if (p.RJ) p.RJ[e] = rejected;
-            if (p.HH) p.HH[e] = hits;
-            if (p.EV) {
+            if constexpr (!LEAN) {
+                if (p.H) p.H[e] = horizon;
+                if (p.AR) p.AR[e] = ar;
+                if (p.EB) p.EB[e] = errored;
+                if (p.RJ) p.RJ[e] = rejected;
+                if (p.HH) p.HH[e] = hits;
+                if (p.EV) {
 #pragma unroll
-                for (int q = 0; q < 5; ++q) p.EV[5 * e + q] = ev[q];
+                    for (int q = 0; q < 5; ++q) p.EV[5 * e + q] = ev[q];
+                }
             }
         }
     }
@@ -1673,14 +1679,16 @@ struct GroupChain {
         int64_t k_end = k_begin + seg_len;
         if (k_end > p.n_sk) k_end = p.n_sk;
         // cs: the chain's index in the ORIGINAL ensemble (state slot, initial state, random stream); c: its index in this launch (outputs)
-        const int64_t cs = (p.chain_map && chain_ok) ? p.chain_map[c] : (chain_ok ? c : 0);
+        int64_t cs = chain_ok ? c : 0;
+        if constexpr (!LEAN) { if (p.chain_map && chain_ok) cs = p.chain_map[c]; }
         // hand-off state of a chain: x[d], v[d], t, horizon, ar, stream position -- and, for StickyZigZag (round 3), the active masks of the
         // chain's G lanes (one word each: bit s = the coordinate of slot s moves), so that sticky chains too run in segments and resume
         const size_t stride = (size_t)(2 * d + 4) + (kSticky ? (size_t)G : 0);
         double *st = state + (size_t)cs * stride;
         double t = 0.0, horizon = p.tmax, ar = 0.0;
         uint64_t n0 = 0;
-        const bool from_state = r > 0 || p.resume != 0;                   // (wave-uniform)
+        bool from_state = r > 0;                                          // (wave-uniform)
+        if constexpr (!LEAN) from_state = from_state || p.resume != 0;
         if (from_state && chain_ok) {
             t = st[2 * d]; horizon = st[2 * d + 1]; ar = st[2 * d + 2];
             n0 = (uint64_t)__double_as_longlong(st[2 * d + 3]);
@@ -1713,9 +1721,8 @@ struct GroupChain {
         const int32_t cap = (int32_t)p.cap, kend = (int32_t)k_end;
         // time-horizon variant: `while state.t < T` (sample.jl:372) -- a chain that has reached t_stop (in an earlier segment, or with
         // T = 0 at its initial state) records nothing more; t_stop = +Inf otherwise
-        const bool fin_before = !(t < p.t_stop);
-        bool stopped = false;
-        if (fin_before) done = true;
+        bool fin_before = false, stopped = false;
+        if constexpr (!LEAN) { fin_before = !(t < p.t_stop); if (fin_before) done = true; }
         if (k >= kend) done = true;
         // Per-lane phase: BOUND (mode FRESH / ERR / REUSE) or PROPOSE.  The BoundBox is never kept across
         // loop iterations: after a rejection the reference re-inverts the SAME bound with a larger
@@ -1847,7 +1854,7 @@ struct GroupChain {
                 for (int q = 0; q < 5; ++q) ev[q] = 0.0;
                 it = 0;
                 if (++k >= kend) done = true;
-                if (!(t < p.t_stop)) { done = true; stopped = true; }     // the event that passed T is recorded, then the loop ends (:372-384)
+                if constexpr (!LEAN) { if (!(t < p.t_stop)) { done = true; stopped = true; } }   // the event that passed T is recorded, then the loop ends (:372-384)
             }
             STAMP(4);
             if (proposed && ++it > cap && !done) { done = true; if (g == 0) atomicAdd(&p.status[0], 1); }
@@ -1869,8 +1876,10 @@ struct GroupChain {
         if (guard && g == 0) { atomicAdd(&p.status[1], guard); guard = 0; }
         if constexpr (TAPE) { if (tp_over && g == 0) atomicAdd(&p.status[3], 1); }
         // columns this chain recorded in this launch: written by the segment it stopped in, else by its last segment
-        if (p.count && chain_ok && g == 0 && !fin_before && (stopped || r == nseg - 1)) p.count[c] = (int64_t)k;
-        if (p.count && chain_ok && g == 0 && fin_before && r == 0) p.count[c] = 1;      // T = 0: the initial point alone (:350-353)
+        if constexpr (!LEAN) {
+            if (p.count && chain_ok && g == 0 && !fin_before && (stopped || r == nseg - 1)) p.count[c] = (int64_t)k;
+            if (p.count && chain_ok && g == 0 && fin_before && r == 0) p.count[c] = 1;  // T = 0: the initial point alone (:350-353)
+        }
     }
 };
 
@@ -1930,7 +1939,7 @@ template <int SAMPLER, int TARGET, bool FD> struct GroupOcc {
         : 3;                                                            // Zig-Zag, Boomerang, ForwardECMC on the separable Gaussians
 };
 
-template <int SAMPLER, int TARGET, bool FD, int KC = 0, int GC = 0, bool TAPE = false>
+template <int SAMPLER, int TARGET, bool FD, int KC = 0, int GC = 0, bool TAPE = false, bool LEAN = false>
 __device__ __forceinline__ void group_kernel_body(const GroupParams &gp) {
     extern __shared__ double smem[];
     const int lane = lane_id();
@@ -1942,7 +1951,7 @@ __device__ __forceinline__ void group_kernel_body(const GroupParams &gp) {
     double *tile = smem + gp.tpar + (size_t)wave * gp.tiles * tsz;
     const int cpw = WAVE / gp.G;
     // register form: no x tile; one K*64-double tile per wave only where refreshed velocities are exchanged between lanes
-    GroupChain<SAMPLER, TARGET, FD, KC, GC, TAPE> chain(gp, lane, tile, KC > 0 ? tile : tile + tsz);
+    GroupChain<SAMPLER, TARGET, FD, KC, GC, TAPE, LEAN> chain(gp, lane, tile, KC > 0 ? tile : tile + tsz);
     chain.tgt.init(smem, gp.s.d);
     if constexpr (SAMPLER == S_FECMC) {
         for (int q = 0; q < 4; ++q) chain.fe_t[q] = tile + (2 + q) * tsz;
@@ -2017,7 +2026,7 @@ template <int SAMPLER, int TARGET, bool FD> struct RegForm {
 // register form (x, v in VGPRs, up to KC slots per lane, G fixed at compile time): no LDS tiles; 2 waves per SIMD -- the
 // instantiations must stay free of VGPR spills (a spill under a partial exec mask loses the inactive lanes' values, and
 // lanes of different chains run different branches here): `make check-spills`
-template <int SAMPLER, int TARGET, bool FD, int KC, int GC, bool FULL>
+template <int SAMPLER, int TARGET, bool FD, int KC, int GC, bool FULL, bool LEAN = false>
 #ifndef PDMP_REG_WAVES
 #define PDMP_REG_WAVES 2
 #endif
@@ -2026,7 +2035,7 @@ __global__ __launch_bounds__(256, PDMP_REG_WAVES) void group_kernel_reg(const Gr
     GroupParams gp = gp_in;
     gp.G = GC;                 // the host launches this instantiation only for G == GC, K <= KC: folds every use of G
     if (FULL) gp.K = KC;       // ... and the FULL one only for K == KC: the per-slot skips fold away too
-    group_kernel_body<SAMPLER, TARGET, FD, KC, GC>(gp);
+    group_kernel_body<SAMPLER, TARGET, FD, KC, GC, false, LEAN>(gp);
 }
 
 #ifndef __HIPCC_RTC__   // host side (not part of a runtime-compiled user kernel)
@@ -2078,6 +2087,11 @@ hipError_t launch_group_impl(const GroupParams &gp_in, hipStream_t stream) {
         } else {
             if constexpr (RF::kPartial && !EXACT) kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, false>;
             if constexpr (RF::template full<GC>()) if (gp.K == KC) kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, true>;
+            if constexpr (RF::template full<GC>() && KC == KREG) {             // the throughput kernels of the BASELINE shapes (d = 50 / G = 4, d = 100 / G = 8, ...)
+                const SkelParams &q = gp.s;
+                const bool plain = !(q.H || q.AR || q.EB || q.RJ || q.HH || q.EV || q.IA || q.count || q.chain_map || q.resume) && !(q.t_stop < __builtin_huge_val());
+                if (gp.K == KC && plain && !getenv("PDMP_NO_LEAN")) kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, true, true>;
+            }
         }
     } else if constexpr (TAPE) kernel = group_kernel_tape<SAMPLER, TARGET, FD>;
     else kernel = group_kernel<SAMPLER, TARGET, FD>;

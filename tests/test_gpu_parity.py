@@ -519,3 +519,25 @@ def test_random_configurations_match_checker(engine, oracle, kind, dim, target, 
     got = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=seed, diagnostics=True)
     ref = oracle.sample_skeleton(cfg, n_sk, x, v, seed, diagnostics=True)
     assert_bitwise(got, ref)
+
+
+@pytest.mark.parametrize("kind,dim,target,kw", [("ZigZagAD", 50, "iso", {}), ("ZigZagAD", 52, "banana", {}), ("ZigZagAD", 13, "diag", {}),
+                                                ("BPS", 50, "banana", {}), ("BPS", 100, "iso", {"refresh_rate": 0.7}), ("BPSAD", 26, "diag", {}),
+                                                ("Boomerang", 100, "iso", {"refresh_rate": 0.5}), ("BoomerangAD", 104, "iso", {"refresh_rate": 0.5}),
+                                                ("Boomerang", 50, "diag", {})])
+def test_lean_throughput_kernels(engine, oracle, monkeypatch, kind, dim, target, kw):
+    """Round 3: a launch that records no diagnostic array and uses no time-horizon feature runs the LEAN instantiation of the FULL
+    13-slot register kernel (the BASELINE shapes: d = 50 with four lanes per chain, d = 100 with eight, ...), which does not contain
+    them.  Same trajectories as the full kernel (PDMP_NO_LEAN=1) and as the checker, hand-off between segments included."""
+    monkeypatch.setenv("PDMP_LANE", "0")
+    monkeypatch.setenv("PDMP_FORCE_SEGMENTS", "3")
+    s, cfg = make_pair(engine, oracle, kind, dim, target, **kw)
+    C, n_sk = 37, 70
+    x, v = make_init(kind, dim, C, seed=8, target=target)
+    lean = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=19, chain_id_offset=4, diagnostics=False)
+    assert s.last_launch_form() == 3
+    ref = oracle.sample_skeleton(cfg, n_sk, x, v, 19, chain_id_offset=4, diagnostics=False)
+    assert_bitwise(lean, ref, keys=("X", "V", "t"))
+    monkeypatch.setenv("PDMP_NO_LEAN", "1")
+    full = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=19, chain_id_offset=4, diagnostics=False)
+    assert_bitwise(full, ref, keys=("X", "V", "t"))
