@@ -3,6 +3,7 @@
 # Alternates the two libraries three times on the SAME GPU (boxes of the pool differ by several %).
 A=$1; B=$2; shift 2
 cp pdmpflux.jl_amd/libpdmphip.so /tmp/lib_orig.so
+trap 'cp /tmp/lib_orig.so pdmpflux.jl_amd/libpdmphip.so' EXIT
 for rep in 1 2 3; do
   for v in A B; do
     if [ $v = A ]; then cp $A pdmpflux.jl_amd/libpdmphip.so; else cp $B pdmpflux.jl_amd/libpdmphip.so; fi

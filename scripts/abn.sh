@@ -3,6 +3,7 @@
 # Alternates the libraries three times on the SAME GPU (boxes of the pool differ by several %).
 LIBS=$1; shift
 cp pdmpflux.jl_amd/libpdmphip.so /tmp/lib_orig.so
+trap 'cp /tmp/lib_orig.so pdmpflux.jl_amd/libpdmphip.so' EXIT
 for rep in 1 2 3; do
   for L in $LIBS; do
     cp $L pdmpflux.jl_amd/libpdmphip.so

@@ -2,6 +2,7 @@
 # like abn.sh, with the live PMC passes: prints ms per step and the HBM bytes written per launch
 LIBS=$1; shift
 cp pdmpflux.jl_amd/libpdmphip.so /tmp/lib_orig.so
+trap 'cp /tmp/lib_orig.so pdmpflux.jl_amd/libpdmphip.so' EXIT
 for rep in 1 2; do
   for L in $LIBS; do
     cp $L pdmpflux.jl_amd/libpdmphip.so
