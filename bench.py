@@ -463,7 +463,8 @@ def main():
                   f"skeleton_kernel<{sampler.name},{a.target}> (wave per chain)")
         form = sampler.last_launch_form()                        # which kernel form served the timed launches (pdmp_last_launch_form)
         if form == 4:
-            kernel = (f"lane_kernel<{a.target}> (one lane per chain, 64 chains per wave; signed positions y = x v in registers, "
+            per = "one lane per chain, 64 chains per wave" if a.dim <= 52 else "a lane pair per chain, 32 chains per wave"
+            kernel = (f"lane_kernel<{a.target}> ({per}; signed positions y = x v in registers, "
                       "events stored as whole 64-byte lines)")
         cnt = measured_counters(a, C_local, G, form)
         if live:                                                  # measured now, on this GPU, for this workload

@@ -16,6 +16,9 @@ hipError_t launch_lane_zigzag(int target, const GroupParams &gp, const int32_t *
 hipError_t launch_lane_zigzag_a(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream); // d = 25 .. 36
 hipError_t launch_lane_zigzag_b(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream); // d = 37 .. 48
 hipError_t launch_lane_check(const double *vinit, int64_t n, int32_t *flag, hipStream_t stream);
+hipError_t launch_lane2_zigzag(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);   // a PAIR of lanes per chain: d = 97 .. 104
+hipError_t launch_lane2_zigzag_a(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream); // d = 53 .. 72
+hipError_t launch_lane2_zigzag_b(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream); // d = 73 .. 96
 hipError_t launch_group_reg_zigzag(int target, bool fd, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_bps(int target, bool fd, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_boomerang(int target, bool fd, const GroupParams &gp, hipStream_t stream);
@@ -1069,9 +1072,13 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
             // measured (one MI355X, n_sk = 1000): up to 65 536 chains the lane kernel takes 9.6 ms (d = 50 Gaussian) / 11.0 ms (banana) / 7.8 ms
             // (d = 32) whatever the count -- one wave per SIMD walks its 64 chains' events one after the other -- while the group kernel grows
             // with the count: it wins below ~41 000 chains at d = 50 (9.4 ms at 40 000, 12.8 ms at 45 000) and below ~48 000 at d = 32
-            const int64_t lane_from = lane_min ? atoll(lane_min) : (c.dim >= 45 ? 42000 : 48000);
+            // d = 53 .. 104 (the group kernel's G = 8): a PAIR of lanes per chain, 32 chains per wave, bit-identical to the G = 8 group kernel
+            const bool lane2 = gp.G == 8;
+            // (the pair kernel, d = 100, n_sk = 1000: 10.6 ms up to 32 768 chains -- one wave per SIMD -- against 9.5 ms of the group kernel at 25 000, 37.9 ms at 10^5)
+            const int64_t lane_from = lane_min ? atoll(lane_min) : (lane2 ? 28000 : (c.dim >= 45 ? 42000 : 48000));
             const bool lane_ok = c.sampler == PDMP_ZIGZAG && !fd && (c.target_id == PDMP_T_GAUSS_ISO || c.target_id == PDMP_T_BANANA) &&
-                                 c.dim >= 25 && c.dim <= 52 && gp.G == 4 && (int64_t)WAVE * n_sk * c.dim * 8 < 0x7fffffffLL;   // (a batch's window of X: 31-bit byte offsets)
+                                 ((gp.G == 4 && c.dim >= 25 && c.dim <= 52) || (lane2 && c.dim >= 53 && c.dim <= 104 && !tgroup)) &&
+                                 (int64_t)(lane2 ? WAVE / 2 : WAVE) * n_sk * c.dim * 8 < 0x7fffffffLL;   // (a batch's window of X: 31-bit byte offsets)
             // (round 3: no alignment preconditions any more -- a chain's rows may start anywhere inside a 64-byte line, lane_kernel.hpp: open_window)
             // a resumed chunk continues in the form whose state layout its first chunk left behind (until->form), whatever its size
             const bool lane_wanted = resuming ? (until->form == PDMP_FORM_LANE && c.sampler == PDMP_ZIGZAG)   // (BPS: its own lane form, below)
@@ -1090,6 +1097,9 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
                 if (!getenv("PDMP_CELL_BUDGET")) lp.cell_budget = 5;   // a pass of 64 chains costs ~2 000 instructions, a cell 240: wait for more cells
                 if (tgroup) lp.nseg = 1;                     // (lane_schedule: a forced segment count)
                 if (le == hipSuccess) le = tgroup ? launch_lane_zigzag_tape(c.target_id, lp, flag, rounds, s)   // (d = 49 .. 52; else the group kernel below replays)
+                                      : c.dim > 96 ? launch_lane2_zigzag(c.target_id, lp, flag, rounds, s)
+                                      : c.dim > 72 ? launch_lane2_zigzag_b(c.target_id, lp, flag, rounds, s)
+                                      : c.dim > 52 ? launch_lane2_zigzag_a(c.target_id, lp, flag, rounds, s)
                                       : c.dim > 48 ? launch_lane_zigzag(c.target_id, lp, flag, rounds, s)
                                       : c.dim > 36 ? launch_lane_zigzag_b(c.target_id, lp, flag, rounds, s) : launch_lane_zigzag_a(c.target_id, lp, flag, rounds, s);
                 if (le == hipSuccess) {                      // (a lane kernel that cannot be launched -- it asks for 145 KB of LDS per block --

@@ -28,6 +28,7 @@
 // One wave per SIMD (512 registers per lane); the launch is bound by the rate at which the events can be written.
 #pragma once
 #include "group_kernel.hpp"
+#include <type_traits>
 
 #ifndef LANE_WAVES
 #define LANE_WAVES 1          // waves per SIMD the kernel is compiled for (512 registers per lane at 1)
@@ -44,8 +45,10 @@ namespace pdmp {
 // LK = slots of the emulated G = 4 layout: one instantiation per LK = 7 .. 13 serves d = 4 LK - 3 .. 4 LK (25 .. 52; the engine's default
 // layout is G = 4 from d = 27 on)
 constexpr int LANE_LK_MIN = 7, LANE_LK_MAX = 13;
-constexpr int lane_row_stride(int lk) { return (7 + 4 * lk) | 1; }   // LDS row: up to 7 carried doubles + 4 LK coordinates, odd stride
-constexpr int lane_lds_per_wave(int lk) { return WAVE * lane_row_stride(lk) + 2 * WAVE + 8 * WAVE; } // doubles: 64 rows + 16 bytes of store parameters per chain + 8 event times per chain
+// gl = lanes per chain (1; 2: the chain's coordinates split over a lane pair, lane_kernel.hpp: GL)
+constexpr int lane_row_stride(int lk, int gl = 1) { return (7 + 4 * gl * lk) | 1; }   // LDS row: up to 7 carried doubles + 4 gl LK coordinates, odd stride
+constexpr int lane_meta_doubles(int gl) { return gl == 1 ? 2 : 4; }                  // store parameters of a chain: 16 bytes (64 sign bits) / 32 bytes (128)
+constexpr int lane_lds_per_wave(int lk, int gl = 1) { return (WAVE / gl) * (lane_row_stride(lk, gl) + lane_meta_doubles(gl) + 8); } // doubles: a row + the store parameters + 8 event times per chain
 
 // Two waves per SIMD (256 registers): slot loops run slot by slot -- without this the scheduler hoists the 52 independent terms of a sum
 // in front of their additions (104 more live registers, spills).  One wave per SIMD (512 registers, the build that ships): no fence, the
@@ -87,38 +90,93 @@ constexpr int lane_lds_per_wave(int lk) { return WAVE * lane_row_stride(lk) + 2 
 // without them (the throughput case) their pointers, counters and the five-slot ring of error values are not compiled in at all.
 // TAPE: pre-recorded variates instead of the Philox stream (pdmp_set_tape; GroupChain's tape source, same format) -- separate
 // instantiations (inst_tape_lane.hip), one segment per chain.
-template <int TARGET, int LK, bool DIAG, bool TAPE = false>
+//
+// GL = 2 (round 3): d = 53 .. 104, the dimensions the engine runs with G = 8 lanes per chain otherwise.  A chain is a PAIR of lanes (32
+// chains per wave); lane h of the pair holds coordinates 8 s + 4 h + g (g = 0 .. 3) of slot s = 0 .. LK - 1 in the same 4 LK registers,
+// with the same four partial sums: its ((p0 + p1) + (p2 + p3)) is what the xor-1 / xor-2 stages of the eight-lane butterfly leave in a
+// quad, and ONE exchange with the partner lane (DPP quad_perm [1,0,3,2]) is the xor-4 stage -- bit-identical to the G = 8 group kernel
+// ("GROUP(8)").  Everything per chain (random stream, exponentials, bound bookkeeping, the state machine) runs identically in both
+// lanes, as it does in the eight lanes of the group kernel -- but for 32 chains per instruction instead of 8.
+struct LaneBits128 { uint64_t lo, hi; };
+__device__ __forceinline__ uint64_t lb_shl(uint64_t a, int n) { return a << n; }                 // n in 0 .. 63
+__device__ __forceinline__ uint64_t lb_shr(uint64_t a, int n) { return a >> n; }
+__device__ __forceinline__ uint64_t lb_or(uint64_t a, uint64_t b) { return a | b; }
+__device__ __forceinline__ uint32_t lb_low(uint64_t a) { return (uint32_t)a; }
+__device__ __forceinline__ LaneBits128 lb_shl(LaneBits128 a, int n) {                            // n in 0 .. 63
+    return {a.lo << n, (a.hi << n) | ((a.lo >> 1) >> (63 - n))};
+}
+__device__ __forceinline__ LaneBits128 lb_shr(LaneBits128 a, int n) {                            // n in 0 .. 127
+    if (n >= 64) { a.lo = a.hi; a.hi = 0; n -= 64; }
+    return {(a.lo >> n) | ((a.hi << 1) << (63 - n)), a.hi >> n};
+}
+__device__ __forceinline__ LaneBits128 lb_or(LaneBits128 a, LaneBits128 b) { return {a.lo | b.lo, a.hi | b.hi}; }
+__device__ __forceinline__ uint32_t lb_low(LaneBits128 a) { return (uint32_t)a.lo; }
+__device__ __forceinline__ uint32_t dpp_xor1_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, DPP_QUAD_XOR1, 0xF, 0xF, true); }
+
+template <int TARGET, int LK, bool DIAG, bool TAPE = false, int GL = 1>
 struct LaneChain {
     static_assert(TARGET == T_GAUSS_ISO || TARGET == T_BANANA, "lane kernel: isotropic Gaussian and banana");
     static_assert(LK >= LANE_LK_MIN && LK <= LANE_LK_MAX, "lane kernel: 7 .. 13 slots of four coordinates");
+    static_assert(GL == 1 || GL == 2, "lane kernel: one lane per chain, or a pair");
+    static_assert(!(TAPE && GL != 1), "tape replay: one lane per chain");
+    static constexpr int GE = 4 * GL;                    // lanes per chain of the group layout whose summation order this is
     static constexpr int LD = 4 * LK;                    // coordinate registers per lane
-    static constexpr int LR = lane_row_stride(LK);       // LDS row stride
-    static constexpr int LANE_DMIN = LD - 3;             // the last slot may be partly padding, no other
+    static constexpr int DMAX = GE * LK;                 // coordinates of a chain, padding included
+    static constexpr int CW = WAVE / GL;                 // chains per wave
+    static constexpr int LR = lane_row_stride(LK, GL);   // LDS row stride
+    static constexpr int MD = lane_meta_doubles(GL);     // doubles of store parameters per chain
+    static constexpr int LANE_DMIN = DMAX - (GE - 1);    // the last slot may be partly padding, no other
     static constexpr bool kBanana = TARGET == T_BANANA;
     using Tgt = GTarget<TARGET>;
+    using SBits = typename std::conditional<GL == 1, uint64_t, LaneBits128>::type;   // one sign bit per row position (7 carried + DMAX)
     const SkelParams &p;
     const int lane, d;
+    int hq = 0;                   // GL = 2: 4 h -- my half of every slot of eight (h = lane & 1)
+    int dl = 4;                   // GL = 2: how many coordinates of MY last four are real: d - 8 (LK - 1) - 4 h (<= 0: none, >= 4: all)
     Tgt tgt;
-    double y[LD];                 // y_i = x_i v_i
-    uint32_t sg0 = 0, sg1 = 0;    // bit i of (sg1:sg0) set <=> v_i = -1
+    double y[LD];                 // y_i = x_i v_i; register j = 4 s + g holds coordinate gi(j) = GE s + 4 h + g
+    uint32_t sg0 = 0, sg1 = 0, sg2 = 0, sg3 = 0;    // bit GE s + g of (sg3:sg2:sg1:sg0) set <=> v = -1 for register 4 s + g (GL = 1: bit j, two words)
     ChainRng rng;
     int32_t guard = 0;
-    double *tile;                 // this wave's LDS: 64 rows of LR doubles, then 64 x (sign bits, window offset, valid range)
+    double *tile;                 // this wave's LDS: CW rows of LR doubles, then CW x (sign bits, window offset, valid range), then the event-time lines
 
-    __device__ __forceinline__ LaneChain(const SkelParams &sp, int l, double *t_) : p(sp), lane(l), d(sp.d), tile(t_) { tgt.init(nullptr, sp.d); }
+    __device__ __forceinline__ LaneChain(const SkelParams &sp, int l, double *t_) : p(sp), lane(l), d(sp.d), tile(t_) {
+        tgt.init(nullptr, sp.d);
+        if constexpr (GL == 2) { hq = 4 * (l & 1); dl = sp.d - GE * (LK - 1) - hq; }
+    }
+    __device__ __forceinline__ bool head() const { if constexpr (GL == 1) return true; else return hq == 0; }   // the lane that does the chain's scalar stores
+    __device__ __forceinline__ int gi(int j) const { if constexpr (GL == 1) return j; else return GE * (j >> 2) + hq + (j & 3); }   // coordinate held by register j
 
     __device__ __forceinline__ static double sgn(double a, uint32_t s) {          // a * v for v = +-1 (exact): flip the sign bit
         return __hiloint2double(__double2hiint(a) ^ (int)s, __double2loint(a));
     }
-    __device__ __forceinline__ uint32_t sw(int i) const {                         // sign word of v_i: 0 or 0x80000000 (i is a constant after unrolling)
-        const uint32_t w = (i < 32) ? sg0 : sg1;
-        const int b = i & 31;
+    __device__ __forceinline__ uint32_t sw(int i) const {                         // sign word of register i's v: 0 or 0x80000000 (i is a constant after unrolling)
+        const int lb = GE * (i >> 2) + (i & 3);
+        const uint32_t w = (lb < 32) ? sg0 : ((lb < 64) ? sg1 : ((lb < 96) ? sg2 : sg3));
+        const int b = lb & 31;
         return (b == 31) ? (w & 0x80000000u) : ((w << (31 - b)) & 0x80000000u);
     }
     __device__ __forceinline__ double X(int i) const { return sgn(y[i], sw(i)); }
     __device__ __forceinline__ double V(int i) const { return __hiloint2double((int)(0x3ff00000u | sw(i)), 0); }
-    __device__ __forceinline__ bool in_dim(int i) const { return i < LANE_DMIN || i < d; }
+    __device__ __forceinline__ bool in_dim(int i) const {                         // register i holds a real coordinate
+        if constexpr (GL == 1) return i < LANE_DMIN || i < d;
+        else return i < LD - 4 || (i & 3) < dl;
+    }
     __device__ __forceinline__ static double gsum4(const double (&a)[4]) { return (a[0] + a[1]) + (a[2] + a[3]); }   // the xor-1, xor-2 butterfly
+    __device__ __forceinline__ static double csum(const double (&a)[4]) {         // the chain's sum: GL = 2 adds the xor-4 stage (the partner lane's four)
+        double r = gsum4(a);
+        if constexpr (GL == 2) r = r + dpp_d<DPP_QUAD_XOR1>(r);
+        return r;
+    }
+    // banana, slot 0 of a lane pair: coordinates 0, 1 (twisted) are registers 0, 1 of the head lane; the partner's are plain
+    template <class T> __device__ __forceinline__ T hgrad(int i, T x, const BananaSh<T> &sh) const {
+        if constexpr (GL == 1) return tgt.grad(i, x, sh);
+        else {
+            if (i >= 2) return x;
+            const T tw = (i == 0) ? sh.g0 : sh.r;
+            return head() ? tw : x;
+        }
+    }
 
     // ---- random stream, prefetched per pass of the state machine (as GroupChain's, without the lane pairing): a pass draws at most three
     // variates of a chain -- the bound's exponential, the acceptance uniform, the jump's uniform: stream positions n, n+1, n+2 = Philox
@@ -173,7 +231,7 @@ struct LaneChain {
     __device__ __forceinline__ double cell_general(int i, double t0, double t1, double h, const BananaSh<Dual> &sh0, const BananaSh<Dual> &sh1) const {
         const double v = V(i), x = X(i);
         const Dual xt0{fma(v, t0, x), v}, xt1{fma(v, t1, x), v};
-        const Dual gd0 = tgt.grad(i, xt0, sh0), gd1 = tgt.grad(i, xt1, sh1);
+        const Dual gd0 = hgrad(i, xt0, sh0), gd1 = hgrad(i, xt1, sh1);
         const double v0 = gd0.v * v, g0 = gd0.e * v, v1 = gd1.v * v, g1 = gd1.e * v;
         const double num = fma(-g0, t0, fma(g1, t1, v0 - v1));
         const double den = g1 - g0;
@@ -218,7 +276,7 @@ struct LaneChain {
                     }
                     LANE_SLOT_FENCE(part, t1);
                 }
-                const double bj = gsum4(part);
+                const double bj = csum(part);
                 b_acc += bj;
                 const double cj = b_acc * h;
                 if (!(cj < E)) { found = true; found_now = true; lbo = bj; }
@@ -234,6 +292,11 @@ struct LaneChain {
         return fin;
     }
 
+    // grad-U .* v of the twisted coordinate i = 0, 1 (plain: gv) -- the head lane's registers 0, 1
+    __device__ __forceinline__ double twisted(int i, double gv, const BananaSh<double> &sh) const {
+        const double gb = sgn(i == 0 ? sh.g0 : sh.r, sw(i));
+        if constexpr (GL == 1) return gb; else return head() ? gb : gv;
+    }
     // ---- GroupChain::true_rate for Zig-Zag: sum max(0, grad-U(x + v t) .* v) in the GROUP(4) order
     __device__ __forceinline__ double true_rate(double t) const {
         double part[4] = {0.0, 0.0, 0.0, 0.0};
@@ -246,23 +309,27 @@ struct LaneChain {
                 const int i = 4 * s + g;
                 if (in_dim(i)) {
                     double gv = y[i] + t;                                         // (x + v t) v
-                    if constexpr (kBanana) { if (i < 2) gv = sgn(i == 0 ? sh.g0 : sh.r, sw(i)); }
+                    if constexpr (kBanana) { if (i < 2) gv = twisted(i, gv, sh); }
                     part[g] += fmax(0.0, gv);
                 }
             }
             LANE_SLOT_FENCE(part, t);
         }
-        return gsum4(part);
+        return csum(part);
     }
     // The state is written in ONE place per pass of the state machine, outside every divergent region (no phi webs over the 104
     // registers of y): flow by tf -- the horizon, the accepted proposal's time, or -0.0 for a lane that does not move (y + (-0.0) = y
     // for every double, zeros included) -- and flip of coordinate m (-1: none).
-    __device__ __forceinline__ void flow_and_flip(double tf, int m) {
+    __device__ __forceinline__ void flow_and_flip(double tf, int mglob) {
+        // m: the sign bit / register position of the flipped coordinate in THIS lane, GE s + g (-1: none, or the partner lane's)
+        int m = mglob;
+        if constexpr (GL == 2) m = (mglob >= 0 && (mglob & 4) == hq) ? (mglob & ~4) : -1;
         const uint32_t bit = 1u << (m & 31);                                      // v[m] *= -1
         sg0 ^= (m >= 0 && m < 32) ? bit : 0u;
-        sg1 ^= (m >= 32) ? bit : 0u;
+        if constexpr (GL == 1) sg1 ^= (m >= 32) ? bit : 0u;
+        else { sg1 ^= (m >= 32 && m < 64) ? bit : 0u; sg2 ^= (m >= 64 && m < 96) ? bit : 0u; sg3 ^= (m >= 96) ? bit : 0u; }
         // the flip: one compare per slot of four, then per coordinate a select of the lane's word for g = m % 4 and the xor
-        const int ms = m >> 2, mg = m & 3;                                        // (m = -1: slot -1, no slot matches)
+        const int ms = m >> (GL == 1 ? 2 : 3), mg = m & 3;                        // (m = -1: slot -1, no slot matches)
         const uint32_t x0 = (mg == 0) ? 0x80000000u : 0u, x1 = (mg == 1) ? 0x80000000u : 0u, x2 = (mg == 2) ? 0x80000000u : 0u,
                        x3 = (mg == 3) ? 0x80000000u : 0u;
 #pragma unroll
@@ -287,10 +354,10 @@ struct LaneChain {
             for (int g = 0; g < 4; ++g) {
                 const int i = 4 * s + g;
                 double gv = y[i] + t;                                             // x v at the accepted point
-                if constexpr (kBanana) { if (i < 2) gv = sgn(i == 0 ? sh.g0 : sh.r, sw(i)); }
+                if constexpr (kBanana) { if (i < 2) gv = twisted(i, gv, sh); }
                 l[g] = in_dim(i) ? fmax(0.0, gv) : 0.0;
             }
-            const double T = gsum4(l);
+            const double T = csum(l);
             if (ms_hit < 0 && (carry + T > theta)) { ms_hit = s; carry_at = carry; lh[0] = l[0]; lh[1] = l[1]; lh[2] = l[2]; lh[3] = l[3]; }
             carry = carry + T;
             LANE_SLOT_FENCE(lh, t);
@@ -299,11 +366,33 @@ struct LaneChain {
 #endif
         }
         int m = -1;
-        if (ms_hit >= 0) {                                                        // Kogge-Stone inclusive scan of the hit slot, written out
-            const double a1 = lh[1] + lh[0], a2 = lh[2] + lh[1], a3 = lh[3] + lh[2];
-            const double inc[4] = {lh[0], a1, a2 + lh[0], a3 + a1};
+        if constexpr (GL == 1) {
+            if (ms_hit >= 0) {                                                    // Kogge-Stone inclusive scan of the hit slot, written out
+                const double a1 = lh[1] + lh[0], a2 = lh[2] + lh[1], a3 = lh[3] + lh[2];
+                const double inc[4] = {lh[0], a1, a2 + lh[0], a3 + a1};
 #pragma unroll
-            for (int g = 3; g >= 0; --g) if ((4 * ms_hit + g < d) && (carry_at + inc[g] > theta)) m = 4 * ms_hit + g;
+                for (int g = 3; g >= 0; --g) if ((4 * ms_hit + g < d) && (carry_at + inc[g] > theta)) m = 4 * ms_hit + g;
+            }
+        } else {
+            // the hit slot's eight rates in both lanes of the pair, then the three Kogge-Stone steps (offsets 1, 2, 4) written out
+            double l8[8];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const double ph = dpp_d<DPP_QUAD_XOR1>(lh[g]);                    // (zeros while no slot is hit; both lanes of a pair are in here together)
+                l8[g] = head() ? lh[g] : ph;
+                l8[4 + g] = head() ? ph : lh[g];
+            }
+            if (ms_hit >= 0) {
+                double a[8], b[8], c[8];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) a[g] = (g >= 1) ? l8[g] + l8[g - 1] : l8[g];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) b[g] = (g >= 2) ? a[g] + a[g - 2] : a[g];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) c[g] = (g >= 4) ? b[g] + b[g - 4] : b[g];
+#pragma unroll
+                for (int g = 7; g >= 0; --g) if ((8 * ms_hit + g < d) && (carry_at + c[g] > theta)) m = 8 * ms_hit + g;
+            }
         }
         if (m < 0) m = d - 1;
         return m;
@@ -331,8 +420,30 @@ struct LaneChain {
     unsigned long long st_acc[16], st_last = 0;
     int st_cur = 8;
 #endif
-    int cl = 0;                                                                   // carried doubles (row positions 0 .. cl - 1 of my LDS row)
-    uint32_t Sc0 = 0, Sc1 = 0;                                                    // sign bits of the carried doubles
+    int cl = 0;                                                                   // carried doubles (row positions 0 .. cl - 1 of my chain's LDS row)
+    SBits Sc{};                                                                   // sign bits of the carried doubles
+    // sign bits of the chain's coordinates in coordinate order (row order).  GL = 2: my bits sit at 8 s + g; shifted by 4 h and
+    // or-ed with the partner's they are the row's -- all lanes of the wave must be here (DPP).
+    __device__ __forceinline__ SBits signs_row() const {
+        if constexpr (GL == 1) return ((uint64_t)sg1 << 32) | (uint64_t)sg0;
+        else {
+            LaneBits128 o{((uint64_t)sg1 << 32) | (uint64_t)sg0, ((uint64_t)sg3 << 32) | (uint64_t)sg2};
+            o = lb_shl(o, hq);
+            const uint32_t w0 = (uint32_t)o.lo, w1 = (uint32_t)(o.lo >> 32), w2 = (uint32_t)o.hi, w3 = (uint32_t)(o.hi >> 32);
+            const uint32_t q0 = dpp_xor1_u32(w0), q1 = dpp_xor1_u32(w1), q2 = dpp_xor1_u32(w2), q3 = dpp_xor1_u32(w3);
+            return {o.lo | (((uint64_t)q1 << 32) | (uint64_t)q0), o.hi | (((uint64_t)q3 << 32) | (uint64_t)q2)};
+        }
+    }
+    __device__ __forceinline__ static SBits low_bits(SBits x, int a) {            // the lowest a <= 7 bits
+        if constexpr (GL == 1) return x & ((1ull << a) - 1ull);
+        else return {x.lo & ((1ull << a) - 1ull), 0ull};
+    }
+    // my registers into the chain's LDS row whose coordinate 0 is at `row0` (GL = 2: the two lanes of a pair interleave fours)
+    __device__ __forceinline__ void row_put(double *row0) const {
+        double *w = row0 + hq;
+#pragma unroll
+        for (int j = 0; j < LD; ++j) w[GE * (j >> 2) + (j & 3)] = y[j];
+    }
     // A segment that starts at event k_first >= 1 of chain c starts a = (address of X[c, k_first, 0] / 8) mod 8 doubles into a 64-byte
     // line -- per chain: round 3 dropped the preconditions "X on a line, n_sk d a multiple of 8" under which a was the same for the
     // whole wave.  Those a doubles in front of it are the tail of the previous event's row, i.e. of the very state the segment starts
@@ -340,24 +451,22 @@ struct LaneChain {
     // again (the previous segment's flush, or record_initial, wrote the same bytes), so no row position ever has to be skipped.  The
     // one row whose head may share a line with something that is not the chain's -- column 0 -- never comes through here
     // (record_initial); the chain's last line goes out as a partial line (flush_carry).  V uses the same offsets from its own base: it
-    // is line-exact when it has X's phase inside a line, correct anywhere.  Called with y, sg loaded, k_first >= 1.
+    // is line-exact when it has X's phase inside a line, correct anywhere.  Called with y, sg loaded, k_first >= 1, by every lane.
     __device__ __forceinline__ void open_window(int64_t b, int64_t c, int64_t k_first) {
-        const size_t first = (size_t)b * WAVE * (size_t)p.n_sk * (size_t)d;
-        int64_t chains = p.C - b * WAVE;
-        if (chains > WAVE) chains = WAVE;
+        const size_t first = (size_t)b * CW * (size_t)p.n_sk * (size_t)d;
+        int64_t chains = p.C - b * CW;
+        if (chains > CW) chains = CW;
         const int bytes = (int)(chains * p.n_sk * d * 8);
         rsX = __builtin_amdgcn_make_buffer_rsrc(p.X + first, 0, bytes, 0x00020000);
         rsV = __builtin_amdgcn_make_buffer_rsrc(p.V + first, 0, bytes, 0x00020000);
         const int a = (int)(((uintptr_t)(p.X + ((size_t)c * (size_t)p.n_sk + (size_t)k_first) * (size_t)d) >> 3) & 7u);   // per chain
         cl = a;
-        Sc0 = Sc1 = 0;
         {                                                                         // (all lanes: a = 0 moves nothing that is read)
             int l = lane;
             asm volatile("" : "+v"(l));
-            double *myrow = tile + l * LR;
+            double *myrow = tile + (l >> (GL - 1)) * LR;
             __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int j = 0; j < LD; ++j) myrow[7 + j] = y[j];                     // the state's coordinates at row positions 7 .. 7 + LD - 1
+            row_put(myrow + 7);                                                   // the state's coordinates at row positions 7 .. 7 + DMAX - 1
             __builtin_amdgcn_wave_barrier();
             const double *from = myrow + 7 + (d - a);                             // its last a coordinates
             double mv[7];
@@ -365,53 +474,78 @@ struct LaneChain {
             for (int j = 0; j < 7; ++j) mv[j] = from[j];
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int j = 0; j < 7; ++j) myrow[j] = mv[j];                         // (positions >= a are overwritten by the next row)
-            const uint64_t Sn = ((((uint64_t)sg1 << 32) | sg0) >> (d - a)) & ((1ull << a) - 1ull);
-            Sc0 = (uint32_t)Sn; Sc1 = (uint32_t)(Sn >> 32);
+            for (int j = 0; j < 7; ++j) myrow[j] = mv[j];                         // (positions >= a are overwritten by the next row; a pair writes the same values twice)
+            Sc = low_bits(lb_shr(signs_row(), d - a), a);
         }
         tfirst = (int)(((uintptr_t)(p.t + (size_t)c * (size_t)p.n_sk + (size_t)k_first) >> 3) & 7);
         tlast = -1;
     }
     // Event times: 8 bytes per event, eight events of a chain per 64-byte line -- stored one by one each would leave the L2 as a
-    // partial line.  They wait in LDS (slot = the time's position in its line, [slot][lane]) until the line is complete.
+    // partial line.  They wait in LDS (slot = the time's position in its line, [slot][chain of the wave]) until the line is complete.
     int tfirst = 0, tlast = -1;                                                   // first valid slot of the line being filled; last slot filled (-1: nothing waits)
     typedef double d2 __attribute__((ext_vector_type(2)));
     __device__ __forceinline__ void store_times(double *line, const double *ring, int lo, int hi) {   // slots lo..hi of my line
         if (lo == 0 && hi == 7) {
             d2 *dst = (d2 *)line;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { d2 v; v.x = ring[(2 * j) * WAVE]; v.y = ring[(2 * j + 1) * WAVE]; dst[j] = v; }
+            for (int j = 0; j < 4; ++j) { d2 v; v.x = ring[(2 * j) * CW]; v.y = ring[(2 * j + 1) * CW]; dst[j] = v; }
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) if (j >= lo && j <= hi) line[j] = ring[j * WAVE];
+            for (int j = 0; j < 8; ++j) if (j >= lo && j <= hi) line[j] = ring[j * CW];
         }
     }
-    // store parameters of a chain, 16 bytes: S (two words), window offset of row position 0 (kNoRow: nothing to store), nfull << 8
-    template <int W, int NR, bool LO, bool HI>      // W positions x 64 / W chains per store, NR stores; LO / HI: check position >= skip / < nfull
+    // store parameters of a chain: S (GL = 1: two words; GL = 2: four), window offset of row position 0 (kNoRow: nothing to store),
+    // nfull << 8 -- 16 bytes (GL = 2: 32, the last 8 unused).  A tile that starts at row position q reads the sign word of q.
+    struct TileMeta { uint32_t s, off, nf; };
+    __device__ __forceinline__ TileMeta tile_meta(int q, int grp, int ch) const { // chain ch + grp of the wave (ch a constant: folds into the DS offset)
+        if constexpr (GL == 1) {
+            const u32x4 v = ((const u32x4 *)(tile + CW * LR) + grp)[ch];
+            return {(q >= 32) ? v.y : v.x, v.z, v.w};
+        } else {
+            const uint32_t *mw = (const uint32_t *)(tile + CW * LR) + 8 * grp + 8 * ch;
+            const u32x2 v = *(const u32x2 *)(mw + 4);
+            return {mw[q >> 5], v.x, v.y};
+        }
+    }
+    __device__ __forceinline__ void meta_put(int cwi, SBits S, uint32_t off, uint32_t nf) {
+        if constexpr (GL == 1) {
+            u32x4 m;
+            m.x = (uint32_t)S; m.y = (uint32_t)(S >> 32); m.z = off; m.w = nf;
+            *((u32x4 *)(tile + CW * LR) + cwi) = m;
+        } else if (head()) {
+            uint32_t *mw = (uint32_t *)(tile + CW * LR) + 8 * cwi;
+            u32x4 m;
+            m.x = (uint32_t)S.lo; m.y = (uint32_t)(S.lo >> 32); m.z = (uint32_t)S.hi; m.w = (uint32_t)(S.hi >> 32);
+            *(u32x4 *)mw = m;
+            u32x2 o;
+            o.x = off; o.y = nf;
+            *(u32x2 *)(mw + 4) = o;
+        }
+    }
+    template <int W, bool LO, bool HI>              // W positions x 64 / W chains per store; LO / HI: check position >= skip / < nfull
     __device__ __forceinline__ void store_tile(int q, int l) {                    // l = lane (opaque copy: see record)
-        constexpr int CH = WAVE / W;                                              // chains per store: store r covers chains CH r .. CH r + CH - 1
+        constexpr int CH = WAVE / W, NR = CW / CH;                                // chains per store: store r covers chains CH r .. CH r + CH - 1
         const int sub = l & (W - 1), grp = l / W;
         const uint32_t pos = (uint32_t)(q + sub);
         const uint32_t sh = 31u - (pos & 31u);                                    // the sign bit of position q + sub, moved to bit 31
         const double *tb = tile + grp * LR + pos;                                 // one base address per array; the chain of store r lies a
-        const u32x4 *mb = (const u32x4 *)(tile + WAVE * LR) + grp;                // constant further on (folds into the DS offset)
+                                                                                  // constant further on (folds into the DS offset)
         // LDS reads of LANE_BATCH stores are issued together, then their stores: one wave per SIMD runs in order, and a read that
         // is waited for before every store costs its ~100-cycle round trip 56 times per event row
         constexpr int NB = NR < LANE_BATCH ? NR : LANE_BATCH;
 #pragma unroll
         for (int r0 = 0; r0 < NR; r0 += NB) {
-            u32x4 m[NB];
+            TileMeta m[NB];
             double yv[NB];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) { m[b] = mb[CH * (r0 + b)]; yv[b] = tb[CH * (r0 + b) * LR]; }
+            for (int b = 0; b < NB; ++b) { m[b] = tile_meta(q, grp, CH * (r0 + b)); yv[b] = tb[CH * (r0 + b) * LR]; }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                uint32_t off = m[b].z + pos * 8u;
-                if constexpr (LO) off = (pos >= (m[b].w & 0xffu)) ? off : kNoRow;
-                if constexpr (HI) off = (pos < (m[b].w >> 8)) ? off : kNoRow;
-                const uint32_t w = (q >= 32) ? m[b].y : m[b].x;
-                const uint32_t s31 = (w << sh) & 0x80000000u;
+                uint32_t off = m[b].off + pos * 8u;
+                if constexpr (LO) off = (pos >= (m[b].nf & 0xffu)) ? off : kNoRow;
+                if constexpr (HI) off = (pos < (m[b].nf >> 8)) ? off : kNoRow;
+                const uint32_t s31 = (m[b].s << sh) & 0x80000000u;
                 u32x2 xv, vv;
                 xv.x = (uint32_t)__double2loint(yv[b]); xv.y = (uint32_t)__double2hiint(yv[b]) ^ s31;
                 vv.x = 0u; vv.y = 0x3ff00000u | s31;
@@ -423,28 +557,27 @@ struct LaneChain {
     }
     // The same with TWO consecutive positions per lane and 16-byte stores (half the store instructions): tiles that need no lower
     // (a pair of positions (even, odd) lies on one side of nfull, a multiple of 8).  W positions per
-    // tile, W / 2 lanes per chain, 128 / W chains per store, W / 2 stores.
+    // tile, W / 2 lanes per chain, 128 / W chains per store.
     template <int W, bool HI>
     __device__ __forceinline__ void store_tile2(int q, int l) {
-        constexpr int LPC = W / 2, CH = WAVE / LPC, NR = WAVE / CH;               // lanes per chain, chains per store, stores per tile
+        constexpr int LPC = W / 2, CH = WAVE / LPC, NR = CW / CH;                 // lanes per chain, chains per store, stores per tile
         const int sub = l & (LPC - 1), grp = l / LPC;
         const uint32_t pos = (uint32_t)(q + 2 * sub);                             // even; pos and pos + 1 share a sign word
         const uint32_t sh = 31u - (pos & 31u);
         const double *tb = tile + grp * LR + pos;
-        const u32x4 *mb = (const u32x4 *)(tile + WAVE * LR) + grp;
         constexpr int NB = NR < LANE_BATCH ? NR : LANE_BATCH;
 #pragma unroll
         for (int r0 = 0; r0 < NR; r0 += NB) {
-            u32x4 m[NB];
+            TileMeta m[NB];
             double ya[NB], yb[NB];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) { m[b] = mb[CH * (r0 + b)]; ya[b] = tb[CH * (r0 + b) * LR]; yb[b] = tb[CH * (r0 + b) * LR + 1]; }
+            for (int b = 0; b < NB; ++b) { m[b] = tile_meta(q, grp, CH * (r0 + b)); ya[b] = tb[CH * (r0 + b) * LR]; yb[b] = tb[CH * (r0 + b) * LR + 1]; }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                uint32_t off = m[b].z + pos * 8u;
-                if constexpr (HI) off = (pos < (m[b].w >> 8)) ? off : kNoRow;
-                const uint32_t w = (q >= 32) ? m[b].y : m[b].x;
+                uint32_t off = m[b].off + pos * 8u;
+                if constexpr (HI) off = (pos < (m[b].nf >> 8)) ? off : kNoRow;
+                const uint32_t w = m[b].s;
                 const uint32_t sa = (w << sh) & 0x80000000u, sb = (w << (sh - 1u)) & 0x80000000u;
                 u32x4 xv, vv;
                 xv.x = (uint32_t)__double2loint(ya[b]); xv.y = (uint32_t)__double2hiint(ya[b]) ^ sa;
@@ -461,31 +594,26 @@ struct LaneChain {
         int l = lane;
         asm volatile("" : "+v"(l));               // LDS addresses are rebuilt here from an opaque copy of the lane id: hoisted out of the
                                                   // event loop they would occupy ~50 registers for the whole launch
-        double *myrow = tile + l * LR;
-        u32x4 *meta = (u32x4 *)(tile + WAVE * LR) + l;
+        const int cwi = l >> (GL - 1);            // my chain's row
+        double *myrow = tile + cwi * LR;
         const int total = cl + d, nfull = total & ~7;
-        const uint64_t S = (((uint64_t)Sc1 << 32) | Sc0) | ((((uint64_t)sg1 << 32) | sg0) << cl);
-        u32x4 m;
-        m.x = (uint32_t)S; m.y = (uint32_t)(S >> 32);
-        m.z = rec ? (((uint32_t)l * (uint32_t)p.n_sk + (uint32_t)k) * (uint32_t)d - (uint32_t)cl) * 8u : kNoRow;
-        m.w = (uint32_t)nfull << 8;
+        const SBits S = lb_or(Sc, lb_shl(signs_row(), cl));
+        const uint32_t off = rec ? (((uint32_t)cwi * (uint32_t)p.n_sk + (uint32_t)k) * (uint32_t)d - (uint32_t)cl) * 8u : kNoRow;
         __builtin_amdgcn_wave_barrier();
         LANE_MARK(9);
-        *meta = m;
-        double *wrow = myrow + cl;
-#pragma unroll
-        for (int j = 0; j < LD; ++j) wrow[j] = y[j];
+        meta_put(cwi, S, off, (uint32_t)nfull << 8);
+        row_put(myrow + cl);
         __builtin_amdgcn_wave_barrier();
         LANE_MARK(10);
         // nfull = 8 floor((cl + d) / 8) lies in [NF_MIN, NF_MAX]: whole tiles of 16 positions below NF_MIN need no check, the rest goes out as
         // tiles of 8 positions checked against nfull
-        constexpr int NF_MIN = LANE_DMIN & ~7, NF_MAX = (LD + 7) & ~7, Q0 = NF_MIN & ~15;
+        constexpr int NF_MIN = LANE_DMIN & ~7, NF_MAX = (DMAX + 7) & ~7, Q0 = NF_MIN & ~15;
 #ifdef LANE_STORE_B64              // A/B builds: 8-byte stores
 #pragma unroll
-        for (int q = 0; q < Q0; q += 16) store_tile<16, 16, false, false>(q, l);
+        for (int q = 0; q < Q0; q += 16) store_tile<16, false, false>(q, l);
         LANE_MARK(13);
 #pragma unroll
-        for (int q = Q0; q < NF_MAX; q += 8) store_tile<8, 8, false, true>(q, l);
+        for (int q = Q0; q < NF_MAX; q += 8) store_tile<8, false, true>(q, l);
 #else
 #pragma unroll
         for (int q = 0; q < Q0; q += 16) store_tile2<16, false>(q, l);
@@ -502,48 +630,53 @@ struct LaneChain {
             for (int j = 0; j < 7; ++j) mv[j] = from[j];
 #pragma unroll
             for (int j = 0; j < 7; ++j) myrow[j] = mv[j];
-            const uint64_t Sn = S >> nfull;
-            Sc0 = (uint32_t)Sn; Sc1 = (uint32_t)(Sn >> 32);
+            Sc = lb_shr(S, nfull);
             cl = total - nfull;
             const size_t e = (size_t)c * (size_t)p.n_sk + (size_t)k;
-            double *ring = tile + WAVE * LR + 2 * WAVE + l;
             const int slot = (int)(((uintptr_t)(p.t + e) >> 3) & 7);
-            ring[slot * WAVE] = t;
-            tlast = slot;
-            if (slot == 7) { store_times(p.t + e - 7, ring, tfirst, 7); tfirst = 0; tlast = -1; }
-            if constexpr (DIAG) {
-                if (p.H) p.H[e] = horizon;
-                if (p.AR) p.AR[e] = ar;
-                if (p.EB) p.EB[e] = errored;
-                if (p.RJ) p.RJ[e] = rejected;
-                if (p.HH) p.HH[e] = hits;
-                if (p.EV) {
+            if (head()) {
+                double *ring = tile + CW * LR + MD * CW + cwi;
+                ring[slot * CW] = t;
+                if (slot == 7) store_times(p.t + e - 7, ring, tfirst, 7);
+                if constexpr (DIAG) {
+                    if (p.H) p.H[e] = horizon;
+                    if (p.AR) p.AR[e] = ar;
+                    if (p.EB) p.EB[e] = errored;
+                    if (p.RJ) p.RJ[e] = rejected;
+                    if (p.HH) p.HH[e] = hits;
+                    if (p.EV) {
 #pragma unroll
-                    for (int q = 0; q < 5; ++q) p.EV[5 * e + q] = ev[q];
+                        for (int q = 0; q < 5; ++q) p.EV[5 * e + q] = ev[q];
+                    }
                 }
             }
+            tlast = slot;
+            if (slot == 7) { tfirst = 0; tlast = -1; }
         }
         LANE_MARK(15);
     }
-    // Column 0 (sample.jl:272; a resumed chunk: the previous chunk's last event again): each lane its own row, straight from the
+    // Column 0 (sample.jl:272; a resumed chunk: the previous chunk's last event again): each lane its own coordinates, straight from the
     // registers -- once per chain, and the only row whose head can share a 64-byte line with bytes that are not the chain's (the
     // previous chain's last row, or whatever precedes X): nothing but the row itself is written.
     __device__ __forceinline__ void record_initial(bool rec, int64_t c, double t, double horizon, double ar) {
-        if (!rec) return;
         const size_t e = (size_t)c * (size_t)p.n_sk;
         double *Xe = p.X + e * (size_t)d, *Ve = p.V + e * (size_t)d;
+        if (rec) {
 #pragma unroll
-        for (int i = 0; i < LD; ++i) if (in_dim(i)) { Xe[i] = X(i); Ve[i] = V(i); }
-        p.t[e] = t;
-        if constexpr (DIAG) {
-            if (p.H) p.H[e] = horizon;
-            if (p.AR) p.AR[e] = ar;
-            if (p.EB) p.EB[e] = 0;
-            if (p.RJ) p.RJ[e] = 0;
-            if (p.HH) p.HH[e] = 0;
-            if (p.EV) {
+            for (int i = 0; i < LD; ++i) if (in_dim(i)) { Xe[gi(i)] = X(i); Ve[gi(i)] = V(i); }
+        }
+        if (rec && head()) {
+            p.t[e] = t;
+            if constexpr (DIAG) {
+                if (p.H) p.H[e] = horizon;
+                if (p.AR) p.AR[e] = ar;
+                if (p.EB) p.EB[e] = 0;
+                if (p.RJ) p.RJ[e] = 0;
+                if (p.HH) p.HH[e] = 0;
+                if (p.EV) {
 #pragma unroll
-                for (int q = 0; q < 5; ++q) p.EV[5 * e + q] = 0.0;
+                    for (int q = 0; q < 5; ++q) p.EV[5 * e + q] = 0.0;
+                }
             }
         }
     }
@@ -551,23 +684,22 @@ struct LaneChain {
     __device__ __forceinline__ void flush_carry(bool mine, int64_t c, int32_t k) {
         int l = lane;
         asm volatile("" : "+v"(l));
-        u32x4 m;
-        m.x = Sc0; m.y = Sc1;
-        m.z = (mine && cl > 0) ? (((uint32_t)l * (uint32_t)p.n_sk + (uint32_t)k) * (uint32_t)d - (uint32_t)cl) * 8u : kNoRow;
-        m.w = (uint32_t)cl << 8;
+        const int cwi = l >> (GL - 1);
+        const uint32_t off = (mine && cl > 0) ? (((uint32_t)cwi * (uint32_t)p.n_sk + (uint32_t)k) * (uint32_t)d - (uint32_t)cl) * 8u : kNoRow;
         __builtin_amdgcn_wave_barrier();
-        *((u32x4 *)(tile + WAVE * LR) + l) = m;
+        meta_put(cwi, Sc, off, (uint32_t)cl << 8);
         __builtin_amdgcn_wave_barrier();
-        store_tile<8, 8, false, true>(0, l);
+        store_tile<8, false, true>(0, l);
         __builtin_amdgcn_wave_barrier();
         cl = 0;
-        if (mine && tlast >= 0)                                                   // the event times of an incomplete line; k - 1 = my last event, in slot tlast
-            store_times(p.t + ((size_t)c * (size_t)p.n_sk + (size_t)k - 1 - (size_t)tlast), tile + WAVE * LR + 2 * WAVE + l, tfirst, tlast);
+        if (mine && head() && tlast >= 0)                                         // the event times of an incomplete line; k - 1 = my last event, in slot tlast
+            store_times(p.t + ((size_t)c * (size_t)p.n_sk + (size_t)k - 1 - (size_t)tlast), tile + CW * LR + MD * CW + cwi, tfirst, tlast);
         tlast = -1;
     }
 
-    // ---- GroupChain::run_segment for the 64 chains of this wave.  Hand-off state of batch b (private to this kernel): word w of
-    // the chain in lane l at state[(b (2d+4) + w) 64 + l] -- y_0..y_{d-1}, the sign words, t, horizon, ar, the stream position.
+    // ---- GroupChain::run_segment for the CW chains of this wave.  Hand-off state (private to this kernel): word w of chain cs at
+    // state[((cs / 64) (2d+4) + w) 64 + cs % 64] -- y_0..y_{d-1}, the sign words (GL = 1: one double; GL = 2: two per lane of the
+    // pair, each lane its own), t, horizon, ar, the stream position.
     __device__ __forceinline__ void run_segment(int64_t b, int64_t c, bool chain_ok, int r, int64_t seg_len, double *state, int budget, int nseg = 1) {
         const int64_t k_begin = 1 + (int64_t)r * seg_len;
         int64_t k_end = k_begin + seg_len;
@@ -581,25 +713,33 @@ struct LaneChain {
         double *st = state + (size_t)(cs >> 6) * (size_t)(2 * d + 4) * WAVE + (size_t)(cs & 63);
         double t = 0.0, horizon = p.tmax, ar = 0.0;
         uint64_t n0 = 0;
-        sg0 = 0; sg1 = 0;
+        sg0 = 0; sg1 = 0; sg2 = 0; sg3 = 0;
+        constexpr int NSD = GL == 1 ? 1 : 2;                                      // doubles of sign words per lane
+        const int w_sg = d + (GL == 1 ? 0 : (hq >> 1)), w_sc = d + NSD * GL;      // my sign words; t, horizon, ar, stream position
         bool from_state = r > 0;
         if constexpr (DIAG) from_state = from_state || p.resume != 0;
         if (from_state) {
 #pragma unroll
-            for (int i = 0; i < LD; ++i) y[i] = in_dim(i) ? st[(size_t)i * WAVE] : 0.0;
-            const uint64_t sgw = (uint64_t)__double_as_longlong(st[(size_t)d * WAVE]);
+            for (int i = 0; i < LD; ++i) y[i] = in_dim(i) ? st[(size_t)gi(i) * WAVE] : 0.0;
+            const uint64_t sgw = (uint64_t)__double_as_longlong(st[(size_t)w_sg * WAVE]);
             sg0 = (uint32_t)sgw; sg1 = (uint32_t)(sgw >> 32);
-            t = st[(size_t)(d + 1) * WAVE]; horizon = st[(size_t)(d + 2) * WAVE]; ar = st[(size_t)(d + 3) * WAVE];
-            n0 = (uint64_t)__double_as_longlong(st[(size_t)(d + 4) * WAVE]);
+            if constexpr (GL == 2) {
+                const uint64_t sgx = (uint64_t)__double_as_longlong(st[(size_t)(w_sg + 1) * WAVE]);
+                sg2 = (uint32_t)sgx; sg3 = (uint32_t)(sgx >> 32);
+            }
+            t = st[(size_t)w_sc * WAVE]; horizon = st[(size_t)(w_sc + 1) * WAVE]; ar = st[(size_t)(w_sc + 2) * WAVE];
+            n0 = (uint64_t)__double_as_longlong(st[(size_t)(w_sc + 3) * WAVE]);
         } else {
 #pragma unroll
             for (int i = 0; i < LD; ++i) {
                 const bool ok = chain_ok && in_dim(i);
-                const double xi = ok ? p.xinit[(size_t)cs * d + i] : 0.0;
-                const double vi = ok ? p.vinit[(size_t)cs * d + i] : 1.0;
+                const double xi = ok ? p.xinit[(size_t)cs * d + gi(i)] : 0.0;
+                const double vi = ok ? p.vinit[(size_t)cs * d + gi(i)] : 1.0;
                 const uint32_t s = (uint32_t)__double2hiint(vi) & 0x80000000u;
                 y[i] = sgn(xi, s);
-                if (i < 32) sg0 |= (s >> 31) << (i & 31); else sg1 |= (s >> 31) << (i & 31);
+                const int lb = GE * (i >> 2) + (i & 3);
+                if (lb < 32) sg0 |= (s >> 31) << (lb & 31); else if (lb < 64) sg1 |= (s >> 31) << (lb & 31);
+                else if (lb < 96) sg2 |= (s >> 31) << (lb & 31); else sg3 |= (s >> 31) << (lb & 31);
             }
         }
         if (r == 0) record_initial(chain_ok, c, t, horizon, ar);                  // (k_begin = 1: the segment's window opens behind column 0)
@@ -675,7 +815,7 @@ struct LaneChain {
                         propose = tp < horizon;
                     }
                     mode = FRESH;
-                    if (++it > cap) { done = true; atomicAdd(&p.status[0], 1); }
+                    if (++it > cap) { done = true; if (head()) atomicAdd(&p.status[0], 1); }
                 }
             }
             LANE_MARK(3);
@@ -712,7 +852,7 @@ struct LaneChain {
                 if constexpr (DIAG) { if (!(t < p.t_stop)) { done = true; stopped = true; } }
             }
             LANE_MARK(7);
-            if (proposed && ++it > cap && !done) { done = true; atomicAdd(&p.status[0], 1); }
+            if (proposed && ++it > cap && !done) { done = true; if (head()) atomicAdd(&p.status[0], 1); }
         }
         LANE_MARK(8);
 #ifdef PDMP_STAMP
@@ -733,27 +873,30 @@ struct LaneChain {
         // would address belongs to another chain of the original ensemble.
         if (chain_ok) {
 #pragma unroll
-            for (int i = 0; i < LD; ++i) if (in_dim(i)) publish(st + (size_t)i * WAVE, y[i]);
-            publish(st + (size_t)d * WAVE, __longlong_as_double((long long)(((uint64_t)sg1 << 32) | (uint64_t)sg0)));
-            publish(st + (size_t)(d + 1) * WAVE, t); publish(st + (size_t)(d + 2) * WAVE, horizon); publish(st + (size_t)(d + 3) * WAVE, ar);
-            publish(st + (size_t)(d + 4) * WAVE, __longlong_as_double((long long)rng.n));
+            for (int i = 0; i < LD; ++i) if (in_dim(i)) publish(st + (size_t)gi(i) * WAVE, y[i]);
+            publish(st + (size_t)w_sg * WAVE, __longlong_as_double((long long)(((uint64_t)sg1 << 32) | (uint64_t)sg0)));
+            if constexpr (GL == 2) publish(st + (size_t)(w_sg + 1) * WAVE, __longlong_as_double((long long)(((uint64_t)sg3 << 32) | (uint64_t)sg2)));
+            if (head()) {
+                publish(st + (size_t)w_sc * WAVE, t); publish(st + (size_t)(w_sc + 1) * WAVE, horizon); publish(st + (size_t)(w_sc + 2) * WAVE, ar);
+                publish(st + (size_t)(w_sc + 3) * WAVE, __longlong_as_double((long long)rng.n));
+            }
         }
-        if (guard) { atomicAdd(&p.status[1], guard); guard = 0; }
+        if (guard) { if (head()) atomicAdd(&p.status[1], guard); guard = 0; }
         if constexpr (TAPE) { if (tp_over && chain_ok) atomicAdd(&p.status[3], 1); }
         if constexpr (DIAG) {
-            if (p.count && chain_ok && !fin_before && (stopped || r == nseg - 1)) p.count[c] = (int64_t)k;
-            if (p.count && chain_ok && fin_before && r == 0) p.count[c] = 1;
+            if (p.count && chain_ok && head() && !fin_before && (stopped || r == nseg - 1)) p.count[c] = (int64_t)k;
+            if (p.count && chain_ok && head() && fin_before && r == 0) p.count[c] = 1;
         }
     }
 };
 
-template <int TARGET, int LK, bool DIAG, bool TAPE = false>
+template <int TARGET, int LK, bool DIAG, bool TAPE = false, int GL = 1>
 __global__ __launch_bounds__(256, LANE_WAVES) void lane_kernel(const GroupParams gp, const int32_t *flag) {
     if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;      // not unit speeds: the group kernel runs instead
     extern __shared__ double smem[];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
-    double *tile = smem + (size_t)wave * lane_lds_per_wave(LK);
-    LaneChain<TARGET, LK, DIAG, TAPE> chain(gp.s, lane, tile);
+    double *tile = smem + (size_t)wave * lane_lds_per_wave(LK, GL);
+    LaneChain<TARGET, LK, DIAG, TAPE, GL> chain(gp.s, lane, tile);
     const int nb = (int)gp.nb, n_units = nb * gp.nseg;
     bool lost = false;
     for (int pulled = 0; pulled <= n_units && !lost; ++pulled) {
@@ -764,7 +907,7 @@ __global__ __launch_bounds__(256, LANE_WAVES) void lane_kernel(const GroupParams
         const int r = u / nb, b = u - r * nb;
         if (r > 0) lost = !wait_progress(gp.progress + b, r);
         if (!lost) {
-            const int64_t c = (int64_t)b * WAVE + lane;
+            const int64_t c = (int64_t)b * (WAVE / GL) + (lane >> (GL - 1));
             chain.run_segment(b, c, c < gp.s.C, r, gp.seg_len, gp.state, gp.cell_budget, gp.nseg);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(&gp.progress[b], r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -788,12 +931,12 @@ inline void lane_schedule(int64_t nb, int64_t slots, int64_t n_sk, int force, in
     nseg = (int32_t)((events + seg_len - 1) / seg_len);
 }
 
-template <int TARGET, int LK, bool DIAG, bool TAPE = false>
+template <int TARGET, int LK, bool DIAG, bool TAPE = false, int GL = 1>
 inline hipError_t launch_lane(const GroupParams &gp_in, const int32_t *flag, int rounds, hipStream_t stream) {
     GroupParams gp = gp_in;
     constexpr int wpb = 4;
-    const size_t lds = (size_t)wpb * lane_lds_per_wave(LK) * sizeof(double);
-    void (*kernel)(const GroupParams, const int32_t *) = lane_kernel<TARGET, LK, DIAG, TAPE>;
+    const size_t lds = (size_t)wpb * lane_lds_per_wave(LK, GL) * sizeof(double);
+    void (*kernel)(const GroupParams, const int32_t *) = lane_kernel<TARGET, LK, DIAG, TAPE, GL>;
     int per_cu = 0, dev = 0, cus = 0;
     hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -803,7 +946,7 @@ inline hipError_t launch_lane(const GroupParams &gp_in, const int32_t *flag, int
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (per_cu < 1) per_cu = 1;
     if (cus < 1) cus = 256;
-    gp.nb = (gp.s.C + WAVE - 1) / WAVE;
+    gp.nb = (gp.s.C + WAVE / GL - 1) / (WAVE / GL);
     const int64_t slots = (int64_t)cus * per_cu * wpb;
     lane_schedule(gp.nb, slots, gp.s.n_sk, gp.nseg, rounds, gp.nseg, gp.seg_len);
     int64_t blocks = (gp.nb * gp.nseg + wpb - 1) / wpb;
@@ -812,22 +955,22 @@ inline hipError_t launch_lane(const GroupParams &gp_in, const int32_t *flag, int
     return hipGetLastError();
 }
 // one translation unit per range of LK (inst_lane_zigzag*.hip); hipErrorNotSupported: not this unit's LK
-template <int TARGET, int LK0, int LK1>
+template <int TARGET, int LK0, int LK1, int GL = 1>
 inline hipError_t launch_lane_by_slots(int lk, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream) {
     if constexpr (LK0 > LK1) return hipErrorNotSupported;
     else {
         const bool diag = gp.s.H || gp.s.AR || gp.s.EB || gp.s.RJ || gp.s.HH || gp.s.EV ||
                           gp.s.count || gp.s.chain_map || gp.s.resume || gp.s.t_stop < __builtin_huge_val();   // (the time-horizon features: DIAG kernels)
-        return lk != LK0 ? launch_lane_by_slots<TARGET, LK0 + 1, LK1>(lk, gp, flag, rounds, stream)
-                         : (diag ? launch_lane<TARGET, LK0, true>(gp, flag, rounds, stream) : launch_lane<TARGET, LK0, false>(gp, flag, rounds, stream));
+        return lk != LK0 ? launch_lane_by_slots<TARGET, LK0 + 1, LK1, GL>(lk, gp, flag, rounds, stream)
+                         : (diag ? launch_lane<TARGET, LK0, true, false, GL>(gp, flag, rounds, stream) : launch_lane<TARGET, LK0, false, false, GL>(gp, flag, rounds, stream));
     }
 }
-template <int LK0, int LK1>
+template <int LK0, int LK1, int GL = 1>
 inline hipError_t launch_lane_range(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream) {
-    const int lk = (gp.s.d + 3) / 4;
+    const int lk = (gp.s.d + 4 * GL - 1) / (4 * GL);
     switch (target) {
-    case T_GAUSS_ISO: return launch_lane_by_slots<T_GAUSS_ISO, LK0, LK1>(lk, gp, flag, rounds, stream);
-    case T_BANANA: return launch_lane_by_slots<T_BANANA, LK0, LK1>(lk, gp, flag, rounds, stream);
+    case T_GAUSS_ISO: return launch_lane_by_slots<T_GAUSS_ISO, LK0, LK1, GL>(lk, gp, flag, rounds, stream);
+    case T_BANANA: return launch_lane_by_slots<T_BANANA, LK0, LK1, GL>(lk, gp, flag, rounds, stream);
     default: return hipErrorNotSupported;
     }
 }
@@ -836,6 +979,10 @@ hipError_t launch_lane_zigzag_a(int target, const GroupParams &gp, const int32_t
 hipError_t launch_lane_zigzag_b(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);     // LK = 10 .. 12
 hipError_t launch_lane_zigzag_tape(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);  // LK = 13, tape source
 hipError_t launch_lane_check(const double *vinit, int64_t n, int32_t *flag, hipStream_t stream);
+// a pair of lanes per chain (GL = 2): d = 53 .. 104, LK = ceil(d / 8)
+hipError_t launch_lane2_zigzag(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);      // LK = 13
+hipError_t launch_lane2_zigzag_a(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);    // LK = 7 .. 9
+hipError_t launch_lane2_zigzag_b(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);    // LK = 10 .. 12
 #endif
 
 }  // namespace pdmp

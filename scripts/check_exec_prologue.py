@@ -1,0 +1,47 @@
+"""Scan AMDGPU assembly (hipcc -S --cuda-device-only) for register copies the allocator placed at the top of a join block BEFORE the
+`s_or_b64 exec, exec, ...` that restores the lanes of the enclosing region: such a copy (v_accvgpr_write/read, v_mov) runs for the
+lanes of the inner region only (or for none, when the block is reached with exec = 0), and the value it was meant to carry is lost
+in the other lanes -- seen on the box as a lane pair kernel whose hand-off pointer was valid in even lanes only.
+usage: check_exec_prologue.py file.s [...]   exit code 1 if anything is found."""
+import re, sys
+
+VALU = re.compile(r'^(v_|global_|buffer_|ds_|flat_|scratch_)')
+COPIES = ('v_accvgpr_write_b32', 'v_accvgpr_read_b32', 'v_accvgpr_mov_b32')      # (v_mov copies in this position are also the program's own: ends of `then` blocks)
+LANEOPS = ('v_writelane_b32', 'v_readlane_b32', 'v_readfirstlane_b32')
+bad = 0
+for fn in sys.argv[1:]:
+    kernel, block, pending = None, None, []
+    for ln, raw in enumerate(open(fn), 1):
+        code = raw.split(';')[0].strip()
+        if not code:
+            continue
+        if code.endswith(':'):
+            if code.startswith('_Z'):
+                kernel = code[:-1]
+            block, pending = code[:-1], []
+            continue
+        if code.startswith('.'):
+            continue
+        if pending is None:
+            continue
+        op = code.split()[0]
+        if op in ('s_or_b64',) and re.match(r's_or_b64\s+exec,\s*exec,', code):
+            copies = [pc for pc in pending if pc[1].split()[0] in COPIES]
+            if copies and len(copies) == len(pending):      # nothing but copies in front of the restore: the allocator's, not the program's
+                try:
+                    for (l, c) in copies:
+                        print(f"{fn}:{l}: [{kernel}] {block}: `{c}` before `{code}`")
+                except BrokenPipeError:
+                    pass
+                bad += len(copies)
+            pending = None            # only the block's prologue matters
+            continue
+        if re.search(r'\bexec\b', code) and op.startswith('s_'):
+            pending = None            # another exec write / read: not the pattern
+            continue
+        if op.startswith(('s_cbranch', 's_branch', 's_endpgm', 's_setpc')):
+            pending = None
+            continue
+        if VALU.match(op) and op not in LANEOPS:
+            pending.append((ln, code))
+sys.exit(1 if bad else 0)
