@@ -247,7 +247,7 @@ def measured_counters(a, C_local, G, form=0):
     except (OSError, ValueError):
         return None
     key = f"{a.sampler}|{a.target}|d={a.dim}|C={C_local}|n_sk={a.n_sk}"
-    if form == 4:                                                # the one-lane-per-chain kernel has its own measurements
+    if form in (4, 7):                                           # the lane kernel (one lane / a pair of lanes per chain) has its own measurements
         return table.get(key + "|lane")
     e = table.get(key + f"|G={G}") or table.get(key)
     return e
@@ -462,8 +462,8 @@ def main():
                   f"group_kernel<{sampler.name},{a.target}> (G={G} lanes per chain)" if G > 0 else
                   f"skeleton_kernel<{sampler.name},{a.target}> (wave per chain)")
         form = sampler.last_launch_form()                        # which kernel form served the timed launches (pdmp_last_launch_form)
-        if form == 4:
-            per = "one lane per chain, 64 chains per wave" if a.dim <= 52 else "a lane pair per chain, 32 chains per wave"
+        if form in (4, 7):
+            per = "one lane per chain, 64 chains per wave" if form == 4 else "a lane pair per chain, 32 chains per wave"
             kernel = (f"lane_kernel<{a.target}> ({per}; signed positions y = x v in registers, "
                       "events stored as whole 64-byte lines)")
         cnt = measured_counters(a, C_local, G, form)
@@ -501,7 +501,7 @@ def main():
                                    "source": cnt.get("valu_source")} if cnt and cnt.get("valu_instr_per_event") else None),
                          "note": ("HBM-write bound: roofline.traffic / kernel_ms is the write rate the launch sustains (a plain fill of this GPU "
                                   "reaches ~5.6 TB/s); roofline.valu = wave-instructions per event and the share of SIMD cycles the VALUs are busy"
-                                  if form == 4 else
+                                  if form in (4, 7) else
                                   "the kernel is bound by fp64 VALU issue, not by HBM (roofline.valu: wave-instructions per event and the share of "
                                   "SIMD cycles the VALUs are busy, from the committed PMC pass); the HBM fraction is the requested headline")},
         }

@@ -139,7 +139,8 @@ int pdmp_set_group_lanes(pdmp_handle h, int32_t G);
 /* Which kernel form served the handle's last pdmp_sample_skeleton* launch (waits for it to finish): a diagnostic for benchmarks and
  * tests, results do not depend on it.  PDMP_FORM_LANE: one lane per chain (csrc/lane_kernel.hpp; large Zig-Zag ensembles at
  * dim 27..52 with unit speeds on the isotropic Gaussian / banana -- bit-identical to the group kernel with G = 4). */
-enum { PDMP_FORM_NONE = 0, PDMP_FORM_WAVE = 1, PDMP_FORM_GROUP = 2, PDMP_FORM_GROUP_REG = 3, PDMP_FORM_LANE = 4, PDMP_FORM_DENSE = 5, PDMP_FORM_USER = 6 };
+enum { PDMP_FORM_NONE = 0, PDMP_FORM_WAVE = 1, PDMP_FORM_GROUP = 2, PDMP_FORM_GROUP_REG = 3, PDMP_FORM_LANE = 4, PDMP_FORM_DENSE = 5, PDMP_FORM_USER = 6,
+       PDMP_FORM_LANE_PAIR = 7 /* the lane kernel with a PAIR of lanes per chain: dim 53..104 (bit-identical to the group kernel with G = 8), and mid-sized launches at dim 25..52 (G = 4) */ };
 int pdmp_last_launch_form(pdmp_handle h);
 
 /* Tape source: replace the built-in Philox stream (the engine's stand-in for Julia's

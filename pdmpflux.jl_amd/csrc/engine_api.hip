@@ -19,6 +19,7 @@ hipError_t launch_lane_check(const double *vinit, int64_t n, int32_t *flag, hipS
 hipError_t launch_lane2_zigzag(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);   // a PAIR of lanes per chain: d = 97 .. 104
 hipError_t launch_lane2_zigzag_a(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream); // d = 53 .. 72
 hipError_t launch_lane2_zigzag_b(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream); // d = 73 .. 96
+hipError_t launch_lane2q_zigzag(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);  // a pair of lanes per chain at d = 25 .. 52 (mid-sized launches)
 hipError_t launch_group_reg_zigzag(int target, bool fd, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_bps(int target, bool fd, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_boomerang(int target, bool fd, const GroupParams &gp, hipStream_t stream);
@@ -842,11 +843,11 @@ int pdmp_create_from_source(const pdmp_config_t *cfg, const char *source, int32_
 
 int pdmp_last_launch_form(pdmp_handle h) {
     if (!h) return -1;
-    if (h->last_form != PDMP_FORM_LANE) return h->last_form;
+    if (h->last_form != PDMP_FORM_LANE && h->last_form != PDMP_FORM_LANE_PAIR) return h->last_form;
     int32_t flag = 0;                              // the lane kernel ran unless the check kernel found a speed other than +-1
     if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->last_stream) != hipSuccess ||
         hipMemcpy(&flag, h->d_status + 4, sizeof flag, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return flag == 0 ? PDMP_FORM_LANE : PDMP_FORM_GROUP_REG;
+    return flag == 0 ? h->last_form : PDMP_FORM_GROUP_REG;
 }
 
 int pdmp_get_group_lanes(pdmp_handle h) { return h ? ((h->tape_chains > 0 && !tape_on_group(h)) ? 0 : h->group_lanes) : -1; }
@@ -1072,17 +1073,27 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
             // measured (one MI355X, n_sk = 1000): up to 65 536 chains the lane kernel takes 9.6 ms (d = 50 Gaussian) / 11.0 ms (banana) / 7.8 ms
             // (d = 32) whatever the count -- one wave per SIMD walks its 64 chains' events one after the other -- while the group kernel grows
             // with the count: it wins below ~41 000 chains at d = 50 (9.4 ms at 40 000, 12.8 ms at 45 000) and below ~48 000 at d = 32
+            // (round 3: between 15 500 chains and these thresholds the PAIR form below serves the launch; with it in the middle the one-lane form starts at 37 000 for d >= 45)
             // d = 53 .. 104 (the group kernel's G = 8): a PAIR of lanes per chain, 32 chains per wave, bit-identical to the G = 8 group kernel
             const bool lane2 = gp.G == 8;
             // (the pair kernel, d = 100, n_sk = 1000: 10.6 ms up to 32 768 chains -- one wave per SIMD -- against 9.5 ms of the group kernel at 25 000, 37.9 ms at 10^5)
-            const int64_t lane_from = lane_min ? atoll(lane_min) : (lane2 ? 28000 : (c.dim >= 45 ? 42000 : 48000));
+            const int64_t lane_from = lane_min ? atoll(lane_min) : (lane2 ? 28000 : (c.dim >= 45 ? 37000 : 48000));
+            // d = 25 .. 52 again, launches between ~a fifth and ~two fifths of the machine (the 4-GPU shard of the headline ensemble): a pair of
+            // lanes per chain with two coordinates of a slot each -- GROUP(4) still -- so that 25 000 chains are 782 waves instead of 391
+            const char *pair_min = getenv("PDMP_LANE_PAIR_MIN_CHAINS");
+            // measured (d = 50 Gaussian, n_sk = 1000; group kernel / one lane / pair): 12 500 chains 4.31 / 8.36 / 5.36 ms, 18 000 6.58 / 8.41 / 5.39,
+            // 25 000 8.42 / 8.43 / 5.45, 32 000 10.27 / 8.47 / 7.02, 40 000 10.99 / 8.48 / 9.60, 50 000 11.53 / 8.57 / 11.50 (profiles/r3/r3q1_*)
+            const int64_t pair_from = pair_min ? atoll(pair_min) : 15500;
             const bool lane_ok = c.sampler == PDMP_ZIGZAG && !fd && (c.target_id == PDMP_T_GAUSS_ISO || c.target_id == PDMP_T_BANANA) &&
                                  ((gp.G == 4 && c.dim >= 25 && c.dim <= 52) || (lane2 && c.dim >= 53 && c.dim <= 104 && !tgroup)) &&
-                                 (int64_t)(lane2 ? WAVE / 2 : WAVE) * n_sk * c.dim * 8 < 0x7fffffffLL;   // (a batch's window of X: 31-bit byte offsets)
+                                 (int64_t)WAVE * n_sk * c.dim * 8 < (lane2 ? 2 : 1) * 0x7fffffffLL;   // (a batch's window of X: 31-bit byte offsets; 64 chains, or 32 of a pair form -- the quad pair is held to the window of 64 so that a resumed chunk may be of either size)
             // (round 3: no alignment preconditions any more -- a chain's rows may start anywhere inside a 64-byte line, lane_kernel.hpp: open_window)
             // a resumed chunk continues in the form whose state layout its first chunk left behind (until->form), whatever its size
-            const bool lane_wanted = resuming ? (until->form == PDMP_FORM_LANE && c.sampler == PDMP_ZIGZAG)   // (BPS: its own lane form, below)
-                                              : (!(lane_env && atoi(lane_env) == 0) && ((lane_env && atoi(lane_env) == 1) || C >= lane_from));
+            const int lane_mode = lane_env ? atoi(lane_env) : -1;      // (2: the pair form at d <= 52 too, whatever the count -- tests)
+            const bool pairq = !lane2 && !tgroup && (resuming ? until->form == PDMP_FORM_LANE_PAIR
+                                                              : (lane_mode == 2 || (lane_mode < 0 && C >= pair_from && C < lane_from)));
+            const bool lane_wanted = resuming ? ((until->form == PDMP_FORM_LANE || until->form == PDMP_FORM_LANE_PAIR) && c.sampler == PDMP_ZIGZAG)   // (BPS: its own lane form, below)
+                                              : (lane_mode != 0 && (lane_mode == 1 || lane_mode == 2 || C >= lane_from || pairq));
             if (resuming && lane_wanted && !lane_ok) {
                 h->pool.push_back(ev);
                 return fail(PDMP_ERR_ARGUMENT, "resume: the first chunk ran one lane per chain; a chunk's capacity must keep 64 * capacity * dim * 8 below 2^31 bytes");
@@ -1097,6 +1108,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
                 if (!getenv("PDMP_CELL_BUDGET")) lp.cell_budget = 5;   // a pass of 64 chains costs ~2 000 instructions, a cell 240: wait for more cells
                 if (tgroup) lp.nseg = 1;                     // (lane_schedule: a forced segment count)
                 if (le == hipSuccess) le = tgroup ? launch_lane_zigzag_tape(c.target_id, lp, flag, rounds, s)   // (d = 49 .. 52; else the group kernel below replays)
+                                      : pairq ? launch_lane2q_zigzag(c.target_id, lp, flag, rounds, s)
                                       : c.dim > 96 ? launch_lane2_zigzag(c.target_id, lp, flag, rounds, s)
                                       : c.dim > 72 ? launch_lane2_zigzag_b(c.target_id, lp, flag, rounds, s)
                                       : c.dim > 52 ? launch_lane2_zigzag_a(c.target_id, lp, flag, rounds, s)
@@ -1104,7 +1116,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
                                       : c.dim > 36 ? launch_lane_zigzag_b(c.target_id, lp, flag, rounds, s) : launch_lane_zigzag_a(c.target_id, lp, flag, rounds, s);
                 if (le == hipSuccess) {                      // (a lane kernel that cannot be launched -- it asks for 145 KB of LDS per block --
                     gp.only_if = flag;                       //  leaves the launch to the group kernel below)
-                    h->last_form = PDMP_FORM_LANE;
+                    h->last_form = (lane2 || pairq) ? PDMP_FORM_LANE_PAIR : PDMP_FORM_LANE;
                 } else (void)hipGetLastError();
             }
             // BPS at d = 27 .. 52 on the isotropic Gaussian / banana, forward-mode slopes, with one LANE per chain (lane_bps_kernel.hpp;

@@ -46,9 +46,11 @@ namespace pdmp {
 // layout is G = 4 from d = 27 on)
 constexpr int LANE_LK_MIN = 7, LANE_LK_MAX = 13;
 // gl = lanes per chain (1; 2: the chain's coordinates split over a lane pair, lane_kernel.hpp: GL)
-constexpr int lane_row_stride(int lk, int gl = 1) { return (7 + 4 * gl * lk) | 1; }   // LDS row: up to 7 carried doubles + 4 gl LK coordinates, odd stride
-constexpr int lane_meta_doubles(int gl) { return gl == 1 ? 2 : 4; }                  // store parameters of a chain: 16 bytes (64 sign bits) / 32 bytes (128)
-constexpr int lane_lds_per_wave(int lk, int gl = 1) { return (WAVE / gl) * (lane_row_stride(lk, gl) + lane_meta_doubles(gl) + 8); } // doubles: a row + the store parameters + 8 event times per chain
+// pg = coordinates of a slot per lane (4; 2: the "quad pair" form, GL = 2 at d <= 52), dmax = pg gl lk = a chain's coordinates with padding
+constexpr int lane_row_stride(int lk, int gl = 1, int pg = 4) { return (7 + pg * gl * lk) | 1; }   // LDS row: up to 7 carried doubles + dmax coordinates, odd stride
+constexpr bool lane_wide(int lk, int gl, int pg) { return 7 + pg * gl * lk > 64; }                 // a row's sign bits need more than one 64-bit word
+constexpr int lane_meta_doubles(int lk, int gl = 1, int pg = 4) { return lane_wide(lk, gl, pg) ? 4 : 2; }   // store parameters of a chain: 16 bytes (64 sign bits) / 32 bytes (128)
+constexpr int lane_lds_per_wave(int lk, int gl = 1, int pg = 4) { return (WAVE / gl) * (lane_row_stride(lk, gl, pg) + lane_meta_doubles(lk, gl, pg) + 8); } // doubles: a row + the store parameters + 8 event times per chain
 
 // Two waves per SIMD (256 registers): slot loops run slot by slot -- without this the scheduler hoists the 52 independent terms of a sum
 // in front of their additions (104 more live registers, spills).  One wave per SIMD (512 registers, the build that ships): no fence, the
@@ -113,45 +115,56 @@ __device__ __forceinline__ LaneBits128 lb_or(LaneBits128 a, LaneBits128 b) { ret
 __device__ __forceinline__ uint32_t lb_low(LaneBits128 a) { return (uint32_t)a.lo; }
 __device__ __forceinline__ uint32_t dpp_xor1_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, DPP_QUAD_XOR1, 0xF, 0xF, true); }
 
-template <int TARGET, int LK, bool DIAG, bool TAPE = false, int GL = 1>
+//
+// GL = 2 with PG = 2 (round 3, the 4-GPU shard of the headline ensemble): d = 25 .. 52 again, for launches of ~20 000 - 40 000 chains that
+// leave most SIMDs without a wave when a wave holds 64 chains.  Lane h of the pair holds coordinates 4 s + 2 h + g (g = 0, 1): its
+// p0 + p1 is the xor-1 stage of the FOUR-lane butterfly, the exchange with the partner the xor-2 stage: GROUP(4) again, bit-identical
+// to the one-lane form and to the G = 4 group kernel.  26 coordinate registers per lane: two waves per SIMD, no AGPRs.
+template <int TARGET, int LK, bool DIAG, bool TAPE = false, int GL = 1, int PG = 4>
 struct LaneChain {
     static_assert(TARGET == T_GAUSS_ISO || TARGET == T_BANANA, "lane kernel: isotropic Gaussian and banana");
     static_assert(LK >= LANE_LK_MIN && LK <= LANE_LK_MAX, "lane kernel: 7 .. 13 slots of four coordinates");
     static_assert(GL == 1 || GL == 2, "lane kernel: one lane per chain, or a pair");
+    static_assert(PG == 4 || (PG == 2 && GL == 2), "lane kernel: four coordinates of a slot per lane, or two in a pair");
     static_assert(!(TAPE && GL != 1), "tape replay: one lane per chain");
-    static constexpr int GE = 4 * GL;                    // lanes per chain of the group layout whose summation order this is
-    static constexpr int LD = 4 * LK;                    // coordinate registers per lane
+    static constexpr int GE = PG * GL;                   // lanes per chain of the group layout whose summation order this is
+    static constexpr int LGE = GE == 4 ? 2 : 3;          // log2(GE)
+    static constexpr int LD = PG * LK;                   // coordinate registers per lane
     static constexpr int DMAX = GE * LK;                 // coordinates of a chain, padding included
     static constexpr int CW = WAVE / GL;                 // chains per wave
-    static constexpr int LR = lane_row_stride(LK, GL);   // LDS row stride
-    static constexpr int MD = lane_meta_doubles(GL);     // doubles of store parameters per chain
+    static constexpr int LR = lane_row_stride(LK, GL, PG);   // LDS row stride
+    static constexpr bool kWide = lane_wide(LK, GL, PG); // 128 sign bits per row (else 64)
+    static constexpr int MD = lane_meta_doubles(LK, GL, PG);   // doubles of store parameters per chain
     static constexpr int LANE_DMIN = DMAX - (GE - 1);    // the last slot may be partly padding, no other
     static constexpr bool kBanana = TARGET == T_BANANA;
     using Tgt = GTarget<TARGET>;
-    using SBits = typename std::conditional<GL == 1, uint64_t, LaneBits128>::type;   // one sign bit per row position (7 carried + DMAX)
+    using SBits = typename std::conditional<!kWide, uint64_t, LaneBits128>::type;   // one sign bit per row position (7 carried + DMAX)
     const SkelParams &p;
     const int lane, d;
-    int hq = 0;                   // GL = 2: 4 h -- my half of every slot of eight (h = lane & 1)
-    int dl = 4;                   // GL = 2: how many coordinates of MY last four are real: d - 8 (LK - 1) - 4 h (<= 0: none, >= 4: all)
+    int hq = 0;                   // GL = 2: PG h -- my half of every slot (h = lane & 1)
+    int dl = PG;                  // GL = 2: how many coordinates of MY last PG are real: d - GE (LK - 1) - PG h (<= 0: none, >= PG: all)
     Tgt tgt;
-    double y[LD];                 // y_i = x_i v_i; register j = 4 s + g holds coordinate gi(j) = GE s + 4 h + g
-    uint32_t sg0 = 0, sg1 = 0, sg2 = 0, sg3 = 0;    // bit GE s + g of (sg3:sg2:sg1:sg0) set <=> v = -1 for register 4 s + g (GL = 1: bit j, two words)
+    double y[LD];                 // y_i = x_i v_i; register j = PG s + g holds coordinate gi(j) = GE s + PG h + g
+    uint32_t sg0 = 0, sg1 = 0, sg2 = 0, sg3 = 0;    // bit GE s + g of (sg3:sg2:sg1:sg0) set <=> v = -1 for register PG s + g (GL = 1: bit j, two words)
     ChainRng rng;
     int32_t guard = 0;
     double *tile;                 // this wave's LDS: CW rows of LR doubles, then CW x (sign bits, window offset, valid range), then the event-time lines
 
     __device__ __forceinline__ LaneChain(const SkelParams &sp, int l, double *t_) : p(sp), lane(l), d(sp.d), tile(t_) {
         tgt.init(nullptr, sp.d);
-        if constexpr (GL == 2) { hq = 4 * (l & 1); dl = sp.d - GE * (LK - 1) - hq; }
+        if constexpr (GL == 2) { hq = PG * (l & 1); dl = sp.d - GE * (LK - 1) - hq; }
     }
+    static constexpr int js(int j) { return j / PG; }    // slot of register j
+    static constexpr int jg(int j) { return j % PG; }    // its place among my coordinates of the slot
+    static constexpr int lbit(int j) { return GE * (j / PG) + (j % PG); }   // its sign bit
     __device__ __forceinline__ bool head() const { if constexpr (GL == 1) return true; else return hq == 0; }   // the lane that does the chain's scalar stores
-    __device__ __forceinline__ int gi(int j) const { if constexpr (GL == 1) return j; else return GE * (j >> 2) + hq + (j & 3); }   // coordinate held by register j
+    __device__ __forceinline__ int gi(int j) const { if constexpr (GL == 1) return j; else return lbit(j) + hq; }   // coordinate held by register j
 
     __device__ __forceinline__ static double sgn(double a, uint32_t s) {          // a * v for v = +-1 (exact): flip the sign bit
         return __hiloint2double(__double2hiint(a) ^ (int)s, __double2loint(a));
     }
     __device__ __forceinline__ uint32_t sw(int i) const {                         // sign word of register i's v: 0 or 0x80000000 (i is a constant after unrolling)
-        const int lb = GE * (i >> 2) + (i & 3);
+        const int lb = lbit(i);
         const uint32_t w = (lb < 32) ? sg0 : ((lb < 64) ? sg1 : ((lb < 96) ? sg2 : sg3));
         const int b = lb & 31;
         return (b == 31) ? (w & 0x80000000u) : ((w << (31 - b)) & 0x80000000u);
@@ -160,10 +173,12 @@ struct LaneChain {
     __device__ __forceinline__ double V(int i) const { return __hiloint2double((int)(0x3ff00000u | sw(i)), 0); }
     __device__ __forceinline__ bool in_dim(int i) const {                         // register i holds a real coordinate
         if constexpr (GL == 1) return i < LANE_DMIN || i < d;
-        else return i < LD - 4 || (i & 3) < dl;
+        else return i < LD - PG || jg(i) < dl;
     }
-    __device__ __forceinline__ static double gsum4(const double (&a)[4]) { return (a[0] + a[1]) + (a[2] + a[3]); }   // the xor-1, xor-2 butterfly
-    __device__ __forceinline__ static double csum(const double (&a)[4]) {         // the chain's sum: GL = 2 adds the xor-4 stage (the partner lane's four)
+    __device__ __forceinline__ static double gsum4(const double (&a)[PG]) {       // my coordinates of a slot: the first stage(s) of the butterfly
+        if constexpr (PG == 4) return (a[0] + a[1]) + (a[2] + a[3]); else return a[0] + a[1];
+    }
+    __device__ __forceinline__ static double csum(const double (&a)[PG]) {        // the chain's sum: GL = 2 adds the last stage (the partner lane's)
         double r = gsum4(a);
         if constexpr (GL == 2) r = r + dpp_d<DPP_QUAD_XOR1>(r);
         return r;
@@ -259,19 +274,19 @@ struct LaneChain {
                 const int j = b_next;
                 const double t0 = (double)j * h;
                 double t1 = (j == GNG - 2) ? harg : (double)(j + 1) * h;
-                double part[4] = {0.0, 0.0, 0.0, 0.0};
-                if constexpr (kBanana) {                                          // slot 0: x_0, x_1 twisted (and x_2, x_3 with them, as the group kernel's slot)
+                double part[PG] = {};
+                if constexpr (kBanana) {                                          // slot 0: x_0, x_1 twisted (and the rest of the slot with them, as the group kernel's slot)
                     if (j == 0) b_shf = head_dual(t0);
                     const BananaSh<Dual> sh0 = b_shf, sh1 = head_dual(t1);
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) part[g] += cell_general(g, t0, t1, h, sh0, sh1);
+                    for (int g = 0; g < PG; ++g) part[g] += cell_general(g, t0, t1, h, sh0, sh1);
                     b_shf = sh1;
                 }
 #pragma unroll
                 for (int s = kBanana ? 1 : 0; s < LK; ++s) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int i = 4 * s + g;
+                    for (int g = 0; g < PG; ++g) {
+                        const int i = PG * s + g;
                         if (in_dim(i)) part[g] += fmax(y[i] + t1, 0.0);           // affine cell, monotone: max(v0, v1, 0) = max(v1, 0), v1 = (x + v t1) v
                     }
                     LANE_SLOT_FENCE(part, t1);
@@ -299,14 +314,14 @@ struct LaneChain {
     }
     // ---- GroupChain::true_rate for Zig-Zag: sum max(0, grad-U(x + v t) .* v) in the GROUP(4) order
     __device__ __forceinline__ double true_rate(double t) const {
-        double part[4] = {0.0, 0.0, 0.0, 0.0};
+        double part[PG] = {};
         BananaSh<double> sh{};
         if constexpr (kBanana) sh = tgt.template shared<double>(fma(V(0), t, X(0)), fma(V(1), t, X(1)));
 #pragma unroll
         for (int s = 0; s < LK; ++s) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int i = 4 * s + g;
+            for (int g = 0; g < PG; ++g) {
+                const int i = PG * s + g;
                 if (in_dim(i)) {
                     double gv = y[i] + t;                                         // (x + v t) v
                     if constexpr (kBanana) { if (i < 2) gv = twisted(i, gv, sh); }
@@ -323,20 +338,20 @@ struct LaneChain {
     __device__ __forceinline__ void flow_and_flip(double tf, int mglob) {
         // m: the sign bit / register position of the flipped coordinate in THIS lane, GE s + g (-1: none, or the partner lane's)
         int m = mglob;
-        if constexpr (GL == 2) m = (mglob >= 0 && (mglob & 4) == hq) ? (mglob & ~4) : -1;
+        if constexpr (GL == 2) m = (mglob >= 0 && (mglob & PG) == hq) ? (mglob & ~PG) : -1;
         const uint32_t bit = 1u << (m & 31);                                      // v[m] *= -1
         sg0 ^= (m >= 0 && m < 32) ? bit : 0u;
         if constexpr (GL == 1) sg1 ^= (m >= 32) ? bit : 0u;
         else { sg1 ^= (m >= 32 && m < 64) ? bit : 0u; sg2 ^= (m >= 64 && m < 96) ? bit : 0u; sg3 ^= (m >= 96) ? bit : 0u; }
         // the flip: one compare per slot of four, then per coordinate a select of the lane's word for g = m % 4 and the xor
-        const int ms = m >> (GL == 1 ? 2 : 3), mg = m & 3;                        // (m = -1: slot -1, no slot matches)
-        const uint32_t x0 = (mg == 0) ? 0x80000000u : 0u, x1 = (mg == 1) ? 0x80000000u : 0u, x2 = (mg == 2) ? 0x80000000u : 0u,
-                       x3 = (mg == 3) ? 0x80000000u : 0u;
+        const int ms = m >> LGE, mg = m & (PG - 1);                               // (m = -1: slot -1, no slot matches)
+        uint32_t xs[PG];
+#pragma unroll
+        for (int g = 0; g < PG; ++g) xs[g] = (mg == g) ? 0x80000000u : 0u;
 #pragma unroll
         for (int i = 0; i < LD; ++i) {                                            // padded coordinates are never read
             asm volatile("v_add_f64 %0, %0, %1" : "+v"(y[i]) : "v"(tf));          // y_i + tf in place (a plain IEEE addition)
-            const uint32_t xg = (i & 3) == 0 ? x0 : ((i & 3) == 1 ? x1 : ((i & 3) == 2 ? x2 : x3));
-            y[i] = sgn(y[i], (ms == (i >> 2)) ? xg : 0u);
+            y[i] = sgn(y[i], (ms == js(i)) ? xs[jg(i)] : 0u);
         }
     }
     // Returns the coordinate to flip (-1: Q11 guard, no flip); reads the state flowed by t (y_i + t: the very doubles flow_and_flip stores).
@@ -345,20 +360,24 @@ struct LaneChain {
         if constexpr (kBanana) sh = tgt.template shared<double>(fma(V(0), t, X(0)), fma(V(1), t, X(1)));
         if (!(S > 0.0)) { guard++; return -1; }                                   // Q11
         const double theta = u * S;
-        double carry = 0.0, carry_at = 0.0, lh[4] = {0.0, 0.0, 0.0, 0.0};
+        double carry = 0.0, carry_at = 0.0, lh[PG] = {};
         int ms_hit = -1;
 #pragma unroll
         for (int s = 0; s < LK; ++s) {
-            double l[4];
+            double l[PG];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int i = 4 * s + g;
+            for (int g = 0; g < PG; ++g) {
+                const int i = PG * s + g;
                 double gv = y[i] + t;                                             // x v at the accepted point
                 if constexpr (kBanana) { if (i < 2) gv = twisted(i, gv, sh); }
                 l[g] = in_dim(i) ? fmax(0.0, gv) : 0.0;
             }
             const double T = csum(l);
-            if (ms_hit < 0 && (carry + T > theta)) { ms_hit = s; carry_at = carry; lh[0] = l[0]; lh[1] = l[1]; lh[2] = l[2]; lh[3] = l[3]; }
+            if (ms_hit < 0 && (carry + T > theta)) {
+                ms_hit = s; carry_at = carry;
+#pragma unroll
+                for (int g = 0; g < PG; ++g) lh[g] = l[g];
+            }
             carry = carry + T;
             LANE_SLOT_FENCE(lh, t);
 #ifndef LANE_NO_FENCE
@@ -374,24 +393,24 @@ struct LaneChain {
                 for (int g = 3; g >= 0; --g) if ((4 * ms_hit + g < d) && (carry_at + inc[g] > theta)) m = 4 * ms_hit + g;
             }
         } else {
-            // the hit slot's eight rates in both lanes of the pair, then the three Kogge-Stone steps (offsets 1, 2, 4) written out
-            double l8[8];
+            // the hit slot's GE rates in both lanes of the pair, then the Kogge-Stone steps (offsets 1, 2 and, for eight, 4) written out
+            double l8[GE];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < PG; ++g) {
                 const double ph = dpp_d<DPP_QUAD_XOR1>(lh[g]);                    // (zeros while no slot is hit; both lanes of a pair are in here together)
                 l8[g] = head() ? lh[g] : ph;
-                l8[4 + g] = head() ? ph : lh[g];
+                l8[PG + g] = head() ? ph : lh[g];
             }
             if (ms_hit >= 0) {
-                double a[8], b[8], c[8];
+                double a[GE], b[GE], c[GE];
 #pragma unroll
-                for (int g = 0; g < 8; ++g) a[g] = (g >= 1) ? l8[g] + l8[g - 1] : l8[g];
+                for (int g = 0; g < GE; ++g) a[g] = (g >= 1) ? l8[g] + l8[g - 1] : l8[g];
 #pragma unroll
-                for (int g = 0; g < 8; ++g) b[g] = (g >= 2) ? a[g] + a[g - 2] : a[g];
+                for (int g = 0; g < GE; ++g) b[g] = (g >= 2) ? a[g] + a[g - 2] : a[g];
 #pragma unroll
-                for (int g = 0; g < 8; ++g) c[g] = (g >= 4) ? b[g] + b[g - 4] : b[g];
+                for (int g = 0; g < GE; ++g) c[g] = (g >= 4) ? b[g] + b[g - 4] : b[g];
 #pragma unroll
-                for (int g = 7; g >= 0; --g) if ((8 * ms_hit + g < d) && (carry_at + c[g] > theta)) m = 8 * ms_hit + g;
+                for (int g = GE - 1; g >= 0; --g) if ((GE * ms_hit + g < d) && (carry_at + c[g] > theta)) m = GE * ms_hit + g;
             }
         }
         if (m < 0) m = d - 1;
@@ -426,7 +445,11 @@ struct LaneChain {
     // or-ed with the partner's they are the row's -- all lanes of the wave must be here (DPP).
     __device__ __forceinline__ SBits signs_row() const {
         if constexpr (GL == 1) return ((uint64_t)sg1 << 32) | (uint64_t)sg0;
-        else {
+        else if constexpr (!kWide) {
+            const uint64_t o = (((uint64_t)sg1 << 32) | (uint64_t)sg0) << hq;
+            const uint32_t q0 = dpp_xor1_u32((uint32_t)o), q1 = dpp_xor1_u32((uint32_t)(o >> 32));
+            return o | (((uint64_t)q1 << 32) | (uint64_t)q0);
+        } else {
             LaneBits128 o{((uint64_t)sg1 << 32) | (uint64_t)sg0, ((uint64_t)sg3 << 32) | (uint64_t)sg2};
             o = lb_shl(o, hq);
             const uint32_t w0 = (uint32_t)o.lo, w1 = (uint32_t)(o.lo >> 32), w2 = (uint32_t)o.hi, w3 = (uint32_t)(o.hi >> 32);
@@ -435,14 +458,14 @@ struct LaneChain {
         }
     }
     __device__ __forceinline__ static SBits low_bits(SBits x, int a) {            // the lowest a <= 7 bits
-        if constexpr (GL == 1) return x & ((1ull << a) - 1ull);
+        if constexpr (!kWide) return x & ((1ull << a) - 1ull);
         else return {x.lo & ((1ull << a) - 1ull), 0ull};
     }
     // my registers into the chain's LDS row whose coordinate 0 is at `row0` (GL = 2: the two lanes of a pair interleave fours)
     __device__ __forceinline__ void row_put(double *row0) const {
         double *w = row0 + hq;
 #pragma unroll
-        for (int j = 0; j < LD; ++j) w[GE * (j >> 2) + (j & 3)] = y[j];
+        for (int j = 0; j < LD; ++j) w[lbit(j)] = y[j];
     }
     // A segment that starts at event k_first >= 1 of chain c starts a = (address of X[c, k_first, 0] / 8) mod 8 doubles into a 64-byte
     // line -- per chain: round 3 dropped the preconditions "X on a line, n_sk d a multiple of 8" under which a was the same for the
@@ -498,7 +521,7 @@ struct LaneChain {
     // nfull << 8 -- 16 bytes (GL = 2: 32, the last 8 unused).  A tile that starts at row position q reads the sign word of q.
     struct TileMeta { uint32_t s, off, nf; };
     __device__ __forceinline__ TileMeta tile_meta(int q, int grp, int ch) const { // chain ch + grp of the wave (ch a constant: folds into the DS offset)
-        if constexpr (GL == 1) {
+        if constexpr (!kWide) {
             const u32x4 v = ((const u32x4 *)(tile + CW * LR) + grp)[ch];
             return {(q >= 32) ? v.y : v.x, v.z, v.w};
         } else {
@@ -508,10 +531,10 @@ struct LaneChain {
         }
     }
     __device__ __forceinline__ void meta_put(int cwi, SBits S, uint32_t off, uint32_t nf) {
-        if constexpr (GL == 1) {
+        if constexpr (!kWide) {
             u32x4 m;
             m.x = (uint32_t)S; m.y = (uint32_t)(S >> 32); m.z = off; m.w = nf;
-            *((u32x4 *)(tile + CW * LR) + cwi) = m;
+            if (head()) *((u32x4 *)(tile + CW * LR) + cwi) = m;
         } else if (head()) {
             uint32_t *mw = (uint32_t *)(tile + CW * LR) + 8 * cwi;
             u32x4 m;
@@ -714,8 +737,8 @@ struct LaneChain {
         double t = 0.0, horizon = p.tmax, ar = 0.0;
         uint64_t n0 = 0;
         sg0 = 0; sg1 = 0; sg2 = 0; sg3 = 0;
-        constexpr int NSD = GL == 1 ? 1 : 2;                                      // doubles of sign words per lane
-        const int w_sg = d + (GL == 1 ? 0 : (hq >> 1)), w_sc = d + NSD * GL;      // my sign words; t, horizon, ar, stream position
+        constexpr int NSD = kWide ? 2 : 1;                                        // doubles of sign words per lane
+        const int w_sg = d + (GL == 1 ? 0 : NSD * (hq / PG)), w_sc = d + NSD * GL;   // my sign words; t, horizon, ar, stream position
         bool from_state = r > 0;
         if constexpr (DIAG) from_state = from_state || p.resume != 0;
         if (from_state) {
@@ -723,7 +746,7 @@ struct LaneChain {
             for (int i = 0; i < LD; ++i) y[i] = in_dim(i) ? st[(size_t)gi(i) * WAVE] : 0.0;
             const uint64_t sgw = (uint64_t)__double_as_longlong(st[(size_t)w_sg * WAVE]);
             sg0 = (uint32_t)sgw; sg1 = (uint32_t)(sgw >> 32);
-            if constexpr (GL == 2) {
+            if constexpr (kWide) {
                 const uint64_t sgx = (uint64_t)__double_as_longlong(st[(size_t)(w_sg + 1) * WAVE]);
                 sg2 = (uint32_t)sgx; sg3 = (uint32_t)(sgx >> 32);
             }
@@ -737,7 +760,7 @@ struct LaneChain {
                 const double vi = ok ? p.vinit[(size_t)cs * d + gi(i)] : 1.0;
                 const uint32_t s = (uint32_t)__double2hiint(vi) & 0x80000000u;
                 y[i] = sgn(xi, s);
-                const int lb = GE * (i >> 2) + (i & 3);
+                const int lb = lbit(i);
                 if (lb < 32) sg0 |= (s >> 31) << (lb & 31); else if (lb < 64) sg1 |= (s >> 31) << (lb & 31);
                 else if (lb < 96) sg2 |= (s >> 31) << (lb & 31); else sg3 |= (s >> 31) << (lb & 31);
             }
@@ -875,7 +898,7 @@ struct LaneChain {
 #pragma unroll
             for (int i = 0; i < LD; ++i) if (in_dim(i)) publish(st + (size_t)gi(i) * WAVE, y[i]);
             publish(st + (size_t)w_sg * WAVE, __longlong_as_double((long long)(((uint64_t)sg1 << 32) | (uint64_t)sg0)));
-            if constexpr (GL == 2) publish(st + (size_t)(w_sg + 1) * WAVE, __longlong_as_double((long long)(((uint64_t)sg3 << 32) | (uint64_t)sg2)));
+            if constexpr (kWide) publish(st + (size_t)(w_sg + 1) * WAVE, __longlong_as_double((long long)(((uint64_t)sg3 << 32) | (uint64_t)sg2)));
             if (head()) {
                 publish(st + (size_t)w_sc * WAVE, t); publish(st + (size_t)(w_sc + 1) * WAVE, horizon); publish(st + (size_t)(w_sc + 2) * WAVE, ar);
                 publish(st + (size_t)(w_sc + 3) * WAVE, __longlong_as_double((long long)rng.n));
@@ -890,13 +913,13 @@ struct LaneChain {
     }
 };
 
-template <int TARGET, int LK, bool DIAG, bool TAPE = false, int GL = 1>
-__global__ __launch_bounds__(256, LANE_WAVES) void lane_kernel(const GroupParams gp, const int32_t *flag) {
+template <int TARGET, int LK, bool DIAG, bool TAPE = false, int GL = 1, int PG = 4>
+__global__ __launch_bounds__(256, ((PG == 2 && !DIAG) ? 2 : LANE_WAVES)) void lane_kernel(const GroupParams gp, const int32_t *flag) {
     if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;      // not unit speeds: the group kernel runs instead
     extern __shared__ double smem[];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
-    double *tile = smem + (size_t)wave * lane_lds_per_wave(LK, GL);
-    LaneChain<TARGET, LK, DIAG, TAPE, GL> chain(gp.s, lane, tile);
+    double *tile = smem + (size_t)wave * lane_lds_per_wave(LK, GL, PG);
+    LaneChain<TARGET, LK, DIAG, TAPE, GL, PG> chain(gp.s, lane, tile);
     const int nb = (int)gp.nb, n_units = nb * gp.nseg;
     bool lost = false;
     for (int pulled = 0; pulled <= n_units && !lost; ++pulled) {
@@ -931,12 +954,12 @@ inline void lane_schedule(int64_t nb, int64_t slots, int64_t n_sk, int force, in
     nseg = (int32_t)((events + seg_len - 1) / seg_len);
 }
 
-template <int TARGET, int LK, bool DIAG, bool TAPE = false, int GL = 1>
+template <int TARGET, int LK, bool DIAG, bool TAPE = false, int GL = 1, int PG = 4>
 inline hipError_t launch_lane(const GroupParams &gp_in, const int32_t *flag, int rounds, hipStream_t stream) {
     GroupParams gp = gp_in;
     constexpr int wpb = 4;
-    const size_t lds = (size_t)wpb * lane_lds_per_wave(LK, GL) * sizeof(double);
-    void (*kernel)(const GroupParams, const int32_t *) = lane_kernel<TARGET, LK, DIAG, TAPE, GL>;
+    const size_t lds = (size_t)wpb * lane_lds_per_wave(LK, GL, PG) * sizeof(double);
+    void (*kernel)(const GroupParams, const int32_t *) = lane_kernel<TARGET, LK, DIAG, TAPE, GL, PG>;
     int per_cu = 0, dev = 0, cus = 0;
     hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -955,22 +978,22 @@ inline hipError_t launch_lane(const GroupParams &gp_in, const int32_t *flag, int
     return hipGetLastError();
 }
 // one translation unit per range of LK (inst_lane_zigzag*.hip); hipErrorNotSupported: not this unit's LK
-template <int TARGET, int LK0, int LK1, int GL = 1>
+template <int TARGET, int LK0, int LK1, int GL = 1, int PG = 4>
 inline hipError_t launch_lane_by_slots(int lk, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream) {
     if constexpr (LK0 > LK1) return hipErrorNotSupported;
     else {
         const bool diag = gp.s.H || gp.s.AR || gp.s.EB || gp.s.RJ || gp.s.HH || gp.s.EV ||
                           gp.s.count || gp.s.chain_map || gp.s.resume || gp.s.t_stop < __builtin_huge_val();   // (the time-horizon features: DIAG kernels)
-        return lk != LK0 ? launch_lane_by_slots<TARGET, LK0 + 1, LK1, GL>(lk, gp, flag, rounds, stream)
-                         : (diag ? launch_lane<TARGET, LK0, true, false, GL>(gp, flag, rounds, stream) : launch_lane<TARGET, LK0, false, false, GL>(gp, flag, rounds, stream));
+        return lk != LK0 ? launch_lane_by_slots<TARGET, LK0 + 1, LK1, GL, PG>(lk, gp, flag, rounds, stream)
+                         : (diag ? launch_lane<TARGET, LK0, true, false, GL, PG>(gp, flag, rounds, stream) : launch_lane<TARGET, LK0, false, false, GL, PG>(gp, flag, rounds, stream));
     }
 }
-template <int LK0, int LK1, int GL = 1>
+template <int LK0, int LK1, int GL = 1, int PG = 4>
 inline hipError_t launch_lane_range(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream) {
-    const int lk = (gp.s.d + 4 * GL - 1) / (4 * GL);
+    const int lk = (gp.s.d + PG * GL - 1) / (PG * GL);
     switch (target) {
-    case T_GAUSS_ISO: return launch_lane_by_slots<T_GAUSS_ISO, LK0, LK1, GL>(lk, gp, flag, rounds, stream);
-    case T_BANANA: return launch_lane_by_slots<T_BANANA, LK0, LK1, GL>(lk, gp, flag, rounds, stream);
+    case T_GAUSS_ISO: return launch_lane_by_slots<T_GAUSS_ISO, LK0, LK1, GL, PG>(lk, gp, flag, rounds, stream);
+    case T_BANANA: return launch_lane_by_slots<T_BANANA, LK0, LK1, GL, PG>(lk, gp, flag, rounds, stream);
     default: return hipErrorNotSupported;
     }
 }
@@ -983,6 +1006,8 @@ hipError_t launch_lane_check(const double *vinit, int64_t n, int32_t *flag, hipS
 hipError_t launch_lane2_zigzag(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);      // LK = 13
 hipError_t launch_lane2_zigzag_a(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);    // LK = 7 .. 9
 hipError_t launch_lane2_zigzag_b(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);    // LK = 10 .. 12
+// a pair of lanes per chain with two coordinates of a slot each (GL = 2, PG = 2): d = 25 .. 52, LK = ceil(d / 4), mid-sized launches
+hipError_t launch_lane2q_zigzag(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);     // LK = 7 .. 13
 #endif
 
 }  // namespace pdmp

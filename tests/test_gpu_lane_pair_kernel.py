@@ -23,7 +23,7 @@ def _run(engine, oracle, dim, target, C, n_sk, seed=3, init_seed=0, diagnostics=
     got = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=seed, diagnostics=diagnostics)
     import os
     if os.environ.get("PDMP_LANE") == "1":
-        assert s.last_launch_form() == 4, "this case is meant to run in the lane kernel"
+        assert s.last_launch_form() == 7, "this case is meant to run in the lane kernel"
     return s, cfg, x, v, got
 
 
@@ -79,7 +79,7 @@ def test_pair_kernel_zero_start(engine, oracle, lane):
     x = np.zeros((33, 100))
     v = np.where(np.random.default_rng(5).random((33, 100)) < 0.5, -1.0, 1.0)
     got = engine.sample_skeleton_ensemble(s, 40, x, v, seed=9, diagnostics=True)
-    assert s.last_launch_form() == 4
+    assert s.last_launch_form() == 7
     assert_bitwise(got, oracle.sample_skeleton(cfg, 40, x, v, 9, diagnostics=True))
 
 
@@ -100,7 +100,7 @@ def test_pair_kernel_full_machine(engine, oracle, monkeypatch):
     C = 33000
     x, v = make_init("ZigZagAD", 100, C, target="banana")
     got = engine.sample_skeleton_ensemble(s, 64, x, v, seed=77, diagnostics=False)
-    assert s.last_launch_form() == 4
+    assert s.last_launch_form() == 7
     for c in np.arange(0, C, 1291):
         r1 = oracle.sample_skeleton(cfg, 64, x[c:c + 1], v[c:c + 1], 77, chain_id_offset=int(c), diagnostics=False)
         for k in ("X", "V", "t"):
@@ -129,7 +129,7 @@ def test_pair_kernel_unaligned_outputs(engine, oracle, lane, offs, n_sk, dim):
         out[name] = b[off:off + n].view(shape)
     from pdmpflux.jl_amd import ensemble
     got = ensemble.sample_skeleton_device(s, n_sk, torch.from_numpy(x).to(dev), torch.from_numpy(v).to(dev), seed=6, out=out)
-    assert s.last_launch_form() == 4
+    assert s.last_launch_form() == 7
     ref = oracle.sample_skeleton(cfg, n_sk, x, v, 6, diagnostics=False)
     for name in ("X", "V", "t"):
         b, off, n = bufs[name]
@@ -147,4 +147,119 @@ def test_pair_kernel_time_horizon_chunks(engine, oracle, lane, target, dim):
     x, v = make_init("ZigZagAD", dim, C, seed=5, target=target)
     stats = {}
     run_until(engine, oracle, s, cfg, x, v, T, 4, 16, stats, lo=7)
-    assert s.last_launch_form() == 4 and stats["chunks"] >= 2
+    assert s.last_launch_form() == 7 and stats["chunks"] >= 2
+
+
+# ---- the pair form at d = 25 .. 52 (two coordinates of a slot per lane, GROUP(4)): mid-sized launches; PDMP_LANE=2 forces it
+
+@pytest.fixture
+def quad(monkeypatch):
+    monkeypatch.setenv("PDMP_LANE", "2")
+    return monkeypatch
+
+
+def _runq(engine, oracle, dim, target, C, n_sk, seed=3, init_seed=0, diagnostics=True, **kw):
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", dim, target, **kw)
+    assert s.group_lanes() == 4
+    x, v = make_init("ZigZagAD", dim, C, seed=init_seed, target=target)
+    got = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=seed, diagnostics=diagnostics)
+    assert s.last_launch_form() == 7, "this case is meant to run in the pair form of the lane kernel"
+    return s, cfg, x, v, got
+
+
+@pytest.mark.parametrize("dim", [25, 27, 28, 29, 32, 33, 36, 37, 40, 41, 44, 45, 47, 48, 49, 50, 51, 52])
+@pytest.mark.parametrize("target", ["iso", "banana"])
+def test_quad_pair_matches_checker(engine, oracle, quad, dim, target):
+    if dim < 27:
+        pytest.skip("d = 25, 26 run with G = 2 lanes per chain by default")
+    s, cfg, x, v, got = _runq(engine, oracle, dim, target, 75, 100)
+    assert_bitwise(got, oracle.sample_skeleton(cfg, 100, x, v, 3, diagnostics=True))
+
+
+@pytest.mark.parametrize("target", ["iso", "banana"])
+def test_quad_pair_equals_the_other_forms(engine, oracle, monkeypatch, target):
+    """Group kernel (G = 4), one lane per chain, a pair of lanes per chain: one result."""
+    outs = []
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("PDMP_LANE", mode)
+        s, cfg = make_pair(engine, oracle, "ZigZagAD", 50, target)
+        x, v = make_init("ZigZagAD", 50, 167, seed=1, target=target)
+        outs.append(engine.sample_skeleton_ensemble(s, 150, x, v, seed=11, diagnostics=True))
+        assert s.last_launch_form() == {"0": 3, "1": 4, "2": 7}[mode]
+    assert_bitwise(outs[1], outs[0])
+    assert_bitwise(outs[2], outs[0])
+
+
+@pytest.mark.parametrize("segments", [2, 7, 1000])
+@pytest.mark.parametrize("target,dim", [("iso", 50), ("banana", 50), ("banana", 31), ("iso", 46)])
+def test_quad_pair_segment_handoff(engine, oracle, quad, segments, target, dim):
+    quad.setenv("PDMP_FORCE_SEGMENTS", str(segments))
+    s, cfg, x, v, got = _runq(engine, oracle, dim, target, 40, 96)
+    assert_bitwise(got, oracle.sample_skeleton(cfg, 96, x, v, 3, diagnostics=True))
+
+
+@pytest.mark.parametrize("dim", [27, 34, 41, 50, 52])
+@pytest.mark.parametrize("target", ["iso", "banana"])
+def test_quad_pair_without_diagnostics(engine, oracle, quad, dim, target):
+    """The throughput instantiations (two waves per SIMD, no diagnostic arrays)."""
+    quad.setenv("PDMP_FORCE_SEGMENTS", "4")
+    s, cfg, x, v, got = _runq(engine, oracle, dim, target, 67, 72, seed=17, diagnostics=False)
+    assert_bitwise(got, oracle.sample_skeleton(cfg, 72, x, v, 17, diagnostics=False), keys=("X", "V", "t"))
+
+
+@pytest.mark.parametrize("kw", [{"tmax": 0.0}, {"tmax": 0.05}, {"tmax": 20.0}, {"adaptive": False, "tmax": 0.4}])
+def test_quad_pair_horizons(engine, oracle, quad, kw):
+    s, cfg, x, v, got = _runq(engine, oracle, 50, "banana", 40, 60, **kw)
+    assert_bitwise(got, oracle.sample_skeleton(cfg, 60, x, v, 3, diagnostics=True))
+
+
+@pytest.mark.parametrize("offs", [(0, 5, 2), (8, 3, 7), (3, 0, 0)])
+@pytest.mark.parametrize("n_sk,dim", [(40, 50), (40, 51), (37, 50), (48, 27), (31, 45)])
+def test_quad_pair_unaligned_outputs(engine, oracle, quad, offs, n_sk, dim):
+    import torch
+    quad.setenv("PDMP_FORCE_SEGMENTS", "3")
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", dim, "banana")
+    C = 40
+    x, v = make_init("ZigZagAD", dim, C, seed=4, target="banana")
+    dev = torch.device("cuda:0")
+    guard = -12345.678
+    bufs, out = {}, {}
+    for name, shape, off in (("X", (C, n_sk, dim), offs[0]), ("V", (C, n_sk, dim), offs[1]), ("t", (C, n_sk), offs[2])):
+        n = int(np.prod(shape))
+        b = torch.full((n + 16,), guard, dtype=torch.float64, device=dev)
+        bufs[name] = (b, off, n)
+        out[name] = b[off:off + n].view(shape)
+    from pdmpflux.jl_amd import ensemble
+    got = ensemble.sample_skeleton_device(s, n_sk, torch.from_numpy(x).to(dev), torch.from_numpy(v).to(dev), seed=6, out=out)
+    assert s.last_launch_form() == 7
+    ref = oracle.sample_skeleton(cfg, n_sk, x, v, 6, diagnostics=False)
+    for name in ("X", "V", "t"):
+        b, off, n = bufs[name]
+        assert np.array_equal(got[name].cpu().numpy(), ref[name]), name
+        assert bool((b[:off] == guard).all()) and bool((b[off + n:] == guard).all()), name
+
+
+@pytest.mark.parametrize("target", ["iso", "banana"])
+def test_quad_pair_time_horizon_chunks(engine, oracle, quad, target):
+    from test_gpu_time_horizon_chunks import _run as run_until
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", 50, target)
+    x, v = make_init("ZigZagAD", 50, 75, seed=5, target=target)
+    stats = {}
+    run_until(engine, oracle, s, cfg, x, v, 1.6, 4, 16, stats, lo=7)
+    assert s.last_launch_form() == 7 and stats["chunks"] >= 2
+
+
+def test_quad_pair_default_selection(engine, oracle, monkeypatch):
+    """No environment: 25 000 chains (the 4-GPU shard of the headline ensemble) take the pair form, 12 500 the group kernel, 43 000 one
+    lane per chain; a strided sample of the 25 000 bit for bit against the checker."""
+    monkeypatch.delenv("PDMP_LANE", raising=False)
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", 50, "iso")
+    for C, form in ((12500, 3), (25000, 7), (43000, 4)):
+        x, v = make_init("ZigZagAD", 50, C)
+        got = engine.sample_skeleton_ensemble(s, 48, x, v, seed=5, diagnostics=False)
+        assert s.last_launch_form() == form, (C, s.last_launch_form())
+        if C == 25000:
+            for c in np.arange(0, C, 997):
+                r1 = oracle.sample_skeleton(cfg, 48, x[c:c + 1], v[c:c + 1], 5, chain_id_offset=int(c), diagnostics=False)
+                for k in ("X", "V", "t"):
+                    assert np.array_equal(got[k][c], r1[k][0]), (k, c)
