@@ -48,7 +48,7 @@ enum { PDMP_ZIGZAG = 0, PDMP_BPS = 1, PDMP_BOOMERANG = 2, PDMP_FECMC = 3,
 enum { PDMP_T_GAUSS_ISO = 0,   /* U = |x|^2/2                         (README.md:36-38)            */
        PDMP_T_GAUSS_DIAG = 1,  /* U = sum prec_i (x_i-mu_i)^2/2 ; params = mu[d], prec[d]            */
        PDMP_T_BANANA = 2,      /* U_banana                           (test/test_config.jl:33-36)   */
-       PDMP_T_GAUSS_DENSE = 3, /* U = x'Px/2 ; params = P[d*d] column-major                         */
+       PDMP_T_GAUSS_DENSE = 3, /* U = x'Px/2 ; params = P[d*d] column-major (Zig-Zag, BPS; Boomerang at dim <= 1024: batched form only) */
        PDMP_T_USER = 4         /* potential given as source: pdmp_create_from_source only              */ };
 /* AD_backend for the time-derivative of the rate (UpperBound.jl:209-224, AbstractPDMP.jl:18-28) */
 enum { PDMP_DERIV_FORWARD = 0 /* "ForwardDiff": exact forward-mode duals */,

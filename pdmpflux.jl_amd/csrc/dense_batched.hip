@@ -291,6 +291,8 @@ struct DiParams {
     double *X, *V, *t, *H, *AR, *EV;
     int32_t *EB, *RJ, *HH;
     int32_t *status;             // [0] itercap, [1] guard
+    double refresh;              // BPS (dr_bps_kernel): refresh_rate
+    int32_t gaussian_velocity, pad;
 };
 
 // SGN: signed_bound (the constructor default).  There the slope of every coordinate's rate is the same double at both ends of a
@@ -509,6 +511,401 @@ __global__ __launch_bounds__(256, SGN ? 2 : 1) void di_segment_kernel(const DiPa
     }
 }
 
+
+// ---------------------------------------------------------------- BPS on a dense precision: one GEMM per EVENT (round 3)
+// BouncyParticleSamplers.jl:39-74 with grad-U = P x.  Between two events of a chain nothing needs a product with P: along the flow
+//     <grad-U(x + v t), v> = <P x, v> + t <P v, v> = A + B t,
+// so with gx = P x and gv = P v at hand the whole thinning iteration -- the grid bound of the scalar bounded function
+// (upper_bound_grid, UpperBound.jl:92-137: values A + B t_j (+ refresh_rate), slope B, tangent intersections, cumulative sum,
+// inversion), horizon moves, rejections, the proposal's rate -- is two dot products and scalar arithmetic, wave-uniform.  Only an
+// accepted event changes v other than by a flow (reflection v - 2 <g, v> / <g, g> g with g = P x at the event, or a refresh by
+// normals), and P v' is a product with all of P: the chain records the event, writes x and v' back and YIELDS; the host multiplies
+// P [x | v] of ALL chains with one fp64 GEMM (rocBLAS, matrix cores) and launches the next event.  n_sk - 1 GEMMs of d x d x 2C per
+// launch instead of ~12 mat-vecs per event and chain (the group kernel's dense target: 7e4 events/s at d = 1000).  P x is taken
+// from the GEMM at every event too (no recurrence across events, no drift).  One wave per chain, layout and state as
+// di_segment_kernel.  Against the checker (reference order: a mat-vec per grid time) to a tolerance, as the Zig-Zag forms.
+template <int KC>
+__global__ __launch_bounds__(256, 2) void dr_bps_kernel(const DiParams p) {
+    const int lane = lane_id();
+    const int64_t c = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (c >= p.C) return;
+    DiState cs;
+    if (p.k_begin == 0) { cs.t = 0.0; cs.horizon = p.tmax; cs.rng_n = 0; cs.dead = 0; cs.pad = 0; }
+    else cs = p.st[c];
+    if (cs.dead) return;
+    const int d = p.d;
+    const bool adaptive = p.adaptive != 0, sgn = p.signed_bound != 0;
+    const double refresh = p.refresh, refresh_b = sgn ? p.refresh : 0.0;     // (the signed bound adds refresh_rate to every cell again, AbstractPDMP.jl:104-112)
+    __shared__ double x_lds[4][KC * WAVE];
+    double *x = x_lds[threadIdx.x >> 6] + lane;          // slot s at x[s * WAVE]
+    double v[KC], gx[KC], gv[KC];
+    {
+        const double *xin = p.In + (size_t)c * d, *vin = p.In + ((size_t)p.C + (size_t)c) * d;
+        const double *gxin = p.Out + (size_t)c * d, *gvin = p.Out + ((size_t)p.C + (size_t)c) * d;
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+            const int i = s * WAVE + lane;
+            const bool ok = i < d;
+            x[s * WAVE] = ok ? xin[i] : 0.0; v[s] = ok ? vin[i] : 0.0; gx[s] = ok ? gxin[i] : 0.0; gv[s] = ok ? gvin[i] : 0.0;
+        }
+    }
+    ChainRng rng;
+    rng.init(p.seed, (uint64_t)(p.chain0 + c));
+    rng.restore(cs.rng_n);
+    double t = cs.t, horizon = cs.horizon, ts = 0.0, ar = 0.0, E = 0.0, hB = horizon;
+    double ev[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    int errored = 0, rejected = 0, hits = 0, mode = DB_FRESH;
+    int64_t k = p.k_begin, it = 0;
+    bool dead = false;
+
+    auto record = [&](int64_t kk) {
+        const size_t e = (size_t)c * (size_t)p.n_sk + (size_t)kk;
+        double *Xe = p.X + e * (size_t)d, *Ve = p.V + e * (size_t)d;
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+            const int i = s * WAVE + lane;
+            if (i < d) { PDMP_ROW_STORE(&Xe[i], x[s * WAVE]); PDMP_ROW_STORE(&Ve[i], v[s]); }
+        }
+        if (lane == 0) {
+            p.t[e] = t;
+            if (p.H) p.H[e] = horizon;
+            if (p.AR) p.AR[e] = ar;
+            if (p.EB) p.EB[e] = errored;
+            if (p.RJ) p.RJ[e] = rejected;
+            if (p.HH) p.HH[e] = hits;
+            if (p.EV) for (int q = 0; q < 5; ++q) p.EV[5 * e + q] = ev[q];
+        }
+    };
+    auto flow = [&](double tau) {              // x <- x + v tau (BouncyParticleSamplers.jl:32) and P x with it
+#pragma unroll
+        for (int s = 0; s < KC; ++s) { x[s * WAVE] = fma(v[s], tau, x[s * WAVE]); gx[s] = fma(tau, gv[s], gx[s]); }
+    };
+
+    if (k == 0) { record(0); k = 1; }          // init_state + record of the initial state (sample.jl:271-272)
+    while (k < p.k_end) {
+        if (++it > p.cap * 4) { dead = true; break; }
+        // ---- the rate along the flow from the current state: A + B t
+        double pa = 0.0, pb = 0.0;
+#pragma unroll
+        for (int s = 0; s < KC; ++s) { pa += gx[s] * v[s]; pb += gv[s] * v[s]; }
+        const double A = wave_sum(pa), B = wave_sum(pb);
+        // ---- bound over [0, harg]: one_step_of_thinning! (:65-85) / erroneous_acceptance_rate! (:131-151) / if_reject! (:188-203)
+        const double harg = (mode == DB_ERR) ? horizon / 2 : ((mode == DB_REUSE) ? hB : horizon);
+        hB = harg;
+        const double h = harg / 9.0;
+        const double e1 = rng.exponential();
+        E = (mode == DB_REUSE) ? E + e1 : e1;
+        double acc = 0.0, cprev = 0.0, bj = 0.0, tp = __builtin_huge_val(), lb = 0.0;
+        bool found = false;
+        auto point = [&](double tt, double &val, double &slp) {                // the bounded function and its t-derivative, :39-47 / UpperBound.jl:97-102
+            const double dv = fma(tt, B, A);
+            val = (sgn ? dv : fmax(0.0, dv)) + refresh;                        // includes refresh_rate (Q2)
+            slp = sgn ? B : ((0.0 < dv) ? B : 0.0);
+        };
+        double f0, s0;
+        point(0.0, f0, s0);
+        for (int j = 0; j < 9 && !found; ++j) {                                // cells in grid order, lazily (upper_bound_grid, UpperBound.jl:92-137)
+            double f1, s1;
+            point((j == 8) ? harg : (double)(j + 1) * h, f1, s1);
+            const double num = fma(s1, h, f0 - f1);                            // :123
+            const double den = s1 - s0;
+            const double q = (den == 0.0) ? ((num > 0.0) ? h : 0.0) : fmin(fmax(num / den, 0.0), h);   // :124-125
+            const double inter = fma(s0, q, f0);                               // :127
+            bj = fmax(fmax(fmax(f0, f1), inter), 0.0) + refresh_b;             // :128-131
+            acc += bj;
+            const double cj = acc * h;                                         // :133-134
+            if (!(cj < E)) { found = true; tp = (double)j * h + (E - cprev) / (cj - cprev) * h; }   // next_event, :264-273
+            cprev = cj;
+            f0 = f1; s0 = s1;
+        }
+        lb = bj;
+        bool propose;
+        if (mode == DB_ERR) {                                                  // :131-151
+            if (adaptive) horizon = hB;
+            errored++;
+            { const int slot = errored % 5;
+#pragma unroll
+              for (int q = 0; q < 5; ++q) if (q == slot) ev[q] = ar; }
+            propose = tp < horizon;
+        } else if (mode == DB_REUSE) {                                         // :188-203
+            if (adaptive) horizon = horizon / 1.04;
+            rejected++;
+            if (tp > horizon) { flow(horizon); ts += horizon; hits++; }
+            propose = tp < horizon;
+        } else if (tp > horizon) {                                             // move_to_horizon!, :87-101
+            flow(horizon);
+            ts += horizon;
+            hits++;
+            if (adaptive) horizon = horizon * 1.01;
+            propose = false;
+        } else {
+            propose = tp < horizon;
+        }
+        mode = DB_FRESH;
+        if (!propose) continue;
+        // ---- proposal at tp (ac_step!, :113-129): lambda = max(0, <grad-U(x + v tp), v>) + refresh_rate
+        const double raw = fma(tp, B, A);
+        const double lam = fmax(0.0, raw) + refresh;
+        ar = lam / lb;
+        if (ar > 1.0) { mode = DB_ERR; continue; }
+        const double u = rng.uniform();
+        if (!(u < ar)) { mode = DB_REUSE; continue; }
+        // ---- accepted (if_accept!, :170-186): flow, then velocity_jump (BouncyParticleSamplers.jl:49-74)
+        flow(tp);                                                              // gx = grad-U at the event
+        const double bounce = fmax(0.0, raw);                                  // dot(grad-U(x), v) = the proposal's sum, :51-52
+        const double prob = bounce / (bounce + refresh);                       // NaN if both 0 (Q9): then the refresh branch
+        const double u2 = rng.uniform();
+        if (u2 < prob) {
+            double pg = 0.0;
+#pragma unroll
+            for (int s = 0; s < KC; ++s) pg += gx[s] * gx[s];
+            const double gg = wave_sum(pg);
+            if (gg != 0.0) {
+                const double scale = 2.0 * raw / gg;                           // :60
+#pragma unroll
+                for (int s = 0; s < KC; ++s) v[s] = v[s] - scale * gx[s];
+            }
+        } else {                                                               // randn!, :65-71
+            double pz = 0.0;
+#pragma unroll
+            for (int s = 0; s < KC; ++s) {
+                const int i = s * WAVE + lane;
+                v[s] = (i < d) ? rng.normal_coord(i) : 0.0;
+                pz += v[s] * v[s];
+            }
+            rng.normals_done(d);
+            if (!p.gaussian_velocity) {                                        // normalize!, :71
+                const double inv = 1.0 / __dsqrt_rn(wave_sum(pz));
+#pragma unroll
+                for (int s = 0; s < KC; ++s) v[s] = v[s] * inv;
+            }
+        }
+        t = t + tp + ts;
+        ts = 0.0;
+        record(k);
+        errored = 0; rejected = 0; hits = 0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) ev[q] = 0.0;
+        it = 0;
+        ++k;
+    }
+    {                                          // x, v back into the GEMM's input: P x and P v' come with the next launch
+        double *xo = p.In + (size_t)c * d, *vo = p.In + ((size_t)p.C + (size_t)c) * d;
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+            const int i = s * WAVE + lane;
+            if (i < d) { xo[i] = x[s * WAVE]; vo[i] = v[s]; }
+        }
+    }
+    if (lane == 0) {
+        cs.t = t; cs.horizon = horizon; cs.rng_n = rng.n; cs.dead = dead ? 1 : 0;
+        p.st[c] = cs;
+        if (dead) atomicAdd(&p.status[0], 1);
+    }
+}
+
+// ---- Boomerang on a dense precision, the same scheme: between events the flow is a rotation of (x, v) and of (P x, P v) by the same angle
+// (16 slots: x, v, P x, P v and the rotation's temporaries need more than 256 registers: one wave per SIMD)
+template <int KC>
+__global__ __launch_bounds__(256, (KC == 16 ? 1 : 2)) void dr_boom_kernel(const DiParams p) {
+    const int lane = lane_id();
+    const int64_t c = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (c >= p.C) return;
+    DiState cs;
+    if (p.k_begin == 0) { cs.t = 0.0; cs.horizon = p.tmax; cs.rng_n = 0; cs.dead = 0; cs.pad = 0; }
+    else cs = p.st[c];
+    if (cs.dead) return;
+    const int d = p.d;
+    const bool adaptive = p.adaptive != 0, sgn = p.signed_bound != 0;
+    const double refresh = p.refresh, refresh_b = sgn ? p.refresh : 0.0;     // (the signed bound adds refresh_rate to every cell again, AbstractPDMP.jl:104-112)
+    __shared__ double x_lds[4][KC * WAVE];
+    double *x = x_lds[threadIdx.x >> 6] + lane;          // slot s at x[s * WAVE]
+    double v[KC], gx[KC], gv[KC];
+    {
+        const double *xin = p.In + (size_t)c * d, *vin = p.In + ((size_t)p.C + (size_t)c) * d;
+        const double *gxin = p.Out + (size_t)c * d, *gvin = p.Out + ((size_t)p.C + (size_t)c) * d;
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+            const int i = s * WAVE + lane;
+            const bool ok = i < d;
+            x[s * WAVE] = ok ? xin[i] : 0.0; v[s] = ok ? vin[i] : 0.0; gx[s] = ok ? gxin[i] : 0.0; gv[s] = ok ? gvin[i] : 0.0;
+        }
+    }
+    ChainRng rng;
+    rng.init(p.seed, (uint64_t)(p.chain0 + c));
+    rng.restore(cs.rng_n);
+    double t = cs.t, horizon = cs.horizon, ts = 0.0, ar = 0.0, E = 0.0, hB = horizon;
+    double ev[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    int errored = 0, rejected = 0, hits = 0, mode = DB_FRESH;
+    int64_t k = p.k_begin, it = 0;
+    bool dead = false;
+
+    auto record = [&](int64_t kk) {
+        const size_t e = (size_t)c * (size_t)p.n_sk + (size_t)kk;
+        double *Xe = p.X + e * (size_t)d, *Ve = p.V + e * (size_t)d;
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+            const int i = s * WAVE + lane;
+            if (i < d) { PDMP_ROW_STORE(&Xe[i], x[s * WAVE]); PDMP_ROW_STORE(&Ve[i], v[s]); }
+        }
+        if (lane == 0) {
+            p.t[e] = t;
+            if (p.H) p.H[e] = horizon;
+            if (p.AR) p.AR[e] = ar;
+            if (p.EB) p.EB[e] = errored;
+            if (p.RJ) p.RJ[e] = rejected;
+            if (p.HH) p.HH[e] = hits;
+            if (p.EV) for (int q = 0; q < 5; ++q) p.EV[5 * e + q] = ev[q];
+        }
+    };
+    auto flow = [&](double tau) {              // the rotation (x, v) <- (x cos + v sin, -x sin + v cos), BoomerangSamplers.jl:31, and (P x, P v) with it
+        double sn, cn;
+        det_sincos(tau, sn, cn);
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+            const double xo = x[s * WAVE], vo = v[s], go = gx[s], ho = gv[s];
+            x[s * WAVE] = xo * cn + vo * sn; v[s] = (-xo) * sn + vo * cn;
+            gx[s] = go * cn + ho * sn; gv[s] = (-go) * sn + ho * cn;
+        }
+    };
+
+    if (k == 0) { record(0); k = 1; }          // init_state + record of the initial state (sample.jl:271-272)
+    while (k < p.k_end) {
+        if (++it > p.cap * 4) { dead = true; break; }
+        // ---- the rate along the flow from the current state.  The reference's Boomerang RATE uses grad-U itself (BoomerangSamplers.jl:38-41;
+        // only the jump uses grad-U - x: Q8 of SURVEY.md 3.7, reproduced), and grad-U = P x is linear, so with gx = P x, gv = P v:
+        //   <grad-U(x_t), v_t> = <gx c + gv s, -x s + v c> = A1 c^2 - A2 s^2 + (A3 - A4) c s,   A1 = <gx, v>, A2 = <gv, x>, A3 = <gv, v>, A4 = <gx, x>
+        double p1 = 0.0, p2 = 0.0, p3 = 0.0, p4 = 0.0;
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+            const double xo = x[s * WAVE];
+            p1 += gx[s] * v[s]; p2 += gv[s] * xo; p3 += gv[s] * v[s]; p4 += gx[s] * xo;
+        }
+        const double A1 = wave_sum(p1), A2 = wave_sum(p2), Dq = wave_sum(p3) - wave_sum(p4), A12 = A1 + A2;
+        auto rate_at = [&](double tt, double &dv, double &de) {
+            double sn, cn;
+            det_sincos(tt, sn, cn);
+            const double cc = cn * cn, ss = sn * sn, cs2 = cn * sn;
+            dv = A1 * cc - A2 * ss + Dq * cs2;
+            de = Dq * (cc - ss) - 2.0 * cs2 * A12;                             // its t-derivative (the forward-mode slope)
+        };
+        // ---- bound over [0, harg]: one_step_of_thinning! (:65-85) / erroneous_acceptance_rate! (:131-151) / if_reject! (:188-203)
+        const double harg = (mode == DB_ERR) ? horizon / 2 : ((mode == DB_REUSE) ? hB : horizon);
+        hB = harg;
+        const double h = harg / 9.0;
+        const double e1 = rng.exponential();
+        E = (mode == DB_REUSE) ? E + e1 : e1;
+        double acc = 0.0, cprev = 0.0, bj = 0.0, tp = __builtin_huge_val(), lb = 0.0;
+        bool found = false;
+        auto point = [&](double tt, double &val, double &slp) {                // the bounded function and its t-derivative, BoomerangSamplers.jl:38-46 / UpperBound.jl:97-102
+            double dv, de;
+            rate_at(tt, dv, de);
+            val = (sgn ? dv : fmax(0.0, dv)) + refresh;                        // includes refresh_rate (Q2)
+            slp = sgn ? de : ((0.0 < dv) ? de : 0.0);
+        };
+        double f0, s0;
+        point(0.0, f0, s0);
+        for (int j = 0; j < 9 && !found; ++j) {                                // cells in grid order, lazily (upper_bound_grid, UpperBound.jl:92-137)
+            double f1, s1;
+            point((j == 8) ? harg : (double)(j + 1) * h, f1, s1);
+            const double num = fma(s1, h, f0 - f1);                            // :123
+            const double den = s1 - s0;
+            const double q = (den == 0.0) ? ((num > 0.0) ? h : 0.0) : fmin(fmax(num / den, 0.0), h);   // :124-125
+            const double inter = fma(s0, q, f0);                               // :127
+            bj = fmax(fmax(fmax(f0, f1), inter), 0.0) + refresh_b;             // :128-131
+            acc += bj;
+            const double cj = acc * h;                                         // :133-134
+            if (!(cj < E)) { found = true; tp = (double)j * h + (E - cprev) / (cj - cprev) * h; }   // next_event, :264-273
+            cprev = cj;
+            f0 = f1; s0 = s1;
+        }
+        lb = bj;
+        bool propose;
+        if (mode == DB_ERR) {                                                  // :131-151
+            if (adaptive) horizon = hB;
+            errored++;
+            { const int slot = errored % 5;
+#pragma unroll
+              for (int q = 0; q < 5; ++q) if (q == slot) ev[q] = ar; }
+            propose = tp < horizon;
+        } else if (mode == DB_REUSE) {                                         // :188-203
+            if (adaptive) horizon = horizon / 1.04;
+            rejected++;
+            if (tp > horizon) { flow(horizon); ts += horizon; hits++; }
+            propose = tp < horizon;
+        } else if (tp > horizon) {                                             // move_to_horizon!, :87-101
+            flow(horizon);
+            ts += horizon;
+            hits++;
+            if (adaptive) horizon = horizon * 1.01;
+            propose = false;
+        } else {
+            propose = tp < horizon;
+        }
+        mode = DB_FRESH;
+        if (!propose) continue;
+        // ---- proposal at tp (ac_step!, :113-129): lambda = max(0, <grad-U(x_tp), v_tp>) + refresh_rate
+        double raw, raw_e;
+        rate_at(tp, raw, raw_e);
+        const double lam = fmax(0.0, raw) + refresh;
+        ar = lam / lb;
+        if (ar > 1.0) { mode = DB_ERR; continue; }
+        const double u = rng.uniform();
+        if (!(u < ar)) { mode = DB_REUSE; continue; }
+        // ---- accepted (if_accept!, :170-186): flow, then velocity_jump (BoomerangSamplers.jl:49-67)
+        flow(tp);                                                              // gx - x = grad-U_effective at the event
+        double pgv = 0.0;                                                      // dot(grad-U(x) - x, v): the JUMP's effective gradient, :51-52 (Q8)
+#pragma unroll
+        for (int s = 0; s < KC; ++s) pgv += (gx[s] - x[s * WAVE]) * v[s];
+        const double bounce = fmax(0.0, wave_sum(pgv));
+        const double prob = bounce / (bounce + refresh);                       // NaN if both 0 (Q9): then the refresh branch
+        const double u2 = rng.uniform();
+        if (u2 < prob) {                                                       // reflection on the unit normal e = grad-U_eff / |grad-U_eff|, :58-59
+            double pg = 0.0;
+#pragma unroll
+            for (int s = 0; s < KC; ++s) { const double ge = gx[s] - x[s * WAVE]; pg += ge * ge; }
+            const double nrm = __dsqrt_rn(wave_sum(pg));
+            double pe = 0.0;
+#pragma unroll
+            for (int s = 0; s < KC; ++s) pe += v[s] * ((gx[s] - x[s * WAVE]) / nrm);
+            const double ve = 2.0 * wave_sum(pe);
+#pragma unroll
+            for (int s = 0; s < KC; ++s) v[s] = v[s] - ve * ((gx[s] - x[s * WAVE]) / nrm);
+        } else {                                                               // randn, :61-65
+            double pz = 0.0;
+#pragma unroll
+            for (int s = 0; s < KC; ++s) {
+                const int i = s * WAVE + lane;
+                v[s] = (i < d) ? rng.normal_coord(i) : 0.0;
+                pz += v[s] * v[s];
+            }
+            rng.normals_done(d);
+            (void)pz;
+        }
+        t = t + tp + ts;
+        ts = 0.0;
+        record(k);
+        errored = 0; rejected = 0; hits = 0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) ev[q] = 0.0;
+        it = 0;
+        ++k;
+    }
+    {                                          // x, v back into the GEMM's input: P x and P v' come with the next launch
+        double *xo = p.In + (size_t)c * d, *vo = p.In + ((size_t)p.C + (size_t)c) * d;
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+            const int i = s * WAVE + lane;
+            if (i < d) { xo[i] = x[s * WAVE]; vo[i] = v[s]; }
+        }
+    }
+    if (lane == 0) {
+        cs.t = t; cs.horizon = horizon; cs.rng_n = rng.n; cs.dead = dead ? 1 : 0;
+        p.st[c] = cs;
+        if (dead) atomicAdd(&p.status[0], 1);
+    }
+}
+
 }  // namespace pdmp
 
 using namespace pdmp;
@@ -598,7 +995,7 @@ fail:
 #undef DB_BLAS
 }
 
-extern "C" int pdmp_dense_batched_last_mode(void) { return g_last_mode; }   // 0 none, 1 GEMM per phase, 2 incremental
+extern "C" int pdmp_dense_batched_last_mode(void) { return g_last_mode; }   // 0 none, 1 GEMM per phase, 2 incremental (Zig-Zag), 3 one GEMM per event (BPS)
 
 
 // Incremental driver: segments of `resync` events (PDMP_DENSE_RESYNC, default 256); before each segment one fp64 GEMM
@@ -639,6 +1036,7 @@ extern "C" int pdmp_dense_incremental_run(int device, int d, int signed_bound, i
     p.In = In; p.Out = Out; p.P = P_dev; p.st = st;
     p.X = X; p.V = V; p.t = t; p.H = H; p.AR = AR; p.EV = EV; p.EB = EB; p.RJ = RJ; p.HH = HH;
     p.status = status;
+    p.refresh = 0.0; p.gaussian_velocity = 0; p.pad = 0;
     const dim3 grid((unsigned)((C + 3) / 4)), block(256);
     const double one = 1.0, zero = 0.0;
     g_last_phases = 0; g_last_columns = 0; g_last_mode = 2;
@@ -654,6 +1052,65 @@ extern "C" int pdmp_dense_incremental_run(int device, int d, int signed_bound, i
         } else {
             if (d <= 4 * WAVE) hipLaunchKernelGGL((di_segment_kernel<4, false>), grid, block, 0, stream, p);
             else hipLaunchKernelGGL((di_segment_kernel<8, false>), grid, block, 0, stream, p);
+        }
+        DB_TRY(hipGetLastError());
+        k0 = k1;
+    }
+    return 0;
+#undef DB_TRY
+#undef DB_BLAS
+}
+
+// BPS / Boomerang on a dense precision: one GEMM + one launch of dr_bps_kernel / dr_boom_kernel per skeleton column (the first launch records columns 0 and 1).
+// Asynchronous on `stream`, workspace as pdmp_dense_incremental_run.  Returns 0, -3, or -5 when d > 1024.
+extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_bound, int adaptive, int gaussian_velocity, double tmax, double refresh,
+                                  int64_t cap, const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
+                                  const double *xinit, const double *vinit, double *X, double *V, double *t,
+                                  double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
+                                  int32_t *status, void *stream_v, void **ws, size_t *ws_cap, char *err, int errlen) {
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (d > 16 * WAVE) return -5;
+#define DB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { snprintf(err, errlen, "%s: %s", #expr, hipGetErrorString(e_)); return -3; } } while (0)
+#define DB_BLAS(expr) do { rocblas_status s_ = (expr); if (s_ != rocblas_status_success) { snprintf(err, errlen, "%s: rocblas status %d", #expr, (int)s_); return -3; } } while (0)
+    const size_t n = (size_t)C * (size_t)d;
+    const size_t need = 4 * n * 8 + (size_t)C * sizeof(DiState);
+    if (need > *ws_cap) {
+        if (*ws) { DB_TRY(hipStreamSynchronize(stream)); DB_TRY(hipFree(*ws)); *ws = nullptr; *ws_cap = 0; }
+        DB_TRY(hipMalloc(ws, need));
+        *ws_cap = need;
+    }
+    double *In = (double *)*ws, *Out = In + 2 * n;
+    DiState *st = (DiState *)(Out + 2 * n);
+    rocblas_handle hb = db_handle(device);
+    if (!hb) { snprintf(err, errlen, "rocblas handle"); return -3; }
+    DB_TRY(hipMemcpyAsync(In, xinit, n * 8, hipMemcpyDeviceToDevice, stream));
+    DB_TRY(hipMemcpyAsync(In + n, vinit, n * 8, hipMemcpyDeviceToDevice, stream));
+    DB_BLAS(rocblas_set_stream(hb, stream));
+    DB_BLAS(rocblas_set_pointer_mode(hb, rocblas_pointer_mode_host));
+    DiParams p;
+    p.d = d; p.signed_bound = signed_bound; p.adaptive = adaptive;
+    p.C = C; p.n_sk = n_sk; p.chain0 = chain0; p.cap = cap; p.seed = seed; p.tmax = tmax;
+    p.In = In; p.Out = Out; p.P = P_dev; p.st = st;
+    p.X = X; p.V = V; p.t = t; p.H = H; p.AR = AR; p.EV = EV; p.EB = EB; p.RJ = RJ; p.HH = HH;
+    p.status = status;
+    p.refresh = refresh; p.gaussian_velocity = gaussian_velocity; p.pad = 0;
+    const dim3 grid((unsigned)((C + 3) / 4)), block(256);
+    const double one = 1.0, zero = 0.0;
+    g_last_phases = 0; g_last_columns = 0; g_last_mode = 3;
+    for (int64_t k0 = 0; k0 < n_sk;) {
+        const int64_t k1 = (k0 == 0) ? ((n_sk < 2) ? n_sk : 2) : k0 + 1;
+        DB_BLAS(rocblas_dgemm(hb, rocblas_operation_none, rocblas_operation_none, d, (int)(2 * C), d, &one, P_dev, d, In, d, &zero, Out, d));
+        ++g_last_phases;
+        g_last_columns += 2 * C;
+        p.k_begin = k0; p.k_end = k1;
+        if (boomerang) {
+            if (d <= 4 * WAVE) hipLaunchKernelGGL((dr_boom_kernel<4>), grid, block, 0, stream, p);
+            else if (d <= 8 * WAVE) hipLaunchKernelGGL((dr_boom_kernel<8>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((dr_boom_kernel<16>), grid, block, 0, stream, p);
+        } else {
+            if (d <= 4 * WAVE) hipLaunchKernelGGL((dr_bps_kernel<4>), grid, block, 0, stream, p);
+            else if (d <= 8 * WAVE) hipLaunchKernelGGL((dr_bps_kernel<8>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((dr_bps_kernel<16>), grid, block, 0, stream, p);
         }
         DB_TRY(hipGetLastError());
         k0 = k1;

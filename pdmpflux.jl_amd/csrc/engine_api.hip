@@ -71,6 +71,11 @@ extern "C" int pdmp_dense_incremental_run(int device, int d, int signed_bound, i
                                       const double *xinit, const double *vinit, double *X, double *V, double *t,
                                       double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
                                       int32_t *status, void *stream, void **ws, size_t *ws_cap, char *err, int errlen);
+extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_bound, int adaptive, int gaussian_velocity, double tmax, double refresh,
+                                  int64_t cap, const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
+                                  const double *xinit, const double *vinit, double *X, double *V, double *t,
+                                  double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
+                                  int32_t *status, void *stream, void **ws, size_t *ws_cap, char *err, int errlen);   // dense_batched.hip: BPS, one GEMM per event
 
 extern "C" int pdmp_user_compile(int device, int sampler, int fd, int kind, const char *source, void **fn_out, char *err, int errlen);
 extern "C" int pdmp_user_launch(void *fn, const GroupParams *gp, void *stream);
@@ -645,8 +650,11 @@ int normalize_config(pdmp_config_t &c, bool from_source = false) {
         return fail(PDMP_ERR_UNSUPPORTED, "potentials given as source run on the group kernel: grid_size = 10 (or 0, Brent)");
     if (c.target_id == PDMP_T_GAUSS_DENSE) {
         if (c.n_target_params != (int64_t)c.dim * c.dim || !c.target_params) return fail(PDMP_ERR_ARGUMENT, "GAUSS_DENSE needs target_params = P[dim*dim] (column-major)");
-        if (c.sampler == PDMP_BOOMERANG || c.deriv_mode != PDMP_DERIV_FORWARD || (c.grid_size != 10 && c.grid_size != 0))
-            return fail(PDMP_ERR_UNSUPPORTED, "dense-precision target: Zig-Zag / BPS with grid_size = 10 and forward-mode slopes only");
+        if (c.deriv_mode != PDMP_DERIV_FORWARD || (c.grid_size != 10 && c.grid_size != 0))
+            return fail(PDMP_ERR_UNSUPPORTED, "dense-precision target: grid_size = 10 (or 0) and forward-mode slopes only");
+        // Boomerang: only the batched form exists (dense_batched.hip: dr_boom_kernel, one GEMM per event over all chains of a launch)
+        if (c.sampler == PDMP_BOOMERANG && (c.grid_size != 10 || c.dim > 16 * WAVE))
+            return fail(PDMP_ERR_UNSUPPORTED, "dense-precision target: Boomerang with grid_size = 10 and dim <= 1024 only");
         if (group_waves_per_block((c.dim + WAVE - 1) / WAVE, 0, 6) < 1) return fail(PDMP_ERR_UNSUPPORTED, "dense-precision target: dim too large for the LDS tiles");
     }
     if (c.deriv_mode != PDMP_DERIV_FORWARD && c.deriv_mode != PDMP_DERIV_FINITE_DIFF) return fail(PDMP_ERR_ARGUMENT, "Unsupported AD_backend id %d", c.deriv_mode);
@@ -1049,6 +1057,25 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
                                         chain_id_offset, seed, xinit, vinit, X, V, t, p.H, p.AR, p.EB, p.EV, p.RJ, p.HH,
                                         h->d_status, stream, msg, (int)sizeof msg);
         if (rc != 0) { h->pool.push_back(ev); return fail(rc == -4 ? PDMP_ERR_ITERCAP : PDMP_ERR_RUNTIME, "dense batched path: %s", msg); }
+        h->last_form = PDMP_FORM_DENSE;
+        return end_timed(h, s, ev);
+    }
+    // BPS / Boomerang on a dense precision, many chains: the rate along the flow is a closed form in a few dot products with P x and P v
+    // (BPS: <P x, v> + t <P v, v>; Boomerang: a quadratic form in cos t, sin t), so only an accepted event needs products with P --
+    // P [x | v'] of ALL chains as one fp64 GEMM per skeleton column (dense_batched.hip: dr_bps_kernel, dr_boom_kernel)
+    const bool bps_batched = c.target_id == PDMP_T_GAUSS_DENSE && (c.sampler == PDMP_BPS || c.sampler == PDMP_BOOMERANG) && c.grid_size == GNG && c.dim <= 16 * WAVE &&
+                             c.deriv_mode == PDMP_DERIV_FORWARD && !taped && !until && 2 * C < 0x7fffffffLL &&
+                             (c.sampler == PDMP_BOOMERANG || (dense_mode ? (strcmp(dense_mode, "gemm") == 0 || strcmp(dense_mode, "incr") == 0) : C >= 64));
+    if (c.target_id == PDMP_T_GAUSS_DENSE && c.sampler == PDMP_BOOMERANG && !bps_batched) {
+        h->pool.push_back(ev);
+        return fail(PDMP_ERR_UNSUPPORTED, "Boomerang on a dense precision runs in the batched form only (no tape replay, no time horizon)");
+    }
+    if (bps_batched) {
+        char msg[256] = "";
+        const int rc = pdmp_dense_bps_run(h->device, c.sampler == PDMP_BOOMERANG ? 1 : 0, c.dim, c.signed_bound, c.adaptive, c.gaussian_velocity, c.tmax, c.refresh_rate, c.max_iter_per_event,
+                                          h->d_tparams, C, n_sk, chain_id_offset, seed, xinit, vinit, X, V, t, p.H, p.AR, p.EB, p.EV, p.RJ, p.HH,
+                                          h->d_status, stream, &h->dense_ws, &h->dense_ws_cap, msg, (int)sizeof msg);
+        if (rc != 0) { h->pool.push_back(ev); return fail(PDMP_ERR_RUNTIME, "dense BPS path: %s", msg); }
         h->last_form = PDMP_FORM_DENSE;
         return end_timed(h, s, ev);
     }

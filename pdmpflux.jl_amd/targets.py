@@ -53,7 +53,9 @@ class Banana:
 
 @dataclass(frozen=True)
 class GaussianPrecision:
-    """U(x) = x' P x / 2 with a dense symmetric precision matrix P (BASELINE config 4: grad-U = P x)."""
+    """U(x) = x' P x / 2 with a dense symmetric precision matrix P (BASELINE config 4: grad-U = P x).  Zig-Zag, BPS and Boomerang
+    (forward-mode slopes, grid_size = 10); ensembles of >= 64 chains run the batched forms of csrc/dense_batched.hip (products with P
+    as fp64 GEMMs over all chains: Zig-Zag incrementally, BPS / Boomerang one GEMM per event)."""
     P: tuple
     dim: int
     target_id: int = T_GAUSS_DENSE

@@ -541,3 +541,54 @@ def test_lean_throughput_kernels(engine, oracle, monkeypatch, kind, dim, target,
     monkeypatch.setenv("PDMP_NO_LEAN", "1")
     full = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=19, chain_id_offset=4, diagnostics=False)
     assert_bitwise(full, ref, keys=("X", "V", "t"))
+
+
+@pytest.mark.parametrize("kw", [{}, {"refresh_rate": 1.5}, {"signed_bound": False}, {"Gaussian_velocity": True, "refresh_rate": 0.7},
+                                {"adaptive": False, "tmax": 0.3}])
+@pytest.mark.parametrize("dim,chains,n_sk", [(40, 64, 60), (257, 70, 30), (600, 64, 16)])
+def test_dense_precision_bps_one_gemm_per_event(engine, oracle, dim, chains, n_sk, kw):
+    """BPS on a dense precision with >= 64 chains (round 3, dense_batched.hip: dr_bps_kernel): the rate along the flow is
+    <P x, v> + t <P v, v>, so a thinning iteration is two dot products and scalar arithmetic, and only an accepted event needs
+    products with P -- P [x | v'] of all chains as ONE fp64 GEMM per skeleton column.  Against the reference-order restatement (a
+    mat-vec per grid time) to a tolerance: the sums are ordered differently (rocBLAS' accumulation, A + B t instead of a fresh
+    dot product per grid time); counters identical.  PDMP_DENSE_MODE=matvec keeps the bit-exact per-chain kernel."""
+    from pdmpflux.jl_amd import _lib
+    s, cfg = make_pair(engine, oracle, "BPS", dim, "dense", arith=oracle.ARITH_REFERENCE, **kw)
+    x, v = make_init("BPS", dim, chains)
+    got = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=21, diagnostics=True)
+    assert _lib.lib().pdmp_dense_batched_last_mode() == 3 and s.last_launch_form() == 5
+    ref = oracle.sample_skeleton(cfg, n_sk, x, v, 21, diagnostics=True)
+    for k in ("rejected", "hitting_horizon", "errored_bound"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert np.allclose(got["t"], ref["t"], rtol=1e-9, atol=0)
+    assert np.allclose(got["X"], ref["X"], rtol=1e-8, atol=1e-10)
+    assert np.allclose(got["V"], ref["V"], rtol=1e-8, atol=1e-10)
+    assert np.allclose(got["horizon"], ref["horizon"], rtol=1e-12) and np.allclose(got["ar"], ref["ar"], rtol=1e-7, atol=1e-12)
+
+
+def test_dense_precision_bps_small_ensembles_keep_the_bit_exact_kernel(engine, oracle):
+    s, cfg = make_pair(engine, oracle, "BPS", 40, "dense")
+    x, v = make_init("BPS", 40, 6)
+    got = engine.sample_skeleton_ensemble(s, 20, x, v, seed=21)
+    assert s.last_launch_form() != 5
+    assert_bitwise(got, oracle.sample_skeleton(cfg, 20, x, v, 21))
+
+
+@pytest.mark.parametrize("kw", [{}, {"refresh_rate": 1.5}, {"signed_bound": False}, {"adaptive": False, "tmax": 0.3}])
+@pytest.mark.parametrize("dim,chains,n_sk", [(40, 64, 60), (257, 70, 30), (600, 64, 16)])
+def test_dense_precision_boomerang_one_gemm_per_event(engine, oracle, dim, chains, n_sk, kw):
+    """Boomerang on a dense precision with >= 64 chains (dense_batched.hip: dr_boom_kernel): grad-U_effective = P x - x is linear and
+    the flow a rotation, so the rate along the flow is a quadratic form in cos t, sin t with four dot products as coefficients;
+    one fp64 GEMM P [x | v'] over all chains per skeleton column.  Same tolerance as the BPS form."""
+    from pdmpflux.jl_amd import _lib
+    s, cfg = make_pair(engine, oracle, "BoomerangAD", dim, "dense", arith=oracle.ARITH_REFERENCE, **kw)
+    x, v = make_init("BoomerangAD", dim, chains)
+    got = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=21, diagnostics=True)
+    assert _lib.lib().pdmp_dense_batched_last_mode() == 3 and s.last_launch_form() == 5
+    ref = oracle.sample_skeleton(cfg, n_sk, x, v, 21, diagnostics=True)
+    for k in ("rejected", "hitting_horizon", "errored_bound"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert np.allclose(got["t"], ref["t"], rtol=1e-9, atol=0)
+    assert np.allclose(got["X"], ref["X"], rtol=1e-8, atol=1e-10)
+    assert np.allclose(got["V"], ref["V"], rtol=1e-8, atol=1e-10)
+    assert np.allclose(got["horizon"], ref["horizon"], rtol=1e-12) and np.allclose(got["ar"], ref["ar"], rtol=1e-7, atol=1e-12)
