@@ -314,7 +314,8 @@ function sample_skeleton_device!(s::HIPSampler, X, V, t, xinit, vinit; seed::Int
 end
 check_status(s::HIPSampler) = check(ccall((:pdmp_check_status, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}), s.handle, C_NULL))
 # which kernel form served the last launch (diagnostic; waits for the launch): 1 wave per chain, 2 group (LDS), 3 group (registers),
-# 4 one lane per chain (large Zig-Zag ensembles, d = 27..52, unit speeds), 5 dense-precision path, 6 potential given as source
+# 4 one lane per chain (large Zig-Zag ensembles, d = 27..52, unit speeds), 5 dense-precision path, 6 potential given as source,
+# 7 a pair of lanes per chain (Zig-Zag, d = 53..104; mid-sized launches at d = 25..52)
 last_launch_form(s::HIPSampler) = Int(ccall((:pdmp_last_launch_form, LIB), Cint, (Ptr{Cvoid},), s.handle))
 
 # One Julia process, n GPUs (pdmp_multi_*): the C chains shard into contiguous ranges over the devices; with gather = true one RCCL

@@ -103,7 +103,8 @@ class AbstractPDMP:
 
     def last_launch_form(self) -> int:
         """Kernel form of the last launch (pdmp_last_launch_form): 1 wave per chain, 2 group (LDS), 3 group (registers), 4 one lane
-        per chain, 5 dense-precision path, 6 potential given as source."""
+        per chain, 5 dense-precision path, 6 potential given as source, 7 a pair of lanes per chain (lane kernel, d = 53..104 and
+        mid-sized launches at d <= 52)."""
         return int(_lib.lib().pdmp_last_launch_form(self.handle()))
 
     def suggest_group_lanes(self, C: int) -> int:
