@@ -170,3 +170,58 @@ def test_config4_dense_precision_1e4_chains(engine, oracle, monkeypatch):
     again = ensemble.sample_skeleton_device(s, n_sk, x[:64].contiguous(), v[:64].contiguous(), seed=99)
     assert bool((again["V"] == V[:64]).all())
     assert float(((again["t"] - t[:64]).abs() / t[:64].clamp_min(1e-300))[:, 1:].max()) < 1e-12
+
+
+@pytest.mark.parametrize("target", ["iso", "banana"])
+def test_metric_shard_25000_chains_runs_the_pair_form(engine, oracle, target):
+    """The 4-GPU shard of the headline ensemble (25 000 chains x 1000): default selection = the lane kernel's pair form (two lanes per
+    chain).  Size-independent properties on every chain, bit-exact spot checks against the checker with global chain ids, and the
+    shard equals the same chains of ... itself under another form (the group kernel) on a strided sample."""
+    import torch
+    from pdmpflux.jl_amd import ensemble
+    C, d, n_sk, lo = 25_000, 50, 1000, 50_000
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", d, target)
+    x, v = _device_inputs(torch, "zz", C, d, banana=(target == "banana"))
+    out = ensemble.sample_skeleton_device(s, n_sk, x, v, seed=2024, chain_id_offset=lo)
+    assert s.last_launch_form() == 7
+    t, X, V = out["t"], out["X"], out["V"]
+    assert bool((t[:, 1:] > t[:, :-1]).all()) and bool((t[:, 0] == 0).all()) and bool(torch.isfinite(X).all())
+    assert bool((V.abs() == 1.0).all())
+    assert bool(((V[:, 1:] != V[:, :-1]).sum(dim=2) == 1).all())               # exactly one coordinate flips per event
+    dt = (t[:, 1:] - t[:, :-1]).unsqueeze(2)
+    assert float((X[:, 1:] - (X[:, :-1] + V[:, :-1] * dt)).abs().max()) < 1e-12
+    xh, vh, th = x.cpu().numpy(), v.cpu().numpy(), t.cpu().numpy()
+    for c in np.arange(0, C, 2503):
+        ref = oracle.sample_skeleton(cfg, n_sk, xh[c:c + 1], vh[c:c + 1], 2024, chain_id_offset=lo + int(c), diagnostics=False)
+        assert np.array_equal(th[c], ref["t"][0]), c
+        assert np.array_equal(X[c].cpu().numpy(), ref["X"][0]), c
+        assert np.array_equal(V[c].cpu().numpy(), ref["V"][0]), c
+
+
+def test_zigzag_d100_1e5_chains_runs_the_pair_form(engine, oracle):
+    """Zig-Zag d = 100 Gaussian, 10^5 chains x 1000 (160.8 GB of events): the lane kernel with a pair of lanes per chain (G = 8 order)."""
+    import torch
+    from pdmpflux.jl_amd import ensemble
+    C, d, n_sk = 100_000, 100, 1000
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", d, "iso")
+    x, v = _device_inputs(torch, "zz", C, d)
+    out = ensemble.sample_skeleton_device(s, n_sk, x, v, seed=2024)
+    assert s.last_launch_form() == 7
+    t, X, V = out["t"], out["X"], out["V"]
+    assert bool((t[:, 1:] > t[:, :-1]).all()) and bool((t[:, 0] == 0).all())
+    ok_v, ok_flip, resid = True, True, 0.0
+    for c0 in range(0, C, 10_000):                                              # in slabs: the temporaries of a full-array expression would not fit
+        Xs, Vs, ts = X[c0:c0 + 10_000], V[c0:c0 + 10_000], t[c0:c0 + 10_000]
+        ok_v = ok_v and bool((Vs.abs() == 1.0).all())
+        ok_flip = ok_flip and bool(((Vs[:, 1:] != Vs[:, :-1]).sum(dim=2) == 1).all())
+        dts = (ts[:, 1:] - ts[:, :-1]).unsqueeze(2)
+        resid = max(resid, float((Xs[:, 1:] - (Xs[:, :-1] + Vs[:, :-1] * dts)).abs().max()))
+        del dts
+    assert ok_v and ok_flip and resid < 1e-12
+    rate = (n_sk - 1) / t[:, -1]
+    assert abs(float(rate.mean()) / (d / np.sqrt(2 * np.pi)) - 1) < 0.02        # stationary event rate d / sqrt(2 pi)
+    xh, vh, th = x.cpu().numpy(), v.cpu().numpy(), t.cpu().numpy()
+    for c in np.arange(0, C, 14281):
+        ref = oracle.sample_skeleton(cfg, n_sk, xh[c:c + 1], vh[c:c + 1], 2024, chain_id_offset=int(c), diagnostics=False)
+        assert np.array_equal(th[c], ref["t"][0]), c
+        assert np.array_equal(X[c].cpu().numpy(), ref["X"][0]), c
