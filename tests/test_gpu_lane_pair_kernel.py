@@ -263,3 +263,40 @@ def test_quad_pair_default_selection(engine, oracle, monkeypatch):
                 r1 = oracle.sample_skeleton(cfg, 48, x[c:c + 1], v[c:c + 1], 5, chain_id_offset=int(c), diagnostics=False)
                 for k in ("X", "V", "t"):
                     assert np.array_equal(got[k][c], r1[k][0]), (k, c)
+
+
+def _random_lane_cases(n, seed=20261004):
+    rs = np.random.default_rng(seed)
+    cases = []
+    for i in range(n):
+        dim = int(rs.integers(27, 105))
+        mode = "1" if dim > 52 else str(rs.choice(["1", "2"]))
+        cases.append(dict(dim=dim, mode=mode, target=str(rs.choice(["iso", "banana"])), C=int(rs.integers(1, 150)),
+                          n_sk=int(rs.integers(2, 90)), segments=int(rs.choice([0, 1, 2, 3, 7])), budget=int(rs.choice([0, 1, 2, 5, 9])),
+                          diag=bool(rs.integers(0, 2)), tmax=float(rs.choice([0.0, 0.05, 0.5, 2.0, 20.0])), adaptive=bool(rs.integers(0, 4)),
+                          lo=int(rs.integers(0, 1000)), seed=int(rs.integers(0, 10**6))))
+    return cases
+
+
+@pytest.mark.parametrize("case", _random_lane_cases(60), ids=lambda c: f"d{c['dim']}-m{c['mode']}-{c['target']}-C{c['C']}-n{c['n_sk']}-s{c['segments']}")
+def test_random_lane_launches_match_checker(engine, oracle, monkeypatch, case):
+    """Sixty random launches of the lane kernel's three forms (one lane per chain, pair at d <= 52, pair at d >= 53): dimension,
+    target, number of chains (ragged batches, fewer chains than a batch), skeleton length, hand-off segments, bound instalments,
+    horizon settings, diagnostic arrays or not, chain id offset -- bit for bit against the checker."""
+    monkeypatch.setenv("PDMP_LANE", case["mode"])
+    if case["segments"]:
+        monkeypatch.setenv("PDMP_FORCE_SEGMENTS", str(case["segments"]))
+    if case["budget"]:
+        monkeypatch.setenv("PDMP_CELL_BUDGET", str(case["budget"]))
+    kw = {"tmax": case["tmax"]}
+    if not case["adaptive"] and case["tmax"] > 0:
+        kw["adaptive"] = False
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", case["dim"], case["target"], **kw)
+    x, v = make_init("ZigZagAD", case["dim"], case["C"], seed=case["seed"] % 997, target=case["target"])
+    got = engine.sample_skeleton_ensemble(s, case["n_sk"], x, v, seed=case["seed"], diagnostics=case["diag"], chain_id_offset=case["lo"])
+    assert s.last_launch_form() == (4 if (case["dim"] <= 52 and case["mode"] == "1") else 7)
+    ref = oracle.sample_skeleton(cfg, case["n_sk"], x, v, case["seed"], diagnostics=case["diag"], chain_id_offset=case["lo"])
+    if case["diag"]:
+        assert_bitwise(got, ref)
+    else:
+        assert_bitwise(got, ref, keys=("X", "V", "t"))
