@@ -1104,7 +1104,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
             // d = 53 .. 104 (the group kernel's G = 8): a PAIR of lanes per chain, 32 chains per wave, bit-identical to the G = 8 group kernel
             const bool lane2 = gp.G == 8;
             // (the pair kernel, d = 100, n_sk = 1000: 10.6 ms up to 32 768 chains -- one wave per SIMD -- against 9.5 ms of the group kernel at 25 000, 37.9 ms at 10^5)
-            const int64_t lane_from = lane_min ? atoll(lane_min) : (lane2 ? 28000 : (c.dim >= 45 ? 37000 : 48000));
+            const int64_t lane_from = lane_min ? atoll(lane_min) : (lane2 ? 28000 : (c.dim >= 45 ? 37000 : 40000));   // (d = 32, 44 000 chains: one lane 6.42 ms, pair 7.34, group kernel 7.43; 30 000: pair 4.99, group 5.92)
             // d = 25 .. 52 again, launches between ~a fifth and ~two fifths of the machine (the 4-GPU shard of the headline ensemble): a pair of
             // lanes per chain with two coordinates of a slot each -- GROUP(4) still -- so that 25 000 chains are 782 waves instead of 391
             const char *pair_min = getenv("PDMP_LANE_PAIR_MIN_CHAINS");
