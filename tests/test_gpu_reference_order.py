@@ -24,13 +24,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # (id, ctor, dim, target, kwargs, chains for the moments check); ids ending in _lane run the one-lane-per-chain kernel (PDMP_LANE=1) --
 # the kernel that produces the headline numbers at full size -- so that it is held to the reference order DIRECTLY, not through
-# its bit-identity with the group kernel
+# its bit-identity with the group kernel; ids ending in _pair likewise the lane kernel's two pair forms (round 3)
 WORKLOADS = [
     ("config1_zigzagad_d10_iso", "ZigZagAD", 10, "iso", {}, 10_000),
     ("config2_zigzagad_d50_iso", "ZigZagAD", 50, "iso", {}, 10_000),
     ("config2_zigzagad_d50_iso_lane", "ZigZagAD", 50, "iso", {}, 10_000),
     ("metric2_zigzagad_d50_banana", "ZigZagAD", 50, "banana", {}, 10_000),
     ("metric2_zigzagad_d50_banana_lane", "ZigZagAD", 50, "banana", {}, 10_000),
+    ("config2_zigzagad_d50_iso_pair", "ZigZagAD", 50, "iso", {}, 10_000),          # the 4-GPU shard's form: two lanes per chain (PDMP_LANE=2)
+    ("metric2_zigzagad_d50_banana_pair", "ZigZagAD", 50, "banana", {}, 10_000),
+    ("zigzagad_d100_iso_pair", "ZigZagAD", 100, "iso", {}, 4_000),                 # d = 53 .. 104: a pair of lanes per chain, GROUP(8) order
     ("config3_bps_d50_banana", "BPS", 50, "banana", {}, 4_000),
     ("config5_boomerang_d100_fd", "Boomerang", 100, "iso", {"refresh_rate": 0.5}, 2_000),
     ("config5_boomerangad_d100", "BoomerangAD", 100, "iso", {"refresh_rate": 0.5}, 2_000),
@@ -69,14 +72,15 @@ def _record(name, stats):
 
 @pytest.mark.parametrize("name,kind,dim,target,kw,_cm", WORKLOADS, ids=[w[0] for w in WORKLOADS])
 def test_reference_order_within_tolerance(engine, oracle, monkeypatch, name, kind, dim, target, kw, _cm):
-    lane = name.endswith("_lane")
-    if lane:
-        monkeypatch.setenv("PDMP_LANE", "1")
+    lane, pair = name.endswith("_lane"), name.endswith("_pair")
+    if lane or pair:
+        monkeypatch.setenv("PDMP_LANE", "1" if (lane or dim > 52) else "2")
     s, cfg = make_pair(engine, oracle, kind, dim, target, arith=oracle.ARITH_REFERENCE, **kw)
-    C, n_sk = (200, 1000) if lane else (64, 1000)                 # lane kernel: four batches of 64 chains, the last one ragged
+    C, n_sk = (200, 1000) if lane else ((100, 1000) if pair else (64, 1000))   # lane kernel: four batches of 64 (32) chains, the last one ragged
     x, v = make_init(kind, dim, C, seed=12, target=target)
     got = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=77, diagnostics=True)
-    assert (s.last_launch_form() == 4) == lane, "the workload did not run on the kernel form it names"
+    assert s.last_launch_form() == (4 if lane else (7 if pair else s.last_launch_form())) and (s.last_launch_form() in (4, 7)) == (lane or pair), \
+        "the workload did not run on the kernel form it names"
     ref = oracle.sample_skeleton(cfg, n_sk, x, v, 77, diagnostics=True)
     zigzag = kind.startswith("ZigZag")
     forks, kinds = [], []
@@ -114,15 +118,15 @@ def test_engine_and_reference_order_moments_agree(engine, oracle, monkeypatch, n
     two are independent) agree within Monte Carlo error: |mean difference| < 5 standard errors per coordinate (Bonferroni-safe)."""
     import torch
     from pdmpflux.jl_amd import ensemble
-    if name.endswith("_lane"):
-        monkeypatch.setenv("PDMP_LANE", "1")
+    if name.endswith("_lane") or name.endswith("_pair"):
+        monkeypatch.setenv("PDMP_LANE", "1" if (name.endswith("_lane") or dim > 52) else "2")
     s, cfg = make_pair(engine, oracle, kind, dim, target, arith=oracle.ARITH_REFERENCE, **kw)
     n_sk, N = 152, 60
     x, v = make_init(kind, dim, C, seed=5, target=target)
     dev = torch.device("cuda:0")
     sk = ensemble.sample_skeleton_device(s, n_sk, torch.from_numpy(x).to(dev), torch.from_numpy(v).to(dev), seed=1001)
     torch.cuda.synchronize()
-    assert (s.last_launch_form() == 4) == name.endswith("_lane")
+    assert (s.last_launch_form() == 4) == name.endswith("_lane") and (s.last_launch_form() == 7) == name.endswith("_pair")
     a = ensemble.sample_from_skeleton_device(s, N, sk["X"], sk["V"], sk["t"]).cpu().numpy()
     r = oracle.sample_skeleton(cfg, n_sk, x, v, 2002, diagnostics=False)
     b = oracle.sample_from_skeleton(cfg, N, r["X"], r["V"], r["t"])
