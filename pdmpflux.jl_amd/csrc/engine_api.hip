@@ -1008,7 +1008,10 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
         gp.K = (c.dim + gp.G - 1) / gp.G;
         gp.tpar = ((c.target_id == PDMP_T_GAUSS_DIAG) ? 2 * c.dim : 0) + ((c.sampler == PDMP_STICKY) ? c.dim : 0);   // mu, prec | kappa staged in LDS
         gp.tiles = (c.target_id == PDMP_T_GAUSS_DENSE || c.sampler == PDMP_FECMC) ? 6 : 2;   // ForwardECMC: n, v_orth, e1, e2
-        gp.cell_budget = 3;
+        // cells of a lazily built bound per pass of the state machine (same bits whatever the number).  A full machine (two waves per SIMD
+        // hiding each other's latency) is fastest with instalments of three; a launch that leaves every wave alone on its SIMD pays each
+        // extra pass of the state machine in full: all nine (12 500 chains: 4.29 -> 3.91 ms, scripts/budget_sweep.sh)
+        gp.cell_budget = ((C + WAVE / h->group_lanes - 1) / (WAVE / h->group_lanes) <= 1024) ? GNG - 1 : 3;
         if (const char *e = getenv("PDMP_CELL_BUDGET")) { const int b = atoi(e); if (b >= 1 && b <= GNG - 1) gp.cell_budget = b; }   // tuning / tests
         const int64_t nb = (C + WAVE / gp.G - 1) / (WAVE / gp.G);
         const size_t need_sched = (size_t)nb + 1, need_state = (size_t)((C + WAVE - 1) / WAVE * WAVE) * ((size_t)(2 * c.dim + 4) + (c.sampler == PDMP_STICKY ? (size_t)gp.G : 0));   // (whole batches of 64: lane_kernel.hpp; StickyZigZag: + the active masks of a chain's lanes)
@@ -1100,7 +1103,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
             // measured (one MI355X, n_sk = 1000): up to 65 536 chains the lane kernel takes 9.6 ms (d = 50 Gaussian) / 11.0 ms (banana) / 7.8 ms
             // (d = 32) whatever the count -- one wave per SIMD walks its 64 chains' events one after the other -- while the group kernel grows
             // with the count: it wins below ~41 000 chains at d = 50 (9.4 ms at 40 000, 12.8 ms at 45 000) and below ~48 000 at d = 32
-            // (round 3: between 15 500 chains and these thresholds the PAIR form below serves the launch; with it in the middle the one-lane form starts at 37 000 for d >= 45)
+            // (round 3: between 16 385 chains and these thresholds the PAIR form below serves the launch; with it in the middle the one-lane form starts at 37 000 for d >= 45)
             // d = 53 .. 104 (the group kernel's G = 8): a PAIR of lanes per chain, 32 chains per wave, bit-identical to the G = 8 group kernel
             const bool lane2 = gp.G == 8;
             // (the pair kernel, d = 100, n_sk = 1000: 10.6 ms up to 32 768 chains -- one wave per SIMD -- against 9.5 ms of the group kernel at 25 000, 37.9 ms at 10^5)
@@ -1110,7 +1113,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
             const char *pair_min = getenv("PDMP_LANE_PAIR_MIN_CHAINS");
             // measured (d = 50 Gaussian, n_sk = 1000; group kernel / one lane / pair): 12 500 chains 4.31 / 8.36 / 5.36 ms, 18 000 6.58 / 8.41 / 5.39,
             // 25 000 8.42 / 8.43 / 5.45, 32 000 10.27 / 8.47 / 7.02, 40 000 10.99 / 8.48 / 9.60, 50 000 11.53 / 8.57 / 11.50 (profiles/r3/r3q1_*)
-            const int64_t pair_from = pair_min ? atoll(pair_min) : 15500;
+            const int64_t pair_from = pair_min ? atoll(pair_min) : 16385;   // (up to 16 384 chains = 1 024 waves of the group kernel, one per SIMD: 3.9 - 4.0 ms flat with the whole bound per pass; 17 000 chains: 6.1 ms against the pair form's 5.4)
             const bool lane_ok = c.sampler == PDMP_ZIGZAG && !fd && (c.target_id == PDMP_T_GAUSS_ISO || c.target_id == PDMP_T_BANANA) &&
                                  ((gp.G == 4 && c.dim >= 25 && c.dim <= 52) || (lane2 && c.dim >= 53 && c.dim <= 104 && !tgroup)) &&
                                  (int64_t)WAVE * n_sk * c.dim * 8 < (lane2 ? 2 : 1) * 0x7fffffffLL;   // (a batch's window of X: 31-bit byte offsets; 64 chains, or 32 of a pair form -- the quad pair is held to the window of 64 so that a resumed chunk may be of either size)
