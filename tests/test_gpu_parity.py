@@ -593,3 +593,21 @@ def test_dense_precision_boomerang_one_gemm_per_event(engine, oracle, dim, chain
     assert np.allclose(got["X"], ref["X"], rtol=1e-8, atol=1e-10)
     assert np.allclose(got["V"], ref["V"], rtol=1e-8, atol=1e-10)
     assert np.allclose(got["horizon"], ref["horizon"], rtol=1e-12) and np.allclose(got["ar"], ref["ar"], rtol=1e-7, atol=1e-12)
+
+
+@pytest.mark.parametrize("target", ["iso", "banana"])
+def test_group_kernel_full_machine_zigzag(engine, oracle, monkeypatch, target):
+    """The group kernel on a launch that fills the machine (PDMP_LANE=0, 40 000 chains: 10 000 batches of 16 for 2 048 resident waves):
+    dynamic (batch, segment) schedule, hand-off between segments, the bound in instalments of three cells -- the defaults of a full
+    machine, which no small test launch takes any more.  A strided sample of chains bit for bit against the checker."""
+    monkeypatch.setenv("PDMP_LANE", "0")
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", 50, target)
+    C, n_sk = 40_000, 80
+    x, v = make_init("ZigZagAD", 50, C, target=target)
+    got = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=31, diagnostics=False)
+    assert s.last_launch_form() == 3
+    for c in np.arange(0, C, 1733):
+        r1 = oracle.sample_skeleton(cfg, n_sk, x[c:c + 1], v[c:c + 1], 31, chain_id_offset=int(c), diagnostics=False)
+        for k in ("X", "V", "t"):
+            assert np.array_equal(got[k][c], r1[k][0]), (k, c)
+    assert (np.diff(got["t"], axis=1) > 0).all() and (np.abs(got["V"]) == 1.0).all()
