@@ -317,3 +317,30 @@ def test_multi_device_entry_with_one_device(engine, oracle):
     assert np.array_equal(single["X"].cpu().numpy(), ref["X"]) and np.array_equal(single["t"].cpu().numpy(), ref["t"])
     bad = C.c_void_p()
     assert L.pdmp_multi_create(C.byref(conf), 99, None, C.byref(bad)) == _lib.ERR_ARGUMENT
+
+
+@pytest.mark.parametrize("kind,T", [("ZigZagAD", 1.5), ("BPS", 4.0), ("BoomerangAD", 6.0)])
+def test_time_horizon_on_the_batched_dense_forms(engine, oracle, kind, T):
+    """`sample_skeleton(sampler, T::Float64, ...)` on the dense-precision target with >= 64 chains: the batched forms
+    (dense_batched.hip: incremental Zig-Zag, one GEMM per event for BPS / Boomerang) have no in-kernel stop, so the call takes the
+    capacity-doubling host loop over the fixed-count path + `pdmp_close_at_time_device` (the sampler's own flow to t = T: the
+    Boomerang's rotation included).  Against the checker's reference-order restatement: history lengths identical, times 1e-9."""
+    import torch
+    from pdmpflux.jl_amd import ensemble, _lib
+    dim, C = 40, 64
+    s, cfg = make_pair(engine, oracle, kind, dim, "dense", arith=oracle.ARITH_REFERENCE)
+    x, v = make_init(kind, dim, C, seed=3)
+    dev = torch.device("cuda:0")
+    got = ensemble.sample_skeleton_until_device(s, T, torch.from_numpy(x).to(dev), torch.from_numpy(v).to(dev), seed=11,
+                                                init_capacity=32, compact=True)
+    assert s.last_launch_form() == 5 and _lib.lib().pdmp_dense_batched_last_mode() in (2, 3)
+    ref = oracle.sample_skeleton_until(cfg, T, x, v, 11, init_capacity=64)
+    cnt, off = got["count"].cpu().numpy(), got["offsets"].cpu().numpy()
+    assert np.array_equal(cnt, ref["count"])
+    tt, X, V = got["t"].cpu().numpy(), got["X"].cpu().numpy(), got["V"].cpu().numpy()
+    for c in range(C):
+        k = int(cnt[c])
+        assert np.allclose(tt[off[c]:off[c + 1]], ref["t"][c, :k], rtol=1e-9, atol=0)
+        assert np.allclose(X[off[c]:off[c + 1]], ref["X"][c, :k], rtol=1e-8, atol=1e-10)
+        assert np.allclose(V[off[c]:off[c + 1]], ref["V"][c, :k], rtol=1e-8, atol=1e-10)
+        assert tt[off[c + 1] - 1] == T
