@@ -285,7 +285,7 @@ struct DiParams {
     uint64_t seed;
     double tmax;
     double *In;                  // d x 2C column-major: [x | v] of every chain (state between segments, GEMM input)
-    const double *Out;           // d x 2C: [P x | P v] (GEMM output)
+    double *Out;                 // d x 2C: [P x | P v] (GEMM output; the BPS / Boomerang kernels carry P x across events in its first half)
     const double *P;
     DiState *st;
     double *X, *V, *t, *H, *AR, *EV;
@@ -521,8 +521,8 @@ __global__ __launch_bounds__(256, SGN ? 2 : 1) void di_segment_kernel(const DiPa
 // accepted event changes v other than by a flow (reflection v - 2 <g, v> / <g, g> g with g = P x at the event, or a refresh by
 // normals), and P v' is a product with all of P: the chain records the event, writes x and v' back and YIELDS; the host multiplies
 // P [x | v] of ALL chains with one fp64 GEMM (rocBLAS, matrix cores) and launches the next event.  n_sk - 1 GEMMs of d x d x 2C per
-// launch instead of ~12 mat-vecs per event and chain (the group kernel's dense target: 7e4 events/s at d = 1000).  P x is taken
-// from the GEMM at every event too (no recurrence across events, no drift).  One wave per chain, layout and state as
+// launch instead of ~12 mat-vecs per event and chain (the group kernel's dense target: 7e4 events/s at d = 1000).  P x is carried
+// by the flows' recurrence (P x += tau P v) and re-based on an exact product every PDMP_DENSE_RESYNC events (default 64).  One wave per chain, layout and state as
 // di_segment_kernel.  Against the checker (reference order: a mat-vec per grid time) to a tolerance, as the Zig-Zag forms.
 template <int KC>
 __global__ __launch_bounds__(256, 2) void dr_bps_kernel(const DiParams p) {
@@ -689,12 +689,13 @@ __global__ __launch_bounds__(256, 2) void dr_bps_kernel(const DiParams p) {
         it = 0;
         ++k;
     }
-    {                                          // x, v back into the GEMM's input: P x and P v' come with the next launch
-        double *xo = p.In + (size_t)c * d, *vo = p.In + ((size_t)p.C + (size_t)c) * d;
+    {                                          // x, v back into the GEMM's input: P v' comes with the next launch; P x is carried along
+        double *xo = p.In + (size_t)c * d, *vo = p.In + ((size_t)p.C + (size_t)c) * d;   // (gx = P x at the event, by the flows' recurrences) and
+        double *go = p.Out + (size_t)c * d;                                              // re-based by a full product every PDMP_DENSE_RESYNC events
 #pragma unroll
         for (int s = 0; s < KC; ++s) {
             const int i = s * WAVE + lane;
-            if (i < d) { xo[i] = x[s * WAVE]; vo[i] = v[s]; }
+            if (i < d) { xo[i] = x[s * WAVE]; vo[i] = v[s]; go[i] = gx[s]; }
         }
     }
     if (lane == 0) {
@@ -891,12 +892,13 @@ __global__ __launch_bounds__(256, (KC == 16 ? 1 : 2)) void dr_boom_kernel(const 
         it = 0;
         ++k;
     }
-    {                                          // x, v back into the GEMM's input: P x and P v' come with the next launch
-        double *xo = p.In + (size_t)c * d, *vo = p.In + ((size_t)p.C + (size_t)c) * d;
+    {                                          // x, v back into the GEMM's input: P v' comes with the next launch; P x is carried along
+        double *xo = p.In + (size_t)c * d, *vo = p.In + ((size_t)p.C + (size_t)c) * d;   // (gx = P x at the event, by the flows' recurrences) and
+        double *go = p.Out + (size_t)c * d;                                              // re-based by a full product every PDMP_DENSE_RESYNC events
 #pragma unroll
         for (int s = 0; s < KC; ++s) {
             const int i = s * WAVE + lane;
-            if (i < d) { xo[i] = x[s * WAVE]; vo[i] = v[s]; }
+            if (i < d) { xo[i] = x[s * WAVE]; vo[i] = v[s]; go[i] = gx[s]; }
         }
     }
     if (lane == 0) {
@@ -1097,11 +1099,15 @@ extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_b
     const dim3 grid((unsigned)((C + 3) / 4)), block(256);
     const double one = 1.0, zero = 0.0;
     g_last_phases = 0; g_last_columns = 0; g_last_mode = 3;
-    for (int64_t k0 = 0; k0 < n_sk;) {
+    int64_t resync = 64;                       // events between two full products P [x | v]; in between only P v' is multiplied
+    if (const char *e = getenv("PDMP_DENSE_RESYNC")) { const long long r = atoll(e); if (r >= 1) resync = r; }
+    for (int64_t k0 = 0, ph = 0; k0 < n_sk; ++ph) {
         const int64_t k1 = (k0 == 0) ? ((n_sk < 2) ? n_sk : 2) : k0 + 1;
-        DB_BLAS(rocblas_dgemm(hb, rocblas_operation_none, rocblas_operation_none, d, (int)(2 * C), d, &one, P_dev, d, In, d, &zero, Out, d));
+        const bool full = (ph % resync) == 0;
+        if (full) DB_BLAS(rocblas_dgemm(hb, rocblas_operation_none, rocblas_operation_none, d, (int)(2 * C), d, &one, P_dev, d, In, d, &zero, Out, d));
+        else DB_BLAS(rocblas_dgemm(hb, rocblas_operation_none, rocblas_operation_none, d, (int)C, d, &one, P_dev, d, In + n, d, &zero, Out + n, d));
         ++g_last_phases;
-        g_last_columns += 2 * C;
+        g_last_columns += full ? 2 * C : C;
         p.k_begin = k0; p.k_end = k1;
         if (boomerang) {
             if (d <= 4 * WAVE) hipLaunchKernelGGL((dr_boom_kernel<4>), grid, block, 0, stream, p);

@@ -547,13 +547,16 @@ def test_lean_throughput_kernels(engine, oracle, monkeypatch, kind, dim, target,
 @pytest.mark.parametrize("kw", [{}, {"refresh_rate": 1.5}, {"signed_bound": False}, {"Gaussian_velocity": True, "refresh_rate": 0.7},
                                 {"adaptive": False, "tmax": 0.3}])
 @pytest.mark.parametrize("dim,chains,n_sk", [(40, 64, 60), (257, 70, 30), (600, 64, 16)])
-def test_dense_precision_bps_one_gemm_per_event(engine, oracle, dim, chains, n_sk, kw):
+@pytest.mark.parametrize("resync", [None, "1", "7"])
+def test_dense_precision_bps_one_gemm_per_event(engine, oracle, monkeypatch, dim, chains, n_sk, kw, resync):
     """BPS on a dense precision with >= 64 chains (round 3, dense_batched.hip: dr_bps_kernel): the rate along the flow is
     <P x, v> + t <P v, v>, so a thinning iteration is two dot products and scalar arithmetic, and only an accepted event needs
     products with P -- P [x | v'] of all chains as ONE fp64 GEMM per skeleton column.  Against the reference-order restatement (a
     mat-vec per grid time) to a tolerance: the sums are ordered differently (rocBLAS' accumulation, A + B t instead of a fresh
     dot product per grid time); counters identical.  PDMP_DENSE_MODE=matvec keeps the bit-exact per-chain kernel."""
     from pdmpflux.jl_amd import _lib
+    if resync:                                # events between two full products P [x | v] (default 64: in between only P v' is multiplied
+        monkeypatch.setenv("PDMP_DENSE_RESYNC", resync)   # and P x follows the flows' recurrence); 1 = both halves at every event
     s, cfg = make_pair(engine, oracle, "BPS", dim, "dense", arith=oracle.ARITH_REFERENCE, **kw)
     x, v = make_init("BPS", dim, chains)
     got = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=21, diagnostics=True)
@@ -577,11 +580,14 @@ def test_dense_precision_bps_small_ensembles_keep_the_bit_exact_kernel(engine, o
 
 @pytest.mark.parametrize("kw", [{}, {"refresh_rate": 1.5}, {"signed_bound": False}, {"adaptive": False, "tmax": 0.3}])
 @pytest.mark.parametrize("dim,chains,n_sk", [(40, 64, 60), (257, 70, 30), (600, 64, 16)])
-def test_dense_precision_boomerang_one_gemm_per_event(engine, oracle, dim, chains, n_sk, kw):
+@pytest.mark.parametrize("resync", [None, "1", "7"])
+def test_dense_precision_boomerang_one_gemm_per_event(engine, oracle, monkeypatch, dim, chains, n_sk, kw, resync):
     """Boomerang on a dense precision with >= 64 chains (dense_batched.hip: dr_boom_kernel): grad-U_effective = P x - x is linear and
     the flow a rotation, so the rate along the flow is a quadratic form in cos t, sin t with four dot products as coefficients;
     one fp64 GEMM P [x | v'] over all chains per skeleton column.  Same tolerance as the BPS form."""
     from pdmpflux.jl_amd import _lib
+    if resync:
+        monkeypatch.setenv("PDMP_DENSE_RESYNC", resync)
     s, cfg = make_pair(engine, oracle, "BoomerangAD", dim, "dense", arith=oracle.ARITH_REFERENCE, **kw)
     x, v = make_init("BoomerangAD", dim, chains)
     got = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=21, diagnostics=True)
