@@ -315,6 +315,16 @@ long long pdmp_dense_batched_last_columns(void);
  * (P x and P v kept current by O(d) updates, one GEMM per `PDMP_DENSE_RESYNC` = 256 events; last_phases() is 0 then). */
 int pdmp_dense_batched_last_mode(void);
 
+/* Synthetic initial states of an ensemble, generated on the device (the ensemble API is new -- the reference starts its one chain
+ * from user arrays, README.md:40-44 -- and BASELINE.md section 3 fixes the synthetic workloads as "xinit[:,c] ~ N(0,I), vinit[i,c] = +-1
+ * from Philox key (seed, c) stream 1; chain RNG = stream 0"): stream 1 of chain c is its Philox stream with the top bit of the 64-bit
+ * chain word set, so the initial states, like the trajectories, depend on the GLOBAL chain id only (sharding-invariant).
+ * xinit[:, c] = x_mean + x_scale * N(0, I); vinit by v_kind: +-1 coordinates, N(0, I), or uniform on the unit sphere.
+ * DEVICE pointers, d x C each, enqueued on `stream`.  Checker: orc_init_states (bit for bit). */
+enum { PDMP_V_RADEMACHER = 0, PDMP_V_GAUSSIAN = 1, PDMP_V_SPHERE = 2 };
+int pdmp_init_states_device(pdmp_handle h, int64_t C, int64_t chain_id_offset, uint64_t seed, double x_mean, double x_scale,
+                            int32_t v_kind, double *xinit, double *vinit, void *stream);
+
 /* Test hook: first n variates of stream (seed, chain) produced ON THE DEVICE with the engine's
  * generator; kind 0 uniform, 1 Exp(1), 2 normal vector.  out is a HOST pointer. */
 int pdmp_debug_rng(pdmp_handle h, uint64_t seed, int64_t chain, int32_t kind, int64_t n, double *out);

@@ -74,6 +74,8 @@ def lib():
         L.orc_sincos.argtypes = [C.c_double, dp, dp]
         L.orc_sincos_2pi.argtypes = [C.c_double, dp, dp]
         L.orc_rng_dump.argtypes = [C.c_uint64, C.c_int64, C.c_int, C.c_int64, dp]
+        L.orc_init_states.argtypes = [C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_int, dp, dp]
+        L.orc_init_states.restype = None
         L.orc_upper_bound.argtypes = [C.POINTER(_Cfg), dp, dp, C.c_double, dp, dp, dp]
         L.orc_upper_bound.restype = C.c_double
         L.orc_next_event.argtypes = [C.c_int, dp, dp, dp, C.c_double, C.c_double, dp, dp]
@@ -273,6 +275,18 @@ def rng_dump(seed: int, chain: int, kind: int, n: int) -> np.ndarray:
     out = np.empty(n)
     lib().orc_rng_dump(C.c_uint64(seed), chain, kind, n, _dp(out))
     return out
+
+
+V_RADEMACHER, V_GAUSSIAN, V_SPHERE = 0, 1, 2
+
+
+def init_states(seed: int, C_: int, d: int, *, chain_id_offset: int = 0, x_mean: float = 0.0, x_scale: float = 1.0,
+                v_kind: int = V_RADEMACHER):
+    """Synthetic initial states of chains ``chain_id_offset .. +C`` from stream 1 of each chain's Philox key (BASELINE.md section 3);
+    the checker's side of pdmp_init_states_device.  Returns ``(x, v)``, each ``(C, d)``."""
+    x, v = np.empty((C_, d)), np.empty((C_, d))
+    lib().orc_init_states(C.c_uint64(seed), int(chain_id_offset), int(C_), int(d), float(x_mean), float(x_scale), int(v_kind), _dp(x), _dp(v))
+    return x, v
 
 
 def upper_bound(cfg: Config, x, v, horizon: float):

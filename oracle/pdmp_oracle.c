@@ -229,6 +229,31 @@ void orc_rng_dump(uint64_t seed, int64_t chain, int kind, int64_t n_draw, double
     for (int64_t i = 0; i < n_draw; ++i) out[i] = (kind == 0) ? rng_uniform(&r) : rng_exp(&r);
 }
 
+/* Synthetic initial states of an ensemble ("xinit[:,c] ~ N(0,I), vinit[i,c] = +-1 from Philox key (2024, c)
+ * stream 1; chain RNG = stream 0"): stream 1 of chain c is the chain's Philox stream with the top bit of the 64-bit chain word set.
+ * Draw order: d normals for x (Box-Muller pairs, as rng_normals), then for v: ORC_V_RADEMACHER d uniforms (u < 0.5 -> -1, else +1),
+ * ORC_V_GAUSSIAN d normals, ORC_V_SPHERE d normals divided by sqrt of their left-to-right sum of squares.
+ * x_i = x_mean + x_scale z_i.  Mirrors pdmp_init_states_device (csrc/engine_api.hip) bit for bit. */
+void orc_init_states(uint64_t seed, int64_t chain0, int64_t C, int d, double x_mean, double x_scale, int v_kind, double *x, double *v) {
+    for (int64_t c = 0; c < C; ++c) {
+        rng_t r = { seed, ((uint64_t)(chain0 + c)) | (1ull << 63), 0, NULL, NULL, NULL, 0, 0, 0, 0, 0, 0, NULL };
+        double *xc = x + c * d, *vc = v + c * d;
+        rng_normals(&r, d, xc);
+        for (int i = 0; i < d; ++i) xc[i] = x_mean + x_scale * xc[i];
+        if (v_kind == ORC_V_RADEMACHER) {
+            for (int i = 0; i < d; ++i) vc[i] = (rng_uniform(&r) < 0.5) ? -1.0 : 1.0;
+        } else {
+            rng_normals(&r, d, vc);
+            if (v_kind == ORC_V_SPHERE) {
+                double ss = 0.0;
+                for (int i = 0; i < d; ++i) ss += vc[i] * vc[i];
+                const double nrm = sqrt(ss);
+                for (int i = 0; i < d; ++i) vc[i] = vc[i] / nrm;
+            }
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------------------------
  * Summation orders (orc_config_t.arith)
  * ------------------------------------------------------------------------------------------ */

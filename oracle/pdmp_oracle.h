@@ -124,6 +124,9 @@ void   orc_sincos(double x, double *s, double *c);
 void   orc_sincos_2pi(double u, double *s, double *c);
 /* first n_draw variates of chain stream (seed, chain): kind 0 uniform, 1 exp, 2 normal-vector (d=n_draw) */
 void   orc_rng_dump(uint64_t seed, int64_t chain, int kind, int64_t n_draw, double *out);
+/* Synthetic initial states from stream 1 of each chain's key; mirrors pdmp_init_states_device. */
+enum { ORC_V_RADEMACHER = 0, ORC_V_GAUSSIAN = 1, ORC_V_SPHERE = 2 };
+void   orc_init_states(uint64_t seed, int64_t chain0, int64_t C, int d, double x_mean, double x_scale, int v_kind, double *x, double *v);
 /* one bound + inversion: fills grid[n], box_max[n-1], cum_sum[n]; returns step_size (UpperBound.jl) */
 double orc_upper_bound(const orc_config_t *cfg, const double *x, const double *v, double horizon,
                        double *grid, double *box_max, double *cum_sum);

@@ -65,7 +65,7 @@ SYMBOLS = (
     "pdmp_sample_skeleton_until_device", "pdmp_close_chunk_device", "pdmp_until_advance_device", "pdmp_compact_chunk_device",
     "pdmp_multi_shard_range", "pdmp_multi_create", "pdmp_multi_destroy", "pdmp_multi_sample_skeleton", "pdmp_multi_get_timing",
     "pdmp_check_status", "pdmp_get_timing", "pdmp_reset_timing",
-    "pdmp_debug_rng", "pdmp_dense_batched_last_phases", "pdmp_dense_batched_last_columns", "pdmp_dense_batched_last_mode",
+    "pdmp_init_states_device", "pdmp_debug_rng", "pdmp_dense_batched_last_phases", "pdmp_dense_batched_last_columns", "pdmp_dense_batched_last_mode",
 )
 
 _lib = None
@@ -130,6 +130,7 @@ def lib():
     L.pdmp_get_timing.argtypes = [vp, C.POINTER(Timing)]
     L.pdmp_reset_timing.argtypes = [vp]
     L.pdmp_debug_rng.argtypes = [vp, u64, i64, i32, i64, vp]
+    L.pdmp_init_states_device.argtypes = [vp, i64, i64, u64, C.c_double, C.c_double, i32, vp, vp, vp]
     L.pdmp_dense_batched_last_phases.restype = C.c_longlong
     L.pdmp_dense_batched_last_columns.restype = C.c_longlong
     L.pdmp_dense_batched_last_mode.restype = C.c_int

@@ -613,6 +613,39 @@ __global__ void debug_rng_kernel(uint64_t seed, int64_t chain, int kind, int64_t
     }
 }
 
+// Synthetic initial states (pdmp_init_states_device): one thread per chain, everything in the chain's own sequential order so that
+// the checker's orc_init_states reproduces it bit for bit.  Stream 1 of a chain = its Philox stream with the top bit of the chain word set.
+__global__ void init_states_kernel(int64_t C, int64_t chain0, uint64_t seed, int d, double x_mean, double x_scale, int v_kind,
+                                   double *__restrict__ x, double *__restrict__ v) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    ChainRng rng;
+    rng.init_lane(seed, ((uint64_t)(chain0 + c)) | (1ull << 63));
+    double *xc = x + c * d, *vc = v + c * d;
+    for (int p = 0; 2 * p < d; ++p) {
+        double z0, z1;
+        rng.normal_pair(p, z0, z1);
+        xc[2 * p] = x_mean + x_scale * z0;
+        if (2 * p + 1 < d) xc[2 * p + 1] = x_mean + x_scale * z1;
+    }
+    rng.normals_done(d);
+    if (v_kind == PDMP_V_RADEMACHER) {
+        for (int i = 0; i < d; ++i) vc[i] = (rng.uniform() < 0.5) ? -1.0 : 1.0;
+        return;
+    }
+    double ss = 0.0;
+    for (int p = 0; 2 * p < d; ++p) {
+        double z0, z1;
+        rng.normal_pair(p, z0, z1);
+        vc[2 * p] = z0; ss = ss + z0 * z0;
+        if (2 * p + 1 < d) { vc[2 * p + 1] = z1; ss = ss + z1 * z1; }
+    }
+    if (v_kind == PDMP_V_SPHERE) {
+        const double nrm = __dsqrt_rn(ss);
+        for (int i = 0; i < d; ++i) vc[i] = vc[i] / nrm;
+    }
+}
+
 int normalize_config(pdmp_config_t &c, bool from_source = false) {
     if (c.dim <= 0) return fail(PDMP_ERR_ARGUMENT, "dimension dim must be positive. Current value: %d", c.dim);          // ZigZagSamplers.jl:62-64
     if (c.grid_size < 0) return fail(PDMP_ERR_ARGUMENT, "grid_size must be non-negative. Current value: %d", c.grid_size); // :66-68
@@ -1582,6 +1615,19 @@ int pdmp_reset_timing(pdmp_handle h) {
     HIP_TRY(hipSetDevice(h->device));
     if (int rc = fold_timing(h)) return rc;
     h->timing = {0.0, 0.0, 0};
+    return PDMP_OK;
+}
+
+int pdmp_init_states_device(pdmp_handle h, int64_t C, int64_t chain_id_offset, uint64_t seed, double x_mean, double x_scale,
+                            int32_t v_kind, double *xinit, double *vinit, void *stream) {
+    if (!h || !xinit || !vinit) return fail(PDMP_ERR_ARGUMENT, "init_states: null argument");
+    if (C <= 0 || chain_id_offset < 0) return fail(PDMP_ERR_ARGUMENT, "init_states: C must be positive and chain_id_offset non-negative");
+    if (v_kind < PDMP_V_RADEMACHER || v_kind > PDMP_V_SPHERE) return fail(PDMP_ERR_ARGUMENT, "init_states: unknown v_kind %d", (int)v_kind);
+    HIP_TRY(hipSetDevice(h->device));
+    const int threads = 64;
+    hipLaunchKernelGGL(init_states_kernel, dim3((unsigned)((C + threads - 1) / threads)), dim3(threads), 0, (hipStream_t)stream,
+                       C, chain_id_offset, seed, h->cfg.dim, x_mean, x_scale, (int)v_kind, xinit, vinit);
+    HIP_TRY(hipGetLastError());
     return PDMP_OK;
 }
 

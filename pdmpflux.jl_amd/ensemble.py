@@ -27,11 +27,42 @@ def _stream_ptr(stream):
     return C.c_void_p(s.cuda_stream)
 
 
+def _on_stream(dev, stream):
+    """Context of a device entry point: ``dev`` current and -- when the caller passed a stream -- that stream torch's current one, so
+    that the torch-side pieces of a host loop (zero fills, clones, ``.item()`` reads) are ordered with the engine's kernels, which are
+    enqueued on ``stream``."""
+    import contextlib
+    st = contextlib.ExitStack()
+    st.enter_context(torch.cuda.device(dev))
+    if stream is not None:
+        st.enter_context(torch.cuda.stream(stream))
+    return st
+
+
 def _need_cuda(*ts):
     for t in ts:
         if t is not None and (not t.is_cuda or t.dtype not in (torch.float64, torch.int32, torch.int64, torch.uint8) or not t.is_contiguous()):
             raise ArgumentError("device entry points need contiguous float64 / int32 / int64 / uint8 CUDA tensors "
                                 "(the engine has no CPU fallback)")
+
+
+V_RADEMACHER, V_GAUSSIAN, V_SPHERE = 0, 1, 2
+
+
+def init_states_device(sampler: AbstractPDMP, C_: int, *, seed, chain_id_offset: int = 0, x_mean: float = 0.0, x_scale: float = 1.0,
+                       v_kind: int = V_RADEMACHER, device=None, stream=None):
+    """pdmp_init_states_device: synthetic initial states of chains ``chain_id_offset .. +C`` generated on the device from stream 1 of
+    each chain's Philox key -- ``x = x_mean + x_scale N(0, I)``; ``v``: +-1 coordinates, ``N(0, I)`` or uniform
+    on the unit sphere.  Keyed by the GLOBAL chain id: a shard's states do not depend on the sharding.  Returns ``(x, v)``, ``(C, d)``."""
+    if C_ <= 0:
+        raise ArgumentError(f"C must be positive. Current value: {C_}")
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    x = torch.empty((C_, sampler.dim), dtype=torch.float64, device=dev)
+    v = torch.empty((C_, sampler.dim), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().pdmp_init_states_device(sampler.handle(), int(C_), int(chain_id_offset), C.c_uint64(_seed(seed)), float(x_mean),
+                                                      float(x_scale), int(v_kind), _ptr(x), _ptr(v), _stream_ptr(stream)))
+    return x, v
 
 
 def sample_skeleton_device(sampler: AbstractPDMP, n_sk: int, xinit: torch.Tensor, vinit: torch.Tensor, *,
@@ -132,10 +163,10 @@ def compact_history_device(sampler: AbstractPDMP, out: dict, count: torch.Tensor
     Cn, n_sk, d = out["X"].shape
     dev = out["X"].device
     L = _lib.lib()
-    offsets = torch.empty((Cn + 1,), dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with _on_stream(dev, stream):
+        offsets = torch.empty((Cn + 1,), dtype=torch.int64, device=dev)
         _lib.check(L.pdmp_compact_offsets_device(sampler.handle(), Cn, _ptr(count), _ptr(offsets), _stream_ptr(stream)))
-        total = int(offsets[-1].item())
+        total = int(offsets[-1].item())           # (.item() waits on torch's current stream = `stream` inside this context)
         res = {"offsets": offsets, "count": count,
                "X": torch.empty((total, d), dtype=torch.float64, device=dev), "V": torch.empty((total, d), dtype=torch.float64, device=dev),
                "t": torch.empty((total,), dtype=torch.float64, device=dev)}
@@ -195,8 +226,10 @@ def sample_skeleton_until_chunked_device(sampler: AbstractPDMP, T: float, xinit:
     L = _lib.lib()
     h = sampler.handle()
     sp = _stream_ptr(stream)
-    cap = -(-max(2, int(init_capacity)) // 8) * 8
-    total = torch.zeros((Cn,), dtype=torch.int64, device=dev)
+    # the lane forms address a wave's window of X / V (64 chains x capacity x d doubles) through a 32-bit buffer descriptor
+    # (engine_api.hip: lane_ok) and a resumed chunk must run in the first chunk's form: keep every capacity below that window
+    cap_limit = ((2 ** 31 - 1) // (64 * 8 * d)) // 8 * 8 if d <= 104 else 1 << 40
+    cap = min(-(-max(2, int(init_capacity)) // 8) * 8, max(cap_limit, 8))
     chunks, cmap, C_l, cap_sum, allocated = [], None, Cn, 0, 0
     prof = [] if (stats is not None and stats.get("profile")) else None
 
@@ -205,7 +238,8 @@ def sample_skeleton_until_chunked_device(sampler: AbstractPDMP, T: float, xinit:
             import time
             torch.cuda.synchronize()
             prof.append((what, time.perf_counter()))
-    with torch.cuda.device(dev):
+    with _on_stream(dev, stream):
+        total = torch.zeros((Cn,), dtype=torch.int64, device=dev)
         while True:
             mark("chunk begin")
             bufs = {"X": torch.empty((C_l, cap, d), dtype=torch.float64, device=dev), "V": torch.empty((C_l, cap, d), dtype=torch.float64, device=dev),
@@ -255,7 +289,7 @@ def sample_skeleton_until_chunked_device(sampler: AbstractPDMP, T: float, xinit:
             else:
                 want = float(need.max().item()) * 1.25 + 16.0
             cap = int(min(max(16.0, want), float(max(4 * cap_sum, 1024))))   # (an estimate gone wild costs chunks or memory, never correctness)
-            cap = -(-cap // 8) * 8
+            cap = min(-(-cap // 8) * 8, max(cap_limit, 8))
             C_l = n
         mark("chunks done")
         if prof is not None:
@@ -317,16 +351,17 @@ def sample_skeleton_until_device(sampler: AbstractPDMP, T: float, xinit: torch.T
     cap = max(2, int(init_capacity))
     seed = _seed(seed)
     while True:
-        out = sample_skeleton_device(sampler, cap, xinit, vinit, seed=seed, chain_id_offset=chain_id_offset,
-                                     diagnostics=diagnostics, stream=stream)
-        Cn = xinit.shape[0]
-        count = torch.empty((Cn,), dtype=torch.int64, device=xinit.device)
-        dg = _diag_of(out)
-        with torch.cuda.device(xinit.device):
+        with _on_stream(xinit.device, stream):               # (the torch-side reduction below must follow the kernels on `stream`)
+            out = sample_skeleton_device(sampler, cap, xinit, vinit, seed=seed, chain_id_offset=chain_id_offset,
+                                         diagnostics=diagnostics, stream=stream)
+            Cn = xinit.shape[0]
+            count = torch.empty((Cn,), dtype=torch.int64, device=xinit.device)
+            dg = _diag_of(out)
             _lib.check(_lib.lib().pdmp_close_at_time_device(sampler.handle(), Cn, cap, _ptr(out["X"]), _ptr(out["V"]), _ptr(out["t"]),
                                                             C.byref(dg) if dg is not None else None, C.c_double(T),
                                                             C.c_void_p(count.data_ptr()), _stream_ptr(stream)))
-        if bool((count > 0).all()):
+            done = bool((count > 0).all())
+        if done:
             break
         cap *= 2                                                                          # newcap = 2 * size, :375-377
     if compact:

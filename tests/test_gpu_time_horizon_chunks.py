@@ -21,12 +21,15 @@ CASES = [
 ]
 
 
-def _run(engine, oracle, s, cfg, x, v, T, seed, cap, stats=None, lo=0):
+def _run(engine, oracle, s, cfg, x, v, T, seed, cap, stats=None, lo=0, stream=None):
     import torch
     from pdmpflux.jl_amd import ensemble
     dev = torch.device("cuda:0")
     got = ensemble.sample_skeleton_until_chunked_device(s, T, torch.from_numpy(x).to(dev), torch.from_numpy(v).to(dev), seed=seed,
-                                                        diagnostics=True, init_capacity=cap, stats=stats, chain_id_offset=lo)
+                                                        diagnostics=True, init_capacity=cap, stats=stats, chain_id_offset=lo,
+                                                        stream=stream)
+    if stream is not None:
+        stream.synchronize()
     ref = oracle.sample_skeleton_until(cfg, T, x, v, seed, init_capacity=max(cap, 64), chain_id_offset=lo)
     off = got["offsets"].cpu().numpy()
     cnt = got["count"].cpu().numpy()
@@ -68,6 +71,23 @@ def test_chunked_time_horizon_on_the_lane_kernel(engine, oracle, monkeypatch, ta
     stats = {}
     _run(engine, oracle, s, cfg, x, v, T, 4, 16, stats, lo=7)            # chain_id_offset: streams keyed by the global chain id
     assert s.last_launch_form() == 4 and stats["chunks"] >= 2
+
+
+def test_chunked_time_horizon_on_a_side_stream(engine, oracle):
+    """A caller's stream that is NOT torch's current stream: the host loop's own torch ops (zero fills, the clone of the list of
+    running chains, the `.item()` reads between chunks) must be ordered with the engine's kernels on that stream.  The current
+    stream is kept busy with a long fill while the side stream runs the chunks, so an op left on the wrong stream shows."""
+    import torch
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", 50, "iso")
+    x, v = make_init("ZigZagAD", 50, 300, seed=11)
+    side = torch.cuda.Stream()
+    busy = torch.empty((1 << 28,), dtype=torch.float64, device="cuda")
+    for rep in range(3):
+        busy.fill_(float(rep))                                           # ~2 GB fill queued on the current stream
+        stats = {}
+        _run(engine, oracle, s, cfg, x, v, 1.4, 6 + rep, 8, stats, stream=side)
+        assert stats["chunks"] >= 3
+    torch.cuda.synchronize()
 
 
 def test_chunked_time_horizon_segment_handoff(engine, oracle, monkeypatch):
