@@ -136,6 +136,10 @@ int pdmp_get_group_lanes(pdmp_handle h);
  * G, which is why a sharded run (pdmp_multi_*, the Python driver) uses ONE G for all shards. */
 int pdmp_suggest_group_lanes(pdmp_handle h, int64_t C);
 int pdmp_set_group_lanes(pdmp_handle h, int32_t G);
+/* Which kernel form serves a launch (results never depend on it) and the forms' tuning numbers are a per-handle POLICY, fixed when the
+ * handle is created: defaults measured on MI355X, overridden by the PDMP_* environment variables of README.md (test hooks, tuning
+ * scripts).  No launch reads the environment; a caller that changes it between launches of one handle calls this to re-read it. */
+int pdmp_reload_policy(pdmp_handle h);
 /* Which kernel form served the handle's last pdmp_sample_skeleton* launch (waits for it to finish): a diagnostic for benchmarks and
  * tests, results do not depend on it.  PDMP_FORM_LANE: one lane per chain (csrc/lane_kernel.hpp; large Zig-Zag ensembles at
  * dim 27..52 with unit speeds on the isotropic Gaussian / banana -- bit-identical to the group kernel with G = 4). */

@@ -58,7 +58,7 @@ class Timing(C.Structure):
 # every symbol include/pdmp_hip.h declares; tests check that the library exports all of them
 SYMBOLS = (
     "pdmp_abi_version", "pdmp_last_error", "pdmp_device_count", "pdmp_create", "pdmp_create_from_source", "pdmp_get_config",
-    "pdmp_destroy", "pdmp_get_group_lanes", "pdmp_suggest_group_lanes", "pdmp_set_group_lanes", "pdmp_last_launch_form", "pdmp_set_tape", "pdmp_clear_tape", "pdmp_sample_skeleton", "pdmp_sample_skeleton_device", "pdmp_sample_from_skeleton",
+    "pdmp_destroy", "pdmp_get_group_lanes", "pdmp_suggest_group_lanes", "pdmp_set_group_lanes", "pdmp_reload_policy", "pdmp_last_launch_form", "pdmp_set_tape", "pdmp_clear_tape", "pdmp_sample_skeleton", "pdmp_sample_skeleton_device", "pdmp_sample_from_skeleton",
     "pdmp_sample_from_skeleton_device", "pdmp_sample_from_skeleton_dt", "pdmp_sample_from_skeleton_dt_device",
     "pdmp_sample_from_skeleton_prefix", "pdmp_sample_from_skeleton_prefix_device", "pdmp_sample_moments_device",
     "pdmp_close_at_time_device", "pdmp_compact_offsets_device", "pdmp_compact_history_device",
@@ -102,6 +102,7 @@ def lib():
     L.pdmp_suggest_group_lanes.argtypes = [vp, i64]
     L.pdmp_suggest_group_lanes.restype = C.c_int
     L.pdmp_set_group_lanes.argtypes = [vp, i32]
+    L.pdmp_reload_policy.argtypes = [vp]
     L.pdmp_set_tape.argtypes = [vp, i64, i64, i64, i64, vp, vp, vp]
     L.pdmp_clear_tape.argtypes = [vp]
     L.pdmp_sample_skeleton.argtypes = [vp, i64, i64, i64, vp, vp, u64, vp, vp, vp, C.POINTER(Diag)]

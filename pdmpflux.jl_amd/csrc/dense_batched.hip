@@ -930,7 +930,7 @@ extern "C" int pdmp_dense_batched_run(int device, int d, int signed_bound, int a
                                       const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
                                       const double *xinit, const double *vinit, double *X, double *V, double *t,
                                       double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
-                                      int32_t *status, void *stream_v, char *err, int errlen) {
+                                      int32_t *status, void *stream_v, int full_pv, char *err, int errlen) {
     hipStream_t stream = (hipStream_t)stream_v;
 #define DB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { snprintf(err, errlen, "%s: %s", #expr, hipGetErrorString(e_)); goto fail; } } while (0)
 #define DB_BLAS(expr) do { rocblas_status s_ = (expr); if (s_ != rocblas_status_success) { snprintf(err, errlen, "%s: rocblas status %d", #expr, (int)s_); goto fail; } } while (0)
@@ -973,7 +973,7 @@ extern "C" int pdmp_dense_batched_run(int device, int d, int signed_bound, int a
             ++g_last_phases;
             // Out (d x C) = P (d x d) * requests (d x C): grad-U of every request.  The velocity half, P v of every chain, changes only
             // at flips, where the step kernel updates it by a rank-one term; a full d x 2C product re-syncs it every 32 phases.
-            const bool full = (ph % 32) == 0 || getenv("PDMP_DENSE_FULL_PV") != nullptr;
+            const bool full = (ph % 32) == 0 || full_pv;
             g_last_columns += full ? 2 * C : C;
             DB_BLAS(rocblas_dgemm(hb, rocblas_operation_none, rocblas_operation_none, d, (int)(full ? 2 * C : C), d, &one,
                                   P_dev, d, In, d, &zero, Out, d));
@@ -1008,7 +1008,7 @@ extern "C" int pdmp_dense_incremental_run(int device, int d, int signed_bound, i
                                           const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
                                           const double *xinit, const double *vinit, double *X, double *V, double *t,
                                           double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
-                                          int32_t *status, void *stream_v, void **ws, size_t *ws_cap, char *err, int errlen) {
+                                          int32_t *status, void *stream_v, void **ws, size_t *ws_cap, int64_t resync_events, char *err, int errlen) {
     hipStream_t stream = (hipStream_t)stream_v;
     // the unsigned bound keeps the tangent intersection's division: its 16-slot instantiation does not fit the register file
     // without spilling (and no kernel with lane-dependent branches may spill, see GroupOcc in group_kernel.hpp)
@@ -1024,8 +1024,7 @@ extern "C" int pdmp_dense_incremental_run(int device, int d, int signed_bound, i
     }
     double *In = (double *)*ws, *Out = In + 2 * n;
     DiState *st = (DiState *)(Out + 2 * n);
-    int64_t resync = 256;
-    if (const char *e = getenv("PDMP_DENSE_RESYNC")) { const long long r = atoll(e); if (r >= 1) resync = r; }
+    const int64_t resync = resync_events >= 1 ? resync_events : 256;   // (policy: PDMP_DENSE_RESYNC)
     rocblas_handle hb = db_handle(device);
     if (!hb) { snprintf(err, errlen, "rocblas handle"); return -3; }
     DB_TRY(hipMemcpyAsync(In, xinit, n * 8, hipMemcpyDeviceToDevice, stream));
@@ -1069,7 +1068,7 @@ extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_b
                                   int64_t cap, const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
                                   const double *xinit, const double *vinit, double *X, double *V, double *t,
                                   double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
-                                  int32_t *status, void *stream_v, void **ws, size_t *ws_cap, char *err, int errlen) {
+                                  int32_t *status, void *stream_v, void **ws, size_t *ws_cap, int64_t resync_events, char *err, int errlen) {
     hipStream_t stream = (hipStream_t)stream_v;
     if (d > 16 * WAVE) return -5;
 #define DB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { snprintf(err, errlen, "%s: %s", #expr, hipGetErrorString(e_)); return -3; } } while (0)
@@ -1099,8 +1098,7 @@ extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_b
     const dim3 grid((unsigned)((C + 3) / 4)), block(256);
     const double one = 1.0, zero = 0.0;
     g_last_phases = 0; g_last_columns = 0; g_last_mode = 3;
-    int64_t resync = 64;                       // events between two full products P [x | v]; in between only P v' is multiplied
-    if (const char *e = getenv("PDMP_DENSE_RESYNC")) { const long long r = atoll(e); if (r >= 1) resync = r; }
+    const int64_t resync = resync_events >= 1 ? resync_events : 64;   // events between two full products P [x | v]; in between only P v' is multiplied (policy: PDMP_DENSE_RESYNC)
     for (int64_t k0 = 0, ph = 0; k0 < n_sk; ++ph) {
         const int64_t k1 = (k0 == 0) ? ((n_sk < 2) ? n_sk : 2) : k0 + 1;
         const bool full = (ph % resync) == 0;

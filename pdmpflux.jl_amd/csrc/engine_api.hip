@@ -27,9 +27,6 @@ hipError_t launch_group_reg_zigzag_exact(int target, const GroupParams &gp, hipS
 hipError_t launch_group_reg_bps_exact(int target, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_boomerang_exact(int target, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_boomerang_exact_fd(int target, const GroupParams &gp, hipStream_t stream);
-hipError_t launch_lane_bps_13(int target, const GroupParams &gp, int rounds, hipStream_t stream);       // lane_bps_kernel.hpp: d = 49 .. 52
-hipError_t launch_lane_bps_a(int target, const GroupParams &gp, int rounds, hipStream_t stream);        // d = 25 .. 36
-hipError_t launch_lane_bps_b(int target, const GroupParams &gp, int rounds, hipStream_t stream);        // d = 37 .. 48
 // tape replay (pdmp_set_tape): the same kernel forms with the tapes as random source (inst_tape_*.hip)
 hipError_t launch_lane_zigzag_tape(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);
 hipError_t launch_group_reg_tape_zigzag(int target, bool fd, const GroupParams &gp, hipStream_t stream);
@@ -65,23 +62,72 @@ extern "C" int pdmp_dense_batched_run(int device, int d, int signed_bound, int a
                                       const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
                                       const double *xinit, const double *vinit, double *X, double *V, double *t,
                                       double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
-                                      int32_t *status, void *stream, char *err, int errlen);
+                                      int32_t *status, void *stream, int full_pv, char *err, int errlen);
 extern "C" int pdmp_dense_incremental_run(int device, int d, int signed_bound, int adaptive, double tmax, int64_t cap,
                                       const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
                                       const double *xinit, const double *vinit, double *X, double *V, double *t,
                                       double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
-                                      int32_t *status, void *stream, void **ws, size_t *ws_cap, char *err, int errlen);
+                                      int32_t *status, void *stream, void **ws, size_t *ws_cap, int64_t resync_events, char *err, int errlen);
 extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_bound, int adaptive, int gaussian_velocity, double tmax, double refresh,
                                   int64_t cap, const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
                                   const double *xinit, const double *vinit, double *X, double *V, double *t,
                                   double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
-                                  int32_t *status, void *stream, void **ws, size_t *ws_cap, char *err, int errlen);   // dense_batched.hip: BPS, one GEMM per event
+                                  int32_t *status, void *stream, void **ws, size_t *ws_cap, int64_t resync_events, char *err, int errlen);   // dense_batched.hip: BPS, one GEMM per event
 
 extern "C" int pdmp_user_compile(int device, int sampler, int fd, int kind, const char *source, void **fn_out, char *err, int errlen);
 extern "C" int pdmp_user_launch(void *fn, const GroupParams *gp, void *stream);
 
+// Launch policy of a handle: which kernel form serves a launch, and the tuning numbers of the forms.  Filled ONCE, when the handle is
+// created, from the defaults below and the PDMP_* environment overrides (test hooks and tuning scripts); no launch reads the
+// environment.  pdmp_reload_policy() re-reads it for a caller that changes the environment between launches of one handle.
+// The defaults were measured on one MI355X at n_sk = 1000 (profiles/r3/r3q1_*); the form never changes results
+// (bit-identical kernels), only speed.
+struct LaunchPolicy {
+    int reg = 1;                   // PDMP_REG=0: keep x, v in LDS tiles (the LDS form) although a register form exists
+    int reg_exact = 1;             // PDMP_REG_EXACT=0: the 13-slot register kernels with per-slot skips instead of the exact-K ones
+    int lane_mode = -1;            // PDMP_LANE: 0 never a lane form, 1 one lane per chain whenever the configuration allows, 2 the pair form
+                                   //   at d <= 52 too; -1 (unset): from the number of chains, thresholds below
+    int64_t lane_min_chains = -1;  // PDMP_LANE_MIN_CHAINS: one lane per chain from this many chains on (-1: lane_from_default())
+    int64_t pair_min_chains = 16385;   // PDMP_LANE_PAIR_MIN_CHAINS: up to 16 384 chains = 1 024 group-kernel waves, one per SIMD: 3.9 - 4.0 ms flat
+    int lane_rounds = 24;          // PDMP_LANE_ROUNDS: work units per resident wave of a lane kernel (8 -> 24: 18.2 -> 16.8 ms at config 2)
+    int cell_budget = 0;           // PDMP_CELL_BUDGET: cells of the lazy Zig-Zag bound per pass (0: the form's default: 9 / 3 group, 5 lane)
+    int force_segments = 0;        // PDMP_FORCE_SEGMENTS: segments per chain (0: from the schedule); test hook for the hand-off
+    int dense_mode = 0;            // PDMP_DENSE_MODE: 0 default (incr for >= 64 chains and d <= 1024, gemm beyond), 1 incr, 2 gemm, 3 matvec
+    int tape_wave = 0;             // PDMP_TAPE_WAVE=1: tape replay on the wave-per-chain kernel
+    int from_skeleton_rows = 0;    // PDMP_FROM_SKELETON_ROWS: the row-per-iteration sample_from_skeleton kernel (A/B runs)
+    int64_t dense_resync = 0;      // PDMP_DENSE_RESYNC: events between two re-basing products of the batched dense forms (0: 256 Zig-Zag / 64 BPS, Boomerang)
+    int dense_full_pv = 0;         // PDMP_DENSE_FULL_PV: the GEMM-per-phase form multiplies the velocity half in every phase
+    int no_lean = 0;               // PDMP_NO_LEAN: the full 13-slot register kernels even where a lean throughput instantiation exists (A/B, tests)
+    int debug_launch = 0;          // PDMP_DEBUG_LAUNCH: print the launch geometry of the lane kernels
+    // one lane per chain from this many chains on: the pair form (GL = 2) at d = 53 .. 104 fills the machine at 32 768 chains; at d <= 52
+    // the one-lane kernel takes 8.2 - 9.7 ms whatever the count up to 65 536 chains and overtakes the pair form at ~37 000 (d >= 45) / ~40 000
+    int64_t lane_from_default(bool pair_dims, int dim) const { return pair_dims ? 28000 : (dim >= 45 ? 37000 : 40000); }
+};
+
+static LaunchPolicy policy_from_env() {
+    LaunchPolicy q;
+    auto geti = [](const char *name, long long dflt) { const char *e = getenv(name); return e ? atoll(e) : dflt; };
+    q.reg = (int)geti("PDMP_REG", 1) != 0;
+    q.reg_exact = (int)geti("PDMP_REG_EXACT", 1) != 0;
+    q.lane_mode = (int)geti("PDMP_LANE", -1);
+    q.lane_min_chains = geti("PDMP_LANE_MIN_CHAINS", -1);
+    q.pair_min_chains = geti("PDMP_LANE_PAIR_MIN_CHAINS", q.pair_min_chains);
+    { const int v = (int)geti("PDMP_LANE_ROUNDS", q.lane_rounds); if (v >= 1 && v <= 64) q.lane_rounds = v; }
+    { const int b = (int)geti("PDMP_CELL_BUDGET", 0); if (b >= 1 && b <= 9) q.cell_budget = b; }
+    q.force_segments = (int)geti("PDMP_FORCE_SEGMENTS", 0);
+    if (const char *m = getenv("PDMP_DENSE_MODE")) q.dense_mode = !strcmp(m, "incr") ? 1 : !strcmp(m, "gemm") ? 2 : !strcmp(m, "matvec") ? 3 : 0;
+    q.tape_wave = (int)geti("PDMP_TAPE_WAVE", 0) == 1;
+    q.from_skeleton_rows = getenv("PDMP_FROM_SKELETON_ROWS") != nullptr;
+    { const long long r = geti("PDMP_DENSE_RESYNC", 0); if (r >= 1) q.dense_resync = r; }
+    q.dense_full_pv = getenv("PDMP_DENSE_FULL_PV") != nullptr;
+    q.no_lean = getenv("PDMP_NO_LEAN") != nullptr;
+    q.debug_launch = getenv("PDMP_DEBUG_LAUNCH") != nullptr;
+    return q;
+}
+
 struct pdmp_engine {
     pdmp_config_t cfg;
+    LaunchPolicy policy;
     void *user_fn = nullptr;          // PDMP_T_USER: the runtime-compiled group kernel (user_jit.hip)
     int group_lanes = 0;              // 0: wave-per-chain kernel; else lanes per chain of the group kernel
     int last_form = 0;                // PDMP_FORM_* of the last launch (PDMP_FORM_LANE: provided the unit-speed flag stayed 0)
@@ -99,6 +145,9 @@ struct pdmp_engine {
     hipStream_t last_stream = nullptr;
     bool until_valid = false;         // d_state holds the hand-off states of a first chunk of `until_chains` chains (time-horizon variant)
     int64_t until_chains = 0;
+    uint64_t until_seed = 0;          // ... of the run (seed, first global chain id, lanes per chain) a resumed chunk must belong to
+    int64_t until_chain0 = 0;
+    int until_lanes = 0;
     bool launched = false;            // a launch has used the per-handle scheduler / hand-off / status buffers
     hipEvent_t order_ev = nullptr;    // orders launches of this handle that arrive on different streams (they share those buffers)
     std::vector<EventPair> pending;   // launches not yet folded into `timing`
@@ -776,7 +825,7 @@ int choose_group_lanes(const pdmp_config_t &c) {
 // the same launch would run with the Philox stream) for every sampler on the built-in separable / banana targets, else the
 // wave-per-chain kernel (grid sizes other than 10: Zig-Zag / BPS / Boomerang), else none.
 bool tape_on_group(const pdmp_engine *h) {
-    return h->group_lanes > 0 && h->cfg.target_id <= PDMP_T_BANANA && !(getenv("PDMP_TAPE_WAVE") && atoi(getenv("PDMP_TAPE_WAVE")) == 1);
+    return h->group_lanes > 0 && h->cfg.target_id <= PDMP_T_BANANA && !h->policy.tape_wave;
 }
 bool tape_on_wave(const pdmp_engine *h) {
     return h->cfg.sampler <= PDMP_BOOMERANG && h->cfg.target_id <= PDMP_T_BANANA && h->cfg.grid_size >= 2 && h->cfg.dim <= 4 * WAVE;
@@ -847,6 +896,7 @@ static int create_impl(const pdmp_config_t *cfg, const char *source, int32_t kin
     h->device = dev;
     h->cfg.target_params = nullptr;
     h->group_lanes = choose_group_lanes(c);
+    h->policy = policy_from_env();
 #define HIP_TRY_H(expr)                                                                            \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
@@ -909,7 +959,7 @@ int pdmp_set_group_lanes(pdmp_handle h, int32_t G) {
     if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
     const pdmp_config_t &c = h->cfg;
     const int def = choose_group_lanes(c);
-    if (G == 0 || G == def) { h->group_lanes = def; return PDMP_OK; }
+    if (G == 0 || G == def) { if (h->group_lanes != def) h->until_valid = false; h->group_lanes = def; return PDMP_OK; }
     if (def <= 0 || c.target_id == PDMP_T_GAUSS_DENSE)
         return fail(PDMP_ERR_UNSUPPORTED, "this configuration does not run on the group kernel with a free lane count");
     if (G < 1 || G > WAVE || (G & (G - 1)) != 0) return fail(PDMP_ERR_ARGUMENT, "lanes per chain must be a power of two in 1..64. Current value: %d", (int)G);
@@ -920,6 +970,14 @@ int pdmp_set_group_lanes(pdmp_handle h, int32_t G) {
     HIP_TRY(hipSetDevice(h->device));
     if (h->launched) HIP_TRY(hipStreamSynchronize(h->last_stream));
     h->group_lanes = G;
+    h->until_valid = false;           // (a first chunk's hand-off states have the layout of the lanes per chain they were written with)
+    return PDMP_OK;
+}
+
+int pdmp_reload_policy(pdmp_handle h) {
+    if (!h) return fail(PDMP_ERR_ARGUMENT, "null handle");
+    h->policy = policy_from_env();
+    h->until_valid = false;
     return PDMP_OK;
 }
 
@@ -929,6 +987,7 @@ int pdmp_clear_tape(pdmp_handle h) {
     HIP_TRY(hipStreamSynchronize(h->last_stream));
     for (int q = 0; q < 3; ++q) { if (h->d_tape[q]) (void)hipFree(h->d_tape[q]); h->d_tape[q] = nullptr; h->tape_n[q] = 0; }
     h->tape_chains = 0;
+    h->until_valid = false;
     return PDMP_OK;
 }
 
@@ -1045,12 +1104,18 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
         // hiding each other's latency) is fastest with instalments of three; a launch that leaves every wave alone on its SIMD pays each
         // extra pass of the state machine in full: all nine (12 500 chains: 4.29 -> 3.91 ms, scripts/budget_sweep.sh)
         gp.cell_budget = ((C + WAVE / h->group_lanes - 1) / (WAVE / h->group_lanes) <= 1024) ? GNG - 1 : 3;
-        if (const char *e = getenv("PDMP_CELL_BUDGET")) { const int b = atoi(e); if (b >= 1 && b <= GNG - 1) gp.cell_budget = b; }   // tuning / tests
+        gp.host_flags = (h->policy.no_lean ? 1 : 0) | (h->policy.debug_launch ? 2 : 0);
+        if (h->policy.cell_budget > 0) gp.cell_budget = h->policy.cell_budget;   // tuning / tests
         const int64_t nb = (C + WAVE / gp.G - 1) / (WAVE / gp.G);
         const size_t need_sched = (size_t)nb + 1, need_state = (size_t)((C + WAVE - 1) / WAVE * WAVE) * ((size_t)(2 * c.dim + 4) + (c.sampler == PDMP_STICKY ? (size_t)gp.G : 0));   // (whole batches of 64: lane_kernel.hpp; StickyZigZag: + the active masks of a chain's lanes)
         if (resuming && (!h->until_valid || !h->d_state || need_state > h->state_cap || C > h->until_chains))
             return fail(PDMP_ERR_ARGUMENT, "resume: this handle holds no hand-off state of a first chunk of at least %lld chains", (long long)C);
-        if (!resuming) { h->until_valid = until != nullptr; h->until_chains = C; }
+        // the hand-off buffer is per handle: a resumed chunk must continue THE run that left it there (another seed, chain range or
+        // lane layout would read another run's states, or states in another layout, without any error)
+        if (resuming && (seed != h->until_seed || chain_id_offset != h->until_chain0 || h->group_lanes != h->until_lanes))
+            return fail(PDMP_ERR_ARGUMENT, "resume: the hand-off state of this handle belongs to another run (seed %llu, chain_id_offset %lld, %d lanes per chain)",
+                        (unsigned long long)h->until_seed, (long long)h->until_chain0, h->until_lanes);
+        if (!resuming) { h->until_valid = until != nullptr; h->until_chains = C; h->until_seed = seed; h->until_chain0 = chain_id_offset; h->until_lanes = h->group_lanes; }
         if (need_sched > h->sched_cap) {
             if (h->d_sched) { HIP_TRY(hipStreamSynchronize(h->last_stream)); HIP_TRY(hipFree(h->d_sched)); h->d_sched = nullptr; h->sched_cap = 0; }
             HIP_TRY(hipMalloc(&h->d_sched, need_sched * sizeof(int32_t)));
@@ -1062,7 +1127,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
             h->state_cap = need_state;
         }
         HIP_TRY(hipMemsetAsync(h->d_sched, 0, need_sched * sizeof(int32_t), s));
-        if (const char *e = getenv("PDMP_FORCE_SEGMENTS")) gp.nseg = atoi(e);   // test hook, see group_schedule
+        if (h->policy.force_segments) gp.nseg = h->policy.force_segments;       // test hook, see group_schedule
         if (tgroup) gp.nseg = 1;                                                // the hand-off state does not carry tape positions
         gp.ctr = h->d_sched;
         gp.progress = h->d_sched + 1;
@@ -1072,7 +1137,8 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
     if (int rc = begin_timed(h, s, ev)) return rc;
     // Dense-precision Zig-Zag on many chains: grad-U of all chains as one fp64 GEMM per phase (dense_batched.hip);
     // small ensembles and PDMP_DENSE_MODE=matvec keep the bit-exact per-chain mat-vec kernel.
-    const char *dense_mode = getenv("PDMP_DENSE_MODE");       // "incr" | "gemm" | "matvec" (default: incr for >= 64 chains and d <= 1024, gemm beyond)
+    const LaunchPolicy &pol = h->policy;
+    const int dense_mode = pol.dense_mode;                    // 1 incr | 2 gemm | 3 matvec (0, default: incr for >= 64 chains and d <= 1024, gemm beyond)
     if (until && (taped || h->group_lanes <= 0 || c.target_id == PDMP_T_GAUSS_DENSE)) {
         h->pool.push_back(ev);
         return fail(PDMP_ERR_UNSUPPORTED, "the in-kernel time horizon runs on the group / lane kernels (grid_size = 10 or 0; not the dense-precision target; "
@@ -1080,18 +1146,18 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
     }
     const bool batched = c.target_id == PDMP_T_GAUSS_DENSE && c.sampler == PDMP_ZIGZAG && c.vectorized_bound && c.grid_size == GNG &&
                          c.deriv_mode == PDMP_DERIV_FORWARD && !taped && 2 * C < 0x7fffffffLL &&
-                         (dense_mode ? (strcmp(dense_mode, "gemm") == 0 || strcmp(dense_mode, "incr") == 0) : C >= 64);
+                         (dense_mode ? (dense_mode == 2 || dense_mode == 1) : C >= 64);
     if (batched) {
         char msg[256] = "";
         int rc = -5;
-        if (!(dense_mode && strcmp(dense_mode, "gemm") == 0))   // P x, P v kept current incrementally: O(d) per gradient (dense_batched.hip)
+        if (dense_mode != 2)                                   // P x, P v kept current incrementally: O(d) per gradient (dense_batched.hip)
             rc = pdmp_dense_incremental_run(h->device, c.dim, c.signed_bound, c.adaptive, c.tmax, c.max_iter_per_event, h->d_tparams, C, n_sk,
                                             chain_id_offset, seed, xinit, vinit, X, V, t, p.H, p.AR, p.EB, p.EV, p.RJ, p.HH,
-                                            h->d_status, stream, &h->dense_ws, &h->dense_ws_cap, msg, (int)sizeof msg);
+                                            h->d_status, stream, &h->dense_ws, &h->dense_ws_cap, pol.dense_resync, msg, (int)sizeof msg);
         if (rc == -5)                                           // d > 1024 (or forced): one GEMM per phase
             rc = pdmp_dense_batched_run(h->device, c.dim, c.signed_bound, c.adaptive, c.tmax, c.max_iter_per_event, h->d_tparams, C, n_sk,
                                         chain_id_offset, seed, xinit, vinit, X, V, t, p.H, p.AR, p.EB, p.EV, p.RJ, p.HH,
-                                        h->d_status, stream, msg, (int)sizeof msg);
+                                        h->d_status, stream, pol.dense_full_pv, msg, (int)sizeof msg);
         if (rc != 0) { h->pool.push_back(ev); return fail(rc == -4 ? PDMP_ERR_ITERCAP : PDMP_ERR_RUNTIME, "dense batched path: %s", msg); }
         h->last_form = PDMP_FORM_DENSE;
         return end_timed(h, s, ev);
@@ -1101,7 +1167,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
     // P [x | v'] of ALL chains as one fp64 GEMM per skeleton column (dense_batched.hip: dr_bps_kernel, dr_boom_kernel)
     const bool bps_batched = c.target_id == PDMP_T_GAUSS_DENSE && (c.sampler == PDMP_BPS || c.sampler == PDMP_BOOMERANG) && c.grid_size == GNG && c.dim <= 16 * WAVE &&
                              c.deriv_mode == PDMP_DERIV_FORWARD && !taped && !until && 2 * C < 0x7fffffffLL &&
-                             (c.sampler == PDMP_BOOMERANG || (dense_mode ? (strcmp(dense_mode, "gemm") == 0 || strcmp(dense_mode, "incr") == 0) : C >= 64));
+                             (c.sampler == PDMP_BOOMERANG || (dense_mode ? (dense_mode == 2 || dense_mode == 1) : C >= 64));
     if (c.target_id == PDMP_T_GAUSS_DENSE && c.sampler == PDMP_BOOMERANG && !bps_batched) {
         h->pool.push_back(ev);
         return fail(PDMP_ERR_UNSUPPORTED, "Boomerang on a dense precision runs in the batched form only (no tape replay, no time horizon)");
@@ -1110,7 +1176,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
         char msg[256] = "";
         const int rc = pdmp_dense_bps_run(h->device, c.sampler == PDMP_BOOMERANG ? 1 : 0, c.dim, c.signed_bound, c.adaptive, c.gaussian_velocity, c.tmax, c.refresh_rate, c.max_iter_per_event,
                                           h->d_tparams, C, n_sk, chain_id_offset, seed, xinit, vinit, X, V, t, p.H, p.AR, p.EB, p.EV, p.RJ, p.HH,
-                                          h->d_status, stream, &h->dense_ws, &h->dense_ws_cap, msg, (int)sizeof msg);
+                                          h->d_status, stream, &h->dense_ws, &h->dense_ws_cap, pol.dense_resync, msg, (int)sizeof msg);
         if (rc != 0) { h->pool.push_back(ev); return fail(PDMP_ERR_RUNTIME, "dense BPS path: %s", msg); }
         h->last_form = PDMP_FORM_DENSE;
         return end_timed(h, s, ev);
@@ -1123,16 +1189,13 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
     } else if (h->group_lanes > 0 && (!taped || tgroup)) {
         hipError_t e = hipErrorNotSupported;
         h->last_form = PDMP_FORM_GROUP_REG;
-        const char *reg = getenv("PDMP_REG");               // PDMP_REG=0: keep x, v in LDS tiles (test hook)
         // register form: the default bound flags only (grid_size = 10; Zig-Zag: vectorized signed bound) -- GroupChain::brent() etc.
         const bool reg_flags = c.grid_size == GNG && (c.sampler != PDMP_ZIGZAG || (c.vectorized_bound && c.signed_bound));
-        if (!(reg && atoi(reg) == 0) && reg_flags) {
+        if (pol.reg && reg_flags) {
             const bool fd = c.deriv_mode != 0;
             // Large Zig-Zag ensembles at d = 49..52 on the isotropic Gaussian / banana: one LANE per chain (lane_kernel.hpp), bit-identical
             // to the G = 4 group kernel.  It needs unit speeds: a check kernel raises a device flag otherwise, the lane kernel then
             // returns at once and the group kernel below (which returns at once while the flag is 0) does the launch's work.
-            const char *lane_env = getenv("PDMP_LANE");     // 0: never, 1: whenever the configuration allows (tests), unset: from the chain count
-            const char *lane_min = getenv("PDMP_LANE_MIN_CHAINS");
             // measured (one MI355X, n_sk = 1000): up to 65 536 chains the lane kernel takes 9.6 ms (d = 50 Gaussian) / 11.0 ms (banana) / 7.8 ms
             // (d = 32) whatever the count -- one wave per SIMD walks its 64 chains' events one after the other -- while the group kernel grows
             // with the count: it wins below ~41 000 chains at d = 50 (9.4 ms at 40 000, 12.8 ms at 45 000) and below ~48 000 at d = 32
@@ -1140,19 +1203,18 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
             // d = 53 .. 104 (the group kernel's G = 8): a PAIR of lanes per chain, 32 chains per wave, bit-identical to the G = 8 group kernel
             const bool lane2 = gp.G == 8;
             // (the pair kernel, d = 100, n_sk = 1000: 10.6 ms up to 32 768 chains -- one wave per SIMD -- against 9.5 ms of the group kernel at 25 000, 37.9 ms at 10^5)
-            const int64_t lane_from = lane_min ? atoll(lane_min) : (lane2 ? 28000 : (c.dim >= 45 ? 37000 : 40000));   // (d = 32, 44 000 chains: one lane 6.42 ms, pair 7.34, group kernel 7.43; 30 000: pair 4.99, group 5.92)
+            const int64_t lane_from = pol.lane_min_chains >= 0 ? pol.lane_min_chains : pol.lane_from_default(lane2, c.dim);   // (d = 32, 44 000 chains: one lane 6.42 ms, pair 7.34, group kernel 7.43; 30 000: pair 4.99, group 5.92)
             // d = 25 .. 52 again, launches between ~a fifth and ~two fifths of the machine (the 4-GPU shard of the headline ensemble): a pair of
             // lanes per chain with two coordinates of a slot each -- GROUP(4) still -- so that 25 000 chains are 782 waves instead of 391
-            const char *pair_min = getenv("PDMP_LANE_PAIR_MIN_CHAINS");
             // measured (d = 50 Gaussian, n_sk = 1000; group kernel / one lane / pair): 12 500 chains 4.31 / 8.36 / 5.36 ms, 18 000 6.58 / 8.41 / 5.39,
             // 25 000 8.42 / 8.43 / 5.45, 32 000 10.27 / 8.47 / 7.02, 40 000 10.99 / 8.48 / 9.60, 50 000 11.53 / 8.57 / 11.50 (profiles/r3/r3q1_*)
-            const int64_t pair_from = pair_min ? atoll(pair_min) : 16385;   // (up to 16 384 chains = 1 024 waves of the group kernel, one per SIMD: 3.9 - 4.0 ms flat with the whole bound per pass; 17 000 chains: 6.1 ms against the pair form's 5.4)
+            const int64_t pair_from = pol.pair_min_chains;   // (up to 16 384 chains = 1 024 waves of the group kernel, one per SIMD: 3.9 - 4.0 ms flat with the whole bound per pass; 17 000 chains: 6.1 ms against the pair form's 5.4)
             const bool lane_ok = c.sampler == PDMP_ZIGZAG && !fd && (c.target_id == PDMP_T_GAUSS_ISO || c.target_id == PDMP_T_BANANA) &&
                                  ((gp.G == 4 && c.dim >= 25 && c.dim <= 52) || (lane2 && c.dim >= 53 && c.dim <= 104 && !tgroup)) &&
                                  (int64_t)WAVE * n_sk * c.dim * 8 < (lane2 ? 2 : 1) * 0x7fffffffLL;   // (a batch's window of X: 31-bit byte offsets; 64 chains, or 32 of a pair form -- the quad pair is held to the window of 64 so that a resumed chunk may be of either size)
             // (round 3: no alignment preconditions any more -- a chain's rows may start anywhere inside a 64-byte line, lane_kernel.hpp: open_window)
             // a resumed chunk continues in the form whose state layout its first chunk left behind (until->form), whatever its size
-            const int lane_mode = lane_env ? atoi(lane_env) : -1;      // (2: the pair form at d <= 52 too, whatever the count -- tests)
+            const int lane_mode = pol.lane_mode;                       // (2: the pair form at d <= 52 too, whatever the count -- tests)
             const bool pairq = !lane2 && !tgroup && (resuming ? until->form == PDMP_FORM_LANE_PAIR
                                                               : (lane_mode == 2 || (lane_mode < 0 && C >= pair_from && C < lane_from)));
             const bool lane_wanted = resuming ? ((until->form == PDMP_FORM_LANE || until->form == PDMP_FORM_LANE_PAIR) && c.sampler == PDMP_ZIGZAG)   // (BPS: its own lane form, below)
@@ -1165,10 +1227,9 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
                 int32_t *flag = h->d_status + 4;
                 hipError_t le = hipMemsetAsync(flag, 0, sizeof(int32_t), s);
                 if (le == hipSuccess && !resuming) le = launch_lane_check(vinit, C * (int64_t)c.dim, flag, s);   // (a resumed chunk: the first chunk's check stands)
-                int rounds = 24;                             // work units per resident wave (measured: 8 -> 24: 18.2 -> 16.8 ms at config 2)
-                if (const char *r = getenv("PDMP_LANE_ROUNDS")) { const int v = atoi(r); if (v >= 1 && v <= 64) rounds = v; }
+                const int rounds = pol.lane_rounds;          // work units per resident wave
                 GroupParams lp = gp;
-                if (!getenv("PDMP_CELL_BUDGET")) lp.cell_budget = 5;   // a pass of 64 chains costs ~2 000 instructions, a cell 240: wait for more cells
+                if (pol.cell_budget == 0) lp.cell_budget = 5;   // a pass of 64 chains costs ~2 000 instructions, a cell 240: wait for more cells
                 if (tgroup) lp.nseg = 1;                     // (lane_schedule: a forced segment count)
                 if (le == hipSuccess) le = tgroup ? launch_lane_zigzag_tape(c.target_id, lp, flag, rounds, s)   // (d = 49 .. 52; else the group kernel below replays)
                                       : pairq ? launch_lane2q_zigzag(c.target_id, lp, flag, rounds, s)
@@ -1182,34 +1243,12 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
                     h->last_form = (lane2 || pairq) ? PDMP_FORM_LANE_PAIR : PDMP_FORM_LANE;
                 } else (void)hipGetLastError();
             }
-            // BPS at d = 27 .. 52 on the isotropic Gaussian / banana, forward-mode slopes, with one LANE per chain (lane_bps_kernel.hpp;
-            // bit-identical to the G = 4 group kernel).  MEASURED SLOWER than the group kernel (config 3: 58.7 ms against 40.3 ms; 131
-            // instead of 194 VALU instructions per event, but VALU busy 37 % instead of 83 %: one wave per SIMD cannot hide the long
-            // dependent chains of the per-chain scalar work -- log, divisions, Box-Muller) and therefore OFF unless PDMP_LANE_BPS=1
-            // asks for it (tests, profiles).  Its hand-off state has its own layout: a resumed chunk of the time-horizon variant stays in it.
-            bool lane_bps_ran = false;
-            {
-                const char *bps_env = getenv("PDMP_LANE_BPS");
-                const bool bps_ok = c.sampler == PDMP_BPS && !fd && !tgroup && (c.target_id == PDMP_T_GAUSS_ISO || c.target_id == PDMP_T_BANANA) &&
-                                    c.dim >= 27 && c.dim <= 52 && gp.G == 4;
-                const bool bps_wanted = resuming ? until->form == PDMP_FORM_LANE : (bps_env && atoi(bps_env) == 1);
-                if (bps_ok && bps_wanted) {
-                    int rounds = 24;
-                    if (const char *r = getenv("PDMP_LANE_ROUNDS")) { const int v = atoi(r); if (v >= 1 && v <= 64) rounds = v; }
-                    hipError_t le = c.dim > 48 ? launch_lane_bps_13(c.target_id, gp, rounds, s)
-                                  : c.dim > 36 ? launch_lane_bps_b(c.target_id, gp, rounds, s) : launch_lane_bps_a(c.target_id, gp, rounds, s);
-                    if (le == hipSuccess) { lane_bps_ran = true; h->last_form = PDMP_FORM_LANE; e = hipSuccess; }
-                    else (void)hipGetLastError();
-                }
-            }
-            const char *ex = getenv("PDMP_REG_EXACT");      // PDMP_REG_EXACT=0: the KREG-slot kernels with per-slot skips (test hook)
-            if (lane_bps_ran) {}                            // (the launch is done)
-            else if (tgroup)                                     // a replay: the 13-slot register kernels with the tapes as random source
+            if (tgroup)                                     // a replay: the 13-slot register kernels with the tapes as random source
                 e = c.sampler == PDMP_ZIGZAG    ? (fd ? hipErrorNotSupported : launch_group_reg_tape_zigzag(c.target_id, fd, gp, s))
                   : c.sampler == PDMP_BPS       ? launch_group_reg_tape_bps(c.target_id, fd, gp, s)
                   : c.sampler == PDMP_BOOMERANG ? launch_group_reg_tape_boomerang(c.target_id, fd, gp, s)
                                                 : hipErrorNotSupported;
-            else if (!(ex && atoi(ex) == 0))                // a kernel of exactly K slots where one exists
+            else if (pol.reg_exact)                         // a kernel of exactly K slots where one exists
                 e = c.sampler == PDMP_BOOMERANG    ? (fd ? launch_group_reg_boomerang_exact_fd(c.target_id, gp, s)
                                                          : launch_group_reg_boomerang_exact(c.target_id, gp, s))
                   : fd                             ? hipErrorNotSupported
@@ -1420,7 +1459,7 @@ static int from_skeleton_launch(pdmp_handle h, int method, int64_t C, int64_t n_
     EventPair ev;
     if (int rc = begin_timed(h, s, ev)) return rc;
     const bool flat = h->cfg.sampler != PDMP_SUZZ && h->cfg.sampler != PDMP_RHMC && (2 * (int64_t)h->cfg.dim + 1) * WAVE < (1ll << 31) / (2 * (int64_t)h->cfg.dim + 1) &&
-                      !getenv("PDMP_FROM_SKELETON_ROWS");            // (env: the row-per-iteration kernel, for A/B runs)
+                      !h->policy.from_skeleton_rows;                 // (policy: the row-per-iteration kernel, for A/B runs)
     if (flat && h->cfg.sampler == PDMP_BOOMERANG)
         hipLaunchKernelGGL(from_skeleton_flat_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, dt, (int)discard_vt, out,
                            is_active, ia_mode, (int)(method == 2), n_prefix, lens, counts);

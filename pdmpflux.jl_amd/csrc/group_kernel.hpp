@@ -51,6 +51,7 @@ struct GroupParams {
     int32_t *progress;    // progress[b] = segments of batch b completed (zeroed before the launch)
     double *state;        // per chain: x[d], v[d], t, horizon, ar, rng counter  (stride 2d+4 doubles)
     const int32_t *only_if;   // null, or a device flag: the register-form kernels return at once while it is 0 (lane_kernel.hpp ran instead)
+    int32_t host_flags;       // read by the host-side launchers only (the handle's launch policy): 1 no lean instantiation, 2 print the launch geometry
 };
 
 // ---------------------------------------------------------------- group-of-lanes primitives (G uniform)
@@ -2090,7 +2091,7 @@ hipError_t launch_group_impl(const GroupParams &gp_in, hipStream_t stream) {
             if constexpr (RF::template full<GC>() && KC == KREG) {             // the throughput kernels of the BASELINE shapes (d = 50 / G = 4, d = 100 / G = 8, ...)
                 const SkelParams &q = gp.s;
                 const bool plain = !(q.H || q.AR || q.EB || q.RJ || q.HH || q.EV || q.IA || q.count || q.chain_map || q.resume) && !(q.t_stop < __builtin_huge_val());
-                if (gp.K == KC && plain && !getenv("PDMP_NO_LEAN")) kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, true, true>;
+                if (gp.K == KC && plain && !(gp.host_flags & 1)) kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, true, true>;
             }
         }
     } else if constexpr (TAPE) kernel = group_kernel_tape<SAMPLER, TARGET, FD>;

@@ -978,7 +978,7 @@ inline hipError_t launch_lane(const GroupParams &gp_in, const int32_t *flag, int
     lane_schedule(gp.nb, slots, gp.s.n_sk, gp.nseg, rounds, gp.nseg, gp.seg_len);
     int64_t blocks = (gp.nb * gp.nseg + wpb - 1) / wpb;
     if (blocks > (int64_t)cus * per_cu) blocks = (int64_t)cus * per_cu;
-    if (getenv("PDMP_DEBUG_LAUNCH")) fprintf(stderr, "lane launch GL=%d PG=%d LK=%d: blocks per CU %d, CUs %d, LDS %zu B / block, batches %lld x segments %d -> %lld blocks\n", GL, PG, LK, per_cu, cus, lds, (long long)gp.nb, (int)gp.nseg, (long long)blocks);
+    if (gp.host_flags & 2) fprintf(stderr, "lane launch GL=%d PG=%d LK=%d: blocks per CU %d, CUs %d, LDS %zu B / block, batches %lld x segments %d -> %lld blocks\n", GL, PG, LK, per_cu, cus, lds, (long long)gp.nb, (int)gp.nseg, (long long)blocks);
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(WAVE * wpb), lds, stream, gp, flag);
     return hipGetLastError();
 }

@@ -84,6 +84,7 @@ struct pdmp_multi {
     std::vector<size_t> init_cap;
     std::vector<rcclComm_t> comm;                // empty until the first gathering call with n > 1
     double kernel_ms = 0.0, exchange_ms = 0.0;
+    bool force_rccl = false;                     // PDMP_MULTI_FORCE_RCCL at pdmp_multi_create (test hook: the collective with one device too)
 };
 
 extern "C" {
@@ -121,6 +122,7 @@ int pdmp_multi_create(const pdmp_config_t *cfg, int32_t n_devices, const int32_t
         return failf(PDMP_ERR_ARGUMENT, "n_devices must be in 1..%s visible devices. Current value: %s", b, a);
     }
     pdmp_multi *m = new pdmp_multi();
+    m->force_rccl = getenv("PDMP_MULTI_FORCE_RCCL") != nullptr;     // (policy of the handle: read once, here)
     for (int r = 0; r < n_devices; ++r) {
         const int d = devices ? devices[r] : r;
         for (int q = 0; q < r; ++q) if (m->dev[q] == d) { pdmp_multi_destroy(m); return failf(PDMP_ERR_ARGUMENT, "duplicate device in the device list"); }
@@ -170,7 +172,7 @@ int pdmp_multi_sample_skeleton(pdmp_multi_handle m, int64_t C, int64_t n_sk, int
     for (int r = 0; r < n; ++r) if (G > 0) { if (int rc = pdmp_set_group_lanes(m->h[r], G)) return rc; }
     // (PDMP_MULTI_FORCE_RCCL: test hook -- run the collective with one device too, which exercises the run-time binding of librccl,
     // the communicator and the grouped in-place all-gather on a one-GPU box)
-    const bool exchange = gather != 0 && (n > 1 || getenv("PDMP_MULTI_FORCE_RCCL") != nullptr);
+    const bool exchange = gather != 0 && (n > 1 || m->force_rccl);
     if (exchange && m->comm.empty()) {
         if (int rc = load_rccl()) return rc;
         m->comm.assign(n, nullptr);

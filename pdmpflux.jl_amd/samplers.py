@@ -116,6 +116,12 @@ class AbstractPDMP:
         the sums over coordinates: compare with a checker in ``ARITH_GROUP(G)`` of the same G."""
         _lib.check(_lib.lib().pdmp_set_group_lanes(self.handle(), int(G)))
 
+    def reload_policy(self) -> None:
+        """Re-read the PDMP_* environment overrides of the launch policy (pdmp_reload_policy): the policy of a handle is fixed when the
+        handle is created; a caller that changes the environment afterwards (tests, tuning scripts) asks for the re-read."""
+        if self._handle is not None:
+            _lib.check(_lib.lib().pdmp_reload_policy(self._handle))
+
     def set_tape(self, exp_tape, uni_tape, nrm_tape):
         """Replay pre-recorded Exp(1) / U(0,1) / N(0,1) variates (arrays of shape ``(C, n_kind)``, row c = chain c,
         each kind in consumption order) instead of the Philox stream (pdmp_set_tape)."""

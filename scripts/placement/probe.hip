@@ -222,6 +222,70 @@ int main(int argc, char **argv)
         }
         return 0;
     }
+    if (mode == "contig") {
+        // hipExtMallocWithFlags(hipDeviceMallocContiguous): does the driver hand out physically contiguous arrays of this size, and are they fast?
+        const int R = argc > 2 ? atoi(argv[2]) : 3;
+        for (int r = 0; r < R; ++r) {
+            double *X = nullptr, *V = nullptr, *t = nullptr;
+            hipError_t ex = hipExtMallocWithFlags((void **)&X, XB, hipDeviceMallocContiguous);
+            hipError_t ev = ex == hipSuccess ? hipExtMallocWithFlags((void **)&V, XB, hipDeviceMallocContiguous) : ex;
+            if (ex != hipSuccess || ev != hipSuccess) {
+                (void)hipGetLastError();
+                printf("{\"probe\":\"contig\",\"rep\":%d,\"error\":\"%s\"}\n", r, hipGetErrorString(ex != hipSuccess ? ex : ev));
+                if (X) (void)hipFree(X);
+                break;
+            }
+            HIPCHECK(hipMalloc(&t, TB));
+            std::string all; float e = run_engine(X, V, t, &all);
+            float s2 = run_synth(X, V, NSK * D, C, int(NSK * D / 8), 1024, 2, 1);
+            printf("{\"probe\":\"contig\",\"rep\":%d,\"engine_ms\":%.2f,\"engine_all\":[%s],\"synth2_ms\":%.2f}\n", r, e, all.c_str(), s2);
+            fflush(stdout);
+            HIPCHECK(hipFree(X)); HIPCHECK(hipFree(V)); HIPCHECK(hipFree(t));
+        }
+        return 0;
+    }
+    if (mode == "chunks") {
+        // Arrays from 1-GiB physical chunks: is a slow placement slow in particular chunks?  Per pool: the engine launch, the synthetic
+        // writer on every (X chunk i, V chunk i) pair alone, then the slowest pairs exchanged for spare chunks and the launch again.
+        const size_t S = size_t(argc > 2 ? atol(argv[2]) : 1024) << 20;
+        const int R = argc > 3 ? atoi(argv[3]) : 3, spare = argc > 4 ? atoi(argv[4]) : 16;
+        Mapped X, V, T;
+        X.reserve(XB, S); V.reserve(XB, S); T.reserve(TB, S);
+        const int nx = int(X.n), nt_ = int(T.n), npool = 2 * nx + nt_ + spare;
+        const int64_t chains_per_chunk = int64_t(S / (NSK * D * 8));
+        for (int r = 0; r < R; ++r) {
+            Pool pool; pool.create(S, npool);
+            std::vector<int> ix(nx), iv(nx), it(nt_);
+            for (int i = 0; i < nx; ++i) { ix[i] = i; iv[i] = nx + i; }
+            for (int i = 0; i < nt_; ++i) it[i] = 2 * nx + i;
+            X.map(pool, ix); V.map(pool, iv); T.map(pool, it);
+            std::string all; float e = run_engine((double *)X.base, (double *)V.base, (double *)T.base, &all);
+            std::vector<float> per(nx);
+            std::string pers;
+            for (int i = 0; i < nx; ++i) {
+                // chains whose rows lie wholly inside chunk i
+                const int64_t c0 = (int64_t(i) * int64_t(S) + NSK * D * 8 - 1) / (NSK * D * 8), c1 = std::min<int64_t>(C, (int64_t(i + 1) * int64_t(S)) / (NSK * D * 8));
+                per[i] = run_synth((double *)X.base + c0 * NSK * D, (double *)V.base + c0 * NSK * D, NSK * D, c1 - c0, int(NSK * D / 8), 1024, 2, 1, 2);
+                char buf[32]; snprintf(buf, sizeof buf, "%s%.3f", i ? "," : "", per[i]); pers += buf;
+            }
+            printf("{\"probe\":\"chunks\",\"chunk_mib\":%zu,\"pool\":%d,\"engine_ms\":%.2f,\"engine_all\":[%s],\"chains_per_chunk\":%lld,\"pair_ms\":[%s]}\n",
+                   S >> 20, r, e, all.c_str(), (long long)chains_per_chunk, pers.c_str());
+            fflush(stdout);
+            // exchange the slowest pairs for spare chunks (both members of the pair), up to spare/2 pairs
+            std::vector<int> order(nx); for (int i = 0; i < nx; ++i) order[i] = i;
+            std::sort(order.begin(), order.end(), [&](int a, int b) { return per[a] > per[b]; });
+            X.unmap(); V.unmap();
+            int next = 2 * nx + nt_;
+            for (int k = 0; k < spare / 2 && k < nx; ++k) { ix[order[k]] = next++; iv[order[k]] = next++; }
+            X.map(pool, ix); V.map(pool, iv);
+            std::string all2; float e2 = run_engine((double *)X.base, (double *)V.base, (double *)T.base, &all2);
+            printf("{\"probe\":\"chunks_swapped\",\"pool\":%d,\"pairs_swapped\":%d,\"engine_ms\":%.2f,\"engine_all\":[%s]}\n", r, spare / 2, e2, all2.c_str());
+            fflush(stdout);
+            X.unmap(); V.unmap(); T.unmap();
+            pool.release();
+        }
+        return 0;
+    }
     // ---- vmm / synth
     const size_t S = size_t(argc > 2 ? atol(argv[2]) : 2048) << 20;
     const int R = argc > 3 ? atoi(argv[3]) : 3, P = argc > 4 ? atoi(argv[4]) : 3;
