@@ -58,6 +58,13 @@ def parse():
                     help="src_banana: U_banana given as source, differentiated by forward mode on the GPU (pdmp_create_from_source)")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time; 0 disables it")
+    ap.add_argument("--alloc", default="auto", choices=["auto", "chunked", "hipmalloc"],
+                    help="allocator of the output arrays: chunked = ensemble.alloc_outputs (pdmp_device_alloc: independent 1-GiB physical chunks, "
+                         "DESIGN.md 6), hipmalloc = torch.empty; auto: chunked at N = 1, hipmalloc for N > 1 (the exchange buffers go through RCCL)")
+    ap.add_argument("--sets", type=int, default=0, help="fresh allocations of X, V, t the timed steps rotate over (0: as many as fit, at most 3)")
+    ap.add_argument("--placement-survey", default="auto", choices=["auto", "off"],
+                    help="auto (N = 1, >= 5 steps): before the timed region, time two more fresh chunked allocations and two hipMalloc'ed ones "
+                         "(reported in config.placement_ms, never in `value`)")
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"],
                     help="auto (N = 1): measure roofline.traffic live -- child runs of this command (one launch each) under rocprofv3 --pmc "
                          "WRITE_SIZE, FETCH_SIZE and the VALU counters, before this process touches the GPU; off: quote profiles/traffic.json")
@@ -136,20 +143,19 @@ def make_sampler(P, a):
     return getattr(P, a.sampler)(a.dim, tgt, **kw)
 
 
-def make_inputs(torch, a, dev):
-    """The WHOLE ensemble's initial states on every rank (16 d bytes per chain; same generator seed everywhere)."""
-    g = torch.Generator(device=dev)
-    g.manual_seed(a.seed * 1000)
-    x = torch.randn((a.chains, a.dim), dtype=torch.float64, device=dev, generator=g)
-    if a.target in ("banana", "src_banana"):
-        x = 1.0 + 0.1 * x
-    if a.sampler.startswith(("ZigZag", "SpeedUp")):
-        v = torch.randint(0, 2, (a.chains, a.dim), device=dev, generator=g).to(torch.float64) * 2 - 1
-    else:
-        v = torch.randn((a.chains, a.dim), dtype=torch.float64, device=dev, generator=g)
-        if a.sampler.startswith(("BPS", "ForwardECMC")):
-            v = v / v.norm(dim=1, keepdim=True)
-    return x.contiguous(), v.contiguous()
+def init_kind(a):
+    """(x_mean, x_scale, v_kind) of the synthetic initial states, BASELINE.md section 3: stationary-ish starts x ~ N(0, I) (banana:
+    ones + 0.1 N(0, I)); v: +-1 coordinates for the Zig-Zag family, uniform on the unit sphere for BPS / ForwardECMC, N(0, I) otherwise."""
+    xm, xs = (1.0, 0.1) if a.target in ("banana", "src_banana") else (0.0, 1.0)
+    vk = 0 if a.sampler.startswith(("ZigZag", "SpeedUp")) else (2 if a.sampler.startswith(("BPS", "ForwardECMC")) else 1)
+    return xm, xs, vk
+
+
+def make_inputs(ensemble, sampler, a, dev):
+    """The WHOLE ensemble's initial states on every rank (16 d bytes per chain), generated on the device from stream 1 of each chain's
+    Philox key (seed, c) -- BASELINE.md section 3; the chains' own draws come from stream 0 of the same key (pdmp_init_states_device)."""
+    xm, xs, vk = init_kind(a)
+    return ensemble.init_states_device(sampler, a.chains, seed=a.seed, x_mean=xm, x_scale=xs, v_kind=vk, device=dev)
 
 
 def cpu_baseline(a, sampler):
@@ -187,7 +193,6 @@ def cpu_baseline(a, sampler):
                    target_id=tid, arith=O.ARITH_REFERENCE, mix_p=getattr(sampler, "mix_p", 0.5), ran_p=getattr(sampler, "ran_p", False),
                    switch=getattr(sampler, "switch", True), positive=getattr(sampler, "positive", True),
                    step_size=getattr(sampler, "step_size", 0.05), phi=getattr(sampler, "phi", 1.5707963267948966))
-    rs = np.random.default_rng(a.seed)
     n_sk = min(a.n_sk, 1000)
 
     bufs = {}
@@ -196,14 +201,8 @@ def cpu_baseline(a, sampler):
         if not bufs or bufs["t"].shape[0] < C:       # output buffers allocated and touched once, reused by every timed run
             bufs.update(X=np.zeros((C, n_sk, a.dim)), V=np.zeros((C, n_sk, a.dim)), t=np.zeros((C, n_sk)))
         out = {k: bufs[k][:C] for k in ("X", "V", "t")}
-        x = rs.normal(size=(C, a.dim))
-        if a.target in ("banana", "src_banana"):
-            x = 1.0 + 0.1 * x
-        if a.sampler.startswith(("ZigZag", "SpeedUp")):
-            v = rs.choice([-1.0, 1.0], size=(C, a.dim))
-        else:
-            v = rs.normal(size=(C, a.dim))
-            v /= np.linalg.norm(v, axis=1, keepdims=True)
+        xm, xs, vk = init_kind(a)                    # the same initial states the GPU run starts chains off .. off + C from (stream 1)
+        x, v = O.init_states(a.seed, C, a.dim, chain_id_offset=off, x_mean=xm, x_scale=xs, v_kind=vk)
         t0 = time.perf_counter()
         O.sample_skeleton(cfg, n_sk, x, v, a.seed, chain_id_offset=off, diagnostics=False, n_threads=cores, out=out)
         return time.perf_counter() - t0
@@ -289,27 +288,29 @@ def main_multi(a):
     n = a.gpus
     assert torch.cuda.is_available() and torch.cuda.device_count() >= n, f"--driver multi --gpus {n}: {torch.cuda.device_count()} device(s) visible"
     sampler = make_sampler(P, a)
-    x, v = make_inputs(torch, a, torch.device("cuda", 0))
-    xh, vh = x.cpu().numpy(), v.cpu().numpy()                  # the entry takes host inits (a Julia host's arrays) and stages each shard
     C_total, d, n_sk = a.chains, a.dim, a.n_sk
     gather = 1 if (a.gather == "skeleton" and n > 1) else 0
     L = _lib.lib()
     cfg = sampler._config()
     m = C.c_void_p()
     _lib.check(L.pdmp_multi_create(C.byref(cfg), n, None, C.byref(m)))
-    bufs = []
+    bufs, inits = [], []
     for r in range(n):
         lo, hi = ensemble.shard_range(C_total, r, n)
         rows = C_total if gather else hi - lo
         dev = torch.device("cuda", r)
         bufs.append({"X": torch.empty((rows, n_sk, d), dtype=torch.float64, device=dev), "V": torch.empty((rows, n_sk, d), dtype=torch.float64, device=dev),
                      "t": torch.empty((rows, n_sk), dtype=torch.float64, device=dev)})
+        inits.append((torch.empty((max(hi - lo, 1), d), dtype=torch.float64, device=dev), torch.empty((max(hi - lo, 1), d), dtype=torch.float64, device=dev)))
     arr = lambda k: (C.c_void_p * n)(*[b[k].data_ptr() for b in bufs])
     AX, AV, At = arr("X"), arr("V"), arr("t")
+    IX, IV = (C.c_void_p * n)(*[q[0].data_ptr() for q in inits]), (C.c_void_p * n)(*[q[1].data_ptr() for q in inits])
+    # the shards' initial states generated ON their devices (stream 1 of each chain's key): nothing crosses PCIe per step
+    xm, xs, vk = init_kind(a)
+    _lib.check(L.pdmp_multi_init_states(m, C_total, 0, C.c_uint64(a.seed), xm, xs, vk, IX, IV))
 
     def step(i):
-        _lib.check(L.pdmp_multi_sample_skeleton(m, C_total, n_sk, 0, C.c_void_p(xh.ctypes.data), C.c_void_p(vh.ctypes.data), C.c_uint64(a.seed + i),
-                                                gather, AX, AV, At))
+        _lib.check(L.pdmp_multi_sample_skeleton_device(m, C_total, n_sk, 0, IX, IV, C.c_uint64(a.seed + i), gather, AX, AV, At))
     for i in range(a.warmup):
         step(i)
     k_ms, x_ms = [], []
@@ -328,7 +329,7 @@ def main_multi(a):
     events_step = C_total * (n_sk - 1)
     bytes_per_event = 8 * (2 * d + 1)
     lo0, hi0 = ensemble.shard_range(C_total, 0, n)
-    kernel_ms = sum(k_ms) / len(k_ms)                           # staging of the shard's inits (host -> device) + the shard kernel, max over devices
+    kernel_ms = sum(k_ms) / len(k_ms)                           # the shard kernel, max over devices
     achieved = (hi0 - lo0) * (n_sk - 1) * bytes_per_event / (kernel_ms * 1e-3) / 1e9
     xbytes = (C_total - (hi0 - lo0)) * n_sk * bytes_per_event if gather else 0
     res = {"metric": metric_label(a, sampler, C_total), "value": events_step * a.steps / elapsed, "unit": "events/s", "n_gpus": n, "steps": a.steps,
@@ -338,10 +339,10 @@ def main_multi(a):
                       "chains": C_total, "chains_rank0": hi0 - lo0, "n_sk": n_sk, "dim": d, "events_per_step": events_step,
                       "exchange": "none" if not gather else f"grouped in-place ncclAllGather of X, V, t inside the library: {xbytes} bytes received per GPU per step",
                       "exchange_bytes_per_gpu": xbytes, "kernel_ms_max_over_devices": kernel_ms, "exchange_ms_max_over_devices": sum(x_ms) / len(x_ms),
-                      "host_inits": "xinit / vinit are host arrays, staged per step (16 d bytes per chain)"},
+                      "inits": "device-resident shards from pdmp_multi_init_states (pdmp_multi_sample_skeleton_device: no PCIe staging per step)"},
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                         "kernel_ms": kernel_ms, "bytes_per_event": bytes_per_event,
-                        "note": "kernel_ms here includes the host -> device staging of the shard's initial states (hipEvents around both)"}}
+                        "note": "kernel_ms = launch begin to kernel end on the slowest device (hipEvents on each device's stream)"}}
     print(json.dumps(res), flush=True)
 
 
@@ -379,7 +380,7 @@ def main():
 
     sampler = make_sampler(P, a)
     sampler.device = local
-    x, v = make_inputs(torch, a, dev)
+    x, v = make_inputs(ensemble, sampler, a, dev)
     C_total, d, n_sk = a.chains, a.dim, a.n_sk
     lo, hi = ensemble.shard_range(C_total, rank, world)
     C_max = ensemble.shard_range(C_total, 0, world)[1]                 # the largest shard (rank 0)
@@ -391,13 +392,21 @@ def main():
     elif a.lanes != "default":
         sampler.set_group_lanes(int(a.lanes))
     gather = a.gather if world > 1 else "none"
-    # full-size buffers, allocated once: the shard is sampled straight into its chain range and gathered in place
+    # Output buffers.  N = 1: the timed steps ROTATE over several fresh allocations of X, V, t (as many as fit, at most 3) -- a launch's
+    # speed depends on where its arrays lie, so `value` is taken over all of them, none picked -- from the product's own
+    # allocator for large outputs (ensemble.alloc_outputs: independent 1-GiB physical chunks).  N > 1: ONE full-size set per rank from
+    # torch's allocator: the shard is sampled straight into its chain range and gathered in place (the buffers go through RCCL).
     rows = C_total if gather == "skeleton" else hi - lo
-    full = {"X": torch.empty((rows, n_sk, d), dtype=torch.float64, device=dev),
-            "V": torch.empty((rows, n_sk, d), dtype=torch.float64, device=dev),
-            "t": torch.empty((rows, n_sk), dtype=torch.float64, device=dev)}
+    set_bytes = 8 * rows * n_sk * (2 * d + 1)
+    allocator = a.alloc if a.alloc != "auto" else ("chunked" if world == 1 else "hipmalloc")
 
-    def step(i):
+    def alloc_set(kind):
+        if kind == "chunked":
+            return ensemble.alloc_outputs(rows, n_sk, d, device=dev, chunked=True)
+        return {"X": torch.empty((rows, n_sk, d), dtype=torch.float64, device=dev), "V": torch.empty((rows, n_sk, d), dtype=torch.float64, device=dev),
+                "t": torch.empty((rows, n_sk), dtype=torch.float64, device=dev)}
+
+    def run_step(i, full):
         if world == 1:
             ensemble.sample_skeleton_device(sampler, n_sk, x, v, seed=a.seed + i, out=full, check=False)
         else:       # rank r samples chains [lo_r, hi_r); gather="skeleton": then one all-gather each for X, V, t
@@ -410,15 +419,53 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_launches(full, n, seed0):                          # hipEvent-timed launches on torch's current stream (the engine's launch stream)
+        evs = []
+        for i in range(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); run_step(seed0 + i, full); e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        return [e0.elapsed_time(e1) for e0, e1 in evs]
+
+    # placement survey (untimed part of the run, N = 1): fresh allocations from both allocators, one warm + two timed launches each
+    survey = []
+    if a.placement_survey == "auto" and world == 1 and a.steps >= 5 and set_bytes >= (1 << 30):
+        for kind in ("chunked", "hipmalloc", "chunked", "hipmalloc"):
+            full = alloc_set(kind)
+            ms = timed_launches(full, 3, 1000 + 10 * len(survey))[1:]
+            survey.append({"allocator": kind, "in_timed_region": False, "launches": len(ms), "kernel_ms": [round(m, 3) for m in ms]})
+            del full
+            torch.cuda.empty_cache()
+    free_b = torch.cuda.mem_get_info()[0]
+    n_sets = a.sets if a.sets > 0 else (1 if world > 1 else max(1, min(3, int(0.9 * free_b // max(set_bytes, 1)))))
+    sets = [alloc_set(allocator) for _ in range(n_sets)]
+    full = sets[0]
+
+    def step(i):
+        run_step(i, sets[i % n_sets])
+
     for i in range(a.warmup):
         step(i)
     fence()
     ensemble.kernel_timing(sampler, reset=True)
+    step_ev = []
     t0 = time.perf_counter()
     for i in range(a.steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         step(a.warmup + i)
+        e1.record()
+        step_ev.append((e0, e1))
     fence()
     elapsed = time.perf_counter() - t0
+    step_ms = [e0.elapsed_time(e1) for e0, e1 in step_ev]        # per step, on the launch stream: which allocation set was slow, if any
+    placement = []
+    for k in range(n_sets):
+        mine = [m for i, m in enumerate(step_ms) if (a.warmup + i) % n_sets == k]
+        if mine:
+            placement.append({"allocator": allocator, "in_timed_region": True, "launches": len(mine), "kernel_ms": [round(m, 3) for m in mine]})
+    placement += survey
     from pdmpflux.jl_amd import _lib
     _lib.check(_lib.lib().pdmp_check_status(sampler.handle(), None))
     tm = ensemble.kernel_timing(sampler)
@@ -489,6 +536,13 @@ def main():
                        "exchange": "none" if gather != "skeleton" else
                                    f"one all-gather each of the X, V, t shards per step (RCCL, in place): {xbytes} bytes received per GPU per step",
                        "exchange_bytes_per_gpu": xbytes,
+                       "allocator": ("ensemble.alloc_outputs: X, V, t built from independent 1-GiB physical chunks (pdmp_device_alloc)" if allocator == "chunked"
+                                     else "torch.empty (hipMalloc)"),
+                       "allocation_sets": n_sets,
+                       "placement_ms": placement,
+                       "placement_note": ("per fresh allocation of X, V, t: hipEvent-timed launches (ms, incl. the exchange when N > 1).  `value` covers every step of the "
+                                          "timed region = every allocation set with in_timed_region true, in rotation, none picked; the others are the untimed survey "
+                                          "(two more chunked allocations, two hipMalloc'ed ones for comparison: the placement lottery of DESIGN.md 6)"),
                        "kernel_ms_max_over_ranks": kernel_ms_max,
                        "kernel_only_events_per_s": events_step / (kernel_ms_max * 1e-3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -27,6 +27,7 @@
  */
 #ifndef PDMP_HIP_H
 #define PDMP_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -301,6 +302,14 @@ int pdmp_multi_sample_skeleton(pdmp_multi_handle m, int64_t C, int64_t n_sk, int
                                double *const *X, double *const *V, double *const *t);
 /* kernel / exchange time of the last pdmp_multi_sample_skeleton (ms, max over devices; hipEvents on each device's stream) */
 int pdmp_multi_get_timing(pdmp_multi_handle m, double *kernel_ms, double *exchange_ms);
+/* The same step with the shards' initial states already ON their devices: xinit[r], vinit[r] = DEVICE pointers on device r holding
+ * shard r only (d x len_r) -- nothing is staged over PCIe (the host-pointer entry copies 16 d bytes per chain per call).
+ * pdmp_multi_init_states fills such buffers with the synthetic states of pdmp_init_states_device, keyed by the global chain id. */
+int pdmp_multi_sample_skeleton_device(pdmp_multi_handle m, int64_t C, int64_t n_sk, int64_t chain_id_offset,
+                                      const double *const *xinit, const double *const *vinit, uint64_t seed, int32_t gather,
+                                      double *const *X, double *const *V, double *const *t);
+int pdmp_multi_init_states(pdmp_multi_handle m, int64_t C, int64_t chain_id_offset, uint64_t seed, double x_mean, double x_scale,
+                           int32_t v_kind, double *const *xinit, double *const *vinit);
 
 /* Synchronises the handle's last stream and returns PDMP_ERR_ITERCAP if any chain of the launches
  * since the previous check hit the iteration cap (Q11 guard events are counted in *n_guard if non-NULL). */
@@ -318,6 +327,16 @@ long long pdmp_dense_batched_last_columns(void);
 /* ... and which form served it: 0 none yet, 1 one GEMM per phase (d > 1024 or PDMP_DENSE_MODE=gemm), 2 incremental
  * (P x and P v kept current by O(d) updates, one GEMM per `PDMP_DENSE_RESYNC` = 256 events; last_phases() is 0 then). */
 int pdmp_dense_batched_last_mode(void);
+
+/* Device memory for the output arrays of a large ensemble, built from independent physical chunks (HIP virtual memory management;
+ * chunk_bytes = 0: 1 GiB).  Plain pointers like any device allocation -- the caller still owns and frees them (pdmp_device_free, which
+ * waits for the device first) -- but the launch time no longer depends on how the driver happened to place two 40 GB blocks relative
+ * to each other: measured on MI355X at config-2 size, hipMalloc'ed arrays run 14.4 ms or ~18 ms per launch for as long as the allocation
+ * lives (about one placement in five), chunked arrays 14.4 - 14.75 ms in every allocation (csrc/device_alloc.hip).
+ * device = -1: the current device.  Errors: PDMP_ERR_ARGUMENT / PDMP_ERR_RUNTIME with pdmp_device_alloc_error(). */
+int pdmp_device_alloc(int32_t device, size_t bytes, size_t chunk_bytes, void **out);
+int pdmp_device_free(void *ptr);
+const char *pdmp_device_alloc_error(void);
 
 /* Synthetic initial states of an ensemble, generated on the device (the ensemble API is new -- the reference starts its one chain
  * from user arrays, README.md:40-44 -- and BASELINE.md section 3 fixes the synthetic workloads as "xinit[:,c] ~ N(0,I), vinit[i,c] = +-1

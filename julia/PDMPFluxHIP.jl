@@ -354,11 +354,17 @@ end
 # that have not reached T, which resume from their hand-off state; finished chains cost nothing, memory is the sum of the history
 # lengths.  `A` = the device array type (AMDGPU.ROCArray); xinit, vinit: d x C device arrays.  Returns the packed `_trim_history`
 # layout (Composites.jl:198-214): X, V (d x total), t (total), offsets (C + 1; chain c = columns offsets[c]+1 : offsets[c+1]), count (C).
-# PDMP_ERR_UNSUPPORTED (-5: StickyZigZag, the dense-precision target, tape replays) -> use the single-chain method above per chain.
+# PDMP_ERR_UNSUPPORTED (-5: the dense-precision target, tape replays) -> use the single-chain method above per chain.  StickyZigZag needs
+# the PDMPHistory.is_active arrays (pdmp_diag_t.is_active, ABI 8) for its closing column (sample.jl:386-401); this method records X, V, t
+# only and therefore refuses a sticky sampler instead of returning an unmasked closing column.
 function sample_skeleton_until(s::HIPSampler, T::Float64, xinit, vinit, A; seed::Int, chain_id_offset::Int=0, init_capacity::Int=1024, stream=C_NULL)
     (isfinite(T) && T >= 0) || throw(ArgumentError("T must be finite and non-negative. Current value: $T"))   # :335-337
+    sticky(s) && throw(ArgumentError("sample_skeleton_until: StickyZigZag histories carry is_active; use the single-chain method"))
     d, C = size(xinit)
-    cap = 8 * cld(max(2, init_capacity), 8)
+    # the lane forms address a wave's window of X / V through a 32-bit buffer descriptor: 64 * capacity * d * 8 < 2^31 (engine_api.hip: lane_ok)
+    cap_limit = d <= 104 ? 8 * fld(fld(2^31 - 1, 64 * 8 * d), 8) : typemax(Int)
+    cap = min(8 * cld(max(2, init_capacity), 8), max(cap_limit, 8))
+    cap_sum = 0
     total = A(zeros(Int64, C))
     chunks = NamedTuple[]
     cmap, Cl, skip = nothing, C, 0
@@ -380,7 +386,10 @@ function sample_skeleton_until(s::HIPSampler, T::Float64, xinit, vinit, A; seed:
         n = Array(nact)[1]
         n == 0 && break
         cmap, Cl, skip = nxt[1:n], n, 1                                          # the chains still running, in launch order
-        cap = 8 * cld(max(16, min(cap, 2 * cap)), 8)                             # (the Python mirror sizes later chunks from the chains' event rates)
+        cap_sum += cap
+        # later chunks: the reference doubles its one chain's buffer (sample.jl:375-377); here the capacity grows with what has been used
+        # so far -- at most four times the columns allocated so far, as in the Python mirror (which also sizes it from the event rates)
+        cap = min(8 * cld(max(16, min(2 * cap, 4 * cap_sum)), 8), max(cap_limit, 8))
     end
     offsets = A{Int64}(undef, C + 1)
     check(ccall((:pdmp_compact_offsets_device, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), s.handle, C, pointer(total), pointer(offsets), stream))

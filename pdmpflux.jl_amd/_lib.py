@@ -63,9 +63,9 @@ SYMBOLS = (
     "pdmp_sample_from_skeleton_prefix", "pdmp_sample_from_skeleton_prefix_device", "pdmp_sample_moments_device",
     "pdmp_close_at_time_device", "pdmp_compact_offsets_device", "pdmp_compact_history_device",
     "pdmp_sample_skeleton_until_device", "pdmp_close_chunk_device", "pdmp_until_advance_device", "pdmp_compact_chunk_device",
-    "pdmp_multi_shard_range", "pdmp_multi_create", "pdmp_multi_destroy", "pdmp_multi_sample_skeleton", "pdmp_multi_get_timing",
+    "pdmp_multi_shard_range", "pdmp_multi_create", "pdmp_multi_destroy", "pdmp_multi_sample_skeleton", "pdmp_multi_sample_skeleton_device", "pdmp_multi_init_states", "pdmp_multi_get_timing",
     "pdmp_check_status", "pdmp_get_timing", "pdmp_reset_timing",
-    "pdmp_init_states_device", "pdmp_debug_rng", "pdmp_dense_batched_last_phases", "pdmp_dense_batched_last_columns", "pdmp_dense_batched_last_mode",
+    "pdmp_init_states_device", "pdmp_device_alloc", "pdmp_device_free", "pdmp_device_alloc_error", "pdmp_debug_rng", "pdmp_dense_batched_last_phases", "pdmp_dense_batched_last_columns", "pdmp_dense_batched_last_mode",
 )
 
 _lib = None
@@ -127,10 +127,15 @@ def lib():
     L.pdmp_multi_destroy.argtypes = [vp]
     L.pdmp_multi_sample_skeleton.argtypes = [vp, i64, i64, i64, vp, vp, u64, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.pdmp_multi_get_timing.argtypes = [vp, C.POINTER(f64), C.POINTER(f64)]
+    L.pdmp_multi_sample_skeleton_device.argtypes = [vp, i64, i64, i64, C.POINTER(vp), C.POINTER(vp), u64, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.pdmp_multi_init_states.argtypes = [vp, i64, i64, u64, C.c_double, C.c_double, i32, C.POINTER(vp), C.POINTER(vp)]
     L.pdmp_check_status.argtypes = [vp, C.POINTER(i64)]
     L.pdmp_get_timing.argtypes = [vp, C.POINTER(Timing)]
     L.pdmp_reset_timing.argtypes = [vp]
     L.pdmp_debug_rng.argtypes = [vp, u64, i64, i32, i64, vp]
+    L.pdmp_device_alloc.argtypes = [i32, C.c_size_t, C.c_size_t, C.POINTER(vp)]
+    L.pdmp_device_free.argtypes = [vp]
+    L.pdmp_device_alloc_error.restype = C.c_char_p
     L.pdmp_init_states_device.argtypes = [vp, i64, i64, u64, C.c_double, C.c_double, i32, vp, vp, vp]
     L.pdmp_dense_batched_last_phases.restype = C.c_longlong
     L.pdmp_dense_batched_last_columns.restype = C.c_longlong

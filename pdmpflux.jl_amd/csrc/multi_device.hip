@@ -148,14 +148,19 @@ int pdmp_multi_create(const pdmp_config_t *cfg, int32_t n_devices, const int32_t
     return PDMP_OK;
 }
 
-int pdmp_multi_sample_skeleton(pdmp_multi_handle m, int64_t C, int64_t n_sk, int64_t chain_id_offset, const double *xinit,
-                               const double *vinit, uint64_t seed, int32_t gather, double *const *X, double *const *V,
-                               double *const *t) {
+}  // extern "C"
+
+// The sharded step.  Initial states either as ONE pair of host arrays (xh, vh: d x C, each shard staged to its device) or as
+// per-device DEVICE arrays of the shards themselves (xd[r], vd[r]: d x len_r on device r -- nothing crosses PCIe).
+static int multi_sample(pdmp_multi_handle m, int64_t C, int64_t n_sk, int64_t chain_id_offset, const double *xh, const double *vh,
+                        const double *const *xd, const double *const *vd, uint64_t seed, int32_t gather, double *const *X,
+                        double *const *V, double *const *t) {
+    const double *xinit = xh, *vinit = vh;
     if (!m) return failf(PDMP_ERR_ARGUMENT, "null handle");
     if (n_sk <= 0) return failf(PDMP_ERR_ARGUMENT, "n_sk must be positive");                     // sample.jl:262-264
     if (C < 0) return failf(PDMP_ERR_ARGUMENT, "number of chains must be non-negative");
     if (C == 0) return PDMP_OK;
-    if (!xinit || !vinit || !X || !V || !t) return failf(PDMP_ERR_ARGUMENT, "null buffer");
+    if ((!xd && (!xinit || !vinit)) || (xd && !vd) || !X || !V || !t) return failf(PDMP_ERR_ARGUMENT, "null buffer");
     pdmp_config_t cfg;
     if (int rc = pdmp_get_config(m->h[0], &cfg)) return rc;
     const size_t d = (size_t)cfg.dim;
@@ -166,6 +171,7 @@ int pdmp_multi_sample_skeleton(pdmp_multi_handle m, int64_t C, int64_t n_sk, int
         (void)pdmp_multi_shard_range(C, r, n, &lo[r], &hi[r]);
         if (hi[r] - lo[r] != hi[0] - lo[0]) equal = false;
         if (!X[r] || !V[r] || !t[r]) return failf(PDMP_ERR_ARGUMENT, "null per-device buffer");
+        if (xd && hi[r] > lo[r] && (!xd[r] || !vd[r])) return failf(PDMP_ERR_ARGUMENT, "null per-device initial-state buffer");
     }
     // ONE layout for every shard (results must not depend on which device a chain lands on): the occupancy choice for the largest shard
     const int G = pdmp_suggest_group_lanes(m->h[0], hi[0] - lo[0]);
@@ -188,6 +194,8 @@ int pdmp_multi_sample_skeleton(pdmp_multi_handle m, int64_t C, int64_t n_sk, int
         M_TRY(hipEventRecord(m->e0[r], m->stream[r]));
         if (len > 0) {
             const size_t need = (size_t)len * d * 8;
+            const double *sx = xd ? xd[r] : nullptr, *sv = xd ? vd[r] : nullptr;
+            if (!xd) {
             if (need > m->init_cap[r]) {
                 M_TRY(hipStreamSynchronize(m->stream[r]));
                 (void)hipFree(m->dx[r]); (void)hipFree(m->dv[r]); m->dx[r] = m->dv[r] = nullptr; m->init_cap[r] = 0;
@@ -197,8 +205,10 @@ int pdmp_multi_sample_skeleton(pdmp_multi_handle m, int64_t C, int64_t n_sk, int
             }
             M_TRY(hipMemcpyAsync(m->dx[r], xinit + (size_t)lo[r] * d, need, hipMemcpyHostToDevice, m->stream[r]));
             M_TRY(hipMemcpyAsync(m->dv[r], vinit + (size_t)lo[r] * d, need, hipMemcpyHostToDevice, m->stream[r]));
+            sx = m->dx[r]; sv = m->dv[r];
+            }
             const size_t off = gather ? (size_t)lo[r] * (size_t)n_sk : 0;         // gather: the shard sits at its chain offset of the full buffer
-            if (int rc = pdmp_sample_skeleton_device(m->h[r], len, n_sk, chain_id_offset + lo[r], m->dx[r], m->dv[r], seed,
+            if (int rc = pdmp_sample_skeleton_device(m->h[r], len, n_sk, chain_id_offset + lo[r], sx, sv, seed,
                                                      X[r] + off * d, V[r] + off * d, t[r] + off, nullptr, m->stream[r]))
                 return rc;
         }
@@ -244,6 +254,38 @@ int pdmp_multi_sample_skeleton(pdmp_multi_handle m, int64_t C, int64_t n_sk, int
         if (hi[r] > lo[r]) { const int rc = pdmp_check_status(m->h[r], nullptr); if (rc != PDMP_OK && rc_all == PDMP_OK) rc_all = rc; }
     }
     return rc_all;
+}
+
+extern "C" {
+
+int pdmp_multi_sample_skeleton(pdmp_multi_handle m, int64_t C, int64_t n_sk, int64_t chain_id_offset, const double *xinit,
+                               const double *vinit, uint64_t seed, int32_t gather, double *const *X, double *const *V,
+                               double *const *t) {
+    return multi_sample(m, C, n_sk, chain_id_offset, xinit, vinit, nullptr, nullptr, seed, gather, X, V, t);
+}
+
+int pdmp_multi_sample_skeleton_device(pdmp_multi_handle m, int64_t C, int64_t n_sk, int64_t chain_id_offset, const double *const *xinit,
+                                      const double *const *vinit, uint64_t seed, int32_t gather, double *const *X, double *const *V,
+                                      double *const *t) {
+    if (!xinit || !vinit) return failf(PDMP_ERR_ARGUMENT, "null buffer");
+    return multi_sample(m, C, n_sk, chain_id_offset, nullptr, nullptr, xinit, vinit, seed, gather, X, V, t);
+}
+
+int pdmp_multi_init_states(pdmp_multi_handle m, int64_t C, int64_t chain_id_offset, uint64_t seed, double x_mean, double x_scale,
+                           int32_t v_kind, double *const *xinit, double *const *vinit) {
+    if (!m || !xinit || !vinit) return failf(PDMP_ERR_ARGUMENT, "null argument");
+    if (C <= 0) return failf(PDMP_ERR_ARGUMENT, "C must be positive");
+    for (int r = 0; r < m->n; ++r) {
+        int64_t lo, hi;
+        (void)pdmp_multi_shard_range(C, r, m->n, &lo, &hi);
+        if (hi <= lo) continue;
+        if (!xinit[r] || !vinit[r]) return failf(PDMP_ERR_ARGUMENT, "null per-device initial-state buffer");
+        M_TRY(hipSetDevice(m->dev[r]));
+        if (int rc = pdmp_init_states_device(m->h[r], hi - lo, chain_id_offset + lo, seed, x_mean, x_scale, v_kind, xinit[r], vinit[r], m->stream[r]))
+            return rc;
+    }
+    for (int r = 0; r < m->n; ++r) { M_TRY(hipSetDevice(m->dev[r])); M_TRY(hipStreamSynchronize(m->stream[r])); }
+    return PDMP_OK;
 }
 
 int pdmp_multi_get_timing(pdmp_multi_handle m, double *kernel_ms, double *exchange_ms) {

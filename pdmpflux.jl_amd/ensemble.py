@@ -46,6 +46,59 @@ def _need_cuda(*ts):
                                 "(the engine has no CPU fallback)")
 
 
+class _ChunkedBuffer:
+    """Device memory from pdmp_device_alloc, exposed through ``__cuda_array_interface__`` so that torch wraps it without a copy
+    (``torch.as_tensor`` keeps this object alive for as long as a tensor views the memory; the memory is released -- after a device
+    synchronisation -- when the last view is gone)."""
+
+    def __init__(self, nbytes: int, device: int, chunk_bytes: int = 0):
+        p = C.c_void_p()
+        rc = _lib.lib().pdmp_device_alloc(int(device), int(nbytes), int(chunk_bytes), C.byref(p))
+        if rc != 0:
+            raise _lib.EngineError(rc, (_lib.lib().pdmp_device_alloc_error() or b"").decode())
+        self.ptr, self.nbytes = p.value, int(nbytes)
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (self.ptr, False), "version": 2, "strides": None}
+
+    def __del__(self):
+        ptr, self.ptr = getattr(self, "ptr", None), None
+        if ptr:
+            try:
+                _lib.lib().pdmp_device_free(C.c_void_p(ptr))
+            except Exception:                                    # interpreter shutdown
+                pass
+
+
+CHUNKED_FROM_BYTES = 1 << 30          # output arrays from this size on are built from physical chunks by default
+
+
+def alloc_chunked(shape, dtype=torch.float64, device=None, chunk_bytes: int = 0) -> torch.Tensor:
+    """An uninitialised tensor whose memory is built from independent 1-GiB physical chunks (pdmp_device_alloc):
+    for the large output arrays of an ensemble.  hipMalloc backs a 40 GB array with a few huge physical blocks, and the launch that
+    streams X and V side by side then runs 14.4 ms or ~18 ms depending on how those blocks lie relative to each other in the memory's
+    channel map, for as long as the allocation lives; chunked arrays run 14.4 - 14.75 ms in every allocation measured."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    n = 1
+    for k in shape:
+        n *= int(k)
+    esize = torch.empty((), dtype=dtype).element_size()
+    buf = _ChunkedBuffer(max(n * esize, 1), dev.index if dev.index is not None else torch.cuda.current_device(), chunk_bytes)
+    with torch.cuda.device(dev):
+        flat = torch.as_tensor(buf, device=dev)                  # uint8 view of the mapping, zero-copy; holds `buf`
+    return flat[: n * esize].view(dtype).reshape(tuple(int(k) for k in shape))
+
+
+def alloc_outputs(C_: int, n_sk: int, d: int, device=None, chunked: bool | None = None) -> dict:
+    """The output arrays of ``sample_skeleton_device`` for ``C`` chains: ``X, V (C, n_sk, d)``, ``t (C, n_sk)``.  ``chunked`` = None:
+    arrays of at least 1 GiB from physical chunks (``alloc_chunked``), smaller ones from torch's allocator."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    out = {}
+    for name, shape in (("X", (C_, n_sk, d)), ("V", (C_, n_sk, d)), ("t", (C_, n_sk))):
+        nbytes = 8 * shape[0] * shape[1] * (shape[2] if len(shape) == 3 else 1)
+        use = chunked if chunked is not None else nbytes >= CHUNKED_FROM_BYTES
+        out[name] = alloc_chunked(shape, torch.float64, dev) if use else torch.empty(shape, dtype=torch.float64, device=dev)
+    return out
+
+
 V_RADEMACHER, V_GAUSSIAN, V_SPHERE = 0, 1, 2
 
 
@@ -81,7 +134,11 @@ def sample_skeleton_device(sampler: AbstractPDMP, n_sk: int, xinit: torch.Tensor
     def buf(name, shape, dtype=torch.float64):
         tns = o.get(name)
         if tns is None or tuple(tns.shape) != tuple(shape):
-            tns = torch.empty(shape, dtype=dtype, device=dev)
+            nbytes = torch.empty((), dtype=dtype).element_size()
+            for k in shape:
+                nbytes *= int(k)
+            # large arrays from independent physical chunks: their launch time does not depend on the placement lottery of hipMalloc
+            tns = alloc_chunked(shape, dtype, dev) if nbytes >= CHUNKED_FROM_BYTES else torch.empty(shape, dtype=dtype, device=dev)
             o[name] = tns
         _need_cuda(tns)
         return tns

@@ -311,6 +311,17 @@ def test_multi_device_entry_with_one_device(engine, oracle):
         km, xm = C.c_double(), C.c_double()
         _lib.check(L.pdmp_multi_get_timing(m, C.byref(km), C.byref(xm)))
         assert km.value > 0.0
+        # the same step with the shard's initial states already on the device (no PCIe staging), and with the states generated there
+        xd, vd = torch.from_numpy(x).to(dev), torch.from_numpy(v).to(dev)
+        X = torch.zeros((Cn, n_sk, d), dtype=torch.float64, device=dev); V = torch.zeros_like(X)
+        t = torch.zeros((Cn, n_sk), dtype=torch.float64, device=dev)
+        _lib.check(L.pdmp_multi_sample_skeleton_device(m, Cn, n_sk, 7, arr(xd), arr(vd), C.c_uint64(31), 0, arr(X), arr(V), arr(t)))
+        for a, b in ((X, single["X"]), (V, single["V"]), (t, single["t"])):
+            assert torch.equal(a, b)
+        gx, gv = torch.empty_like(xd), torch.empty_like(vd)
+        _lib.check(L.pdmp_multi_init_states(m, Cn, 7, C.c_uint64(2024), 1.0, 0.1, 2, arr(gx), arr(gv)))
+        rx, rv = oracle.init_states(2024, Cn, d, chain_id_offset=7, x_mean=1.0, x_scale=0.1, v_kind=2)
+        assert np.array_equal(gx.cpu().numpy(), rx) and np.array_equal(gv.cpu().numpy(), rv)
     finally:
         L.pdmp_multi_destroy(m)
     ref = oracle.sample_skeleton(cfg, n_sk, x, v, 31, chain_id_offset=7, diagnostics=False)
