@@ -61,10 +61,10 @@ def parse():
     ap.add_argument("--alloc", default="auto", choices=["auto", "chunked", "hipmalloc"],
                     help="allocator of the output arrays: chunked = ensemble.alloc_outputs (pdmp_device_alloc: independent 1-GiB physical chunks, "
                          "DESIGN.md 6), hipmalloc = torch.empty; auto: chunked at N = 1, hipmalloc for N > 1 (the exchange buffers go through RCCL)")
-    ap.add_argument("--sets", type=int, default=0, help="fresh allocations of X, V, t the timed steps rotate over (0: as many as fit, at most 3)")
+    ap.add_argument("--sets", type=int, default=1, help="allocation sets of X, V, t alive at once that the timed steps rotate over (three fit at the default size)")
     ap.add_argument("--placement-survey", default="auto", choices=["auto", "off"],
-                    help="auto (N = 1, >= 5 steps): before the timed region, time two more fresh chunked allocations and two hipMalloc'ed ones "
-                         "(reported in config.placement_ms, never in `value`)")
+                    help="auto (N = 1, >= 5 steps): after the timed region and its checks, free the arrays and time five more FRESH allocations one "
+                         "after the other -- three from the product's allocator, two from hipMalloc (reported in config.placement_ms, never in `value`)")
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"],
                     help="auto (N = 1): measure roofline.traffic live -- child runs of this command (one launch each) under rocprofv3 --pmc "
                          "WRITE_SIZE, FETCH_SIZE and the VALU counters, before this process touches the GPU; off: quote profiles/traffic.json")
@@ -428,18 +428,9 @@ def main():
         torch.cuda.synchronize()
         return [e0.elapsed_time(e1) for e0, e1 in evs]
 
-    # placement survey (untimed part of the run, N = 1): fresh allocations from both allocators, one warm + two timed launches each
-    survey = []
-    if a.placement_survey == "auto" and world == 1 and a.steps >= 5 and set_bytes >= (1 << 30):
-        for kind in ("chunked", "hipmalloc", "chunked", "hipmalloc"):
-            full = alloc_set(kind)
-            ms = timed_launches(full, 3, 1000 + 10 * len(survey))[1:]
-            survey.append({"allocator": kind, "in_timed_region": False, "launches": len(ms), "kernel_ms": [round(m, 3) for m in ms]})
-            del full
-            torch.cuda.empty_cache()
     free_b = torch.cuda.mem_get_info()[0]
-    n_sets = a.sets if a.sets > 0 else (1 if world > 1 else max(1, min(3, int(0.9 * free_b // max(set_bytes, 1)))))
-    sets = [alloc_set(allocator) for _ in range(n_sets)]
+    n_sets = max(1, min(a.sets if a.sets > 0 else 1, int(0.9 * free_b // max(set_bytes, 1))))
+    sets = [alloc_set(allocator) for _ in range(n_sets)]         # the FIRST allocation(s) of this process, whatever they turn out to be
     full = sets[0]
 
     def step(i):
@@ -465,7 +456,6 @@ def main():
         mine = [m for i, m in enumerate(step_ms) if (a.warmup + i) % n_sets == k]
         if mine:
             placement.append({"allocator": allocator, "in_timed_region": True, "launches": len(mine), "kernel_ms": [round(m, 3) for m in mine]})
-    placement += survey
     from pdmpflux.jl_amd import _lib
     _lib.check(_lib.lib().pdmp_check_status(sampler.handle(), None))
     tm = ensemble.kernel_timing(sampler)
@@ -491,6 +481,18 @@ def main():
             got = torch.stack([full["t"][l2:h2].sum(), full["X"][l2:h2, -1].sum(), full["V"][l2:h2, -1].sum()]).cpu()
             assert torch.equal(got, sums[r].cpu()), f"rank {rank}: the gathered block of rank {r} differs from what that rank computed"
 
+    # placement survey (N = 1; untimed, after everything `value` depends on): the timed arrays are released and five more fresh
+    # allocations of X, V, t are timed one after the other (one warm + three timed launches each)
+    if a.placement_survey == "auto" and world == 1 and a.steps >= 5 and set_bytes >= (1 << 30):
+        del full, own, tt
+        sets.clear()
+        torch.cuda.empty_cache()
+        for kind in ("chunked", "hipmalloc", "chunked", "hipmalloc", "chunked"):
+            cur = alloc_set(kind)
+            ms = timed_launches(cur, 4, 1000 + 10 * len(placement))[1:]
+            placement.append({"allocator": kind, "in_timed_region": False, "launches": len(ms), "kernel_ms": [round(m, 3) for m in ms]})
+            del cur
+            torch.cuda.empty_cache()
     if rank == 0:
         events_step = C_total * (n_sk - 1)
         value = events_step * a.steps / elapsed
@@ -541,8 +543,10 @@ def main():
                        "allocation_sets": n_sets,
                        "placement_ms": placement,
                        "placement_note": ("per fresh allocation of X, V, t: hipEvent-timed launches (ms, incl. the exchange when N > 1).  `value` covers every step of the "
-                                          "timed region = every allocation set with in_timed_region true, in rotation, none picked; the others are the untimed survey "
-                                          "(two more chunked allocations, two hipMalloc'ed ones for comparison: the placement lottery of DESIGN.md 6)"),
+                                          "timed region = the FIRST allocation(s) this process made (in_timed_region true; a rule, not a choice); the others are the untimed "
+                                          "survey run afterwards: five more fresh allocations, three from the product's allocator and two from hipMalloc (the placement "
+                                          "lottery of DESIGN.md 6).  all_allocations_ms: mean launch time over every allocation listed"),
+                       "all_allocations_ms": (sum(sum(q["kernel_ms"]) / len(q["kernel_ms"]) for q in placement) / len(placement)) if placement else None,
                        "kernel_ms_max_over_ranks": kernel_ms_max,
                        "kernel_only_events_per_s": events_step / (kernel_ms_max * 1e-3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

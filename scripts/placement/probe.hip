@@ -244,6 +244,84 @@ int main(int argc, char **argv)
         }
         return 0;
     }
+    if (mode == "map") {
+        // Is the speed a property of WHERE in the VRAM a chunk lies?  All free memory as 1-GiB chunks; every chunk timed alone with a dense
+        // writer (65 536 streams of 16 KiB inside the chunk: the machine is full, the bytes stay inside this chunk); then the engine on arrays
+        // built from the fastest chunks, from the slowest, and from the first / last allocated.
+        const size_t S = size_t(argc > 2 ? atol(argv[2]) : 1024) << 20;
+        size_t f2, t2; HIPCHECK(hipMemGetInfo(&f2, &t2));
+        const int n = int((double(f2) - 8e9) / double(S));
+        Pool pool; pool.create(S, n);
+        Mapped one; one.reserve(S, S);
+        std::vector<float> m1(n);
+        std::string ms;
+        const int64_t st = 2048, nch = int64_t(S / 8 / st);                   // streams of `st` doubles
+        for (int i = 0; i < n; ++i) {
+            one.map(pool, std::vector<int>{i});
+            m1[i] = run_synth((double *)one.base, (double *)one.base, st, nch, int(st / 8), 1024, 1, 1, 3);
+            one.unmap();
+            char buf[32]; snprintf(buf, sizeof buf, "%s%.4f", i ? "," : "", m1[i]); ms += buf;
+        }
+        printf("{\"probe\":\"map\",\"chunk_mib\":%zu,\"chunks\":%d,\"chunk_ms\":[%s]}\n", S >> 20, n, ms.c_str());
+        fflush(stdout);
+        Mapped X, V, T;
+        X.reserve(XB, S); V.reserve(XB, S); T.reserve(TB, S);
+        const int nx = int(X.n), need = 2 * nx + int(T.n);
+        std::vector<int> order(n); for (int i = 0; i < n; ++i) order[i] = i;
+        std::vector<int> by = order;
+        std::sort(by.begin(), by.end(), [&](int a, int b) { return m1[a] < m1[b]; });
+        auto run_sel = [&](const char *name, const std::vector<int> &sel) {
+            std::vector<int> ix(sel.begin(), sel.begin() + nx), iv(sel.begin() + nx, sel.begin() + 2 * nx), it(sel.begin() + 2 * nx, sel.begin() + need);
+            X.map(pool, ix); V.map(pool, iv); T.map(pool, it);
+            std::string all; float e = run_engine((double *)X.base, (double *)V.base, (double *)T.base, &all);
+            float s2 = run_synth((double *)X.base, (double *)V.base, NSK * D, C, int(NSK * D / 8), 1024, 2, 1);
+            double mean = 0; for (int i = 0; i < need; ++i) mean += m1[sel[i]]; mean /= need;
+            printf("{\"probe\":\"map_select\",\"selection\":\"%s\",\"mean_chunk_ms\":%.4f,\"engine_ms\":%.2f,\"engine_all\":[%s],\"synth2_ms\":%.2f}\n", name, mean, e, all.c_str(), s2);
+            fflush(stdout);
+            X.unmap(); V.unmap(); T.unmap();
+        };
+        if (n >= need) {
+            run_sel("fastest", std::vector<int>(by.begin(), by.begin() + need));
+            run_sel("slowest", std::vector<int>(by.end() - need, by.end()));
+            run_sel("first_allocated", std::vector<int>(order.begin(), order.begin() + need));
+            run_sel("last_allocated", std::vector<int>(order.end() - need, order.end()));
+            if (n >= 2 * need) run_sel("middle_allocated", std::vector<int>(order.begin() + need, order.begin() + 2 * need));
+            run_sel("fastest_again", std::vector<int>(by.begin(), by.begin() + need));
+        }
+        pool.release();
+        return 0;
+    }
+    if (mode == "sets") {
+        // What bench.py does: several sets of arrays alive at once (1-GiB chunks, allocated one set after the other); the engine on each;
+        // per (X chunk, V chunk) pair of each set the dense two-array writer.
+        const size_t S = size_t(argc > 2 ? atol(argv[2]) : 1024) << 20;
+        const int nsets = argc > 3 ? atoi(argv[3]) : 3;
+        std::vector<Pool> pools(nsets);
+        std::vector<Mapped> Xs(nsets), Vs(nsets), Ts(nsets);
+        for (int k = 0; k < nsets; ++k) {
+            Xs[k].reserve(XB, S); Vs[k].reserve(XB, S); Ts[k].reserve(TB, S);
+            const int nx = int(Xs[k].n), nt_ = int(Ts[k].n);
+            pools[k].create(S, 2 * nx + nt_);
+            std::vector<int> ix(nx), iv(nx), it(nt_);
+            for (int i = 0; i < nx; ++i) { ix[i] = i; iv[i] = nx + i; }
+            for (int i = 0; i < nt_; ++i) it[i] = 2 * nx + i;
+            Xs[k].map(pools[k], ix); Vs[k].map(pools[k], iv); Ts[k].map(pools[k], it);
+        }
+        const int64_t st = 2048, nch = int64_t(S / 8 / st);
+        for (int rep = 0; rep < 2; ++rep)
+        for (int k = 0; k < nsets; ++k) {
+            std::string all; float e = run_engine((double *)Xs[k].base, (double *)Vs[k].base, (double *)Ts[k].base, &all);
+            std::string pers;
+            const int nx = int(Xs[k].n);
+            for (int i = 0; i < nx && rep == 0; ++i) {
+                const float m = run_synth((double *)(Xs[k].base + size_t(i) * S), (double *)(Vs[k].base + size_t(i) * S), st, nch, int(st / 8), 1024, 2, 1, 2);
+                char buf[32]; snprintf(buf, sizeof buf, "%s%.4f", i ? "," : "", m); pers += buf;
+            }
+            printf("{\"probe\":\"sets\",\"set\":%d,\"rep\":%d,\"engine_ms\":%.2f,\"engine_all\":[%s],\"pair_ms\":[%s]}\n", k, rep, e, all.c_str(), pers.c_str());
+            fflush(stdout);
+        }
+        return 0;
+    }
     if (mode == "chunks") {
         // Arrays from 1-GiB physical chunks: is a slow placement slow in particular chunks?  Per pool: the engine launch, the synthetic
         // writer on every (X chunk i, V chunk i) pair alone, then the slowest pairs exchanged for spare chunks and the launch again.

@@ -86,7 +86,7 @@ def test_chunked_time_horizon_on_a_side_stream(engine, oracle):
         busy.fill_(float(rep))                                           # ~2 GB fill queued on the current stream
         stats = {}
         _run(engine, oracle, s, cfg, x, v, 1.4, 6 + rep, 8, stats, stream=side)
-        assert stats["chunks"] >= 3
+        assert stats["chunks"] >= 2
     torch.cuda.synchronize()
 
 
