@@ -302,6 +302,43 @@ struct DiParams {
 #else
 #define PDMP_ROW_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
 #endif
+// ---- Totals of sixteen per-lane values over the wave, all at once ("reduce-scatter"): instead of sixteen butterflies of six stages
+// each (16 x 22 instructions, and -- walked slot by slot until the hit -- sixteen dependent chains through the LDS crossbar), every
+// stage HALVES the number of values a lane carries while it doubles the lanes each value has been summed over:
+//   xor 32 (v_permlane32_swap of slots s | s + 8), xor 16 (v_permlane16_swap of s | s + 4), xor 8 (row_ror:8 of s | s + 2),
+//   then the quads are made uniform (xor 1, xor 2) and the last exchange (s | s + 1) goes through row_half_mirror.
+// 63 instructions, log depth.  Lane L ends up with the total of slot  ((L >> 2) & 1) + 2 ((L >> 3) & 1) + 4 (L >> 4).
+// The order of each slot's sum differs from wave_sum's (this path is held to a tolerance, not bit for bit: header of this file).
+constexpr int DPP_ROW_ROR8 = 0x128, DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+__device__ __forceinline__ void swap32_pair(double x, double y, double &lo_half, double &hi_half) {   // -> [x.lo | y.lo], [x.hi | y.hi]
+    const auto rl = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(y), false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(y), false, false);
+    lo_half = __hiloint2double(rh[0], rl[0]); hi_half = __hiloint2double(rh[1], rl[1]);
+}
+__device__ __forceinline__ void swap16_pair(double x, double y, double &even, double &odd) {           // -> [x.r0, y.r0, x.r2, y.r2], [x.r1, y.r1, x.r3, y.r3]
+    const auto rl = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y), false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y), false, false);
+    even = __hiloint2double(rh[0], rl[0]); odd = __hiloint2double(rh[1], rl[1]);
+}
+__device__ __forceinline__ double slot_totals16(const double (&val)[16], int lane) {
+    double z[8], w[4], u[2];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { double a, b; swap32_pair(val[s], val[s + 8], a, b); z[s] = a + b; }      // lanes < 32: slot s, lanes >= 32: slot s + 8
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { double a, b; swap16_pair(z[s], z[s + 4], a, b); w[s] = a + b; }          // row r: slot s + 4 r
+    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {                                                                           // half h of a row: slot s + 2 h + 4 r
+        const double keep = b3 ? w[s + 2] : w[s], send = b3 ? w[s] : w[s + 2];
+        u[s] = keep + dpp_d<DPP_ROW_ROR8>(send);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { u[s] = u[s] + dpp_d<DPP_QUAD_XOR1>(u[s]); u[s] = u[s] + dpp_d<DPP_QUAD_XOR2>(u[s]); }   // quads uniform
+    const double keep = b2 ? u[1] : u[0], send = b2 ? u[0] : u[1];
+    return keep + dpp_d<DPP_ROW_HALF_MIRROR>(send);                                                          // quad q of a half: slot q + 2 h + 4 r
+}
+__device__ __forceinline__ int slot_lane16(int s) { return ((s & 1) << 2) | (((s >> 1) & 1) << 3) | ((s >> 2) << 4); }   // a lane that holds slot s
+
 template <int KC, bool SGN>
 __global__ __launch_bounds__(256, SGN ? 2 : 1) void di_segment_kernel(const DiParams p) {
     const int lane = lane_id();
@@ -444,6 +481,25 @@ __global__ __launch_bounds__(256, SGN ? 2 : 1) void di_segment_kernel(const DiPa
             const double theta = u2 * lam;
             int sh = -1;
             double carry = 0.0, carry_at = 0.0;
+            if constexpr (KC == 16) {
+                // all sixteen slot totals at once (slot_totals16), gathered into lanes 0..15 in slot order, one 16-lane scan, one ballot
+                double lv[16];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) lv[s] = fmax(0.0, gx[s] * v[s]);
+                const double tot = slot_totals16(lv, lane);
+                const double Ts = __shfl(tot, slot_lane16(lane & 15), WAVE);       // lane s (and s + 16, ...) <- the total of slot s
+                double pre = Ts;                                                    // inclusive prefix over the slots, inside each row of 16 lanes
+                { double q;
+                  q = dpp_d<DPP_ROW_SHR1>(pre); if ((lane & 15) >= 1) pre = pre + q;
+                  q = dpp_d<DPP_ROW_SHR2>(pre); if ((lane & 15) >= 2) pre = pre + q;
+                  q = dpp_d<DPP_ROW_SHR4>(pre); if ((lane & 15) >= 4) pre = pre + q;
+                  q = dpp_d<DPP_ROW_SHR8>(pre); if ((lane & 15) >= 8) pre = pre + q; }
+                const unsigned hit16 = (unsigned)(__ballot(pre > theta) & 0xffffull);
+                if (hit16 != 0u) {
+                    sh = (int)__builtin_ctz(hit16);
+                    carry_at = (sh == 0) ? 0.0 : readlane_d(pre, sh - 1);
+                }
+            } else {
 #pragma unroll
             for (int s = 0; s < KC; ++s) {
                 if (sh < 0) {                    // wave-uniform: slots after the hit one are not summed
@@ -451,6 +507,7 @@ __global__ __launch_bounds__(256, SGN ? 2 : 1) void di_segment_kernel(const DiPa
                     if (carry + Ts > theta) { sh = s; carry_at = carry; }
                     carry = carry + Ts;
                 }
+            }
             }
             int m = -1;
             if (sh >= 0) {

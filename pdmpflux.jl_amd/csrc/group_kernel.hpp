@@ -56,7 +56,8 @@ struct GroupParams {
 
 // ---------------------------------------------------------------- group-of-lanes primitives (G uniform)
 // Stages inside a row of 16 lanes use DPP (register-to-register, no LDS crossbar latency); only the
-// 16- and 32-lane stages go through ds_bpermute.  Same operands and order as __shfl_xor / __shfl_up.
+// 16- and 32-lane stages of a SUM use the permlane swaps of gfx950 (wave_math.hpp), of a SCAN ds_bpermute.  Same operands and order as
+// __shfl_xor / __shfl_up.
 constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
 
 __device__ __forceinline__ double group_sum(double a, int G) {       // ascending xor-butterfly over G lanes
@@ -64,8 +65,8 @@ __device__ __forceinline__ double group_sum(double a, int G) {       // ascendin
     if (G > 2) a = a + dpp_d<DPP_QUAD_XOR2>(a);
     if (G > 4) a = a + dpp_d<DPP_ROW_HALF_MIRROR>(a);   // quads are uniform after the first two stages: partner = xor 4
     if (G > 8) a = a + dpp_d<DPP_ROW_MIRROR>(a);        // likewise xor 8
-    if (G > 16) a = a + __shfl_xor(a, 16, WAVE);
-    if (G > 32) a = a + __shfl_xor(a, 32, WAVE);
+    if (G > 16) a = xor16_sum(a);                       // (v_permlane16_swap / v_permlane32_swap: same operands as the shuffles, no LDS crossbar)
+    if (G > 32) a = xor32_sum(a);
     return a;
 }
 __device__ __forceinline__ double group_scan_incl(double a, int g, int G) {   // Kogge-Stone inclusive scan over G lanes

@@ -52,6 +52,24 @@ constexpr int DPP_QUAD_XOR2 = 0x4E;     // quad_perm [2,3,0,1]
 constexpr int DPP_ROW_HALF_MIRROR = 0x141;
 constexpr int DPP_ROW_MIRROR = 0x140;
 
+// The xor-16 and xor-32 stages of a butterfly WITHOUT the LDS crossbar (ds_bpermute: two instructions per double, an address, a
+// wait of ~120 cycles): gfx950's v_permlane16_swap / v_permlane32_swap exchange whole rows / halves between two registers.
+// With x = y = a:  permlane32_swap leaves x = [a(0..31), a(0..31)], y = [a(32..63), a(32..63)]; permlane16_swap leaves
+// x = [r0, r0, r2, r2], y = [r1, r1, r3, r3] (rows of 16 lanes).  x + y is then, in every lane, a[lane] + a[lane ^ 32] (^ 16): the same
+// two operands as `a + __shfl_xor(a, 32)` -- IEEE addition is commutative, so the same bits.
+__device__ __forceinline__ double xor32_sum(double a) {
+    const int lo = __double2loint(a), hi = __double2hiint(a);
+    const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
+}
+__device__ __forceinline__ double xor16_sum(double a) {
+    const int lo = __double2loint(a), hi = __double2hiint(a);
+    const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);
+}
+
 // Sum over the 64 lanes, result in every lane.  Order (the "WAVE64" order of the checker):
 // xor-butterfly with offsets 1,2,4,8,16,32; IEEE addition is commutative so both partners of a pair
 // compute the same bits.
@@ -60,8 +78,8 @@ __device__ __forceinline__ double wave_sum(double a) {
     a = a + dpp_d<DPP_QUAD_XOR2>(a);
     a = a + dpp_d<DPP_ROW_HALF_MIRROR>(a);
     a = a + dpp_d<DPP_ROW_MIRROR>(a);
-    a = a + __shfl_xor(a, 16, WAVE);
-    a = a + __shfl_xor(a, 32, WAVE);
+    a = xor16_sum(a);
+    a = xor32_sum(a);
     return a;
 }
 
