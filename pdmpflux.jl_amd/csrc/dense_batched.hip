@@ -18,6 +18,8 @@
 #include "skeleton_kernel.hpp"
 
 #include <rocblas/rocblas.h>
+extern "C" int pdmp_dgemm_mfma(int M, int N, int K, const double *A, int lda, const double *B, int ldb, double *C, int ldc, void *stream);   // dgemm_mfma.hip
+extern "C" int pdmp_dgemm_mfma_polite(int max_wg, int M, int N, int K, const double *A, int lda, const double *B, int ldb, double *C, int ldc, void *stream);
 
 #include <cstdio>
 #include <cstdlib>
@@ -293,6 +295,7 @@ struct DiParams {
     int32_t *status;             // [0] itercap, [1] guard
     double refresh;              // BPS (dr_bps_kernel): refresh_rate
     int32_t gaussian_velocity, pad;
+    int64_t c_lo, c_hi;          // the chains this launch advances: [c_lo, c_hi) of the C chains of the workspace (two half-ensembles on two streams)
 };
 
 // SGN: signed_bound (the constructor default).  There the slope of every coordinate's rate is the same double at both ends of a
@@ -342,8 +345,8 @@ __device__ __forceinline__ int slot_lane16(int s) { return ((s & 1) << 2) | (((s
 template <int KC, bool SGN>
 __global__ __launch_bounds__(256, SGN ? 2 : 1) void di_segment_kernel(const DiParams p) {
     const int lane = lane_id();
-    const int64_t c = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (c >= p.C) return;
+    const int64_t c = p.c_lo + (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (c >= p.c_hi) return;
     DiState cs;
     if (p.k_begin == 0) { cs.t = 0.0; cs.horizon = p.tmax; cs.rng_n = 0; cs.dead = 0; cs.pad = 0; }
     else cs = p.st[c];
@@ -351,7 +354,10 @@ __global__ __launch_bounds__(256, SGN ? 2 : 1) void di_segment_kernel(const DiPa
     const int d = p.d;
     const bool adaptive = p.adaptive != 0;
     constexpr bool sgn = SGN;
-    // v, gx = P x, gv = P v in registers; x is only touched by flows and records: it lives in LDS (KC*512 B per wave)
+    // v, gx = P x, gv = P v in registers; x is only touched by flows and records: it lives in LDS (KC*512 B per wave).
+    // (Carrying the signed products (P x) .* v, (P v) .* v instead -- 4 instead of 7 instructions per coordinate and cell, the right end of
+    // a cell reused as the left end of the next -- was built twice and measured slower both times: round 3 8.31 -> 8.70 ms, round 4 (after
+    // the wave sums had lost their LDS stages) 7.54 -> 8.03 ms: sixteen more live registers cost more than the instructions save.)
     __shared__ double x_lds[4][KC * WAVE];
     double *x = x_lds[threadIdx.x >> 6] + lane;          // slot s at x[s * WAVE]
     double v[KC], gx[KC], gv[KC];
@@ -584,8 +590,8 @@ __global__ __launch_bounds__(256, SGN ? 2 : 1) void di_segment_kernel(const DiPa
 template <int KC>
 __global__ __launch_bounds__(256, 2) void dr_bps_kernel(const DiParams p) {
     const int lane = lane_id();
-    const int64_t c = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (c >= p.C) return;
+    const int64_t c = p.c_lo + (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (c >= p.c_hi) return;
     DiState cs;
     if (p.k_begin == 0) { cs.t = 0.0; cs.horizon = p.tmax; cs.rng_n = 0; cs.dead = 0; cs.pad = 0; }
     else cs = p.st[c];
@@ -767,8 +773,8 @@ __global__ __launch_bounds__(256, 2) void dr_bps_kernel(const DiParams p) {
 template <int KC>
 __global__ __launch_bounds__(256, (KC == 16 ? 1 : 2)) void dr_boom_kernel(const DiParams p) {
     const int lane = lane_id();
-    const int64_t c = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (c >= p.C) return;
+    const int64_t c = p.c_lo + (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (c >= p.c_hi) return;
     DiState cs;
     if (p.k_begin == 0) { cs.t = 0.0; cs.horizon = p.tmax; cs.rng_n = 0; cs.dead = 0; cs.pad = 0; }
     else cs = p.st[c];
@@ -971,24 +977,46 @@ using namespace pdmp;
 
 static long long g_last_phases = 0, g_last_columns = 0;
 static int g_last_mode = 0;
-static rocblas_handle db_handle(int device) {                      // one rocBLAS handle per device, created on first use
-    static rocblas_handle handles[16] = {nullptr};
+static rocblas_handle db_handle(int device, int lane = 0) {        // rocBLAS handles per device (one per pipeline lane), created on first use
+    static rocblas_handle handles[16][2] = {{nullptr}};
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (device < 0 || device >= 16 || lane < 0 || lane > 1) return nullptr;
+    if (!handles[device][lane] && rocblas_create_handle(&handles[device][lane]) != rocblas_status_success) handles[device][lane] = nullptr;
+    return handles[device][lane];
+}
+// the second stream of a two-lane run and the events that fork / join it (per device, created on first use, never destroyed)
+struct DbSide { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+static DbSide *db_side(int device) {
+    static DbSide sides[16];
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
     if (device < 0 || device >= 16) return nullptr;
-    if (!handles[device] && rocblas_create_handle(&handles[device]) != rocblas_status_success) handles[device] = nullptr;
-    return handles[device];
+    DbSide &q = sides[device];
+    if (!q.stream) {
+        if (hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking) != hipSuccess) { q.stream = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&q.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&q.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    return &q;
 }
 extern "C" long long pdmp_dense_batched_last_phases(void) { return g_last_phases; }   // GEMM phases of the last run (diagnostics)
 extern "C" long long pdmp_dense_batched_last_columns(void) { return g_last_columns; } // right-hand-side columns multiplied over those phases
+
+// The product P * B of the batched forms: the hand-written fp64 MFMA kernel (dgemm_mfma.hip; gemm_impl = 1, even d) or rocBLAS (the A/B
+// baseline; odd d).  Expands where DB_TRY / DB_BLAS, hb, one, zero, d, P_dev and stream are in scope.
+#define DB_GEMM(ncols, Bp, Op) do {                                                                                              \
+        if (gemm_impl == 1 && (d & 1) == 0) DB_TRY((hipError_t)pdmp_dgemm_mfma_polite(gemm_polite, d, (ncols), d, P_dev, d, (Bp), d, (Op), d, stream)); \
+        else DB_BLAS(rocblas_dgemm(hb, rocblas_operation_none, rocblas_operation_none, d, (ncols), d, &one, P_dev, d, (Bp), d, &zero, (Op), d)); \
+    } while (0)
 
 // Host driver.  Returns hipSuccess-like 0, or a negative code: -3 runtime, -5 unsupported.
 extern "C" int pdmp_dense_batched_run(int device, int d, int signed_bound, int adaptive, double tmax, int64_t cap,
                                       const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
                                       const double *xinit, const double *vinit, double *X, double *V, double *t,
                                       double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
-                                      int32_t *status, void *stream_v, int full_pv, char *err, int errlen) {
+                                      int32_t *status, void *stream_v, int full_pv, int gemm_impl, char *err, int errlen) {
     hipStream_t stream = (hipStream_t)stream_v;
+    const int gemm_polite = 0;
 #define DB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { snprintf(err, errlen, "%s: %s", #expr, hipGetErrorString(e_)); goto fail; } } while (0)
 #define DB_BLAS(expr) do { rocblas_status s_ = (expr); if (s_ != rocblas_status_success) { snprintf(err, errlen, "%s: rocblas status %d", #expr, (int)s_); goto fail; } } while (0)
     double *Xs = nullptr, *In = nullptr, *Out = nullptr, *Gprev = nullptr;
@@ -1032,8 +1060,7 @@ extern "C" int pdmp_dense_batched_run(int device, int d, int signed_bound, int a
             // at flips, where the step kernel updates it by a rank-one term; a full d x 2C product re-syncs it every 32 phases.
             const bool full = (ph % 32) == 0 || full_pv;
             g_last_columns += full ? 2 * C : C;
-            DB_BLAS(rocblas_dgemm(hb, rocblas_operation_none, rocblas_operation_none, d, (int)(full ? 2 * C : C), d, &one,
-                                  P_dev, d, In, d, &zero, Out, d));
+            DB_GEMM((int)(full ? 2 * C : C), In, Out);
             hipLaunchKernelGGL(db_step_kernel, grid, block, 0, stream, p);
             if ((ph & 7) == 7) {
                 DB_TRY(hipMemcpyAsync(&live, remaining, sizeof live, hipMemcpyDeviceToHost, stream));
@@ -1065,11 +1092,12 @@ extern "C" int pdmp_dense_incremental_run(int device, int d, int signed_bound, i
                                           const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
                                           const double *xinit, const double *vinit, double *X, double *V, double *t,
                                           double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
-                                          int32_t *status, void *stream_v, void **ws, size_t *ws_cap, int64_t resync_events, char *err, int errlen) {
+                                          int32_t *status, void *stream_v, void **ws, size_t *ws_cap, int64_t resync_events, int gemm_impl, char *err, int errlen) {
     hipStream_t stream = (hipStream_t)stream_v;
     // the unsigned bound keeps the tangent intersection's division: its 16-slot instantiation does not fit the register file
     // without spilling (and no kernel with lane-dependent branches may spill, see GroupOcc in group_kernel.hpp)
     if (d > 16 * WAVE || (!signed_bound && d > 8 * WAVE)) return -5;
+    const int gemm_polite = 0;
 #define DB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { snprintf(err, errlen, "%s: %s", #expr, hipGetErrorString(e_)); return -3; } } while (0)
 #define DB_BLAS(expr) do { rocblas_status s_ = (expr); if (s_ != rocblas_status_success) { snprintf(err, errlen, "%s: rocblas status %d", #expr, (int)s_); return -3; } } while (0)
     const size_t n = (size_t)C * (size_t)d;
@@ -1100,9 +1128,10 @@ extern "C" int pdmp_dense_incremental_run(int device, int d, int signed_bound, i
     g_last_phases = 0; g_last_columns = 0; g_last_mode = 2;
     for (int64_t k0 = 0; k0 < n_sk;) {
         const int64_t from = (k0 == 0) ? 1 : k0, k1 = (from + resync < n_sk) ? from + resync : n_sk;
-        DB_BLAS(rocblas_dgemm(hb, rocblas_operation_none, rocblas_operation_none, d, (int)(2 * C), d, &one, P_dev, d, In, d, &zero, Out, d));
+        DB_GEMM((int)(2 * C), In, Out);
         g_last_columns += 2 * C;
         p.k_begin = k0; p.k_end = k1;
+        p.c_lo = 0; p.c_hi = C;
         if (signed_bound) {
             if (d <= 4 * WAVE) hipLaunchKernelGGL((di_segment_kernel<4, true>), grid, block, 0, stream, p);
             else if (d <= 8 * WAVE) hipLaunchKernelGGL((di_segment_kernel<8, true>), grid, block, 0, stream, p);
@@ -1125,7 +1154,7 @@ extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_b
                                   int64_t cap, const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
                                   const double *xinit, const double *vinit, double *X, double *V, double *t,
                                   double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
-                                  int32_t *status, void *stream_v, void **ws, size_t *ws_cap, int64_t resync_events, char *err, int errlen) {
+                                  int32_t *status, void *stream_v, void **ws, size_t *ws_cap, int64_t resync_events, int gemm_impl, int lanes, char *err, int errlen) {
     hipStream_t stream = (hipStream_t)stream_v;
     if (d > 16 * WAVE) return -5;
 #define DB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { snprintf(err, errlen, "%s: %s", #expr, hipGetErrorString(e_)); return -3; } } while (0)
@@ -1152,29 +1181,62 @@ extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_b
     p.X = X; p.V = V; p.t = t; p.H = H; p.AR = AR; p.EV = EV; p.EB = EB; p.RJ = RJ; p.HH = HH;
     p.status = status;
     p.refresh = refresh; p.gaussian_velocity = gaussian_velocity; p.pad = 0;
-    const dim3 grid((unsigned)((C + 3) / 4)), block(256);
+    const dim3 block(256);
     const double one = 1.0, zero = 0.0;
     g_last_phases = 0; g_last_columns = 0; g_last_mode = 3;
     const int64_t resync = resync_events >= 1 ? resync_events : 64;   // events between two full products P [x | v]; in between only P v' is multiplied (policy: PDMP_DENSE_RESYNC)
+    // Chains are independent, and an event of a chain is GEMM (matrix cores) -> step kernel (vector ALUs, memory): with the ensemble cut into
+    // TWO half-ensembles on two streams the product of one half runs beside the step of the other -- the MFMA waves and the VALU waves share
+    // the CUs (1 + 1 waves per SIMD fit both kernels' registers and LDS) -- instead of the two kinds of unit taking turns.  Same arithmetic per
+    // chain: bit-identical to one lane with the hand-written product (rocBLAS may pick another kernel for another column count).
+    const int nl = (lanes >= 2 && C >= 256) ? 2 : 1;
+    static const int polite_env = getenv("PDMP_DGEMM_POLITE") ? atoi(getenv("PDMP_DGEMM_POLITE")) : 2;   // (tuning: workgroups of the product per CU beside the other lane's step kernel)
+    const int gemm_polite = (nl == 2) ? polite_env : 0;
+    DbSide *side = (nl == 2) ? db_side(device) : nullptr;
+    if (nl == 2 && !side) { snprintf(err, errlen, "side stream"); return -3; }
+    hipStream_t ls[2] = {stream, side ? side->stream : stream};
+    rocblas_handle lh[2] = {hb, (nl == 2) ? db_handle(device, 1) : hb};
+    if (!lh[1]) { snprintf(err, errlen, "rocblas handle"); return -3; }
+    if (nl == 2) {
+        DB_BLAS(rocblas_set_stream(lh[1], ls[1]));
+        DB_BLAS(rocblas_set_pointer_mode(lh[1], rocblas_pointer_mode_host));
+        DB_TRY(hipEventRecord(side->fork, stream));                       // the side lane starts after the initial states are in the workspace
+        DB_TRY(hipStreamWaitEvent(ls[1], side->fork, 0));
+    }
+    const int64_t cut = (nl == 2) ? ((C / 2 + 3) / 4 * 4) : C;           // (whole blocks of four chains per lane)
     for (int64_t k0 = 0, ph = 0; k0 < n_sk; ++ph) {
         const int64_t k1 = (k0 == 0) ? ((n_sk < 2) ? n_sk : 2) : k0 + 1;
         const bool full = (ph % resync) == 0;
-        if (full) DB_BLAS(rocblas_dgemm(hb, rocblas_operation_none, rocblas_operation_none, d, (int)(2 * C), d, &one, P_dev, d, In, d, &zero, Out, d));
-        else DB_BLAS(rocblas_dgemm(hb, rocblas_operation_none, rocblas_operation_none, d, (int)C, d, &one, P_dev, d, In + n, d, &zero, Out + n, d));
         ++g_last_phases;
         g_last_columns += full ? 2 * C : C;
         p.k_begin = k0; p.k_end = k1;
-        if (boomerang) {
-            if (d <= 4 * WAVE) hipLaunchKernelGGL((dr_boom_kernel<4>), grid, block, 0, stream, p);
-            else if (d <= 8 * WAVE) hipLaunchKernelGGL((dr_boom_kernel<8>), grid, block, 0, stream, p);
-            else hipLaunchKernelGGL((dr_boom_kernel<16>), grid, block, 0, stream, p);
-        } else {
-            if (d <= 4 * WAVE) hipLaunchKernelGGL((dr_bps_kernel<4>), grid, block, 0, stream, p);
-            else if (d <= 8 * WAVE) hipLaunchKernelGGL((dr_bps_kernel<8>), grid, block, 0, stream, p);
-            else hipLaunchKernelGGL((dr_bps_kernel<16>), grid, block, 0, stream, p);
+        for (int l = 0; l < nl; ++l) {
+            const int64_t lo = (l == 0) ? 0 : cut, hi = (l == 0) ? cut : C;
+            if (hi <= lo) continue;
+            hipStream_t stream = ls[l];                                    // (DB_GEMM and the launches below use this lane's stream and handle)
+            rocblas_handle hb = lh[l];
+            const size_t off = (size_t)lo * (size_t)d;
+            const int cols = (int)(hi - lo);
+            if (full) DB_GEMM(cols, In + off, Out + off);                  // P x of this lane's chains
+            DB_GEMM(cols, In + n + off, Out + n + off);                    // P v'
+            p.c_lo = lo; p.c_hi = hi;
+            const dim3 grid((unsigned)((hi - lo + 3) / 4));
+            if (boomerang) {
+                if (d <= 4 * WAVE) hipLaunchKernelGGL((dr_boom_kernel<4>), grid, block, 0, stream, p);
+                else if (d <= 8 * WAVE) hipLaunchKernelGGL((dr_boom_kernel<8>), grid, block, 0, stream, p);
+                else hipLaunchKernelGGL((dr_boom_kernel<16>), grid, block, 0, stream, p);
+            } else {
+                if (d <= 4 * WAVE) hipLaunchKernelGGL((dr_bps_kernel<4>), grid, block, 0, stream, p);
+                else if (d <= 8 * WAVE) hipLaunchKernelGGL((dr_bps_kernel<8>), grid, block, 0, stream, p);
+                else hipLaunchKernelGGL((dr_bps_kernel<16>), grid, block, 0, stream, p);
+            }
+            DB_TRY(hipGetLastError());
         }
-        DB_TRY(hipGetLastError());
         k0 = k1;
+    }
+    if (nl == 2) {
+        DB_TRY(hipEventRecord(side->join, ls[1]));                        // the caller's stream ends after both lanes
+        DB_TRY(hipStreamWaitEvent(stream, side->join, 0));
     }
     return 0;
 #undef DB_TRY

@@ -62,17 +62,17 @@ extern "C" int pdmp_dense_batched_run(int device, int d, int signed_bound, int a
                                       const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
                                       const double *xinit, const double *vinit, double *X, double *V, double *t,
                                       double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
-                                      int32_t *status, void *stream, int full_pv, char *err, int errlen);
+                                      int32_t *status, void *stream, int full_pv, int gemm_impl, char *err, int errlen);
 extern "C" int pdmp_dense_incremental_run(int device, int d, int signed_bound, int adaptive, double tmax, int64_t cap,
                                       const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
                                       const double *xinit, const double *vinit, double *X, double *V, double *t,
                                       double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
-                                      int32_t *status, void *stream, void **ws, size_t *ws_cap, int64_t resync_events, char *err, int errlen);
+                                      int32_t *status, void *stream, void **ws, size_t *ws_cap, int64_t resync_events, int gemm_impl, char *err, int errlen);
 extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_bound, int adaptive, int gaussian_velocity, double tmax, double refresh,
                                   int64_t cap, const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
                                   const double *xinit, const double *vinit, double *X, double *V, double *t,
                                   double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
-                                  int32_t *status, void *stream, void **ws, size_t *ws_cap, int64_t resync_events, char *err, int errlen);   // dense_batched.hip: BPS, one GEMM per event
+                                  int32_t *status, void *stream, void **ws, size_t *ws_cap, int64_t resync_events, int gemm_impl, int lanes, char *err, int errlen);   // dense_batched.hip: BPS, one GEMM per event
 
 extern "C" int pdmp_user_compile(int device, int sampler, int fd, int kind, const char *source, void **fn_out, char *err, int errlen);
 extern "C" int pdmp_user_launch(void *fn, const GroupParams *gp, void *stream);
@@ -97,6 +97,13 @@ struct LaunchPolicy {
     int from_skeleton_rows = 0;    // PDMP_FROM_SKELETON_ROWS: the row-per-iteration sample_from_skeleton kernel (A/B runs)
     int64_t dense_resync = 0;      // PDMP_DENSE_RESYNC: events between two re-basing products of the batched dense forms (0: 256 Zig-Zag / 64 BPS, Boomerang)
     int dense_full_pv = 0;         // PDMP_DENSE_FULL_PV: the GEMM-per-phase form multiplies the velocity half in every phase
+    int dense_gemm = -1;           // PDMP_DENSE_GEMM=mfma | rocblas: the product P [x | v] of the batched dense forms by the hand-written fp64 MFMA kernel
+                                   //   (csrc/dgemm_mfma.hip) or by rocBLAS.  -1 (unset): the hand-written kernel for the Zig-Zag forms (one product of 2 C
+                                   //   columns per 256 events: 57 - 58 TFLOP/s, on a par with the library), rocBLAS for BPS / Boomerang, whose per-event
+                                   //   products of C / 2 columns in two concurrent lanes it serves better (65 against 53 TFLOP/s at 5 000 columns, and its
+                                   //   kernel overlaps with the other lane's step kernel where ours does not: 92.8 against 108 ms, profiles/r4)
+    int dense_lanes = 2;           // PDMP_DENSE_LANES=1 | 2: BPS / Boomerang on a dense precision as ONE ensemble, or as two half-ensembles on two
+                                   //   streams (the product of one half beside the step kernel of the other)
     int no_lean = 0;               // PDMP_NO_LEAN: the full 13-slot register kernels even where a lean throughput instantiation exists (A/B, tests)
     int debug_launch = 0;          // PDMP_DEBUG_LAUNCH: print the launch geometry of the lane kernels
     // one lane per chain from this many chains on: the pair form (GL = 2) at d = 53 .. 104 fills the machine at 32 768 chains; at d <= 52
@@ -120,6 +127,8 @@ static LaunchPolicy policy_from_env() {
     q.from_skeleton_rows = getenv("PDMP_FROM_SKELETON_ROWS") != nullptr;
     { const long long r = geti("PDMP_DENSE_RESYNC", 0); if (r >= 1) q.dense_resync = r; }
     q.dense_full_pv = getenv("PDMP_DENSE_FULL_PV") != nullptr;
+    if (const char *m = getenv("PDMP_DENSE_GEMM")) q.dense_gemm = !strcmp(m, "mfma") ? 1 : (!strcmp(m, "rocblas") ? 0 : -1);
+    { const int v = (int)geti("PDMP_DENSE_LANES", q.dense_lanes); if (v == 1 || v == 2) q.dense_lanes = v; }
     q.no_lean = getenv("PDMP_NO_LEAN") != nullptr;
     q.debug_launch = getenv("PDMP_DEBUG_LAUNCH") != nullptr;
     return q;
@@ -1153,11 +1162,11 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
         if (dense_mode != 2)                                   // P x, P v kept current incrementally: O(d) per gradient (dense_batched.hip)
             rc = pdmp_dense_incremental_run(h->device, c.dim, c.signed_bound, c.adaptive, c.tmax, c.max_iter_per_event, h->d_tparams, C, n_sk,
                                             chain_id_offset, seed, xinit, vinit, X, V, t, p.H, p.AR, p.EB, p.EV, p.RJ, p.HH,
-                                            h->d_status, stream, &h->dense_ws, &h->dense_ws_cap, pol.dense_resync, msg, (int)sizeof msg);
+                                            h->d_status, stream, &h->dense_ws, &h->dense_ws_cap, pol.dense_resync, pol.dense_gemm < 0 ? 1 : pol.dense_gemm, msg, (int)sizeof msg);
         if (rc == -5)                                           // d > 1024 (or forced): one GEMM per phase
             rc = pdmp_dense_batched_run(h->device, c.dim, c.signed_bound, c.adaptive, c.tmax, c.max_iter_per_event, h->d_tparams, C, n_sk,
                                         chain_id_offset, seed, xinit, vinit, X, V, t, p.H, p.AR, p.EB, p.EV, p.RJ, p.HH,
-                                        h->d_status, stream, pol.dense_full_pv, msg, (int)sizeof msg);
+                                        h->d_status, stream, pol.dense_full_pv, pol.dense_gemm < 0 ? 1 : pol.dense_gemm, msg, (int)sizeof msg);
         if (rc != 0) { h->pool.push_back(ev); return fail(rc == -4 ? PDMP_ERR_ITERCAP : PDMP_ERR_RUNTIME, "dense batched path: %s", msg); }
         h->last_form = PDMP_FORM_DENSE;
         return end_timed(h, s, ev);
@@ -1176,7 +1185,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
         char msg[256] = "";
         const int rc = pdmp_dense_bps_run(h->device, c.sampler == PDMP_BOOMERANG ? 1 : 0, c.dim, c.signed_bound, c.adaptive, c.gaussian_velocity, c.tmax, c.refresh_rate, c.max_iter_per_event,
                                           h->d_tparams, C, n_sk, chain_id_offset, seed, xinit, vinit, X, V, t, p.H, p.AR, p.EB, p.EV, p.RJ, p.HH,
-                                          h->d_status, stream, &h->dense_ws, &h->dense_ws_cap, pol.dense_resync, msg, (int)sizeof msg);
+                                          h->d_status, stream, &h->dense_ws, &h->dense_ws_cap, pol.dense_resync, pol.dense_gemm < 0 ? 0 : pol.dense_gemm, pol.dense_lanes, msg, (int)sizeof msg);
         if (rc != 0) { h->pool.push_back(ev); return fail(PDMP_ERR_RUNTIME, "dense BPS path: %s", msg); }
         h->last_form = PDMP_FORM_DENSE;
         return end_timed(h, s, ev);

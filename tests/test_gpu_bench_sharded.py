@@ -1,0 +1,37 @@
+"""bench.py's sharded path itself under test (the driver launches it on N GPUs at round end; a test box has one): two ranks started by
+`python -m torch.distributed.run`, both on GPU 0, the exchange through gloo on host copies (PDMP_BENCH_REHEARSAL=1 -- RCCL refuses two ranks
+on one device).  Same code as the N-GPU run: contiguous chain ranges, global chain ids, the in-place gather of X, V, t, max-over-ranks
+timing, rank 0's JSON line; checked against a one-rank run of the same small workload."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(cmd, env):
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                    # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_rehearsal():
+    common = ["--steps", "2", "--warmup", "1", "--chains", "3001", "--n-sk", "64", "--cpu-seconds", "0", "--pmc", "off"]
+    env = dict(os.environ, PDMP_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29731", "bench.py", "--gpus", "2"] + common, env)
+    one = _run([sys.executable, "bench.py", "--gpus", "1"] + common, dict(os.environ))
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["scaling"] == "strong" and two["unit"] == "events/s" and two["metric"] == one["metric"]
+    c2 = two["config"]
+    assert c2["chains"] == 3001 and c2["chains_rank0"] == 1501                      # ragged shards: 1501 + 1500
+    assert c2["events_per_step"] == 3001 * 63 == one["config"]["events_per_step"]
+    assert c2["exchange_bytes_per_gpu"] == 1500 * 64 * 8 * (2 * 50 + 1)             # rank 0 receives the other shard's X, V, t
+    assert two["value"] > 0 and two["roofline"]["kernel_ms"] > 0
+    assert "hipMalloc" in c2["allocator"]                                           # the exchange buffers come from torch's allocator
