@@ -36,6 +36,9 @@ class _Cfg(C.Structure):
         ("fe_mix_p", C.c_double), ("fe_ran_p", C.c_int32), ("fe_switch", C.c_int32), ("fe_positive", C.c_int32),
         ("no_identities", C.c_int32), ("rh_step_size", C.c_double), ("rh_phi", C.c_double),
         ("fe_speed_factor", C.c_double), ("is_active_out", C.c_void_p),
+        ("julia_rng", C.c_int32), ("pad0_", C.c_int32),
+        ("jl_tape_exp", C.POINTER(C.c_double)), ("jl_tape_uni", C.POINTER(C.c_double)), ("jl_tape_nrm", C.POINTER(C.c_double)),
+        ("jl_cap_exp", C.c_int64), ("jl_cap_uni", C.c_int64), ("jl_cap_nrm", C.c_int64), ("jl_count", C.POINTER(C.c_int64)),
     ]
 
 
@@ -128,6 +131,7 @@ class Config:
     speed_factor: float = 1.0          # ForwardECMC
     no_identities: bool = False        # GROUP order without the engine order's three algebraic identities (checker-side comparisons only)
     is_active_out: int | None = None   # StickyZigZag: address of a (C, n_sk, d) uint8 array receiving PDMPHistory.is_active
+    julia_rng: int = 0                 # 0 Philox / tapes; JL_SEED_LIMBS (1) / JL_SEED_SHA256 (2): chain c draws from Julia's MersenneTwister(seed + c)
     _keep: list = field(default_factory=list, repr=False)
 
     def c(self) -> _Cfg:
@@ -147,7 +151,8 @@ class Config:
                     int(self.adaptive), int(self.gaussian_velocity), self.deriv_mode, self.target_id, self.arith,
                     float(self.tmax), float(self.refresh_rate), p, n, self.max_iter_per_event, self.group_lanes,
                     te, tu, tn, ne, nu, nn, float(self.mix_p), int(self.ran_p), int(self.switch), int(self.positive), int(self.no_identities),
-                    float(self.step_size), float(self.phi), float(self.speed_factor), self.is_active_out)
+                    float(self.step_size), float(self.phi), float(self.speed_factor), self.is_active_out,
+                    int(self.julia_rng), 0, None, None, None, 0, 0, 0, None)
 
 
 def _check(rc):
@@ -192,6 +197,53 @@ def sample_skeleton(cfg: Config, n_sk: int, xinit, vinit, seed: int, chain_id_of
                                      _dp(g("horizon")), _dp(g("ar")), _ip(g("errored_bound")),
                                      _dp(g("error_value_ar")), _ip(g("rejected")), _ip(g("hitting_horizon")),
                                      n_threads))
+    return out
+
+
+JL_SEED_LIMBS, JL_SEED_SHA256 = 1, 2
+
+
+def sample_skeleton_julia(cfg: Config, n_sk: int, xinit, vinit, seed: int, seeding: int = JL_SEED_SHA256, tape_capacity=None,
+                          diagnostics: bool = True) -> dict:
+    """``sample_skeleton`` with the reference's own random source restated (oracle/julia_rng.c): chain c draws from Julia's
+    ``MersenneTwister(seed + c)`` -- ``randexp`` / ``rand`` / ``randn`` in the reference's program order, ONE stream for the three kinds --
+    seeded as Julia 1.11 (``JL_SEED_SHA256``) or as 1.0 - 1.10 (``JL_SEED_LIMBS``).  Returns the skeleton plus ``tape`` = (exp, uni, nrm)
+    arrays ``(C, n_kind)`` holding what every chain consumed (zero-padded) and ``tape_counts`` ``(C, 3)``: replayed through ``Config(tape=...)``
+    or the engine's ``set_tape`` they reproduce the run draw for draw.  Unverified against a running Julia (none in this pipeline)."""
+    x = np.ascontiguousarray(np.atleast_2d(np.asarray(xinit, dtype=np.float64)))
+    Cn, d = x.shape
+    n = int(n_sk)
+    cap = tape_capacity or (64 * n + 64, 64 * n + 64, (n + 8) * max(2 * d, 8) if cfg.sampler != ZIGZAG else 8)
+    te, tu, tn = np.zeros((Cn, cap[0])), np.zeros((Cn, cap[1])), np.zeros((Cn, cap[2]))
+    counts = np.zeros((Cn, 3), dtype=np.int64)
+    jcfg = Config(**{**{k: getattr(cfg, k) for k in cfg.__dataclass_fields__ if k != "_keep"}, "julia_rng": int(seeding), "tape": None})
+    v = np.ascontiguousarray(np.atleast_2d(np.asarray(vinit, dtype=np.float64)))
+    out = {"X": np.empty((Cn, n, d)), "V": np.empty((Cn, n, d)), "t": np.empty((Cn, n))}
+    if diagnostics:
+        out.update(horizon=np.empty((Cn, n)), ar=np.empty((Cn, n)), errored_bound=np.empty((Cn, n), np.int32),
+                   error_value_ar=np.empty((Cn, n, 5)), rejected=np.empty((Cn, n), np.int32), hitting_horizon=np.empty((Cn, n), np.int32))
+    g = out.get
+    c = jcfg.c()
+    c.jl_tape_exp, c.jl_tape_uni, c.jl_tape_nrm = _dp(te), _dp(tu), _dp(tn)
+    c.jl_cap_exp, c.jl_cap_uni, c.jl_cap_nrm = cap
+    c.jl_count = counts.ctypes.data_as(C.POINTER(C.c_int64))
+    if cfg.sampler == STICKY:
+        out["is_active"] = np.empty((Cn, n, d), np.uint8)
+        c.is_active_out = out["is_active"].ctypes.data
+    _check(lib().orc_sample_skeleton(C.byref(c), Cn, n, 0, _dp(x), _dp(v), C.c_uint64(seed & (2**64 - 1)), _dp(out["X"]), _dp(out["V"]),
+                                     _dp(out["t"]), _dp(g("horizon")), _dp(g("ar")), _ip(g("errored_bound")), _dp(g("error_value_ar")),
+                                     _ip(g("rejected")), _ip(g("hitting_horizon")), 0))
+    out["tape"] = (te, tu, tn)
+    out["tape_counts"] = counts
+    return out
+
+
+def julia_draws(seed: int, n: int, kind: str = "rand", seeding: int = JL_SEED_LIMBS) -> np.ndarray:
+    """First n draws of ``rand`` / ``randn`` / ``randexp`` from Julia's ``MersenneTwister(seed)`` as restated in oracle/julia_rng.c."""
+    L = lib()
+    L.orc_julia_draws.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_double)]
+    out = np.empty(n)
+    L.orc_julia_draws(int(seed), int(seeding), {"rand": 0, "randexp": 1, "randn": 2}[kind], n, _dp(out))
     return out
 
 

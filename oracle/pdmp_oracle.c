@@ -12,6 +12,7 @@
  * Citations are file:line under /root/reference/.
  */
 #include "pdmp_oracle.h"
+#include "julia_rng.h"
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -58,7 +59,15 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
  * Julia's MersenneTwister randexp/rand/randn, because the control flow is a function of the variates) instead of
  * drawing from Philox.  An exhausted tape yields 1.0 / 0.5 / 0.0 and sets *overrun. */
 typedef struct { uint64_t seed; uint64_t chain; uint64_t n;
-                 const double *te, *tu, *tn; int64_t ne, nu, nn, ie, iu, in; int *overrun; } rng_t;
+                 const double *te, *tu, *tn; int64_t ne, nu, nn, ie, iu, in; int *overrun;
+                 /* Julia source (julia_rng.c): the chain's MersenneTwister and, optionally, the log of what it hands out (le / lu / ln: this
+                  * chain's output tapes of capacity ce / cu / cn; je / ju / jn: variates logged so far) */
+                 jl_mt_t *jl; double *le, *lu, *ln; int64_t ce, cu, cn, je, ju, jn; } rng_t;
+static inline double jl_log_put(double v, double *tape, int64_t cap, int64_t *n, int *overrun) {
+    if (tape) { if (*n < cap) tape[*n] = v; else if (overrun) *overrun = 1; }
+    ++*n;
+    return v;
+}
 
 static inline double bits_to_u(uint64_t bits) {
     return ((double)(bits >> 12) + 0.5) * 0x1p-52;
@@ -69,6 +78,7 @@ static void rng_block(const rng_t *r, uint64_t blk, uint32_t w[4]) {
     orc_philox4x32_10(ctr, key, w);
 }
 static double rng_uniform(rng_t *r) {
+    if (r->jl) return jl_log_put(jl_rand(r->jl), r->lu, r->cu, &r->ju, r->overrun);
     if (r->tu) { if (r->iu < r->nu) return r->tu[r->iu++]; if (r->overrun) *r->overrun = 1; return 0.5; }
     uint32_t w[4];
     rng_block(r, r->n >> 1, w);
@@ -198,12 +208,17 @@ void orc_sincos(double x, double *s, double *c) {
 }
 
 static double rng_exp(rng_t *r) {
+    if (r->jl) return jl_log_put(jl_randexp(r->jl), r->le, r->ce, &r->je, r->overrun);
     if (r->te) { if (r->ie < r->ne) return r->te[r->ie++]; if (r->overrun) *r->overrun = 1; return 1.0; }
     return -orc_log(rng_uniform(r));
 }
 
 /* d standard normals; aligns the variate counter to a block boundary first. */
 static void rng_normals(rng_t *r, int d, double *z) {
+    if (r->jl) {            /* randn!(rng, v) / randn(dim) as d scalar draws in index order (what a wrapped rng -- julia/dump_tape.jl's TapeRNG -- sees) */
+        for (int i = 0; i < d; ++i) z[i] = jl_log_put(jl_randn(r->jl), r->ln, r->cn, &r->jn, r->overrun);
+        return;
+    }
     if (r->tn) {
         for (int i = 0; i < d; ++i) { if (r->in < r->nn) z[i] = r->tn[r->in++]; else { z[i] = 0.0; if (r->overrun) *r->overrun = 1; } }
         return;
@@ -223,8 +238,15 @@ static void rng_normals(rng_t *r, int d, double *z) {
     r->n += 2 * (uint64_t)((d + 1) / 2);
 }
 
+/* First n draws of rand (0) / randexp (1) / randn (2) from the restated MersenneTwister(seed): known-answer tests (tests/test_julia_rng.py). */
+void orc_julia_draws(int64_t seed, int seeding, int kind, int64_t n, double *out) {
+    jl_mt_t m;
+    jl_mt_seed(&m, seed, seeding);
+    for (int64_t i = 0; i < n; ++i) out[i] = (kind == 0) ? jl_rand(&m) : (kind == 1) ? jl_randexp(&m) : jl_randn(&m);
+}
+
 void orc_rng_dump(uint64_t seed, int64_t chain, int kind, int64_t n_draw, double *out) {
-    rng_t r = { seed, (uint64_t)chain, 0, NULL, NULL, NULL, 0, 0, 0, 0, 0, 0, NULL };
+    rng_t r = { .seed = seed, .chain = (uint64_t)chain };
     if (kind == 2) { rng_normals(&r, (int)n_draw, out); return; }
     for (int64_t i = 0; i < n_draw; ++i) out[i] = (kind == 0) ? rng_uniform(&r) : rng_exp(&r);
 }
@@ -236,7 +258,7 @@ void orc_rng_dump(uint64_t seed, int64_t chain, int kind, int64_t n_draw, double
  * x_i = x_mean + x_scale z_i.  Mirrors pdmp_init_states_device (csrc/engine_api.hip) bit for bit. */
 void orc_init_states(uint64_t seed, int64_t chain0, int64_t C, int d, double x_mean, double x_scale, int v_kind, double *x, double *v) {
     for (int64_t c = 0; c < C; ++c) {
-        rng_t r = { seed, ((uint64_t)(chain0 + c)) | (1ull << 63), 0, NULL, NULL, NULL, 0, 0, 0, 0, 0, 0, NULL };
+        rng_t r = { .seed = seed, .chain = ((uint64_t)(chain0 + c)) | (1ull << 63) };
         double *xc = x + c * d, *vc = v + c * d;
         rng_normals(&r, d, xc);
         for (int i = 0; i < d; ++i) xc[i] = x_mean + x_scale * xc[i];
@@ -1114,7 +1136,19 @@ static int run_chain(const orc_config_t *cfg, ws_t *w, int64_t n_sk, uint64_t se
     const int d = w->d, n = w->n;
     const int64_t cap = cfg->max_iter_per_event > 0 ? cfg->max_iter_per_event : 1000000;
     int overrun = 0;
-    rng_t rng = { seed, chain, 0, NULL, NULL, NULL, 0, 0, 0, 0, 0, 0, &overrun };
+    rng_t rng = { .seed = seed, .chain = chain, .overrun = &overrun };
+    jl_mt_t jl_state;
+#define JL_COUNTS() do { if (cfg->julia_rng && cfg->jl_count) { int64_t *q_ = cfg->jl_count + 3 * (int64_t)chain; q_[0] = rng.je; q_[1] = rng.ju; q_[2] = rng.jn; } } while (0)
+    if (cfg->julia_rng) {                           /* chain c <- MersenneTwister(seed + c) */
+        jl_mt_seed(&jl_state, (int64_t)(seed + chain), cfg->julia_rng);
+        rng.jl = &jl_state;
+        if (cfg->jl_tape_exp) {
+            const int64_t c = (int64_t)chain;
+            rng.le = cfg->jl_tape_exp + c * cfg->jl_cap_exp; rng.ce = cfg->jl_cap_exp;
+            rng.lu = cfg->jl_tape_uni + c * cfg->jl_cap_uni; rng.cu = cfg->jl_cap_uni;
+            rng.ln = cfg->jl_tape_nrm + c * cfg->jl_cap_nrm; rng.cn = cfg->jl_cap_nrm;
+        }
+    } else
     if (cfg->tape_exp) {
         const int64_t c = (int64_t)chain;          /* tapes are indexed by the global chain id */
         rng.te = cfg->tape_exp + c * cfg->tape_n_exp; rng.ne = cfg->tape_n_exp;
@@ -1132,7 +1166,7 @@ static int run_chain(const orc_config_t *cfg, ws_t *w, int64_t n_sk, uint64_t se
     for (int64_t k = 0; k < n_sk; ++k) {
         int32_t errored = 0, rejected = 0, hits = 0; double ev[5] = { 0, 0, 0, 0, 0 };   /* :28-31 */
         if (until && k > 0) {
-            if (!(t < T_until)) { if (count_out) *count_out = k; return overrun ? -6 : 0; }   /* while state.t < T, :362 (T == 0: :350-353) */
+            if (!(t < T_until)) { if (count_out) *count_out = k; JL_COUNTS(); return overrun ? -6 : 0; }   /* while state.t < T, :362 (T == 0: :350-353) */
             memcpy(x_prev, w->x, (size_t)d * 8); memcpy(v_prev, w->v, (size_t)d * 8); memcpy(a_prev, w->actf, (size_t)d * 8);   /* :363-368 */
             t_prev = t;
         }
@@ -1291,6 +1325,7 @@ static int run_chain(const orc_config_t *cfg, ws_t *w, int64_t n_sk, uint64_t se
             if (HH) HH[k] = 0;
             if (IA) for (int i = 0; i < d; ++i) IA[(size_t)k * d + i] = (uint8_t)(w->actf[i] != 0.0);
             if (count_out) *count_out = k + 1;
+            JL_COUNTS();
             return overrun ? -6 : 0;
         }
         /* record!, Composites.jl:239-260 */
@@ -1309,7 +1344,9 @@ static int run_chain(const orc_config_t *cfg, ws_t *w, int64_t n_sk, uint64_t se
     if (until) {                                    /* the capacity ran out (or the last column sits at t >= T exactly) */
         if (count_out) *count_out = (t < T_until) ? -n_sk - 1 : n_sk;
     }
+    JL_COUNTS();
     return overrun ? -6 : 0;
+#undef JL_COUNTS
 }
 
 static int sample_skeleton_impl(const orc_config_t *cfg_in, int64_t C, int64_t n_sk, int64_t chain_id_offset,

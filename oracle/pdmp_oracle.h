@@ -73,6 +73,17 @@ typedef struct orc_config_t {
     double  rh_step_size, rh_phi;
     double  fe_speed_factor;     /* ForwardECMC speed_factor (ForwardEventChainMonteCarlo.jl:177-218); 0 -> 1.0 */
     uint8_t *is_active_out;      /* StickyZigZag: PDMPHistory.is_active (Composites.jl:142,256), d x n_sk x C bytes, or NULL */
+    /* Julia random source (oracle/julia_rng.c): 0 = off (Philox or tapes); JL_SEED_LIMBS (1) / JL_SEED_SHA256 (2): chain c draws
+     * from MersenneTwister(seed + c) -- the reference's own idiom for many chains, `seed = 42 + i`, test/test_property_based.jl:138 -- seeded as
+     * Julia 1.0 - 1.10 / as Julia 1.11, through randexp / rand / randn in the reference's program order: one stream for the
+     * three kinds, as in the reference.  Unverified against a running Julia. */
+    int32_t julia_rng;
+    int32_t pad0_;
+    /* ... and, when jl_tape_exp is set, the variates every chain consumed, per kind in consumption order: chain c (global id) at c * jl_cap_*,
+     * its counts at jl_count[3 c + kind] -- the tapes pdmp_set_tape replays on the engine.  A chain that overruns a capacity returns -6. */
+    double *jl_tape_exp, *jl_tape_uni, *jl_tape_nrm;
+    int64_t jl_cap_exp, jl_cap_uni, jl_cap_nrm;
+    int64_t *jl_count;
 } orc_config_t;
 
 const char *orc_last_error(void);
@@ -124,6 +135,7 @@ void   orc_sincos(double x, double *s, double *c);
 void   orc_sincos_2pi(double u, double *s, double *c);
 /* first n_draw variates of chain stream (seed, chain): kind 0 uniform, 1 exp, 2 normal-vector (d=n_draw) */
 void   orc_rng_dump(uint64_t seed, int64_t chain, int kind, int64_t n_draw, double *out);
+void   orc_julia_draws(int64_t seed, int seeding, int kind, int64_t n, double *out);   /* rand / randexp / randn of the restated MersenneTwister(seed) */
 /* Synthetic initial states from stream 1 of each chain's key; mirrors pdmp_init_states_device. */
 enum { ORC_V_RADEMACHER = 0, ORC_V_GAUSSIAN = 1, ORC_V_SPHERE = 2 };
 void   orc_init_states(uint64_t seed, int64_t chain0, int64_t C, int d, double x_mean, double x_scale, int v_kind, double *x, double *v);

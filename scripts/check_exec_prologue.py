@@ -8,7 +8,10 @@ import re, sys
 VALU = re.compile(r'^(v_|global_|buffer_|ds_|flat_|scratch_)')
 COPIES = ('v_accvgpr_write_b32', 'v_accvgpr_read_b32', 'v_accvgpr_mov_b32')      # (v_mov copies in this position are also the program's own: ends of `then` blocks)
 LANEOPS = ('v_writelane_b32', 'v_readlane_b32', 'v_readfirstlane_b32')
+import os
 ALLOW = ()          # (kernel-name substring, block label or '*'): blocks reviewed by hand and found benign -- none today
+# (PDMP_EXEC_PROLOGUE_ALLOW="kernel-substring:label,..." adds entries for one build: a reviewed block while the list above is being updated)
+ALLOW += tuple(tuple(e.split(':', 1)) for e in os.environ.get('PDMP_EXEC_PROLOGUE_ALLOW', '').split(',') if ':' in e)
 bad = 0
 for fn in sys.argv[1:]:
     kernel, block, pending = None, None, []

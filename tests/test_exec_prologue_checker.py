@@ -37,7 +37,19 @@ _ZN4pdmp11lane_kernelILi0ELi13ELb1ELb0ELi1ELi4EEEvNS_11GroupParamsEPKi:
 	v_readlane_b32 s16, v254, 4
 	s_or_b64 exec, exec, s[12:13]
 	v_accvgpr_write_b32 a30, v96            ; after the restore: every lane
-.LBB1_11:                               ; the end of a `then` block laid out behind its join: real work in front of the restore
+.LBB1_11:                               ; a block that sets its own mask before it copies: the join's prologue ends at the exec write
+	v_cmp_lt_i32_e32 vcc, 0, v51
+	s_and_saveexec_b64 s[0:1], vcc
+	v_accvgpr_read_b32 v2, a22
+	s_or_b64 exec, exec, s[0:1]
+	s_endpgm
+"""
+
+# round 4 (fail closed): a prologue that MIXES the allocator's copies with other vector work is flagged too -- round 3's rule wanted copies
+# only and would have let it through; a block reviewed by hand is let through by name
+MIXED = """
+_ZN4pdmp11lane_kernelILi2ELi13ELb1ELb0ELi1ELi4EEEvNS_11GroupParamsEPKi:
+.LBB3_7:
 	v_add_f64 v[12:13], v[8:9], -v[14:15]
 	v_accvgpr_write_b32 a5, v12
 	s_or_b64 exec, exec, s[16:17]
@@ -60,3 +72,12 @@ def test_checker_flags_the_miscompiled_join(tmp_path):
 def test_checker_passes_harmless_neighbours(tmp_path):
     r = _run(tmp_path, GOOD, "good.s")
     assert r.returncode == 0 and r.stdout == ""
+
+
+def test_checker_fails_closed_on_a_mixed_prologue_and_honours_the_allow_list(tmp_path):
+    r = _run(tmp_path, MIXED, "mixed.s")
+    assert r.returncode == 1 and ".LBB3_7" in r.stdout
+    f = tmp_path / "mixed.s"
+    ok = subprocess.run([sys.executable, CHECK, str(f)], capture_output=True, text=True,
+                        env=dict(os.environ, PDMP_EXEC_PROLOGUE_ALLOW="lane_kernelILi2ELi13:.LBB3_7"))
+    assert ok.returncode == 0 and ok.stdout == ""

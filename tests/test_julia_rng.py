@@ -1,0 +1,87 @@
+"""oracle/julia_rng.c -- Julia's MersenneTwister(seed) with rand / randexp / randn, restated from the published algorithms (dSFMT-19937,
+Marsaglia-Tsang ziggurat with Julia's tables, SHA-256 seeding of 1.11) as a TAPE PRODUCER for the checker.
+Pinned here by every known answer that could be recalled without a Julia at hand -- values printed in Julia's own documentation and
+countless forum posts for the pre-1.11 seeding, entries of the literal tables of Random/src/normal.jl, the FIPS 180 vectors -- and by
+the round trip through the tape replay.  Unverified against a running Julia: the SHA-256 seeding of 1.11 and the draws inside the
+ziggurat's unlikely branches."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def test_mersenne_twister_known_answers(oracle):
+    O = oracle
+    # rand(MersenneTwister(1234), 5) of Julia 0.4 - 1.10 (docs of Random.seed!, the manual's "Random numbers" page)
+    assert O.julia_draws(1234, 5, "rand").tolist() == [0.5908446386657102, 0.7667970365022592, 0.5662374165061859, 0.4600853424625171,
+                                                       0.7940257103317943]
+    assert O.julia_draws(0, 1, "rand")[0] == 0.8236475079774124
+    assert O.julia_draws(1, 2, "rand").tolist() == [0.23603334566204692, 0.34651701419196046]
+    # randn(MersenneTwister(1234), 4)
+    assert O.julia_draws(1234, 4, "randn").tolist() == [0.8673472019512456, -0.9017438158568171, -0.4944787535042339, -0.9029142938652416]
+
+
+def test_ziggurat_tables_match_normal_jl_entries(oracle):
+    L = oracle.lib()
+    u64p, dp = C.POINTER(C.c_uint64), C.POINTER(C.c_double)
+    ki, wi, fi, ke, we, fe = u64p(), dp(), dp(), u64p(), dp(), dp()
+    L.jl_zig_tables(C.byref(ki), C.byref(wi), C.byref(fi), C.byref(ke), C.byref(we), C.byref(fe))
+    # 1-based in Julia: ki[1], ki[2], ki[3], ki[4]; ke[1..3]; the first widths
+    assert [ki[i] for i in range(4)] == [0x0007799EC012F7B2, 0, 0x0006045F4C7DE363, 0x0006D1AA7D5EC0A5]
+    assert [ke[i] for i in range(3)] == [0x000E290A13924BE3, 0, 0x0009BEADEBCE18BF]
+    assert (wi[0], wi[1]) == (1.7367254121602630e-15, 9.5586603514556339e-17)
+    assert (we[0], we[1]) == (1.9311480126418366e-15, 1.4178028487910829e-17)
+    assert fi[0] == 1.0 and fe[0] == 1.0
+    kin = np.array([ki[i] for i in range(256)], dtype=np.uint64)
+    assert (kin[2:] < 2 ** 51).all() and (np.diff(np.array([fi[i] for i in range(256)])) < 0).all()   # strips: f decreasing from 1
+
+
+def test_sha256_vectors(oracle):
+    L = oracle.lib()
+    out = (C.c_uint8 * 32)()
+    L.jl_sha256(b"abc", 3, out)
+    assert bytes(out).hex() == "ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad"
+    L.jl_sha256(b"", 0, out)
+    assert bytes(out).hex() == "e3b0c44298fc1c149afbf4c8996fb92427ae41e4649b934ca495991b7852b855"
+    msg = b"abcdbcdecdefdefgefghfghighijhijkijkljklmklmnlmnomnopnopq"
+    L.jl_sha256(msg, len(msg), out)
+    assert bytes(out).hex() == "248d6a61d20638b8e5c026930c3e6039a33ce45964ff2167f6ecedd419db06c1"
+
+
+def test_variate_distributions(oracle):
+    O = oracle
+    for seeding in (O.JL_SEED_LIMBS, O.JL_SEED_SHA256):
+        e = O.julia_draws(7, 200000, "randexp", seeding)
+        z = O.julia_draws(7, 200000, "randn", seeding)
+        u = O.julia_draws(7, 200000, "rand", seeding)
+        assert abs(e.mean() - 1.0) < 0.01 and abs(e.var() - 1.0) < 0.03 and e.min() > 0
+        assert abs(z.mean()) < 0.01 and abs(z.var() - 1.0) < 0.02 and abs((z ** 4).mean() - 3.0) < 0.1
+        assert abs(u.mean() - 0.5) < 0.005 and 0.0 <= u.min() and u.max() < 1.0
+        assert (e > 7.69711747013105).sum() > 20 and (np.abs(z) > 3.6541528853610088).sum() > 20     # the tails of both ziggurats are reached
+    assert not np.array_equal(O.julia_draws(7, 8, "rand", O.JL_SEED_LIMBS), O.julia_draws(7, 8, "rand", O.JL_SEED_SHA256))
+
+
+@pytest.mark.parametrize("kind,dim,target,kw", [("zigzag", 10, "iso", {}), ("bps", 8, "banana", {"refresh_rate": 0.5, "tmax": 1.0}),
+                                                ("boomerang", 6, "iso", {"refresh_rate": 0.3, "tmax": 1.0})])
+def test_julia_source_run_replays_from_its_tapes(oracle, kind, dim, target, kw):
+    """A run of the checker on the Julia source logs the variates it consumed; replayed from those tapes (the path a dump of a real Julia
+    run takes, julia/dump_tape.jl) the checker reproduces the run bit for bit -- one interleaved stream in, three tapes out."""
+    O = oracle
+    sid = {"zigzag": O.ZIGZAG, "bps": O.BPS, "boomerang": O.BOOMERANG}[kind]
+    tid = {"iso": O.T_GAUSS_ISO, "banana": O.T_BANANA}[target]
+    cfg = O.Config(sampler=sid, dim=dim, target_id=tid, vectorized_bound=(sid == O.ZIGZAG), **kw)
+    rs = np.random.default_rng(3)
+    x, v = rs.normal(size=(4, dim)), (rs.choice([-1.0, 1.0], size=(4, dim)) if sid == O.ZIGZAG else rs.normal(size=(4, dim)))
+    a = O.sample_skeleton_julia(cfg, 60, x, v, 42)
+    cnt = a["tape_counts"]
+    assert (cnt[:, 0] >= 59).all() and (cnt[:, 1] >= 59).all()
+    if sid != O.ZIGZAG:
+        assert (cnt[:, 2] > 0).any() and (cnt[:, 2] % dim == 0).all()          # refreshes draw whole vectors
+    kwargs = {k: getattr(cfg, k) for k in cfg.__dataclass_fields__ if k != "_keep"}
+    kwargs["tape"] = tuple(t[:, :max(int(cnt[:, q].max()), 1)] for q, t in enumerate(a["tape"]))
+    b = O.sample_skeleton(O.Config(**kwargs), 60, x, v, 0)
+    for k in ("X", "V", "t", "rejected", "hitting_horizon", "errored_bound"):
+        assert np.array_equal(a[k], b[k]), k
+    # chain c draws from MersenneTwister(seed + c): chain 1 of seed 42 is chain 0 of seed 43
+    c = O.sample_skeleton_julia(cfg, 60, x[1:2], v[1:2], 43)
+    assert np.array_equal(c["t"][0], a["t"][1])
