@@ -507,6 +507,9 @@ def main():
         reg_form = (G > 0 and sid in (0, 1, 2) and K <= 13 and G <= 16 and K >= 2 and a.target in ("iso", "diag", "banana")
                     and not (sid == 0 and fd) and not (sid == 2 and K != 13 and K < 7) and not (small_k and (fd or sid == 2))
                     and os.environ.get("PDMP_REG", "1") != "0")
+        if sid == 5:                                              # RHMC (round 4): FULL 13-slot kernels on iso / banana, partial ones on diag
+            reg_form = (G > 0 and G <= 16 and os.environ.get("PDMP_REG", "1") != "0" and
+                        ((a.target in ("iso", "banana") and K == 13) or (a.target == "diag" and K <= 13 and (G == 1 or K >= 7))))
         kernel = (f"group_kernel_reg<{sampler.name},{a.target}> (G={G} lanes per chain, K={K} slots, x and v in registers)" if reg_form else
                   f"group_kernel<{sampler.name},{a.target}> (G={G} lanes per chain)" if G > 0 else
                   f"skeleton_kernel<{sampler.name},{a.target}> (wave per chain)")

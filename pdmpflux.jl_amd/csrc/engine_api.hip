@@ -23,6 +23,7 @@ hipError_t launch_lane2q_zigzag(int target, const GroupParams &gp, const int32_t
 hipError_t launch_group_reg_zigzag(int target, bool fd, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_bps(int target, bool fd, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_boomerang(int target, bool fd, const GroupParams &gp, hipStream_t stream);
+hipError_t launch_group_reg_rhmc(int target, const GroupParams &gp, hipStream_t stream);                        // inst_reg_rhmc.hip
 hipError_t launch_group_reg_zigzag_exact(int target, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_bps_exact(int target, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_boomerang_exact(int target, const GroupParams &gp, hipStream_t stream);
@@ -1199,7 +1200,8 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
         hipError_t e = hipErrorNotSupported;
         h->last_form = PDMP_FORM_GROUP_REG;
         // register form: the default bound flags only (grid_size = 10; Zig-Zag: vectorized signed bound) -- GroupChain::brent() etc.
-        const bool reg_flags = c.grid_size == GNG && (c.sampler != PDMP_ZIGZAG || (c.vectorized_bound && c.signed_bound));
+        const bool reg_flags = c.sampler == PDMP_RHMC ||        // (RHMC: its bound is the constant refresh clock whatever the flags)
+                               (c.grid_size == GNG && (c.sampler != PDMP_ZIGZAG || (c.vectorized_bound && c.signed_bound)));
         if (pol.reg && reg_flags) {
             const bool fd = c.deriv_mode != 0;
             // Large Zig-Zag ensembles at d = 49..52 on the isotropic Gaussian / banana: one LANE per chain (lane_kernel.hpp), bit-identical
@@ -1267,6 +1269,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
                 e = c.sampler == PDMP_ZIGZAG    ? launch_group_reg_zigzag(c.target_id, fd, gp, s)
                   : c.sampler == PDMP_BPS       ? launch_group_reg_bps(c.target_id, fd, gp, s)
                   : c.sampler == PDMP_BOOMERANG ? launch_group_reg_boomerang(c.target_id, fd, gp, s)
+                  : c.sampler == PDMP_RHMC      ? launch_group_reg_rhmc(c.target_id, gp, s)      // round 4: FULL 13-slot kernels (iso, banana), partial ones (diag)
                                                 : hipErrorNotSupported;
         }
         if (e == hipErrorNotSupported) {

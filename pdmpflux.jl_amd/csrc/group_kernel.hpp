@@ -1459,10 +1459,16 @@ struct GroupChain {
                 r_normal_pair(P, z0, z1);
                 const int i0 = 2 * P, i1 = 2 * P + 1;
                 const int o0 = (i0 >> logG) * WAVE + base + (i0 & (G - 1)), o1 = (i1 >> logG) * WAVE + base + (i1 & (G - 1));
-                vs[o0] = cphi * vs[o0] + sphi * z0;
-                if (i1 < d) vs[o1] = cphi * vs[o1] + sphi * z1;
+                if constexpr (kReg) {            // register form: v lives in registers; the normals cross the lanes through the exchange tile
+                    vs[o0] = z0;
+                    if (i1 < d) vs[o1] = z1;
+                } else {
+                    vs[o0] = cphi * vs[o0] + sphi * z0;
+                    if (i1 < d) vs[o1] = cphi * vs[o1] + sphi * z1;
+                }
             }
             r_normals_done(d);
+            if constexpr (kReg) { PDMP_SLOTS(s) { const int i = s * G + g; if (in_dim(s, i)) V(s) = cphi * V(s) + sphi * vs[s * WAVE + lane]; } }   // (the same expression per coordinate)
             return false;
         } else if constexpr (SAMPLER == S_FECMC) {
             return fecmc_jump(sh);
@@ -2018,11 +2024,19 @@ __global__ __launch_bounds__(256, 1) void group_kernel_reg_tape(const GroupParam
 // instantiation spills a VGPR (see below), and from measurements (Zig-Zag with finite differences: the LDS form is faster).
 template <int SAMPLER, int TARGET, bool FD> struct RegForm {
     static constexpr bool kSlowZz = SAMPLER == S_ZIGZAG && FD;                       // measured: 88 ms against 73 ms in the LDS form
-    static constexpr bool kPartial = !kSlowZz && !(SAMPLER == S_BOOMERANG && TARGET != T_GAUSS_DIAG);   // would spill: Boomerang iso / banana with the skips
+    // RHMC (round 4): the FULL 13-slot kernels are free of spills on the isotropic Gaussian and the banana, the ones with the per-slot
+    // skips on the diagonal Gaussian (FULL there spills 2 - 4 registers with the diagnostic arrays compiled in); the slope mode plays no
+    // part in RHMC (constant refresh clock): only FD = false is instantiated.  SpeedUpZigZag spills 110 - 700 registers in every variant
+    // at two waves per SIMD (its flow and effective gradient on forward-mode numbers) and still 30 -- into AGPRs -- at one wave per SIMD
+    // (tried in round 4; a spill is not allowed here, see below): LDS form only, like ForwardECMC (six tiles).
+    static constexpr bool kRhmc = SAMPLER == S_RHMC;
+    static constexpr bool kPartial = kRhmc ? (TARGET == T_GAUSS_DIAG)
+                                           : (!kSlowZz && !(SAMPLER == S_BOOMERANG && TARGET != T_GAUSS_DIAG));   // would spill: Boomerang iso / banana with the skips
     template <int GC> static constexpr bool full() {        // would spill: Zig-Zag and (since the time-horizon stop of round 3) Boomerang on the diagonal Gaussian at one lane per chain
+        if constexpr (kRhmc) return !(TARGET == T_GAUSS_DIAG && GC >= 2);
         return !kSlowZz && !((SAMPLER == S_ZIGZAG || SAMPLER == S_BOOMERANG) && TARGET == T_GAUSS_DIAG && GC == 1);
     }
-    static constexpr bool kAny = !kSlowZz && SAMPLER != S_FECMC;
+    static constexpr bool kAny = !kSlowZz && SAMPLER != S_FECMC && SAMPLER != S_SUZZ && SAMPLER != S_STICKY && !(kRhmc && FD);
 };
 
 // register form (x, v in VGPRs, up to KC slots per lane, G fixed at compile time): no LDS tiles; 2 waves per SIMD -- the

@@ -39,9 +39,14 @@ def test_engine_replays_the_julia_source(engine, oracle, monkeypatch, kind, dim,
     kw_ref = {k: getattr(cfg, k) for k in cfg.__dataclass_fields__ if k != "_keep"}
     kw_ref.update(arith=O.ARITH_REFERENCE, group_lanes=1)
     r0 = O.sample_skeleton_julia(O.Config(**kw_ref), n_sk, x, v, 42, seeding=mode)
-    same = (np.array_equal(r0["rejected"], got["rejected"]) and np.array_equal(r0["hitting_horizon"], got["hitting_horizon"]))
-    if same:                                                                      # (a fork -- a 1-ulp difference on the other side of a comparison -- is legitimate but rare)
-        assert np.allclose(got["t"], r0["t"], rtol=1e-5, atol=1e-12) and np.allclose(got["X"], r0["X"], rtol=1e-5, atol=1e-9)
+    # per chain: the first event where a recorded decision or a value (1e-5 relative) differs between the two orders -- a fork: a 1-ulp
+    # difference landing on the other side of a comparison, after which the two runs are different, equally valid realisations
+    # (reflections amplify rounding: BPS / Boomerang share a long prefix, Zig-Zag chains do not fork at this length)
+    dec = (r0["rejected"] != got["rejected"]) | (r0["hitting_horizon"] != got["hitting_horizon"]) | (r0["errored_bound"] != got["errored_bound"])
+    val = ~np.isclose(got["t"], r0["t"], rtol=1e-5, atol=1e-12) | ~np.isclose(got["X"], r0["X"], rtol=1e-5, atol=1e-9).all(axis=2)
+    bad = dec | val
+    first = np.where(bad.any(axis=1), bad.argmax(axis=1), n_sk)
+    if kind.startswith("ZigZag"):
+        assert (first == n_sk).mean() >= 0.95, first
     else:
-        agree = (r0["rejected"] == got["rejected"]).all(axis=1).mean()
-        assert agree > 0.9, f"only {agree:.2f} of the chains make the same decisions in engine order and reference order"
+        assert np.median(first) >= 40, first
