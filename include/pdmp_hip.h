@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PDMP_ABI_VERSION 8   /* 8: + the time horizon as a kernel feature (pdmp_sample_skeleton_until_device, pdmp_close_chunk_device, pdmp_until_advance_device, pdmp_compact_chunk_device); tape replay on every kernel form; 7: + pdmp_last_launch_form; 6: is_active / ragged lengths in sample_from_skeleton*, moments and close_at; + the (N, dt) method, pdmp_compact_*, pdmp_multi_*; 5: + PDMP_STICKY, pdmp_diag_t.is_active; 2: + pdmp_create_from_source, PDMP_T_USER; 3: + PDMP_FECMC and its keywords at the end of pdmp_config_t; 4: + PDMP_SUZZ, PDMP_RHMC and its keywords */
+#define PDMP_ABI_VERSION 9   /* 9: + pdmp_device_alloc / pdmp_device_free (output arrays from independent physical chunks), pdmp_init_states_device, pdmp_multi_sample_skeleton_device / pdmp_multi_init_states, pdmp_reload_policy (launch policy fixed per handle); 8: + the time horizon as a kernel feature (pdmp_sample_skeleton_until_device, pdmp_close_chunk_device, pdmp_until_advance_device, pdmp_compact_chunk_device); tape replay on every kernel form; 7: + pdmp_last_launch_form; 6: is_active / ragged lengths in sample_from_skeleton*, moments and close_at; + the (N, dt) method, pdmp_compact_*, pdmp_multi_*; 5: + PDMP_STICKY, pdmp_diag_t.is_active; 2: + pdmp_create_from_source, PDMP_T_USER; 3: + PDMP_FECMC and its keywords at the end of pdmp_config_t; 4: + PDMP_SUZZ, PDMP_RHMC and its keywords */
 
 enum { PDMP_OK = 0, PDMP_ERR_ARGUMENT = -1, PDMP_ERR_DIMENSION = -2, PDMP_ERR_RUNTIME = -3,
        PDMP_ERR_ITERCAP = -4, PDMP_ERR_UNSUPPORTED = -5 };

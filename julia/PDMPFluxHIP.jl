@@ -19,7 +19,7 @@ using PDMPFlux: AbstractPDMP, PDMPHistory
 import PDMPFlux: sample, sample_skeleton, sample_from_skeleton
 
 const LIB = get(ENV, "PDMPHIP_LIB", "libpdmphip.so")
-const ABI_VERSION = 8
+const ABI_VERSION = 9
 
 # ---------------------------------------------------------------------------------------------- C structs (include/pdmp_hip.h)
 struct Config   # pdmp_config_t
@@ -347,6 +347,38 @@ function sample_skeleton!(m::MultiSampler, X::Vector, V::Vector, t::Vector, xini
         m.handle, C, n_sk, chain_id_offset, xinit, vinit, seed_word(seed), gather, px, pv, pt))
     return nothing
 end
+
+# ---- ABI 9: device-resident initial states, chunked device memory for the output arrays, the launch policy
+# Shards of the initial states already on their devices: xinit[r], vinit[r] = d x len_r device arrays on device r (no PCIe staging per call).
+function sample_skeleton_device!(m::MultiSampler, X::Vector, V::Vector, t::Vector, xinit::Vector, vinit::Vector, C::Int, n_sk::Int;
+                                 seed::Int, chain_id_offset::Int=0, gather::Bool=true)
+    px, pv, pt = [Ptr{Cvoid}(pointer(a)) for a in X], [Ptr{Cvoid}(pointer(a)) for a in V], [Ptr{Cvoid}(pointer(a)) for a in t]
+    ix, iv = [Ptr{Cvoid}(pointer(a)) for a in xinit], [Ptr{Cvoid}(pointer(a)) for a in vinit]
+    GC.@preserve px pv pt ix iv check(ccall((:pdmp_multi_sample_skeleton_device, LIB), Cint,
+        (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, UInt64, Int32, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}),
+        m.handle, C, n_sk, chain_id_offset, ix, iv, seed_word(seed), gather, px, pv, pt))
+    return nothing
+end
+# Synthetic initial states on the device (BASELINE.md section 3): x = x_mean + x_scale N(0, I); v_kind 0: +-1 coordinates, 1: N(0, I),
+# 2: uniform on the unit sphere -- from stream 1 of each chain's Philox key (seed, chain id), the chains' own draws come from stream 0.
+function init_states_device!(s::HIPSampler, xinit, vinit; seed::Int, chain_id_offset::Int=0, x_mean::Float64=0.0, x_scale::Float64=1.0,
+                             v_kind::Int=0, stream=C_NULL)
+    d, C = size(xinit)
+    check(ccall((:pdmp_init_states_device, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, UInt64, Cdouble, Cdouble, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                s.handle, C, chain_id_offset, seed_word(seed), x_mean, x_scale, v_kind, pointer(xinit), pointer(vinit), stream))
+    return nothing
+end
+# Device memory built from independent 1-GiB physical chunks for the large output arrays (DESIGN.md section 6): wrap the pointer with
+# `unsafe_wrap(ROCArray, Ptr{Float64}(p), dims)`; release with device_free (waits for the device first).
+function device_alloc(bytes::Integer; device::Int=-1, chunk_bytes::Integer=0)
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:pdmp_device_alloc, LIB), Cint, (Int32, Csize_t, Csize_t, Ref{Ptr{Cvoid}}), device, bytes, chunk_bytes, p)
+    rc == 0 || error(unsafe_string(ccall((:pdmp_device_alloc_error, LIB), Cstring, ())))
+    return p[]
+end
+device_free(p::Ptr{Cvoid}) = ccall((:pdmp_device_free, LIB), Cint, (Ptr{Cvoid},), p)
+# The PDMP_* environment overrides of the launch policy are read once, when the handle is created; re-read them after changing ENV.
+reload_policy!(s::HIPSampler) = check(ccall((:pdmp_reload_policy, LIB), Cint, (Ptr{Cvoid},), s.handle))
 
 # ---------------------------------------------------------------------------------------------- time horizon for an ensemble (ABI 8)
 # sample_skeleton(sampler, T::Float64, xinit, vinit; seed, init_capacity) (src/sample.jl:323-439) for C chains held in HBM, with the time

@@ -140,7 +140,7 @@ def lib():
     L.pdmp_dense_batched_last_phases.restype = C.c_longlong
     L.pdmp_dense_batched_last_columns.restype = C.c_longlong
     L.pdmp_dense_batched_last_mode.restype = C.c_int
-    if L.pdmp_abi_version() != 8:
+    if L.pdmp_abi_version() != 9:
         raise EngineError(ERR_RUNTIME, "ABI version mismatch")
     _lib = L
     return L
