@@ -400,9 +400,14 @@ def main():
     set_bytes = 8 * rows * n_sk * (2 * d + 1)
     allocator = a.alloc if a.alloc != "auto" else ("chunked" if world == 1 else "hipmalloc")
 
+    alloc_log = []                                               # per allocation: what the product's allocator drew and measured
+
     def alloc_set(kind):
-        if kind == "chunked":
-            return ensemble.alloc_outputs(rows, n_sk, d, device=dev, chunked=True)
+        if kind in ("chunked", "chunked_one_draw"):              # the product's allocator (up to three draws, the fastest kept) / a single draw
+            o = ensemble.alloc_outputs(rows, n_sk, d, device=dev, chunked=True, draws=None if kind == "chunked" else 1)
+            alloc_log.append(dict(ensemble.last_alloc_info))
+            return o
+        alloc_log.append({})
         return {"X": torch.empty((rows, n_sk, d), dtype=torch.float64, device=dev), "V": torch.empty((rows, n_sk, d), dtype=torch.float64, device=dev),
                 "t": torch.empty((rows, n_sk), dtype=torch.float64, device=dev)}
 
@@ -455,7 +460,7 @@ def main():
     for k in range(n_sets):
         mine = [m for i, m in enumerate(step_ms) if (a.warmup + i) % n_sets == k]
         if mine:
-            placement.append({"allocator": allocator, "in_timed_region": True, "launches": len(mine), "kernel_ms": [round(m, 3) for m in mine]})
+            placement.append({"allocator": allocator, "in_timed_region": True, "launches": len(mine), "kernel_ms": [round(m, 3) for m in mine], "alloc": alloc_log[k]})
     from pdmpflux.jl_amd import _lib
     _lib.check(_lib.lib().pdmp_check_status(sampler.handle(), None))
     tm = ensemble.kernel_timing(sampler)
@@ -487,10 +492,10 @@ def main():
         del full, own, tt
         sets.clear()
         torch.cuda.empty_cache()
-        for kind in ("chunked", "hipmalloc", "chunked", "hipmalloc", "chunked"):
+        for kind in ("chunked", "hipmalloc", "chunked_one_draw", "hipmalloc", "chunked"):
             cur = alloc_set(kind)
             ms = timed_launches(cur, 4, 1000 + 10 * len(placement))[1:]
-            placement.append({"allocator": kind, "in_timed_region": False, "launches": len(ms), "kernel_ms": [round(m, 3) for m in ms]})
+            placement.append({"allocator": kind, "in_timed_region": False, "launches": len(ms), "kernel_ms": [round(m, 3) for m in ms], "alloc": alloc_log[-1]})
             del cur
             torch.cuda.empty_cache()
     if rank == 0:
@@ -541,13 +546,13 @@ def main():
                        "exchange": "none" if gather != "skeleton" else
                                    f"one all-gather each of the X, V, t shards per step (RCCL, in place): {xbytes} bytes received per GPU per step",
                        "exchange_bytes_per_gpu": xbytes,
-                       "allocator": ("ensemble.alloc_outputs: X, V, t built from independent 1-GiB physical chunks (pdmp_device_alloc)" if allocator == "chunked"
+                       "allocator": ("ensemble.alloc_outputs: X, V, t built from independent 1-GiB physical chunks, the set drawn up to three times and the one a store-pattern kernel writes fastest kept (pdmp_device_alloc_streams)" if allocator == "chunked"
                                      else "torch.empty (hipMalloc)"),
                        "allocation_sets": n_sets,
                        "placement_ms": placement,
                        "placement_note": ("per fresh allocation of X, V, t: hipEvent-timed launches (ms, incl. the exchange when N > 1).  `value` covers every step of the "
                                           "timed region = the FIRST allocation(s) this process made (in_timed_region true; a rule, not a choice); the others are the untimed "
-                                          "survey run afterwards: five more fresh allocations, three from the product's allocator and two from hipMalloc (the placement "
+                                          "survey run afterwards: five more fresh allocations -- two from the product's allocator, one single draw of it without selection (chunked_one_draw), two from hipMalloc; `alloc`: the draws the allocator timed with its store-pattern kernel, ms, and what the allocation cost in seconds (the placement "
                                           "lottery of DESIGN.md 6).  all_allocations_ms: mean launch time over every allocation listed"),
                        "all_allocations_ms": (sum(sum(q["kernel_ms"]) / len(q["kernel_ms"]) for q in placement) / len(placement)) if placement else None,
                        "kernel_ms_max_over_ranks": kernel_ms_max,

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PDMP_ABI_VERSION 9   /* 9: + pdmp_device_alloc / pdmp_device_free (output arrays from independent physical chunks), pdmp_init_states_device, pdmp_multi_sample_skeleton_device / pdmp_multi_init_states, pdmp_reload_policy (launch policy fixed per handle); 8: + the time horizon as a kernel feature (pdmp_sample_skeleton_until_device, pdmp_close_chunk_device, pdmp_until_advance_device, pdmp_compact_chunk_device); tape replay on every kernel form; 7: + pdmp_last_launch_form; 6: is_active / ragged lengths in sample_from_skeleton*, moments and close_at; + the (N, dt) method, pdmp_compact_*, pdmp_multi_*; 5: + PDMP_STICKY, pdmp_diag_t.is_active; 2: + pdmp_create_from_source, PDMP_T_USER; 3: + PDMP_FECMC and its keywords at the end of pdmp_config_t; 4: + PDMP_SUZZ, PDMP_RHMC and its keywords */
+#define PDMP_ABI_VERSION 10   /* 10: + pdmp_device_alloc_streams (the streamed output arrays drawn several times, the fastest set kept); 9: + pdmp_device_alloc / pdmp_device_free (output arrays from independent physical chunks), pdmp_init_states_device, pdmp_multi_sample_skeleton_device / pdmp_multi_init_states, pdmp_reload_policy (launch policy fixed per handle); 8: + the time horizon as a kernel feature (pdmp_sample_skeleton_until_device, pdmp_close_chunk_device, pdmp_until_advance_device, pdmp_compact_chunk_device); tape replay on every kernel form; 7: + pdmp_last_launch_form; 6: is_active / ragged lengths in sample_from_skeleton*, moments and close_at; + the (N, dt) method, pdmp_compact_*, pdmp_multi_*; 5: + PDMP_STICKY, pdmp_diag_t.is_active; 2: + pdmp_create_from_source, PDMP_T_USER; 3: + PDMP_FECMC and its keywords at the end of pdmp_config_t; 4: + PDMP_SUZZ, PDMP_RHMC and its keywords */
 
 enum { PDMP_OK = 0, PDMP_ERR_ARGUMENT = -1, PDMP_ERR_DIMENSION = -2, PDMP_ERR_RUNTIME = -3,
        PDMP_ERR_ITERCAP = -4, PDMP_ERR_UNSUPPORTED = -5 };
@@ -336,6 +336,17 @@ int pdmp_dense_batched_last_mode(void);
  * device = -1: the current device.  Errors: PDMP_ERR_ARGUMENT / PDMP_ERR_RUNTIME with pdmp_device_alloc_error(). */
 int pdmp_device_alloc(int32_t device, size_t bytes, size_t chunk_bytes, void **out);
 int pdmp_device_free(void *ptr);
+
+/* The arrays one launch streams side by side (X, V of an ensemble first, then t and anything else), allocated like pdmp_device_alloc --
+ * and drawn up to `draws` times: how fast the event rows of X and V can be written depends on where their physical chunks lie relative
+ * to each other (14.3 ms or 17 - 19 ms for the same launch), a fresh set of chunks is a fresh draw, and a set can be
+ * judged in 20 ms by a kernel with the launch's store pattern (one 64-byte line of each chain's X row and V row per step, chains
+ * `stride_bytes` apart, 1 024 waves).  Every draw allocates all n arrays (as long as the free memory holds another set beside the best
+ * one so far), times that writer on arrays 0 and 1, and only the fastest set survives; draw_ms[k] (may be NULL, room for `draws`
+ * values) receives the times, *n_drawn how many sets were drawn.  draws <= 1 or n == 1: no measurement.  The arrays' contents are
+ * undefined afterwards.  Each returned pointer is released with pdmp_device_free.  stride_bytes = 8 n_sk dim for X, V (C, n_sk, dim). */
+int pdmp_device_alloc_streams(int32_t device, int32_t n, const size_t *bytes, size_t chunk_bytes, size_t stride_bytes, int32_t draws,
+                              void **out_ptrs, float *draw_ms, int32_t *n_drawn);
 const char *pdmp_device_alloc_error(void);
 
 /* Synthetic initial states of an ensemble, generated on the device (the ensemble API is new -- the reference starts its one chain

@@ -19,7 +19,7 @@ using PDMPFlux: AbstractPDMP, PDMPHistory
 import PDMPFlux: sample, sample_skeleton, sample_from_skeleton
 
 const LIB = get(ENV, "PDMPHIP_LIB", "libpdmphip.so")
-const ABI_VERSION = 9
+const ABI_VERSION = 10
 
 # ---------------------------------------------------------------------------------------------- C structs (include/pdmp_hip.h)
 struct Config   # pdmp_config_t
@@ -377,6 +377,19 @@ function device_alloc(bytes::Integer; device::Int=-1, chunk_bytes::Integer=0)
     return p[]
 end
 device_free(p::Ptr{Cvoid}) = ccall((:pdmp_device_free, LIB), Cint, (Ptr{Cvoid},), p)
+# X, V (d x n_sk x C) and t (n_sk x C) of an ensemble, drawn up to `draws` times: each draw a fresh set of chunks, judged by a kernel with
+# the launch's store pattern, the fastest set kept (ABI 10, DESIGN.md section 6b).  Returns the three pointers (release each with
+# device_free) and the time of every draw in ms.
+function alloc_outputs(d::Integer, n_sk::Integer, C::Integer; device::Int=-1, draws::Integer=3)
+    sizes = Csize_t[8 * d * n_sk * C, 8 * d * n_sk * C, 8 * n_sk * C]
+    ptrs = fill(C_NULL, 3)
+    ms = zeros(Cfloat, max(draws, 1))
+    drawn = Ref{Int32}(0)
+    rc = ccall((:pdmp_device_alloc_streams, LIB), Cint, (Int32, Int32, Ptr{Csize_t}, Csize_t, Csize_t, Int32, Ptr{Ptr{Cvoid}}, Ptr{Cfloat}, Ref{Int32}),
+               device, 3, sizes, 0, 8 * d * n_sk, draws, ptrs, ms, drawn)
+    rc == 0 || error(unsafe_string(ccall((:pdmp_device_alloc_error, LIB), Cstring, ())))
+    return (X = ptrs[1], V = ptrs[2], t = ptrs[3], draw_ms = draws > 1 ? ms[1:drawn[]] : Cfloat[])
+end
 # The PDMP_* environment overrides of the launch policy are read once, when the handle is created; re-read them after changing ENV.
 reload_policy!(s::HIPSampler) = check(ccall((:pdmp_reload_policy, LIB), Cint, (Ptr{Cvoid},), s.handle))
 

@@ -65,7 +65,7 @@ SYMBOLS = (
     "pdmp_sample_skeleton_until_device", "pdmp_close_chunk_device", "pdmp_until_advance_device", "pdmp_compact_chunk_device",
     "pdmp_multi_shard_range", "pdmp_multi_create", "pdmp_multi_destroy", "pdmp_multi_sample_skeleton", "pdmp_multi_sample_skeleton_device", "pdmp_multi_init_states", "pdmp_multi_get_timing",
     "pdmp_check_status", "pdmp_get_timing", "pdmp_reset_timing",
-    "pdmp_init_states_device", "pdmp_device_alloc", "pdmp_device_free", "pdmp_device_alloc_error", "pdmp_debug_rng", "pdmp_dense_batched_last_phases", "pdmp_dense_batched_last_columns", "pdmp_dense_batched_last_mode",
+    "pdmp_init_states_device", "pdmp_device_alloc", "pdmp_device_free", "pdmp_device_alloc_error", "pdmp_device_alloc_streams", "pdmp_debug_rng", "pdmp_dense_batched_last_phases", "pdmp_dense_batched_last_columns", "pdmp_dense_batched_last_mode",
 )
 
 _lib = None
@@ -136,11 +136,12 @@ def lib():
     L.pdmp_device_alloc.argtypes = [i32, C.c_size_t, C.c_size_t, C.POINTER(vp)]
     L.pdmp_device_free.argtypes = [vp]
     L.pdmp_device_alloc_error.restype = C.c_char_p
+    L.pdmp_device_alloc_streams.argtypes = [i32, i32, C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t, i32, C.POINTER(vp), C.POINTER(C.c_float), C.POINTER(i32)]
     L.pdmp_init_states_device.argtypes = [vp, i64, i64, u64, C.c_double, C.c_double, i32, vp, vp, vp]
     L.pdmp_dense_batched_last_phases.restype = C.c_longlong
     L.pdmp_dense_batched_last_columns.restype = C.c_longlong
     L.pdmp_dense_batched_last_mode.restype = C.c_int
-    if L.pdmp_abi_version() != 9:
+    if L.pdmp_abi_version() != 10:
         raise EngineError(ERR_RUNTIME, "ABI version mismatch")
     _lib = L
     return L

@@ -1,13 +1,15 @@
-// device_alloc.hip -- output arrays of an ensemble built from independent physical chunks (HIP virtual memory management).
+// device_alloc.hip -- output arrays of an ensemble built from independent physical chunks (HIP virtual memory management), and the
+// streamed arrays of an ensemble drawn several times with the fastest set kept.
 //
-// Why (profiles/r4/placement_*): a 40 GB array from hipMalloc is backed by a few huge physical blocks, and the
-// launch that streams the event rows of X and V side by side runs 14.4 ms or 18 ms depending on how those blocks happen to lie relative
-// to each other in the memory's channel / bank map (write requests then stall on DRAM credits 3 - 8 x as often: TCC_EA0_WRREQ_DRAM_
-// CREDIT_STALL 2.6e8 against 3 - 8e7 per launch; translation misses unchanged) -- one draw for the whole array, fast or slow for as long
-// as the allocation lives.  Built from 1-GiB chunks, every (X chunk, V chunk) pair draws on its own (3 % of the pairs are 6 - 13 % slower),
-// so the launch time concentrates: 14.4 - 14.75 ms in every one of thirty pools and mappings measured, no slow mode.  The chunks must not
-// be small either: below ~32 MiB of physically contiguous memory per translation the kernel's 131 000 concurrent write streams miss in the
-// translation caches (TCP_UTCL1_TRANSLATION_MISS 1.2e5 -> 7e7 .. 1.3e8 per launch; 16.0 ms at 16 MiB, 18.9 ms at 4 MiB, 22.5 ms at 2 MiB).
+// Why (profiles/r4/placement/): the launch that streams the event rows of X and V side by side runs 14.3 ms or
+// 17 - 19 ms depending on where the physical memory behind the two arrays lies -- chunks of the VRAM fall into a few classes (regions of
+// tens of GiB), an X chunk and the V chunk written together with it are 50 % slower when they come from the same class (write requests
+// then stall on DRAM credits 3 - 8 x as often; translation misses unchanged), and a hipMalloc'ed 40 GB array is a few huge blocks, so
+// the relation is drawn once for the whole array.  Nothing in user space says which class a chunk is in, but a set of arrays can be
+// JUDGED in 20 ms by a kernel with the launch's store pattern: pdmp_device_alloc_streams draws up to `draws` sets and keeps the fastest
+// (three consecutive draws of one process: 15.3 / 14.4 / 17.0 ms, 14.5 / 14.3 / 14.4, 15.3 / 14.3 / 15.7, 16.0 / 14.8 / 15.0).  The chunks
+// must not be small either: below ~32 MiB of physically contiguous memory per translation the kernel's 131 000 concurrent write streams
+// miss in the translation caches (TCP_UTCL1_TRANSLATION_MISS 1.2e5 -> 7e7 .. 1.3e8 per launch; 16.0 ms at 16 MiB, 22.5 ms at 2 MiB).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
@@ -28,6 +30,18 @@ std::mutex g_mu;
 std::map<void *, ChunkedAlloc> g_allocs;
 
 thread_local char g_err[256];
+
+// An address that has been unmapped (hipMemUnmap) and mapped to OTHER physical memory keeps its old translation for the compute queues
+// on this stack: kernels go on reading and writing the memory that was mapped there first -- even after that memory has been released --
+// while hipMemcpy sees the new mapping (scripts/placement/probe.hip, mode `stale2`; profiles/r4/placement/c15_stale2.jsonl).  The unmap
+// of an ORDINARY allocation flushes the translation caches, so every mapping made here is followed by one hipMalloc + hipFree of 64 MiB
+// (c16_stale2.jsonl: with it, kernel and copy agree in every variant).  Without this a pdmp_device_alloc that is handed the address range
+// of an earlier, freed allocation would let kernels write into memory that is no longer theirs.
+void flush_translations() {
+    void *t = nullptr;
+    if (hipMalloc(&t, (size_t)64 << 20) == hipSuccess) (void)hipFree(t);
+    (void)hipGetLastError();
+}
 
 void release_all(char *base, ChunkedAlloc &a, size_t mapped) {
     size_t off = 0;
@@ -89,12 +103,115 @@ int pdmp_device_alloc(int32_t device, size_t bytes, size_t chunk_bytes, void **o
     hipMemAccessDesc desc;
     desc.location.type = hipMemLocationTypeDevice; desc.location.id = dev; desc.flags = hipMemAccessFlagsProtReadWrite;
     DA_TRY(hipMemSetAccess(base, a.va_bytes, &desc, 1), a.handles.size());
+    flush_translations();
 #undef DA_TRY
     {
         std::lock_guard<std::mutex> lk(g_mu);
         g_allocs[base] = a;
     }
     *out = base;
+    return PDMP_OK;
+}
+
+// ---- the streamed arrays of an ensemble, drawn several times (include/pdmp_hip.h: pdmp_device_alloc_streams)
+namespace {
+// The launch's store pattern without its arithmetic: a wave owns 64 consecutive chains and writes, step by step, ONE 64-byte line of each
+// chain's row in A and in B (eight lanes per line, eight chains per store instruction, streaming stores); chains `stride` doubles apart;
+// batches of 64 chains handed out by an atomic counter to `gridDim.x` persistent waves.  Correlates with the lane kernel's launch time
+// over placements to a few per cent (profiles/r4/placement: synth2_ms against engine_ms).
+__global__ __launch_bounds__(64) void stream_pair_writer(double *A, double *B, long long stride, long long n_chains, int lines, int *queue, int n_batches) {
+    __shared__ int s_b;
+    const int lane = threadIdx.x;
+    for (;;) {
+        if (lane == 0) s_b = atomicAdd(queue, 1);
+        __syncthreads();
+        const int b = s_b;
+        __syncthreads();
+        if (b >= n_batches) return;
+        for (int l = 0; l < lines; ++l) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const long long c = (long long)b * 64 + 8 * r + (lane >> 3);
+                if (c < n_chains) {
+                    const long long off = c * stride + (long long)l * 8 + (lane & 7);
+                    const double val = (double)(l + lane);
+                    __builtin_nontemporal_store(val, A + off);
+                    __builtin_nontemporal_store(-val, B + off);
+                }
+            }
+        }
+    }
+}
+// minimum of two timed passes after one untimed pass; < 0 on an error
+float time_stream_pair(void *A, void *B, size_t bytes, size_t stride_bytes) {
+    const long long stride = (long long)(stride_bytes / 8), chains = (long long)(bytes / stride_bytes);
+    const int lines = (int)(stride_bytes / 64);
+    if (chains < 1 || lines < 1) return -1.f;
+    int *queue = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    float best = -1.f;
+    if (hipMalloc(&queue, sizeof(int)) != hipSuccess) return -1.f;
+    if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) {
+        const int nb = (int)((chains + 63) / 64);
+        for (int i = 0; i < 3; ++i) {
+            if (hipMemsetAsync(queue, 0, sizeof(int), 0) != hipSuccess || hipEventRecord(a, 0) != hipSuccess) { best = -1.f; break; }
+            hipLaunchKernelGGL(stream_pair_writer, dim3(1024), dim3(64), 0, 0, (double *)A, (double *)B, stride, chains, lines, queue, nb);
+            float ms = 0.f;
+            if (hipEventRecord(b, 0) != hipSuccess || hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&ms, a, b) != hipSuccess) { best = -1.f; break; }
+            if (i >= 1 && (best < 0.f || ms < best)) best = ms;
+        }
+    }
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    (void)hipFree(queue);
+    (void)hipGetLastError();
+    return best;
+}
+}  // namespace
+
+int pdmp_device_alloc_streams(int32_t device, int32_t n, const size_t *bytes, size_t chunk_bytes, size_t stride_bytes, int32_t draws,
+                              void **out_ptrs, float *draw_ms, int32_t *n_drawn) {
+    g_err[0] = 0;
+    if (!bytes || !out_ptrs || n < 1 || n > 16) { snprintf(g_err, sizeof g_err, "device_alloc_streams: null pointer or array count outside 1..16"); return PDMP_ERR_ARGUMENT; }
+    if (n_drawn) *n_drawn = 0;
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) { if (!bytes[i]) { snprintf(g_err, sizeof g_err, "device_alloc_streams: zero size"); return PDMP_ERR_ARGUMENT; } total += bytes[i]; }
+    const bool measure = draws > 1 && n >= 2 && stride_bytes >= 64 && stride_bytes % 64 == 0 && bytes[0] == bytes[1] && bytes[0] >= stride_bytes;
+    int dev = device, cur = 0;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) { snprintf(g_err, sizeof g_err, "device_alloc_streams: no current device"); return PDMP_ERR_RUNTIME; }
+    (void)hipGetDevice(&cur);
+    (void)hipSetDevice(dev);
+    std::vector<void *> best(n, nullptr), cand(n, nullptr);
+    float best_ms = -1.f;
+    int rc = PDMP_OK, drawn = 0;
+    auto free_set = [&](std::vector<void *> &v) { for (auto &p : v) { if (p) (void)pdmp_device_free(p); p = nullptr; } };
+    for (int k = 0; k < (measure ? draws : 1); ++k) {
+        if (k > 0) {                                                        // another set must fit beside the best one so far
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < total + total / 8 + ((size_t)2 << 30)) break;
+        }
+        int e = PDMP_OK;
+        for (int i = 0; i < n && e == PDMP_OK; ++i) e = pdmp_device_alloc(dev, bytes[i], chunk_bytes, &cand[i]);
+        if (e != PDMP_OK) {                                                 // (pdmp_device_alloc has set the message)
+            char keep[sizeof g_err]; memcpy(keep, g_err, sizeof keep);
+            free_set(cand);
+            if (k == 0) { memcpy(g_err, keep, sizeof keep); rc = e; }
+            break;
+        }
+        float ms = -1.f;
+        if (measure) {
+            ms = time_stream_pair(cand[0], cand[1], bytes[0], stride_bytes);
+            if (draw_ms) draw_ms[k] = ms;
+        }
+        ++drawn;
+        if (!best[0] || (ms >= 0.f && (best_ms < 0.f || ms < best_ms))) { free_set(best); best.swap(cand); best_ms = ms; }
+        else free_set(cand);
+        if (!measure) break;
+    }
+    (void)hipSetDevice(cur);
+    if (rc != PDMP_OK) return rc;
+    for (int i = 0; i < n; ++i) out_ptrs[i] = best[i];
+    if (n_drawn) *n_drawn = drawn;
     return PDMP_OK;
 }
 
@@ -114,6 +231,7 @@ int pdmp_device_free(void *ptr) {
     (void)hipSetDevice(a.device);
     (void)hipDeviceSynchronize();                                           // no kernel may still be writing through the mapping
     release_all((char *)ptr, a, a.handles.size());
+    flush_translations();                                                  // (no translation of the released memory may outlive it)
     (void)hipSetDevice(cur);
     return PDMP_OK;
 }

@@ -87,15 +87,50 @@ def alloc_chunked(shape, dtype=torch.float64, device=None, chunk_bytes: int = 0)
     return flat[: n * esize].view(dtype).reshape(tuple(int(k) for k in shape))
 
 
-def alloc_outputs(C_: int, n_sk: int, d: int, device=None, chunked: bool | None = None) -> dict:
+class _StreamBuffer(_ChunkedBuffer):
+    """One array of pdmp_device_alloc_streams (same ownership rules as _ChunkedBuffer: released with pdmp_device_free)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.ptr, self.nbytes = int(ptr), int(nbytes)
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (self.ptr, False), "version": 2, "strides": None}
+
+
+DEFAULT_DRAWS = 3                      # sets of (X, V, t) drawn by alloc_outputs for arrays of at least CHUNKED_FROM_BYTES
+last_alloc_info: dict = {}             # what the last alloc_outputs call measured: {"draws": k, "draw_ms": [...], "seconds": s}
+
+
+def alloc_outputs(C_: int, n_sk: int, d: int, device=None, chunked: bool | None = None, draws: int | None = None) -> dict:
     """The output arrays of ``sample_skeleton_device`` for ``C`` chains: ``X, V (C, n_sk, d)``, ``t (C, n_sk)``.  ``chunked`` = None:
-    arrays of at least 1 GiB from physical chunks (``alloc_chunked``), smaller ones from torch's allocator."""
+    arrays of at least 1 GiB from physical chunks, smaller ones from torch's allocator.  Chunked sets are DRAWN up to ``draws`` times
+    (default 3, as far as the free memory holds a second set) and the set on which a kernel with the launch's store pattern runs fastest
+    is kept (pdmp_device_alloc_streams; DESIGN.md section 6b: the same launch takes 14.3 ms or 17 - 19 ms depending on where the physical
+    chunks of X and V lie relative to each other, and a fresh set is a fresh draw).  ``last_alloc_info`` keeps the times measured."""
+    import time
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    shapes = (("X", (C_, n_sk, d)), ("V", (C_, n_sk, d)), ("t", (C_, n_sk)))
+    nbytes = [8 * C_ * n_sk * d, 8 * C_ * n_sk * d, 8 * C_ * n_sk]
+    use = chunked if chunked is not None else nbytes[0] >= CHUNKED_FROM_BYTES
+    last_alloc_info.clear()
+    if not use or min(nbytes) <= 0:
+        return {name: torch.empty(shape, dtype=torch.float64, device=dev) for name, shape in shapes}
+    k = DEFAULT_DRAWS if draws is None else max(1, int(draws))
+    sizes = (C.c_size_t * 3)(*nbytes)
+    ptrs = (C.c_void_p * 3)()
+    ms = (C.c_float * k)()
+    drawn = C.c_int32(0)
+    t0 = time.perf_counter()
+    with torch.cuda.device(dev):
+        rc = _lib.lib().pdmp_device_alloc_streams(dev.index if dev.index is not None else torch.cuda.current_device(), 3, sizes, 0, 8 * n_sk * d, k,
+                                                  ptrs, ms, C.byref(drawn))
+    if rc != 0:
+        raise _lib.EngineError(rc, (_lib.lib().pdmp_device_alloc_error() or b"").decode())
+    last_alloc_info.update({"draws": int(drawn.value), "draw_ms": [round(float(ms[i]), 3) for i in range(int(drawn.value))] if k > 1 else [],
+                            "seconds": round(time.perf_counter() - t0, 3)})
     out = {}
-    for name, shape in (("X", (C_, n_sk, d)), ("V", (C_, n_sk, d)), ("t", (C_, n_sk))):
-        nbytes = 8 * shape[0] * shape[1] * (shape[2] if len(shape) == 3 else 1)
-        use = chunked if chunked is not None else nbytes >= CHUNKED_FROM_BYTES
-        out[name] = alloc_chunked(shape, torch.float64, dev) if use else torch.empty(shape, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        for (name, shape), ptr, nb in zip(shapes, ptrs, nbytes):
+            flat = torch.as_tensor(_StreamBuffer(ptr, nb), device=dev)       # zero-copy view; holds the buffer object, which frees the memory
+            out[name] = flat.view(torch.float64).reshape(shape)
     return out
 
 

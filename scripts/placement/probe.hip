@@ -11,6 +11,7 @@
 //
 // Build: make -C scripts/placement      Run on the GPU box: scripts/placement/probe vmm 2048 4 4
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -58,6 +59,16 @@ __global__ __launch_bounds__(64) void synth_writer(double *X, double *V, int64_t
             }
         }
     }
+}
+
+__global__ void fill_kernel(double *p, size_t n, double val)
+{
+    for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) p[i] = val;
+}
+
+__global__ void probe_read_kernel(const double *p, size_t n, double *out)
+{
+    if (threadIdx.x == 0) *out = p[n / 2];
 }
 
 static int *g_queue = nullptr;
@@ -123,6 +134,18 @@ static float run_engine(double *X, double *V, double *t, std::string *all = null
 }
 
 // ---------------------------------------------------------------- physical chunks
+// hipMemUnmap + hipMemMap of OTHER memory at an address leaves the compute queues' translation of that address pointing at the old
+// memory (mode `stale2`: kernels keep writing the chunk that was mapped there first, even after it has been released; hipMemcpy sees the
+// new one).  A hipMalloc + hipFree of 64 MiB in between makes the new mapping take effect (the unmap of an ordinary allocation flushes
+// the TLBs).  The modes of calls 1 - 13 ran WITHOUT this (PROBE_NO_FLUSH=1 reproduces them): wherever they re-mapped an address, the
+// kernels were still writing the first chunks mapped there.
+static bool g_flush_after_map = true;
+static void flush_translations()
+{
+    void *t = nullptr;
+    HIPCHECK(hipMalloc(&t, size_t(64) << 20));
+    HIPCHECK(hipFree(t));
+}
 struct Pool {
     size_t S = 0;
     std::vector<hipMemGenericAllocationHandle_t> h;
@@ -145,10 +168,22 @@ struct Mapped {
         for (size_t i = 0; i < n; ++i) HIPCHECK(hipMemMap(base + i * S, S, 0, p.h[ids[i]], 0));
         hipMemAccessDesc d; d.location.type = hipMemLocationTypeDevice; d.location.id = 0; d.flags = hipMemAccessFlagsProtReadWrite;
         HIPCHECK(hipMemSetAccess(base, n * S, &d, 1));
+        if (g_flush_after_map) flush_translations();
     }
     void unmap() { for (size_t i = 0; i < n; ++i) HIPCHECK(hipMemUnmap(base + i * S, S)); }
     void free_va() { HIPCHECK(hipMemAddressFree(base, n * S)); base = nullptr; }
 };
+
+static void malloc_ctl(const char *name)
+{
+    double *X, *V, *t;
+    HIPCHECK(hipMalloc(&X, XB)); HIPCHECK(hipMalloc(&V, XB)); HIPCHECK(hipMalloc(&t, TB));
+    std::string all; const float e = run_engine(X, V, t, &all);
+    const float s2 = run_synth(X, V, NSK * D, C, int(NSK * D / 8), 1024, 2, 1);
+    printf("{\"probe\":\"malloc_ctl\",\"name\":\"%s\",\"engine_ms\":%.2f,\"engine_all\":[%s],\"synth2_ms\":%.2f,\"x\":\"%p\",\"v\":\"%p\"}\n", name, e, all.c_str(), s2, (void *)X, (void *)V);
+    fflush(stdout);
+    HIPCHECK(hipFree(X)); HIPCHECK(hipFree(V)); HIPCHECK(hipFree(t));
+}
 
 static std::string ids_str(const std::vector<int> &v, size_t lim = 64)
 {
@@ -159,6 +194,7 @@ static std::string ids_str(const std::vector<int> &v, size_t lim = 64)
 
 int main(int argc, char **argv)
 {
+    if (getenv("PROBE_NO_FLUSH")) g_flush_after_map = false;
     const std::string mode = argc > 1 ? argv[1] : "malloc";
     HIPCHECK(hipSetDevice(0));
     size_t fr, tot; HIPCHECK(hipMemGetInfo(&fr, &tot));
@@ -320,6 +356,436 @@ int main(int argc, char **argv)
             printf("{\"probe\":\"sets\",\"set\":%d,\"rep\":%d,\"engine_ms\":%.2f,\"engine_all\":[%s],\"pair_ms\":[%s]}\n", k, rep, e, all.c_str(), pers.c_str());
             fflush(stdout);
         }
+        return 0;
+    }
+    if (mode == "valign") {
+        // Does the VIRTUAL address the chunks are mapped at matter (the page-table fragment a mapping can use is bounded by the alignment of
+        // the virtual address as well as of the physical block)?  One pool of 1-GiB chunks, mapped at a 1-GiB-aligned address plus an offset
+        // of 0 / 2 / 4 / ... MiB inside an over-sized reservation; the engine on each; a hipMalloc'ed set before and after as the control.
+        const size_t S = size_t(argc > 2 ? atol(argv[2]) : 1024) << 20, G1 = size_t(1) << 30;
+        malloc_ctl("hipmalloc_before");
+        const int nx = int((XB + S - 1) / S), nt_ = int((TB + S - 1) / S);
+        Pool pool; pool.create(S, 2 * nx + nt_);
+        std::vector<int> ix(nx), iv(nx), it(nt_);
+        for (int i = 0; i < nx; ++i) { ix[i] = i; iv[i] = nx + i; }
+        for (int i = 0; i < nt_; ++i) it[i] = 2 * nx + i;
+        hipMemAccessDesc ad; ad.location.type = hipMemLocationTypeDevice; ad.location.id = 0; ad.flags = hipMemAccessFlagsProtReadWrite;
+        // what a plain reservation and one that asks for 1 GiB alignment return
+        for (size_t al : {size_t(0), G1}) {
+            void *p = nullptr; HIPCHECK(hipMemAddressReserve(&p, size_t(nx) * S, al, nullptr, 0));
+            printf("{\"probe\":\"valign_reserve\",\"alignment_asked\":%zu,\"ptr\":\"%p\",\"mod_1gib_mib\":%zu}\n", al, p, (size_t(p) % G1) >> 20);
+            HIPCHECK(hipMemAddressFree(p, size_t(nx) * S));
+        }
+        const size_t span = size_t(nx) * S + 2 * G1;
+        char *rx = nullptr, *rv = nullptr, *rt = nullptr;
+        HIPCHECK(hipMemAddressReserve((void **)&rx, span, 0, nullptr, 0));
+        HIPCHECK(hipMemAddressReserve((void **)&rv, span, 0, nullptr, 0));
+        HIPCHECK(hipMemAddressReserve((void **)&rt, size_t(nt_) * S + 2 * G1, 0, nullptr, 0));
+        auto up = [&](char *p) { return (char *)((size_t(p) + G1 - 1) / G1 * G1); };
+        const size_t offs_mib[] = {0, 2, 4, 8, 16, 32, 64, 128, 256, 512, 0};
+        for (size_t om : offs_mib) {
+            const size_t off = om << 20;
+            char *bx = up(rx) + off, *bv = up(rv) + off, *bt = up(rt) + off;
+            for (int i = 0; i < nx; ++i) { HIPCHECK(hipMemMap(bx + size_t(i) * S, S, 0, pool.h[ix[i]], 0)); HIPCHECK(hipMemMap(bv + size_t(i) * S, S, 0, pool.h[iv[i]], 0)); }
+            for (int i = 0; i < nt_; ++i) HIPCHECK(hipMemMap(bt + size_t(i) * S, S, 0, pool.h[it[i]], 0));
+            HIPCHECK(hipMemSetAccess(bx, size_t(nx) * S, &ad, 1)); HIPCHECK(hipMemSetAccess(bv, size_t(nx) * S, &ad, 1)); HIPCHECK(hipMemSetAccess(bt, size_t(nt_) * S, &ad, 1));
+            std::string all; const float e = run_engine((double *)bx, (double *)bv, (double *)bt, &all);
+            printf("{\"probe\":\"valign\",\"offset_mib\":%zu,\"engine_ms\":%.2f,\"engine_all\":[%s],\"x\":\"%p\",\"v\":\"%p\"}\n", om, e, all.c_str(), (void *)bx, (void *)bv);
+            fflush(stdout);
+            for (int i = 0; i < nx; ++i) { HIPCHECK(hipMemUnmap(bx + size_t(i) * S, S)); HIPCHECK(hipMemUnmap(bv + size_t(i) * S, S)); }
+            for (int i = 0; i < nt_; ++i) HIPCHECK(hipMemUnmap(bt + size_t(i) * S, S));
+        }
+        pool.release();
+        malloc_ctl("hipmalloc_after");
+        return 0;
+    }
+    if (mode == "tswap") {
+        // Which allocation decides?  One pool; (a) X, V fixed, the t array on twelve different chunks; (b) t fixed, X / V on other chunks;
+        // (c) everything fixed, the engine handle (its scheduler, hand-off and status buffers) destroyed and re-created, with a spacer
+        // allocation in between so that the new buffers land elsewhere; (d) the initial states re-allocated.
+        const size_t S = size_t(argc > 2 ? atol(argv[2]) : 1024) << 20;
+        Mapped X, V, T;
+        X.reserve(XB, S); V.reserve(XB, S); T.reserve(TB, S);
+        const int nx = int(X.n), nt_ = int(T.n), nsp = 14, npool = 4 * nx + nsp * nt_;
+        Pool pool; pool.create(S, npool);
+        std::vector<int> ix(nx), iv(nx), it(nt_);
+        auto run = [&](const char *what, int k) {
+            X.map(pool, ix); V.map(pool, iv); T.map(pool, it);
+            std::string all; const float e = run_engine((double *)X.base, (double *)V.base, (double *)T.base, &all);
+            X.unmap(); V.unmap(); T.unmap();
+            printf("{\"probe\":\"tswap\",\"varied\":\"%s\",\"k\":%d,\"engine_ms\":%.2f,\"engine_all\":[%s],\"x0\":%d,\"v0\":%d,\"t0\":%d}\n", what, k, e, all.c_str(), ix[0], iv[0], it[0]);
+            fflush(stdout);
+        };
+        for (int i = 0; i < nx; ++i) { ix[i] = i; iv[i] = nx + i; }
+        for (int k = 0; k < nsp; ++k) { for (int i = 0; i < nt_; ++i) it[i] = 4 * nx + k * nt_ + i; run("t", k); }
+        for (int i = 0; i < nt_; ++i) it[i] = 4 * nx + i;
+        for (int k = 0; k < 2; ++k) { for (int i = 0; i < nx; ++i) { ix[i] = 2 * k * nx + i; iv[i] = (2 * k + 1) * nx + i; } run("xv", k); }
+        for (int i = 0; i < nx; ++i) { ix[i] = i; iv[i] = 3 * nx + i; }
+        run("xv", 2);
+        for (int i = 0; i < nx; ++i) { ix[i] = i; iv[i] = nx + i; }
+        std::vector<void *> spacers;
+        for (int k = 0; k < 6; ++k) {
+            pdmp_destroy(g_h); g_h = nullptr;
+            void *sp = nullptr; HIPCHECK(hipMalloc(&sp, size_t(37 + 61 * k) << 20)); spacers.push_back(sp);
+            double *keep_x0 = g_x0, *keep_v0 = g_v0;
+            engine_init();                                                    // (allocates new initial states as well; the old ones are freed below)
+            HIPCHECK(hipFree(keep_x0)); HIPCHECK(hipFree(keep_v0));
+            run("handle_and_inits", k);
+        }
+        for (void *sp : spacers) HIPCHECK(hipFree(sp));
+        pool.release();
+        return 0;
+    }
+    if (mode == "spacer") {
+        // Is the process-wide constant the physical OFFSET the pool starts at (chunks created back to back are physically consecutive, so
+        // every chunk of a pool has the same address modulo its size)?  A spacer allocation of k x 2 MiB is created -- and held -- before
+        // the pool; the engine on each pool; (b) the same with the spacer between the X chunks and the V chunks.
+        const size_t S = size_t(argc > 2 ? atol(argv[2]) : 1024) << 20, M2 = size_t(2) << 20;
+        Mapped X, V, T;
+        X.reserve(XB, S); V.reserve(XB, S); T.reserve(TB, S);
+        const int nx = int(X.n), nt_ = int(T.n);
+        hipMemAllocationProp prop; memset(&prop, 0, sizeof prop);
+        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = 0;
+        const size_t ks[] = {0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 3, 5, 96, 0};
+        for (int where = 0; where < 2; ++where)
+        for (size_t k : ks) {
+            hipMemGenericAllocationHandle_t sp{}; 
+            Pool px, pv;
+            if (where == 0 && k) HIPCHECK(hipMemCreate(&sp, k * M2, &prop, 0));
+            px.create(S, nx);
+            if (where == 1 && k) HIPCHECK(hipMemCreate(&sp, k * M2, &prop, 0));
+            pv.create(S, nx + nt_);
+            std::vector<int> ix(nx), iv(nx), it(nt_);
+            for (int i = 0; i < nx; ++i) { ix[i] = i; iv[i] = i; }
+            for (int i = 0; i < nt_; ++i) it[i] = nx + i;
+            X.map(px, ix); V.map(pv, iv); T.map(pv, it);
+            std::string all; const float e = run_engine((double *)X.base, (double *)V.base, (double *)T.base, &all);
+            const float pr = run_synth((double *)X.base, (double *)V.base, 2048, int64_t(S / 8 / 2048), 256, 1024, 2, 1, 2);
+            X.unmap(); V.unmap(); T.unmap();
+            printf("{\"probe\":\"spacer\",\"where\":\"%s\",\"spacer_mib\":%zu,\"engine_ms\":%.2f,\"engine_all\":[%s],\"pair0_ms\":%.3f}\n", where ? "between_x_and_v" : "before_pool", 2 * k, e, all.c_str(), pr);
+            fflush(stdout);
+            px.release(); pv.release();
+            if (k) HIPCHECK(hipMemRelease(sp));
+        }
+        return 0;
+    }
+    if (mode == "vadelta") {
+        // Is the process-wide constant the VIRTUAL distance between the X and the V array (their reservations are made once per process)?
+        // One pool, one big reservation; X mapped at its 1-GiB-aligned start, V at X + 38 GiB + delta for a list of deltas; t fixed.
+        const size_t S = size_t(1024) << 20, G1 = size_t(1) << 30;
+        const int nx = int((XB + S - 1) / S), nt_ = int((TB + S - 1) / S);
+        Pool pool; pool.create(S, 2 * nx + nt_);
+        hipMemAccessDesc ad; ad.location.type = hipMemLocationTypeDevice; ad.location.id = 0; ad.flags = hipMemAccessFlagsProtReadWrite;
+        const size_t span = size_t(2 * nx + 70) * G1;
+        char *r = nullptr, *rt = nullptr;
+        HIPCHECK(hipMemAddressReserve((void **)&r, span, 0, nullptr, 0));
+        HIPCHECK(hipMemAddressReserve((void **)&rt, size_t(nt_ + 1) * G1, 0, nullptr, 0));
+        char *bx = (char *)((size_t(r) + G1 - 1) / G1 * G1), *bt = (char *)((size_t(rt) + G1 - 1) / G1 * G1);
+        for (int i = 0; i < nx; ++i) HIPCHECK(hipMemMap(bx + size_t(i) * S, S, 0, pool.h[i], 0));
+        for (int i = 0; i < nt_; ++i) HIPCHECK(hipMemMap(bt + size_t(i) * S, S, 0, pool.h[2 * nx + i], 0));
+        HIPCHECK(hipMemSetAccess(bx, size_t(nx) * S, &ad, 1)); HIPCHECK(hipMemSetAccess(bt, size_t(nt_) * S, &ad, 1));
+        const double deltas_gib[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 12, 16, 24, 32, 64, 0.5, 0.25, 0.001953125 /* 2 MiB */, 1.5, 0};
+        for (double dg : deltas_gib) {
+            char *bv = bx + size_t(nx) * S + size_t(dg * double(G1));
+            for (int i = 0; i < nx; ++i) HIPCHECK(hipMemMap(bv + size_t(i) * S, S, 0, pool.h[nx + i], 0));
+            HIPCHECK(hipMemSetAccess(bv, size_t(nx) * S, &ad, 1));
+            std::string all; const float e = run_engine((double *)bx, (double *)bv, (double *)bt, &all);
+            printf("{\"probe\":\"vadelta\",\"delta_gib\":%.6f,\"engine_ms\":%.2f,\"engine_all\":[%s],\"x\":\"%p\",\"v\":\"%p\",\"t\":\"%p\"}\n", dg, e, all.c_str(), (void *)bx, (void *)bv, (void *)bt);
+            fflush(stdout);
+            for (int i = 0; i < nx; ++i) HIPCHECK(hipMemUnmap(bv + size_t(i) * S, S));
+        }
+        // and X, V, t in fresh, separate reservations (what the allocator does today), six times
+        for (int k = 0; k < 6; ++k) {
+            Mapped X, V, T;
+            void *pad = nullptr; HIPCHECK(hipMemAddressReserve(&pad, size_t(3 + 5 * k) * G1 + (size_t(k) << 21), 0, nullptr, 0));
+            X.reserve(XB, S); V.reserve(XB, S); T.reserve(TB, S);
+            std::vector<int> ix(nx), iv(nx), it(nt_);
+            for (int i = 0; i < nx; ++i) { ix[i] = i; iv[i] = nx + i; }
+            for (int i = 0; i < nt_; ++i) it[i] = 2 * nx + i;
+            for (int i = 0; i < nx; ++i) HIPCHECK(hipMemUnmap(bx + size_t(i) * S, S));          // a handle is mapped once at a time here
+            for (int i = 0; i < nt_; ++i) HIPCHECK(hipMemUnmap(bt + size_t(i) * S, S));
+            X.map(pool, ix); V.map(pool, iv); T.map(pool, it);
+            std::string all; const float e = run_engine((double *)X.base, (double *)V.base, (double *)T.base, &all);
+            printf("{\"probe\":\"vadelta_fresh\",\"k\":%d,\"engine_ms\":%.2f,\"engine_all\":[%s],\"x\":\"%p\",\"v\":\"%p\",\"t\":\"%p\"}\n", k, e, all.c_str(), (void *)X.base, (void *)V.base, (void *)T.base);
+            fflush(stdout);
+            X.unmap(); V.unmap(); T.unmap();
+            for (int i = 0; i < nx; ++i) HIPCHECK(hipMemMap(bx + size_t(i) * S, S, 0, pool.h[i], 0));
+            for (int i = 0; i < nt_; ++i) HIPCHECK(hipMemMap(bt + size_t(i) * S, S, 0, pool.h[2 * nx + i], 0));
+            HIPCHECK(hipMemSetAccess(bx, size_t(nx) * S, &ad, 1)); HIPCHECK(hipMemSetAccess(bt, size_t(nt_) * S, &ad, 1));
+        }
+        pool.release();
+        return 0;
+    }
+    if (mode == "vamap") {
+        // The launch time as a function of WHERE in the virtual address space X and V are mapped (same physical chunks throughout): X at
+        // base + ox GiB, V at base + ov GiB inside one reservation whose base is aligned to 256 GiB; t fixed elsewhere.
+        const size_t S = size_t(1024) << 20, G1 = size_t(1) << 30;
+        const int nx = int((XB + S - 1) / S), nt_ = int((TB + S - 1) / S);
+        Pool pool; pool.create(S, 2 * nx + nt_);
+        hipMemAccessDesc ad; ad.location.type = hipMemLocationTypeDevice; ad.location.id = 0; ad.flags = hipMemAccessFlagsProtReadWrite;
+        const size_t span = size_t(1024 + 256) * G1;
+        char *r = nullptr, *rt = nullptr;
+        HIPCHECK(hipMemAddressReserve((void **)&r, span, 0, nullptr, 0));
+        HIPCHECK(hipMemAddressReserve((void **)&rt, size_t(nt_ + 1) * G1, 0, nullptr, 0));
+        char *base = (char *)((size_t(r) + 256 * G1 - 1) / (256 * G1) * (256 * G1)), *bt = (char *)((size_t(rt) + G1 - 1) / G1 * G1);
+        printf("{\"probe\":\"vamap_base\",\"base\":\"%p\",\"t\":\"%p\"}\n", (void *)base, (void *)bt);
+        for (int i = 0; i < nt_; ++i) HIPCHECK(hipMemMap(bt + size_t(i) * S, S, 0, pool.h[2 * nx + i], 0));
+        HIPCHECK(hipMemSetAccess(bt, size_t(nt_) * S, &ad, 1));
+        auto at = [&](int ox, int ov) {
+            char *bx = base + size_t(ox) * G1, *bv = base + size_t(ov) * G1;
+            for (int i = 0; i < nx; ++i) { HIPCHECK(hipMemMap(bx + size_t(i) * S, S, 0, pool.h[i], 0)); HIPCHECK(hipMemMap(bv + size_t(i) * S, S, 0, pool.h[nx + i], 0)); }
+            HIPCHECK(hipMemSetAccess(bx, size_t(nx) * S, &ad, 1)); HIPCHECK(hipMemSetAccess(bv, size_t(nx) * S, &ad, 1));
+            std::string all; const float e = run_engine((double *)bx, (double *)bv, (double *)bt, &all, 2);
+            printf("{\"probe\":\"vamap\",\"ox\":%d,\"ov\":%d,\"engine_ms\":%.2f,\"engine_all\":[%s]}\n", ox, ov, e, all.c_str());
+            fflush(stdout);
+            for (int i = 0; i < nx; ++i) { HIPCHECK(hipMemUnmap(bx + size_t(i) * S, S)); HIPCHECK(hipMemUnmap(bv + size_t(i) * S, S)); }
+        };
+        const int oxs[] = {0, 8, 16, 32, 64, 100};
+        for (int ox : oxs)
+            for (int d = 0; d <= 160; d += 4) at(ox, ox + nx + d);
+        for (int d = 0; d <= 160; d += 8) at(200 + nx + d, 200);          // V below X
+        at(0, nx); at(0, nx + 24);
+        pool.release();
+        return 0;
+    }
+    if (mode == "vascan") {
+        // The launch time over the virtual address of X across two and a half 512-GiB windows (V right behind X, t fixed far away), then
+        // with t right behind V, then V far from X: which array's address decides, and with which period?
+        const size_t S = size_t(1024) << 20, G1 = size_t(1) << 30;
+        const int nx = int((XB + S - 1) / S), nt_ = int((TB + S - 1) / S);
+        Pool pool; pool.create(S, 2 * nx + nt_);
+        hipMemAccessDesc ad; ad.location.type = hipMemLocationTypeDevice; ad.location.id = 0; ad.flags = hipMemAccessFlagsProtReadWrite;
+        const size_t span = size_t(512 * 3 + 512) * G1;
+        char *r = nullptr;
+        HIPCHECK(hipMemAddressReserve((void **)&r, span, 0, nullptr, 0));
+        char *base = (char *)((size_t(r) + 512 * G1 - 1) / (512 * G1) * (512 * G1));
+        printf("{\"probe\":\"vascan_base\",\"reserved\":\"%p\",\"base\":\"%p\",\"x0\":\"%p\",\"v0\":\"%p\"}\n", (void *)r, (void *)base, (void *)g_x0, (void *)g_v0);
+        auto at = [&](const char *what, int ox, int ov, int ot) {
+            char *bx = base + size_t(ox) * G1, *bv = base + size_t(ov) * G1, *bt = base + size_t(ot) * G1;
+            for (int i = 0; i < nx; ++i) { HIPCHECK(hipMemMap(bx + size_t(i) * S, S, 0, pool.h[i], 0)); HIPCHECK(hipMemMap(bv + size_t(i) * S, S, 0, pool.h[nx + i], 0)); }
+            for (int i = 0; i < nt_; ++i) HIPCHECK(hipMemMap(bt + size_t(i) * S, S, 0, pool.h[2 * nx + i], 0));
+            HIPCHECK(hipMemSetAccess(bx, size_t(nx) * S, &ad, 1)); HIPCHECK(hipMemSetAccess(bv, size_t(nx) * S, &ad, 1)); HIPCHECK(hipMemSetAccess(bt, size_t(nt_) * S, &ad, 1));
+            std::string all; const float e = run_engine((double *)bx, (double *)bv, (double *)bt, &all, 2);
+            printf("{\"probe\":\"vascan\",\"series\":\"%s\",\"ox\":%d,\"ov\":%d,\"ot\":%d,\"engine_ms\":%.2f,\"engine_all\":[%s]}\n", what, ox, ov, ot, e, all.c_str());
+            fflush(stdout);
+            for (int i = 0; i < nx; ++i) { HIPCHECK(hipMemUnmap(bx + size_t(i) * S, S)); HIPCHECK(hipMemUnmap(bv + size_t(i) * S, S)); }
+            for (int i = 0; i < nt_; ++i) HIPCHECK(hipMemUnmap(bt + size_t(i) * S, S));
+        };
+        const int TFAR = 512 * 3 + 100;
+        for (int ox = 0; ox <= 1320; ox += 24) at("x_moves_t_far", ox, ox + nx, TFAR);
+        for (int ox = 0; ox <= 600; ox += 40) at("x_moves_t_behind_v", ox, ox + nx, ox + 2 * nx);
+        for (int ox = 0; ox <= 600; ox += 40) at("x_moves_t_before_x", ox + 1, ox + 1 + nx, ox);
+        for (int ov = 40; ov <= 640; ov += 40) at("v_moves_x_at_0", 0, ov, TFAR);
+        for (int ot = 80; ot <= 680; ot += 40) at("t_moves_x_at_0", 0, nx, ot);
+        pool.release();
+        return 0;
+    }
+    if (mode == "stale") {
+        // Does an address that is unmapped and then mapped to OTHER physical memory really point there?  Chunk A mapped at p, filled with
+        // 1; p unmapped; chunk B mapped at p, filled with 2 through p.  Then p is read (expect 2), and A and B are each mapped at a FRESH
+        // address (never used before) and read: A should hold 1, B should hold 2.  variant 1: with a device synchronisation and 20 ms of
+        // sleep after the re-map; variant 2: the reservation of p is freed and reserved again between the two mappings.
+        const size_t S = size_t(argc > 2 ? atol(argv[2]) : 64) << 20;
+        const int iters = argc > 3 ? atoi(argv[3]) : 4;
+        const size_t n = S / 8;
+        std::vector<double> host(n);
+        auto count = [&](const void *dev, double want) {
+            HIPCHECK(hipMemcpy(host.data(), dev, S, hipMemcpyDeviceToHost));
+            long bad = 0; for (size_t i = 0; i < n; ++i) bad += host[i] != want;
+            printf("{\"probe\":\"stale_read\",\"ptr\":\"%p\",\"want\":%g,\"first\":%g,\"middle\":%g,\"last\":%g,\"wrong\":%ld}\n", dev, want, host[0], host[n / 2], host[n - 1], bad);
+            return bad;
+        };
+        for (int variant = 0; variant < 3; ++variant)
+        for (int it = 0; it < iters; ++it) {
+            Pool pool; pool.create(S, 2);
+            Mapped P, QA, QB; P.reserve(S, S);
+            void *p_first = P.base;
+            P.map(pool, std::vector<int>{0});
+            hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, (double *)P.base, n, 1.0);
+            HIPCHECK(hipDeviceSynchronize());
+            P.unmap();
+            if (variant == 2) { P.free_va(); P.reserve(S, S); }
+            P.map(pool, std::vector<int>{1});
+            if (variant == 1) { HIPCHECK(hipDeviceSynchronize()); usleep(20000); }
+            hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, (double *)P.base, n, 2.0);
+            HIPCHECK(hipDeviceSynchronize());
+            const long bad_p = count(P.base, 2.0);
+            QA.reserve(S, S); QA.map(pool, std::vector<int>{0});
+            const long bad_a = count(QA.base, 1.0);
+            QB.reserve(S, S); QB.map(pool, std::vector<int>{1});
+            const long bad_b = count(QB.base, 2.0);
+            printf("{\"probe\":\"stale\",\"variant\":%d,\"iteration\":%d,\"p_first\":\"%p\",\"p_second\":\"%p\",\"qa\":\"%p\",\"qb\":\"%p\",\"wrong_through_p\":%ld,\"wrong_in_A\":%ld,\"wrong_in_B\":%ld,\"doubles_per_chunk\":%zu}\n",
+                   variant, it, p_first, (void *)P.base, (void *)QA.base, (void *)QB.base, bad_p, bad_a, bad_b, n);
+            fflush(stdout);
+            P.unmap(); QA.unmap(); QB.unmap();
+            P.free_va(); QA.free_va(); QB.free_va();
+            pool.release();
+        }
+        return 0;
+    }
+    if (mode == "stale2") {
+        // (a) the product's allocator: pdmp_device_alloc, fill by a kernel, pdmp_device_free, pdmp_device_alloc again (same address?), fill
+        // with another value, read back by hipMemcpy AND by a kernel (sum).  (b) what makes a re-mapped address valid for kernels: nothing /
+        // a hipMalloc + hipFree of 64 MiB in between / a second of sleep / a dummy kernel first.
+        const size_t S = size_t(64) << 20, n = S / 8;
+        std::vector<double> host(n);
+        auto read_copy = [&](const void *dev) { HIPCHECK(hipMemcpy(host.data(), dev, S, hipMemcpyDeviceToHost)); return host[n / 2]; };
+        double *d_sum; HIPCHECK(hipMalloc(&d_sum, 8));
+        auto read_kernel = [&](const void *dev) {
+            HIPCHECK(hipMemset(d_sum, 0, 8));
+            hipLaunchKernelGGL(probe_read_kernel, dim3(1), dim3(64), 0, 0, (const double *)dev, n, d_sum);
+            double v; HIPCHECK(hipMemcpy(&v, d_sum, 8, hipMemcpyDeviceToHost)); return v;
+        };
+        for (int it = 0; it < 3; ++it) {
+            void *a1 = nullptr, *a2 = nullptr;
+            if (pdmp_device_alloc(0, 4 * S, S, &a1) != PDMP_OK) { fprintf(stderr, "%s\n", pdmp_device_alloc_error()); return 2; }
+            hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, (double *)a1, 4 * n, 1.0 + it);
+            HIPCHECK(hipDeviceSynchronize());
+            const double c1 = read_copy(a1), k1 = read_kernel(a1);
+            pdmp_device_free(a1);
+            if (pdmp_device_alloc(0, 4 * S, S, &a2) != PDMP_OK) { fprintf(stderr, "%s\n", pdmp_device_alloc_error()); return 2; }
+            const double c2_before = read_copy(a2), k2_before = read_kernel(a2);
+            hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, (double *)a2, 4 * n, 100.0 + it);
+            HIPCHECK(hipDeviceSynchronize());
+            const double c2 = read_copy(a2), k2 = read_kernel(a2);
+            printf("{\"probe\":\"stale2_alloc_free\",\"iteration\":%d,\"a1\":\"%p\",\"a2\":\"%p\",\"a1_copy\":%g,\"a1_kernel\":%g,\"a2_before_copy\":%g,\"a2_before_kernel\":%g,\"a2_copy\":%g,\"a2_kernel\":%g,\"want_a2\":%g}\n",
+                   it, a1, a2, c1, k1, c2_before, k2_before, c2, k2, 100.0 + it);
+            fflush(stdout);
+            pdmp_device_free(a2);
+        }
+        for (int flush = 0; flush < 4; ++flush) {
+            Pool pool; pool.create(S, 2);
+            Mapped P, QA, QB; P.reserve(S, S);
+            P.map(pool, std::vector<int>{0});
+            hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, (double *)P.base, n, 1.0);
+            HIPCHECK(hipDeviceSynchronize());
+            P.unmap();
+            P.map(pool, std::vector<int>{1});
+            if (flush == 1) { void *t = nullptr; HIPCHECK(hipMalloc(&t, S)); HIPCHECK(hipFree(t)); }
+            if (flush == 2) sleep(1);
+            if (flush == 3) { hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, 0, d_sum, size_t(1), 0.0); HIPCHECK(hipDeviceSynchronize()); }
+            hipLaunchKernelGGL(fill_kernel, dim3(1024), dim3(256), 0, 0, (double *)P.base, n, 2.0);
+            HIPCHECK(hipDeviceSynchronize());
+            const double pc = read_copy(P.base), pk = read_kernel(P.base);
+            QA.reserve(S, S); QA.map(pool, std::vector<int>{0});
+            const double ac = read_copy(QA.base);
+            QB.reserve(S, S); QB.map(pool, std::vector<int>{1});
+            const double bc = read_copy(QB.base);
+            printf("{\"probe\":\"stale2_remap\",\"between\":\"%s\",\"p_copy\":%g,\"p_kernel\":%g,\"A_holds\":%g,\"B_holds\":%g,\"want\":\"p 2, A 1, B 2\"}\n",
+                   flush == 0 ? "nothing" : flush == 1 ? "hipMalloc+hipFree 64 MiB" : flush == 2 ? "sleep 1 s" : "dummy kernel", pc, pk, ac, bc);
+            fflush(stdout);
+            P.unmap(); QA.unmap(); QB.unmap(); P.free_va(); QA.free_va(); QB.free_va();
+            pool.release();
+        }
+        return 0;
+    }
+    if (mode == "pairs") {
+        // Is "slow" a RELATION between the X chunk and the V chunk written together, and can an allocator arrange it?  1-GiB chunks; the dense
+        // two-array writer on (chunk i, chunk j) for a block of the pool (the matrix shows whether the relation has classes); then the engine
+        // on three sets made of the same pool: the pairing as allocated, a pairing chosen so that every (X chunk, V chunk) pair is fast, and
+        // one chosen so that every pair is slow.
+        const size_t S = size_t(argc > 2 ? atol(argv[2]) : 1024) << 20;
+        const int spare = argc > 3 ? atoi(argv[3]) : 44, nmat = argc > 4 ? atoi(argv[4]) : 24;
+        const float thr = argc > 5 ? float(atof(argv[5])) : 0.52f;
+        Mapped X, V, T;
+        X.reserve(XB, S); V.reserve(XB, S); T.reserve(TB, S);
+        const int nx = int(X.n), nt_ = int(T.n), npool = 2 * nx + nt_ + spare;
+        malloc_ctl("hipmalloc_before");
+        Pool pool; pool.create(S, npool);
+        Mapped A, B; A.reserve(S, S); B.reserve(S, S);
+        const int64_t st = 2048, nch = int64_t(S / 8 / st);
+        int tests = 0;
+        {   // every chunk alone (one array): a globally slow box shows here, a relation between chunks does not
+            std::string one;
+            for (int i = 0; i < npool; ++i) {
+                A.map(pool, std::vector<int>{i});
+                const float m = run_synth((double *)A.base, (double *)A.base, st, nch, int(st / 8), 1024, 1, 1, 2);
+                A.unmap();
+                char buf[32]; snprintf(buf, sizeof buf, "%s%.3f", i ? "," : "", m); one += buf;
+            }
+            printf("{\"probe\":\"single_chunk_ms\",\"ms\":[%s]}\n", one.c_str());
+            fflush(stdout);
+        }
+        auto pair = [&](int i, int j) {
+            A.map(pool, std::vector<int>{i}); B.map(pool, std::vector<int>{j});
+            const float m = run_synth((double *)A.base, (double *)B.base, st, nch, int(st / 8), 1024, 2, 1, 2);
+            A.unmap(); B.unmap(); ++tests;
+            return m;
+        };
+        const int mstep = std::max(1, npool / nmat);               // the matrix over chunks spread through the pool
+        for (int i = 0; i < nmat && i * mstep < npool; ++i) {
+            std::string row;
+            for (int j = 0; j < nmat && j * mstep < npool; ++j) {
+                char buf[32]; snprintf(buf, sizeof buf, "%s%.3f", j ? "," : "", i == j ? 0.f : pair(i * mstep, j * mstep)); row += buf;
+            }
+            printf("{\"probe\":\"pair_matrix\",\"i\":%d,\"ms\":[%s]}\n", i * mstep, row.c_str());
+            fflush(stdout);
+        }
+        // sets "as allocated": set k = chunks [k per, (k + 1) per): X, then V, then t -- what an allocator that takes chunks in order gets
+        const int per = 2 * nx + nt_, nsets = npool / per;
+        std::vector<int> ix(nx), iv(nx), it(nt_);
+        for (int i = 0; i < nt_; ++i) it[i] = 2 * nx + i;
+        T.map(pool, it);
+        auto run_set = [&](const char *name, int k, const std::vector<int> &jv) {
+            std::string pers; int slow = 0;
+            for (int i = 0; i < nx; ++i) {
+                const float m = pair(ix[i], jv[i]); slow += m >= thr;
+                char buf[32]; snprintf(buf, sizeof buf, "%s%.3f", i ? "," : "", m); pers += buf;
+            }
+            X.map(pool, ix); V.map(pool, jv);
+            std::string all; const float e = run_engine((double *)X.base, (double *)V.base, (double *)T.base, &all);
+            const float s2 = run_synth((double *)X.base, (double *)V.base, NSK * D, C, int(NSK * D / 8), 1024, 2, 1);
+            X.unmap(); V.unmap();
+            printf("{\"probe\":\"pairs_set\",\"pairing\":\"%s\",\"set\":%d,\"slow_pairs\":%d,\"of\":%d,\"engine_ms\":%.2f,\"engine_all\":[%s],\"synth2_ms\":%.2f,\"v_ids\":%s,\"pair_ms\":[%s]}\n",
+                   name, k, slow, nx, e, all.c_str(), s2, ids_str(jv).c_str(), pers.c_str());
+            fflush(stdout);
+            return slow;
+        };
+        int worst = 0, worst_slow = -1;
+        for (int k = 0; k < nsets; ++k) {
+            for (int i = 0; i < nx; ++i) { ix[i] = k * per + i; iv[i] = k * per + nx + i; }
+            const int sl = run_set("as_allocated", k, iv);
+            if (sl > worst_slow) { worst_slow = sl; worst = k; }
+        }
+        // the set with the most slow pairs, re-paired: for X chunk i the first unused candidate (any chunk of the pool that is not an X chunk
+        // of this set or a t chunk) whose pair time is on the wanted side of the threshold
+        for (int i = 0; i < nx; ++i) { ix[i] = worst * per + i; iv[i] = worst * per + nx + i; }
+        auto arrange = [&](bool want_fast) {
+            std::vector<int> cand;
+            for (int j = 0; j < npool; ++j) {
+                const bool is_x = j >= worst * per && j < worst * per + nx, is_t = j >= 2 * nx && j < 2 * nx + nt_;
+                if (!is_x && !is_t) cand.push_back(j);
+            }
+            // this set's own V chunks first (keep what is already good)
+            std::stable_sort(cand.begin(), cand.end(), [&](int a, int b) { const bool oa = a >= worst * per + nx && a < worst * per + 2 * nx, ob = b >= worst * per + nx && b < worst * per + 2 * nx; return oa > ob; });
+            std::vector<char> used(cand.size(), 0);
+            std::vector<int> jv(nx);
+            for (int i = 0; i < nx; ++i) {
+                int pick = -1; float best = want_fast ? 1e30f : -1.f; int bestk = -1, tried = 0;
+                for (size_t k = 0; k < cand.size() && tried < 24; ++k) {
+                    if (used[k]) continue;
+                    const float m = pair(ix[i], cand[k]); ++tried;
+                    if (want_fast ? m < best : m > best) { best = m; bestk = int(k); }
+                    if (want_fast ? m < thr : m >= thr) { pick = int(k); break; }
+                }
+                if (pick < 0) pick = bestk;
+                used[pick] = 1; jv[i] = cand[pick];
+            }
+            return jv;
+        };
+        int t0 = tests;
+        const std::vector<int> fastv = arrange(true);
+        printf("{\"probe\":\"pairs_arrange\",\"want\":\"fast\",\"set\":%d,\"pair_tests\":%d}\n", worst, tests - t0);
+        run_set("all_fast", worst, fastv);
+        t0 = tests;
+        const std::vector<int> slowv = arrange(false);
+        printf("{\"probe\":\"pairs_arrange\",\"want\":\"slow\",\"set\":%d,\"pair_tests\":%d}\n", worst, tests - t0);
+        run_set("all_slow", worst, slowv);
+        run_set("as_allocated_again", worst, iv);
+        run_set("all_fast_again", worst, fastv);
+        T.unmap();
+        pool.release();
+        malloc_ctl("hipmalloc_after");
         return 0;
     }
     if (mode == "chunks") {

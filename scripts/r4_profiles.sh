@@ -21,6 +21,8 @@ python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_r4_driver_command.jso
 python3 bench.py --target dense --dim 1000 --chains 10000 --n-sk 200 --steps 10 --warmup 2 --cpu-seconds 0 > $O/bench_r4_config4.json 2>/dev/null || exit 1
 python3 bench.py --sampler BPS --target dense --dim 1000 --chains 10000 --n-sk 200 --steps 3 --warmup 1 --cpu-seconds 0 --pmc off > $O/bench_r4_dense_bps.json 2>/dev/null || exit 1
 python3 bench.py --sampler BoomerangAD --target dense --dim 1000 --chains 10000 --n-sk 200 --steps 3 --warmup 1 --cpu-seconds 0 --pmc off > $O/bench_r4_dense_boomerang.json 2>/dev/null || exit 1
+PDMP_DENSE_GEMM=mfma python3 bench.py --sampler BPS --target dense --dim 1000 --chains 10000 --n-sk 200 --steps 3 --warmup 1 --cpu-seconds 0 --pmc off > $O/bench_r4_dense_bps_mfma.json 2>/dev/null || exit 1
+PDMP_DENSE_GEMM=mfma python3 bench.py --sampler BoomerangAD --target dense --dim 1000 --chains 10000 --n-sk 200 --steps 3 --warmup 1 --cpu-seconds 0 --pmc off > $O/bench_r4_dense_boomerang_mfma.json 2>/dev/null || exit 1
 python3 bench.py --gpus 1 --driver multi --steps 5 --warmup 2 > $O/bench_r4_driver_multi.json 2>/dev/null || exit 1
 for c in 50000 25000 12500; do python3 bench.py --chains $c --steps 10 --warmup 2 --cpu-seconds 0 > $O/bench_r4_shard_$c.json 2>/dev/null || exit 1; done
 python3 bench.py --sampler BPS --target banana --steps 6 --warmup 2 --cpu-seconds 0 > $O/bench_r4_config3.json 2>/dev/null || exit 1

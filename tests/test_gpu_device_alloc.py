@@ -56,3 +56,74 @@ def test_device_alloc_abi(engine):
     assert o["X"].numel() * 8 >= ensemble.CHUNKED_FROM_BYTES and o["t"].numel() * 8 < ensemble.CHUNKED_FROM_BYTES
     o["X"].fill_(1.5); o["t"].zero_()
     assert float(o["X"].sum().item()) == 1.5 * o["X"].numel()
+
+
+def test_streamed_outputs_are_drawn_and_equal_plain_outputs(engine, oracle):
+    """pdmp_device_alloc_streams through ensemble.alloc_outputs: three sets drawn, each timed with the store-pattern kernel, one kept --
+    and the kept arrays are ordinary device memory: the skeleton sampled into them is the checker's."""
+    import torch
+    from pdmpflux.jl_amd import ensemble
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", 50, "iso")
+    Cn, n_sk = 640, 64
+    x, v = make_init("ZigZagAD", 50, Cn, seed=4)
+    xd, vd = torch.from_numpy(x).cuda(), torch.from_numpy(v).cuda()
+    free0 = torch.cuda.mem_get_info()[0]
+    out = ensemble.alloc_outputs(Cn, n_sk, 50, chunked=True, draws=3)
+    info = dict(ensemble.last_alloc_info)
+    assert info["draws"] == 3 and len(info["draw_ms"]) == 3 and all(m > 0 for m in info["draw_ms"]), info
+    assert torch.cuda.mem_get_info()[0] >= free0 - (256 << 20)              # the two losing sets went back
+    got = ensemble.sample_skeleton_device(s, n_sk, xd, vd, seed=9, out=out)
+    ref = oracle.sample_skeleton(cfg, n_sk, x, v, 9, diagnostics=False)
+    assert_bitwise({k: got[k].cpu().numpy() for k in ("X", "V", "t")}, ref, keys=("X", "V", "t"))
+    one = ensemble.alloc_outputs(Cn, n_sk, 50, chunked=True, draws=1)
+    assert ensemble.last_alloc_info["draws"] == 1 and ensemble.last_alloc_info["draw_ms"] == []
+    del out, got, one
+    torch.cuda.synchronize()
+
+
+def test_alloc_streams_abi(engine):
+    import torch
+    from pdmpflux.jl_amd import _lib
+    L = _lib.lib()
+    torch.cuda.init()
+    sizes = (C.c_size_t * 3)(8 << 20, 8 << 20, 1 << 20)
+    ptrs = (C.c_void_p * 3)()
+    ms = (C.c_float * 4)()
+    drawn = C.c_int32(-1)
+    assert L.pdmp_device_alloc_streams(-1, 3, sizes, 2 << 20, 4096, 4, ptrs, ms, C.byref(drawn)) == 0
+    assert drawn.value == 4 and all(ms[i] > 0 for i in range(4)) and len({ptrs[i] for i in range(3)}) == 3
+    for i in range(3):
+        assert L.pdmp_device_free(C.c_void_p(ptrs[i])) == 0
+    # a stride that does not fit (not a multiple of 64 bytes) or unequal stream sizes: one set, no measurement
+    assert L.pdmp_device_alloc_streams(-1, 3, sizes, 2 << 20, 100, 4, ptrs, None, C.byref(drawn)) == 0 and drawn.value == 1
+    for i in range(3):
+        assert L.pdmp_device_free(C.c_void_p(ptrs[i])) == 0
+    assert L.pdmp_device_alloc_streams(-1, 0, sizes, 0, 4096, 2, ptrs, None, None) == _lib.ERR_ARGUMENT
+    zero = (C.c_size_t * 2)(1 << 20, 0)
+    assert L.pdmp_device_alloc_streams(-1, 2, zero, 0, 4096, 2, ptrs, None, None) == _lib.ERR_ARGUMENT
+
+
+def test_reused_addresses_point_at_the_new_memory(engine):
+    """Regression for the stale translations of this stack (csrc/device_alloc.hip, flush_translations): free a chunked array, let other
+    allocations take its physical memory, allocate again (the address range usually comes back) -- what a KERNEL writes through the new
+    array must be what a COPY reads from it, and an array that lived through it must be untouched."""
+    import torch
+    from pdmpflux.jl_amd import ensemble
+    n = (96 << 20) // 8
+    for rep in range(4):
+        a = ensemble.alloc_chunked((n,), chunk_bytes=32 << 20)
+        a.fill_(1.0 + rep)
+        pa = a.data_ptr()
+        keep = ensemble.alloc_chunked((n,), chunk_bytes=32 << 20)
+        keep.fill_(-7.0)
+        torch.cuda.synchronize()
+        del a
+        filler = torch.full((n,), 3.25, dtype=torch.float64, device="cuda")  # ordinary allocations may take the freed pages
+        b = ensemble.alloc_chunked((n,), chunk_bytes=32 << 20)
+        b.fill_(100.0 + rep)                                                 # written by a kernel
+        torch.cuda.synchronize()
+        host = b.cpu()                                                       # read by a copy
+        assert bool((host == 100.0 + rep).all()), (rep, hex(pa), hex(b.data_ptr()), host[:4])
+        assert bool((keep.cpu() == -7.0).all()) and bool((filler.cpu() == 3.25).all())
+        del b, keep, filler, host
+        torch.cuda.synchronize()
