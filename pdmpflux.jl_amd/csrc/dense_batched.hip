@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256, SGN ? 2 : 1) void di_segment_kernel(const DiPa
 // by the flows' recurrence (P x += tau P v) and re-based on an exact product every PDMP_DENSE_RESYNC events (default 64).  One wave per chain, layout and state as
 // di_segment_kernel.  Against the checker (reference order: a mat-vec per grid time) to a tolerance, as the Zig-Zag forms.
 template <int KC>
-__global__ __launch_bounds__(256, 2) void dr_bps_kernel(const DiParams p) {
+__global__ __launch_bounds__(256, (KC >= 32 ? 1 : 2)) void dr_bps_kernel(const DiParams p) {
     const int lane = lane_id();
     const int64_t c = p.c_lo + (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (c >= p.c_hi) return;
@@ -771,7 +771,7 @@ __global__ __launch_bounds__(256, 2) void dr_bps_kernel(const DiParams p) {
 // ---- Boomerang on a dense precision, the same scheme: between events the flow is a rotation of (x, v) and of (P x, P v) by the same angle
 // (16 slots: x, v, P x, P v and the rotation's temporaries need more than 256 registers: one wave per SIMD)
 template <int KC>
-__global__ __launch_bounds__(256, (KC == 16 ? 1 : 2)) void dr_boom_kernel(const DiParams p) {
+__global__ __launch_bounds__(256, (KC >= 16 ? 1 : 2)) void dr_boom_kernel(const DiParams p) {
     const int lane = lane_id();
     const int64_t c = p.c_lo + (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (c >= p.c_hi) return;
@@ -1149,14 +1149,14 @@ extern "C" int pdmp_dense_incremental_run(int device, int d, int signed_bound, i
 }
 
 // BPS / Boomerang on a dense precision: one GEMM + one launch of dr_bps_kernel / dr_boom_kernel per skeleton column (the first launch records columns 0 and 1).
-// Asynchronous on `stream`, workspace as pdmp_dense_incremental_run.  Returns 0, -3, or -5 when d > 1024.
+// Asynchronous on `stream`, workspace as pdmp_dense_incremental_run.  Returns 0, -3, or -5 when d > 2048.
 extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_bound, int adaptive, int gaussian_velocity, double tmax, double refresh,
                                   int64_t cap, const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
                                   const double *xinit, const double *vinit, double *X, double *V, double *t,
                                   double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
                                   int32_t *status, void *stream_v, void **ws, size_t *ws_cap, int64_t resync_events, int gemm_impl, int lanes, char *err, int errlen) {
     hipStream_t stream = (hipStream_t)stream_v;
-    if (d > 16 * WAVE) return -5;
+    if (d > (boomerang ? 24 : 32) * WAVE) return -5;
 #define DB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { snprintf(err, errlen, "%s: %s", #expr, hipGetErrorString(e_)); return -3; } } while (0)
 #define DB_BLAS(expr) do { rocblas_status s_ = (expr); if (s_ != rocblas_status_success) { snprintf(err, errlen, "%s: rocblas status %d", #expr, (int)s_); return -3; } } while (0)
     const size_t n = (size_t)C * (size_t)d;
@@ -1224,11 +1224,13 @@ extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_b
             if (boomerang) {
                 if (d <= 4 * WAVE) hipLaunchKernelGGL((dr_boom_kernel<4>), grid, block, 0, stream, p);
                 else if (d <= 8 * WAVE) hipLaunchKernelGGL((dr_boom_kernel<8>), grid, block, 0, stream, p);
-                else hipLaunchKernelGGL((dr_boom_kernel<16>), grid, block, 0, stream, p);
+                else if (d <= 16 * WAVE) hipLaunchKernelGGL((dr_boom_kernel<16>), grid, block, 0, stream, p);
+                else hipLaunchKernelGGL((dr_boom_kernel<24>), grid, block, 0, stream, p);      // d <= 1536 (32 slots of v, P x, P v spill)
             } else {
                 if (d <= 4 * WAVE) hipLaunchKernelGGL((dr_bps_kernel<4>), grid, block, 0, stream, p);
                 else if (d <= 8 * WAVE) hipLaunchKernelGGL((dr_bps_kernel<8>), grid, block, 0, stream, p);
-                else hipLaunchKernelGGL((dr_bps_kernel<16>), grid, block, 0, stream, p);
+                else if (d <= 16 * WAVE) hipLaunchKernelGGL((dr_bps_kernel<16>), grid, block, 0, stream, p);
+                else hipLaunchKernelGGL((dr_bps_kernel<32>), grid, block, 0, stream, p);       // d <= 2048: 64 KB of LDS per block, one block per CU
             }
             DB_TRY(hipGetLastError());
         }

@@ -745,8 +745,8 @@ int normalize_config(pdmp_config_t &c, bool from_source = false) {
         if (c.deriv_mode != PDMP_DERIV_FORWARD || (c.grid_size != 10 && c.grid_size != 0))
             return fail(PDMP_ERR_UNSUPPORTED, "dense-precision target: grid_size = 10 (or 0) and forward-mode slopes only");
         // Boomerang: only the batched form exists (dense_batched.hip: dr_boom_kernel, one GEMM per event over all chains of a launch)
-        if (c.sampler == PDMP_BOOMERANG && (c.grid_size != 10 || c.dim > 16 * WAVE))
-            return fail(PDMP_ERR_UNSUPPORTED, "dense-precision target: Boomerang with grid_size = 10 and dim <= 1024 only");
+        if (c.sampler == PDMP_BOOMERANG && (c.grid_size != 10 || c.dim > 24 * WAVE))
+            return fail(PDMP_ERR_UNSUPPORTED, "dense-precision target: Boomerang with grid_size = 10 and dim <= 1536 only");
         if (group_waves_per_block((c.dim + WAVE - 1) / WAVE, 0, 6) < 1) return fail(PDMP_ERR_UNSUPPORTED, "dense-precision target: dim too large for the LDS tiles");
     }
     if (c.deriv_mode != PDMP_DERIV_FORWARD && c.deriv_mode != PDMP_DERIV_FINITE_DIFF) return fail(PDMP_ERR_ARGUMENT, "Unsupported AD_backend id %d", c.deriv_mode);
@@ -1175,7 +1175,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
     // BPS / Boomerang on a dense precision, many chains: the rate along the flow is a closed form in a few dot products with P x and P v
     // (BPS: <P x, v> + t <P v, v>; Boomerang: a quadratic form in cos t, sin t), so only an accepted event needs products with P --
     // P [x | v'] of ALL chains as one fp64 GEMM per skeleton column (dense_batched.hip: dr_bps_kernel, dr_boom_kernel)
-    const bool bps_batched = c.target_id == PDMP_T_GAUSS_DENSE && (c.sampler == PDMP_BPS || c.sampler == PDMP_BOOMERANG) && c.grid_size == GNG && c.dim <= 16 * WAVE &&
+    const bool bps_batched = c.target_id == PDMP_T_GAUSS_DENSE && (c.sampler == PDMP_BPS || c.sampler == PDMP_BOOMERANG) && c.grid_size == GNG && c.dim <= (c.sampler == PDMP_BOOMERANG ? 24 : 32) * WAVE &&
                              c.deriv_mode == PDMP_DERIV_FORWARD && !taped && !until && 2 * C < 0x7fffffffLL &&
                              (c.sampler == PDMP_BOOMERANG || (dense_mode ? (dense_mode == 2 || dense_mode == 1) : C >= 64));
     if (c.target_id == PDMP_T_GAUSS_DENSE && c.sampler == PDMP_BOOMERANG && !bps_batched) {

@@ -602,6 +602,32 @@ def test_dense_precision_boomerang_one_gemm_per_event(engine, oracle, monkeypatc
     assert np.allclose(got["horizon"], ref["horizon"], rtol=1e-12) and np.allclose(got["ar"], ref["ar"], rtol=1e-7, atol=1e-12)
 
 
+@pytest.mark.parametrize("kind,dim,kw", [("BPS", 1100, {}), ("BPS", 2048, {"refresh_rate": 1.5}), ("BPS", 1537, {"signed_bound": False}),
+                                         ("BoomerangAD", 1100, {}), ("BoomerangAD", 1536, {"refresh_rate": 1.5})])
+def test_dense_precision_one_gemm_per_event_beyond_d_1024(engine, oracle, kind, dim, kw):
+    """Round 4: the one-GEMM-per-event forms with 32 (BPS, d <= 2048) / 24 (Boomerang, d <= 1536) slots of v, P x, P v per lane; beyond
+    that BPS falls back to the per-chain kernel and the Boomerang is refused at creation.  Same tolerances as at d <= 1024."""
+    from pdmpflux.jl_amd import _lib
+    s, cfg = make_pair(engine, oracle, kind, dim, "dense", arith=oracle.ARITH_REFERENCE, **kw)
+    chains, n_sk = 64, 8
+    x, v = make_init(kind, dim, chains)
+    got = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=23, diagnostics=True)
+    assert _lib.lib().pdmp_dense_batched_last_mode() == 3 and s.last_launch_form() == 5
+    ref = oracle.sample_skeleton(cfg, n_sk, x, v, 23, diagnostics=True)
+    for k in ("rejected", "hitting_horizon", "errored_bound"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert np.allclose(got["t"], ref["t"], rtol=1e-9, atol=0)
+    assert np.allclose(got["X"], ref["X"], rtol=1e-8, atol=1e-10)
+    assert np.allclose(got["V"], ref["V"], rtol=1e-8, atol=1e-10)
+
+
+def test_dense_precision_boomerang_refused_beyond_its_slots(engine, oracle):
+    with pytest.raises(Exception):
+        s, _ = make_pair(engine, oracle, "BoomerangAD", 1537, "dense")
+        x, v = make_init("BoomerangAD", 1537, 64)
+        engine.sample_skeleton_ensemble(s, 4, x, v, seed=1)
+
+
 @pytest.mark.parametrize("target", ["iso", "banana"])
 def test_group_kernel_full_machine_zigzag(engine, oracle, monkeypatch, target):
     """The group kernel on a launch that fills the machine (PDMP_LANE=0, 40 000 chains: 10 000 batches of 16 for 2 048 resident waves):
