@@ -515,6 +515,9 @@ def main():
         if sid == 5:                                              # RHMC (round 4): FULL 13-slot kernels on iso / banana, partial ones on diag
             reg_form = (G > 0 and G <= 16 and os.environ.get("PDMP_REG", "1") != "0" and
                         ((a.target in ("iso", "banana") and K == 13) or (a.target == "diag" and K <= 13 and (G == 1 or K >= 7))))
+        if sid == 3:                                              # ForwardECMC (round 4): exact-K kernels, K <= 7 (five LDS tiles per wave beside the registers)
+            reg_form = (G > 0 and G <= 16 and not fd and a.target in ("iso", "diag", "banana") and K <= 7 and K >= (2 if G == 1 else 4)
+                        and os.environ.get("PDMP_REG", "1") != "0" and os.environ.get("PDMP_REG_EXACT", "1") != "0")
         kernel = (f"group_kernel_reg<{sampler.name},{a.target}> (G={G} lanes per chain, K={K} slots, x and v in registers)" if reg_form else
                   f"group_kernel<{sampler.name},{a.target}> (G={G} lanes per chain)" if G > 0 else
                   f"skeleton_kernel<{sampler.name},{a.target}> (wave per chain)")

@@ -26,6 +26,7 @@ hipError_t launch_group_reg_boomerang(int target, bool fd, const GroupParams &gp
 hipError_t launch_group_reg_rhmc(int target, const GroupParams &gp, hipStream_t stream);                        // inst_reg_rhmc.hip
 hipError_t launch_group_reg_zigzag_exact(int target, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_bps_exact(int target, const GroupParams &gp, hipStream_t stream);
+hipError_t launch_group_reg_fecmc_exact(int target, const GroupParams &gp, hipStream_t stream);                 // inst_reg_fecmc_k*.hip
 hipError_t launch_group_reg_boomerang_exact(int target, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_boomerang_exact_fd(int target, const GroupParams &gp, hipStream_t stream);
 // tape replay (pdmp_set_tape): the same kernel forms with the tapes as random source (inst_tape_*.hip)
@@ -816,6 +817,14 @@ int choose_group_lanes(const pdmp_config_t &c) {
         if (G == 0) return 0;
         if (G >= 1 && G <= WAVE && (G & (G - 1)) == 0 && group_waves_per_block((c.dim + G - 1) / G, 2 * c.dim) >= 1) return G;
     }
+    if (c.sampler == PDMP_FECMC && c.deriv_mode == PDMP_DERIV_FORWARD && c.grid_size == GNG && c.target_id <= PDMP_T_BANANA) {
+        // register form (round 4, inst_reg_fecmc_k*.hip): x, v in VGPRs, five LDS tiles of K x 64 doubles per wave (exchange, n, v_orth,
+        // e1, e2) -- K <= 7 keeps two blocks of four waves per CU; exact-K kernels for K = 2 .. 7 at one lane per chain, 4 .. 7 otherwise
+        for (int G = 1; G <= 16; G <<= 1) {
+            const int K = (c.dim + G - 1) / G;
+            if (K <= 7 && K >= (G == 1 ? 2 : 4)) return G;
+        }
+    }
     if (c.sampler == PDMP_FECMC) {         // six LDS tiles per wave (x, v, n, v_orth, e1, e2): 20 KB keep two blocks per CU (measured
         for (int G = 1; G <= WAVE; G <<= 1)   // at d = 50: G = 4 / 8 / 16 -> 467 / 566 / 306 ms); 40 KB for very large d
             if (6 * (size_t)((c.dim + G - 1) / G) * WAVE * sizeof(double) <= 20 * 1024) return G;
@@ -1264,7 +1273,8 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
                                                          : launch_group_reg_boomerang_exact(c.target_id, gp, s))
                   : fd                             ? hipErrorNotSupported
                   : c.sampler == PDMP_ZIGZAG       ? launch_group_reg_zigzag_exact(c.target_id, gp, s)
-                  : c.sampler == PDMP_BPS          ? launch_group_reg_bps_exact(c.target_id, gp, s) : hipErrorNotSupported;
+                  : c.sampler == PDMP_BPS          ? launch_group_reg_bps_exact(c.target_id, gp, s)
+                  : c.sampler == PDMP_FECMC        ? launch_group_reg_fecmc_exact(c.target_id, gp, s) : hipErrorNotSupported;   // round 4: K <= 7
             if (e == hipErrorNotSupported && !tgroup)
                 e = c.sampler == PDMP_ZIGZAG    ? launch_group_reg_zigzag(c.target_id, fd, gp, s)
                   : c.sampler == PDMP_BPS       ? launch_group_reg_bps(c.target_id, fd, gp, s)

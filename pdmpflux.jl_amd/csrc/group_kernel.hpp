@@ -1961,8 +1961,8 @@ __device__ __forceinline__ void group_kernel_body(const GroupParams &gp) {
     // register form: no x tile; one K*64-double tile per wave only where refreshed velocities are exchanged between lanes
     GroupChain<SAMPLER, TARGET, FD, KC, GC, TAPE, LEAN> chain(gp, lane, tile, KC > 0 ? tile : tile + tsz);
     chain.tgt.init(smem, gp.s.d);
-    if constexpr (SAMPLER == S_FECMC) {
-        for (int q = 0; q < 4; ++q) chain.fe_t[q] = tile + (2 + q) * tsz;
+    if constexpr (SAMPLER == S_FECMC) {                              // (register form: the exchange tile first, then the four jump vectors)
+        for (int q = 0; q < 4; ++q) chain.fe_t[q] = tile + ((KC > 0 ? 1 : 2) + q) * tsz;
     }
     if constexpr (SAMPLER == S_STICKY) chain.kap = smem + (gp.tpar - gp.s.d);   // kappa[d]: the last d staged parameters
     if constexpr (GTarget<TARGET>::kTile) {
@@ -2028,7 +2028,9 @@ template <int SAMPLER, int TARGET, bool FD> struct RegForm {
     // skips on the diagonal Gaussian (FULL there spills 2 - 4 registers with the diagnostic arrays compiled in); the slope mode plays no
     // part in RHMC (constant refresh clock): only FD = false is instantiated.  SpeedUpZigZag spills 110 - 700 registers in every variant
     // at two waves per SIMD (its flow and effective gradient on forward-mode numbers) and still 30 -- into AGPRs -- at one wave per SIMD
-    // (tried in round 4; a spill is not allowed here, see below): LDS form only, like ForwardECMC (six tiles).
+    // (tried in round 4; a spill is not allowed here, see below): LDS form only.  ForwardECMC (round 4): x, v in registers, the jump's four
+    // d-vectors stay in LDS tiles (five tiles per wave with the exchange tile), exact-K kernels for K <= 7 only (inst_reg_fecmc_k*.hip: 160 - 253
+    // VGPRs, no spill, two waves per SIMD; forward-mode slopes) -- d = 50: 50.4 -> 27.5 ms (iso), 72.3 -> 28.7 ms (banana) against the LDS form's best layout.
     static constexpr bool kRhmc = SAMPLER == S_RHMC;
     static constexpr bool kPartial = kRhmc ? (TARGET == T_GAUSS_DIAG)
                                            : (!kSlowZz && !(SAMPLER == S_BOOMERANG && TARGET != T_GAUSS_DIAG));   // would spill: Boomerang iso / banana with the skips
@@ -2036,7 +2038,8 @@ template <int SAMPLER, int TARGET, bool FD> struct RegForm {
         if constexpr (kRhmc) return !(TARGET == T_GAUSS_DIAG && GC >= 2);
         return !kSlowZz && !((SAMPLER == S_ZIGZAG || SAMPLER == S_BOOMERANG) && TARGET == T_GAUSS_DIAG && GC == 1);
     }
-    static constexpr bool kAny = !kSlowZz && SAMPLER != S_FECMC && SAMPLER != S_SUZZ && SAMPLER != S_STICKY && !(kRhmc && FD);
+    static constexpr bool kFecmc = SAMPLER == S_FECMC;
+    static constexpr bool kAny = !kSlowZz && !(kFecmc && FD) && SAMPLER != S_SUZZ && SAMPLER != S_STICKY && !(kRhmc && FD);
 };
 
 // register form (x, v in VGPRs, up to KC slots per lane, G fixed at compile time): no LDS tiles; 2 waves per SIMD -- the
@@ -2090,7 +2093,7 @@ hipError_t launch_group_tape(const GroupParams &gp, hipStream_t stream);       /
 template <int SAMPLER, int TARGET, bool FD, int KC = 0, int GC = 0, bool EXACT = false, bool TAPE = false>
 hipError_t launch_group_impl(const GroupParams &gp_in, hipStream_t stream) {
     GroupParams gp = gp_in;
-    if (KC > 0) gp.tiles = (SAMPLER == S_ZIGZAG) ? 0 : 1;
+    if (KC > 0) gp.tiles = (SAMPLER == S_ZIGZAG) ? 0 : (SAMPLER == S_FECMC ? 5 : 1);      // (ForwardECMC: the exchange tile + n, v_orth, e1, e2)
     const int cpw = WAVE / gp.G, wpb = KC > 0 ? 4 : group_waves_per_block(gp.K, gp.tpar, gp.tiles);
     if (wpb < 1) return hipErrorInvalidValue;
     const size_t lds = ((size_t)gp.tpar + (size_t)wpb * gp.tiles * gp.K * WAVE) * sizeof(double);

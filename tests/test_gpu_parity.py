@@ -413,6 +413,8 @@ def test_dense_precision_batched_paths_match_oracle(engine, oracle, monkeypatch,
     ("Boomerang", 100, "iso", {}), ("BoomerangAD", 100, "iso", {}), ("BoomerangAD", 60, "diag", {}), ("Boomerang", 26, "iso", {}),
     ("BoomerangAD", 50, "banana", {}),
     ("RHMC", 50, "iso", {}), ("RHMC", 50, "banana", {"step_size": 0.013}), ("RHMC", 13, "diag", {"phi": 0.7}), ("RHMC", 100, "iso", {"refresh_rate": 2.5}),
+    ("ForwardECMC", 50, "iso", {}), ("ForwardECMC", 50, "banana", {"mix_p": 0.9}), ("ForwardECMC", 7, "diag", {}), ("ForwardECMC", 13, "iso", {"switch": False}),
+    ("ForwardECMC", 30, "diag", {"ran_p": False}), ("ForwardECMC", 100, "banana", {"positive": False}), ("ForwardECMC", 3, "iso", {}),
 ])
 def test_register_and_lds_forms_agree(engine, oracle, monkeypatch, kind, dim, target, kw):
     """With ceil(d/G) <= 13 the group kernel keeps x, v in registers (inst_reg_*.hip; RegForm says for which sampler /
