@@ -91,6 +91,46 @@ int main(void) {
     bad += run_case(ORC_ZIGZAG, ORC_T_GAUSS_DENSE, 9, ORC_ARITH_REFERENCE, 1, 0, 10, 1, 2, 30); ++n;     /* dense precision */
     bad += run_case(ORC_ZIGZAG, ORC_T_GAUSS_ISO, 50, ORC_ARITH_GROUP, 4, 0, 10, 1, 5, 60); ++n;          /* config 2's shape */
     bad += run_case(ORC_ZIGZAG, ORC_T_GAUSS_ISO, 7, ORC_ARITH_REFERENCE, 1, 0, 64, 1, 2, 20); ++n;       /* the largest grid */
+    /* Julia's random source restated (oracle/julia_rng.c): the three draw kinds under both seedings, then skeletons drawn from it with the
+     * tapes of what every chain consumed recorded (the producer side of pdmp_set_tape) -- incl. a tape capacity that is too small (-6, no overrun) */
+    for (int seeding = 1; seeding <= 2; ++seeding)
+        for (int kind = 0; kind < 3; ++kind) {
+            double buf[1500];
+            orc_julia_draws(1234 + kind, seeding, kind, 1500, buf);
+            for (int i = 0; i < 1500; ++i) if (!(buf[i] == buf[i]) || (kind != 2 && buf[i] < 0.0) || (kind == 0 && buf[i] >= 1.0)) { fprintf(stderr, "julia draw kind %d seeding %d: %g\n", kind, seeding, buf[i]); bad++; break; }
+            ++n;
+        }
+    {
+        const int smp[] = {ORC_ZIGZAG, ORC_BPS, ORC_BOOMERANG, ORC_FECMC};
+        for (int si = 0; si < 4; ++si)
+            for (int seeding = 1; seeding <= 2; ++seeding)
+                for (int small = 0; small < 2; ++small) {
+                    orc_config_t cfg;
+                    memset(&cfg, 0, sizeof cfg);
+                    const int d = 6 + si, C = 3, n_sk = 30;
+                    cfg.sampler = smp[si]; cfg.dim = d; cfg.grid_size = 10; cfg.arith = ORC_ARITH_REFERENCE; cfg.group_lanes = 1;
+                    cfg.target_id = ORC_T_GAUSS_ISO; cfg.adaptive = 1; cfg.signed_bound = 1; cfg.max_iter_per_event = 100000;
+                    cfg.vectorized_bound = smp[si] == ORC_ZIGZAG;
+                    cfg.tmax = smp[si] == ORC_ZIGZAG ? 2.0 : 1.0; cfg.refresh_rate = (smp[si] == ORC_BPS || smp[si] == ORC_BOOMERANG) ? 0.3 : 0.0;
+                    cfg.fe_mix_p = 0.5; cfg.fe_switch = 1; cfg.fe_positive = 1; cfg.fe_speed_factor = 1.0;
+                    cfg.julia_rng = seeding;
+                    const int64_t cap = small ? 7 : 6000;
+                    double *te = malloc(8 * (size_t)C * cap), *tu = malloc(8 * (size_t)C * cap), *tn = malloc(8 * (size_t)C * cap);
+                    int64_t cnt[9];
+                    cfg.jl_tape_exp = te; cfg.jl_tape_uni = tu; cfg.jl_tape_nrm = tn; cfg.jl_cap_exp = cfg.jl_cap_uni = cfg.jl_cap_nrm = cap; cfg.jl_count = cnt;
+                    int rc = orc_normalize_config(&cfg);
+                    double x[3 * 9], v[3 * 9];
+                    uint64_t s = 777u + (uint64_t)si;
+                    for (int i = 0; i < C * d; ++i) { x[i] = 2.0 * urand(&s) - 1.0; v[i] = smp[si] == ORC_ZIGZAG ? (urand(&s) < 0.5 ? -1.0 : 1.0) : 2.0 * urand(&s) - 1.0; }
+                    const size_t ne = (size_t)C * n_sk;
+                    double *X = malloc(8 * ne * d), *V = malloc(8 * ne * d), *t = malloc(8 * ne);
+                    if (rc == 0) rc = orc_sample_skeleton(&cfg, C, n_sk, 0, x, v, 42, X, V, t, NULL, NULL, NULL, NULL, NULL, NULL, 1);
+                    if (small ? rc != -6 : rc != 0) { fprintf(stderr, "julia source sampler %d seeding %d cap %lld: rc %d (%s)\n", smp[si], seeding, (long long)cap, rc, orc_last_error()); bad++; }
+                    if (!small && rc == 0) for (int c = 0; c < C; ++c) if (cnt[3 * c] < n_sk - 1 || cnt[3 * c] > cap) { fprintf(stderr, "julia source: exponential count %lld\n", (long long)cnt[3 * c]); bad++; }
+                    free(te); free(tu); free(tn); free(X); free(V); free(t);
+                    ++n;
+                }
+    }
     printf("sanitize_driver: %d cases, %d failed\n", n, bad);
     return bad ? 1 : 0;
 }

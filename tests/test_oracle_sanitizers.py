@@ -1,6 +1,6 @@
 """The checker's C restatement under AddressSanitizer + UndefinedBehaviorSanitizer ("sanitizers on the CPU build"; GPU
 sanitizers are not available on the pool).  `make -C oracle check-sanitize` builds oracle/sanitize_driver.c with
--fsanitize=address,undefined -fno-sanitize-recover=all and runs 131 sampler / target / order / slope-mode cases plus the callers of the
+-fsanitize=address,undefined -fno-sanitize-recover=all and runs 153 cases: 131 sampler / target / order / slope-mode cases plus the callers of the
 path (the three sample_from_skeleton methods with ragged histories, the time-horizon variant incl. a capacity that is too small);
 any finding aborts the driver.  CPU only, a few seconds."""
 import os
