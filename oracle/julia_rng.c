@@ -143,6 +143,31 @@ static void ds_init_by_array(jl_mt_t *m, const uint32_t *key, int key_length) { 
     m->idx = 2 * JL_DSFMT_N;                                     /* the buffer is consumed: the first draw generates */
 }
 
+/* dsfmt_chk_init_gen_rand (dSFMT.c): the generator's own 32-bit seeding -- Julia never uses it; here for the known-answer vector that ships
+ * with the dSFMT sources (dSFMT.19937.out.txt: init_gen_rand(0), the first values in [1, 2)). */
+void jl_dsfmt_init_gen_rand(jl_mt_t *m, uint32_t seed) {
+    uint32_t *p = m->st.flat32;
+    const int size = (JL_DSFMT_N + 1) * 4;
+    p[0] = seed;
+    for (int i = 1; i < size; ++i) p[i] = 1812433253u * (p[i - 1] ^ (p[i - 1] >> 30)) + (uint32_t)i;
+    for (int i = 0; i < 2 * JL_DSFMT_N; ++i) m->st.flat[i] = (m->st.flat[i] & DS_LOW_MASK) | DS_HIGH_CONST;
+    {
+        const uint64_t t0 = m->st.w[JL_DSFMT_N].u[0] ^ DS_FIX1, t1 = m->st.w[JL_DSFMT_N].u[1] ^ DS_FIX2;
+        uint64_t inner = (t0 & DS_PCV1) ^ (t1 & DS_PCV2);
+        for (int i = 32; i > 0; i >>= 1) inner ^= inner >> i;
+        if ((inner & 1) == 0) m->st.w[JL_DSFMT_N].u[1] ^= 1;
+    }
+    m->idx = 2 * JL_DSFMT_N;
+}
+void jl_dsfmt_close1_open2(uint32_t seed, int n, double *out) {
+    jl_mt_t m;
+    jl_dsfmt_init_gen_rand(&m, seed);
+    for (int i = 0; i < n; ++i) {
+        if (m.idx >= 2 * JL_DSFMT_N) { ds_gen_rand_all(&m); m.idx = 0; }
+        union { uint64_t u; double d; } c; c.u = m.st.flat[m.idx++]; out[i] = c.d;
+    }
+}
+
 void jl_mt_seed(jl_mt_t *m, int64_t seed, int seeding) {
     /* the 32-bit limbs of the (non-negative) seed, little end first: Julia's make_seed(n) (1.0 - 1.10: the key itself); 1.11 hashes the same
      * limbs (and a trailing 0x01 byte for a negative seed, whose limbs are those of ~seed) with SHA-256: hash_seed(seed::Integer) */

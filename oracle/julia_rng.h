@@ -21,6 +21,7 @@ typedef struct jl_mt_t {
 
 void   jl_init_tables(void);                 /* builds the ziggurat tables (not thread-safe: call once before threads start) */
 void   jl_mt_seed(jl_mt_t *m, int64_t seed, int seeding);
+void   jl_dsfmt_close1_open2(uint32_t seed, int n, double *out);   /* dSFMT's own init_gen_rand(seed), then n values in [1, 2): the published test vector */
 double jl_rand(jl_mt_t *m);                  /* rand(rng)     in [0, 1) */
 double jl_randexp(jl_mt_t *m);               /* randexp(rng)  */
 double jl_randn(jl_mt_t *m);                 /* randn(rng)    */

@@ -21,6 +21,19 @@ def test_mersenne_twister_known_answers(oracle):
     assert O.julia_draws(1234, 4, "randn").tolist() == [0.8673472019512456, -0.9017438158568171, -0.4944787535042339, -0.9029142938652416]
 
 
+def test_dsfmt_published_vector(oracle):
+    """The known-answer file that ships with the dSFMT sources (dSFMT.19937.out.txt: `init_gen_rand(0)`, "generated randoms [1, 2)",
+    printed with %.15f): the first eight values.  Pins the recursion, the masks, the initial mask and the period certification of
+    oracle/julia_rng.c independently of Julia's seeding."""
+    import ctypes as C
+    import numpy as np
+    L = oracle.lib()
+    out = np.empty(8)
+    L.jl_dsfmt_close1_open2(C.c_uint32(0), 8, out.ctypes.data_as(C.POINTER(C.c_double)))
+    assert ["%.15f" % x for x in out] == ["1.030581026769374", "1.213140320067012", "1.299002525016001", "1.381138853044628",
+                                          "1.863488397063594", "1.133443440024236", "1.073465290616508", "1.924735636004535"]
+
+
 def test_ziggurat_tables_match_normal_jl_entries(oracle):
     L = oracle.lib()
     u64p, dp = C.POINTER(C.c_uint64), C.POINTER(C.c_double)
