@@ -103,7 +103,13 @@ int pdmp_device_alloc(int32_t device, size_t bytes, size_t chunk_bytes, void **o
     hipMemAccessDesc desc;
     desc.location.type = hipMemLocationTypeDevice; desc.location.id = dev; desc.flags = hipMemAccessFlagsProtReadWrite;
     DA_TRY(hipMemSetAccess(base, a.va_bytes, &desc, 1), a.handles.size());
-    flush_translations();
+    {                                                                      // (the flush belongs to the device the memory lives on)
+        int cur = dev;
+        (void)hipGetDevice(&cur);
+        if (cur != dev) (void)hipSetDevice(dev);
+        flush_translations();
+        if (cur != dev) (void)hipSetDevice(cur);
+    }
 #undef DA_TRY
     {
         std::lock_guard<std::mutex> lk(g_mu);
