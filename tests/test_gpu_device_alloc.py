@@ -110,7 +110,7 @@ def test_reused_addresses_point_at_the_new_memory(engine):
     import torch
     from pdmpflux.jl_amd import ensemble
     n = (96 << 20) // 8
-    for rep in range(4):
+    for rep in range(16):                                                    # (many cycles: the flush must keep working late in a process, too)
         a = ensemble.alloc_chunked((n,), chunk_bytes=32 << 20)
         a.fill_(1.0 + rep)
         pa = a.data_ptr()
