@@ -588,10 +588,7 @@ __global__ __launch_bounds__(256, SGN ? 2 : 1) void di_segment_kernel(const DiPa
 // by the flows' recurrence (P x += tau P v) and re-based on an exact product every PDMP_DENSE_RESYNC events (default 64).  One wave per chain, layout and state as
 // di_segment_kernel.  Against the checker (reference order: a mat-vec per grid time) to a tolerance, as the Zig-Zag forms.
 template <int KC>
-__global__ __launch_bounds__(256, (KC >= 32 ? 1 : 2)) void dr_bps_kernel(const DiParams p) {
-    const int lane = lane_id();
-    const int64_t c = p.c_lo + (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (c >= p.c_hi) return;
+__device__ __forceinline__ void dr_bps_chain(const DiParams &p, const int64_t c, double *x_tile, const int lane) {
     DiState cs;
     if (p.k_begin == 0) { cs.t = 0.0; cs.horizon = p.tmax; cs.rng_n = 0; cs.dead = 0; cs.pad = 0; }
     else cs = p.st[c];
@@ -599,8 +596,7 @@ __global__ __launch_bounds__(256, (KC >= 32 ? 1 : 2)) void dr_bps_kernel(const D
     const int d = p.d;
     const bool adaptive = p.adaptive != 0, sgn = p.signed_bound != 0;
     const double refresh = p.refresh, refresh_b = sgn ? p.refresh : 0.0;     // (the signed bound adds refresh_rate to every cell again, AbstractPDMP.jl:104-112)
-    __shared__ double x_lds[4][KC * WAVE];
-    double *x = x_lds[threadIdx.x >> 6] + lane;          // slot s at x[s * WAVE]
+    double *x = x_tile + lane;                           // slot s at x[s * WAVE]
     double v[KC], gx[KC], gv[KC];
     {
         const double *xin = p.In + (size_t)c * d, *vin = p.In + ((size_t)p.C + (size_t)c) * d;
@@ -767,14 +763,19 @@ __global__ __launch_bounds__(256, (KC >= 32 ? 1 : 2)) void dr_bps_kernel(const D
         if (dead) atomicAdd(&p.status[0], 1);
     }
 }
+// one wave per chain; a launch of fewer workgroups than chains / 4 walks the chains with the grid's stride (PDMP_DENSE_STEP_BLOCKS: a step
+// kernel that leaves room on the CUs for the other lane's product, dense BPS / Boomerang pipeline)
+template <int KC>
+__global__ __launch_bounds__(256, (KC >= 32 ? 1 : 2)) void dr_bps_kernel(const DiParams p) {
+    __shared__ double x_lds[4][KC * WAVE];
+    const int lane = lane_id(), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (int64_t c = p.c_lo + (int64_t)blockIdx.x * 4 + wv; c < p.c_hi; c += (int64_t)gridDim.x * 4) dr_bps_chain<KC>(p, c, x_lds[wv], lane);
+}
 
 // ---- Boomerang on a dense precision, the same scheme: between events the flow is a rotation of (x, v) and of (P x, P v) by the same angle
 // (16 slots: x, v, P x, P v and the rotation's temporaries need more than 256 registers: one wave per SIMD)
 template <int KC>
-__global__ __launch_bounds__(256, (KC >= 16 ? 1 : 2)) void dr_boom_kernel(const DiParams p) {
-    const int lane = lane_id();
-    const int64_t c = p.c_lo + (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (c >= p.c_hi) return;
+__device__ __forceinline__ void dr_boom_chain(const DiParams &p, const int64_t c, double *x_tile, const int lane) {
     DiState cs;
     if (p.k_begin == 0) { cs.t = 0.0; cs.horizon = p.tmax; cs.rng_n = 0; cs.dead = 0; cs.pad = 0; }
     else cs = p.st[c];
@@ -782,8 +783,7 @@ __global__ __launch_bounds__(256, (KC >= 16 ? 1 : 2)) void dr_boom_kernel(const 
     const int d = p.d;
     const bool adaptive = p.adaptive != 0, sgn = p.signed_bound != 0;
     const double refresh = p.refresh, refresh_b = sgn ? p.refresh : 0.0;     // (the signed bound adds refresh_rate to every cell again, AbstractPDMP.jl:104-112)
-    __shared__ double x_lds[4][KC * WAVE];
-    double *x = x_lds[threadIdx.x >> 6] + lane;          // slot s at x[s * WAVE]
+    double *x = x_tile + lane;                           // slot s at x[s * WAVE]
     double v[KC], gx[KC], gv[KC];
     {
         const double *xin = p.In + (size_t)c * d, *vin = p.In + ((size_t)p.C + (size_t)c) * d;
@@ -969,6 +969,14 @@ __global__ __launch_bounds__(256, (KC >= 16 ? 1 : 2)) void dr_boom_kernel(const 
         p.st[c] = cs;
         if (dead) atomicAdd(&p.status[0], 1);
     }
+}
+// one wave per chain; a launch of fewer workgroups than chains / 4 walks the chains with the grid's stride (PDMP_DENSE_STEP_BLOCKS: a step
+// kernel that leaves room on the CUs for the other lane's product, dense BPS / Boomerang pipeline)
+template <int KC>
+__global__ __launch_bounds__(256, (KC >= 16 ? 1 : 2)) void dr_boom_kernel(const DiParams p) {
+    __shared__ double x_lds[4][KC * WAVE];
+    const int lane = lane_id(), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (int64_t c = p.c_lo + (int64_t)blockIdx.x * 4 + wv; c < p.c_hi; c += (int64_t)gridDim.x * 4) dr_boom_chain<KC>(p, c, x_lds[wv], lane);
 }
 
 }  // namespace pdmp
@@ -1192,6 +1200,19 @@ extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_b
     const int nl = (lanes >= 2 && C >= 256) ? 2 : 1;
     static const int polite_env = getenv("PDMP_DGEMM_POLITE") ? atoi(getenv("PDMP_DGEMM_POLITE")) : 2;   // (tuning: workgroups of the product per CU beside the other lane's step kernel)
     const int gemm_polite = (nl == 2) ? polite_env : 0;
+    // workgroups of a step kernel (PDMP_DENSE_STEP_BLOCKS; 0 = one wave per chain).  The kernels that fit one workgroup per CU only (Boomerang
+    // from 9 slots on, BPS with 32: 256 registers) run as ONE persistent workgroup per CU beside the other lane's product: measured at
+    // d = 1000, 10^4 chains x 200, Boomerang: 115.2 -> 103.7 ms (192 / 320 workgroups: 107.6 / 111.5); BPS with 16 slots (two workgroups per
+    // CU): 94 - 96 ms whatever the count
+    static const int step_env = getenv("PDMP_DENSE_STEP_BLOCKS") ? atoi(getenv("PDMP_DENSE_STEP_BLOCKS")) : -1;
+    int step_blocks = 0;
+    if (nl == 2) {
+        step_blocks = step_env >= 0 ? step_env : 0;
+        if (step_env < 0 && (boomerang ? d > 8 * WAVE : d > 16 * WAVE)) {
+            int cus = 0;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) step_blocks = cus;
+        }
+    }
     DbSide *side = (nl == 2) ? db_side(device) : nullptr;
     if (nl == 2 && !side) { snprintf(err, errlen, "side stream"); return -3; }
     hipStream_t ls[2] = {stream, side ? side->stream : stream};
@@ -1220,7 +1241,8 @@ extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_b
             if (full) DB_GEMM(cols, In + off, Out + off);                  // P x of this lane's chains
             DB_GEMM(cols, In + n + off, Out + n + off);                    // P v'
             p.c_lo = lo; p.c_hi = hi;
-            const dim3 grid((unsigned)((hi - lo + 3) / 4));
+            const unsigned full_grid = (unsigned)((hi - lo + 3) / 4);
+            const dim3 grid((step_blocks > 0 && (unsigned)step_blocks < full_grid) ? (unsigned)step_blocks : full_grid);
             if (boomerang) {
                 if (d <= 4 * WAVE) hipLaunchKernelGGL((dr_boom_kernel<4>), grid, block, 0, stream, p);
                 else if (d <= 8 * WAVE) hipLaunchKernelGGL((dr_boom_kernel<8>), grid, block, 0, stream, p);
