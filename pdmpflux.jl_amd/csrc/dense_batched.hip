@@ -1193,10 +1193,11 @@ extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_b
     const double one = 1.0, zero = 0.0;
     g_last_phases = 0; g_last_columns = 0; g_last_mode = 3;
     const int64_t resync = resync_events >= 1 ? resync_events : 64;   // events between two full products P [x | v]; in between only P v' is multiplied (policy: PDMP_DENSE_RESYNC)
-    // Chains are independent, and an event of a chain is GEMM (matrix cores) -> step kernel (vector ALUs, memory): with the ensemble cut into
-    // TWO half-ensembles on two streams the product of one half runs beside the step of the other -- the MFMA waves and the VALU waves share
-    // the CUs (1 + 1 waves per SIMD fit both kernels' registers and LDS) -- instead of the two kinds of unit taking turns.  Same arithmetic per
-    // chain: bit-identical to one lane with the hand-written product (rocBLAS may pick another kernel for another column count).
+    // Chains are independent: the ensemble is cut into TWO half-ensembles that run the same event loop on two streams.  Measured (d = 1000,
+    // 10^4 chains x 200): 108 -> 93 ms for BPS.  What it buys is mostly the library's better rate on the half-sized product (65 against 51
+    // TFLOP/s) and the launch gaps it fills; the products and the step kernels of the two lanes do NOT end up side by side (see the note in the
+    // loop below).  Same arithmetic per chain: bit-identical to one lane with the hand-written product (rocBLAS may pick another kernel for
+    // another column count).
     const int nl = (lanes >= 2 && C >= 256) ? 2 : 1;
     static const int polite_env = getenv("PDMP_DGEMM_POLITE") ? atoi(getenv("PDMP_DGEMM_POLITE")) : 2;   // (tuning: workgroups of the product per CU beside the other lane's step kernel)
     const int gemm_polite = (nl == 2) ? polite_env : 0;
@@ -1238,6 +1239,10 @@ extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_b
             rocblas_handle hb = lh[l];
             const size_t off = (size_t)lo * (size_t)d;
             const int cols = (int)(hi - lo);
+            // (what the two lanes buy is the library's better rate on the half-sized product, 65 against 51 TFLOP/s -- the kernel trace shows the
+            //  lanes running IN phase, product beside product and step beside step, and the launch costs the sum of the two kinds of work;
+            //  round 4 tried to change that and could not: products forced to take turns across the lanes 94.6 -> 112 ms, a step kernel with
+            //  110 registers and no LDS that could share a SIMD with the product 95.4 -> 96.1 ms: DESIGN.md 4.3c)
             if (full) DB_GEMM(cols, In + off, Out + off);                  // P x of this lane's chains
             DB_GEMM(cols, In + n + off, Out + n + off);                    // P v'
             p.c_lo = lo; p.c_hi = hi;
