@@ -6,7 +6,7 @@ from pdmpflux.jl_amd import _lib
 L = _lib.lib()
 L.pdmp_dgemm_mfma.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
 d = 1000
-for N in (10000, 20000, 5000):
+for N in (10000, 20000, 5000, 3334, 2500, 1250):
     At = torch.randn((d, d), dtype=torch.float64, device="cuda")
     Bt = torch.randn((N, d), dtype=torch.float64, device="cuda")
     Ct = torch.empty((N, d), dtype=torch.float64, device="cuda")
