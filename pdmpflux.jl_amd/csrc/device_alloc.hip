@@ -38,8 +38,11 @@ thread_local char g_err[256];
 // (c16_stale2.jsonl: with it, kernel and copy agree in every variant).  Without this a pdmp_device_alloc that is handed the address range
 // of an earlier, freed allocation would let kernels write into memory that is no longer theirs.
 void flush_translations() {
-    void *t = nullptr;
-    if (hipMalloc(&t, (size_t)64 << 20) == hipSuccess) (void)hipFree(t);
+    for (size_t mib = 64; mib >= 2; mib /= 4) {                             // (64 MiB is what was measured; smaller ones only when the memory is that full)
+        void *t = nullptr;
+        if (hipMalloc(&t, mib << 20) == hipSuccess) { (void)hipFree(t); break; }
+        (void)hipGetLastError();
+    }
     (void)hipGetLastError();
 }
 
