@@ -793,6 +793,8 @@ glaunch_fn pick_group_launcher(int sampler, int target) {
 }
 
 glaunch_fn pick_group_tape_launcher(int sampler, int target) {
+    if (target == T_GAUSS_DENSE)                               // (round 4: the per-chain mat-vec kernel replays tapes for Zig-Zag and BPS)
+        return sampler == S_ZIGZAG ? launch_group_tape<S_ZIGZAG, T_GAUSS_DENSE> : sampler == S_BPS ? launch_group_tape<S_BPS, T_GAUSS_DENSE> : nullptr;
     static const glaunch_fn table[7][3] = {
         {launch_group_tape<S_ZIGZAG, T_GAUSS_ISO>, launch_group_tape<S_ZIGZAG, T_GAUSS_DIAG>, launch_group_tape<S_ZIGZAG, T_BANANA>},
         {launch_group_tape<S_BPS, T_GAUSS_ISO>, launch_group_tape<S_BPS, T_GAUSS_DIAG>, launch_group_tape<S_BPS, T_BANANA>},
@@ -844,6 +846,7 @@ int choose_group_lanes(const pdmp_config_t &c) {
 // the same launch would run with the Philox stream) for every sampler on the built-in separable / banana targets, else the
 // wave-per-chain kernel (grid sizes other than 10: Zig-Zag / BPS / Boomerang), else none.
 bool tape_on_group(const pdmp_engine *h) {
+    if (h->cfg.target_id == PDMP_T_GAUSS_DENSE) return h->group_lanes > 0 && (h->cfg.sampler == PDMP_ZIGZAG || h->cfg.sampler == PDMP_BPS);
     return h->group_lanes > 0 && h->cfg.target_id <= PDMP_T_BANANA && !h->policy.tape_wave;
 }
 bool tape_on_wave(const pdmp_engine *h) {
@@ -1092,7 +1095,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
             return fail(PDMP_ERR_ARGUMENT, "tape holds %lld chains; requested chains [%lld, %lld)", (long long)h->tape_chains,
                         (long long)chain_id_offset, (long long)(chain_id_offset + C));
         if (!tape_on_group(h) && !tape_on_wave(h))
-            return fail(PDMP_ERR_UNSUPPORTED, "tape replay: built-in separable / banana targets only");
+            return fail(PDMP_ERR_UNSUPPORTED, "tape replay: built-in separable / banana targets, and Zig-Zag / BPS on the dense-precision target");
         p.tape_exp = h->d_tape[0]; p.tape_uni = h->d_tape[1]; p.tape_nrm = h->d_tape[2];
         p.tape_n_exp = h->tape_n[0]; p.tape_n_uni = h->tape_n[1]; p.tape_n_nrm = h->tape_n[2];
     }

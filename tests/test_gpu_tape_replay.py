@@ -45,6 +45,8 @@ CASES = [
     ("ZigZagAD", 8, "iso", {"grid_size": 0}, {}, FORM_GROUP),                # Brent constant bound
     ("ZigZagAD", 50, "iso", {}, {"PDMP_TAPE_WAVE": "1"}, FORM_WAVE),         # round 1's replaying form
     ("ZigZagAD", 7, "iso", {"grid_size": 6}, {}, FORM_WAVE),                 # grid sizes other than 10: wave per chain
+    ("ZigZagAD", 40, "dense", {}, {}, FORM_GROUP),                           # round 4: the dense-precision target on the per-chain mat-vec kernel
+    ("BPS", 33, "dense", {"refresh_rate": 0.5}, {}, FORM_GROUP),
 ]
 
 
