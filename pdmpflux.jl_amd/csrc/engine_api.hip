@@ -745,9 +745,10 @@ int normalize_config(pdmp_config_t &c, bool from_source = false) {
         if (c.n_target_params != (int64_t)c.dim * c.dim || !c.target_params) return fail(PDMP_ERR_ARGUMENT, "GAUSS_DENSE needs target_params = P[dim*dim] (column-major)");
         if (c.deriv_mode != PDMP_DERIV_FORWARD || (c.grid_size != 10 && c.grid_size != 0))
             return fail(PDMP_ERR_UNSUPPORTED, "dense-precision target: grid_size = 10 (or 0) and forward-mode slopes only");
-        // Boomerang: only the batched form exists (dense_batched.hip: dr_boom_kernel, one GEMM per event over all chains of a launch)
-        if (c.sampler == PDMP_BOOMERANG && (c.grid_size != 10 || c.dim > 24 * WAVE))
-            return fail(PDMP_ERR_UNSUPPORTED, "dense-precision target: Boomerang with grid_size = 10 and dim <= 1536 only");
+        // Boomerang: the batched form (dense_batched.hip: dr_boom_kernel, one GEMM per event over all chains of a launch) up to dim = 1536, the
+        // per-chain mat-vec kernel for small ensembles, tape replays and beyond (round 4); the default bound only
+        if (c.sampler == PDMP_BOOMERANG && c.grid_size != 10)
+            return fail(PDMP_ERR_UNSUPPORTED, "dense-precision target: Boomerang with grid_size = 10 only");
         if (group_waves_per_block((c.dim + WAVE - 1) / WAVE, 0, 6) < 1) return fail(PDMP_ERR_UNSUPPORTED, "dense-precision target: dim too large for the LDS tiles");
     }
     if (c.deriv_mode != PDMP_DERIV_FORWARD && c.deriv_mode != PDMP_DERIV_FINITE_DIFF) return fail(PDMP_ERR_ARGUMENT, "Unsupported AD_backend id %d", c.deriv_mode);
@@ -782,7 +783,7 @@ glaunch_fn pick_group_launcher(int sampler, int target) {
     static const glaunch_fn table[7][4] = {
         {launch_group<S_ZIGZAG, T_GAUSS_ISO>, launch_group<S_ZIGZAG, T_GAUSS_DIAG>, launch_group<S_ZIGZAG, T_BANANA>, launch_group<S_ZIGZAG, T_GAUSS_DENSE>},
         {launch_group<S_BPS, T_GAUSS_ISO>, launch_group<S_BPS, T_GAUSS_DIAG>, launch_group<S_BPS, T_BANANA>, launch_group<S_BPS, T_GAUSS_DENSE>},
-        {launch_group<S_BOOMERANG, T_GAUSS_ISO>, launch_group<S_BOOMERANG, T_GAUSS_DIAG>, launch_group<S_BOOMERANG, T_BANANA>, nullptr},
+        {launch_group<S_BOOMERANG, T_GAUSS_ISO>, launch_group<S_BOOMERANG, T_GAUSS_DIAG>, launch_group<S_BOOMERANG, T_BANANA>, launch_group<S_BOOMERANG, T_GAUSS_DENSE>},
         {launch_group<S_FECMC, T_GAUSS_ISO>, launch_group<S_FECMC, T_GAUSS_DIAG>, launch_group<S_FECMC, T_BANANA>, nullptr},
         {launch_group<S_SUZZ, T_GAUSS_ISO>, launch_group<S_SUZZ, T_GAUSS_DIAG>, launch_group<S_SUZZ, T_BANANA>, nullptr},
         {launch_group<S_RHMC, T_GAUSS_ISO>, launch_group<S_RHMC, T_GAUSS_DIAG>, launch_group<S_RHMC, T_BANANA>, nullptr},
@@ -794,7 +795,8 @@ glaunch_fn pick_group_launcher(int sampler, int target) {
 
 glaunch_fn pick_group_tape_launcher(int sampler, int target) {
     if (target == T_GAUSS_DENSE)                               // (round 4: the per-chain mat-vec kernel replays tapes for Zig-Zag and BPS)
-        return sampler == S_ZIGZAG ? launch_group_tape<S_ZIGZAG, T_GAUSS_DENSE> : sampler == S_BPS ? launch_group_tape<S_BPS, T_GAUSS_DENSE> : nullptr;
+        return sampler == S_ZIGZAG ? launch_group_tape<S_ZIGZAG, T_GAUSS_DENSE> : sampler == S_BPS ? launch_group_tape<S_BPS, T_GAUSS_DENSE>
+             : sampler == S_BOOMERANG ? launch_group_tape<S_BOOMERANG, T_GAUSS_DENSE> : nullptr;
     static const glaunch_fn table[7][3] = {
         {launch_group_tape<S_ZIGZAG, T_GAUSS_ISO>, launch_group_tape<S_ZIGZAG, T_GAUSS_DIAG>, launch_group_tape<S_ZIGZAG, T_BANANA>},
         {launch_group_tape<S_BPS, T_GAUSS_ISO>, launch_group_tape<S_BPS, T_GAUSS_DIAG>, launch_group_tape<S_BPS, T_BANANA>},
@@ -846,7 +848,7 @@ int choose_group_lanes(const pdmp_config_t &c) {
 // the same launch would run with the Philox stream) for every sampler on the built-in separable / banana targets, else the
 // wave-per-chain kernel (grid sizes other than 10: Zig-Zag / BPS / Boomerang), else none.
 bool tape_on_group(const pdmp_engine *h) {
-    if (h->cfg.target_id == PDMP_T_GAUSS_DENSE) return h->group_lanes > 0 && (h->cfg.sampler == PDMP_ZIGZAG || h->cfg.sampler == PDMP_BPS);
+    if (h->cfg.target_id == PDMP_T_GAUSS_DENSE) return h->group_lanes > 0 && h->cfg.sampler <= PDMP_BOOMERANG;
     return h->group_lanes > 0 && h->cfg.target_id <= PDMP_T_BANANA && !h->policy.tape_wave;
 }
 bool tape_on_wave(const pdmp_engine *h) {
@@ -1095,7 +1097,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
             return fail(PDMP_ERR_ARGUMENT, "tape holds %lld chains; requested chains [%lld, %lld)", (long long)h->tape_chains,
                         (long long)chain_id_offset, (long long)(chain_id_offset + C));
         if (!tape_on_group(h) && !tape_on_wave(h))
-            return fail(PDMP_ERR_UNSUPPORTED, "tape replay: built-in separable / banana targets, and Zig-Zag / BPS on the dense-precision target");
+            return fail(PDMP_ERR_UNSUPPORTED, "tape replay: built-in separable / banana targets, and Zig-Zag / BPS / Boomerang on the dense-precision target");
         p.tape_exp = h->d_tape[0]; p.tape_uni = h->d_tape[1]; p.tape_nrm = h->d_tape[2];
         p.tape_n_exp = h->tape_n[0]; p.tape_n_uni = h->tape_n[1]; p.tape_n_nrm = h->tape_n[2];
     }
@@ -1189,11 +1191,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
     // P [x | v'] of ALL chains as one fp64 GEMM per skeleton column (dense_batched.hip: dr_bps_kernel, dr_boom_kernel)
     const bool bps_batched = c.target_id == PDMP_T_GAUSS_DENSE && (c.sampler == PDMP_BPS || c.sampler == PDMP_BOOMERANG) && c.grid_size == GNG && c.dim <= (c.sampler == PDMP_BOOMERANG ? 24 : 32) * WAVE &&
                              c.deriv_mode == PDMP_DERIV_FORWARD && !taped && !until && 2 * C < 0x7fffffffLL &&
-                             (c.sampler == PDMP_BOOMERANG || (dense_mode ? (dense_mode == 2 || dense_mode == 1) : C >= 64));
-    if (c.target_id == PDMP_T_GAUSS_DENSE && c.sampler == PDMP_BOOMERANG && !bps_batched) {
-        h->pool.push_back(ev);
-        return fail(PDMP_ERR_UNSUPPORTED, "Boomerang on a dense precision runs in the batched form only (no tape replay, no time horizon)");
-    }
+                             (dense_mode ? (dense_mode == 2 || dense_mode == 1) : C >= 64);
     if (bps_batched) {
         char msg[256] = "";
         const int rc = pdmp_dense_bps_run(h->device, c.sampler == PDMP_BOOMERANG ? 1 : 0, c.dim, c.signed_bound, c.adaptive, c.gaussian_velocity, c.tmax, c.refresh_rate, c.max_iter_per_event,

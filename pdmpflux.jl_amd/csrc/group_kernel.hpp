@@ -518,6 +518,15 @@ struct GroupChain {
                 tgt.tx[s * WAVE + lane] = xt;
             }
             matvec(tgt.P, tgt.tx, tgt.tg[which]);
+            if constexpr (SAMPLER == S_BOOMERANG) {                 // the Boomerang's flow rotates the velocity: d/dt (P x_t) = P v_t, a product per time point
+                PDMP_SLOTS(s) {                                     // (round 4: with the kept P v the slopes were those of t = 0 at every grid time, and the
+                    double xt, vt;                                  //  chains whose bound takes a tangent intersection left the checker by ~1e-4)
+                    flow(X(s), VU(s), tp, xt, vt);
+                    tgt.tx[s * WAVE + lane] = vt;
+                }
+                matvec(tgt.P, tgt.tx, tgt.tb);
+                tgt.b_valid = false;
+            } else
             if (!tgt.b_valid) { matvec(tgt.P, vs, tgt.tb); tgt.b_valid = true; }   // G = 64: the v tile is the vector v
             return {tgt.tg[which], tgt.tb};
         } else if constexpr (Tgt::kUser) {

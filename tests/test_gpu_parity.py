@@ -623,11 +623,23 @@ def test_dense_precision_one_gemm_per_event_beyond_d_1024(engine, oracle, kind, 
     assert np.allclose(got["V"], ref["V"], rtol=1e-8, atol=1e-10)
 
 
-def test_dense_precision_boomerang_refused_beyond_its_slots(engine, oracle):
-    with pytest.raises(Exception):
-        s, _ = make_pair(engine, oracle, "BoomerangAD", 1537, "dense")
-        x, v = make_init("BoomerangAD", 1537, 64)
-        engine.sample_skeleton_ensemble(s, 4, x, v, seed=1)
+@pytest.mark.parametrize("dim,chains,n_sk,kw", [(40, 6, 20, {}), (40, 6, 20, {"refresh_rate": 1.5, "signed_bound": False}), (130, 3, 12, {"adaptive": False, "tmax": 0.3}),
+                                                (1537, 64, 4, {})])
+def test_dense_precision_boomerang_per_chain_kernel_is_bit_exact(engine, oracle, monkeypatch, dim, chains, n_sk, kw):
+    """Round 4: the Boomerang on a dense precision also has the per-chain mat-vec form of Zig-Zag and BPS (the group kernel's dense
+    target: one chain per wave, the checker's GROUP(64) order bit for bit) -- fewer than 64 chains, dimensions beyond the batched
+    form's 1536, PDMP_DENSE_MODE=matvec, tape replays.  Its slope needs P v_t, a second product per time point: the flow rotates v."""
+    s, cfg = make_pair(engine, oracle, "BoomerangAD", dim, "dense", **kw)
+    x, v = make_init("BoomerangAD", dim, chains)
+    got = engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=21, diagnostics=True)
+    assert s.last_launch_form() != 5
+    assert_bitwise(got, oracle.sample_skeleton(cfg, n_sk, x, v, 21, diagnostics=True))
+    if dim == 40:                                                          # the same sampler forced onto it with a larger ensemble
+        monkeypatch.setenv("PDMP_DENSE_MODE", "matvec")
+        x2, v2 = make_init("BoomerangAD", dim, 70)
+        got2 = engine.sample_skeleton_ensemble(s, n_sk, x2, v2, seed=21)
+        assert s.last_launch_form() != 5
+        assert_bitwise(got2, oracle.sample_skeleton(cfg, n_sk, x2, v2, 21))
 
 
 @pytest.mark.parametrize("target", ["iso", "banana"])

@@ -47,6 +47,7 @@ CASES = [
     ("ZigZagAD", 7, "iso", {"grid_size": 6}, {}, FORM_WAVE),                 # grid sizes other than 10: wave per chain
     ("ZigZagAD", 40, "dense", {}, {}, FORM_GROUP),                           # round 4: the dense-precision target on the per-chain mat-vec kernel
     ("BPS", 33, "dense", {"refresh_rate": 0.5}, {}, FORM_GROUP),
+    ("BoomerangAD", 33, "dense", {}, {}, FORM_GROUP),
 ]
 
 
