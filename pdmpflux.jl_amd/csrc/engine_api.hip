@@ -834,6 +834,10 @@ int choose_group_lanes(const pdmp_config_t &c) {
             if (6 * (size_t)((c.dim + G - 1) / G) * WAVE * sizeof(double) <= 20 * 1024) return G;
         return (6 * (size_t)((c.dim + WAVE - 1) / WAVE) * WAVE * sizeof(double) <= 40 * 1024) ? WAVE : 0;
     }
+    // Zig-Zag at d = 25, 26 in the configuration the lane kernel serves (its 7-slot instantiation covers d = 25 .. 28): the G = 4 layout, so
+    // that large ensembles run one lane per chain there as well (round 4: d = 26, 10^5 chains: 14.8 ms with G = 2 -> the lane kernel's ~10 ms)
+    if (c.sampler == PDMP_ZIGZAG && (c.dim == 25 || c.dim == 26) && c.deriv_mode == PDMP_DERIV_FORWARD && c.vectorized_bound && c.signed_bound &&
+        (c.target_id == PDMP_T_GAUSS_ISO || c.target_id == PDMP_T_BANANA)) return 4;
     for (int G = 1; G <= 16; G <<= 1)      // register form (inst_reg_*.hip): at most KREG slots per lane, G <= 16
         if ((c.dim + G - 1) / G <= KREG) return G;
     const size_t budget = 20 * 1024;      // two blocks (8 waves) per CU
