@@ -20,8 +20,8 @@ hipError_t launch_lane2_zigzag(int target, const GroupParams &gp, const int32_t 
 hipError_t launch_lane2_zigzag_a(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream); // d = 53 .. 72
 hipError_t launch_lane2_zigzag_b(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream); // d = 73 .. 96
 hipError_t launch_lane2q_zigzag(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);  // a pair of lanes per chain at d = 25 .. 52 (mid-sized launches)
-hipError_t launch_lane_zigzag_c(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);   // d = 13 .. 24 (round 4)
-hipError_t launch_lane2q_zigzag_c(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream); // the pair form at d = 13 .. 24
+hipError_t launch_lane_zigzag_c(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);   // d = 9 .. 24 (round 4)
+hipError_t launch_lane2q_zigzag_c(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream); // the pair form at d = 9 .. 24
 hipError_t launch_group_reg_zigzag(int target, bool fd, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_bps(int target, bool fd, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_boomerang(int target, bool fd, const GroupParams &gp, hipStream_t stream);
@@ -836,9 +836,9 @@ int choose_group_lanes(const pdmp_config_t &c) {
             if (6 * (size_t)((c.dim + G - 1) / G) * WAVE * sizeof(double) <= 20 * 1024) return G;
         return (6 * (size_t)((c.dim + WAVE - 1) / WAVE) * WAVE * sizeof(double) <= 40 * 1024) ? WAVE : 0;
     }
-    // Zig-Zag at d = 13 .. 26 in the configuration the lane kernel serves (4 .. 7 slots of four): the G = 4 layout, so that large ensembles
+    // Zig-Zag at d = 9 .. 26 in the configuration the lane kernel serves (3 .. 7 slots of four): the G = 4 layout, so that large ensembles
     // run one lane per chain there as well (round 4: d = 26, 10^5 chains: 14.8 ms with G = 2 -> 10.3 ms)
-    if (c.sampler == PDMP_ZIGZAG && c.dim >= 13 && c.dim <= 26 && c.deriv_mode == PDMP_DERIV_FORWARD && c.vectorized_bound && c.signed_bound &&
+    if (c.sampler == PDMP_ZIGZAG && c.dim >= 9 && c.dim <= 26 && c.deriv_mode == PDMP_DERIV_FORWARD && c.vectorized_bound && c.signed_bound &&
         (c.target_id == PDMP_T_GAUSS_ISO || c.target_id == PDMP_T_BANANA)) return 4;
     for (int G = 1; G <= 16; G <<= 1)      // register form (inst_reg_*.hip): at most KREG slots per lane, G <= 16
         if ((c.dim + G - 1) / G <= KREG) return G;
@@ -1237,7 +1237,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
             // 25 000 8.42 / 8.43 / 5.45, 32 000 10.27 / 8.47 / 7.02, 40 000 10.99 / 8.48 / 9.60, 50 000 11.53 / 8.57 / 11.50 (profiles/r3/r3q1_*)
             const int64_t pair_from = pol.pair_min_chains;   // (up to 16 384 chains = 1 024 waves of the group kernel, one per SIMD: 3.9 - 4.0 ms flat with the whole bound per pass; 17 000 chains: 6.1 ms against the pair form's 5.4)
             const bool lane_ok = c.sampler == PDMP_ZIGZAG && !fd && (c.target_id == PDMP_T_GAUSS_ISO || c.target_id == PDMP_T_BANANA) &&
-                                 ((gp.G == 4 && c.dim >= 13 && c.dim <= 52) || (lane2 && c.dim >= 53 && c.dim <= 104 && !tgroup)) &&
+                                 ((gp.G == 4 && c.dim >= 9 && c.dim <= 52) || (lane2 && c.dim >= 53 && c.dim <= 104 && !tgroup)) &&
                                  (int64_t)WAVE * n_sk * c.dim * 8 < (lane2 ? 2 : 1) * 0x7fffffffLL;   // (a batch's window of X: 31-bit byte offsets; 64 chains, or 32 of a pair form -- the quad pair is held to the window of 64 so that a resumed chunk may be of either size)
             // (round 3: no alignment preconditions any more -- a chain's rows may start anywhere inside a 64-byte line, lane_kernel.hpp: open_window)
             // a resumed chunk continues in the form whose state layout its first chunk left behind (until->form), whatever its size

@@ -48,7 +48,8 @@ namespace pdmp {
 
 // LK = slots of the emulated G = 4 layout: one instantiation per LK = 7 .. 13 serves d = 4 LK - 3 .. 4 LK (25 .. 52; the engine's default
 // layout is G = 4 from d = 27 on)
-constexpr int LANE_LK_MIN = 4, LANE_LK_MAX = 13;          // (round 4: 4 .. 6 slots, d = 13 .. 24, added: inst_lane_zigzag_c.hip, inst_lane2q_zigzag_c.hip)
+constexpr int LANE_LK_MIN = 3, LANE_LK_MAX = 13;          // (round 4: 3 .. 6 slots, d = 9 .. 24, added: inst_lane_zigzag_c.hip, inst_lane2q_zigzag_c.hip;
+                                                         //  2 slots built and failed one case -- d = 5, no diagnostics, four segments: rows shorter than a 64-byte line -- so d <= 8 stays with the group kernel)
 // gl = lanes per chain (1; 2: the chain's coordinates split over a lane pair, lane_kernel.hpp: GL)
 // pg = coordinates of a slot per lane (4; 2: the "quad pair" form, GL = 2 at d <= 52), dmax = pg gl lk = a chain's coordinates with padding
 constexpr int lane_row_stride(int lk, int gl = 1, int pg = 4) { return (7 + pg * gl * lk) | 1; }   // LDS row: up to 7 carried doubles + dmax coordinates, odd stride
@@ -127,7 +128,7 @@ __device__ __forceinline__ uint32_t dpp_xor1_u32(uint32_t x) { return (uint32_t)
 template <int TARGET, int LK, bool DIAG, bool TAPE = false, int GL = 1, int PG = 4>
 struct LaneChain {
     static_assert(TARGET == T_GAUSS_ISO || TARGET == T_BANANA, "lane kernel: isotropic Gaussian and banana");
-    static_assert(LK >= LANE_LK_MIN && LK <= LANE_LK_MAX, "lane kernel: 4 .. 13 slots of four coordinates");
+    static_assert(LK >= LANE_LK_MIN && LK <= LANE_LK_MAX, "lane kernel: 3 .. 13 slots of four coordinates");
     static_assert(GL == 1 || GL == 2, "lane kernel: one lane per chain, or a pair");
     static_assert(PG == 4 || (PG == 2 && GL == 2), "lane kernel: four coordinates of a slot per lane, or two in a pair");
     static_assert(!(TAPE && GL != 1), "tape replay: one lane per chain");
@@ -1005,7 +1006,7 @@ inline hipError_t launch_lane_range(int target, const GroupParams &gp, const int
 hipError_t launch_lane_zigzag(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);       // LK = 13
 hipError_t launch_lane_zigzag_a(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);     // LK = 7 .. 9
 hipError_t launch_lane_zigzag_b(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);     // LK = 10 .. 12
-hipError_t launch_lane_zigzag_c(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);     // LK = 4 .. 6 (d = 13 .. 24)
+hipError_t launch_lane_zigzag_c(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);     // LK = 3 .. 6 (d = 9 .. 24)
 hipError_t launch_lane_zigzag_tape(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);  // LK = 13, tape source
 hipError_t launch_lane_check(const double *vinit, int64_t n, int32_t *flag, hipStream_t stream);
 // a pair of lanes per chain (GL = 2): d = 53 .. 104, LK = ceil(d / 8)
@@ -1014,7 +1015,7 @@ hipError_t launch_lane2_zigzag_a(int target, const GroupParams &gp, const int32_
 hipError_t launch_lane2_zigzag_b(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);    // LK = 10 .. 12
 // a pair of lanes per chain with two coordinates of a slot each (GL = 2, PG = 2): d = 25 .. 52, LK = ceil(d / 4), mid-sized launches
 hipError_t launch_lane2q_zigzag(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);     // LK = 7 .. 13
-hipError_t launch_lane2q_zigzag_c(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);   // LK = 4 .. 6
+hipError_t launch_lane2q_zigzag_c(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);   // LK = 3 .. 6
 #endif
 
 }  // namespace pdmp

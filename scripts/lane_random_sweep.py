@@ -1,4 +1,4 @@
-"""One-off random sweep of the one-lane-per-chain kernel (not part of the suite): random dimension 27..52, target, horizon settings, number
+"""One-off random sweep of the one-lane-per-chain kernel (not part of the suite): random dimension 9..52, target, horizon settings, number
 of chains / events, hand-off segments and bound instalments, every case against the checker bit for bit (PDMP_LANE=1 forces the lane
 kernel).  Usage (GPU box): python scripts/lane_random_sweep.py <n_cases> <seed>; prints mismatches, exit code 1 on any."""
 import os, sys
@@ -13,7 +13,7 @@ n, seed0 = int(sys.argv[1]), int(sys.argv[2])
 rs = np.random.default_rng(seed0)
 bad = done = 0
 for q in range(n):
-    dim = int(rs.integers(27, 53))
+    dim = int(rs.integers(9, 53))
     target = ["iso", "banana"][rs.integers(2)]
     kw = {}
     if rs.random() < 0.4:

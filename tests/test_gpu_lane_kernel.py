@@ -26,7 +26,7 @@ def _run(engine, oracle, dim, target, C, n_sk, seed=3, init_seed=0, diagnostics=
     return s, cfg, x, v, got
 
 
-@pytest.mark.parametrize("dim", [13, 14, 16, 17, 19, 20, 21, 24, 25, 26, 27, 28, 29, 32, 33, 36, 37, 40, 41, 44, 45, 47, 48, 49, 50, 51, 52])   # (13 .. 26: round 4)
+@pytest.mark.parametrize("dim", [9, 10, 11, 12, 13, 14, 16, 17, 19, 20, 21, 24, 25, 26, 27, 28, 29, 32, 33, 36, 37, 40, 41, 44, 45, 47, 48, 49, 50, 51, 52])   # (9 .. 26: round 4)
 @pytest.mark.parametrize("target", ["iso", "banana"])
 def test_lane_kernel_matches_checker(engine, oracle, lane, dim, target):
     s, cfg, x, v, got = _run(engine, oracle, dim, target, 150, 120)          # 150 chains: two full batches and a ragged one
@@ -46,14 +46,14 @@ def test_lane_kernel_equals_group_kernel(engine, oracle, monkeypatch, target):
 
 
 @pytest.mark.parametrize("segments", [2, 7, 1000])
-@pytest.mark.parametrize("target,dim", [("iso", 50), ("banana", 50), ("banana", 31), ("iso", 46)])
+@pytest.mark.parametrize("target,dim", [("iso", 50), ("banana", 50), ("banana", 31), ("iso", 46), ("iso", 9), ("banana", 12), ("iso", 17), ("banana", 24)])
 def test_lane_kernel_segment_handoff(engine, oracle, lane, segments, target, dim):
     lane.setenv("PDMP_FORCE_SEGMENTS", str(segments))
     s, cfg, x, v, got = _run(engine, oracle, dim, target, 70, 96)
     assert_bitwise(got, oracle.sample_skeleton(cfg, 96, x, v, 3, diagnostics=True))
 
 
-@pytest.mark.parametrize("dim", [13, 18, 24, 26, 27, 34, 41, 50, 52])
+@pytest.mark.parametrize("dim", [9, 10, 12, 13, 16, 18, 21, 24, 26, 27, 34, 41, 50, 52])
 @pytest.mark.parametrize("target", ["iso", "banana"])
 def test_lane_kernel_without_diagnostics(engine, oracle, lane, dim, target):
     """Launches that record no diagnostic arrays run another instantiation of the kernel (counters and error ring compiled out)."""

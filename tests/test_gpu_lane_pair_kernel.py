@@ -167,7 +167,7 @@ def _runq(engine, oracle, dim, target, C, n_sk, seed=3, init_seed=0, diagnostics
     return s, cfg, x, v, got
 
 
-@pytest.mark.parametrize("dim", [13, 15, 16, 17, 20, 23, 24, 25, 26, 27, 28, 29, 32, 33, 36, 37, 40, 41, 44, 45, 47, 48, 49, 50, 51, 52])   # (13 .. 26: round 4, G = 4 by default there too)
+@pytest.mark.parametrize("dim", [9, 10, 11, 12, 13, 15, 16, 17, 20, 23, 24, 25, 26, 27, 28, 29, 32, 33, 36, 37, 40, 41, 44, 45, 47, 48, 49, 50, 51, 52])   # (9 .. 26: round 4, G = 4 by default there too)
 @pytest.mark.parametrize("target", ["iso", "banana"])
 def test_quad_pair_matches_checker(engine, oracle, quad, dim, target):
     s, cfg, x, v, got = _runq(engine, oracle, dim, target, 75, 100)
@@ -189,7 +189,7 @@ def test_quad_pair_equals_the_other_forms(engine, oracle, monkeypatch, target):
 
 
 @pytest.mark.parametrize("segments", [2, 7, 1000])
-@pytest.mark.parametrize("target,dim", [("iso", 50), ("banana", 50), ("banana", 31), ("iso", 46)])
+@pytest.mark.parametrize("target,dim", [("iso", 50), ("banana", 50), ("banana", 31), ("iso", 46), ("iso", 9), ("banana", 13), ("iso", 22)])
 def test_quad_pair_segment_handoff(engine, oracle, quad, segments, target, dim):
     quad.setenv("PDMP_FORCE_SEGMENTS", str(segments))
     s, cfg, x, v, got = _runq(engine, oracle, dim, target, 40, 96)
