@@ -22,6 +22,8 @@ hipError_t launch_lane2_zigzag_b(int target, const GroupParams &gp, const int32_
 hipError_t launch_lane2q_zigzag(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);  // a pair of lanes per chain at d = 25 .. 52 (mid-sized launches)
 hipError_t launch_lane_zigzag_c(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);   // d = 9 .. 24 (round 4)
 hipError_t launch_lane2q_zigzag_c(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream); // the pair form at d = 9 .. 24
+hipError_t launch_lane_zigzag_d(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);   // d = 1 .. 8 (round 4: rows shorter than a line)
+hipError_t launch_lane2q_zigzag_d(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream); // the pair form at d = 1 .. 8
 hipError_t launch_group_reg_zigzag(int target, bool fd, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_bps(int target, bool fd, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_boomerang(int target, bool fd, const GroupParams &gp, hipStream_t stream);
@@ -144,6 +146,7 @@ struct pdmp_engine {
     void *user_fn = nullptr;          // PDMP_T_USER: the runtime-compiled group kernel (user_jit.hip)
     int group_lanes = 0;              // 0: wave-per-chain kernel; else lanes per chain of the group kernel
     int last_form = 0;                // PDMP_FORM_* of the last launch (PDMP_FORM_LANE: provided the unit-speed flag stayed 0)
+    int lane_fallback = PDMP_FORM_GROUP_REG;   // the group kernel queued behind a lane kernel (it runs when the unit-speed check fails): register or LDS form
     int device = 0;
     double *d_tparams = nullptr;
     int32_t *d_status = nullptr;      // [0] itercap chains, [1] guard events, [2] lost hand-offs, [3] spare
@@ -836,9 +839,9 @@ int choose_group_lanes(const pdmp_config_t &c) {
             if (6 * (size_t)((c.dim + G - 1) / G) * WAVE * sizeof(double) <= 20 * 1024) return G;
         return (6 * (size_t)((c.dim + WAVE - 1) / WAVE) * WAVE * sizeof(double) <= 40 * 1024) ? WAVE : 0;
     }
-    // Zig-Zag at d = 9 .. 26 in the configuration the lane kernel serves (3 .. 7 slots of four): the G = 4 layout, so that large ensembles
-    // run one lane per chain there as well (round 4: d = 26, 10^5 chains: 14.8 ms with G = 2 -> 10.3 ms)
-    if (c.sampler == PDMP_ZIGZAG && c.dim >= 9 && c.dim <= 26 && c.deriv_mode == PDMP_DERIV_FORWARD && c.vectorized_bound && c.signed_bound &&
+    // Zig-Zag at d <= 26 in the configuration the lane kernel serves (1 .. 7 slots of four): the G = 4 layout, so that large ensembles
+    // run one lane per chain there as well (round 4: d = 26, 10^5 chains: 14.8 ms with G = 2 -> 10.3 ms; d <= 8 later in the round)
+    if (c.sampler == PDMP_ZIGZAG && c.dim >= 1 && c.dim <= 26 && c.deriv_mode == PDMP_DERIV_FORWARD && c.vectorized_bound && c.signed_bound &&
         (c.target_id == PDMP_T_GAUSS_ISO || c.target_id == PDMP_T_BANANA)) return 4;
     for (int G = 1; G <= 16; G <<= 1)      // register form (inst_reg_*.hip): at most KREG slots per lane, G <= 16
         if ((c.dim + G - 1) / G <= KREG) return G;
@@ -968,7 +971,7 @@ int pdmp_last_launch_form(pdmp_handle h) {
     int32_t flag = 0;                              // the lane kernel ran unless the check kernel found a speed other than +-1
     if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->last_stream) != hipSuccess ||
         hipMemcpy(&flag, h->d_status + 4, sizeof flag, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return flag == 0 ? h->last_form : PDMP_FORM_GROUP_REG;
+    return flag == 0 ? h->last_form : h->lane_fallback;
 }
 
 int pdmp_get_group_lanes(pdmp_handle h) { return h ? ((h->tape_chains > 0 && !tape_on_group(h)) ? 0 : h->group_lanes) : -1; }
@@ -1137,7 +1140,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
         gp.host_flags = (h->policy.no_lean ? 1 : 0) | (h->policy.debug_launch ? 2 : 0);
         if (h->policy.cell_budget > 0) gp.cell_budget = h->policy.cell_budget;   // tuning / tests
         const int64_t nb = (C + WAVE / gp.G - 1) / (WAVE / gp.G);
-        const size_t need_sched = (size_t)nb + 1, need_state = (size_t)((C + WAVE - 1) / WAVE * WAVE) * ((size_t)(2 * c.dim + 4) + (c.sampler == PDMP_STICKY ? (size_t)gp.G : 0));   // (whole batches of 64: lane_kernel.hpp; StickyZigZag: + the active masks of a chain's lanes)
+        const size_t need_sched = (size_t)nb + 1, need_state = (size_t)((C + WAVE - 1) / WAVE * WAVE) * ((size_t)lane_state_words(c.dim) + (c.sampler == PDMP_STICKY ? (size_t)gp.G : 0));   // (whole batches of 64: lane_kernel.hpp; StickyZigZag: + the active masks of a chain's lanes)
         if (resuming && (!h->until_valid || !h->d_state || need_state > h->state_cap || C > h->until_chains))
             return fail(PDMP_ERR_ARGUMENT, "resume: this handle holds no hand-off state of a first chunk of at least %lld chains", (long long)C);
         // the hand-off buffer is per handle: a resumed chunk must continue THE run that left it there (another seed, chain range or
@@ -1237,7 +1240,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
             // 25 000 8.42 / 8.43 / 5.45, 32 000 10.27 / 8.47 / 7.02, 40 000 10.99 / 8.48 / 9.60, 50 000 11.53 / 8.57 / 11.50 (profiles/r3/r3q1_*)
             const int64_t pair_from = pol.pair_min_chains;   // (up to 16 384 chains = 1 024 waves of the group kernel, one per SIMD: 3.9 - 4.0 ms flat with the whole bound per pass; 17 000 chains: 6.1 ms against the pair form's 5.4)
             const bool lane_ok = c.sampler == PDMP_ZIGZAG && !fd && (c.target_id == PDMP_T_GAUSS_ISO || c.target_id == PDMP_T_BANANA) &&
-                                 ((gp.G == 4 && c.dim >= 9 && c.dim <= 52) || (lane2 && c.dim >= 53 && c.dim <= 104 && !tgroup)) &&
+                                 ((gp.G == 4 && c.dim >= 1 && c.dim <= 52) || (lane2 && c.dim >= 53 && c.dim <= 104 && !tgroup)) &&
                                  (int64_t)WAVE * n_sk * c.dim * 8 < (lane2 ? 2 : 1) * 0x7fffffffLL;   // (a batch's window of X: 31-bit byte offsets; 64 chains, or 32 of a pair form -- the quad pair is held to the window of 64 so that a resumed chunk may be of either size)
             // (round 3: no alignment preconditions any more -- a chain's rows may start anywhere inside a 64-byte line, lane_kernel.hpp: open_window)
             // a resumed chunk continues in the form whose state layout its first chunk left behind (until->form), whatever its size
@@ -1256,17 +1259,20 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
                 if (le == hipSuccess && !resuming) le = launch_lane_check(vinit, C * (int64_t)c.dim, flag, s);   // (a resumed chunk: the first chunk's check stands)
                 const int rounds = pol.lane_rounds;          // work units per resident wave
                 GroupParams lp = gp;
-                if (pol.cell_budget == 0) lp.cell_budget = 5;   // a pass of 64 chains costs ~2 000 instructions, a cell 240: wait for more cells
+                if (pol.cell_budget == 0) lp.cell_budget = c.dim <= 16 ? GNG - 1 : 5;   // a pass of 64 chains costs ~2 000 instructions, a cell 240 at d = 50: wait for more cells;
+                                                                                     // d <= 16, where a cell is a few dozen: the whole bound in one pass (d = 2 / 10 / 16, 10^5 chains: 10.4 / 8.5 / 9.7 -> 8.4 / 7.9 / 9.4 ms; scripts/r4_short_rows3.sh)
                 if (tgroup) lp.nseg = 1;                     // (lane_schedule: a forced segment count)
                 if (le == hipSuccess) le = tgroup ? launch_lane_zigzag_tape(c.target_id, lp, flag, rounds, s)   // (d = 49 .. 52; else the group kernel below replays)
-                                      : pairq ? (c.dim > 24 ? launch_lane2q_zigzag(c.target_id, lp, flag, rounds, s) : launch_lane2q_zigzag_c(c.target_id, lp, flag, rounds, s))
+                                      : pairq ? (c.dim > 24 ? launch_lane2q_zigzag(c.target_id, lp, flag, rounds, s) : c.dim > 8 ? launch_lane2q_zigzag_c(c.target_id, lp, flag, rounds, s) : launch_lane2q_zigzag_d(c.target_id, lp, flag, rounds, s))
                                       : c.dim > 96 ? launch_lane2_zigzag(c.target_id, lp, flag, rounds, s)
                                       : c.dim > 72 ? launch_lane2_zigzag_b(c.target_id, lp, flag, rounds, s)
                                       : c.dim > 52 ? launch_lane2_zigzag_a(c.target_id, lp, flag, rounds, s)
                                       : c.dim > 48 ? launch_lane_zigzag(c.target_id, lp, flag, rounds, s)
                                       : c.dim > 36 ? launch_lane_zigzag_b(c.target_id, lp, flag, rounds, s)
-                                      : c.dim > 24 ? launch_lane_zigzag_a(c.target_id, lp, flag, rounds, s) : launch_lane_zigzag_c(c.target_id, lp, flag, rounds, s);
+                                      : c.dim > 24 ? launch_lane_zigzag_a(c.target_id, lp, flag, rounds, s)
+                                      : c.dim > 8 ? launch_lane_zigzag_c(c.target_id, lp, flag, rounds, s) : launch_lane_zigzag_d(c.target_id, lp, flag, rounds, s);
                 if (le == hipSuccess) {                      // (a lane kernel that cannot be launched -- it asks for 145 KB of LDS per block --
+                    h->lane_fallback = PDMP_FORM_GROUP_REG;
                     gp.only_if = flag;                       //  leaves the launch to the group kernel below)
                     h->last_form = (lane2 || pairq) ? PDMP_FORM_LANE_PAIR : PDMP_FORM_LANE;
                 } else (void)hipGetLastError();
@@ -1291,7 +1297,8 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
                                                 : hipErrorNotSupported;
         }
         if (e == hipErrorNotSupported) {
-            h->last_form = PDMP_FORM_GROUP;
+            if (gp.only_if) h->lane_fallback = PDMP_FORM_GROUP;      // (behind a lane kernel: last_form stays the lane form; d <= 4 at G = 4 has no register form)
+            else h->last_form = PDMP_FORM_GROUP;
             const glaunch_fn f = tgroup ? pick_group_tape_launcher(c.sampler, c.target_id) : pick_group_launcher(c.sampler, c.target_id);
             if (!f) { h->pool.push_back(ev); return fail(PDMP_ERR_UNSUPPORTED, "no group kernel for sampler %d on target %d", c.sampler, c.target_id); }
             e = f(gp, s);

@@ -2028,6 +2028,10 @@ __global__ __launch_bounds__(256, 1) void group_kernel_reg_tape(const GroupParam
     if (FULL) gp.K = KC;
     group_kernel_body<SAMPLER, TARGET, FD, KC, GC, true>(gp);
 }
+// hand-off words per chain in the launch's state buffer: 2 d + 4 (x, v, t, horizon, ar, stream position); the lane kernel's pair form
+// keeps d + 6 (lane_kernel.hpp: two sign words) -- more than that at d = 1
+__host__ __device__ constexpr int lane_state_words(int d) { return 2 * d + 4 < 8 ? 8 : 2 * d + 4; }
+
 // Which register-form kernels exist.  kAny: the form is used at all; kPartial: also for K < KC (with the per-slot skips);
 // full<GC>(): a separate instantiation without the skips for K == KC.  Set from the compiler's resource-usage remarks so that no
 // instantiation spills a VGPR (see below), and from measurements (Zig-Zag with finite differences: the LDS form is faster).

@@ -1,0 +1,9 @@
+// Lane-pair-per-chain kernels with two coordinates of a slot per lane (lane_kernel.hpp, GL = 2, PG = 2) for d = 1 .. 8 (1, 2 slots of
+// four; round 4): mid-sized launches.
+#include "lane_kernel.hpp"
+
+namespace pdmp {
+hipError_t launch_lane2q_zigzag_d(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream) {
+    return launch_lane_range<1, 2, 2, 2>(target, gp, flag, rounds, stream);
+}
+}  // namespace pdmp

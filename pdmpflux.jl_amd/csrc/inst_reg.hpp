@@ -56,6 +56,9 @@ static hipError_t exact_by_slots(const GroupParams &gp, hipStream_t stream) {
     static_assert(KREG == 13, "one case per K below");
     if constexpr (HALF == 2) {
         if (gp.G < 2) return hipErrorNotSupported;
+        if constexpr (S == S_ZIGZAG && !FD) {     // d <= 4 in the lane kernel's layout (G = 4 by default there since round 4): small ensembles
+            if (gp.K == 1) return gp.G == 4 ? launch_group_impl<S, T, FD, 2, 4, false>(gp, stream) : hipErrorNotSupported;   // (two slots, the second skipped: GroupChain needs KC >= 2)
+        }
         switch (gp.K) {
         case 2: return exact_by_lanes<S, T, FD, 2>(gp, stream);
         case 3: return exact_by_lanes<S, T, FD, 3>(gp, stream);

@@ -48,8 +48,8 @@ namespace pdmp {
 
 // LK = slots of the emulated G = 4 layout: one instantiation per LK = 7 .. 13 serves d = 4 LK - 3 .. 4 LK (25 .. 52; the engine's default
 // layout is G = 4 from d = 27 on)
-constexpr int LANE_LK_MIN = 3, LANE_LK_MAX = 13;          // (round 4: 3 .. 6 slots, d = 9 .. 24, added: inst_lane_zigzag_c.hip, inst_lane2q_zigzag_c.hip;
-                                                         //  2 slots built and failed one case -- d = 5, no diagnostics, four segments: rows shorter than a 64-byte line -- so d <= 8 stays with the group kernel)
+constexpr int LANE_LK_MIN = 1, LANE_LK_MAX = 13;          // (round 4: 3 .. 6 slots, d = 9 .. 24, added: inst_lane_zigzag_c.hip, inst_lane2q_zigzag_c.hip;
+                                                         //  then 1 and 2 slots, d = 1 .. 8 -- rows shorter than a 64-byte line, LaneChain::kShort: inst_lane_zigzag_d.hip, inst_lane2q_zigzag_d.hip)
 // gl = lanes per chain (1; 2: the chain's coordinates split over a lane pair, lane_kernel.hpp: GL)
 // pg = coordinates of a slot per lane (4; 2: the "quad pair" form, GL = 2 at d <= 52), dmax = pg gl lk = a chain's coordinates with padding
 constexpr int lane_row_stride(int lk, int gl = 1, int pg = 4) { return (7 + pg * gl * lk) | 1; }   // LDS row: up to 7 carried doubles + dmax coordinates, odd stride
@@ -128,7 +128,7 @@ __device__ __forceinline__ uint32_t dpp_xor1_u32(uint32_t x) { return (uint32_t)
 template <int TARGET, int LK, bool DIAG, bool TAPE = false, int GL = 1, int PG = 4>
 struct LaneChain {
     static_assert(TARGET == T_GAUSS_ISO || TARGET == T_BANANA, "lane kernel: isotropic Gaussian and banana");
-    static_assert(LK >= LANE_LK_MIN && LK <= LANE_LK_MAX, "lane kernel: 3 .. 13 slots of four coordinates");
+    static_assert(LK >= LANE_LK_MIN && LK <= LANE_LK_MAX, "lane kernel: 1 .. 13 slots of four coordinates");
     static_assert(GL == 1 || GL == 2, "lane kernel: one lane per chain, or a pair");
     static_assert(PG == 4 || (PG == 2 && GL == 2), "lane kernel: four coordinates of a slot per lane, or two in a pair");
     static_assert(!(TAPE && GL != 1), "tape replay: one lane per chain");
@@ -142,6 +142,7 @@ struct LaneChain {
     static constexpr int MD = lane_meta_doubles(LK, GL, PG);   // doubles of store parameters per chain
     static constexpr int LANE_DMIN = DMAX - (GE - 1);    // the last slot may be partly padding, no other
     static constexpr bool kBanana = TARGET == T_BANANA;
+    static constexpr bool kShort = DMAX <= 8;            // d <= 8: a row may be shorter than what precedes it in its 64-byte line (open_window: skip)
     using Tgt = GTarget<TARGET>;
     using SBits = typename std::conditional<!kWide, uint64_t, LaneBits128>::type;   // one sign bit per row position (7 carried + DMAX)
     const SkelParams &p;
@@ -284,7 +285,7 @@ struct LaneChain {
                     if (j == 0) b_shf = head_dual(t0);
                     const BananaSh<Dual> sh0 = b_shf, sh1 = head_dual(t1);
 #pragma unroll
-                    for (int g = 0; g < PG; ++g) part[g] += cell_general(g, t0, t1, h, sh0, sh1);
+                    for (int g = 0; g < PG; ++g) if (in_dim(g)) part[g] += cell_general(g, t0, t1, h, sh0, sh1);   // (d = 2, 3: the slot's padding)
                     b_shf = sh1;
                 }
 #pragma unroll
@@ -445,6 +446,7 @@ struct LaneChain {
     int st_cur = 8;
 #endif
     int cl = 0;                                                                   // carried doubles (row positions 0 .. cl - 1 of my chain's LDS row)
+    int skip = 0;                                                                 // kShort: the first `skip` positions of the line being filled are not mine to write (open_window)
     SBits Sc{};                                                                   // sign bits of the carried doubles
     // sign bits of the chain's coordinates in coordinate order (row order).  GL = 2: my bits sit at 8 s + g; shifted by 4 h and
     // or-ed with the partner's they are the row's -- all lanes of the wave must be here (DPP).
@@ -480,6 +482,9 @@ struct LaneChain {
     // one row whose head may share a line with something that is not the chain's -- column 0 -- never comes through here
     // (record_initial); the chain's last line goes out as a partial line (flush_carry).  V uses the same offsets from its own base: it
     // is line-exact when it has X's phase inside a line, correct anywhere.  Called with y, sg loaded, k_first >= 1, by every lane.
+    // d <= 6 (kShort): a may exceed d -- the line then starts with rows older than the state (a later segment: the previous segment's
+    // flush wrote them) or with bytes that are not the chain's (the first segment; a resumed chunk).  Those a - d positions are skipped:
+    // the line is written from the state's row on, once, as a partial line (store_tile's lower check).
     __device__ __forceinline__ void open_window(int64_t b, int64_t c, int64_t k_first) {
         const size_t first = (size_t)b * CW * (size_t)p.n_sk * (size_t)d;
         int64_t chains = p.C - b * CW;
@@ -503,6 +508,10 @@ struct LaneChain {
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int j = 0; j < 7; ++j) myrow[j] = mv[j];                         // (positions >= a are overwritten by the next row; a pair writes the same values twice)
+            if constexpr (kShort) {
+                skip = a > d ? a - d : 0;
+                Sc = low_bits(a > d ? lb_shl(signs_row(), a - d) : lb_shr(signs_row(), d - a), a);
+            } else
             Sc = low_bits(lb_shr(signs_row(), d - a), a);
         }
         tfirst = (int)(((uintptr_t)(p.t + (size_t)c * (size_t)p.n_sk + (size_t)k_first) >> 3) & 7);
@@ -629,13 +638,17 @@ struct LaneChain {
         const uint32_t off = rec ? (((uint32_t)cwi * (uint32_t)p.n_sk + (uint32_t)k) * (uint32_t)d - (uint32_t)cl) * 8u : kNoRow;
         __builtin_amdgcn_wave_barrier();
         LANE_MARK(9);
-        meta_put(cwi, S, off, (uint32_t)nfull << 8);
+        meta_put(cwi, S, off, ((uint32_t)nfull << 8) | (kShort ? (uint32_t)skip : 0u));
         row_put(myrow + cl);
         __builtin_amdgcn_wave_barrier();
         LANE_MARK(10);
         // nfull = 8 floor((cl + d) / 8) lies in [NF_MIN, NF_MAX]: whole tiles of 16 positions below NF_MIN need no check, the rest goes out as
         // tiles of 8 positions checked against nfull
         constexpr int NF_MIN = LANE_DMIN & ~7, NF_MAX = (DMAX + 7) & ~7, Q0 = NF_MIN & ~15;
+        if constexpr (kShort) {      // one tile of eight positions, checked on both sides (a pair of positions may straddle `skip`: 8-byte stores)
+            static_assert(Q0 == 0 && NF_MAX == 8, "short rows: one line per event at most");
+            store_tile<8, true, true>(0, l);
+        } else {
 #ifdef LANE_STORE_B64              // A/B builds: 8-byte stores
 #pragma unroll
         for (int q = 0; q < Q0; q += 16) store_tile<16, false, false>(q, l);
@@ -649,9 +662,11 @@ struct LaneChain {
 #pragma unroll
         for (int q = Q0; q < NF_MAX; q += 8) store_tile2<8, true>(q, l);
 #endif
+        }
         __builtin_amdgcn_wave_barrier();
         LANE_MARK(14);
         if (rec) {
+            if constexpr (kShort) { if (nfull) skip = 0; }
             const double *from = myrow + nfull;                                   // the row's tail that completes no line: the next carry
             double mv[7];
 #pragma unroll
@@ -715,11 +730,11 @@ struct LaneChain {
         const int cwi = l >> (GL - 1);
         const uint32_t off = (mine && cl > 0) ? (((uint32_t)cwi * (uint32_t)p.n_sk + (uint32_t)k) * (uint32_t)d - (uint32_t)cl) * 8u : kNoRow;
         __builtin_amdgcn_wave_barrier();
-        meta_put(cwi, Sc, off, (uint32_t)cl << 8);
+        meta_put(cwi, Sc, off, ((uint32_t)cl << 8) | (kShort ? (uint32_t)skip : 0u));
         __builtin_amdgcn_wave_barrier();
-        store_tile<8, false, true>(0, l);
+        store_tile<8, kShort, true>(0, l);
         __builtin_amdgcn_wave_barrier();
-        cl = 0;
+        cl = 0; skip = 0;
         if (mine && head() && tlast >= 0)                                         // the event times of an incomplete line; k - 1 = my last event, in slot tlast
             store_times(p.t + ((size_t)c * (size_t)p.n_sk + (size_t)k - 1 - (size_t)tlast), tile + CW * LR + MD * CW + cwi, tfirst, tlast);
         tlast = -1;
@@ -738,7 +753,7 @@ struct LaneChain {
         // throughput kernels keep the registers and instructions they had; the host routes every such launch to a DIAG kernel.)
         int64_t cs = c;
         if constexpr (DIAG) { if (p.chain_map && chain_ok) cs = p.chain_map[c]; }
-        double *st = state + (size_t)(cs >> 6) * (size_t)(2 * d + 4) * WAVE + (size_t)(cs & 63);
+        double *st = state + (size_t)(cs >> 6) * (size_t)lane_state_words(d) * WAVE + (size_t)(cs & 63);
         double t = 0.0, horizon = p.tmax, ar = 0.0;
         uint64_t n0 = 0;
         sg0 = 0; sg1 = 0; sg2 = 0; sg3 = 0;
@@ -1007,6 +1022,7 @@ hipError_t launch_lane_zigzag(int target, const GroupParams &gp, const int32_t *
 hipError_t launch_lane_zigzag_a(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);     // LK = 7 .. 9
 hipError_t launch_lane_zigzag_b(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);     // LK = 10 .. 12
 hipError_t launch_lane_zigzag_c(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);     // LK = 3 .. 6 (d = 9 .. 24)
+hipError_t launch_lane_zigzag_d(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);     // LK = 1, 2 (d = 1 .. 8)
 hipError_t launch_lane_zigzag_tape(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);  // LK = 13, tape source
 hipError_t launch_lane_check(const double *vinit, int64_t n, int32_t *flag, hipStream_t stream);
 // a pair of lanes per chain (GL = 2): d = 53 .. 104, LK = ceil(d / 8)
@@ -1016,6 +1032,7 @@ hipError_t launch_lane2_zigzag_b(int target, const GroupParams &gp, const int32_
 // a pair of lanes per chain with two coordinates of a slot each (GL = 2, PG = 2): d = 25 .. 52, LK = ceil(d / 4), mid-sized launches
 hipError_t launch_lane2q_zigzag(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);     // LK = 7 .. 13
 hipError_t launch_lane2q_zigzag_c(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);   // LK = 3 .. 6
+hipError_t launch_lane2q_zigzag_d(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);   // LK = 1, 2
 #endif
 
 }  // namespace pdmp

@@ -1,9 +1,12 @@
 """One-off random sweep of the one-lane-per-chain kernel (not part of the suite): random dimension 9..52, target, horizon settings, number
 of chains / events, hand-off segments and bound instalments, every case against the checker bit for bit (PDMP_LANE=1 forces the lane
-kernel).  Usage (GPU box): python scripts/lane_random_sweep.py <n_cases> <seed>; prints mismatches, exit code 1 on any."""
+kernel).  Usage (GPU box): python scripts/lane_random_sweep.py <n_cases> <seed> [dmin dmax [lane mode: 1 one lane, 2 pair form]];
+prints mismatches, exit code 1 on any."""
 import os, sys
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
-os.environ["PDMP_LANE"] = "1"
+DMIN, DMAX = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (9, 52)
+MODE = sys.argv[5] if len(sys.argv) > 5 else "1"
+os.environ["PDMP_LANE"] = MODE
 import numpy as np
 import pdmpflux.jl_amd as P
 from oracle import oracle as O
@@ -13,8 +16,8 @@ n, seed0 = int(sys.argv[1]), int(sys.argv[2])
 rs = np.random.default_rng(seed0)
 bad = done = 0
 for q in range(n):
-    dim = int(rs.integers(9, 53))
-    target = ["iso", "banana"][rs.integers(2)]
+    dim = int(rs.integers(DMIN, DMAX + 1))
+    target = ["iso", "banana"][rs.integers(2)] if dim >= 2 else "iso"
     kw = {}
     if rs.random() < 0.4:
         kw["tmax"] = float(rs.choice([0.0, 0.02, 0.3, 1.0, 5.0, 50.0]))
@@ -35,7 +38,7 @@ for q in range(n):
             x[:] = 0.0                                  # exact zeros: y = x v starts at +-0
         diag = bool(rs.random() < 0.5)              # without diagnostics the kernel instantiation is another one (DIAG = false)
         got = P.sample_skeleton_ensemble(s, n_sk, x, v, seed=seed, diagnostics=diag)
-        assert s.last_launch_form() == 4, "unexpected kernel form"      # (round 3: no alignment preconditions any more)
+        assert s.last_launch_form() == (4 if MODE == "1" else 7), "unexpected kernel form"      # (round 3: no alignment preconditions any more)
         ref = O.sample_skeleton(cfg, n_sk, x, v, seed, diagnostics=diag)
         assert_bitwise(got, ref) if diag else assert_bitwise(got, ref, keys=("X", "V", "t"))
         done += 1

@@ -167,7 +167,7 @@ def _runq(engine, oracle, dim, target, C, n_sk, seed=3, init_seed=0, diagnostics
     return s, cfg, x, v, got
 
 
-@pytest.mark.parametrize("dim", [9, 10, 11, 12, 13, 15, 16, 17, 20, 23, 24, 25, 26, 27, 28, 29, 32, 33, 36, 37, 40, 41, 44, 45, 47, 48, 49, 50, 51, 52])   # (9 .. 26: round 4, G = 4 by default there too)
+@pytest.mark.parametrize("dim", [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 17, 20, 23, 24, 25, 26, 27, 28, 29, 32, 33, 36, 37, 40, 41, 44, 45, 47, 48, 49, 50, 51, 52])   # (9 .. 26: round 4, G = 4 by default there too)
 @pytest.mark.parametrize("target", ["iso", "banana"])
 def test_quad_pair_matches_checker(engine, oracle, quad, dim, target):
     s, cfg, x, v, got = _runq(engine, oracle, dim, target, 75, 100)
@@ -189,14 +189,15 @@ def test_quad_pair_equals_the_other_forms(engine, oracle, monkeypatch, target):
 
 
 @pytest.mark.parametrize("segments", [2, 7, 1000])
-@pytest.mark.parametrize("target,dim", [("iso", 50), ("banana", 50), ("banana", 31), ("iso", 46), ("iso", 9), ("banana", 13), ("iso", 22)])
+@pytest.mark.parametrize("target,dim", [("iso", 50), ("banana", 50), ("banana", 31), ("iso", 46), ("iso", 9), ("banana", 13), ("iso", 22),
+                                         ("iso", 1), ("banana", 2), ("iso", 3), ("banana", 5), ("iso", 5), ("banana", 6), ("iso", 7), ("banana", 8)])
 def test_quad_pair_segment_handoff(engine, oracle, quad, segments, target, dim):
     quad.setenv("PDMP_FORCE_SEGMENTS", str(segments))
     s, cfg, x, v, got = _runq(engine, oracle, dim, target, 40, 96)
     assert_bitwise(got, oracle.sample_skeleton(cfg, 96, x, v, 3, diagnostics=True))
 
 
-@pytest.mark.parametrize("dim", [27, 34, 41, 50, 52])
+@pytest.mark.parametrize("dim", [2, 3, 5, 6, 7, 8, 27, 34, 41, 50, 52])
 @pytest.mark.parametrize("target", ["iso", "banana"])
 def test_quad_pair_without_diagnostics(engine, oracle, quad, dim, target):
     """The throughput instantiations (two waves per SIMD, no diagnostic arrays)."""
@@ -212,7 +213,7 @@ def test_quad_pair_horizons(engine, oracle, quad, kw):
 
 
 @pytest.mark.parametrize("offs", [(0, 5, 2), (8, 3, 7), (3, 0, 0)])
-@pytest.mark.parametrize("n_sk,dim", [(40, 50), (40, 51), (37, 50), (48, 27), (31, 45)])
+@pytest.mark.parametrize("n_sk,dim", [(40, 50), (40, 51), (37, 50), (48, 27), (31, 45), (37, 3), (33, 5), (35, 6), (31, 7)])
 def test_quad_pair_unaligned_outputs(engine, oracle, quad, offs, n_sk, dim):
     import torch
     quad.setenv("PDMP_FORCE_SEGMENTS", "3")
