@@ -295,7 +295,14 @@ struct DiParams {
     int32_t *status;             // [0] itercap, [1] guard
     double refresh;              // BPS (dr_bps_kernel): refresh_rate
     int32_t gaussian_velocity, pad;
-    int64_t c_lo, c_hi;          // the chains this launch advances: [c_lo, c_hi) of the C chains of the workspace (two half-ensembles on two streams)
+    int64_t c_lo, c_hi;          // the output slots this launch advances: [c_lo, c_hi) (two half-ensembles on two streams); slot j = chain j of the workspace unless chain_map
+    // time horizon (sample_skeleton(sampler, T, ...), sample.jl:323-439; pdmp_sample_skeleton_until_device): a chain stops after its first event
+    // with t >= t_stop; resume: the workspace holds the state the previous chunk left (column 0 = its last event again); chain_map: slot -> chain
+    // of a resumed chunk (the chains still running, compacted); count[slot] = columns recorded in this chunk
+    double t_stop;
+    const int64_t *chain_map;
+    int64_t *count;
+    int32_t resume, pad2;
 };
 
 // SGN: signed_bound (the constructor default).  There the slope of every coordinate's rate is the same double at both ends of a
@@ -342,15 +349,18 @@ __device__ __forceinline__ double slot_totals16(const double (&val)[16], int lan
 }
 __device__ __forceinline__ int slot_lane16(int s) { return ((s & 1) << 2) | (((s >> 1) & 1) << 3) | ((s >> 2) << 4); }   // a lane that holds slot s
 
-template <int KC, bool SGN>
+// UNTIL: the time-horizon features (t_stop, resume, chain_map, count) -- separate instantiations, so that the fixed-count kernels keep the
+// registers and instructions they had (config 4: 7.44 ms; with the features compiled in 7.85)
+template <int KC, bool SGN, bool UNTIL = false>
 __global__ __launch_bounds__(256, SGN ? 2 : 1) void di_segment_kernel(const DiParams p) {
     const int lane = lane_id();
-    const int64_t c = p.c_lo + (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (c >= p.c_hi) return;
+    const int64_t j = p.c_lo + (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // slot in this launch's outputs
+    if (j >= p.c_hi) return;
+    const int64_t c = (UNTIL && p.chain_map) ? p.chain_map[j] : j;      // the chain: workspace columns, state record, random stream
     DiState cs;
-    if (p.k_begin == 0) { cs.t = 0.0; cs.horizon = p.tmax; cs.rng_n = 0; cs.dead = 0; cs.pad = 0; }
+    if (p.k_begin == 0 && !(UNTIL && p.resume)) { cs.t = 0.0; cs.horizon = p.tmax; cs.rng_n = 0; cs.dead = 0; cs.pad = 0; }
     else cs = p.st[c];
-    if (cs.dead) return;
+    if (cs.dead || (UNTIL && cs.pad && p.k_begin != 0)) return;      // (pad: the chain has passed t_stop -- in this chunk; a resumed chunk still records its column 0)
     const int d = p.d;
     const bool adaptive = p.adaptive != 0;
     constexpr bool sgn = SGN;
@@ -381,7 +391,7 @@ __global__ __launch_bounds__(256, SGN ? 2 : 1) void di_segment_kernel(const DiPa
     bool dead = false;
 
     auto record = [&](int64_t kk) {
-        const size_t e = (size_t)c * (size_t)p.n_sk + (size_t)kk;
+        const size_t e = (size_t)j * (size_t)p.n_sk + (size_t)kk;      // (j: the chain's slot in this launch's outputs)
         double *Xe = p.X + e * (size_t)d, *Ve = p.V + e * (size_t)d;
 #pragma unroll
         for (int s = 0; s < KC; ++s) {
@@ -406,7 +416,7 @@ __global__ __launch_bounds__(256, SGN ? 2 : 1) void di_segment_kernel(const DiPa
     };
 
     if (k == 0) { record(0); k = 1; }          // init_state + record of the initial state (sample.jl:271-272)
-    while (k < p.k_end) {
+    while (k < p.k_end && (!UNTIL || t < p.t_stop)) {              // (`while state.t < T`, sample.jl:372; t_stop = +inf for the fixed-count path)
         if (++it > p.cap * 4) { dead = true; break; }
         // ---- bound over [0, harg]: one_step_of_thinning! (:65-85) / erroneous_acceptance_rate! (:131-151) / if_reject! (:188-203)
         const double harg = (mode == DB_ERR) ? horizon / 2 : ((mode == DB_REUSE) ? hB : horizon);
@@ -569,6 +579,8 @@ __global__ __launch_bounds__(256, SGN ? 2 : 1) void di_segment_kernel(const DiPa
     }
     if (lane == 0) {
         cs.t = t; cs.horizon = horizon; cs.rng_n = rng.n; cs.dead = dead ? 1 : 0;
+        cs.pad = (UNTIL && !(t < p.t_stop)) ? 1 : 0;
+        if (UNTIL && p.count && (cs.pad || k >= p.n_sk)) p.count[j] = k;      // columns recorded in this chunk (the group kernel's rule: engine_api.hip, UntilArgs)
         p.st[c] = cs;
         if (dead) atomicAdd(&p.status[0], 1);
     }
@@ -588,11 +600,15 @@ __global__ __launch_bounds__(256, SGN ? 2 : 1) void di_segment_kernel(const DiPa
 // by the flows' recurrence (P x += tau P v) and re-based on an exact product every PDMP_DENSE_RESYNC events (default 64).  One wave per chain, layout and state as
 // di_segment_kernel.  Against the checker (reference order: a mat-vec per grid time) to a tolerance, as the Zig-Zag forms.
 template <int KC>
-__device__ __forceinline__ void dr_bps_chain(const DiParams &p, const int64_t c, double *x_tile, const int lane) {
+__device__ __forceinline__ void dr_bps_chain(const DiParams &p, const int64_t j, double *x_tile, const int lane) {
+    // (the 32-slot kernel, d = 1025 .. 2048, has no register to spare: 256 + spills into AGPRs with the time horizon compiled in -- the host
+    //  refuses the horizon there)
+    constexpr bool kUntil = KC < 32;
+    const int64_t c = (kUntil && p.chain_map) ? p.chain_map[j] : j;      // (j: output slot of this launch; c: the chain -- as di_segment_kernel)
     DiState cs;
-    if (p.k_begin == 0) { cs.t = 0.0; cs.horizon = p.tmax; cs.rng_n = 0; cs.dead = 0; cs.pad = 0; }
+    if (p.k_begin == 0 && !(kUntil && p.resume)) { cs.t = 0.0; cs.horizon = p.tmax; cs.rng_n = 0; cs.dead = 0; cs.pad = 0; }
     else cs = p.st[c];
-    if (cs.dead) return;
+    if (cs.dead || (kUntil && cs.pad && p.k_begin != 0)) return;      // (pad: the chain has passed t_stop -- in this chunk; a resumed chunk still records its column 0)
     const int d = p.d;
     const bool adaptive = p.adaptive != 0, sgn = p.signed_bound != 0;
     const double refresh = p.refresh, refresh_b = sgn ? p.refresh : 0.0;     // (the signed bound adds refresh_rate to every cell again, AbstractPDMP.jl:104-112)
@@ -618,7 +634,7 @@ __device__ __forceinline__ void dr_bps_chain(const DiParams &p, const int64_t c,
     bool dead = false;
 
     auto record = [&](int64_t kk) {
-        const size_t e = (size_t)c * (size_t)p.n_sk + (size_t)kk;
+        const size_t e = (size_t)j * (size_t)p.n_sk + (size_t)kk;      // (j: the chain's slot in this launch's outputs)
         double *Xe = p.X + e * (size_t)d, *Ve = p.V + e * (size_t)d;
 #pragma unroll
         for (int s = 0; s < KC; ++s) {
@@ -641,7 +657,7 @@ __device__ __forceinline__ void dr_bps_chain(const DiParams &p, const int64_t c,
     };
 
     if (k == 0) { record(0); k = 1; }          // init_state + record of the initial state (sample.jl:271-272)
-    while (k < p.k_end) {
+    while (k < p.k_end && (!kUntil || t < p.t_stop)) {              // (`while state.t < T`, sample.jl:372; t_stop = +inf for the fixed-count path)
         if (++it > p.cap * 4) { dead = true; break; }
         // ---- the rate along the flow from the current state: A + B t
         double pa = 0.0, pb = 0.0;
@@ -759,6 +775,8 @@ __device__ __forceinline__ void dr_bps_chain(const DiParams &p, const int64_t c,
     }
     if (lane == 0) {
         cs.t = t; cs.horizon = horizon; cs.rng_n = rng.n; cs.dead = dead ? 1 : 0;
+        cs.pad = (kUntil && !(t < p.t_stop)) ? 1 : 0;
+        if (kUntil && p.count && (cs.pad || k >= p.n_sk)) p.count[j] = k;      // columns recorded in this chunk (the group kernel's rule: engine_api.hip, UntilArgs)
         p.st[c] = cs;
         if (dead) atomicAdd(&p.status[0], 1);
     }
@@ -775,11 +793,12 @@ __global__ __launch_bounds__(256, (KC >= 32 ? 1 : 2)) void dr_bps_kernel(const D
 // ---- Boomerang on a dense precision, the same scheme: between events the flow is a rotation of (x, v) and of (P x, P v) by the same angle
 // (16 slots: x, v, P x, P v and the rotation's temporaries need more than 256 registers: one wave per SIMD)
 template <int KC>
-__device__ __forceinline__ void dr_boom_chain(const DiParams &p, const int64_t c, double *x_tile, const int lane) {
+__device__ __forceinline__ void dr_boom_chain(const DiParams &p, const int64_t j, double *x_tile, const int lane) {
+    const int64_t c = p.chain_map ? p.chain_map[j] : j;
     DiState cs;
-    if (p.k_begin == 0) { cs.t = 0.0; cs.horizon = p.tmax; cs.rng_n = 0; cs.dead = 0; cs.pad = 0; }
+    if (p.k_begin == 0 && !p.resume) { cs.t = 0.0; cs.horizon = p.tmax; cs.rng_n = 0; cs.dead = 0; cs.pad = 0; }
     else cs = p.st[c];
-    if (cs.dead) return;
+    if (cs.dead || (cs.pad && p.k_begin != 0)) return;      // (pad: the chain has passed t_stop -- in this chunk; a resumed chunk still records its column 0)
     const int d = p.d;
     const bool adaptive = p.adaptive != 0, sgn = p.signed_bound != 0;
     const double refresh = p.refresh, refresh_b = sgn ? p.refresh : 0.0;     // (the signed bound adds refresh_rate to every cell again, AbstractPDMP.jl:104-112)
@@ -805,7 +824,7 @@ __device__ __forceinline__ void dr_boom_chain(const DiParams &p, const int64_t c
     bool dead = false;
 
     auto record = [&](int64_t kk) {
-        const size_t e = (size_t)c * (size_t)p.n_sk + (size_t)kk;
+        const size_t e = (size_t)j * (size_t)p.n_sk + (size_t)kk;      // (j: the chain's slot in this launch's outputs)
         double *Xe = p.X + e * (size_t)d, *Ve = p.V + e * (size_t)d;
 #pragma unroll
         for (int s = 0; s < KC; ++s) {
@@ -834,7 +853,7 @@ __device__ __forceinline__ void dr_boom_chain(const DiParams &p, const int64_t c
     };
 
     if (k == 0) { record(0); k = 1; }          // init_state + record of the initial state (sample.jl:271-272)
-    while (k < p.k_end) {
+    while (k < p.k_end && t < p.t_stop) {              // (`while state.t < T`, sample.jl:372; t_stop = +inf for the fixed-count path)
         if (++it > p.cap * 4) { dead = true; break; }
         // ---- the rate along the flow from the current state.  The reference's Boomerang RATE uses grad-U itself (BoomerangSamplers.jl:38-41;
         // only the jump uses grad-U - x: Q8 of SURVEY.md 3.7, reproduced), and grad-U = P x is linear, so with gx = P x, gv = P v:
@@ -966,6 +985,8 @@ __device__ __forceinline__ void dr_boom_chain(const DiParams &p, const int64_t c
     }
     if (lane == 0) {
         cs.t = t; cs.horizon = horizon; cs.rng_n = rng.n; cs.dead = dead ? 1 : 0;
+        cs.pad = !(t < p.t_stop) ? 1 : 0;
+        if (p.count && (cs.pad || k >= p.n_sk)) p.count[j] = k;      // columns recorded in this chunk (the group kernel's rule: engine_api.hip, UntilArgs)
         p.st[c] = cs;
         if (dead) atomicAdd(&p.status[0], 1);
     }
@@ -1100,7 +1121,9 @@ extern "C" int pdmp_dense_incremental_run(int device, int d, int signed_bound, i
                                           const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
                                           const double *xinit, const double *vinit, double *X, double *V, double *t,
                                           double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
-                                          int32_t *status, void *stream_v, void **ws, size_t *ws_cap, int64_t resync_events, int gemm_impl, char *err, int errlen) {
+                                          int32_t *status, void *stream_v, void **ws, size_t *ws_cap, int64_t resync_events, int gemm_impl,
+                                          double t_stop, int resume, int64_t n_launch, const int64_t *chain_map, int64_t *count, char *err, int errlen) {
+    // (time horizon: C = the chains of the workspace = the first chunk's; n_launch <= C output slots in this chunk, chain_map their chains)
     hipStream_t stream = (hipStream_t)stream_v;
     // the unsigned bound keeps the tangent intersection's division: its 16-slot instantiation does not fit the register file
     // without spilling (and no kernel with lane-dependent branches may spill, see GroupOcc in group_kernel.hpp)
@@ -1110,6 +1133,7 @@ extern "C" int pdmp_dense_incremental_run(int device, int d, int signed_bound, i
 #define DB_BLAS(expr) do { rocblas_status s_ = (expr); if (s_ != rocblas_status_success) { snprintf(err, errlen, "%s: rocblas status %d", #expr, (int)s_); return -3; } } while (0)
     const size_t n = (size_t)C * (size_t)d;
     const size_t need = 4 * n * 8 + (size_t)C * sizeof(DiState);
+    if (resume && (!*ws || need > *ws_cap)) { snprintf(err, errlen, "resume: no workspace of a first chunk of %lld chains", (long long)C); return -3; }
     if (need > *ws_cap) {
         if (*ws) { DB_TRY(hipStreamSynchronize(stream)); DB_TRY(hipFree(*ws)); *ws = nullptr; *ws_cap = 0; }
         DB_TRY(hipMalloc(ws, need));
@@ -1120,8 +1144,10 @@ extern "C" int pdmp_dense_incremental_run(int device, int d, int signed_bound, i
     const int64_t resync = resync_events >= 1 ? resync_events : 256;   // (policy: PDMP_DENSE_RESYNC)
     rocblas_handle hb = db_handle(device);
     if (!hb) { snprintf(err, errlen, "rocblas handle"); return -3; }
-    DB_TRY(hipMemcpyAsync(In, xinit, n * 8, hipMemcpyDeviceToDevice, stream));
-    DB_TRY(hipMemcpyAsync(In + n, vinit, n * 8, hipMemcpyDeviceToDevice, stream));
+    if (!resume) {
+        DB_TRY(hipMemcpyAsync(In, xinit, n * 8, hipMemcpyDeviceToDevice, stream));
+        DB_TRY(hipMemcpyAsync(In + n, vinit, n * 8, hipMemcpyDeviceToDevice, stream));
+    }
     DB_BLAS(rocblas_set_stream(hb, stream));
     DB_BLAS(rocblas_set_pointer_mode(hb, rocblas_pointer_mode_host));
     DiParams p;
@@ -1131,7 +1157,8 @@ extern "C" int pdmp_dense_incremental_run(int device, int d, int signed_bound, i
     p.X = X; p.V = V; p.t = t; p.H = H; p.AR = AR; p.EV = EV; p.EB = EB; p.RJ = RJ; p.HH = HH;
     p.status = status;
     p.refresh = 0.0; p.gaussian_velocity = 0; p.pad = 0;
-    const dim3 grid((unsigned)((C + 3) / 4)), block(256);
+    p.t_stop = t_stop; p.chain_map = chain_map; p.count = count; p.resume = resume; p.pad2 = 0;
+    const dim3 grid((unsigned)((n_launch + 3) / 4)), block(256);
     const double one = 1.0, zero = 0.0;
     g_last_phases = 0; g_last_columns = 0; g_last_mode = 2;
     for (int64_t k0 = 0; k0 < n_sk;) {
@@ -1139,8 +1166,18 @@ extern "C" int pdmp_dense_incremental_run(int device, int d, int signed_bound, i
         DB_GEMM((int)(2 * C), In, Out);
         g_last_columns += 2 * C;
         p.k_begin = k0; p.k_end = k1;
-        p.c_lo = 0; p.c_hi = C;
-        if (signed_bound) {
+        p.c_lo = 0; p.c_hi = n_launch;
+        const bool until = count != nullptr || resume || chain_map != nullptr || t_stop < __builtin_huge_val();
+        if (until) {
+            if (signed_bound) {
+                if (d <= 4 * WAVE) hipLaunchKernelGGL((di_segment_kernel<4, true, true>), grid, block, 0, stream, p);
+                else if (d <= 8 * WAVE) hipLaunchKernelGGL((di_segment_kernel<8, true, true>), grid, block, 0, stream, p);
+                else hipLaunchKernelGGL((di_segment_kernel<16, true, true>), grid, block, 0, stream, p);
+            } else {
+                if (d <= 4 * WAVE) hipLaunchKernelGGL((di_segment_kernel<4, false, true>), grid, block, 0, stream, p);
+                else hipLaunchKernelGGL((di_segment_kernel<8, false, true>), grid, block, 0, stream, p);
+            }
+        } else if (signed_bound) {
             if (d <= 4 * WAVE) hipLaunchKernelGGL((di_segment_kernel<4, true>), grid, block, 0, stream, p);
             else if (d <= 8 * WAVE) hipLaunchKernelGGL((di_segment_kernel<8, true>), grid, block, 0, stream, p);
             else hipLaunchKernelGGL((di_segment_kernel<16, true>), grid, block, 0, stream, p);
@@ -1162,13 +1199,15 @@ extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_b
                                   int64_t cap, const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
                                   const double *xinit, const double *vinit, double *X, double *V, double *t,
                                   double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
-                                  int32_t *status, void *stream_v, void **ws, size_t *ws_cap, int64_t resync_events, int gemm_impl, int lanes, char *err, int errlen) {
+                                  int32_t *status, void *stream_v, void **ws, size_t *ws_cap, int64_t resync_events, int gemm_impl, int lanes,
+                                  double t_stop, int resume, int64_t n_launch, const int64_t *chain_map, int64_t *count, char *err, int errlen) {
     hipStream_t stream = (hipStream_t)stream_v;
     if (d > (boomerang ? 24 : 32) * WAVE) return -5;
 #define DB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { snprintf(err, errlen, "%s: %s", #expr, hipGetErrorString(e_)); return -3; } } while (0)
 #define DB_BLAS(expr) do { rocblas_status s_ = (expr); if (s_ != rocblas_status_success) { snprintf(err, errlen, "%s: rocblas status %d", #expr, (int)s_); return -3; } } while (0)
     const size_t n = (size_t)C * (size_t)d;
     const size_t need = 4 * n * 8 + (size_t)C * sizeof(DiState);
+    if (resume && (!*ws || need > *ws_cap)) { snprintf(err, errlen, "resume: no workspace of a first chunk of %lld chains", (long long)C); return -3; }
     if (need > *ws_cap) {
         if (*ws) { DB_TRY(hipStreamSynchronize(stream)); DB_TRY(hipFree(*ws)); *ws = nullptr; *ws_cap = 0; }
         DB_TRY(hipMalloc(ws, need));
@@ -1178,8 +1217,10 @@ extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_b
     DiState *st = (DiState *)(Out + 2 * n);
     rocblas_handle hb = db_handle(device);
     if (!hb) { snprintf(err, errlen, "rocblas handle"); return -3; }
-    DB_TRY(hipMemcpyAsync(In, xinit, n * 8, hipMemcpyDeviceToDevice, stream));
-    DB_TRY(hipMemcpyAsync(In + n, vinit, n * 8, hipMemcpyDeviceToDevice, stream));
+    if (!resume) {
+        DB_TRY(hipMemcpyAsync(In, xinit, n * 8, hipMemcpyDeviceToDevice, stream));
+        DB_TRY(hipMemcpyAsync(In + n, vinit, n * 8, hipMemcpyDeviceToDevice, stream));
+    }
     DB_BLAS(rocblas_set_stream(hb, stream));
     DB_BLAS(rocblas_set_pointer_mode(hb, rocblas_pointer_mode_host));
     DiParams p;
@@ -1189,6 +1230,7 @@ extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_b
     p.X = X; p.V = V; p.t = t; p.H = H; p.AR = AR; p.EV = EV; p.EB = EB; p.RJ = RJ; p.HH = HH;
     p.status = status;
     p.refresh = refresh; p.gaussian_velocity = gaussian_velocity; p.pad = 0;
+    p.t_stop = t_stop; p.chain_map = chain_map; p.count = count; p.resume = resume; p.pad2 = 0;
     const dim3 block(256);
     const double one = 1.0, zero = 0.0;
     g_last_phases = 0; g_last_columns = 0; g_last_mode = 3;
@@ -1198,7 +1240,7 @@ extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_b
     // TFLOP/s) and the launch gaps it fills; the products and the step kernels of the two lanes do NOT end up side by side (see the note in the
     // loop below).  Same arithmetic per chain: bit-identical to one lane with the hand-written product (rocBLAS may pick another kernel for
     // another column count).
-    const int nl = (lanes >= 2 && C >= 256) ? 2 : 1;
+    const int nl = (lanes >= 2 && C >= 256 && !chain_map && n_launch == C) ? 2 : 1;   // (a compacted chunk: its slots are not a contiguous range of the workspace's columns)
     static const int polite_env = getenv("PDMP_DGEMM_POLITE") ? atoi(getenv("PDMP_DGEMM_POLITE")) : 2;   // (tuning: workgroups of the product per CU beside the other lane's step kernel)
     const int gemm_polite = (nl == 2) ? polite_env : 0;
     // workgroups of a step kernel (PDMP_DENSE_STEP_BLOCKS; 0 = one wave per chain).  The kernels that fit one workgroup per CU only (Boomerang
@@ -1225,7 +1267,7 @@ extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_b
         DB_TRY(hipEventRecord(side->fork, stream));                       // the side lane starts after the initial states are in the workspace
         DB_TRY(hipStreamWaitEvent(ls[1], side->fork, 0));
     }
-    const int64_t cut = (nl == 2) ? ((C / 2 + 3) / 4 * 4) : C;           // (whole blocks of four chains per lane)
+    const int64_t cut = (nl == 2) ? ((C / 2 + 3) / 4 * 4) : n_launch;    // (whole blocks of four chains per lane)
     for (int64_t k0 = 0, ph = 0; k0 < n_sk; ++ph) {
         const int64_t k1 = (k0 == 0) ? ((n_sk < 2) ? n_sk : 2) : k0 + 1;
         const bool full = (ph % resync) == 0;
@@ -1233,12 +1275,12 @@ extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_b
         g_last_columns += full ? 2 * C : C;
         p.k_begin = k0; p.k_end = k1;
         for (int l = 0; l < nl; ++l) {
-            const int64_t lo = (l == 0) ? 0 : cut, hi = (l == 0) ? cut : C;
+            const int64_t lo = (l == 0) ? 0 : cut, hi = (l == 0) ? cut : n_launch;
             if (hi <= lo) continue;
             hipStream_t stream = ls[l];                                    // (DB_GEMM and the launches below use this lane's stream and handle)
             rocblas_handle hb = lh[l];
             const size_t off = (size_t)lo * (size_t)d;
-            const int cols = (int)(hi - lo);
+            const int cols = (nl == 2) ? (int)(hi - lo) : (int)C;          // (one lane: every column of the workspace -- a compacted chunk's chains lie anywhere in it)
             // (what the two lanes buy is the library's better rate on the half-sized product, 65 against 51 TFLOP/s -- the kernel trace shows the
             //  lanes running IN phase, product beside product and step beside step, and the launch costs the sum of the two kinds of work;
             //  round 4 tried to change that and could not: products forced to take turns across the lanes 94.6 -> 112 ms, a step kernel with

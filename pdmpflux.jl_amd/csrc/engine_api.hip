@@ -73,12 +73,14 @@ extern "C" int pdmp_dense_incremental_run(int device, int d, int signed_bound, i
                                       const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
                                       const double *xinit, const double *vinit, double *X, double *V, double *t,
                                       double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
-                                      int32_t *status, void *stream, void **ws, size_t *ws_cap, int64_t resync_events, int gemm_impl, char *err, int errlen);
+                                      int32_t *status, void *stream, void **ws, size_t *ws_cap, int64_t resync_events, int gemm_impl,
+                                      double t_stop, int resume, int64_t n_launch, const int64_t *chain_map, int64_t *count, char *err, int errlen);
 extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_bound, int adaptive, int gaussian_velocity, double tmax, double refresh,
                                   int64_t cap, const double *P_dev, int64_t C, int64_t n_sk, int64_t chain0, uint64_t seed,
                                   const double *xinit, const double *vinit, double *X, double *V, double *t,
                                   double *H, double *AR, int32_t *EB, double *EV, int32_t *RJ, int32_t *HH,
-                                  int32_t *status, void *stream, void **ws, size_t *ws_cap, int64_t resync_events, int gemm_impl, int lanes, char *err, int errlen);   // dense_batched.hip: BPS, one GEMM per event
+                                  int32_t *status, void *stream, void **ws, size_t *ws_cap, int64_t resync_events, int gemm_impl, int lanes,
+                                  double t_stop, int resume, int64_t n_launch, const int64_t *chain_map, int64_t *count, char *err, int errlen);   // dense_batched.hip: BPS, one GEMM per event
 
 extern "C" int pdmp_user_compile(int device, int sampler, int fd, int kind, const char *source, void **fn_out, char *err, int errlen);
 extern "C" int pdmp_user_launch(void *fn, const GroupParams *gp, void *stream);
@@ -1172,21 +1174,31 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
     // small ensembles and PDMP_DENSE_MODE=matvec keep the bit-exact per-chain mat-vec kernel.
     const LaunchPolicy &pol = h->policy;
     const int dense_mode = pol.dense_mode;                    // 1 incr | 2 gemm | 3 matvec (0, default: incr for >= 64 chains and d <= 1024, gemm beyond)
-    if (until && (taped || h->group_lanes <= 0 || c.target_id == PDMP_T_GAUSS_DENSE)) {
-        h->pool.push_back(ev);
-        return fail(PDMP_ERR_UNSUPPORTED, "the in-kernel time horizon runs on the group / lane kernels (grid_size = 10 or 0; not the dense-precision target; "
-                                          "no tape): rerun the fixed-count path with a doubled capacity instead");
-    }
+    // (time horizon on the dense-precision target, round 4: the batched forms below -- their workspace holds every chain's state between
+    //  chunks; a resumed chunk stays in the form of its first chunk whatever its size; the per-chain mat-vec kernel has no horizon)
+    const bool dense_resume = resuming && until->form == PDMP_FORM_DENSE;
+    const int64_t C_ws = dense_resume ? h->until_chains : C;       // chains of the workspace: the first chunk's
     const bool batched = c.target_id == PDMP_T_GAUSS_DENSE && c.sampler == PDMP_ZIGZAG && c.vectorized_bound && c.grid_size == GNG &&
-                         c.deriv_mode == PDMP_DERIV_FORWARD && !taped && 2 * C < 0x7fffffffLL &&
-                         (dense_mode ? (dense_mode == 2 || dense_mode == 1) : C >= 64);
+                         c.deriv_mode == PDMP_DERIV_FORWARD && !taped && 2 * C_ws < 0x7fffffffLL && (!resuming || dense_resume) &&
+                         (dense_resume || (dense_mode ? (dense_mode == 2 || dense_mode == 1) : C >= 64)) && !(until && dense_mode == 2);
+    const bool bps_batched = c.target_id == PDMP_T_GAUSS_DENSE && (c.sampler == PDMP_BPS || c.sampler == PDMP_BOOMERANG) && c.grid_size == GNG && c.dim <= (c.sampler == PDMP_BOOMERANG ? 24 : 32) * WAVE &&
+                             c.deriv_mode == PDMP_DERIV_FORWARD && !taped && 2 * C_ws < 0x7fffffffLL && (!resuming || dense_resume) &&
+                             (dense_resume || (dense_mode ? (dense_mode == 2 || dense_mode == 1) : C >= 64));
+    if (until && (taped || h->group_lanes <= 0 || (c.target_id == PDMP_T_GAUSS_DENSE && !batched && !bps_batched) ||
+                  (batched && (c.dim > 16 * WAVE || (!c.signed_bound && c.dim > 8 * WAVE))) || (bps_batched && c.dim > 16 * WAVE))) {   // (the largest kernels: no horizon)
+        h->pool.push_back(ev);
+        return fail(PDMP_ERR_UNSUPPORTED, "the in-kernel time horizon runs on the group / lane kernels (grid_size = 10 or 0) and on the batched dense-precision forms "
+                                          "(>= 64 chains, d <= 1024); no tape: rerun the fixed-count path with a doubled capacity instead");
+    }
+    const double t_stop = until ? until->T : __builtin_huge_val();
     if (batched) {
         char msg[256] = "";
         int rc = -5;
         if (dense_mode != 2)                                   // P x, P v kept current incrementally: O(d) per gradient (dense_batched.hip)
-            rc = pdmp_dense_incremental_run(h->device, c.dim, c.signed_bound, c.adaptive, c.tmax, c.max_iter_per_event, h->d_tparams, C, n_sk,
+            rc = pdmp_dense_incremental_run(h->device, c.dim, c.signed_bound, c.adaptive, c.tmax, c.max_iter_per_event, h->d_tparams, C_ws, n_sk,
                                             chain_id_offset, seed, xinit, vinit, X, V, t, p.H, p.AR, p.EB, p.EV, p.RJ, p.HH,
-                                            h->d_status, stream, &h->dense_ws, &h->dense_ws_cap, pol.dense_resync, pol.dense_gemm < 0 ? 1 : pol.dense_gemm, msg, (int)sizeof msg);
+                                            h->d_status, stream, &h->dense_ws, &h->dense_ws_cap, pol.dense_resync, pol.dense_gemm < 0 ? 1 : pol.dense_gemm,
+                                            t_stop, resuming ? 1 : 0, C, until ? until->chain_map : nullptr, until ? until->count : nullptr, msg, (int)sizeof msg);
         if (rc == -5)                                           // d > 1024 (or forced): one GEMM per phase
             rc = pdmp_dense_batched_run(h->device, c.dim, c.signed_bound, c.adaptive, c.tmax, c.max_iter_per_event, h->d_tparams, C, n_sk,
                                         chain_id_offset, seed, xinit, vinit, X, V, t, p.H, p.AR, p.EB, p.EV, p.RJ, p.HH,
@@ -1198,14 +1210,12 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
     // BPS / Boomerang on a dense precision, many chains: the rate along the flow is a closed form in a few dot products with P x and P v
     // (BPS: <P x, v> + t <P v, v>; Boomerang: a quadratic form in cos t, sin t), so only an accepted event needs products with P --
     // P [x | v'] of ALL chains as one fp64 GEMM per skeleton column (dense_batched.hip: dr_bps_kernel, dr_boom_kernel)
-    const bool bps_batched = c.target_id == PDMP_T_GAUSS_DENSE && (c.sampler == PDMP_BPS || c.sampler == PDMP_BOOMERANG) && c.grid_size == GNG && c.dim <= (c.sampler == PDMP_BOOMERANG ? 24 : 32) * WAVE &&
-                             c.deriv_mode == PDMP_DERIV_FORWARD && !taped && !until && 2 * C < 0x7fffffffLL &&
-                             (dense_mode ? (dense_mode == 2 || dense_mode == 1) : C >= 64);
     if (bps_batched) {
         char msg[256] = "";
         const int rc = pdmp_dense_bps_run(h->device, c.sampler == PDMP_BOOMERANG ? 1 : 0, c.dim, c.signed_bound, c.adaptive, c.gaussian_velocity, c.tmax, c.refresh_rate, c.max_iter_per_event,
-                                          h->d_tparams, C, n_sk, chain_id_offset, seed, xinit, vinit, X, V, t, p.H, p.AR, p.EB, p.EV, p.RJ, p.HH,
-                                          h->d_status, stream, &h->dense_ws, &h->dense_ws_cap, pol.dense_resync, pol.dense_gemm < 0 ? 0 : pol.dense_gemm, pol.dense_lanes, msg, (int)sizeof msg);
+                                          h->d_tparams, C_ws, n_sk, chain_id_offset, seed, xinit, vinit, X, V, t, p.H, p.AR, p.EB, p.EV, p.RJ, p.HH,
+                                          h->d_status, stream, &h->dense_ws, &h->dense_ws_cap, pol.dense_resync, pol.dense_gemm < 0 ? 0 : pol.dense_gemm, pol.dense_lanes,
+                                          t_stop, resuming ? 1 : 0, C, until ? until->chain_map : nullptr, until ? until->count : nullptr, msg, (int)sizeof msg);
         if (rc != 0) { h->pool.push_back(ev); return fail(PDMP_ERR_RUNTIME, "dense BPS path: %s", msg); }
         h->last_form = PDMP_FORM_DENSE;
         return end_timed(h, s, ev);

@@ -333,9 +333,10 @@ def test_multi_device_entry_with_one_device(engine, oracle):
 @pytest.mark.parametrize("kind,T", [("ZigZagAD", 1.5), ("BPS", 4.0), ("BoomerangAD", 6.0)])
 def test_time_horizon_on_the_batched_dense_forms(engine, oracle, kind, T):
     """`sample_skeleton(sampler, T::Float64, ...)` on the dense-precision target with >= 64 chains: the batched forms
-    (dense_batched.hip: incremental Zig-Zag, one GEMM per event for BPS / Boomerang) have no in-kernel stop, so the call takes the
-    capacity-doubling host loop over the fixed-count path + `pdmp_close_at_time_device` (the sampler's own flow to t = T: the
-    Boomerang's rotation included).  Against the checker's reference-order restatement: history lengths identical, times 1e-9."""
+    (dense_batched.hip: incremental Zig-Zag, one GEMM per event for BPS / Boomerang).  Rounds 1-3: no in-kernel stop there, the call
+    took the capacity-doubling host loop over the fixed-count path + `pdmp_close_at_time_device`; round 4: the chunked path with the stop
+    inside the kernels (test_gpu_time_horizon_chunks.py has the chunk structure under test).  Either way the sampler's own flow closes at
+    t = T (the Boomerang's rotation included).  Against the checker's reference-order restatement: history lengths identical, times 1e-9."""
     import torch
     from pdmpflux.jl_amd import ensemble, _lib
     dim, C = 40, 64

@@ -165,3 +165,36 @@ def test_chunked_time_horizon_sticky(engine, oracle, dim, target, kap, T, cap):
         for c in range(C):
             assert np.array_equal(a[off[c]:off[c + 1]], ref[key][c, :cnt[c]], equal_nan=True), (key, c)
     assert (got["is_active"] == 0).any()
+
+
+@pytest.mark.parametrize("cap", [8, 24, 40])
+@pytest.mark.parametrize("kind,dim,T", [("ZigZagAD", 40, 1.5), ("ZigZagAD", 300, 0.3), ("BPS", 40, 4.0), ("BoomerangAD", 40, 6.0), ("BPS", 130, 12.0)])
+def test_chunked_time_horizon_on_the_batched_dense_forms(engine, oracle, kind, dim, T, cap):
+    """Round 4: the time horizon inside the batched dense-precision kernels (dense_batched.hip: `t_stop`, `resume`, `chain_map`, `count` --
+    the workspace holds every chain's state between chunks, a resumed chunk's slots are the chains still running).  Several chunks with
+    compaction from a small first capacity; against the checker's reference-order restatement: history lengths identical, times 1e-9
+    (the batched forms are held to a tolerance: P x is carried by recurrences between re-basing products)."""
+    import torch
+    from pdmpflux.jl_amd import ensemble, _lib
+    C_ = 70                                                              # (two ragged blocks of four chains at the end)
+    s, cfg = make_pair(engine, oracle, kind, dim, "dense", arith=oracle.ARITH_REFERENCE)
+    x, v = make_init(kind, dim, C_, seed=3)
+    dev = torch.device("cuda:0")
+    stats = {}
+    got = ensemble.sample_skeleton_until_chunked_device(s, T, torch.from_numpy(x).to(dev), torch.from_numpy(v).to(dev), seed=11,
+                                                        init_capacity=cap, stats=stats)
+    assert s.last_launch_form() == 5 and _lib.lib().pdmp_dense_batched_last_mode() in (2, 3)
+    ref = oracle.sample_skeleton_until(cfg, T, x, v, 11, init_capacity=64)
+    cnt, off = got["count"].cpu().numpy(), got["offsets"].cpu().numpy()
+    assert np.array_equal(cnt, ref["count"])
+    assert len(set(cnt.tolist())) > 1
+    if cnt.max() > cap + 1:
+        assert stats["chunks"] >= 2, stats                               # resumed chunks
+    print(kind, dim, cap, stats["capacities"], stats["chains"])          # (-s: which cases compact -- chains[-1] < 70)
+    tt, X, V = got["t"].cpu().numpy(), got["X"].cpu().numpy(), got["V"].cpu().numpy()
+    for c in range(C_):
+        k = int(cnt[c])
+        assert np.allclose(tt[off[c]:off[c + 1]], ref["t"][c, :k], rtol=1e-9, atol=0), c
+        assert np.allclose(X[off[c]:off[c + 1]], ref["X"][c, :k], rtol=1e-8, atol=1e-10), c
+        assert np.allclose(V[off[c]:off[c + 1]], ref["V"][c, :k], rtol=1e-8, atol=1e-10), c
+        assert tt[off[c + 1] - 1] == T
