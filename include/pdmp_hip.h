@@ -247,8 +247,9 @@ int pdmp_close_at_time_device(pdmp_handle h, int64_t C, int64_t n_sk, double *X,
  *     chain_id_offset must be the first chunk's.  X, V, t (and diag) are this chunk's own buffers, d x capacity x C etc.
  *   n_recorded[c] (int64, DEVICE) = columns chain c recorded in this chunk (capacity, or fewer when it reached T).
  *   Runs on the group / lane kernels: every sampler (StickyZigZag: the hand-off state carries the active masks; pass diag->is_active),
- *   built-in and source-given targets except the dense-precision one, grid_size = 10 or 0, no tape; PDMP_ERR_UNSUPPORTED otherwise
- *   (use the fixed-count path + pdmp_close_at_time_device with a doubled capacity).
+ *   built-in and source-given targets, grid_size = 10 or 0, no tape; and (round 4) on the batched dense-precision forms -- Zig-Zag / BPS /
+ *   Boomerang, first chunk of >= 64 chains, d <= 1024: the handle's workspace holds the chains' states between chunks.
+ *   PDMP_ERR_UNSUPPORTED otherwise (use the fixed-count path + pdmp_close_at_time_device with a doubled capacity).
  * pdmp_close_chunk_device: pdmp_close_at_time_device restricted to the recorded columns of a chunk (stride = capacity):
  *   count[c] >= 0: the chain's history ends in this chunk with count[c] columns, the last one at exactly t = T (the closing
  *   column written in place over the overshooting event, :385-420; none when an event sits at exactly T);
