@@ -52,7 +52,7 @@ def parse():
                          "pdmp_multi_sample_skeleton over --gpus devices (the library's own RCCL path)")
     ap.add_argument("--n-sk", type=int, default=1000)
     ap.add_argument("--dim", type=int, default=50)
-    ap.add_argument("--sampler", default="ZigZagAD", choices=["ZigZagAD", "ZigZag", "BPS", "BPSAD", "Boomerang", "BoomerangAD", "ForwardECMC", "ForwardECMCAD", "SpeedUpZigZag", "SpeedUpZigZagAD", "RHMC"])
+    ap.add_argument("--sampler", default="ZigZagAD", choices=["ZigZagAD", "ZigZag", "BPS", "BPSAD", "Boomerang", "BoomerangAD", "ForwardECMC", "ForwardECMCAD", "SpeedUpZigZag", "SpeedUpZigZagAD", "RHMC", "StickyZigZag", "StickyZigZagAD"])
     ap.add_argument("--refresh-rate", type=float, default=None, help="BPS / Boomerang refresh_rate (default: the constructor's)")
     ap.add_argument("--target", default="iso", choices=["iso", "diag", "banana", "dense", "src_banana"],
                     help="src_banana: U_banana given as source, differentiated by forward mode on the GPU (pdmp_create_from_source)")
@@ -140,6 +140,9 @@ def make_sampler(P, a):
     tgt = {"iso": P.GaussianIso, "banana": P.Banana, "src_banana": lambda: P.SourcePotential(P.U_BANANA_SOURCE)}.get(a.target)
     tgt = tgt() if tgt else P.GaussianPrecision(dense_precision(a))
     kw = {} if a.refresh_rate is None else {"refresh_rate": a.refresh_rate}
+    if a.sampler.startswith("Sticky"):           # spike-and-slab: thawing rate 0.5 for every coordinate (tests/test_gpu_sticky.py's regime)
+        import numpy as np
+        return getattr(P, a.sampler)(a.dim, tgt, np.full(a.dim, 0.5), **kw)
     return getattr(P, a.sampler)(a.dim, tgt, **kw)
 
 
@@ -147,7 +150,7 @@ def init_kind(a):
     """(x_mean, x_scale, v_kind) of the synthetic initial states, BASELINE.md section 3: stationary-ish starts x ~ N(0, I) (banana:
     ones + 0.1 N(0, I)); v: +-1 coordinates for the Zig-Zag family, uniform on the unit sphere for BPS / ForwardECMC, N(0, I) otherwise."""
     xm, xs = (1.0, 0.1) if a.target in ("banana", "src_banana") else (0.0, 1.0)
-    vk = 0 if a.sampler.startswith(("ZigZag", "SpeedUp")) else (2 if a.sampler.startswith(("BPS", "ForwardECMC")) else 1)
+    vk = 0 if a.sampler.startswith(("ZigZag", "SpeedUp", "Sticky")) else (2 if a.sampler.startswith(("BPS", "ForwardECMC")) else 1)
     return xm, xs, vk
 
 

@@ -25,6 +25,7 @@ hipError_t launch_lane2q_zigzag_c(int target, const GroupParams &gp, const int32
 hipError_t launch_lane_zigzag_d(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);   // d = 1 .. 8 (round 4: rows shorter than a line)
 hipError_t launch_lane2q_zigzag_d(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream); // the pair form at d = 1 .. 8
 hipError_t launch_group_reg_zigzag(int target, bool fd, const GroupParams &gp, hipStream_t stream);
+hipError_t launch_group_reg_sticky_exact(int target, const GroupParams &gp, hipStream_t stream);      // round 4: StickyZigZag, K <= 7 (inst_reg_sticky_k*.hip)
 hipError_t launch_group_reg_bps(int target, bool fd, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_boomerang(int target, bool fd, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_rhmc(int target, const GroupParams &gp, hipStream_t stream);                        // inst_reg_rhmc.hip
@@ -828,7 +829,8 @@ int choose_group_lanes(const pdmp_config_t &c) {
         if (G == 0) return 0;
         if (G >= 1 && G <= WAVE && (G & (G - 1)) == 0 && group_waves_per_block((c.dim + G - 1) / G, 2 * c.dim) >= 1) return G;
     }
-    if (c.sampler == PDMP_FECMC && c.deriv_mode == PDMP_DERIV_FORWARD && c.grid_size == GNG && c.target_id <= PDMP_T_BANANA) {
+    if ((c.sampler == PDMP_FECMC || (c.sampler == PDMP_STICKY && c.vectorized_bound && c.signed_bound)) &&   // (StickyZigZag: x, v, the active mask in VGPRs; 13 slots spill)
+        c.deriv_mode == PDMP_DERIV_FORWARD && c.grid_size == GNG && c.target_id <= PDMP_T_BANANA) {
         // register form (round 4, inst_reg_fecmc_k*.hip): x, v in VGPRs, five LDS tiles of K x 64 doubles per wave (exchange, n, v_orth,
         // e1, e2) -- K <= 7 keeps two blocks of four waves per CU; exact-K kernels for K = 2 .. 7 at one lane per chain, 4 .. 7 otherwise
         for (int G = 1; G <= 16; G <<= 1) {
@@ -1230,7 +1232,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
         h->last_form = PDMP_FORM_GROUP_REG;
         // register form: the default bound flags only (grid_size = 10; Zig-Zag: vectorized signed bound) -- GroupChain::brent() etc.
         const bool reg_flags = c.sampler == PDMP_RHMC ||        // (RHMC: its bound is the constant refresh clock whatever the flags)
-                               (c.grid_size == GNG && (c.sampler != PDMP_ZIGZAG || (c.vectorized_bound && c.signed_bound)));
+                               (c.grid_size == GNG && ((c.sampler != PDMP_ZIGZAG && c.sampler != PDMP_STICKY) || (c.vectorized_bound && c.signed_bound)));
         if (pol.reg && reg_flags) {
             const bool fd = c.deriv_mode != 0;
             // Large Zig-Zag ensembles at d = 49..52 on the isotropic Gaussian / banana: one LANE per chain (lane_kernel.hpp), bit-identical
@@ -1298,7 +1300,8 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
                   : fd                             ? hipErrorNotSupported
                   : c.sampler == PDMP_ZIGZAG       ? launch_group_reg_zigzag_exact(c.target_id, gp, s)
                   : c.sampler == PDMP_BPS          ? launch_group_reg_bps_exact(c.target_id, gp, s)
-                  : c.sampler == PDMP_FECMC        ? launch_group_reg_fecmc_exact(c.target_id, gp, s) : hipErrorNotSupported;   // round 4: K <= 7
+                  : c.sampler == PDMP_FECMC        ? launch_group_reg_fecmc_exact(c.target_id, gp, s)           // round 4: K <= 7
+                  : c.sampler == PDMP_STICKY       ? launch_group_reg_sticky_exact(c.target_id, gp, s) : hipErrorNotSupported;
             if (e == hipErrorNotSupported && !tgroup)
                 e = c.sampler == PDMP_ZIGZAG    ? launch_group_reg_zigzag(c.target_id, fd, gp, s)
                   : c.sampler == PDMP_BPS       ? launch_group_reg_bps(c.target_id, fd, gp, s)

@@ -383,8 +383,11 @@ struct GroupChain {
         const int s = (G == WAVE) ? (i >> 6) : i / G, l = base + (i - s * G);
         if constexpr (kSticky) {
             const uint32_t m = (uint32_t)__shfl((int)amask, l, WAVE);
-            x = xs[s * WAVE + l];
-            v = ((m >> s) & 1u) ? vs[s * WAVE + l] : 0.0;
+            double xv, vv;
+            if constexpr (kReg) { xv = __shfl((s == 0) ? xr[0] : xr[1], l, WAVE); vv = __shfl((s == 0) ? vr[0] : vr[1], l, WAVE); }   // (round 4: the register form has no x / v tiles)
+            else { xv = xs[s * WAVE + l]; vv = vs[s * WAVE + l]; }
+            x = xv;
+            v = ((m >> s) & 1u) ? vv : 0.0;
             return;
         }
         if constexpr (kReg) {
@@ -2052,7 +2055,7 @@ template <int SAMPLER, int TARGET, bool FD> struct RegForm {
         return !kSlowZz && !((SAMPLER == S_ZIGZAG || SAMPLER == S_BOOMERANG) && TARGET == T_GAUSS_DIAG && GC == 1);
     }
     static constexpr bool kFecmc = SAMPLER == S_FECMC;
-    static constexpr bool kAny = !kSlowZz && !(kFecmc && FD) && SAMPLER != S_SUZZ && SAMPLER != S_STICKY && !(kRhmc && FD);
+    static constexpr bool kAny = !kSlowZz && !(kFecmc && FD) && SAMPLER != S_SUZZ && !(SAMPLER == S_STICKY && FD) && !(kRhmc && FD);   // (StickyZigZag, round 4: exact-K kernels, K <= 7 -- 13 slots spill; inst_reg_sticky_k*.hip)
 };
 
 // register form (x, v in VGPRs, up to KC slots per lane, G fixed at compile time): no LDS tiles; 2 waves per SIMD -- the

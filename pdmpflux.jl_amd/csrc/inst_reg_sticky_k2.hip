@@ -1,0 +1,21 @@
+// Register form of StickyZigZag, K = 6, 7 slots per lane (see inst_reg_sticky_k.hip).
+#include "inst_reg.hpp"
+
+namespace pdmp {
+template <int T>
+static hipError_t sticky_hi(const GroupParams &gp, hipStream_t stream) {
+    switch (gp.K) {
+    case 6: return exact_by_lanes<S_STICKY, T, false, 6>(gp, stream);
+    case 7: return exact_by_lanes<S_STICKY, T, false, 7>(gp, stream);
+    default: return hipErrorNotSupported;
+    }
+}
+hipError_t launch_group_reg_sticky_exact_hi(int target, const GroupParams &gp, hipStream_t stream) {
+    switch (target) {
+    case T_GAUSS_ISO: return sticky_hi<T_GAUSS_ISO>(gp, stream);
+    case T_GAUSS_DIAG: return sticky_hi<T_GAUSS_DIAG>(gp, stream);
+    case T_BANANA: return sticky_hi<T_BANANA>(gp, stream);
+    default: return hipErrorNotSupported;
+    }
+}
+}  // namespace pdmp

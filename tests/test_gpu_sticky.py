@@ -81,3 +81,25 @@ def test_sticky_zigzag_segment_handoff(engine, oracle, monkeypatch, segments, di
     ref = oracle.sample_skeleton(cfg, n_sk, x, v, 51, diagnostics=True)
     assert_bitwise(got, ref, keys=("X", "V", "t", "is_active") + DIAG_KEYS)
     assert (ref["is_active"] == 0).any()
+
+
+@pytest.mark.parametrize("dim,target,kap,seg", [(2, "iso", 0.5, 0), (3, "banana", 0.6, 0), (13, "diag", 0.3, 3), (20, "banana", 0.5, 0), (24, "iso", 0.4, 5),
+                                                (50, "iso", 0.7, 4), (50, "banana", 0.5, 0), (100, "iso", 0.2, 0), (7, "iso", 0.6, 0), (112, "diag", 0.3, 2)])
+def test_sticky_register_and_lds_forms_agree(engine, oracle, monkeypatch, dim, target, kap, seg):
+    """Round 4: StickyZigZag in the register form (x, v and the active mask in VGPRs; exact-K kernels for K <= 7 slots per lane,
+    inst_reg_sticky_k*.hip; forward-mode slopes, the default bound flags): the same bits as the LDS form and the checker, hand-off
+    segments (the masks travel in the hand-off state) included."""
+    if seg:
+        monkeypatch.setenv("PDMP_FORCE_SEGMENTS", str(seg))
+    outs = []
+    for reg in ("1", "0"):
+        monkeypatch.setenv("PDMP_REG", reg)
+        s, cfg = pair(engine, oracle, "StickyZigZagAD", dim, target, kap)
+        K = -(-dim // s.group_lanes())
+        assert K <= 7
+        x, v = make_init("ZigZag", dim, 37, seed=5, target=target)
+        outs.append(engine.sample_skeleton_ensemble(s, 90, x, v, seed=13, diagnostics=True))
+        assert s.last_launch_form() == (3 if reg == "1" else 2)
+    assert_bitwise(outs[0], outs[1], keys=("X", "V", "t", "is_active") + DIAG_KEYS)
+    assert_bitwise(outs[0], oracle.sample_skeleton(cfg, 90, x, v, 13, diagnostics=True), keys=("X", "V", "t", "is_active") + DIAG_KEYS)
+    assert (outs[0]["is_active"] == 0).any()
