@@ -25,6 +25,7 @@ hipError_t launch_lane2q_zigzag_c(int target, const GroupParams &gp, const int32
 hipError_t launch_lane_zigzag_d(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);   // d = 1 .. 8 (round 4: rows shorter than a line)
 hipError_t launch_lane2q_zigzag_d(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream); // the pair form at d = 1 .. 8
 hipError_t launch_group_reg_zigzag(int target, bool fd, const GroupParams &gp, hipStream_t stream);
+hipError_t launch_group_reg_suzz_exact(int target, const GroupParams &gp, hipStream_t stream);        // round 4: SpeedUpZigZag, the slot counts that do not spill (inst_reg_suzz_k*.hip)
 hipError_t launch_group_reg_sticky_exact(int target, const GroupParams &gp, hipStream_t stream);      // round 4: StickyZigZag, K <= 7 (inst_reg_sticky_k*.hip)
 hipError_t launch_group_reg_bps(int target, bool fd, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_boomerang(int target, bool fd, const GroupParams &gp, hipStream_t stream);
@@ -838,6 +839,17 @@ int choose_group_lanes(const pdmp_config_t &c) {
             if (K <= 7 && K >= (G == 1 ? 2 : 4)) return G;
         }
     }
+    if (c.sampler == PDMP_SUZZ && c.vectorized_bound && c.signed_bound && c.deriv_mode == PDMP_DERIV_FORWARD && c.grid_size == GNG && c.target_id <= PDMP_T_BANANA) {
+        // register form (round 4, inst_reg_suzz_k*.hip): exact-K kernels where they fit 256 registers -- K <= 7 (isotropic Gaussian), 6 (diagonal), 4 (banana)
+        const int kmax = c.target_id == PDMP_T_GAUSS_ISO ? 7 : (c.target_id == PDMP_T_GAUSS_DIAG ? 6 : 4);
+        // (measured at d = 50, 10^5 chains x 500, against the LDS form at G = 4: iso G = 8 / K = 7 55.9 -> 48.9 ms; banana G = 16 / K = 4 107.4 -> 76.6 ms;
+        //  the diagonal Gaussian would need G = 16 / K = 4 there and loses, 59.3 -> 70.3 ms: at most 8 lanes per chain for it)
+        const int gmax = c.target_id == PDMP_T_GAUSS_DIAG ? 8 : 16;
+        for (int G = 1; G <= gmax; G <<= 1) {
+            const int K = (c.dim + G - 1) / G;
+            if (K <= kmax && K >= 2) return G;
+        }
+    }
     if (c.sampler == PDMP_FECMC) {         // six LDS tiles per wave (x, v, n, v_orth, e1, e2): 20 KB keep two blocks per CU (measured
         for (int G = 1; G <= WAVE; G <<= 1)   // at d = 50: G = 4 / 8 / 16 -> 467 / 566 / 306 ms); 40 KB for very large d
             if (6 * (size_t)((c.dim + G - 1) / G) * WAVE * sizeof(double) <= 20 * 1024) return G;
@@ -1232,7 +1244,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
         h->last_form = PDMP_FORM_GROUP_REG;
         // register form: the default bound flags only (grid_size = 10; Zig-Zag: vectorized signed bound) -- GroupChain::brent() etc.
         const bool reg_flags = c.sampler == PDMP_RHMC ||        // (RHMC: its bound is the constant refresh clock whatever the flags)
-                               (c.grid_size == GNG && ((c.sampler != PDMP_ZIGZAG && c.sampler != PDMP_STICKY) || (c.vectorized_bound && c.signed_bound)));
+                               (c.grid_size == GNG && ((c.sampler != PDMP_ZIGZAG && c.sampler != PDMP_STICKY && c.sampler != PDMP_SUZZ) || (c.vectorized_bound && c.signed_bound)));
         if (pol.reg && reg_flags) {
             const bool fd = c.deriv_mode != 0;
             // Large Zig-Zag ensembles at d = 49..52 on the isotropic Gaussian / banana: one LANE per chain (lane_kernel.hpp), bit-identical
@@ -1301,7 +1313,8 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
                   : c.sampler == PDMP_ZIGZAG       ? launch_group_reg_zigzag_exact(c.target_id, gp, s)
                   : c.sampler == PDMP_BPS          ? launch_group_reg_bps_exact(c.target_id, gp, s)
                   : c.sampler == PDMP_FECMC        ? launch_group_reg_fecmc_exact(c.target_id, gp, s)           // round 4: K <= 7
-                  : c.sampler == PDMP_STICKY       ? launch_group_reg_sticky_exact(c.target_id, gp, s) : hipErrorNotSupported;
+                  : c.sampler == PDMP_STICKY       ? launch_group_reg_sticky_exact(c.target_id, gp, s)
+                  : c.sampler == PDMP_SUZZ         ? launch_group_reg_suzz_exact(c.target_id, gp, s) : hipErrorNotSupported;
             if (e == hipErrorNotSupported && !tgroup)
                 e = c.sampler == PDMP_ZIGZAG    ? launch_group_reg_zigzag(c.target_id, fd, gp, s)
                   : c.sampler == PDMP_BPS       ? launch_group_reg_bps(c.target_id, fd, gp, s)

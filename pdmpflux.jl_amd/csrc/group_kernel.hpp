@@ -2055,7 +2055,7 @@ template <int SAMPLER, int TARGET, bool FD> struct RegForm {
         return !kSlowZz && !((SAMPLER == S_ZIGZAG || SAMPLER == S_BOOMERANG) && TARGET == T_GAUSS_DIAG && GC == 1);
     }
     static constexpr bool kFecmc = SAMPLER == S_FECMC;
-    static constexpr bool kAny = !kSlowZz && !(kFecmc && FD) && SAMPLER != S_SUZZ && !(SAMPLER == S_STICKY && FD) && !(kRhmc && FD);   // (StickyZigZag, round 4: exact-K kernels, K <= 7 -- 13 slots spill; inst_reg_sticky_k*.hip)
+    static constexpr bool kAny = !kSlowZz && !(kFecmc && FD) && !(SAMPLER == S_SUZZ && FD) && !(SAMPLER == S_STICKY && FD) && !(kRhmc && FD);   // (StickyZigZag, round 4: exact-K kernels, K <= 7 -- 13 slots spill; inst_reg_sticky_k*.hip)
 };
 
 // register form (x, v in VGPRs, up to KC slots per lane, G fixed at compile time): no LDS tiles; 2 waves per SIMD -- the

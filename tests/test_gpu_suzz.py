@@ -76,3 +76,24 @@ def test_moments_and_time_horizon_use_the_samplers_own_flow(engine, kind, dim, t
         assert out["t"][c, k - 1].item() == T
         one = engine.sample_from_skeleton_ensemble(s, 1, Xh[c:c + 1], Vh[c:c + 1], th[c:c + 1], discard_vt=False, dt=T)[0, 0]   # the point at 1 * dt = T
         assert np.array_equal(out["X"][c, k - 1].cpu().numpy(), one[:dim]) and np.array_equal(out["V"][c, k - 1].cpu().numpy(), one[dim:2 * dim])
+
+
+@pytest.mark.parametrize("dim,target,seg", [(2, "iso", 0), (5, "iso", 3), (13, "diag", 0), (50, "iso", 4), (20, "banana", 0), (50, "banana", 2), (48, "diag", 0),
+                                            (100, "iso", 0), (7, "banana", 0), (24, "diag", 5), (64, "banana", 0)])
+def test_speed_up_zigzag_register_and_lds_forms_agree(engine, oracle, monkeypatch, dim, target, seg):
+    """Round 4: SpeedUpZigZag in the register form (exact-K kernels for the slot counts that stay free of spills: K <= 7 on the isotropic
+    Gaussian, 6 on the diagonal one, 4 on the banana -- inst_reg_suzz_k*.hip; forward-mode slopes, the default bound flags): the same
+    bits as the LDS form and the checker, hand-off segments included."""
+    if seg:
+        monkeypatch.setenv("PDMP_FORCE_SEGMENTS", str(seg))
+    outs = []
+    for reg in ("1", "0"):
+        monkeypatch.setenv("PDMP_REG", reg)
+        s, cfg = make_pair(engine, oracle, "SpeedUpZigZagAD", dim, target)
+        K = -(-dim // s.group_lanes())
+        assert 2 <= K <= {"iso": 7, "diag": 6, "banana": 4}[target]
+        x, v = make_init("SpeedUpZigZagAD", dim, 37, seed=5, target=target)
+        outs.append(engine.sample_skeleton_ensemble(s, 60, x, v, seed=13, diagnostics=True))
+        assert s.last_launch_form() == (3 if reg == "1" else 2)
+    assert_bitwise(outs[0], outs[1])
+    assert_bitwise(outs[0], oracle.sample_skeleton(cfg, 60, x, v, 13, diagnostics=True))
