@@ -314,8 +314,8 @@ function sample_skeleton_device!(s::HIPSampler, X, V, t, xinit, vinit; seed::Int
 end
 check_status(s::HIPSampler) = check(ccall((:pdmp_check_status, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}), s.handle, C_NULL))
 # which kernel form served the last launch (diagnostic; waits for the launch): 1 wave per chain, 2 group (LDS), 3 group (registers),
-# 4 one lane per chain (large Zig-Zag ensembles, d = 27..52, unit speeds), 5 dense-precision path, 6 potential given as source,
-# 7 a pair of lanes per chain (Zig-Zag, d = 53..104; mid-sized launches at d = 25..52)
+# 4 one lane per chain (large Zig-Zag ensembles, d = 1..52, unit speeds), 5 dense-precision path, 6 potential given as source,
+# 7 a pair of lanes per chain (Zig-Zag, d = 53..104; mid-sized launches at d = 1..52)
 last_launch_form(s::HIPSampler) = Int(ccall((:pdmp_last_launch_form, LIB), Cint, (Ptr{Cvoid},), s.handle))
 
 # One Julia process, n GPUs (pdmp_multi_*): the C chains shard into contiguous ranges over the devices; with gather = true one RCCL
@@ -399,7 +399,8 @@ reload_policy!(s::HIPSampler) = check(ccall((:pdmp_reload_policy, LIB), Cint, (P
 # that have not reached T, which resume from their hand-off state; finished chains cost nothing, memory is the sum of the history
 # lengths.  `A` = the device array type (AMDGPU.ROCArray); xinit, vinit: d x C device arrays.  Returns the packed `_trim_history`
 # layout (Composites.jl:198-214): X, V (d x total), t (total), offsets (C + 1; chain c = columns offsets[c]+1 : offsets[c+1]), count (C).
-# PDMP_ERR_UNSUPPORTED (-5: the dense-precision target, tape replays) -> use the single-chain method above per chain.  StickyZigZag needs
+# PDMP_ERR_UNSUPPORTED (-5: tape replays; the dense-precision target with fewer than 64 chains or d > 1024 -- the batched dense forms serve the
+# horizon in-kernel since round 4) -> use the single-chain method above per chain.  StickyZigZag needs
 # the PDMPHistory.is_active arrays (pdmp_diag_t.is_active, ABI 8) for its closing column (sample.jl:386-401); this method records X, V, t
 # only and therefore refuses a sticky sampler instead of returning an unmasked closing column.
 function sample_skeleton_until(s::HIPSampler, T::Float64, xinit, vinit, A; seed::Int, chain_id_offset::Int=0, init_capacity::Int=1024, stream=C_NULL)
