@@ -60,14 +60,15 @@ def test_chunked_time_horizon_matches_checker(engine, oracle, kind, dim, target,
     assert stats["chains"] == sorted(stats["chains"], reverse=True)
 
 
+@pytest.mark.parametrize("dim", [50, 12, 5, 3])                          # (12, 5, 3: the lane kernels of round 4 -- 5 and 3: rows shorter than a 64-byte line)
 @pytest.mark.parametrize("target", ["iso", "banana"])
-def test_chunked_time_horizon_on_the_lane_kernel(engine, oracle, monkeypatch, target):
+def test_chunked_time_horizon_on_the_lane_kernel(engine, oracle, monkeypatch, target, dim):
     """PDMP_LANE=1: the first chunk runs one lane per chain; the resumed chunks -- a handful of chains -- must continue in the SAME
     form (the hand-off state has that kernel's layout: signed positions, sign words, batch-major)."""
     monkeypatch.setenv("PDMP_LANE", "1")
-    s, cfg = make_pair(engine, oracle, "ZigZagAD", 50, target)
-    C, T = 150, 1.6                                                      # three batches of 64 chains, the last one ragged
-    x, v = make_init("ZigZagAD", 50, C, seed=5, target=target)
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", dim, target)
+    C, T = 150, 80.0 / dim                                               # three batches of 64 chains, the last one ragged; ~30 events per chain
+    x, v = make_init("ZigZagAD", dim, C, seed=5, target=target)
     stats = {}
     _run(engine, oracle, s, cfg, x, v, T, 4, 16, stats, lo=7)            # chain_id_offset: streams keyed by the global chain id
     assert s.last_launch_form() == 4 and stats["chunks"] >= 2
