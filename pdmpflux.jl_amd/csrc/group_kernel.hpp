@@ -2044,7 +2044,8 @@ template <int SAMPLER, int TARGET, bool FD> struct RegForm {
     // skips on the diagonal Gaussian (FULL there spills 2 - 4 registers with the diagnostic arrays compiled in); the slope mode plays no
     // part in RHMC (constant refresh clock): only FD = false is instantiated.  SpeedUpZigZag spills 110 - 700 registers in every variant
     // at two waves per SIMD (its flow and effective gradient on forward-mode numbers) and still 30 -- into AGPRs -- at one wave per SIMD
-    // (tried in round 4; a spill is not allowed here, see below): LDS form only.  ForwardECMC (round 4): x, v in registers, the jump's four
+    // (tried in round 4; a spill is not allowed here, see below) -- with THIRTEEN slots; exact-K kernels fit for K <= 7 (isotropic Gaussian),
+    // 6 (diagonal), 4 (banana) and ship since the end of round 4 (inst_reg_suzz_k*.hip; forward-mode slopes).  ForwardECMC (round 4): x, v in registers, the jump's four
     // d-vectors stay in LDS tiles (five tiles per wave with the exchange tile), exact-K kernels for K <= 7 only (inst_reg_fecmc_k*.hip: 160 - 253
     // VGPRs, no spill, two waves per SIMD; forward-mode slopes) -- d = 50: 50.4 -> 27.5 ms (iso), 72.3 -> 28.7 ms (banana) against the LDS form's best layout.
     static constexpr bool kRhmc = SAMPLER == S_RHMC;
