@@ -861,6 +861,9 @@ int choose_group_lanes(const pdmp_config_t &c) {
         (c.target_id == PDMP_T_GAUSS_ISO || c.target_id == PDMP_T_BANANA)) return 4;
     for (int G = 1; G <= 16; G <<= 1)      // register form (inst_reg_*.hip): at most KREG slots per lane, G <= 16
         if ((c.dim + G - 1) / G <= KREG) return G;
+    if (c.sampler == PDMP_ZIGZAG && c.deriv_mode == PDMP_DERIV_FORWARD && c.vectorized_bound && c.signed_bound && c.grid_size == GNG && c.target_id <= PDMP_T_BANANA)
+        for (int G = 32; G <= WAVE; G <<= 1)   // Zig-Zag, d = 209 .. 832 (round 4, last): register kernels with half a wave / a wave per chain
+            if ((c.dim + G - 1) / G <= KREG) return G;
     const size_t budget = 20 * 1024;      // two blocks (8 waves) per CU
     for (int G = 1; G <= WAVE; G <<= 1) {
         const size_t K = (size_t)(c.dim + G - 1) / G;

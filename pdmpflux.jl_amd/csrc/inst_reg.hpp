@@ -18,6 +18,9 @@ static hipError_t reg_by_lanes(const GroupParams &gp, hipStream_t stream) {
         case 4: return launch_group_impl<S, T, FD, KREG, 4, false, TAPE>(gp, stream);
         case 8: return launch_group_impl<S, T, FD, KREG, 8, false, TAPE>(gp, stream);
         case 16: return launch_group_impl<S, T, FD, KREG, 16, false, TAPE>(gp, stream);
+        // (round 4, last: Zig-Zag at d = 209 .. 832 -- half a wave or a wave per chain; the other samplers keep the LDS form there)
+        case 32: if constexpr (S == S_ZIGZAG && !FD && !TAPE) return launch_group_impl<S, T, FD, KREG, 32, false, TAPE>(gp, stream); else return hipErrorNotSupported;
+        // (a whole wave per chain: the exact-slot-count kernels only, K = 7 .. 12 -- with thirteen slots the diagonal Gaussian and the banana spill 2 - 18 registers)
         default: return hipErrorNotSupported;
         }
     }
@@ -45,6 +48,8 @@ static hipError_t exact_by_lanes(const GroupParams &gp, hipStream_t stream) {
     case 4: return launch_group_impl<S, T, FD, KC, 4, true>(gp, stream);
     case 8: return launch_group_impl<S, T, FD, KC, 8, true>(gp, stream);
     case 16: return launch_group_impl<S, T, FD, KC, 16, true>(gp, stream);
+    case 32: if constexpr (S == S_ZIGZAG && !FD && KC >= 7) return launch_group_impl<S, T, FD, KC, 32, true>(gp, stream); else return hipErrorNotSupported;
+    case 64: if constexpr (S == S_ZIGZAG && !FD && KC >= 7) return launch_group_impl<S, T, FD, KC, 64, true>(gp, stream); else return hipErrorNotSupported;
     default: return hipErrorNotSupported;
     }
 }

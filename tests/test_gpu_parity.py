@@ -431,6 +431,28 @@ def test_register_and_lds_forms_agree(engine, oracle, monkeypatch, kind, dim, ta
     assert_bitwise(lds, ref)
 
 
+@pytest.mark.parametrize("dim", [209, 224, 260, 300, 352, 416, 417, 500, 640, 768, 832])   # G = 32: K = 7, 7, 9, 10, 11, 13; G = 64: K = 7, 8, 10, 12, 13 (13 at G = 64: LDS form)
+@pytest.mark.parametrize("target", ["iso", "diag", "banana"])
+def test_wide_zigzag_register_kernels(engine, oracle, monkeypatch, dim, target):
+    """Round 4 (last): Zig-Zag at d = 209 .. 832 keeps x, v in registers with half a wave (G = 32) or a whole wave (G = 64) per chain --
+    the exact-slot-count kernels and the 13-slot ones; before, these dimensions ran the LDS form.  Both equal the checker bit for bit."""
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", dim, target)
+    assert s.group_lanes() == (32 if dim <= 416 else 64)
+    C, n_sk = 9, 30
+    x, v = make_init("ZigZagAD", dim, C, seed=8, target=target)
+    ref = oracle.sample_skeleton(cfg, n_sk, x, v, 17, diagnostics=True)
+    assert_bitwise(engine.sample_skeleton_ensemble(s, n_sk, x, v, seed=17, diagnostics=True), ref)
+    assert s.last_launch_form() == (3 if dim <= 768 else 2)            # (a whole wave per chain with thirteen slots would spill: LDS form)
+    monkeypatch.setenv("PDMP_FORCE_SEGMENTS", "3")
+    monkeypatch.setenv("PDMP_REG_EXACT", "0")                          # the 13-slot kernel with per-slot skips (G = 32, K < 13), hand-off segments
+    s2, _ = make_pair(engine, oracle, "ZigZagAD", dim, target)
+    assert_bitwise(engine.sample_skeleton_ensemble(s2, n_sk, x, v, seed=17, diagnostics=True), ref)
+    monkeypatch.setenv("PDMP_REG", "0")
+    s3, _ = make_pair(engine, oracle, "ZigZagAD", dim, target)
+    assert_bitwise(engine.sample_skeleton_ensemble(s3, n_sk, x, v, seed=17, diagnostics=True), ref)
+    assert s3.last_launch_form() == 2
+
+
 @pytest.mark.parametrize("dim", [14, 30, 70, 160, 22, 48, 96, 183])   # (G, K) = (2,7) (4,8) (8,9) (16,10) (2,11) (4,12) (8,12) (16,12)
 @pytest.mark.parametrize("kind,target", [("ZigZagAD", "iso"), ("ZigZagAD", "diag"), ("ZigZagAD", "banana"),
                                          ("BPS", "iso"), ("BPS", "diag"), ("BPS", "banana"),
