@@ -525,8 +525,10 @@ def main():
                   f"group_kernel<{sampler.name},{a.target}> (G={G} lanes per chain)" if G > 0 else
                   f"skeleton_kernel<{sampler.name},{a.target}> (wave per chain)")
         form = sampler.last_launch_form()                        # which kernel form served the timed launches (pdmp_last_launch_form)
-        if form == 3 and not reg_form:                           # (the mirror above lags the engine: e.g. Zig-Zag K = 1 at G = 4 runs the two-slot kernel)
+        if form == 3:                                            # (the engine's own report wins over the mirror above)
             kernel = f"group_kernel_reg<{sampler.name},{a.target}> (G={G} lanes per chain, K={K} slots, x and v in registers)"
+        elif form == 2:
+            kernel = f"group_kernel<{sampler.name},{a.target}> (G={G} lanes per chain)"
         if form in (4, 7):
             per = "one lane per chain, 64 chains per wave" if form == 4 else "a lane pair per chain, 32 chains per wave"
             kernel = (f"lane_kernel<{a.target}> ({per}; signed positions y = x v in registers, "
