@@ -594,7 +594,8 @@ def main():
                                             "(not all of them hold fp64 arithmetic); peak = fp64 vector peak at 2.4 GHz; `busy` is the same share against the "
                                             "clock the chip actually held (4 SQ_ACTIVE_INST_VALU / SIMD cycles)"}
         if a.target == "dense" and int(_lib.lib().pdmp_dense_batched_last_mode()) == 2:
-            res["roofline"]["kernel"] = ("di_segment_kernel (wave per chain; P x and P v kept current by O(d) updates, one rocBLAS dgemm over all "
+            gemm = "rocBLAS dgemm" if os.environ.get("PDMP_DENSE_GEMM", "mfma") == "rocblas" else "fp64 MFMA product (csrc/dgemm_mfma.hip)"
+            res["roofline"]["kernel"] = ("di_segment_kernel (wave per chain; P x and P v kept current by O(d) updates, one " + gemm + " over all "
                                          "chains per 256 events re-bases them)")
             res["roofline"]["note"] = ("latency-bound: one chain per wave, 2 waves/SIMD; per event it writes 8(2d+1) B and reads one 8d-byte "
                                        "column of P (profiles/r1/c4_incr_pmc.json)")
