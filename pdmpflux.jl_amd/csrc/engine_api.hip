@@ -118,7 +118,9 @@ struct LaunchPolicy {
     int debug_launch = 0;          // PDMP_DEBUG_LAUNCH: print the launch geometry of the lane kernels
     // one lane per chain from this many chains on: the pair form (GL = 2) at d = 53 .. 104 fills the machine at 32 768 chains; at d <= 52
     // the one-lane kernel takes 8.2 - 9.7 ms whatever the count up to 65 536 chains and overtakes the pair form at ~37 000 (d >= 45) / ~40 000
-    int64_t lane_from_default(bool pair_dims, int dim) const { return pair_dims ? 28000 : (dim >= 45 ? 37000 : 40000); }
+    // (d <= 52: the pair form is the best form exactly while its waves -- 32 chains each -- are alone on their SIMDs: 32 768 chains; measured at the end of
+    //  round 4, d = 16 / 32 / 50, 33 500 .. 39 000 chains: pair 6.2 / 7.0-7.2 / 8.4-8.7 ms, one lane 5.45 / 6.6 / 8.2-8.3 -- scripts/r4_lane_from.sh; before: 37 000 / 40 000)
+    int64_t lane_from_default(bool pair_dims, int dim) const { (void)dim; return pair_dims ? 28000 : 32769; }
 };
 
 static LaunchPolicy policy_from_env() {
