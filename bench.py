@@ -44,8 +44,14 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--chains", type=int, default=100_000, help="chains of the ensemble (sharded over the GPUs)")
-    ap.add_argument("--gather", default="skeleton", choices=["skeleton", "none"],
-                    help="N > 1: the exchange that ends every step (skeleton: all-gather of X, V, t -- the north star's)")
+    ap.add_argument("--gather", default="skeleton", choices=["skeleton", "none", "moments", "samples"],
+                    help="N > 1: the exchange that ends every step.  skeleton: all-gather of X, V, t -- the north star's, 808 B per event; "
+                         "samples: sample_from_skeleton(--n-samples) on every shard, all-gather of the samples; moments: the fused moment sums of "
+                         "those samples, one all-reduce of 2 dim + 1 doubles")
+    ap.add_argument("--n-samples", type=int, default=0, help="--gather samples / moments: samples per chain (0: n_sk)")
+    ap.add_argument("--pipeline", default="auto",
+                    help="N > 1, --gather skeleton: batches of chains whose all-gather overlaps the sampling of the next batch "
+                         "(ensemble.sample_skeleton_sharded(pipeline=B)); auto = 4, 1 = the exchange after the whole shard")
     ap.add_argument("--lanes", default="auto", help="lanes per chain: auto (pdmp_suggest_group_lanes: the default layout for every shard size), default, or a power of two")
     ap.add_argument("--driver", default="ranks", choices=["ranks", "multi"],
                     help="ranks: one process per GPU over torch.distributed (what the round driver launches); multi: ONE process, "
@@ -349,10 +355,33 @@ def main_multi(a):
     print(json.dumps(res), flush=True)
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` (N > 1) without a launcher around it: start the N rank processes ourselves -- a child
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` --
+    BEFORE this process has touched the GPU, pass its output through and exit with its code (the line the driver reads is rank 0's)."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()                              # (counting devices does not initialise the GPU)
+    if have < a.gpus and os.environ.get("PDMP_BENCH_REHEARSAL") != "1":
+        raise SystemExit(f"bench.py --gpus {a.gpus}: {have} GPU(s) visible.  (PDMP_BENCH_REHEARSAL=1 runs the N ranks on device 0 with the exchange "
+                         "over gloo -- a rehearsal of the code path on a one-GPU box, not a measurement)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     a = parse()
     if a.driver == "multi":
         return main_multi(a)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     live = live_counters(a) if (a.pmc == "auto" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.gpus == 1) else None
     import torch
     import pdmpflux.jl_amd as P
@@ -361,9 +390,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
     # Rehearsal hook for a one-GPU box (never used by the driver): all ranks share device 0 and the exchange goes
     # through gloo on host copies, because RCCL refuses two ranks on one device.
@@ -395,11 +421,15 @@ def main():
     elif a.lanes != "default":
         sampler.set_group_lanes(int(a.lanes))
     gather = a.gather if world > 1 else "none"
+    n_samples = a.n_samples if a.n_samples > 0 else a.n_sk
+    pipeline = 1
+    if world > 1 and gather == "skeleton":
+        pipeline = 4 if a.pipeline == "auto" else max(1, int(a.pipeline))
     # Output buffers.  N = 1: the timed steps ROTATE over several fresh allocations of X, V, t (as many as fit, at most 3) -- a launch's
     # speed depends on where its arrays lie, so `value` is taken over all of them, none picked -- from the product's own
     # allocator for large outputs (ensemble.alloc_outputs: independent 1-GiB physical chunks).  N > 1: ONE full-size set per rank from
     # torch's allocator: the shard is sampled straight into its chain range and gathered in place (the buffers go through RCCL).
-    rows = C_total if gather == "skeleton" else hi - lo
+    rows = C_total if gather == "skeleton" else hi - lo        # (gather none / samples / moments: shard-sized skeleton buffers)
     set_bytes = 8 * rows * n_sk * (2 * d + 1)
     allocator = a.alloc if a.alloc != "auto" else ("chunked" if world == 1 else "hipmalloc")
 
@@ -417,9 +447,10 @@ def main():
     def run_step(i, full):
         if world == 1:
             ensemble.sample_skeleton_device(sampler, n_sk, x, v, seed=a.seed + i, out=full, check=False)
-        else:       # rank r samples chains [lo_r, hi_r); gather="skeleton": then one all-gather each for X, V, t
-            ensemble.sample_skeleton_sharded(sampler, n_sk, x, v, seed=a.seed + i, gather=gather, out_full=full, check=False,
-                                             via_host=rehearsal)
+        else:       # rank r samples chains [lo_r, hi_r); gather="skeleton": then one all-gather each for X, V, t (pipeline > 1: per batch of chains,
+                    # overlapping the next batch's kernel); "samples" / "moments": sample_from_skeleton on the shard, then the exchange of its result
+            return ensemble.sample_skeleton_sharded(sampler, n_sk, x, v, seed=a.seed + i, gather=gather, out_full=full, check=False,
+                                                    via_host=rehearsal, pipeline=pipeline, N_samples=n_samples if gather in ("samples", "moments") else None)
 
     def fence():
         torch.cuda.synchronize()
@@ -441,8 +472,11 @@ def main():
     sets = [alloc_set(allocator) for _ in range(n_sets)]         # the FIRST allocation(s) of this process, whatever they turn out to be
     full = sets[0]
 
+    last_step = []
+
     def step(i):
-        run_step(i, sets[i % n_sets])
+        r = run_step(i, sets[i % n_sets])
+        last_step[:] = [r]
 
     for i in range(a.warmup):
         step(i)
@@ -467,27 +501,53 @@ def main():
     from pdmpflux.jl_amd import _lib
     _lib.check(_lib.lib().pdmp_check_status(sampler.handle(), None))
     tm = ensemble.kernel_timing(sampler)
-    kernel_ms = tm["kernel_ms_total"] / max(tm["launches"], 1)
+    kernel_ms = tm["kernel_ms_total"] / max(a.steps, 1)        # kernel time per step on this rank: every launch of the step (a pipelined step makes one per batch;
+                                                                # --gather samples / moments add their sample_from_skeleton / moments kernel)
+    launches_per_step = tm["launches"] / max(a.steps, 1)
     kernel_ms_max = kernel_ms
     if world > 1:
         te = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms_max = float(te[0].item()), float(te[1].item())
+    n_batches = min(pipeline, max(1, C_total // world)) if pipeline > 1 else 1
+
+    def ranges_of(r):                                             # the chains rank r samples
+        if n_batches > 1:
+            return [ensemble.batch_shard_range(C_total, j, n_batches, r, world) for j in range(n_batches)]
+        return [ensemble.shard_range(C_total, r, world)]
+    C_local = sum(h2 - l2 for l2, h2 in ranges_of(rank))
 
     # sanity inside the bench: strictly increasing event times on a slice, finite outputs; after the exchange every rank holds
-    # every rank's chains: the block of the LAST rank must be what a checksum of that rank says
-    own = full["t"][lo:hi] if gather == "skeleton" else full["t"]
+    # every rank's chains: the blocks of every rank must be what a checksum by that rank says
+    l0, h0 = ranges_of(rank)[0]
+    own = full["t"][l0:h0] if gather == "skeleton" else full["t"]
     tt = own[:256]
-    assert bool((tt[:, 1:] > tt[:, :-1]).all()) and bool(torch.isfinite(full["X"][:256]).all())
+    assert bool((tt[:, 1:] > tt[:, :-1]).all()) and bool(torch.isfinite((full["X"][l0:h0] if gather == "skeleton" else full["X"])[:256]).all())
+    exchange_ms = None
     if gather == "skeleton":
         cdev = "cpu" if rehearsal else dev
-        mine = torch.stack([full["t"][lo:hi].sum(), full["X"][lo:hi, -1].sum(), full["V"][lo:hi, -1].sum()]).to(cdev)
+
+        def checksum(r):
+            parts = [torch.stack([full["t"][l2:h2].sum(), full["X"][l2:h2, -1].sum(), full["V"][l2:h2, -1].sum()]) for l2, h2 in ranges_of(r) if h2 > l2]
+            return torch.stack(parts).sum(0)
+        mine = checksum(rank).to(cdev)
         sums = [torch.zeros(3, dtype=torch.float64, device=cdev) for _ in range(world)]
         dist.all_gather(sums, mine)
         for r in range(world):
-            l2, h2 = ensemble.shard_range(C_total, r, world)
-            got = torch.stack([full["t"][l2:h2].sum(), full["X"][l2:h2, -1].sum(), full["V"][l2:h2, -1].sum()]).cpu()
-            assert torch.equal(got, sums[r].cpu()), f"rank {rank}: the gathered block of rank {r} differs from what that rank computed"
+            assert torch.equal(checksum(r).cpu(), sums[r].cpu()), f"rank {rank}: the gathered blocks of rank {r} differ from what that rank computed"
+        # the exchange ALONE (untimed calibration, after the timed region): the three all-gathers of one step on the buffers as they stand
+        fence()
+        tx = time.perf_counter()
+        for k in ("X", "V", "t"):
+            ensemble._gather_in_place(full[k], C_total, rank, world, None, via_host=rehearsal)
+        fence()
+        exchange_ms = (time.perf_counter() - tx) * 1e3
+    elif world > 1 and gather in ("samples", "moments") and last_step:
+        res_last = last_step[-1]
+        if gather == "moments":
+            assert bool(torch.isfinite(res_last["mean"]).all()) and float(res_last["count"]) == float(C_total * n_samples)
+        else:
+            assert tuple(res_last["samples"].shape) == (C_total, n_samples, d) and bool(torch.isfinite(res_last["samples"][:64]).all())
 
     # placement survey (N = 1; untimed, after everything `value` depends on): the timed arrays are released and five more fresh
     # allocations of X, V, t are timed one after the other (one warm + three timed launches each)
@@ -505,7 +565,6 @@ def main():
         events_step = C_total * (n_sk - 1)
         value = events_step * a.steps / elapsed
         bytes_per_event = 8 * (2 * d + 1)                         # X, V, t of one event
-        C_local = hi - lo
         achieved = C_local * (n_sk - 1) * bytes_per_event / (kernel_ms * 1e-3) / 1e9
         G = sampler.group_lanes()
         K = (d + G - 1) // G if G > 0 else 0
@@ -545,7 +604,13 @@ def main():
                             "salu_instr_per_event": live.get("SQ_INSTS_SALU", 0.0) / events_launch,
                             "valu_busy": 4 * live["SQ_ACTIVE_INST_VALU"] / (live["GRBM_GUI_ACTIVE"] / 8 * 1024),
                             "valu_source": "LIVE: SQ_INSTS_VALU / events of one launch; busy = 4 SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)"})
-        xbytes = 0 if gather != "skeleton" else (C_total - C_local) * n_sk * bytes_per_event
+        xbytes = ((C_total - C_local) * n_sk * bytes_per_event if gather == "skeleton" else
+                  (C_total - C_local) * n_samples * d * 8 if gather == "samples" else
+                  (2 * d + 1) * 8 if gather == "moments" else 0)
+        xdesc = {"none": "none",
+                 "skeleton": f"one all-gather each of the X, V, t shards per step (RCCL, in place{', in %d batches of chains overlapping the sampling' % n_batches if n_batches > 1 else ''}): {xbytes} bytes received per GPU per step",
+                 "samples": f"sample_from_skeleton({n_samples}) on every shard, one all-gather of the (chains, {n_samples}, dim) samples: {xbytes} bytes received per GPU per step",
+                 "moments": f"fused moment sums of sample_from_skeleton({n_samples}) on every shard (pdmp_sample_moments_device), one all-reduce of {2 * d + 1} doubles"}[gather]
         res = {
             "metric": metric_label(a, sampler, C_total),
             "value": value, "unit": "events/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -553,9 +618,14 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload_label(a, sampler, world, C_local), "chains": C_total, "chains_rank0": C_local,
                        "n_sk": n_sk, "dim": d, "events_per_step": events_step, "lanes_per_chain": G,
-                       "exchange": "none" if gather != "skeleton" else
-                                   f"one all-gather each of the X, V, t shards per step (RCCL, in place): {xbytes} bytes received per GPU per step",
+                       "exchange": xdesc, "gather": gather, "pipeline_batches": n_batches,
                        "exchange_bytes_per_gpu": xbytes,
+                       "exchange_ms": exchange_ms,
+                       "exchange_note": (None if exchange_ms is None else
+                                         "exchange_ms: the three all-gathers of one step ALONE, timed once after the timed region (wall clock between two barriers); "
+                                         "ms_per_step covers sampling and exchange together (overlapped when pipeline_batches > 1); "
+                                         "kernel_only_events_per_s = events per step / the slowest rank's kernel time per step"),
+                       "kernel_launches_per_step": launches_per_step,
                        "allocator": ("ensemble.alloc_outputs: X, V, t built from independent 1-GiB physical chunks, the set drawn up to three times and the one a store-pattern kernel writes fastest kept (pdmp_device_alloc_streams)" if allocator == "chunked"
                                      else "torch.empty (hipMalloc)"),
                        "allocation_sets": n_sets,

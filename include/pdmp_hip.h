@@ -14,7 +14,7 @@
  *       t, horizon, ar            : n_sk x C       (double)
  *       errored_bound, rejected, hitting_horizon : n_sk x C (int32, Composites.jl:145-148)
  *       error_value_ar            : 5 x n_sk x C
- *   - Chain c draws from the Philox4x32-10 stream keyed (seed, chain_id_offset + c): results do not
+ *   - Chain c draws from the Philox4x32 stream (7 rounds; 10 with rng_version = 1) keyed (seed, chain_id_offset + c): results do not
  *     depend on how chains are sharded over GPUs (mirrors `seed = 42 + i`, test/test_property_based.jl:138).
  *   - Return 0 on success; <0 on error with a message in pdmp_last_error():
  *       PDMP_ERR_ARGUMENT  (-1)  -> Julia ArgumentError   (sample.jl:262-264,476-478; ZigZagSamplers.jl:62-68)
@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PDMP_ABI_VERSION 10   /* 10: + pdmp_device_alloc_streams (the streamed output arrays drawn several times, the fastest set kept); 9: + pdmp_device_alloc / pdmp_device_free (output arrays from independent physical chunks), pdmp_init_states_device, pdmp_multi_sample_skeleton_device / pdmp_multi_init_states, pdmp_reload_policy (launch policy fixed per handle); 8: + the time horizon as a kernel feature (pdmp_sample_skeleton_until_device, pdmp_close_chunk_device, pdmp_until_advance_device, pdmp_compact_chunk_device); tape replay on every kernel form; 7: + pdmp_last_launch_form; 6: is_active / ragged lengths in sample_from_skeleton*, moments and close_at; + the (N, dt) method, pdmp_compact_*, pdmp_multi_*; 5: + PDMP_STICKY, pdmp_diag_t.is_active; 2: + pdmp_create_from_source, PDMP_T_USER; 3: + PDMP_FECMC and its keywords at the end of pdmp_config_t; 4: + PDMP_SUZZ, PDMP_RHMC and its keywords */
+#define PDMP_ABI_VERSION 11   /* 11: + pdmp_config_t.rng_version (arithmetic contract v2 the default), grid_size 2..64 on the group kernel for every sampler / potential; 10: + pdmp_device_alloc_streams (the streamed output arrays drawn several times, the fastest set kept); 9: + pdmp_device_alloc / pdmp_device_free (output arrays from independent physical chunks), pdmp_init_states_device, pdmp_multi_sample_skeleton_device / pdmp_multi_init_states, pdmp_reload_policy (launch policy fixed per handle); 8: + the time horizon as a kernel feature (pdmp_sample_skeleton_until_device, pdmp_close_chunk_device, pdmp_until_advance_device, pdmp_compact_chunk_device); tape replay on every kernel form; 7: + pdmp_last_launch_form; 6: is_active / ragged lengths in sample_from_skeleton*, moments and close_at; + the (N, dt) method, pdmp_compact_*, pdmp_multi_*; 5: + PDMP_STICKY, pdmp_diag_t.is_active; 2: + pdmp_create_from_source, PDMP_T_USER; 3: + PDMP_FECMC and its keywords at the end of pdmp_config_t; 4: + PDMP_SUZZ, PDMP_RHMC and its keywords */
 
 enum { PDMP_OK = 0, PDMP_ERR_ARGUMENT = -1, PDMP_ERR_DIMENSION = -2, PDMP_ERR_RUNTIME = -3,
        PDMP_ERR_ITERCAP = -4, PDMP_ERR_UNSUPPORTED = -5 };
@@ -81,6 +81,12 @@ typedef struct pdmp_config_t {
      * (RandomizedHamiltonianMonteCarlo.jl:48-57); ignored by the other samplers. */
     double  rh_step_size, rh_phi;
     double  fe_speed_factor;    /* ForwardECMC(...; speed_factor = 1.0) (:292, jump variant :177-218); 0 -> 1.0 */
+    /* Arithmetic contract of the build-defined random stream (the engine's stand-in for MersenneTwister / randexp / randn, AbstractPDMP.jl:100)
+     * and of the elementary functions log / exp / sin / cos.  0 = the default = 2 (round 5: Philox4x32-7, Horner-on-fma polynomials, octant
+     * Box-Muller -- every kernel form); 1 = the contract of rounds 1-4 (Philox4x32-10, fdlibm forms without fma), kept for the fixtures frozen
+     * then: served by the LDS-form group kernels and the wave-per-chain kernel only (no register / lane / batched dense form, no tape). */
+    int32_t rng_version;
+    int32_t reserved0;
 } pdmp_config_t;
 
 typedef struct pdmp_engine *pdmp_handle;
@@ -120,7 +126,7 @@ int pdmp_create(const pdmp_config_t *cfg, pdmp_handle *out);
  * (the slope of the rate along the flow, UpperBound.jl:102,210) and -- for a potential -- on the nested forward-mode
  * numbers that yield grad-U (one partial per pass; pdmpflux.jl_amd/csrc/user_ad.hpp states every rule).  cfg->target_id
  * and target_params are ignored.  A source that does not compile returns PDMP_ERR_ARGUMENT with the compiler's log in
- * pdmp_last_error().  grid_size must be 10 (or 0, the Brent bound). */
+ * pdmp_last_error().  grid_size: 2..64, or 0 (the Brent bound). */
 enum { PDMP_SRC_POTENTIAL = 0, PDMP_SRC_GRADIENT = 1 };
 int pdmp_create_from_source(const pdmp_config_t *cfg, const char *source, int32_t kind, pdmp_handle *out);
 int pdmp_get_config(pdmp_handle h, pdmp_config_t *out);

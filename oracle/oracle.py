@@ -39,6 +39,7 @@ class _Cfg(C.Structure):
         ("julia_rng", C.c_int32), ("pad0_", C.c_int32),
         ("jl_tape_exp", C.POINTER(C.c_double)), ("jl_tape_uni", C.POINTER(C.c_double)), ("jl_tape_nrm", C.POINTER(C.c_double)),
         ("jl_cap_exp", C.c_int64), ("jl_cap_uni", C.c_int64), ("jl_cap_nrm", C.c_int64), ("jl_count", C.POINTER(C.c_int64)),
+        ("rng_version", C.c_int32), ("pad1_", C.c_int32),
     ]
 
 
@@ -73,6 +74,9 @@ def lib():
         L.orc_sample_skeleton_until.argtypes = [C.POINTER(_Cfg), C.c_int64, C.c_int64, C.c_int64, dp, dp, C.c_uint64, C.c_double,
                                                 dp, dp, dp, dp, dp, ip, dp, ip, ip, C.c_void_p, C.c_int]
         L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
+        L.orc_philox4x32_r.argtypes = [C.c_int] + [C.POINTER(C.c_uint32)] * 3
+        L.orc_set_arith_version.argtypes = [C.c_int]
+        L.orc_exp.argtypes = [C.c_double]; L.orc_exp.restype = C.c_double
         L.orc_log.argtypes = [C.c_double]; L.orc_log.restype = C.c_double
         L.orc_sincos.argtypes = [C.c_double, dp, dp]
         L.orc_sincos_2pi.argtypes = [C.c_double, dp, dp]
@@ -132,6 +136,7 @@ class Config:
     no_identities: bool = False        # GROUP order without the engine order's three algebraic identities (checker-side comparisons only)
     is_active_out: int | None = None   # StickyZigZag: address of a (C, n_sk, d) uint8 array receiving PDMPHistory.is_active
     julia_rng: int = 0                 # 0 Philox / tapes; JL_SEED_LIMBS (1) / JL_SEED_SHA256 (2): chain c draws from Julia's MersenneTwister(seed + c)
+    rng_version: int = 0               # arithmetic contract of the stream and of log / exp / sin / cos: 0 = the default (DEFAULT_RNG_VERSION = 2), 1 = the round 1-4 contract
     _keep: list = field(default_factory=list, repr=False)
 
     def c(self) -> _Cfg:
@@ -152,7 +157,7 @@ class Config:
                     float(self.tmax), float(self.refresh_rate), p, n, self.max_iter_per_event, self.group_lanes,
                     te, tu, tn, ne, nu, nn, float(self.mix_p), int(self.ran_p), int(self.switch), int(self.positive), int(self.no_identities),
                     float(self.step_size), float(self.phi), float(self.speed_factor), self.is_active_out,
-                    int(self.julia_rng), 0, None, None, None, 0, 0, 0, None)
+                    int(self.julia_rng), 0, None, None, None, 0, 0, 0, None, int(self.rng_version), 0)
 
 
 def _check(rc):
@@ -301,29 +306,46 @@ def sample_skeleton_until(cfg: Config, T: float, xinit, vinit, seed: int, chain_
     return out
 
 
-def philox(ctr, key):
+DEFAULT_RNG_VERSION = 2
+
+
+def _ver(v: int):
+    """The cfg-less helpers below run in the arithmetic contract `v` (0 = the default); thread-local in the C library."""
+    lib().orc_set_arith_version(int(v) if v else DEFAULT_RNG_VERSION)
+
+
+def philox(ctr, key, rounds: int = 10):
     a = (C.c_uint32 * 4)(*ctr); k = (C.c_uint32 * 2)(*key); o = (C.c_uint32 * 4)()
-    lib().orc_philox4x32_10(a, k, o)
+    lib().orc_philox4x32_r(int(rounds), a, k, o)
     return list(o)
 
 
-def log(x: float) -> float:
+def log(x: float, rng_version: int = 0) -> float:
+    _ver(rng_version)
     return lib().orc_log(x)
 
 
-def sincos(x: float):
+def exp(x: float, rng_version: int = 0) -> float:
+    _ver(rng_version)
+    return lib().orc_exp(x)
+
+
+def sincos(x: float, rng_version: int = 0):
+    _ver(rng_version)
     s, c = C.c_double(), C.c_double()
     lib().orc_sincos(x, C.byref(s), C.byref(c))
     return s.value, c.value
 
 
-def sincos_2pi(u: float):
+def sincos_2pi(u: float, rng_version: int = 0):
+    _ver(rng_version)
     s, c = C.c_double(), C.c_double()
     lib().orc_sincos_2pi(u, C.byref(s), C.byref(c))
     return s.value, c.value
 
 
-def rng_dump(seed: int, chain: int, kind: int, n: int) -> np.ndarray:
+def rng_dump(seed: int, chain: int, kind: int, n: int, rng_version: int = 0) -> np.ndarray:
+    _ver(rng_version)
     out = np.empty(n)
     lib().orc_rng_dump(C.c_uint64(seed), chain, kind, n, _dp(out))
     return out
@@ -333,10 +355,11 @@ V_RADEMACHER, V_GAUSSIAN, V_SPHERE = 0, 1, 2
 
 
 def init_states(seed: int, C_: int, d: int, *, chain_id_offset: int = 0, x_mean: float = 0.0, x_scale: float = 1.0,
-                v_kind: int = V_RADEMACHER):
+                v_kind: int = V_RADEMACHER, rng_version: int = 0):
     """Synthetic initial states of chains ``chain_id_offset .. +C`` from stream 1 of each chain's Philox key (BASELINE.md section 3);
     the checker's side of pdmp_init_states_device.  Returns ``(x, v)``, each ``(C, d)``."""
     x, v = np.empty((C_, d)), np.empty((C_, d))
+    _ver(rng_version)
     lib().orc_init_states(C.c_uint64(seed), int(chain_id_offset), int(C_), int(d), float(x_mean), float(x_scale), int(v_kind), _dp(x), _dp(v))
     return x, v
 

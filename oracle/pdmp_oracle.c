@@ -42,9 +42,20 @@ int orc_num_threads(void) {
  *   u = ((bits >> 12) + 0.5) * 2^-52  in (0,1);  Exp(1) = -log(u) with the log below.
  *   Normal pairs (Box-Muller) consume one whole block: (z0,z1) = sqrt(-2 log u0) (cos,sin)(2 pi u1).
  * ------------------------------------------------------------------------------------------ */
-void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+/* Arithmetic contract version of the calling thread (orc_config_t.rng_version; set per chain by the entry points below):
+ *   1  Philox4x32-10, fdlibm-style log / exp / sin / cos written with + - * / only (rounds 1-4: every frozen fixture of that time);
+ *   2  (default since round 5) Philox4x32-7 -- the smallest round count Salmon et al. report as passing BigCrush --, the same
+ *      polynomials evaluated by Horner's rule on fma() (exact IEEE fusedMultiplyAdd on both sides: C fma() == v_fma_f64), argument
+ *      reduction by frexp / rint, and a Box-Muller pair whose angle is drawn as (octant angle, swap bit, sign bit) instead of
+ *      2 pi u with a quadrant reduction.  Same stream layout: variate n = block n>>1, half n&1; uniforms are the same function of
+ *      a block's words.  DESIGN.md "Arithmetic contract v2". */
+static __thread int g_ver = 2;
+void orc_set_arith_version(int v) { g_ver = (v == 1) ? 1 : 2; }
+int orc_get_arith_version(void) { return g_ver; }
+
+void orc_philox4x32_r(int rounds, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
     uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < rounds; ++r) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
         uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
@@ -53,6 +64,7 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { orc_philox4x32_r(10, ctr, key, out); }
 
 /* Tape source: when te/tu/tn are set the chain replays pre-recorded Exp(1), U(0,1) and N(0,1)
  * variates (one tape per kind, each in consumption order -- enough to replay a run of ANY generator, e.g. a dump of
@@ -75,7 +87,7 @@ static inline double bits_to_u(uint64_t bits) {
 static void rng_block(const rng_t *r, uint64_t blk, uint32_t w[4]) {
     uint32_t ctr[4] = { (uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)r->chain, (uint32_t)(r->chain >> 32) };
     uint32_t key[2] = { (uint32_t)r->seed, (uint32_t)(r->seed >> 32) };
-    orc_philox4x32_10(ctr, key, w);
+    orc_philox4x32_r(g_ver == 1 ? 10 : 7, ctr, key, w);
 }
 static double rng_uniform(rng_t *r) {
     if (r->jl) return jl_log_put(jl_rand(r->jl), r->lu, r->cu, &r->ju, r->overrun);
@@ -89,7 +101,7 @@ static double rng_uniform(rng_t *r) {
 
 /* log(x) for normal x > 0: the fdlibm e_log.c algorithm (Sun Microsystems, freely distributable),
  * written with +,-,*,/ only so that CPU and GPU agree bit for bit. */
-double orc_log(double x) {
+static double log_v1(double x) {
     static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
         Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
         Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
@@ -124,7 +136,7 @@ double orc_log(double x) {
 
 /* exp(x): the fdlibm e_exp.c algorithm (Sun Microsystems, freely distributable) with +,-,*,/ and integer operations on the
  * exponent field only, so that CPU and GPU agree bit for bit.  Overflow -> +Inf, underflow below -745.13 -> 0. */
-double orc_exp(double x) {
+static double exp_v1(double x) {
     static const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
         invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
         P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
@@ -192,19 +204,129 @@ static inline void quadrant(int q, double sa, double ca, double *s, double *c) {
     }
 }
 /* sin/cos(2 pi u), u in (0,1): exact quadrant reduction on u, then the kernels. */
-void orc_sincos_2pi(double u, double *s, double *c) {
+static void sincos_2pi_v1(double u, double *s, double *c) {
     int q = (int)(4.0 * u + 0.5);
     double f = u - 0.25 * (double)q;               /* exact, |f| <= 1/8 */
     double a = f * 6.283185307179586476925;
     quadrant(q, ksin(a), kcos(a), s, c);
 }
 /* sin/cos(x) for 0 <= |x| < ~1e5: two-term Cody-Waite reduction by pi/2 (fdlibm constants). */
-void orc_sincos(double x, double *s, double *c) {
+static void sincos_v1(double x, double *s, double *c) {
     static const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
         pio2_1t = 6.07710050650619224932e-11;
     double fn = floor(x * invpio2 + 0.5);
     double a = (x - fn * pio2_1) - fn * pio2_1t;
     quadrant((int)((int64_t)fn & 3), ksin(a), kcos(a), s, c);
+}
+
+
+/* ---- arithmetic contract v2: the same series, Horner on fma(); mirrored statement by statement in csrc/wave_math.hpp ---- */
+/* log(x), x normal and positive.  x = 2^e m, m in [sqrt(1/2), sqrt(2)); f = m - 1; s = f / (2 + f);
+ * log(1 + f) = f - (f^2/2 - s (f^2/2 + R(s^2)))  (the fdlibm series, its coefficients); + e ln2 in two pieces. */
+static double log_v2(double x) {
+    static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+        Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+        Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+        Lg7 = 1.479819860511658591e-01;
+    int e;
+    double m = frexp(x, &e);                                  /* [0.5, 1) */
+    const int c = m < 0.70710678118654752440;
+    m = c ? m + m : m;                                        /* [sqrt(1/2), sqrt(2)) */
+    e -= c;
+    const double f = m - 1.0, dk = (double)e;
+    const double s = f / (2.0 + f), z = s * s;
+    const double P = fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, Lg7, Lg6), Lg5), Lg4), Lg3), Lg2), Lg1);
+    const double R = z * P;
+    const double hfsq = (0.5 * f) * f;
+    const double t = fma(s, hfsq + R, dk * ln2_lo);
+    return fma(dk, ln2_hi, f - (hfsq - t));
+}
+/* exp(x): k = rint(x / ln2), r = (x - k ln2_hi) - k ln2_lo, exp(r) = 1 + (r c / (2 - c) ... ) with c = r - r^2 P(r^2) (fdlibm's series), 2^k by ldexp */
+static double exp_v2(double x) {
+    static const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+        invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+        P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (x != x) return x;
+    if (x > 7.09782712893383973096e+02) return INFINITY;
+    if (x < -7.45133219101941108420e+02) return 0.0;
+    const double kf = rint(x * invln2);
+    const double hi = fma(-kf, ln2HI, x), lo = kf * ln2LO;
+    const double r = hi - lo, t = r * r;
+    const double P = fma(t, fma(t, fma(t, fma(t, P5, P4), P3), P2), P1);
+    const double c = fma(-t, P, r);
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    return ldexp(y, (int)kf);
+}
+static inline double ksin_v2(double a) {
+    static const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+        S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+        S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double z = a * a;
+    const double P = fma(z, fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2), S1);
+    return fma(z * a, P, a);
+}
+static inline double kcos_v2(double a) {
+    static const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+        C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+        C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double z = a * a;
+    const double P = fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
+    return fma(z * z, P, fma(z, -0.5, 1.0));
+}
+/* sin / cos of x: n = rint(x 2/pi), a = (x - n pio2_1) - n pio2_1t by two fma, kernels on |a| <= pi/4, quadrant n mod 4 as one swap and two signs */
+static void sincos_v2(double x, double *s, double *c) {
+    static const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
+        pio2_1t = 6.07710050650619224932e-11;
+    const double fn = rint(x * invpio2);
+    const double a = fma(-fn, pio2_1t, fma(-fn, pio2_1, x));
+    const int q = (int)fn;
+    const double sa = ksin_v2(a), ca = kcos_v2(a);
+    double ss = (q & 1) ? ca : sa, cc = (q & 1) ? sa : ca;
+    if (q & 2) ss = -ss;
+    if ((q + 1) & 2) cc = -cc;
+    *s = ss; *c = cc;
+}
+/* sin / cos (2 pi u), u in (0, 1): n = rint(4 u), a = 2 pi (u - n/4) (exact difference), as above */
+static void sincos_2pi_v2(double u, double *s, double *c) {
+    const double fn = rint(4.0 * u);
+    const double a = fma(-0.25, fn, u) * 6.283185307179586476925;
+    const int q = (int)fn;
+    const double sa = ksin_v2(a), ca = kcos_v2(a);
+    double ss = (q & 1) ? ca : sa, cc = (q & 1) ? sa : ca;
+    if (q & 2) ss = -ss;
+    if ((q + 1) & 2) cc = -cc;
+    *s = ss; *c = cc;
+}
+double orc_log(double x) { return g_ver == 1 ? log_v1(x) : log_v2(x); }
+double orc_exp(double x) { return g_ver == 1 ? exp_v1(x) : exp_v2(x); }
+void orc_sincos(double x, double *s, double *c) { if (g_ver == 1) sincos_v1(x, s, c); else sincos_v2(x, s, c); }
+void orc_sincos_2pi(double u, double *s, double *c) { if (g_ver == 1) sincos_2pi_v1(u, s, c); else sincos_2pi_v2(u, s, c); }
+
+/* One Box-Muller pair from the four words of a block.  v1: (z0, z1) = sqrt(-2 log u0) (cos, sin)(2 pi u1).
+ * v2: the radius as before; the angle is uniform on the circle as  a in [-pi/4, pi/4)  (52 bits of the second half as the mantissa
+ * of m in [1, 2): a = m pi/2 - 3 pi/4),  one SWAP bit (sin <-> cos: the angle pi/2 - a covers (pi/4, 3 pi/4]) and one SIGN bit
+ * (the angle + pi), bits 0 and 1 of the same 64-bit half -- no quadrant reduction, the same distribution. */
+static inline double mant_12(uint64_t bits) {                  /* the top 52 bits as the mantissa of a double in [1, 2) */
+    const uint64_t i = 0x3FF0000000000000ull | (bits >> 12);
+    double m; memcpy(&m, &i, 8);
+    return m;
+}
+static void box_muller(const uint32_t w[4], double *z0, double *z1) {
+    const uint64_t b0 = (uint64_t)w[0] | ((uint64_t)w[1] << 32), b1 = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+    if (g_ver == 1) {
+        const double u0 = bits_to_u(b0), u1 = bits_to_u(b1);
+        double rad = sqrt(-2.0 * log_v1(u0)), sn, cs;
+        sincos_2pi_v1(u1, &sn, &cs);
+        *z0 = rad * cs; *z1 = rad * sn;
+        return;
+    }
+    const double u0 = mant_12(b0) - 0x1.fffffffffffffp-1;      /* (k + 0.5) 2^-52, exactly bits_to_u(b0) */
+    double rad = sqrt(-2.0 * log_v2(u0));
+    const double a = fma(mant_12(b1), 1.57079632679489661923, -2.35619449019234492885);
+    double sa = ksin_v2(a), ca = kcos_v2(a);
+    if (b1 & 1ull) { const double tmp = sa; sa = ca; ca = tmp; }
+    if (b1 & 2ull) rad = -rad;
+    *z0 = rad * ca; *z1 = rad * sa;
 }
 
 static double rng_exp(rng_t *r) {
@@ -228,12 +350,10 @@ static void rng_normals(rng_t *r, int d, double *z) {
     for (int p = 0; 2 * p < d; ++p) {
         uint32_t w[4];
         rng_block(r, blk0 + (uint64_t)p, w);
-        double u0 = bits_to_u((uint64_t)w[0] | ((uint64_t)w[1] << 32));
-        double u1 = bits_to_u((uint64_t)w[2] | ((uint64_t)w[3] << 32));
-        double rad = sqrt(-2.0 * orc_log(u0)), sn, cs;
-        orc_sincos_2pi(u1, &sn, &cs);
-        z[2 * p] = rad * cs;
-        if (2 * p + 1 < d) z[2 * p + 1] = rad * sn;
+        double za, zb;
+        box_muller(w, &za, &zb);
+        z[2 * p] = za;
+        if (2 * p + 1 < d) z[2 * p + 1] = zb;
     }
     r->n += 2 * (uint64_t)((d + 1) / 2);
 }
@@ -881,6 +1001,7 @@ void orc_next_event(int n, const double *grid, const double *box, const double *
 
 double orc_upper_bound(const orc_config_t *cfg, const double *x, const double *v, double horizon,
                        double *grid, double *box_max, double *cum_sum) {
+    g_ver = (cfg->rng_version == 1) ? 1 : 2;
     ws_t w; ws_init(&w, cfg->dim, cfg->grid_size == 0 ? 2 : cfg->grid_size);
     memcpy(w.x, x, (size_t)cfg->dim * 8); memcpy(w.v, v, (size_t)cfg->dim * 8);
     upper_bound(cfg, &w, x, v, horizon);
@@ -1136,6 +1257,7 @@ static int run_chain(const orc_config_t *cfg, ws_t *w, int64_t n_sk, uint64_t se
     const int d = w->d, n = w->n;
     const int64_t cap = cfg->max_iter_per_event > 0 ? cfg->max_iter_per_event : 1000000;
     int overrun = 0;
+    g_ver = (cfg->rng_version == 1) ? 1 : 2;        /* (thread-local: this chain's arithmetic contract) */
     rng_t rng = { .seed = seed, .chain = chain, .overrun = &overrun };
     jl_mt_t jl_state;
 #define JL_COUNTS() do { if (cfg->julia_rng && cfg->jl_count) { int64_t *q_ = cfg->jl_count + 3 * (int64_t)chain; q_[0] = rng.je; q_[1] = rng.ju; q_[2] = rng.jn; } } while (0)
@@ -1477,6 +1599,7 @@ int orc_sample_from_skeleton_ex(const orc_config_t *cfg, int method, int64_t C, 
 #endif
 #pragma omp parallel for num_threads(n_threads) schedule(static)
     for (int64_t c = 0; c < C; ++c) {
+        g_ver = (cfg->rng_version == 1) ? 1 : 2;
         const double *Xc = X + (size_t)c * n_sk * d, *Vc = V + (size_t)c * n_sk * d, *tc = t + (size_t)c * n_sk;
         const uint8_t *Ac = is_active ? is_active + (size_t)c * n_sk * d : NULL;
         double *oc = out + (size_t)c * N * rows;

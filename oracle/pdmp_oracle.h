@@ -84,6 +84,11 @@ typedef struct orc_config_t {
     double *jl_tape_exp, *jl_tape_uni, *jl_tape_nrm;
     int64_t jl_cap_exp, jl_cap_uni, jl_cap_nrm;
     int64_t *jl_count;
+    /* Arithmetic contract of the random stream and the elementary functions: 0 / 2 = v2 (default since round 5: Philox4x32-7,
+     * fma-Horner log / exp / sin / cos, octant Box-Muller), 1 = v1 (Philox4x32-10, fdlibm forms without fma: rounds 1-4 and their
+     * frozen fixtures).  pdmp_oracle.c "Arithmetic contract version"; mirrors pdmp_config_t.rng_version. */
+    int32_t rng_version;
+    int32_t pad1_;
 } orc_config_t;
 
 const char *orc_last_error(void);
@@ -129,6 +134,10 @@ int orc_sample_skeleton_until(const orc_config_t *cfg, int64_t C, int64_t capaci
 
 /* --- pieces exposed for known-answer tests --- */
 void   orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void   orc_philox4x32_r(int rounds, const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+/* the arithmetic contract (1 / 2) the cfg-less functions below use on the calling thread: orc_log .. orc_init_states */
+void   orc_set_arith_version(int v);
+int    orc_get_arith_version(void);
 double orc_log(double x);
 double orc_exp(double x);
 void   orc_sincos(double x, double *s, double *c);

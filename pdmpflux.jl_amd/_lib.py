@@ -41,7 +41,7 @@ class Config(C.Structure):
         ("max_iter_per_event", C.c_int64),
         ("fe_mix_p", C.c_double), ("fe_ran_p", C.c_int32), ("fe_switch", C.c_int32), ("fe_positive", C.c_int32),
         ("fe_reserved", C.c_int32), ("rh_step_size", C.c_double), ("rh_phi", C.c_double),
-        ("fe_speed_factor", C.c_double),
+        ("fe_speed_factor", C.c_double), ("rng_version", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -141,7 +141,7 @@ def lib():
     L.pdmp_dense_batched_last_phases.restype = C.c_longlong
     L.pdmp_dense_batched_last_columns.restype = C.c_longlong
     L.pdmp_dense_batched_last_mode.restype = C.c_int
-    if L.pdmp_abi_version() != 10:
+    if L.pdmp_abi_version() != 11:
         raise EngineError(ERR_RUNTIME, "ABI version mismatch")
     _lib = L
     return L

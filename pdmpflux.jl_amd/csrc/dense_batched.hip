@@ -25,7 +25,7 @@ extern "C" int pdmp_dgemm_mfma_polite(int max_wg, int M, int N, int K, const dou
 #include <cstdlib>
 #include <mutex>
 
-namespace pdmp {
+PDMP_NS_BEGIN
 
 enum : int { DB_LEFT = 0, DB_CELL = 1, DB_RATE = 2 };
 enum : int { DB_FRESH = 0, DB_ERR = 1, DB_REUSE = 2 };
@@ -1000,7 +1000,7 @@ __global__ __launch_bounds__(256, (KC >= 16 ? 1 : 2)) void dr_boom_kernel(const 
     for (int64_t c = p.c_lo + (int64_t)blockIdx.x * 4 + wv; c < p.c_hi; c += (int64_t)gridDim.x * 4) dr_boom_chain<KC>(p, c, x_lds[wv], lane);
 }
 
-}  // namespace pdmp
+PDMP_NS_END
 
 using namespace pdmp;
 

@@ -11,7 +11,7 @@
 #include <vector>
 
 using namespace pdmp;
-namespace pdmp {
+PDMP_NS_BEGIN
 hipError_t launch_lane_zigzag(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);   // lane_kernel.hpp: d = 49 .. 52
 hipError_t launch_lane_zigzag_a(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream); // d = 25 .. 36
 hipError_t launch_lane_zigzag_b(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream); // d = 37 .. 48
@@ -40,6 +40,14 @@ hipError_t launch_lane_zigzag_tape(int target, const GroupParams &gp, const int3
 hipError_t launch_group_reg_tape_zigzag(int target, bool fd, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_tape_bps(int target, bool fd, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_tape_boomerang(int target, bool fd, const GroupParams &gp, hipStream_t stream);
+PDMP_NS_END
+// The arithmetic contract v1 (pdmp_config_t.rng_version = 1: Philox4x32-10, the fdlibm forms without fma -- rounds 1-4 and the fixtures
+// frozen then): the LDS-form group kernels and the wave-per-chain kernel compiled a second time with -DPDMP_RNG_VERSION=1 (csrc/Makefile,
+// v1/*.o; inline namespace pdmp::av1), reached through these two entry points of v1_bridge.hip.  GroupParams / SkelParams are the same
+// plain structs in both namespaces.
+namespace pdmp {
+hipError_t v1_launch_group(int sampler, int target, const void *group_params, hipStream_t stream);
+hipError_t v1_launch_skeleton(int sampler, int target, const void *skel_params, hipStream_t stream);
 }
 
 namespace {
@@ -84,7 +92,7 @@ extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_b
                                   int32_t *status, void *stream, void **ws, size_t *ws_cap, int64_t resync_events, int gemm_impl, int lanes,
                                   double t_stop, int resume, int64_t n_launch, const int64_t *chain_map, int64_t *count, char *err, int errlen);   // dense_batched.hip: BPS, one GEMM per event
 
-extern "C" int pdmp_user_compile(int device, int sampler, int fd, int kind, const char *source, void **fn_out, char *err, int errlen);
+extern "C" int pdmp_user_compile(int device, int sampler, int fd, int kind, int rng_version, const char *source, void **fn_out, char *err, int errlen);
 extern "C" int pdmp_user_launch(void *fn, const GroupParams *gp, void *stream);
 
 // Launch policy of a handle: which kernel form serves a launch, and the tuning numbers of the forms.  Filled ONCE, when the handle is
@@ -182,7 +190,7 @@ namespace {
 // ---- flows of the samplers whose flow is not x + v t / a rotation, in the wave layout (lane owns coordinates lane, lane + 64, ...);
 // shared by sample_from_skeleton, the fused moments and the time-horizon cut.
 // SpeedUpZigZag (SpeedUpZigZagSamplers.jl:71-79): x_t = (x - av v) + kv v; dot products in the wave order of the checker.
-__device__ __forceinline__ void suzz_scalars(int d, int lane, const double *x0, const double *v0, double ta, double &av, double &kv) {
+__device__ __forceinline__ void suzz_scalars(int d, int lane, const double *x0, const double *v0, double ta, double &av, double &kv, int rv) {   // rv: arithmetic contract of exp
     const double x1 = x0[0], v1 = v0[0], dd = (double)d;
     av = v1 * x1;
     double yv = 0.0, yy = 0.0;
@@ -190,7 +198,8 @@ __device__ __forceinline__ void suzz_scalars(int d, int lane, const double *x0, 
     yv = wave_sum(yv);
     yy = wave_sum(yy);
     const double c = v1 * yv, a = (1.0 + yy) / dd - (c * c) / (dd * dd), Y0 = x1 + c / dd;
-    const double bt = (Y0 + __dsqrt_rn(Y0 * Y0 + a)) * det_exp(__dsqrt_rn(dd) * v1 * ta);
+    const double ea = __dsqrt_rn(dd) * v1 * ta;
+    const double bt = (Y0 + __dsqrt_rn(Y0 * Y0 + a)) * (rv == 1 ? det_exp_v1(ea) : det_exp_v2(ea));
     const double X1 = (bt * bt - a) / (2.0 * bt) - c / dd;
     kv = v1 * X1;
 }
@@ -242,13 +251,13 @@ __device__ __forceinline__ void rhmc_integrate(int d, int lane, const double *x0
 // instead of the pointer walk's last i with t[i] <= tm (:493-495).  n_use <= n_sk: only the first n_use columns of every chain
 // are history (the (N, dt) method's views 1:N, :650-653; ragged histories of the time-horizon variant pass count[c] via `lens`).
 // counts != nullptr (dt methods on ensembles): samples of chain c = floor(t_end / dt), at most N; the others are left untouched.
-template <bool BOOMERANG>
+template <int BOOMERANG>   // 0: linear flow; 1 / 2: the Boomerang's rotation in arithmetic contract v2 / v1 (pdmp_config_t.rng_version)
 __global__ __launch_bounds__(256) void from_skeleton_kernel(int d, int64_t C, int64_t n_sk, const double *X,
                                                             const double *V, const double *t, int64_t N,
                                                             double dt_in, int discard_vt, double *out, int suzz = 0,
                                                             int rhmc_target = -1, double rhmc_h = 0.0, const double *tparams = nullptr,
                                                             const uint8_t *IA = nullptr, int ia_mode = 0, int strict = 0,
-                                                            int64_t n_use = 0, const int64_t *lens = nullptr, int64_t *counts = nullptr) {
+                                                            int64_t n_use = 0, const int64_t *lens = nullptr, int64_t *counts = nullptr, int arv = 2) {
     const int lane = lane_id();
     const int64_t tiles = (N + WAVE - 1) / WAVE;
     const int64_t w = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(256) void from_skeleton_kernel(int d, int64_t C, in
         const uint8_t *a0 = (IA && ia_mode) ? IA + ((size_t)c * n_sk + (size_t)i) * d : nullptr;
         double *o = out + ((size_t)c * N + (size_t)(tile * WAVE + s)) * rows;
         double sn = 0.0, cs = 1.0;
-        if (BOOMERANG) det_sincos(ta, sn, cs);
+        if (BOOMERANG) { if (BOOMERANG == 2) det_sincos_v1(ta, sn, cs); else det_sincos_v2(ta, sn, cs); }
         if (rhmc_target >= 0) {                                       // RHMC: velocity-Verlet from the event's (x, v)
             double xq[4], vq[4];
             rhmc_integrate(d, lane, x0, v0, ta, rhmc_h, rhmc_target, tparams, xq, vq);
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(256) void from_skeleton_kernel(int d, int64_t C, in
             for (int k = 0; k < 4; ++k) { const int q = lane + k * WAVE; if (q < d) { o[q] = xq[k]; if (!discard_vt) o[d + q] = vq[k]; } }
         } else if (suzz) {                                            // SpeedUpZigZagSamplers.jl:71-79: x_t = y + (v1 X1(t)) v
             double av, kv;
-            suzz_scalars(d, lane, x0, v0, ta, av, kv);
+            suzz_scalars(d, lane, x0, v0, ta, av, kv, arv);
             for (int q = lane; q < d; q += WAVE) {
                 const double vq = v0[q], y = x0[q] - av * vq;
                 o[q] = y + kv * vq;
@@ -324,7 +333,7 @@ __global__ __launch_bounds__(256) void from_skeleton_kernel(int d, int64_t C, in
 // contiguous bytes and every lane works (a d = 50 row fills 50 of 64 lanes in the row-per-iteration form); the per-sample segment
 // index, residual time and sin / cos sit in LDS.  Four elements per lane in flight.  HBM-bound: 8(2d+1) B read per touched event +
 // 8 rows B written per sample.
-template <bool BOOMERANG>
+template <int BOOMERANG>   // 0: linear flow; 1 / 2: the Boomerang's rotation in arithmetic contract v2 / v1 (pdmp_config_t.rng_version)
 __global__ __launch_bounds__(256) void from_skeleton_flat_kernel(int d, int64_t C, int64_t n_sk, const double *X, const double *V,
                                                                  const double *t, int64_t N, double dt_in, int discard_vt, double *out,
                                                                  const uint8_t *IA, int ia_mode, int strict, int64_t n_use,
@@ -358,7 +367,7 @@ __global__ __launch_bounds__(256) void from_skeleton_flat_kernel(int d, int64_t 
     }
     const double tau = tm - tc[lo];                                   // :497
     double sn = 0.0, cs = 1.0;
-    if (BOOMERANG) det_sincos(tau, sn, cs);
+    if (BOOMERANG) { if (BOOMERANG == 2) det_sincos_v1(tau, sn, cs); else det_sincos_v2(tau, sn, cs); }
     seg_s[wv][lane] = lo; tau_s[wv][lane] = tau; tm_s[wv][lane] = tm; sn_s[wv][lane] = sn; cs_s[wv][lane] = cs;
     __builtin_amdgcn_wave_barrier();                                  // (LDS traffic of one wave is ordered; the barrier only stops reordering by the compiler)
     int64_t nvalid = (nmax - tile * WAVE) < WAVE ? (nmax - tile * WAVE) : WAVE;
@@ -412,10 +421,10 @@ __global__ __launch_bounds__(256) void from_skeleton_flat_kernel(int d, int64_t 
 // last of them lies strictly before T, one closing column at exactly t = T obtained by flow from it (:385-420), which
 // overwrites the overshooting event in place; count[c] = -(events) - 1 when the chain has not passed T yet (capacity too
 // small: the caller reruns with a larger n_sk, as _grow_history does, Composites.jl:172-191).  One wave per chain.
-template <bool BOOMERANG>
+template <int BOOMERANG>   // 0: linear flow; 1 / 2: the Boomerang's rotation in arithmetic contract v2 / v1 (pdmp_config_t.rng_version)
 __global__ __launch_bounds__(256) void close_at_kernel(int d, int64_t C, int64_t n_sk_cap, double *X, double *V, double *t, double T,
                                                        int64_t *count, int mode = 0, int target = 0, double rhmc_h = 0.0,
-                                                       const double *tparams = nullptr, pdmp_diag_t dg = {}, const int64_t *valid = nullptr) {
+                                                       const double *tparams = nullptr, pdmp_diag_t dg = {}, const int64_t *valid = nullptr, int arv = 2) {
     const int lane = lane_id();
     const int64_t c = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (c >= C) return;
@@ -440,7 +449,7 @@ __global__ __launch_bounds__(256) void close_at_kernel(int d, int64_t C, int64_t
     const uint8_t *a0 = (mode == 3 && dg.is_active) ? dg.is_active + ((size_t)c * n_sk_cap + (size_t)lo) * d : nullptr;
     uint8_t *a1 = a0 ? dg.is_active + ((size_t)c * n_sk_cap + (size_t)k) * d : nullptr;
     double sn = 0.0, cs = 1.0;
-    if (BOOMERANG) det_sincos(tau, sn, cs);
+    if (BOOMERANG) { if (BOOMERANG == 2) det_sincos_v1(tau, sn, cs); else det_sincos_v2(tau, sn, cs); }
     if (mode == 2) {                                                                      // RHMC: velocity-Verlet to T
         double rx[4], rv[4];
         rhmc_integrate(d, lane, x0, v0, tau, rhmc_h, target, tparams, rx, rv);
@@ -448,7 +457,7 @@ __global__ __launch_bounds__(256) void close_at_kernel(int d, int64_t C, int64_t
         for (int k2 = 0; k2 < 4; ++k2) { const int q = lane + k2 * WAVE; if (q < d) { x1[q] = rx[k2]; v1[q] = rv[k2]; } }
     } else if (mode == 1) {                                                               // SpeedUpZigZag
         double av, kv;
-        suzz_scalars(d, lane, x0, v0, tau, av, kv);
+        suzz_scalars(d, lane, x0, v0, tau, av, kv, arv);
         for (int q = lane; q < d; q += WAVE) { const double vq = v0[q]; x1[q] = (x0[q] - av * vq) + kv * vq; v1[q] = vq; }
     } else
     for (int q = lane; q < d; q += WAVE) {
@@ -608,11 +617,11 @@ __global__ __launch_bounds__(256) void compact_chunk_kernel(int d, int64_t C, in
 // equispaced samples of sample.jl:475-513, without materialising the d x N x C sample array.  One wave per chain,
 // samples in order, each lane accumulates its coordinates left to right: deterministic (no atomics), equal to
 // a sequential sum over the samples of sample_from_skeleton.
-template <bool BOOMERANG>
+template <int BOOMERANG>   // 0: linear flow; 1 / 2: the Boomerang's rotation in arithmetic contract v2 / v1 (pdmp_config_t.rng_version)
 __global__ __launch_bounds__(256) void moments_kernel(int d, int64_t C, int64_t n_sk, const double *X, const double *V,
                                                       const double *t, int64_t N, double *sum_x, double *sum_x2,
                                                       int mode = 0, int target = 0, double rhmc_h = 0.0, const double *tparams = nullptr,
-                                                      const uint8_t *IA = nullptr, const int64_t *lens = nullptr) {
+                                                      const uint8_t *IA = nullptr, const int64_t *lens = nullptr, int arv = 2) {
     const int lane = lane_id();
     const int64_t c = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (c >= C) return;
@@ -645,9 +654,9 @@ __global__ __launch_bounds__(256) void moments_kernel(int d, int64_t C, int64_t 
                 const double *x0 = X + ((size_t)c * n_sk + (size_t)i) * d, *v0 = V + ((size_t)c * n_sk + (size_t)i) * d;
                 const uint8_t *a0 = (IA && mode == 3) ? IA + ((size_t)c * n_sk + (size_t)i) * d : nullptr;   // StickyPDMP, sample.jl:547-549
                 double sn = 0.0, cs = 1.0;
-                if (BOOMERANG) det_sincos(ta, sn, cs);
+                if (BOOMERANG) { if (BOOMERANG == 2) det_sincos_v1(ta, sn, cs); else det_sincos_v2(ta, sn, cs); }
                 double av = 0.0, kv = 0.0, rx[4] = {0, 0, 0, 0}, rv[4];
-                if (mode == 1) suzz_scalars(d, lane, x0, v0, ta, av, kv);                          // SpeedUpZigZag: the sampler's own flow
+                if (mode == 1) suzz_scalars(d, lane, x0, v0, ta, av, kv, arv);                          // SpeedUpZigZag: the sampler's own flow
                 else if (mode == 2) rhmc_integrate(d, lane, x0, v0, ta, rhmc_h, target, tparams, rx, rv);   // RHMC (d <= 256: q0 == 0)
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
@@ -670,8 +679,9 @@ __global__ __launch_bounds__(256) void moments_kernel(int d, int64_t C, int64_t 
     }
 }
 
+template <int RV>
 __global__ void debug_rng_kernel(uint64_t seed, int64_t chain, int kind, int64_t n, double *out) {
-    ChainRng rng;
+    ChainRngT<RV> rng;
     rng.init(seed, (uint64_t)chain);
     const int lane = lane_id();
     if (kind == 2) {
@@ -686,11 +696,12 @@ __global__ void debug_rng_kernel(uint64_t seed, int64_t chain, int kind, int64_t
 
 // Synthetic initial states (pdmp_init_states_device): one thread per chain, everything in the chain's own sequential order so that
 // the checker's orc_init_states reproduces it bit for bit.  Stream 1 of a chain = its Philox stream with the top bit of the chain word set.
+template <int RV>
 __global__ void init_states_kernel(int64_t C, int64_t chain0, uint64_t seed, int d, double x_mean, double x_scale, int v_kind,
                                    double *__restrict__ x, double *__restrict__ v) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    ChainRng rng;
+    ChainRngT<RV> rng;
     rng.init_lane(seed, ((uint64_t)(chain0 + c)) | (1ull << 63));
     double *xc = x + c * d, *vc = v + c * d;
     for (int p = 0; 2 * p < d; ++p) {
@@ -722,9 +733,10 @@ int normalize_config(pdmp_config_t &c, bool from_source = false) {
     if (c.grid_size < 0) return fail(PDMP_ERR_ARGUMENT, "grid_size must be non-negative. Current value: %d", c.grid_size); // :66-68
     if (c.grid_size == 1 || c.grid_size > WAVE) return fail(PDMP_ERR_UNSUPPORTED, "grid_size must be in 2..64. Current value: %d", c.grid_size);
     if (c.sampler < PDMP_ZIGZAG || c.sampler > PDMP_STICKY) return fail(PDMP_ERR_ARGUMENT, "unknown sampler id %d", c.sampler);
+    if (c.rng_version == 0) c.rng_version = 2;                                                       // the default arithmetic contract (DESIGN.md "Arithmetic contract v2")
+    if (c.rng_version != 1 && c.rng_version != 2) return fail(PDMP_ERR_ARGUMENT, "rng_version must be 0 (default), 1 or 2. Current value: %d", c.rng_version);
     if (c.sampler == PDMP_STICKY) {
         if (c.target_id == PDMP_T_GAUSS_DENSE || c.target_id == PDMP_T_USER) return fail(PDMP_ERR_UNSUPPORTED, "StickyZigZag: built-in separable / banana targets only");
-        if (c.grid_size != GNG && c.grid_size != 0) return fail(PDMP_ERR_UNSUPPORTED, "StickyZigZag runs on the group kernel: grid_size = 10 (or 0, Brent)");
         const int64_t base_params = (c.target_id == PDMP_T_GAUSS_DIAG) ? 2 * (int64_t)c.dim : 0;
         if (c.n_target_params != base_params + c.dim || !c.target_params) return fail(PDMP_ERR_ARGUMENT, "StickyZigZag needs kappa[dim] as the last dim target_params");
     }
@@ -737,7 +749,6 @@ int normalize_config(pdmp_config_t &c, bool from_source = false) {
     }
     if (c.sampler == PDMP_SUZZ) {
         if (c.target_id == PDMP_T_GAUSS_DENSE || c.target_id == PDMP_T_USER) return fail(PDMP_ERR_UNSUPPORTED, "SpeedUpZigZag: built-in separable / banana targets only");
-        if (c.grid_size != GNG && c.grid_size != 0) return fail(PDMP_ERR_UNSUPPORTED, "SpeedUpZigZag runs on the group kernel: grid_size = 10 (or 0, Brent)");
     }
     if (c.sampler == PDMP_FECMC) {                                                                   // ForwardEventChainMonteCarlo.jl:298-310
         if (c.dim < 2) return fail(PDMP_ERR_ARGUMENT, "The dimension must be at least 2 to use the ForwardEventChain. Got dimension %d", c.dim);
@@ -746,20 +757,16 @@ int normalize_config(pdmp_config_t &c, bool from_source = false) {
         if (c.fe_speed_factor == 0.0) c.fe_speed_factor = 1.0;
         if (!std::isfinite(c.fe_speed_factor)) return fail(PDMP_ERR_ARGUMENT, "speed_factor must be finite");
         if (c.target_id == PDMP_T_GAUSS_DENSE) return fail(PDMP_ERR_UNSUPPORTED, "ForwardECMC: no dense-precision target");
-        if (c.grid_size != GNG && c.grid_size != 0) return fail(PDMP_ERR_UNSUPPORTED, "ForwardECMC runs on the group kernel: grid_size = 10 (or 0, Brent)");
     }
     if (c.target_id == PDMP_T_USER && !from_source) return fail(PDMP_ERR_ARGUMENT, "PDMP_T_USER handles are made by pdmp_create_from_source");
     if (c.target_id < 0 || c.target_id > PDMP_T_USER) return fail(PDMP_ERR_ARGUMENT, "unknown target id %d", c.target_id);
-    if (c.target_id == PDMP_T_USER && c.grid_size != GNG && c.grid_size != 0)
-        return fail(PDMP_ERR_UNSUPPORTED, "potentials given as source run on the group kernel: grid_size = 10 (or 0, Brent)");
     if (c.target_id == PDMP_T_GAUSS_DENSE) {
         if (c.n_target_params != (int64_t)c.dim * c.dim || !c.target_params) return fail(PDMP_ERR_ARGUMENT, "GAUSS_DENSE needs target_params = P[dim*dim] (column-major)");
-        if (c.deriv_mode != PDMP_DERIV_FORWARD || (c.grid_size != 10 && c.grid_size != 0))
-            return fail(PDMP_ERR_UNSUPPORTED, "dense-precision target: grid_size = 10 (or 0) and forward-mode slopes only");
+        if (c.deriv_mode != PDMP_DERIV_FORWARD)
+            return fail(PDMP_ERR_UNSUPPORTED, "dense-precision target: forward-mode slopes only");
         // Boomerang: the batched form (dense_batched.hip: dr_boom_kernel, one GEMM per event over all chains of a launch) up to dim = 1536, the
-        // per-chain mat-vec kernel for small ensembles, tape replays and beyond (round 4); the default bound only
-        if (c.sampler == PDMP_BOOMERANG && c.grid_size != 10)
-            return fail(PDMP_ERR_UNSUPPORTED, "dense-precision target: Boomerang with grid_size = 10 only");
+        // per-chain mat-vec kernel for small ensembles, tape replays and beyond (round 4).  The batched forms serve grid_size = 10; every
+        // other grid_size (round 5: a free parameter of the group kernel, UpperBound.jl:92,203) runs the per-chain mat-vec kernel.
         if (group_waves_per_block((c.dim + WAVE - 1) / WAVE, 0, 6) < 1) return fail(PDMP_ERR_UNSUPPORTED, "dense-precision target: dim too large for the LDS tiles");
     }
     if (c.deriv_mode != PDMP_DERIV_FORWARD && c.deriv_mode != PDMP_DERIV_FINITE_DIFF) return fail(PDMP_ERR_ARGUMENT, "Unsupported AD_backend id %d", c.deriv_mode);
@@ -826,7 +833,8 @@ glaunch_fn pick_group_tape_launcher(int sampler, int target) {
 // waves per CU.  0 = the configuration is served by the wave-per-chain kernel instead.
 int choose_group_lanes(const pdmp_config_t &c) {
     if (c.target_id == PDMP_T_GAUSS_DENSE) return WAVE;        // one chain per wave: the gradient is a mat-vec
-    if (c.grid_size != GNG && c.grid_size != 0) return 0;           // 0: Brent constant bound (group kernel only)
+    // (round 5: grid_size is a run-time parameter of the LDS-form group kernel, 2 .. 64 -- UpperBound.jl:92,203; rounds 1-4 sent every
+    //  grid_size other than 10 / 0 to the wave-per-chain kernel, which PDMP_GROUP_LANES=0 still selects)
     if (const char *e = getenv("PDMP_GROUP_LANES")) {
         const int G = atoi(e);
         if (G == 0) return 0;
@@ -859,7 +867,8 @@ int choose_group_lanes(const pdmp_config_t &c) {
     }
     // Zig-Zag at d <= 26 in the configuration the lane kernel serves (1 .. 7 slots of four): the G = 4 layout, so that large ensembles
     // run one lane per chain there as well (round 4: d = 26, 10^5 chains: 14.8 ms with G = 2 -> 10.3 ms; d <= 8 later in the round)
-    if (c.sampler == PDMP_ZIGZAG && c.dim >= 1 && c.dim <= 26 && c.deriv_mode == PDMP_DERIV_FORWARD && c.vectorized_bound && c.signed_bound &&
+    // (grid_size = 10 only: the lane kernels serve no other grid, and at d <= 8 the G = 4 layout leaves lanes idle for nothing)
+    if (c.sampler == PDMP_ZIGZAG && c.dim >= 1 && c.dim <= 26 && c.deriv_mode == PDMP_DERIV_FORWARD && c.vectorized_bound && c.signed_bound && c.grid_size == GNG &&
         (c.target_id == PDMP_T_GAUSS_ISO || c.target_id == PDMP_T_BANANA)) return 4;
     for (int G = 1; G <= 16; G <<= 1)      // register form (inst_reg_*.hip): at most KREG slots per lane, G <= 16
         if ((c.dim + G - 1) / G <= KREG) return G;
@@ -967,7 +976,7 @@ static int create_impl(const pdmp_config_t *cfg, const char *source, int32_t kin
         if (h->group_lanes <= 0) { pdmp_destroy(h); return fail(PDMP_ERR_UNSUPPORTED, "potentials given as source: dim too large for the LDS tiles"); }
         static thread_local char log[sizeof g_err];
         log[0] = '\0';
-        const int rc = pdmp_user_compile(dev, c.sampler, c.deriv_mode == PDMP_DERIV_FINITE_DIFF, kind, source, &h->user_fn, log, (int)sizeof log);
+        const int rc = pdmp_user_compile(dev, c.sampler, c.deriv_mode == PDMP_DERIV_FINITE_DIFF, kind, c.rng_version, source, &h->user_fn, log, (int)sizeof log);
         if (rc != 0) {
             pdmp_destroy(h);
             // a potential that does not compile is the caller's mistake: the ArgumentError of ADBackend.jl:68-70
@@ -1122,6 +1131,8 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
     p.t_stop = __builtin_huge_val();
     if (until) { p.t_stop = until->T; p.resume = until->resume; p.chain_map = until->chain_map; p.count = until->count; }
     const bool taped = h->tape_chains > 0;
+    const bool v1 = c.rng_version == 1;        // arithmetic contract v1: the LDS-form group kernels and the wave-per-chain kernel of the v1 build (v1_bridge.hip)
+    if (taped && v1) return fail(PDMP_ERR_UNSUPPORTED, "tape replay runs in the default arithmetic contract (rng_version = 2)");
     if (taped) {
         if (chain_id_offset < 0 || chain_id_offset + C > h->tape_chains)
             return fail(PDMP_ERR_ARGUMENT, "tape holds %lld chains; requested chains [%lld, %lld)", (long long)h->tape_chains,
@@ -1157,7 +1168,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
         // cells of a lazily built bound per pass of the state machine (same bits whatever the number).  A full machine (two waves per SIMD
         // hiding each other's latency) is fastest with instalments of three; a launch that leaves every wave alone on its SIMD pays each
         // extra pass of the state machine in full: all nine (12 500 chains: 4.29 -> 3.91 ms, scripts/budget_sweep.sh)
-        gp.cell_budget = ((C + WAVE / h->group_lanes - 1) / (WAVE / h->group_lanes) <= 1024) ? GNG - 1 : 3;
+        gp.cell_budget = ((C + WAVE / h->group_lanes - 1) / (WAVE / h->group_lanes) <= 1024) ? (c.grid_size == GNG ? GNG - 1 : WAVE) : 3;   // (WAVE: every cell of any grid_size)
         gp.host_flags = (h->policy.no_lean ? 1 : 0) | (h->policy.debug_launch ? 2 : 0);
         if (h->policy.cell_budget > 0) gp.cell_budget = h->policy.cell_budget;   // tuning / tests
         const int64_t nb = (C + WAVE / gp.G - 1) / (WAVE / gp.G);
@@ -1198,10 +1209,10 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
     const bool dense_resume = resuming && until->form == PDMP_FORM_DENSE;
     const int64_t C_ws = dense_resume ? h->until_chains : C;       // chains of the workspace: the first chunk's
     const bool batched = c.target_id == PDMP_T_GAUSS_DENSE && c.sampler == PDMP_ZIGZAG && c.vectorized_bound && c.grid_size == GNG &&
-                         c.deriv_mode == PDMP_DERIV_FORWARD && !taped && 2 * C_ws < 0x7fffffffLL && (!resuming || dense_resume) &&
+                         c.deriv_mode == PDMP_DERIV_FORWARD && !taped && !v1 && 2 * C_ws < 0x7fffffffLL && (!resuming || dense_resume) &&
                          (dense_resume || (dense_mode ? (dense_mode == 2 || dense_mode == 1) : C >= 64)) && !(until && dense_mode == 2);
     const bool bps_batched = c.target_id == PDMP_T_GAUSS_DENSE && (c.sampler == PDMP_BPS || c.sampler == PDMP_BOOMERANG) && c.grid_size == GNG && c.dim <= (c.sampler == PDMP_BOOMERANG ? 24 : 32) * WAVE &&
-                             c.deriv_mode == PDMP_DERIV_FORWARD && !taped && 2 * C_ws < 0x7fffffffLL && (!resuming || dense_resume) &&
+                             c.deriv_mode == PDMP_DERIV_FORWARD && !taped && !v1 && 2 * C_ws < 0x7fffffffLL && (!resuming || dense_resume) &&
                              (dense_resume || (dense_mode ? (dense_mode == 2 || dense_mode == 1) : C >= 64));
     if (until && (taped || h->group_lanes <= 0 || (c.target_id == PDMP_T_GAUSS_DENSE && !batched && !bps_batched) ||
                   (batched && (c.dim > 16 * WAVE || (!c.signed_bound && c.dim > 8 * WAVE))) || (bps_batched && c.dim > 16 * WAVE))) {   // (the largest kernels: no horizon)
@@ -1250,7 +1261,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
         // register form: the default bound flags only (grid_size = 10; Zig-Zag: vectorized signed bound) -- GroupChain::brent() etc.
         const bool reg_flags = c.sampler == PDMP_RHMC ||        // (RHMC: its bound is the constant refresh clock whatever the flags)
                                (c.grid_size == GNG && ((c.sampler != PDMP_ZIGZAG && c.sampler != PDMP_STICKY && c.sampler != PDMP_SUZZ) || (c.vectorized_bound && c.signed_bound)));
-        if (pol.reg && reg_flags) {
+        if (pol.reg && reg_flags && !v1) {
             const bool fd = c.deriv_mode != 0;
             // Large Zig-Zag ensembles at d = 49..52 on the isotropic Gaussian / banana: one LANE per chain (lane_kernel.hpp), bit-identical
             // to the G = 4 group kernel.  It needs unit speeds: a check kernel raises a device flag otherwise, the lane kernel then
@@ -1332,14 +1343,14 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
             else h->last_form = PDMP_FORM_GROUP;
             const glaunch_fn f = tgroup ? pick_group_tape_launcher(c.sampler, c.target_id) : pick_group_launcher(c.sampler, c.target_id);
             if (!f) { h->pool.push_back(ev); return fail(PDMP_ERR_UNSUPPORTED, "no group kernel for sampler %d on target %d", c.sampler, c.target_id); }
-            e = f(gp, s);
+            e = v1 ? v1_launch_group(c.sampler, c.target_id, &gp, s) : f(gp, s);
         }
         if (e != hipSuccess) { h->pool.push_back(ev); return fail(PDMP_ERR_RUNTIME, "group kernel launch: %s", hipGetErrorString(e)); }
     } else {
         h->last_form = PDMP_FORM_WAVE;
         const launch_fn f = pick_launcher(c.sampler, c.target_id);
         if (!f) { h->pool.push_back(ev); return fail(PDMP_ERR_UNSUPPORTED, "the wave-per-chain kernel serves Zig-Zag / BPS / Boomerang on the built-in separable / banana targets"); }
-        const hipError_t e = f(p, s);
+        const hipError_t e = v1 ? v1_launch_skeleton(c.sampler, c.target_id, &p, s) : f(p, s);
         if (e != hipSuccess) { h->pool.push_back(ev); return fail(PDMP_ERR_RUNTIME, "wave kernel launch: %s", hipGetErrorString(e)); }
     }
     return end_timed(h, s, ev);
@@ -1384,11 +1395,11 @@ int pdmp_close_chunk_device(pdmp_handle h, int64_t C, int64_t capacity, double *
     pdmp_diag_t dg = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (diag) dg = *diag;
     if (h->cfg.sampler == PDMP_BOOMERANG)
-        hipLaunchKernelGGL(close_at_kernel<true>, grid, block, 0, s, h->cfg.dim, C, capacity, X, V, t, T, count, 0, 0, 0.0, (const double *)nullptr, dg, n_recorded);
+        hipLaunchKernelGGL((h->cfg.rng_version == 1 ? close_at_kernel<2> : close_at_kernel<1>), grid, block, 0, s, h->cfg.dim, C, capacity, X, V, t, T, count, 0, 0, 0.0, (const double *)nullptr, dg, n_recorded, 2);
     else
-        hipLaunchKernelGGL(close_at_kernel<false>, grid, block, 0, s, h->cfg.dim, C, capacity, X, V, t, T, count,
+        hipLaunchKernelGGL(close_at_kernel<0>, grid, block, 0, s, h->cfg.dim, C, capacity, X, V, t, T, count,
                            h->cfg.sampler == PDMP_SUZZ ? 1 : (h->cfg.sampler == PDMP_RHMC ? 2 : (h->cfg.sampler == PDMP_STICKY ? 3 : 0)),
-                           h->cfg.target_id, h->cfg.rh_step_size, (const double *)h->d_tparams, dg, n_recorded);
+                           h->cfg.target_id, h->cfg.rh_step_size, (const double *)h->d_tparams, dg, n_recorded, (h->cfg.rng_version == 1 ? 1 : 2));
     HIP_TRY(hipGetLastError());
     h->last_stream = s;
     return PDMP_OK;
@@ -1529,18 +1540,18 @@ static int from_skeleton_launch(pdmp_handle h, int method, int64_t C, int64_t n_
     const bool flat = h->cfg.sampler != PDMP_SUZZ && h->cfg.sampler != PDMP_RHMC && (2 * (int64_t)h->cfg.dim + 1) * WAVE < (1ll << 31) / (2 * (int64_t)h->cfg.dim + 1) &&
                       !h->policy.from_skeleton_rows;                 // (policy: the row-per-iteration kernel, for A/B runs)
     if (flat && h->cfg.sampler == PDMP_BOOMERANG)
-        hipLaunchKernelGGL(from_skeleton_flat_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, dt, (int)discard_vt, out,
+        hipLaunchKernelGGL((h->cfg.rng_version == 1 ? from_skeleton_flat_kernel<2> : from_skeleton_flat_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, dt, (int)discard_vt, out,
                            is_active, ia_mode, (int)(method == 2), n_prefix, lens, counts);
     else if (flat)
-        hipLaunchKernelGGL(from_skeleton_flat_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, dt, (int)discard_vt, out,
+        hipLaunchKernelGGL(from_skeleton_flat_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, dt, (int)discard_vt, out,
                            is_active, ia_mode, (int)(method == 2), n_prefix, lens, counts);
     else if (h->cfg.sampler == PDMP_BOOMERANG)
-        hipLaunchKernelGGL(from_skeleton_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, dt, (int)discard_vt, out, 0,
-                           -1, 0.0, (const double *)nullptr, is_active, ia_mode, (int)(method == 2), n_prefix, lens, counts);
+        hipLaunchKernelGGL((h->cfg.rng_version == 1 ? from_skeleton_kernel<2> : from_skeleton_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, dt, (int)discard_vt, out, 0,
+                           -1, 0.0, (const double *)nullptr, is_active, ia_mode, (int)(method == 2), n_prefix, lens, counts, 2);
     else
-        hipLaunchKernelGGL(from_skeleton_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, dt, (int)discard_vt, out,
+        hipLaunchKernelGGL(from_skeleton_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, h->cfg.dim, C, n_sk, X, V, t, N, dt, (int)discard_vt, out,
                            (int)(h->cfg.sampler == PDMP_SUZZ), h->cfg.sampler == PDMP_RHMC ? h->cfg.target_id : -1, h->cfg.rh_step_size,
-                           (const double *)h->d_tparams, is_active, ia_mode, (int)(method == 2), n_prefix, lens, counts);
+                           (const double *)h->d_tparams, is_active, ia_mode, (int)(method == 2), n_prefix, lens, counts, (h->cfg.rng_version == 1 ? 1 : 2));
     if (hipError_t e = hipGetLastError(); e != hipSuccess) { h->pool.push_back(ev); return fail(PDMP_ERR_RUNTIME, "from_skeleton_kernel: %s", hipGetErrorString(e)); }
     return end_timed(h, s, ev);
 }
@@ -1632,11 +1643,11 @@ int pdmp_close_at_time_device(pdmp_handle h, int64_t C, int64_t n_sk, double *X,
     pdmp_diag_t dg = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (diag) dg = *diag;
     if (h->cfg.sampler == PDMP_BOOMERANG)
-        hipLaunchKernelGGL(close_at_kernel<true>, grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, T, count, 0, 0, 0.0, (const double *)nullptr, dg);
+        hipLaunchKernelGGL((h->cfg.rng_version == 1 ? close_at_kernel<2> : close_at_kernel<1>), grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, T, count, 0, 0, 0.0, (const double *)nullptr, dg, (const int64_t *)nullptr, 2);
     else
-        hipLaunchKernelGGL(close_at_kernel<false>, grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, T, count,
+        hipLaunchKernelGGL(close_at_kernel<0>, grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, T, count,
                            h->cfg.sampler == PDMP_SUZZ ? 1 : (h->cfg.sampler == PDMP_RHMC ? 2 : (h->cfg.sampler == PDMP_STICKY ? 3 : 0)),
-                           h->cfg.target_id, h->cfg.rh_step_size, (const double *)h->d_tparams, dg);
+                           h->cfg.target_id, h->cfg.rh_step_size, (const double *)h->d_tparams, dg, (const int64_t *)nullptr, (h->cfg.rng_version == 1 ? 1 : 2));
     HIP_TRY(hipGetLastError());
     h->last_stream = s;
     return PDMP_OK;
@@ -1692,12 +1703,12 @@ int pdmp_sample_moments_device(pdmp_handle h, int64_t C, int64_t n_sk, const dou
     if (int rc = begin_timed(h, s, ev)) return rc;
     const dim3 grid((unsigned)((C + 3) / 4)), block(256);
     if (h->cfg.sampler == PDMP_BOOMERANG)
-        hipLaunchKernelGGL(moments_kernel<true>, grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, N, sum_x, sum_x2, 0, 0, 0.0, (const double *)nullptr,
-                           (const uint8_t *)nullptr, lens);
+        hipLaunchKernelGGL((h->cfg.rng_version == 1 ? moments_kernel<2> : moments_kernel<1>), grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, N, sum_x, sum_x2, 0, 0, 0.0, (const double *)nullptr,
+                           (const uint8_t *)nullptr, lens, 2);
     else
-        hipLaunchKernelGGL(moments_kernel<false>, grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, N, sum_x, sum_x2,
+        hipLaunchKernelGGL(moments_kernel<0>, grid, block, 0, s, h->cfg.dim, C, n_sk, X, V, t, N, sum_x, sum_x2,
                            h->cfg.sampler == PDMP_SUZZ ? 1 : (h->cfg.sampler == PDMP_RHMC ? 2 : (h->cfg.sampler == PDMP_STICKY ? 3 : 0)),
-                           h->cfg.target_id, h->cfg.rh_step_size, (const double *)h->d_tparams, is_active, lens);
+                           h->cfg.target_id, h->cfg.rh_step_size, (const double *)h->d_tparams, is_active, lens, (h->cfg.rng_version == 1 ? 1 : 2));
     if (hipError_t e = hipGetLastError(); e != hipSuccess) { h->pool.push_back(ev); return fail(PDMP_ERR_RUNTIME, "moments_kernel: %s", hipGetErrorString(e)); }
     return end_timed(h, s, ev);
 }
@@ -1732,7 +1743,7 @@ int pdmp_init_states_device(pdmp_handle h, int64_t C, int64_t chain_id_offset, u
     if (v_kind < PDMP_V_RADEMACHER || v_kind > PDMP_V_SPHERE) return fail(PDMP_ERR_ARGUMENT, "init_states: unknown v_kind %d", (int)v_kind);
     HIP_TRY(hipSetDevice(h->device));
     const int threads = 64;
-    hipLaunchKernelGGL(init_states_kernel, dim3((unsigned)((C + threads - 1) / threads)), dim3(threads), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((h->cfg.rng_version == 1 ? init_states_kernel<1> : init_states_kernel<2>), dim3((unsigned)((C + threads - 1) / threads)), dim3(threads), 0, (hipStream_t)stream,
                        C, chain_id_offset, seed, h->cfg.dim, x_mean, x_scale, (int)v_kind, xinit, vinit);
     HIP_TRY(hipGetLastError());
     return PDMP_OK;
@@ -1743,7 +1754,7 @@ int pdmp_debug_rng(pdmp_handle h, uint64_t seed, int64_t chain, int32_t kind, in
     HIP_TRY(hipSetDevice(h->device));
     double *d = nullptr;
     HIP_TRY(hipMalloc(&d, (size_t)n * 8));
-    hipLaunchKernelGGL(debug_rng_kernel, dim3(1), dim3(WAVE), 0, nullptr, seed, chain, (int)kind, n, d);
+    hipLaunchKernelGGL((h->cfg.rng_version == 1 ? debug_rng_kernel<1> : debug_rng_kernel<2>), dim3(1), dim3(WAVE), 0, nullptr, seed, chain, (int)kind, n, d);
     hipError_t e = hipMemcpy(out, d, (size_t)n * 8, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(PDMP_ERR_RUNTIME, "debug_rng: %s", hipGetErrorString(e));

@@ -26,14 +26,14 @@
 #include "skeleton_kernel.hpp"
 #include "user_ad.hpp"
 
-namespace pdmp {
+PDMP_NS_BEGIN
 
 #ifdef PDMP_NO_DPP_BOUND        // A/B builds
 constexpr bool defined_no_dpp_bound = true;
 #else
 constexpr bool defined_no_dpp_bound = false;
 #endif
-constexpr int GNG = 10;   // grid_size served by this kernel (the default of every reference constructor)
+constexpr int GNG = 10;   // grid_size of the register / lane forms (the default of every reference constructor); the LDS form takes any 2 .. 64 at run time
 constexpr int KREG = 13;  // slots per lane of the register form (x, v in VGPRs): d <= 13 G
 
 struct GroupParams {
@@ -239,6 +239,9 @@ struct GroupChain {
     // bound (the host routes every other combination to the LDS form): the unsigned / non-vectorized / Brent code is not compiled into
     // these kernels at all, which is what keeps them inside 2 waves per SIMD without spills.
     __device__ __forceinline__ bool brent() const { if constexpr (kReg) return false; else return p.n_grid == 0; }
+    // grid_size of the bounds (UpperBound.jl:92,203: n_grid is a free parameter; the reference's tests use 5, 8, 10, 20): a run-time number
+    // in the LDS form (2 .. 64), the constructors' default in the register form
+    __device__ __forceinline__ int ng() const { if constexpr (kReg) return GNG; else return p.n_grid; }
     __device__ __forceinline__ bool vectorized() const { if constexpr (kReg) return true; else return p.vectorized != 0; }
     __device__ __forceinline__ bool zz_signed() const { if constexpr (kReg) return true; else return p.signed_bound != 0; }
     // coordinate i = s*G + g exists (i < d): only the last slot K-1 can be partly padded (register form: a scalar test for the others)
@@ -715,7 +718,7 @@ struct GroupChain {
     // returns true when this lane's bound is finished: its cell was found (tpo, lbo set) or all cells are built (lbo = box_max[end])
     template <bool SIGNED, bool FDM>
     __device__ __forceinline__ bool bound_advance_vect(double harg, double E, double &tpo, double &lbo, int budget) {
-        const double h = harg / (double)(GNG - 1);
+        const double h = harg / (double)(ng() - 1);
         bool found = false, found_now = false;
 #ifdef PDMP_STAMP
         if (lane == 0 && p.stamps) atomicAdd(&p.stamps[7], 1ull);
@@ -729,14 +732,14 @@ struct GroupChain {
             }
         }
         for (int pass = 0; pass < budget; ++pass) {
-            const bool act = !found && b_next < GNG - 1;                                // the lanes of a chain agree
+            const bool act = !found && b_next < ng() - 1;                                // the lanes of a chain agree
             if (__ballot(act) == 0ull) break;
 #ifdef PDMP_STAMP
             if (lane == 0 && p.stamps) atomicAdd(&p.stamps[6], 1ull);
 #endif
             if (act) {
                 const int j = b_next;
-                const double t0 = (double)j * h, t1 = (j == GNG - 2) ? harg : (double)(j + 1) * h;
+                const double t0 = (double)j * h, t1 = (j == ng() - 2) ? harg : (double)(j + 1) * h;
                 double bsum = 0.0;
                 if constexpr (!FDM) {
                     TimePt p0, p1;
@@ -802,7 +805,7 @@ struct GroupChain {
         }
         // next_event, :269, for the chains that found their cell in this pass: cell b_next - 1, cum_sum b_cbefore before and b_cprev after it
         if (found_now) tpo = (double)(b_next - 1) * h + (E - b_cbefore) / (b_cprev - b_cbefore) * h;
-        const bool fin = found || b_next >= GNG - 1;
+        const bool fin = found || b_next >= ng() - 1;
         if (fin && !found) lbo = b_last;                                               // box_max[end], :270
         return fin;
     }
@@ -924,7 +927,7 @@ struct GroupChain {
     }
     template <bool FDM>
     __device__ __forceinline__ void bound_invert_scalar(double harg, double E, double &tpo, double &lbo) {
-        const double h = harg / (double)(GNG - 1);
+        const double h = harg / (double)(ng() - 1);
         const double refresh = (p.signed_bound != 0) ? p.refresh : 0.0;               // AbstractPDMP.jl:104-112
         double acc = 0.0, cprev = 0.0, bj = 0.0, f0, s0;
         bool found = false;
@@ -1040,9 +1043,9 @@ struct GroupChain {
                 }
             };
             point(0.0, f0, s0);
-            for (int j = 0; j < GNG - 1; ++j) {
+            for (int j = 0; j < ng() - 1; ++j) {
                 double f1, s1;
-                point((j == GNG - 2) ? harg : (double)(j + 1) * h, f1, s1);
+                point((j == ng() - 2) ? harg : (double)(j + 1) * h, f1, s1);
                 cell(j, f1, s1);
                 if (__ballot(!found) == 0ull) break;
             }
@@ -1057,39 +1060,41 @@ struct GroupChain {
                 slp = sgn ? de : ((0.0 < dv) ? de : 0.0);
             };
             point(0.0, f0, s0);
-            for (int j = 0; j < GNG - 1; ++j) {                                        // lazy, cell by cell: a grid time is O(1) now
+            for (int j = 0; j < ng() - 1; ++j) {                                        // lazy, cell by cell: a grid time is O(1) now
                 double f1, s1;
-                point((j == GNG - 2) ? harg : (double)(j + 1) * h, f1, s1);
+                point((j == ng() - 2) ? harg : (double)(j + 1) * h, f1, s1);
                 cell(j, f1, s1);
                 if (__ballot(!found) == 0ull) break;
             }
         } else
         if constexpr (!FDM && !Tgt::kTile) {
-            // lazy in batches of three cells: grid times {0,1,2,3}, {4,5,6}, {7,8,9}, one coordinate pass per batch
+            // lazy in batches of three cells: grid times {0,1,2,3}, {4,5,6}, {7,8,9}, ... one coordinate pass per batch (grid time j sits at
+            // j h, the last one at the horizon itself; a batch that reaches past the grid evaluates the horizon again and skips those cells)
+            const int n = ng();
             {
                 TimePt tp[4];
                 double f[4], sl[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) time_pt((double)q * h, tp[q]);
+                for (int q = 0; q < 4; ++q) time_pt((q >= n - 1) ? harg : (double)q * h, tp[q]);
                 eval_scalar_multi<4>(tp, f, sl);                                       // :97, :102
                 f0 = f[0]; s0 = sl[0];
 #pragma unroll
-                for (int q = 1; q < 4; ++q) cell(q - 1, f[q], sl[q]);
+                for (int q = 1; q < 4; ++q) if (q <= n - 1) cell(q - 1, f[q], sl[q]);
             }
-            for (int jb = 3; jb < GNG - 1 && __ballot(!found) != 0ull; jb += 3) {
+            for (int jb = 3; jb < n - 1 && __ballot(!found) != 0ull; jb += 3) {
                 TimePt tp[3];
                 double f[3], sl[3];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) time_pt((jb + q == GNG - 2) ? harg : (double)(jb + q + 1) * h, tp[q]);
+                for (int q = 0; q < 3; ++q) time_pt((jb + q >= n - 2) ? harg : (double)(jb + q + 1) * h, tp[q]);
                 eval_scalar_multi<3>(tp, f, sl);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) cell(jb + q, f[q], sl[q]);
+                for (int q = 0; q < 3; ++q) if (jb + q < n - 1) cell(jb + q, f[q], sl[q]);
             }
         } else {
             double f1, s1;
             point_scalar<FDM>(0.0, harg, f0, s0);
-            for (int j = 0; j < GNG - 1; ++j) {
-                point_scalar<FDM>((j == GNG - 2) ? harg : (double)(j + 1) * h, harg, f1, s1);
+            for (int j = 0; j < ng() - 1; ++j) {
+                point_scalar<FDM>((j == ng() - 2) ? harg : (double)(j + 1) * h, harg, f1, s1);
                 cell(j, f1, s1);
                 if (__ballot(!found) == 0ull) break;
             }
@@ -1753,7 +1758,7 @@ struct GroupChain {
         bool propose = false, brun = false;                              // brun: this lane's bound is under construction (bound_advance)
         int mode = FRESH;
         double hB = horizon;
-        const int budget = (G == WAVE) ? GNG : cell_budget;               // one chain per wave: nobody to wait for
+        const int budget = (G == WAVE) ? WAVE : cell_budget;               // one chain per wave: nobody to wait for
         const bool resumable = kZz && vectorized() && !brent() && !Tgt::kTile;   // bounds built by bound_advance_vect
 #ifdef PDMP_STAMP
         unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
@@ -2166,4 +2171,4 @@ hipError_t launch_group_impl(const GroupParams &gp_in, hipStream_t stream) {
 
 #endif  // __HIPCC_RTC__
 
-}  // namespace pdmp
+PDMP_NS_END

@@ -2,8 +2,8 @@
 // the flow, rate and bound of the Bouncy Particle Sampler without refreshment, its own velocity jump (fecmc_jump).
 #include "group_kernel.hpp"
 
-namespace pdmp {
+PDMP_NS_BEGIN
 PDMP_DEFINE_GROUP_LAUNCHER(S_FECMC, T_GAUSS_ISO)
 PDMP_DEFINE_GROUP_LAUNCHER(S_FECMC, T_GAUSS_DIAG)
 PDMP_DEFINE_GROUP_LAUNCHER(S_FECMC, T_BANANA)
-}  // namespace pdmp
+PDMP_NS_END

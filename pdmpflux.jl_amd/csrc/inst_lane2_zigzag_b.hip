@@ -1,8 +1,8 @@
 // Lane-pair-per-chain kernels (lane_kernel.hpp, GL = 2) for d = 73 .. 96 (10 .. 12 slots of eight).
 #include "lane_kernel.hpp"
 
-namespace pdmp {
+PDMP_NS_BEGIN
 hipError_t launch_lane2_zigzag_b(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream) {
     return launch_lane_range<10, 12, 2>(target, gp, flag, rounds, stream);
 }
-}  // namespace pdmp
+PDMP_NS_END

@@ -2,8 +2,8 @@
 // four; round 4): mid-sized launches.
 #include "lane_kernel.hpp"
 
-namespace pdmp {
+PDMP_NS_BEGIN
 hipError_t launch_lane2q_zigzag_c(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream) {
     return launch_lane_range<3, 6, 2, 2>(target, gp, flag, rounds, stream);
 }
-}  // namespace pdmp
+PDMP_NS_END

@@ -1,7 +1,7 @@
 // Lane-per-chain kernels of the Zig-Zag hot path (lane_kernel.hpp): isotropic Gaussian and banana, d = 49 .. 52 (13 slots of four).
 #include "lane_kernel.hpp"
 
-namespace pdmp {
+PDMP_NS_BEGIN
 // flag[0] != 0 after this kernel: some |v_i| != 1 -- the lane kernel leaves the launch to the group kernel (GroupParams::only_if)
 __global__ __launch_bounds__(256) void lane_check_kernel(const double *vinit, int64_t n, int32_t *flag) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -17,4 +17,4 @@ hipError_t launch_lane_check(const double *vinit, int64_t n, int32_t *flag, hipS
     hipLaunchKernelGGL(lane_check_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, vinit, n, flag);
     return hipGetLastError();
 }
-}  // namespace pdmp
+PDMP_NS_END

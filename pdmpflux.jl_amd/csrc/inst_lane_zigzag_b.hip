@@ -1,8 +1,8 @@
 // Lane-per-chain kernels (lane_kernel.hpp) for d = 37 .. 48 (10 .. 12 slots of four).
 #include "lane_kernel.hpp"
 
-namespace pdmp {
+PDMP_NS_BEGIN
 hipError_t launch_lane_zigzag_b(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream) {
     return launch_lane_range<10, 12>(target, gp, flag, rounds, stream);
 }
-}  // namespace pdmp
+PDMP_NS_END

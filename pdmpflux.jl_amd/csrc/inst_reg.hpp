@@ -4,7 +4,7 @@
 #pragma once
 #include "group_kernel.hpp"
 
-namespace pdmp {
+PDMP_NS_BEGIN
 
 // TAPE: the tape-replay instantiations (inst_tape_reg_*.hip; group_kernel_reg_tape, one wave per SIMD).  A replay runs the
 // 13-slot kernels (with the per-slot skips where K < 13) for every configuration the register form serves with the Philox stream.
@@ -105,4 +105,4 @@ static hipError_t exact_by_target(int target, const GroupParams &gp, hipStream_t
     }
 }
 
-}  // namespace pdmp
+PDMP_NS_END

@@ -1,6 +1,6 @@
 // Register-form kernels of the group kernel for sampler S_BOOMERANG (see inst_reg.hpp).
 #include "inst_reg.hpp"
 
-namespace pdmp {
+PDMP_NS_BEGIN
 hipError_t launch_group_reg_boomerang(int target, bool fd, const GroupParams &gp, hipStream_t stream) { return reg_by_target<S_BOOMERANG>(target, fd, gp, stream); }
-}  // namespace pdmp
+PDMP_NS_END

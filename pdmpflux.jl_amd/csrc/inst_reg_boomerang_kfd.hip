@@ -2,9 +2,9 @@
 // K = 9..12 are in inst_reg_boomerang_kfd2.hip.
 #include "inst_reg.hpp"
 
-namespace pdmp {
+PDMP_NS_BEGIN
 hipError_t launch_group_reg_boomerang_exact_fd_hi(int target, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_boomerang_exact_fd(int target, const GroupParams &gp, hipStream_t stream) {
     return gp.K >= 9 ? launch_group_reg_boomerang_exact_fd_hi(target, gp, stream) : exact_by_target<S_BOOMERANG, true, 0>(target, gp, stream);
 }
-}  // namespace pdmp
+PDMP_NS_END

@@ -2,11 +2,11 @@
 // K = 9..12 are in inst_reg_bps_k2.hip.
 #include "inst_reg.hpp"
 
-namespace pdmp {
+PDMP_NS_BEGIN
 hipError_t launch_group_reg_bps_exact_hi(int target, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_bps_exact_lo(int target, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_bps_exact(int target, const GroupParams &gp, hipStream_t stream) {
     if (gp.K < 7 && gp.G >= 2) return launch_group_reg_bps_exact_lo(target, gp, stream);
     return gp.K >= 9 ? launch_group_reg_bps_exact_hi(target, gp, stream) : exact_by_target<S_BPS, false, 0>(target, gp, stream);
 }
-}  // namespace pdmp
+PDMP_NS_END

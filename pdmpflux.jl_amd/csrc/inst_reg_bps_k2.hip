@@ -1,6 +1,6 @@
 // Exact-K register-form kernels (K = 9..12, forward-mode slopes) of the group kernel for sampler S_BPS (see inst_reg.hpp).
 #include "inst_reg.hpp"
 
-namespace pdmp {
+PDMP_NS_BEGIN
 hipError_t launch_group_reg_bps_exact_hi(int target, const GroupParams &gp, hipStream_t stream) { return exact_by_target<S_BPS, false, 1>(target, gp, stream); }
-}  // namespace pdmp
+PDMP_NS_END

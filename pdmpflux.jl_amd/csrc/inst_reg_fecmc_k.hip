@@ -4,7 +4,7 @@
 // inst_reg_fecmc_k2.hip.
 #include "inst_reg.hpp"
 
-namespace pdmp {
+PDMP_NS_BEGIN
 template <int T>
 static hipError_t fecmc_lo(const GroupParams &gp, hipStream_t stream) {
     switch (gp.K) {
@@ -25,4 +25,4 @@ hipError_t launch_group_reg_fecmc_exact(int target, const GroupParams &gp, hipSt
     default: return hipErrorNotSupported;
     }
 }
-}  // namespace pdmp
+PDMP_NS_END

@@ -2,7 +2,7 @@
 // one LDS tile per wave to hand the refreshment's normals across the lanes of a chain -- round 4.
 #include "inst_reg.hpp"
 
-namespace pdmp {
+PDMP_NS_BEGIN
 // (the slope mode plays no part in RHMC -- its bound is the constant refresh clock --: one instantiation serves both)
 hipError_t launch_group_reg_rhmc(int target, const GroupParams &gp, hipStream_t stream) { return reg_by_target<S_RHMC>(target, false, gp, stream); }
-}  // namespace pdmp
+PDMP_NS_END

@@ -2,7 +2,7 @@
 // slopes; the 13-slot kernels spill): K = 2, 3 with one lane per chain and K = 4, 5 with every G here, K = 6, 7 in inst_reg_sticky_k2.hip.
 #include "inst_reg.hpp"
 
-namespace pdmp {
+PDMP_NS_BEGIN
 template <int T>
 static hipError_t sticky_lo(const GroupParams &gp, hipStream_t stream) {
     switch (gp.K) {
@@ -23,4 +23,4 @@ hipError_t launch_group_reg_sticky_exact(int target, const GroupParams &gp, hipS
     default: return hipErrorNotSupported;
     }
 }
-}  // namespace pdmp
+PDMP_NS_END

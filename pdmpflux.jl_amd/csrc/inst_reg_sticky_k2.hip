@@ -1,7 +1,7 @@
 // Register form of StickyZigZag, K = 6, 7 slots per lane (see inst_reg_sticky_k.hip).
 #include "inst_reg.hpp"
 
-namespace pdmp {
+PDMP_NS_BEGIN
 template <int T>
 static hipError_t sticky_hi(const GroupParams &gp, hipStream_t stream) {
     switch (gp.K) {
@@ -18,4 +18,4 @@ hipError_t launch_group_reg_sticky_exact_hi(int target, const GroupParams &gp, h
     default: return hipErrorNotSupported;
     }
 }
-}  // namespace pdmp
+PDMP_NS_END

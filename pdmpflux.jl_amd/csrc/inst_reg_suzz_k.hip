@@ -3,7 +3,7 @@
 // here; the diagonal Gaussian K = 2 .. 6 and the banana K = 2 .. 4 in inst_reg_suzz_k2.hip.  Forward-mode slopes.
 #include "inst_reg.hpp"
 
-namespace pdmp {
+PDMP_NS_BEGIN
 hipError_t launch_group_reg_suzz_exact_other(int target, const GroupParams &gp, hipStream_t stream);
 hipError_t launch_group_reg_suzz_exact(int target, const GroupParams &gp, hipStream_t stream) {
     if (target != T_GAUSS_ISO) return launch_group_reg_suzz_exact_other(target, gp, stream);
@@ -17,4 +17,4 @@ hipError_t launch_group_reg_suzz_exact(int target, const GroupParams &gp, hipStr
     default: return hipErrorNotSupported;
     }
 }
-}  // namespace pdmp
+PDMP_NS_END

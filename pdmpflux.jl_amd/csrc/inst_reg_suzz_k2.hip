@@ -1,7 +1,7 @@
 // Register form of SpeedUpZigZag on the diagonal Gaussian (K = 2 .. 6) and the banana (K = 2 .. 4): see inst_reg_suzz_k.hip.
 #include "inst_reg.hpp"
 
-namespace pdmp {
+PDMP_NS_BEGIN
 hipError_t launch_group_reg_suzz_exact_other(int target, const GroupParams &gp, hipStream_t stream) {
     if (target == T_GAUSS_DIAG) {
         switch (gp.K) {
@@ -23,4 +23,4 @@ hipError_t launch_group_reg_suzz_exact_other(int target, const GroupParams &gp, 
     }
     return hipErrorNotSupported;
 }
-}  // namespace pdmp
+PDMP_NS_END

@@ -2,8 +2,8 @@
 // velocity-Verlet flow, constant refresh clock, Horowitz refreshment.
 #include "group_kernel.hpp"
 
-namespace pdmp {
+PDMP_NS_BEGIN
 PDMP_DEFINE_GROUP_LAUNCHER(S_RHMC, T_GAUSS_ISO)
 PDMP_DEFINE_GROUP_LAUNCHER(S_RHMC, T_GAUSS_DIAG)
 PDMP_DEFINE_GROUP_LAUNCHER(S_RHMC, T_BANANA)
-}  // namespace pdmp
+PDMP_NS_END

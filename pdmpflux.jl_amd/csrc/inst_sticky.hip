@@ -2,8 +2,8 @@
 // of src/StickySamplingLoop.jl): the Zig-Zag loop on v .* is_active with sticking at the axes and thawing at rates kappa.
 #include "group_kernel.hpp"
 
-namespace pdmp {
+PDMP_NS_BEGIN
 PDMP_DEFINE_GROUP_LAUNCHER(S_STICKY, T_GAUSS_ISO)
 PDMP_DEFINE_GROUP_LAUNCHER(S_STICKY, T_GAUSS_DIAG)
 PDMP_DEFINE_GROUP_LAUNCHER(S_STICKY, T_BANANA)
-}  // namespace pdmp
+PDMP_NS_END

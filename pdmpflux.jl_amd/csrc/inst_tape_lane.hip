@@ -2,7 +2,7 @@
 // the diagnostic arrays (a replay is compared field by field).  pdmp_set_tape + a launch the lane kernel would serve anyway.
 #include "lane_kernel.hpp"
 
-namespace pdmp {
+PDMP_NS_BEGIN
 hipError_t launch_lane_zigzag_tape(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream) {
     if ((gp.s.d + 3) / 4 != 13) return hipErrorNotSupported;
     switch (target) {
@@ -11,4 +11,4 @@ hipError_t launch_lane_zigzag_tape(int target, const GroupParams &gp, const int3
     default: return hipErrorNotSupported;
     }
 }
-}  // namespace pdmp
+PDMP_NS_END

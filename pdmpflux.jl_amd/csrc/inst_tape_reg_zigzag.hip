@@ -2,6 +2,6 @@
 // 13-slot kernels with and without the per-slot skips, every lane count, every built-in separable / banana target, both slope modes.
 #include "inst_reg.hpp"
 
-namespace pdmp {
+PDMP_NS_BEGIN
 hipError_t launch_group_reg_tape_zigzag(int target, bool fd, const GroupParams &gp, hipStream_t stream) { return reg_by_target<S_ZIGZAG, true>(target, fd, gp, stream); }
-}  // namespace pdmp
+PDMP_NS_END

@@ -44,7 +44,7 @@
 #define LANE_STORE_AUX 2      // nt: streaming stores (measured 16.6 -> 15.1 ms at config 2); cache-policy bits of the event stores (buffer_store ... sc0 = 1 / nt = 2 / sc1 = 16)
 #endif
 
-namespace pdmp {
+PDMP_NS_BEGIN
 
 // LK = slots of the emulated G = 4 layout: one instantiation per LK = 7 .. 13 serves d = 4 LK - 3 .. 4 LK (25 .. 52; the engine's default
 // layout is G = 4 from d = 27 on)
@@ -1035,4 +1035,4 @@ hipError_t launch_lane2q_zigzag_c(int target, const GroupParams &gp, const int32
 hipError_t launch_lane2q_zigzag_d(int target, const GroupParams &gp, const int32_t *flag, int rounds, hipStream_t stream);   // LK = 1, 2
 #endif
 
-}  // namespace pdmp
+PDMP_NS_END

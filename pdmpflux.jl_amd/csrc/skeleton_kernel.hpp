@@ -13,7 +13,7 @@
 #pragma once
 #include "targets.hpp"
 
-namespace pdmp {
+PDMP_NS_BEGIN
 
 enum : int { S_ZIGZAG = 0, S_BPS = 1, S_BOOMERANG = 2, S_FECMC = 3, S_SUZZ = 4, S_RHMC = 5, S_STICKY = 6 };   // ids >= 3: group kernel only
 
@@ -552,4 +552,4 @@ hipError_t launch_skeleton(const SkelParams &p, hipStream_t stream);
     }
 #endif  // __HIPCC_RTC__
 
-}  // namespace pdmp
+PDMP_NS_END

@@ -4,7 +4,7 @@
 #pragma once
 #include "wave_math.hpp"
 
-namespace pdmp {
+PDMP_NS_BEGIN
 
 enum : int { T_GAUSS_ISO = 0, T_GAUSS_DIAG = 1, T_BANANA = 2, T_GAUSS_DENSE = 3, T_USER = 4 };
 
@@ -66,4 +66,4 @@ struct Target<T_BANANA, K> {
     }
 };
 
-}  // namespace pdmp
+PDMP_NS_END

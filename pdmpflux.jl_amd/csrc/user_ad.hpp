@@ -11,7 +11,7 @@
 #pragma once
 #include "wave_math.hpp"
 
-namespace pdmp {
+PDMP_NS_BEGIN
 
 template <class T> struct Fwd { T v, e; };
 
@@ -70,4 +70,4 @@ template <class T> __device__ __forceinline__ void sincos_(Fwd<T> a, Fwd<T> &s, 
 template <class N> __device__ __forceinline__ N sin_(N a) { N s, c; sincos_(a, s, c); return s; }
 template <class N> __device__ __forceinline__ N cos_(N a) { N s, c; sincos_(a, s, c); return c; }
 
-}  // namespace pdmp
+PDMP_NS_END

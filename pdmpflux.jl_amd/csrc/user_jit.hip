@@ -37,9 +37,9 @@ void put(char *err, int errlen, const std::string &s) {
 }  // namespace
 
 // 0 ok; -1 the source does not compile (log in err); -3 runtime failure
-extern "C" int pdmp_user_compile(int device, int sampler, int fd, int kind, const char *source, void **fn_out, char *err, int errlen) {
+extern "C" int pdmp_user_compile(int device, int sampler, int fd, int kind, int rng_version, const char *source, void **fn_out, char *err, int errlen) {
     std::lock_guard<std::mutex> lock(g_mu);
-    const auto key = std::make_tuple(device, sampler, fd, kind, std::string(source));
+    const auto key = std::make_tuple(device, sampler, fd, kind + 16 * rng_version, std::string(source));   // (the arithmetic contract is part of the kernel)
     auto it = g_cache.find(key);
     if (it != g_cache.end()) { *fn_out = (void *)it->second.fn; return 0; }
     // The kernel may not use scratch: a register spilled inside a lane-dependent branch comes back wrong in the lanes that were
@@ -50,6 +50,7 @@ extern "C" int pdmp_user_compile(int device, int sampler, int fd, int kind, cons
     bool ok = false;
     for (int waves = 2; waves >= 1 && !ok; --waves) {
         std::string prog;
+        prog += "#define PDMP_RNG_VERSION " + std::to_string(rng_version == 1 ? 1 : 2) + "\n";
         prog += "#define PDMP_USER_KIND " + std::to_string(kind) + "\n";
         prog += "#include \"wave_math.hpp\"\n#include \"user_ad.hpp\"\n";
         prog += "namespace pdmp_user {\nusing namespace pdmp;\n#line 1 \"potential\"\n";

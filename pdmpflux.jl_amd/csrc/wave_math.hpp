@@ -18,9 +18,26 @@ typedef unsigned long size_t;
 typedef unsigned long uintptr_t;
 #endif
 
-namespace pdmp {
+// ---------------------------------------------------------------- arithmetic contract version of a translation unit
+// PDMP_RNG_VERSION (DESIGN.md "Arithmetic contract v2"; pdmp_config_t.rng_version): the random stream and the elementary functions the
+// kernels of this translation unit are compiled with.  2 (default since round 5): Philox4x32-7, log / exp / sin / cos as Horner
+// schemes on fma, octant Box-Muller.  1: Philox4x32-10 and the fdlibm forms without fma (rounds 1-4, the fixtures frozen then) --
+// built for the LDS-form group kernels and the wave-per-chain kernel only (csrc/Makefile: v1/*.o).  Every name of the engine lives in
+// an inline namespace per version so that the two builds of one kernel template are two symbols.
+#ifndef PDMP_RNG_VERSION
+#define PDMP_RNG_VERSION 2
+#endif
+#if PDMP_RNG_VERSION == 1
+#define PDMP_NS_BEGIN namespace pdmp { inline namespace av1 {
+#else
+#define PDMP_NS_BEGIN namespace pdmp { inline namespace av2 {
+#endif
+#define PDMP_NS_END } }
+
+PDMP_NS_BEGIN
 
 constexpr int WAVE = 64;
+constexpr int kRngVersion = PDMP_RNG_VERSION;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 
@@ -120,10 +137,11 @@ __device__ __forceinline__ Dual readlane_t(Dual x, int l) { return {readlane_d(x
 __device__ __forceinline__ double pmax(double a, double b) { return a > b ? a : b; }
 
 // ---------------------------------------------------------------- Philox4x32-10
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t (&w)[4]) {
+template <int ROUNDS>
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                           uint32_t k0, uint32_t k1, uint32_t (&w)[4]) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;   // one v_mad_u64_u32 each
         const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
         c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
@@ -131,14 +149,28 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     }
     w[0] = c0; w[1] = c1; w[2] = c2; w[3] = c3;
 }
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&w)[4]) { philox4x32<10>(c0, c1, c2, c3, k0, k1, w); }
 
-__device__ __forceinline__ double bits_to_u(uint32_t lo, uint32_t hi) {
-    uint64_t bits = ((uint64_t)hi << 32) | lo;
-    return ((double)(bits >> 12) + 0.5) * 0x1p-52;
+// the top 52 bits of a 64-bit half as the mantissa of a double in [1, 2)
+__device__ __forceinline__ double mant_12(uint32_t lo, uint32_t hi) {
+    return __hiloint2double((int)(0x3FF00000u | (hi >> 12)), (int)((lo >> 12) | (hi << 20)));
 }
+// u = (k + 0.5) 2^-52 in (0, 1), k = the top 52 bits.  v1 computes it by an integer conversion, v2 as m - (1 - 2^-53) from the
+// mantissa form: the same double (both exact), three instructions instead of seven.
+template <int RV>
+__device__ __forceinline__ double bits_to_u_v(uint32_t lo, uint32_t hi) {
+    if constexpr (RV == 1) {
+        uint64_t bits = ((uint64_t)hi << 32) | lo;
+        return ((double)(bits >> 12) + 0.5) * 0x1p-52;
+    } else {
+        return mant_12(lo, hi) - 0x1.fffffffffffffp-1;
+    }
+}
+__device__ __forceinline__ double bits_to_u(uint32_t lo, uint32_t hi) { return bits_to_u_v<kRngVersion>(lo, hi); }
 
-// log(x), x normal and positive: fdlibm e_log.c algorithm with +,-,*,/ only.
-__device__ __forceinline__ double det_log(double x) {
+// ---- v1: log(x), x normal and positive: fdlibm e_log.c algorithm with +,-,*,/ only.
+__device__ __forceinline__ double det_log_v1(double x) {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
                  Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
                  Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
@@ -173,7 +205,7 @@ __device__ __forceinline__ double det_log(double x) {
 }
 
 // exp(x): fdlibm e_exp.c algorithm with +,-,*,/ and integer operations on the exponent field only (same statements as the checker).
-__device__ __forceinline__ double det_exp(double x) {
+__device__ __forceinline__ double det_exp_v1(double x) {
     const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
                  invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
                  P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
@@ -229,13 +261,13 @@ __device__ __forceinline__ void quadrant(int q, double sa, double ca, double &s,
     s = (q == 0) ? sa : (q == 1) ? ca : (q == 2) ? -sa : -ca;
     c = (q == 0) ? ca : (q == 1) ? -sa : (q == 2) ? -ca : sa;
 }
-__device__ __forceinline__ void det_sincos_2pi(double u, double &s, double &c) {
+__device__ __forceinline__ void det_sincos_2pi_v1(double u, double &s, double &c) {
     const int q = (int)(4.0 * u + 0.5);
     const double f = u - 0.25 * (double)q;
     const double a = f * 6.283185307179586476925;
     quadrant(q, ksin(a), kcos(a), s, c);
 }
-__device__ __forceinline__ void det_sincos(double x, double &s, double &c) {
+__device__ __forceinline__ void det_sincos_v1(double x, double &s, double &c) {
     const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
                  pio2_1t = 6.07710050650619224932e-11;
     const double fn = floor(x * invpio2 + 0.5);
@@ -243,10 +275,141 @@ __device__ __forceinline__ void det_sincos(double x, double &s, double &c) {
     quadrant((int)((long long)fn & 3), ksin(a), kcos(a), s, c);
 }
 
+
+// ---- v2 (mirrored statement by statement by the CPU checker: log_v2 .. box_muller there; fma = v_fma_f64 = C fma())
+// A real function unless PDMP_INLINE_MATH is set (the lane kernels set it): inlined into the register-form group kernels -- built to the last
+// register of their budget -- it costs 2 .. 14 VGPRs more than the branchy v1 code did (measured: 19 translation units spilled; with the
+// call none does: the nine coefficients then live in scalar registers only while the function runs instead of across the event loop).
+#ifdef PDMP_INLINE_MATH
+#define PDMP_MATH_FN __device__ __forceinline__
+#else
+#define PDMP_MATH_FN __device__ __attribute__((noinline))
+#endif
+__device__ __forceinline__ double det_log_v2_inl(double x) {
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    double m = __builtin_amdgcn_frexp_mant(x);                 // [0.5, 1): v_frexp_mant_f64 == frexp()
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool c = m < 0.70710678118654752440;
+    m = c ? m + m : m;
+    e -= c ? 1 : 0;
+    const double f = m - 1.0, dk = (double)e;
+    const double s = f / (2.0 + f), z = s * s;
+    const double P = fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, Lg7, Lg6), Lg5), Lg4), Lg3), Lg2), Lg1);
+    const double R = z * P;
+    const double hfsq = (0.5 * f) * f;
+    const double t = fma(s, hfsq + R, dk * ln2_lo);
+    return fma(dk, ln2_hi, f - (hfsq - t));
+}
+PDMP_MATH_FN double det_log_v2(double x) { return det_log_v2_inl(x); }   // (a LEAF function: a call that calls again would need a stack)
+PDMP_MATH_FN double det_exp_v2(double x) {
+    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+                 invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+                 P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (x != x) return x;
+    if (x > 7.09782712893383973096e+02) return __builtin_huge_val();
+    if (x < -7.45133219101941108420e+02) return 0.0;
+    const double kf = __builtin_rint(x * invln2);
+    const double hi = fma(-kf, ln2HI, x), lo = kf * ln2LO;
+    const double r = hi - lo, t = r * r;
+    const double P = fma(t, fma(t, fma(t, fma(t, P5, P4), P3), P2), P1);
+    const double c = fma(-t, P, r);
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    return __builtin_amdgcn_ldexp(y, (int)kf);
+}
+__device__ __forceinline__ double ksin_v2(double a) {
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double z = a * a;
+    const double P = fma(z, fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2), S1);
+    return fma(z * a, P, a);
+}
+__device__ __forceinline__ double kcos_v2(double a) {
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double z = a * a;
+    const double P = fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
+    return fma(z * z, P, fma(z, -0.5, 1.0));
+}
+// quadrant q mod 4 as one swap and two sign flips (integer operations on the sign words)
+__device__ __forceinline__ void quadrant_v2(int q, double sa, double ca, double &s, double &c) {
+    const bool sw = (q & 1) != 0;
+    const double ss = sw ? ca : sa, cc = sw ? sa : ca;
+    s = __hiloint2double(__double2hiint(ss) ^ (int)(((uint32_t)q & 2u) << 30), __double2loint(ss));
+    c = __hiloint2double(__double2hiint(cc) ^ (int)(((uint32_t)(q + 1) & 2u) << 30), __double2loint(cc));
+}
+struct Pair64 { double a, b; };                                  // two doubles returned in registers
+PDMP_MATH_FN Pair64 sincos_core_v2(double x) {
+    const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
+                 pio2_1t = 6.07710050650619224932e-11;
+    const double fn = __builtin_rint(x * invpio2);
+    const double a = fma(-fn, pio2_1t, fma(-fn, pio2_1, x));
+    Pair64 r;
+    quadrant_v2((int)fn, ksin_v2(a), kcos_v2(a), r.a, r.b);
+    return r;
+}
+__device__ __forceinline__ void det_sincos_v2(double x, double &s, double &c) { const Pair64 r = sincos_core_v2(x); s = r.a; c = r.b; }
+PDMP_MATH_FN Pair64 sincos_2pi_core_v2(double u) {
+    const double fn = __builtin_rint(4.0 * u);
+    const double a = fma(-0.25, fn, u) * 6.283185307179586476925;
+    Pair64 r;
+    quadrant_v2((int)fn, ksin_v2(a), kcos_v2(a), r.a, r.b);
+    return r;
+}
+__device__ __forceinline__ void det_sincos_2pi_v2(double u, double &s, double &c) { const Pair64 r = sincos_2pi_core_v2(u); s = r.a; c = r.b; }
+template <int RV> __device__ __forceinline__ double det_log_v(double x) { if constexpr (RV == 1) return det_log_v1(x); else return det_log_v2(x); }
+template <int RV> __device__ __forceinline__ double det_exp_v(double x) { if constexpr (RV == 1) return det_exp_v1(x); else return det_exp_v2(x); }
+template <int RV> __device__ __forceinline__ void det_sincos_v(double x, double &s, double &c) { if constexpr (RV == 1) det_sincos_v1(x, s, c); else det_sincos_v2(x, s, c); }
+template <int RV> __device__ __forceinline__ void det_sincos_2pi_v(double u, double &s, double &c) { if constexpr (RV == 1) det_sincos_2pi_v1(u, s, c); else det_sincos_2pi_v2(u, s, c); }
+// the functions of this translation unit's contract
+__device__ __forceinline__ double det_log(double x) { return det_log_v<kRngVersion>(x); }
+__device__ __forceinline__ double det_exp(double x) { return det_exp_v<kRngVersion>(x); }
+__device__ __forceinline__ void det_sincos(double x, double &s, double &c) { det_sincos_v<kRngVersion>(x, s, c); }
+__device__ __forceinline__ void det_sincos_2pi(double u, double &s, double &c) { det_sincos_2pi_v<kRngVersion>(u, s, c); }
+
+// One Box-Muller pair from the four words of a block.  v1: (z0, z1) = sqrt(-2 log u0) (cos, sin)(2 pi u1).  v2: the same radius; the
+// angle is uniform on the circle as a in [-pi/4, pi/4) (the top 52 bits of the second half as a mantissa m in [1, 2): a = m pi/2 - 3 pi/4),
+// one SWAP bit (sin <-> cos: the angle pi/2 - a covers (pi/4, 3 pi/4]) and one SIGN bit (the angle + pi) -- bits 0 and 1 of the same half:
+// no quadrant reduction and no integer conversion, the same distribution.
+PDMP_MATH_FN Pair64 box_muller_core_v2(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+    const double u0 = bits_to_u_v<2>(w0, w1);
+    double rad = __dsqrt_rn(-2.0 * det_log_v2_inl(u0));
+    const double a = fma(mant_12(w2, w3), 1.57079632679489661923, -2.35619449019234492885);
+    const double sa = ksin_v2(a), ca = kcos_v2(a);
+    const bool sw = (w2 & 1u) != 0u;
+    rad = __hiloint2double(__double2hiint(rad) ^ (int)((w2 & 2u) << 30), __double2loint(rad));
+    Pair64 r;
+    r.a = rad * (sw ? sa : ca);
+    r.b = rad * (sw ? ca : sa);
+    return r;
+}
+template <int RV>
+__device__ __forceinline__ void box_muller_v(const uint32_t (&w)[4], double &z0, double &z1) {
+    if constexpr (RV == 1) {
+        const double u0 = bits_to_u_v<1>(w[0], w[1]), u1 = bits_to_u_v<1>(w[2], w[3]);
+        const double rad = __dsqrt_rn(-2.0 * det_log_v1(u0));
+        double sn, cs;
+        det_sincos_2pi_v1(u1, sn, cs);
+        z0 = rad * cs;
+        z1 = rad * sn;
+    } else {
+        const Pair64 r = box_muller_core_v2(w[0], w[1], w[2], w[3]);
+        z0 = r.a;
+        z1 = r.b;
+    }
+}
+
 // ---------------------------------------------------------------- per-chain random stream
 // One stream per chain (= per wave); all state is wave-uniform so the Philox rounds run on the
 // scalar unit.  Variate n uses block n>>1, half n&1 (spec: DESIGN.md "Random stream").
-struct ChainRng {
+template <int RV>
+struct ChainRngT {
+    static constexpr int kRounds = RV == 1 ? 10 : 7;
     uint32_t k0, k1, c2, c3;   // key = seed, counter high words = chain id
     uint64_t n;                // variates consumed
     uint32_t w2, w3;           // second half of the current block
@@ -269,7 +432,7 @@ struct ChainRng {
         if (n0 & 1) {
             uint32_t w[4];
             const uint64_t blk = n0 >> 1;
-            philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), c2, c3, k0, k1, w);
+            philox4x32<kRounds>((uint32_t)blk, (uint32_t)(blk >> 32), c2, c3, k0, k1, w);
             w2 = w[2]; w3 = w[3];
         }
     }
@@ -278,45 +441,39 @@ struct ChainRng {
         if ((n & 1) == 0) {
             uint32_t w[4];
             const uint64_t blk = n >> 1;
-            philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), c2, c3, k0, k1, w);
+            philox4x32<kRounds>((uint32_t)blk, (uint32_t)(blk >> 32), c2, c3, k0, k1, w);
             lo = w[0]; hi = w[1]; w2 = w[2]; w3 = w[3];
         } else {
             lo = w2; hi = w3;
         }
         ++n;
-        return bits_to_u(lo, hi);
+        return bits_to_u_v<RV>(lo, hi);
     }
-    __device__ __forceinline__ double exponential() { return -det_log(uniform()); }
+    __device__ __forceinline__ double exponential() { return -det_log_v<RV>(uniform()); }
     // the four words of block `blk` of this stream (variates 2 blk and 2 blk + 1), stateless
     __device__ __forceinline__ void block_at(uint64_t blk, uint32_t (&w)[4]) const {
-        philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), c2, c3, k0, k1, w);
+        philox4x32<kRounds>((uint32_t)blk, (uint32_t)(blk >> 32), c2, c3, k0, k1, w);
     }
     // standard normal for coordinate i of a d-vector; call normals_done(d) once afterwards
     __device__ __forceinline__ double normal_coord(int i) const {
         const uint64_t blk = ((n + 1) >> 1) + (uint64_t)(i >> 1);
         uint32_t w[4];
-        philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), c2, c3, k0, k1, w);
-        const double u0 = bits_to_u(w[0], w[1]), u1 = bits_to_u(w[2], w[3]);
-        const double rad = __dsqrt_rn(-2.0 * det_log(u0));
-        double sn, cs;
-        det_sincos_2pi(u1, sn, cs);
-        return (i & 1) ? rad * sn : rad * cs;
+        philox4x32<kRounds>((uint32_t)blk, (uint32_t)(blk >> 32), c2, c3, k0, k1, w);
+        double z0, z1;
+        box_muller_v<RV>(w, z0, z1);
+        return (i & 1) ? z1 : z0;
     }
     // both normals of pair P (coordinates 2P and 2P+1) from one Philox block
     __device__ __forceinline__ void normal_pair(int P, double &z0, double &z1) const {
         const uint64_t blk = ((n + 1) >> 1) + (uint64_t)P;
         uint32_t w[4];
-        philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), c2, c3, k0, k1, w);
-        const double u0 = bits_to_u(w[0], w[1]), u1 = bits_to_u(w[2], w[3]);
-        const double rad = __dsqrt_rn(-2.0 * det_log(u0));
-        double sn, cs;
-        det_sincos_2pi(u1, sn, cs);
-        z0 = rad * cs;
-        z1 = rad * sn;
+        philox4x32<kRounds>((uint32_t)blk, (uint32_t)(blk >> 32), c2, c3, k0, k1, w);
+        box_muller_v<RV>(w, z0, z1);
     }
     __device__ __forceinline__ void normals_done(int d) {
         n = ((n + 1) & ~1ull) + 2 * (uint64_t)((d + 1) / 2);
     }
 };
+using ChainRng = ChainRngT<kRngVersion>;
 
-}  // namespace pdmp
+PDMP_NS_END

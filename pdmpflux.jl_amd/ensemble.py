@@ -172,8 +172,12 @@ def sample_skeleton_device(sampler: AbstractPDMP, n_sk: int, xinit: torch.Tensor
             nbytes = torch.empty((), dtype=dtype).element_size()
             for k in shape:
                 nbytes *= int(k)
-            # large arrays from independent physical chunks: their launch time does not depend on the placement lottery of hipMalloc
-            tns = alloc_chunked(shape, dtype, dev) if nbytes >= CHUNKED_FROM_BYTES else torch.empty(shape, dtype=dtype, device=dev)
+            # large arrays from independent physical chunks: their launch time does not depend on the placement lottery of hipMalloc --
+            # in a single-process run only: memory mapped through HIP's virtual-memory API is enabled for the local device alone and has
+            # never been handed to RCCL on hardware, so a multi-rank run keeps torch's allocator for everything it may exchange
+            import torch.distributed as _dist
+            multi = _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1
+            tns = alloc_chunked(shape, dtype, dev) if (nbytes >= CHUNKED_FROM_BYTES and not multi) else torch.empty(shape, dtype=dtype, device=dev)
             o[name] = tns
         _need_cuda(tns)
         return tns
@@ -481,6 +485,14 @@ def shard_range(C_total: int, rank: int, world: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def batch_shard_range(C_total: int, batch: int, n_batches: int, rank: int, world: int) -> tuple[int, int]:
+    """The pipelined partition (``sample_skeleton_sharded(pipeline=B)``): the ensemble is cut into ``n_batches`` contiguous batches,
+    each batch into ``world`` contiguous shards; returns the global chain range of ``rank`` inside ``batch``."""
+    a, b = shard_range(C_total, batch, n_batches)
+    lo, hi = shard_range(b - a, rank, world)
+    return a + lo, a + hi
+
+
 def _all_gather_rows(local: torch.Tensor, C_total: int, world: int, group) -> torch.Tensor:
     """All-gather along dim 0 of per-rank shards of (possibly) unequal length: pad to the longest shard,
     one all_gather_into_tensor (RCCL: one direct exchange per peer link), then drop the padding."""
@@ -498,12 +510,15 @@ def _all_gather_rows(local: torch.Tensor, C_total: int, world: int, group) -> to
     return torch.cat(parts, 0) if pad or world > 1 else full
 
 
-def _gather_in_place(full: torch.Tensor, C_total: int, rank: int, world: int, group, via_host: bool = False) -> None:
+def _gather_in_place(full: torch.Tensor, C_total: int, rank: int, world: int, group, via_host: bool = False, async_op: bool = False) -> list:
     """The all-gather of one output array, in place: ``full`` holds ``C_total`` rows on every rank, rank r has filled rows
     ``shard_range(C_total, r, world)``.  Equal shards: ONE all_gather_into_tensor whose input is this rank's slice of the output
     (RCCL's in-place form: no staging copy; one direct exchange per xGMI peer link).  Unequal shards: one broadcast per shard
-    (all-gather-v).  ``via_host`` (rehearsals of GPU ranks under gloo) / CPU tensors: through a copy, gloo does not alias."""
+    (all-gather-v).  ``via_host`` (rehearsals of GPU ranks under gloo) / CPU tensors: through a copy, gloo does not alias.
+    ``async_op`` (device path): the collectives are enqueued behind the work already on the current stream and run on the backend's
+    own stream; the returned work handles are waited for by the caller -- kernels launched meanwhile overlap the exchange."""
     import torch.distributed as dist
+    works = []
     ranges = [shard_range(C_total, r, world) for r in range(world)]
     lo, hi = ranges[rank]
     equal = len({b - a for a, b in ranges}) == 1
@@ -521,22 +536,27 @@ def _gather_in_place(full: torch.Tensor, C_total: int, rank: int, world: int, gr
         for r, (a, b) in enumerate(ranges):
             if r != rank:
                 full[a:b].copy_(parts[r])
-        return
+        return works
     if equal:
         try:
-            dist.all_gather_into_tensor(full, full[lo:hi], group=group)          # in place: input = this rank's slice of the output
+            w = dist.all_gather_into_tensor(full, full[lo:hi], group=group, async_op=async_op)          # in place: input = this rank's slice of the output
         except (RuntimeError, ValueError):                                        # a backend that refuses aliased buffers (argument check:
-            dist.all_gather_into_tensor(full, full[lo:hi].clone(), group=group)   # every rank takes the same branch)
+            w = dist.all_gather_into_tensor(full, full[lo:hi].clone(), group=group, async_op=async_op)   # every rank takes the same branch)
+        if async_op and w is not None:
+            works.append(w)
     else:
         for r, (a, b) in enumerate(ranges):
             if b > a:
-                dist.broadcast(full[a:b], src=dist.get_global_rank(group, r) if group is not None else r, group=group)
+                w = dist.broadcast(full[a:b], src=dist.get_global_rank(group, r) if group is not None else r, group=group, async_op=async_op)
+                if async_op and w is not None:
+                    works.append(w)
+    return works
 
 
 def sample_skeleton_sharded(sampler: AbstractPDMP, n_sk: int, xinit: torch.Tensor, vinit: torch.Tensor, *, seed,
                             gather: str = "none", N_samples: int | None = None, group=None, compute=None,
                             out_full: dict | None = None, check: bool = True, via_host: bool = False,
-                            lanes: str | int | None = None) -> dict:
+                            lanes: str | int | None = None, pipeline: int = 1) -> dict:
     """Ensemble over all ranks of ``group``.  ``xinit``/``vinit`` hold ALL ``C_total`` chains on every
     rank (cheap: 16 d bytes per chain); this rank samples its contiguous shard.
 
@@ -549,6 +569,11 @@ def sample_skeleton_sharded(sampler: AbstractPDMP, n_sk: int, xinit: torch.Tenso
     "none": shard-sized); the shard is sampled straight into its rows and the gather runs in place (``_gather_in_place``).
     ``lanes``: "auto" picks the lanes-per-chain layout from the largest shard (pdmp_suggest_group_lanes), an int pins it;
     None leaves the handle as it is.  One layout for all ranks -- results are bit-identical across shardings for equal layouts.
+    ``pipeline`` = B > 1 (gather "skeleton" with ``out_full``): the exchange overlaps the sampling.  The ensemble is cut into B
+    contiguous batches of chains, every rank samples ITS shard of batch j (``batch_shard_range``) and the all-gather of batch j runs
+    on the backend's stream while the kernel of batch j + 1 runs on the launch stream: a step costs about max(exchange, sampling)
+    instead of their sum.  Chain ids stay global, so every chain's history is bit for bit what the unpipelined run (and a single
+    GPU) computes -- only which rank computes it changes.
     ``compute`` (tests only) replaces the HIP engine by a callable
     ``(x_shard, v_shard, chain0) -> {"X","V","t"}`` so the sharding logic can run under gloo on CPU.
     """
@@ -559,14 +584,41 @@ def sample_skeleton_sharded(sampler: AbstractPDMP, n_sk: int, xinit: torch.Tenso
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     C_total = xinit.shape[0]
     lo, hi = shard_range(C_total, rank, world)
-    xs, vs = xinit[lo:hi].contiguous(), vinit[lo:hi].contiguous()
     if lanes is not None and compute is None:
         G = sampler.suggest_group_lanes(shard_range(C_total, 0, world)[1]) if lanes == "auto" else int(lanes)
         sampler.set_group_lanes(G)
+    if pipeline and int(pipeline) > 1:
+        if gather != "skeleton" or out_full is None:
+            raise ArgumentError("pipeline > 1 overlaps the all-gather of gather = 'skeleton' with the sampling and needs out_full")
+        if any(out_full[k].shape[0] != C_total for k in ("X", "V", "t")):
+            raise DimensionMismatch(f"out_full tensors must hold {C_total} chains")
+        B = min(int(pipeline), max(1, C_total // max(world, 1)))
+        works = []
+        for j in range(B):
+            a, b = shard_range(C_total, j, B)                         # batch j: chains [a, b)
+            l2, h2 = batch_shard_range(C_total, j, B, rank, world)    # ... of which this rank samples [l2, h2)
+            if h2 > l2:
+                piece = {k: out_full[k][l2:h2] for k in ("X", "V", "t")}
+                if compute is None:
+                    sample_skeleton_device(sampler, n_sk, xinit[l2:h2].contiguous(), vinit[l2:h2].contiguous(), seed=seed, chain_id_offset=l2,
+                                           out=piece, check=False)
+                else:
+                    got = compute(xinit[l2:h2].contiguous(), vinit[l2:h2].contiguous(), l2)
+                    for k in ("X", "V", "t"):
+                        piece[k].copy_(got[k])
+            if world > 1:
+                for k in ("X", "V", "t"):
+                    works += _gather_in_place(out_full[k][a:b], b - a, rank, world, group, via_host=via_host, async_op=not via_host and out_full[k].is_cuda)
+        for w in works:
+            w.wait()                                                  # (the launch stream waits for the exchange; the host does not block)
+        if check and compute is None:
+            _lib.check(_lib.lib().pdmp_check_status(sampler.handle(), None))
+        return {"X": out_full["X"], "V": out_full["V"], "t": out_full["t"], "chain_range": (0, C_total), "pipeline": B}
+    xs, vs = xinit[lo:hi].contiguous(), vinit[lo:hi].contiguous()
     local_out = None
     if out_full is not None:
-        if gather not in ("none", "skeleton"):
-            raise ArgumentError("out_full serves gather = 'none' / 'skeleton'")
+        if gather not in ("none", "skeleton", "moments", "samples"):
+            raise ArgumentError("out_full serves gather = 'none' / 'skeleton' (and, shard-sized, 'moments' / 'samples')")
         want = C_total if gather == "skeleton" else hi - lo
         if any(out_full[k].shape[0] != want for k in ("X", "V", "t")):
             raise DimensionMismatch(f"out_full tensors must hold {want} chains")

@@ -41,7 +41,7 @@ class AbstractPDMP:
     name = "AbstractPDMP"
 
     def __init__(self, dim, target, *, grid_size, tmax, refresh_rate, vectorized_bound, signed_bound,
-                 adaptive, AD_backend, gaussian_velocity=False, device=-1, max_iter_per_event=0):
+                 adaptive, AD_backend, gaussian_velocity=False, device=-1, max_iter_per_event=0, rng_version=0):
         if not isinstance(dim, (int, np.integer)) or isinstance(dim, bool):
             raise TypeError("dim must be an Int")                    # MethodError in Julia
         if target is None or not hasattr(target, "target_id"):
@@ -66,6 +66,9 @@ class AbstractPDMP:
         self.gaussian_velocity = bool(gaussian_velocity)
         self.device = int(device)
         self.max_iter_per_event = int(max_iter_per_event)
+        # engine-only keyword (not in the reference): the arithmetic contract of the build-defined random stream and of log / exp / sin / cos
+        # (pdmp_config_t.rng_version: 0 = the default = 2; 1 = the contract of rounds 1-4, for the fixtures frozen then)
+        self.rng_version = int(rng_version)
         self._params = target.params(self.dim)
         self._handle = None
         self.state = None
@@ -82,7 +85,7 @@ class AbstractPDMP:
                            p, n, self.max_iter_per_event, float(getattr(self, "mix_p", 0.5)), int(getattr(self, "ran_p", False)),
                            int(getattr(self, "switch", True)), int(getattr(self, "positive", True)), 0,
                            float(getattr(self, "step_size", 0.05)), float(getattr(self, "phi", math.pi / 2)),
-                           float(getattr(self, "speed_factor", 1.0)))
+                           float(getattr(self, "speed_factor", 1.0)), int(self.rng_version), 0)
 
     def handle(self):
         if self._handle is None:

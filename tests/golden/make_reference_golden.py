@@ -22,9 +22,10 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "reference_order")
+OUT_V2 = os.path.join(HERE, "reference_order_v2")   # round 5: the same nineteen cases under arithmetic contract v2 (`--rng-version 2`), frozen once in the same way
 
 # name, sampler, kwargs (the reference constructors' defaults spelled out), target, dim
-def cases(O):
+def cases(O, rng_version=1):
     zzad = dict(sampler=O.ZIGZAG, grid_size=10, tmax=2.0, refresh_rate=0.0, vectorized_bound=True, deriv_mode=O.DERIV_FORWARD)
     zzfd = dict(zzad, deriv_mode=O.DERIV_FINITE_DIFF)
     bps = dict(sampler=O.BPS, grid_size=10, tmax=1.0, refresh_rate=0.1, vectorized_bound=False, deriv_mode=O.DERIV_FORWARD)
@@ -51,16 +52,18 @@ def cases(O):
         ("forwardecmc_banana_d6", fe, "banana", 6),
         ("forwardecmc_ranp_iso_d20", dict(fe, ran_p=True), "iso", 20),
         ("forwardecmc_fullrefresh_diag_d9", dict(fe, switch=False), "diag", 9),
-    ]
+    ] + ([] if rng_version == 1 else [
+        ("boomerang_fd_iso_d100_baseline", boo, "iso", 100),                     # BASELINE config 5 at the constructor's own refresh_rate = 0.1 (the v1 set holds 0.5 only)
+    ])
 
 
-def build_case(O, name, kw, target, d, C=2, n_sk=40, seed=20260104):
+def build_case(O, name, kw, target, d, C=2, n_sk=40, seed=20260104, rng_version=1):
     rs = np.random.default_rng(sum(map(ord, name)) + 17)
     params = None
     tid = {"iso": O.T_GAUSS_ISO, "diag": O.T_GAUSS_DIAG, "banana": O.T_BANANA}[target]
     if target == "diag":
         params = np.concatenate([rs.normal(size=d), np.exp(rs.uniform(-1, 1, size=d))])
-    cfg = O.Config(dim=d, target_id=tid, target_params=params, arith=O.ARITH_REFERENCE, **kw)
+    cfg = O.Config(dim=d, target_id=tid, target_params=params, arith=O.ARITH_REFERENCE, rng_version=rng_version, **kw)
     x = rs.normal(size=(C, d))
     if target == "banana":
         x = 1 + 0.1 * x
@@ -74,17 +77,19 @@ def build_case(O, name, kw, target, d, C=2, n_sk=40, seed=20260104):
     smp = O.sample_from_skeleton(cfg, 13, out["X"], out["V"], out["t"])
     keys = ("X", "V", "t", "horizon", "ar", "errored_bound", "error_value_ar", "rejected", "hitting_horizon")
     return dict(name=name, kwargs=repr(kw), target=target, dim=d, seed=seed, chain_id_offset=3, n_sk=n_sk, xinit=x, vinit=v,
-                params=np.zeros(0) if params is None else params, samples=smp, **{k: out[k] for k in keys})
+                params=np.zeros(0) if params is None else params, samples=smp, rng_version=rng_version, **{k: out[k] for k in keys})
 
 
 if __name__ == "__main__":
     sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
     from oracle import oracle as O
-    os.makedirs(OUT, exist_ok=True)
-    for name, kw, target, d in cases(O):
-        path = os.path.join(OUT, name + ".npz")
+    ver = int(sys.argv[sys.argv.index("--rng-version") + 1]) if "--rng-version" in sys.argv else 1
+    out_dir = OUT if ver == 1 else OUT_V2
+    os.makedirs(out_dir, exist_ok=True)
+    for name, kw, target, d in cases(O, ver):
+        path = os.path.join(out_dir, name + ".npz")
         if os.path.exists(path):
             print(name, "exists: kept (this set is frozen)")
             continue
-        np.savez_compressed(path, **build_case(O, name, kw, target, d))
+        np.savez_compressed(path, **build_case(O, name, kw, target, d, rng_version=ver))
         print(name, "written")

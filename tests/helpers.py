@@ -39,7 +39,8 @@ def make_pair(P, O, kind, dim, target="iso", arith=None, **kw):
                    gaussian_velocity=s.gaussian_velocity, deriv_mode=s.deriv_mode, target_id=tid,
                    target_params=params, arith=arith, group_lanes=group,
                    mix_p=getattr(s, "mix_p", 0.5), ran_p=getattr(s, "ran_p", False), switch=getattr(s, "switch", True),
-                   positive=getattr(s, "positive", True), step_size=getattr(s, "step_size", 0.05), phi=getattr(s, "phi", 1.5707963267948966), speed_factor=getattr(s, "speed_factor", 1.0))
+                   positive=getattr(s, "positive", True), step_size=getattr(s, "step_size", 0.05), phi=getattr(s, "phi", 1.5707963267948966), speed_factor=getattr(s, "speed_factor", 1.0),
+                   rng_version=getattr(s, "rng_version", 0))
     return s, cfg
 
 

@@ -44,7 +44,8 @@ CASES = [
     ("ZigZagAD", 300, "iso", {}, {}, FORM_GROUP),                            # K > 13: LDS form, G = 32
     ("ZigZagAD", 8, "iso", {"grid_size": 0}, {}, FORM_GROUP),                # Brent constant bound
     ("ZigZagAD", 50, "iso", {}, {"PDMP_TAPE_WAVE": "1"}, FORM_WAVE),         # round 1's replaying form
-    ("ZigZagAD", 7, "iso", {"grid_size": 6}, {}, FORM_WAVE),                 # grid sizes other than 10: wave per chain
+    ("ZigZagAD", 7, "iso", {"grid_size": 6}, {}, FORM_GROUP),                # grid sizes other than 10: the LDS-form group kernel (a run-time grid_size since round 5)
+    ("ZigZagAD", 7, "iso", {"grid_size": 6}, {"PDMP_GROUP_LANES": "0"}, FORM_WAVE),   # ... or, asked for, the wave-per-chain kernel as in rounds 1-4
     ("ZigZagAD", 40, "dense", {}, {}, FORM_GROUP),                           # round 4: the dense-precision target on the per-chain mat-vec kernel
     ("BPS", 33, "dense", {"refresh_rate": 0.5}, {}, FORM_GROUP),
     ("BoomerangAD", 33, "dense", {}, {}, FORM_GROUP),

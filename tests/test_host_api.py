@@ -109,7 +109,7 @@ def test_library_exports_every_declared_symbol(engine):
     for sym in decl:
         assert hasattr(L, sym), f"{sym} declared in include/pdmp_hip.h but not exported"
     assert sorted(_lib.SYMBOLS) == decl, "python binding table and header disagree"
-    assert _lib.lib().pdmp_abi_version() == 10
+    assert _lib.lib().pdmp_abi_version() == 11
 
 
 def test_fails_loudly_without_gpu(engine):

@@ -19,6 +19,74 @@ def test_philox_known_answers(oracle, ctr, key, out):
     assert oracle.philox(ctr, key) == out
 
 
+# Random123 v1.14 kat_vectors: philox4x32 7 rounds -- the generator of arithmetic contract v2 (the default since round 5)
+PHILOX7_KAT = [
+    ([0, 0, 0, 0], [0, 0], [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]),
+    ([0xffffffff] * 4, [0xffffffff] * 2, [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]),
+    ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+     [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a]),
+]
+
+
+@pytest.mark.parametrize("ctr,key,out", PHILOX7_KAT)
+def test_philox7_known_answers(oracle, ctr, key, out):
+    assert oracle.philox(ctr, key, rounds=7) == out
+
+
+@pytest.mark.parametrize("ver", [1, 2])
+def test_stream_layout_from_the_block_function(oracle, ver):
+    """DESIGN.md "Random stream": variate n of chain c under key `seed` = 64-bit half n & 1 of Philox block n >> 1 with counter
+    (block, chain); u = (top 52 bits + 0.5) 2^-52; Exp(1) = -log u.  v1: ten rounds, v2: seven."""
+    seed, chain = 0x1234567811223344, 77
+    u = oracle.rng_dump(seed, chain, 0, 8, rng_version=ver)
+    e = oracle.rng_dump(seed, chain, 1, 8, rng_version=ver)
+    for n in range(8):
+        w = oracle.philox([n >> 1, 0, chain, 0], [seed & 0xffffffff, seed >> 32], rounds=10 if ver == 1 else 7)
+        bits = w[2 * (n & 1)] | (w[2 * (n & 1) + 1] << 32)
+        assert u[n] == ((bits >> 12) + 0.5) * 2.0 ** -52
+        assert e[n] == -oracle.log(u[n], rng_version=ver)
+
+
+def test_box_muller_v2_from_its_definition(oracle):
+    """Contract v2's normal pair from one block (oracle/pdmp_oracle.c: box_muller): radius sqrt(-2 log u0) from the first half; angle =
+    (m - 3/2) pi/2 with m in [1, 2) from the top 52 bits of the second half, bit 0 swaps sin and cos, bit 1 flips both signs."""
+    import mpmath
+    mpmath.mp.prec = 100
+    seed, chain, d = 99, 5, 64
+    z = oracle.rng_dump(seed, chain, 2, d, rng_version=2)
+    for p in range(d // 2):
+        w = oracle.philox([p, 0, chain, 0], [seed, 0], rounds=7)
+        b0, b1 = w[0] | (w[1] << 32), w[2] | (w[3] << 32)
+        u0 = mpmath.mpf((b0 >> 12) + 0.5) * mpmath.mpf(2) ** -52
+        rad = mpmath.sqrt(-2 * mpmath.log(u0))
+        a = (mpmath.mpf(1) + mpmath.mpf(b1 >> 12) * mpmath.mpf(2) ** -52 - mpmath.mpf(3) / 2) * mpmath.pi / 2
+        sa, ca = mpmath.sin(a), mpmath.cos(a)
+        if b1 & 1:
+            sa, ca = ca, sa
+        if b1 & 2:
+            rad = -rad
+        assert abs(z[2 * p] - float(rad * ca)) < 1e-14 and abs(z[2 * p + 1] - float(rad * sa)) < 1e-14
+
+
+@pytest.mark.parametrize("ver", [1, 2])
+def test_elementary_functions_against_mpmath(oracle, ver):
+    """log / exp / sin / cos of both contracts within 2 ulp of the true values (fdlibm's series; v2 evaluates them by Horner on fma)."""
+    import mpmath
+    mpmath.mp.prec = 120
+    rs = np.random.default_rng(ver)
+
+    def ulps(got, ref):
+        rf = float(ref)
+        return float(abs(mpmath.mpf(got) - ref) / (math.ulp(rf) if rf != 0 else 5e-324))
+    for x in list(rs.random(2000)) + list(np.exp(rs.uniform(-40, 40, 2000))) + [1.0, 0.5, 2.0, 0.7071067811865476, 0.7071067811865475, 2.0 ** -53]:
+        assert ulps(oracle.log(x, ver), mpmath.log(mpmath.mpf(x))) < 1.0
+    for x in list(rs.uniform(-700, 700, 2000)) + list(rs.uniform(-1, 1, 2000)) + [0.0]:
+        assert ulps(oracle.exp(x, ver), mpmath.exp(mpmath.mpf(x))) < 1.0
+    for x in list(rs.uniform(-50, 50, 2000)) + [0.0, math.pi / 4, math.pi / 2, math.pi]:
+        s, c = oracle.sincos(x, ver)
+        assert abs(s - float(mpmath.sin(mpmath.mpf(x)))) < 1e-15 and abs(c - float(mpmath.cos(mpmath.mpf(x)))) < 1e-15
+
+
 def test_log_within_one_ulp_of_libm(oracle):
     rs = np.random.default_rng(0)
     xs = np.concatenate([rs.random(5000), 2.0 ** rs.uniform(-60, 0, 5000), 1 - 2.0 ** rs.uniform(-52, -1, 1000),
