@@ -555,12 +555,14 @@ def main():
         del full, own, tt
         sets.clear()
         torch.cuda.empty_cache()
+        ensemble.pool_trim()                                      # (the survey wants FRESH allocations: nothing may come back from the allocator's pool)
         for kind in ("chunked", "hipmalloc", "chunked_one_draw", "hipmalloc", "chunked"):
             cur = alloc_set(kind)
             ms = timed_launches(cur, 4, 1000 + 10 * len(placement))[1:]
             placement.append({"allocator": kind, "in_timed_region": False, "launches": len(ms), "kernel_ms": [round(m, 3) for m in ms], "alloc": alloc_log[-1]})
             del cur
             torch.cuda.empty_cache()
+            ensemble.pool_trim()
     if rank == 0:
         events_step = C_total * (n_sk - 1)
         value = events_step * a.steps / elapsed

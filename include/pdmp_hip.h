@@ -354,6 +354,11 @@ int pdmp_device_free(void *ptr);
  * undefined afterwards.  Each returned pointer is released with pdmp_device_free.  stride_bytes = 8 n_sk dim for X, V (C, n_sk, dim). */
 int pdmp_device_alloc_streams(int32_t device, int32_t n, const size_t *bytes, size_t chunk_bytes, size_t stride_bytes, int32_t draws,
                               void **out_ptrs, float *draw_ms, int32_t *n_drawn);
+/* The pool behind these allocators (round 5): pdmp_device_free PARKS an allocation -- address range and mapping intact -- and the next
+ * pdmp_device_alloc of the same size on the same device, or the next pdmp_device_alloc_streams of the same set of sizes, returns it
+ * (for a set judged before: *n_drawn = 0, nothing is drawn or timed again; microseconds instead of seconds).  Parked memory is released
+ * when an allocation would otherwise fail, or by pdmp_device_pool_trim().  PDMP_ALLOC_POOL=0 in the environment disables the pool. */
+int pdmp_device_pool_trim(void);
 const char *pdmp_device_alloc_error(void);
 
 /* Synthetic initial states of an ensemble, generated on the device (the ensemble API is new -- the reference starts its one chain

@@ -1,5 +1,5 @@
 # PDMPFluxHIP.jl -- the reference-side binding a PDMPFlux.jl maintainer would add (see INTEGRATION.md).
-# NOT executed anywhere in this pipeline (no Julia toolchain in the image); the same ABI (include/pdmp_hip.h, version 8) is
+# NOT executed anywhere in this pipeline (no Julia toolchain in the image); the same ABI (include/pdmp_hip.h, version 11) is
 # exercised through ctypes by tests/ and bench.py.  Struct layouts mirror the header field for field.
 #
 # Every constructor of the reference has a method here that takes a TARGET DESCRIPTOR in place of the closure `∇U` / `U`
@@ -19,7 +19,7 @@ using PDMPFlux: AbstractPDMP, PDMPHistory
 import PDMPFlux: sample, sample_skeleton, sample_from_skeleton
 
 const LIB = get(ENV, "PDMPHIP_LIB", "libpdmphip.so")
-const ABI_VERSION = 10
+const ABI_VERSION = 11
 
 # ---------------------------------------------------------------------------------------------- C structs (include/pdmp_hip.h)
 struct Config   # pdmp_config_t
@@ -30,6 +30,7 @@ struct Config   # pdmp_config_t
     fe_mix_p::Cdouble; fe_ran_p::Cint; fe_switch::Cint; fe_positive::Cint; fe_reserved::Cint   # ForwardECMC keywords
     rh_step_size::Cdouble; rh_phi::Cdouble                                                      # RHMC keywords
     fe_speed_factor::Cdouble                                                                    # ForwardECMC speed_factor
+    rng_version::Cint; reserved0::Cint     # arithmetic contract of the engine's random stream and log / exp / sin / cos: 0 = default (2), 1 = rounds 1-4
 end
 struct Diag     # pdmp_diag_t
     horizon::Ptr{Cdouble}; ar::Ptr{Cdouble}; errored_bound::Ptr{Int32}
@@ -92,7 +93,7 @@ function make(id::Int, name::String, dim::Int, target::Target; grid_size=10, tma
     p = vcat(params(target), extra)                                   # StickyZigZag: kappa travels as the last dim parameters
     cfg = Config(id, dim, grid_size, vectorized_bound, signed_bound, adaptive, Gaussian_velocity, deriv_mode(AD_backend),
                  target_id(target), device, Float64(tmax), Float64(refresh_rate), pointer(p), length(p), 0,
-                 Float64(mix_p), ran_p, switch, positive, 0, Float64(step_size), Float64(phi), Float64(speed_factor))
+                 Float64(mix_p), ran_p, switch, positive, 0, Float64(step_size), Float64(phi), Float64(speed_factor), 0, 0)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve p begin
         if target isa Union{HIPSource,HIPGradient}

@@ -225,9 +225,11 @@ double jl_randexp(jl_mt_t *m) {                                   /* randexp(rng
         if ((g_fe[idx - 1] - g_fe[idx]) * jl_rand(m) + g_fe[idx] < exp(-x)) return x;   /* fe[idx] - fe[idx+1] in 1-based indexing: the wedge */
     }
 }
-double jl_randn(jl_mt_t *m) {                                     /* randn(rng), normal.jl */
+/* _randn(rng, r) of normal.jl: one ziggurat attempt on the 52 random bits r; a rejection in the wedge falls back to a fresh randn(rng)
+ * (randn_unlikely ends in `return randn(rng)`), the tail loops on its own two draws */
+static double jl_randn_bits(jl_mt_t *m, uint64_t r) {
     for (;;) {
-        const uint64_t r = jl_next_bits(m) & DS_LOW_MASK;
+        r &= DS_LOW_MASK;
         const int64_t rabs = (int64_t)(r >> 1);                   /* one bit for the sign */
         const int idx = (int)(rabs & 0xFF);
         const double x = (double)((r & 1) ? -rabs : rabs) * g_wi[idx];
@@ -240,5 +242,25 @@ double jl_randn(jl_mt_t *m) {                                     /* randn(rng),
             }
         }
         if ((g_fi[idx - 1] - g_fi[idx]) * jl_rand(m) + g_fi[idx] < exp(-0.5 * x * x)) return x;   /* the wedge */
+        r = jl_next_bits(m);                                      /* rejected: randn(rng) again */
     }
+}
+double jl_randn(jl_mt_t *m) { return jl_randn_bits(m, jl_next_bits(m)); }   /* randn(rng), normal.jl */
+
+/* randn!(rng::MersenneTwister, A::Array{Float64}) (normal.jl, the MersenneTwister method generated for randn! / randexp!): arrays shorter than
+ * 13 are filled by scalar draws; longer ones are FIRST filled with rand!(rng, A, CloseOpen12()) -- for n <= 383 that is _rand_max383!: the next n
+ * doubles of the generator's cache, in order, exactly what n scalar draws would take -- and THEN every element is passed through
+ * _randn(rng, reinterpret(UInt64, A[i])): the draws a rejected element needs (0.7 % of them) come after the whole fill, not in between.
+ * This is what `randn!(rng, v)` (BouncyParticleSamplers.jl:67) and `randn(key, dim)` / `randn(key, 2, dim)` (ForwardEventChainMonteCarlo.jl)
+ * do on a plain MersenneTwister for dim >= 13; an AbstractRNG WRAPPED around it (julia/dump_tape.jl's TapeRNG) takes the generic loop of
+ * scalar draws instead (`scalar` != 0).  n > 383 (the dSFMT array-fill path with its alignment rules) is not restated: scalar order.
+ * Recalled from the Julia sources, unverified against a running Julia like the rest of this file. */
+void jl_randn_fill(jl_mt_t *m, int n, double *out, int scalar) {
+    if (scalar || n < 13 || n > 383) {
+        for (int i = 0; i < n; ++i) out[i] = jl_randn(m);
+        return;
+    }
+    uint64_t bits[383];
+    for (int i = 0; i < n; ++i) bits[i] = jl_next_bits(m);
+    for (int i = 0; i < n; ++i) out[i] = jl_randn_bits(m, bits[i]);
 }

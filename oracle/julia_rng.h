@@ -25,6 +25,7 @@ void   jl_dsfmt_close1_open2(uint32_t seed, int n, double *out);   /* dSFMT's ow
 double jl_rand(jl_mt_t *m);                  /* rand(rng)     in [0, 1) */
 double jl_randexp(jl_mt_t *m);               /* randexp(rng)  */
 double jl_randn(jl_mt_t *m);                 /* randn(rng)    */
+void   jl_randn_fill(jl_mt_t *m, int n, double *out, int scalar);   /* randn!(rng, A::Array{Float64}) of a plain MersenneTwister (bulk fill from 13 elements on), or n scalar draws */
 void   jl_sha256(const uint8_t *msg, size_t len, uint8_t out[32]);
 void   jl_zig_tables(const uint64_t **ki, const double **wi, const double **fi, const uint64_t **ke, const double **we, const double **fe);
 

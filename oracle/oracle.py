@@ -206,6 +206,7 @@ def sample_skeleton(cfg: Config, n_sk: int, xinit, vinit, seed: int, chain_id_of
 
 
 JL_SEED_LIMBS, JL_SEED_SHA256 = 1, 2
+JL_SCALAR_RANDN = 4        # + 4: vectors of normals as scalar draws (an AbstractRNG wrapped around the MersenneTwister); default: randn!'s bulk method from 13 elements on
 
 
 def sample_skeleton_julia(cfg: Config, n_sk: int, xinit, vinit, seed: int, seeding: int = JL_SEED_SHA256, tape_capacity=None,
@@ -249,6 +250,16 @@ def julia_draws(seed: int, n: int, kind: str = "rand", seeding: int = JL_SEED_LI
     L.orc_julia_draws.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_double)]
     out = np.empty(n)
     L.orc_julia_draws(int(seed), int(seeding), {"rand": 0, "randexp": 1, "randn": 2}[kind], n, _dp(out))
+    return out
+
+
+def julia_randn_fill(seed: int, n: int, scalar: bool = False, seeding: int = JL_SEED_LIMBS) -> np.ndarray:
+    """``randn!(MersenneTwister(seed), zeros(n))`` as restated (oracle/julia_rng.c: jl_randn_fill): the bulk method of a plain MersenneTwister
+    from 13 elements on, or -- ``scalar`` -- n scalar draws in index order."""
+    L = lib()
+    L.orc_julia_randn_fill.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    out = np.empty(n)
+    L.orc_julia_randn_fill(int(seed), int(seeding), int(n), int(bool(scalar)), _dp(out))
     return out
 
 

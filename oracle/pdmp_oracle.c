@@ -74,7 +74,7 @@ typedef struct { uint64_t seed; uint64_t chain; uint64_t n;
                  const double *te, *tu, *tn; int64_t ne, nu, nn, ie, iu, in; int *overrun;
                  /* Julia source (julia_rng.c): the chain's MersenneTwister and, optionally, the log of what it hands out (le / lu / ln: this
                   * chain's output tapes of capacity ce / cu / cn; je / ju / jn: variates logged so far) */
-                 jl_mt_t *jl; double *le, *lu, *ln; int64_t ce, cu, cn, je, ju, jn; } rng_t;
+                 jl_mt_t *jl; double *le, *lu, *ln; int64_t ce, cu, cn, je, ju, jn; int jl_scalar; } rng_t;
 static inline double jl_log_put(double v, double *tape, int64_t cap, int64_t *n, int *overrun) {
     if (tape) { if (*n < cap) tape[*n] = v; else if (overrun) *overrun = 1; }
     ++*n;
@@ -337,8 +337,10 @@ static double rng_exp(rng_t *r) {
 
 /* d standard normals; aligns the variate counter to a block boundary first. */
 static void rng_normals(rng_t *r, int d, double *z) {
-    if (r->jl) {            /* randn!(rng, v) / randn(dim) as d scalar draws in index order (what a wrapped rng -- julia/dump_tape.jl's TapeRNG -- sees) */
-        for (int i = 0; i < d; ++i) z[i] = jl_log_put(jl_randn(r->jl), r->ln, r->cn, &r->jn, r->overrun);
+    if (r->jl) {            /* randn!(rng, v) on the chain's MersenneTwister: the bulk method from 13 elements on (julia_rng.c: jl_randn_fill), or -- jl_scalar,
+                             * what an rng WRAPPED around it sees, julia/dump_tape.jl's TapeRNG -- d scalar draws in index order */
+        jl_randn_fill(r->jl, d, z, r->jl_scalar);
+        for (int i = 0; i < d; ++i) (void)jl_log_put(z[i], r->ln, r->cn, &r->jn, r->overrun);
         return;
     }
     if (r->tn) {
@@ -363,6 +365,13 @@ void orc_julia_draws(int64_t seed, int seeding, int kind, int64_t n, double *out
     jl_mt_t m;
     jl_mt_seed(&m, seed, seeding);
     for (int64_t i = 0; i < n; ++i) out[i] = (kind == 0) ? jl_rand(&m) : (kind == 1) ? jl_randexp(&m) : jl_randn(&m);
+}
+
+/* randn!(MersenneTwister(seed), Vector{Float64}(undef, n)) as restated in julia_rng.c (bulk method from 13 elements on; scalar != 0: n scalar draws) */
+void orc_julia_randn_fill(int64_t seed, int seeding, int n, int scalar, double *out) {
+    jl_mt_t m;
+    jl_mt_seed(&m, seed, seeding);
+    jl_randn_fill(&m, n, out, scalar);
 }
 
 void orc_rng_dump(uint64_t seed, int64_t chain, int kind, int64_t n_draw, double *out) {
@@ -1262,8 +1271,9 @@ static int run_chain(const orc_config_t *cfg, ws_t *w, int64_t n_sk, uint64_t se
     jl_mt_t jl_state;
 #define JL_COUNTS() do { if (cfg->julia_rng && cfg->jl_count) { int64_t *q_ = cfg->jl_count + 3 * (int64_t)chain; q_[0] = rng.je; q_[1] = rng.ju; q_[2] = rng.jn; } } while (0)
     if (cfg->julia_rng) {                           /* chain c <- MersenneTwister(seed + c) */
-        jl_mt_seed(&jl_state, (int64_t)(seed + chain), cfg->julia_rng);
+        jl_mt_seed(&jl_state, (int64_t)(seed + chain), cfg->julia_rng & 3);
         rng.jl = &jl_state;
+        rng.jl_scalar = (cfg->julia_rng & 4) != 0;  /* ORC_JL_SCALAR_RANDN: vectors of normals as scalar draws (an rng wrapped around the MersenneTwister) */
         if (cfg->jl_tape_exp) {
             const int64_t c = (int64_t)chain;
             rng.le = cfg->jl_tape_exp + c * cfg->jl_cap_exp; rng.ce = cfg->jl_cap_exp;

@@ -76,7 +76,11 @@ typedef struct orc_config_t {
     /* Julia random source (oracle/julia_rng.c): 0 = off (Philox or tapes); JL_SEED_LIMBS (1) / JL_SEED_SHA256 (2): chain c draws
      * from MersenneTwister(seed + c) -- the reference's own idiom for many chains, `seed = 42 + i`, test/test_property_based.jl:138 -- seeded as
      * Julia 1.0 - 1.10 / as Julia 1.11, through randexp / rand / randn in the reference's program order: one stream for the
-     * three kinds, as in the reference.  Unverified against a running Julia. */
+     * three kinds, as in the reference.  Vectors of normals (`randn!(rng, v)`, BouncyParticleSamplers.jl:67; `randn(key, dim)`, ForwardECMC) follow the
+     * MersenneTwister method of randn! -- from 13 elements on: bulk fill first, rejections drawn afterwards (julia_rng.c: jl_randn_fill) -- unless
+     * + 4 (ORC_JL_SCALAR_RANDN) asks for scalar draws in index order, what an rng WRAPPED around the MersenneTwister takes (julia/dump_tape.jl's TapeRNG).
+     * The Boomerang's refresh `randn(dim)` (BoomerangSamplers.jl:65) draws from Julia's GLOBAL rng, which the reference never seeds: not
+     * reproducible in the reference itself, drawn from the chain's stream here (Q8).  Unverified against a running Julia. */
     int32_t julia_rng;
     int32_t pad0_;
     /* ... and, when jl_tape_exp is set, the variates every chain consumed, per kind in consumption order: chain c (global id) at c * jl_cap_*,
@@ -144,7 +148,8 @@ void   orc_sincos(double x, double *s, double *c);
 void   orc_sincos_2pi(double u, double *s, double *c);
 /* first n_draw variates of chain stream (seed, chain): kind 0 uniform, 1 exp, 2 normal-vector (d=n_draw) */
 void   orc_rng_dump(uint64_t seed, int64_t chain, int kind, int64_t n_draw, double *out);
-void   orc_julia_draws(int64_t seed, int seeding, int kind, int64_t n, double *out);   /* rand / randexp / randn of the restated MersenneTwister(seed) */
+void   orc_julia_draws(int64_t seed, int seeding, int kind, int64_t n, double *out);
+void   orc_julia_randn_fill(int64_t seed, int seeding, int n, int scalar, double *out);   /* randn!(MersenneTwister(seed), zeros(n)): bulk method (n >= 13) or scalar draws */   /* rand / randexp / randn of the restated MersenneTwister(seed) */
 /* Synthetic initial states from stream 1 of each chain's key; mirrors pdmp_init_states_device. */
 enum { ORC_V_RADEMACHER = 0, ORC_V_GAUSSIAN = 1, ORC_V_SPHERE = 2 };
 void   orc_init_states(uint64_t seed, int64_t chain0, int64_t C, int d, double x_mean, double x_scale, int v_kind, double *x, double *v);

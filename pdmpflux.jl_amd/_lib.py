@@ -65,7 +65,7 @@ SYMBOLS = (
     "pdmp_sample_skeleton_until_device", "pdmp_close_chunk_device", "pdmp_until_advance_device", "pdmp_compact_chunk_device",
     "pdmp_multi_shard_range", "pdmp_multi_create", "pdmp_multi_destroy", "pdmp_multi_sample_skeleton", "pdmp_multi_sample_skeleton_device", "pdmp_multi_init_states", "pdmp_multi_get_timing",
     "pdmp_check_status", "pdmp_get_timing", "pdmp_reset_timing",
-    "pdmp_init_states_device", "pdmp_device_alloc", "pdmp_device_free", "pdmp_device_alloc_error", "pdmp_device_alloc_streams", "pdmp_debug_rng", "pdmp_dense_batched_last_phases", "pdmp_dense_batched_last_columns", "pdmp_dense_batched_last_mode",
+    "pdmp_init_states_device", "pdmp_device_alloc", "pdmp_device_free", "pdmp_device_alloc_error", "pdmp_device_alloc_streams", "pdmp_device_pool_trim", "pdmp_debug_rng", "pdmp_dense_batched_last_phases", "pdmp_dense_batched_last_columns", "pdmp_dense_batched_last_mode",
 )
 
 _lib = None

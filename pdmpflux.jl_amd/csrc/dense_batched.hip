@@ -23,6 +23,7 @@ extern "C" int pdmp_dgemm_mfma_polite(int max_wg, int M, int N, int K, const dou
 
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
 
 PDMP_NS_BEGIN
@@ -1004,24 +1005,45 @@ PDMP_NS_END
 
 using namespace pdmp;
 
-static long long g_last_phases = 0, g_last_columns = 0;
-static int g_last_mode = 0;
-static rocblas_handle db_handle(int device, int lane = 0) {        // rocBLAS handles per device (one per pipeline lane), created on first use
-    static rocblas_handle handles[16][2] = {{nullptr}};
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    if (device < 0 || device >= 16 || lane < 0 || lane > 1) return nullptr;
-    if (!handles[device][lane] && rocblas_create_handle(&handles[device][lane]) != rocblas_status_success) handles[device][lane] = nullptr;
-    return handles[device][lane];
-}
-// the second stream of a two-lane run and the events that fork / join it (per device, created on first use, never destroyed)
+// Diagnostics of the last batched run of this process (pdmp_dense_batched_last_*): atomics, written by whichever handle ran last.
+static std::atomic<long long> g_last_phases{0}, g_last_columns{0};
+static std::atomic<int> g_last_mode{0};
+// Everything a batched dense run needs beside its workspace -- the rocBLAS handles (one per pipeline lane; rocblas_set_stream on a handle
+// shared between two engine handles would race), the second stream of a two-lane run and the events that fork / join it -- belongs to
+// the ENGINE HANDLE that runs (round 5; rounds 1-4 kept them per device, process-wide): `pdmp_dense_bind_context(&handle->dense_ctx)` on
+// the calling thread right before a run, created on first use, released by pdmp_dense_destroy_context when the handle is destroyed.
+// "Distinct handles may be used from distinct host threads" (include/pdmp_hip.h) holds for the dense paths too.
 struct DbSide { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-static DbSide *db_side(int device) {
-    static DbSide sides[16];
+struct DenseCtx { rocblas_handle hb[2] = {nullptr, nullptr}; DbSide side; };
+static thread_local DenseCtx **g_ctx_slot = nullptr;
+extern "C" void pdmp_dense_bind_context(void **slot) { g_ctx_slot = (DenseCtx **)slot; }
+extern "C" void pdmp_dense_destroy_context(void *ctx_v) {
+    DenseCtx *c = (DenseCtx *)ctx_v;
+    if (!c) return;
+    for (int l = 0; l < 2; ++l) if (c->hb[l]) (void)rocblas_destroy_handle(c->hb[l]);
+    if (c->side.fork) (void)hipEventDestroy(c->side.fork);
+    if (c->side.join) (void)hipEventDestroy(c->side.join);
+    if (c->side.stream) (void)hipStreamDestroy(c->side.stream);
+    delete c;
+}
+static DenseCtx *db_ctx() {
+    static DenseCtx *fallback = nullptr;               // a caller that binds nothing (none in this library): one process-wide context
     static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    if (device < 0 || device >= 16) return nullptr;
-    DbSide &q = sides[device];
+    if (!g_ctx_slot) { std::lock_guard<std::mutex> lock(mu); if (!fallback) fallback = new DenseCtx(); return fallback; }
+    if (!*g_ctx_slot) *g_ctx_slot = new DenseCtx();
+    return *g_ctx_slot;
+}
+static rocblas_handle db_handle(int device, int lane = 0) {        // the bound context's rocBLAS handle of a pipeline lane, created on first use
+    (void)device;                                                  // (created with the handle's device current: the run functions set it)
+    if (lane < 0 || lane > 1) return nullptr;
+    DenseCtx *c = db_ctx();
+    if (!c->hb[lane] && rocblas_create_handle(&c->hb[lane]) != rocblas_status_success) c->hb[lane] = nullptr;
+    return c->hb[lane];
+}
+// the second stream of a two-lane run and the events that fork / join it (the bound context's, created on first use)
+static DbSide *db_side(int device) {
+    (void)device;
+    DbSide &q = db_ctx()->side;
     if (!q.stream) {
         if (hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking) != hipSuccess) { q.stream = nullptr; return nullptr; }
         if (hipEventCreateWithFlags(&q.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&q.join, hipEventDisableTiming) != hipSuccess) return nullptr;

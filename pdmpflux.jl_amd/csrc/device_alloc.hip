@@ -12,6 +12,7 @@
 // miss in the translation caches (TCP_UTCL1_TRANSLATION_MISS 1.2e5 -> 7e7 .. 1.3e8 per launch; 16.0 ms at 16 MiB, 22.5 ms at 2 MiB).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -22,12 +23,26 @@ namespace {
 
 struct ChunkedAlloc {
     int device = 0;
-    size_t va_bytes = 0;
+    size_t va_bytes = 0, bytes = 0, chunk = 0;      // bytes / chunk: what the caller asked for (the pool's key)
+    long long set_id = 0;                           // > 0: one of the arrays of a set pdmp_device_alloc_streams judged and kept; index in the set below
+    int set_index = 0;
     std::vector<hipMemGenericAllocationHandle_t> handles;
     std::vector<size_t> sizes;
 };
 std::mutex g_mu;
 std::map<void *, ChunkedAlloc> g_allocs;
+// The pool (round 5): a freed allocation keeps its address range AND its mapping and waits here for the next request of the same size on
+// the same device -- a caller that frees and re-allocates its output arrays (every fresh `alloc_outputs`) gets the very arrays back,
+// in microseconds instead of the 3 - 6.5 s of mapping and judging 80 GB again, and because nothing is ever unmapped and mapped anew there
+// is no stale translation to worry about.  Parked memory is released when an allocation would otherwise fail, by pdmp_device_pool_trim(),
+// or never parked at all with PDMP_ALLOC_POOL=0 (read once).
+std::map<void *, ChunkedAlloc> g_pool;
+long long g_next_set = 1;
+thread_local bool g_release_now = false;        // pdmp_device_alloc_streams frees the sets it did not keep for real (they must not wait in the pool beside the kept one)
+bool pool_enabled() {
+    static const bool on = [] { const char *e = getenv("PDMP_ALLOC_POOL"); return !(e && e[0] == '0'); }();
+    return on;
+}
 
 thread_local char g_err[256];
 
@@ -37,13 +52,18 @@ thread_local char g_err[256];
 // of an ORDINARY allocation flushes the translation caches, so every mapping made here is followed by one hipMalloc + hipFree of 64 MiB
 // (c16_stale2.jsonl: with it, kernel and copy agree in every variant).  Without this a pdmp_device_alloc that is handed the address range
 // of an earlier, freed allocation would let kernels write into memory that is no longer theirs.
-void flush_translations() {
-    for (size_t mib = 64; mib >= 2; mib /= 4) {                             // (64 MiB is what was measured; smaller ones only when the memory is that full)
+// Returns false when no trial allocation succeeded (memory completely full): the caller must then NOT hand out the mapping.
+// Since round 5 the hazard itself is designed out as well: an address range released here is never given back to the driver
+// (release_all keeps the reservation), so no later mapping can land on a range with old translations; the flush stays as the second fence.
+bool flush_translations() {
+    bool ok = false;
+    for (size_t mib = 64; mib >= 2 && !ok; mib /= 4) {                      // (64 MiB is what was measured; smaller ones only when the memory is that full)
         void *t = nullptr;
-        if (hipMalloc(&t, mib << 20) == hipSuccess) { (void)hipFree(t); break; }
-        (void)hipGetLastError();
+        if (hipMalloc(&t, mib << 20) == hipSuccess) { (void)hipFree(t); ok = true; }
+        else (void)hipGetLastError();
     }
     (void)hipGetLastError();
+    return ok;
 }
 
 void release_all(char *base, ChunkedAlloc &a, size_t mapped) {
@@ -53,7 +73,13 @@ void release_all(char *base, ChunkedAlloc &a, size_t mapped) {
         (void)hipMemRelease(a.handles[i]);
         off += a.sizes[i];
     }
-    if (base) (void)hipMemAddressFree(base, a.va_bytes);
+    // the address range stays reserved for the life of the process (it is only address space: 2^47 bytes of it): a range that is never
+    // returned can never be handed out again with stale translations behind it
+    (void)base;
+}
+void release_pool_locked() {
+    for (auto &kv : g_pool) release_all((char *)kv.first, kv.second, kv.second.handles.size());
+    g_pool.clear();
 }
 
 }  // namespace
@@ -74,8 +100,20 @@ int pdmp_device_alloc(int32_t device, size_t bytes, size_t chunk_bytes, void **o
     const size_t gran = (size_t)2 << 20;                                    // (the runtime reports 4 KiB; whole 2-MiB pages keep the translations large)
     size_t S = chunk_bytes ? chunk_bytes : ((size_t)1 << 30);
     S = (S + gran - 1) / gran * gran;
+    if (pool_enabled()) {                                                    // the same request as an allocation parked in the pool: that allocation
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (auto it = g_pool.begin(); it != g_pool.end(); ++it)
+            if (it->second.device == dev && it->second.bytes == bytes && it->second.chunk == chunk_bytes) {
+                void *p = it->first;
+                it->second.set_id = 0;                                       // (handed out on its own: no longer part of a judged set)
+                g_allocs[p] = it->second;
+                g_pool.erase(it);
+                *out = p;
+                return PDMP_OK;
+            }
+    }
     ChunkedAlloc a;
-    a.device = dev;
+    a.device = dev; a.bytes = bytes; a.chunk = chunk_bytes;
     for (size_t left = bytes; left > 0;) {
         const size_t want = left < S ? left : S;
         const size_t sz = (want + gran - 1) / gran * gran;
@@ -98,7 +136,14 @@ int pdmp_device_alloc(int32_t device, size_t bytes, size_t chunk_bytes, void **o
     size_t off = 0;
     for (size_t i = 0; i < a.sizes.size(); ++i) {
         hipMemGenericAllocationHandle_t h;
-        DA_TRY(hipMemCreate(&h, a.sizes[i], &prop, 0), i);
+        hipError_t ce = hipMemCreate(&h, a.sizes[i], &prop, 0);
+        if (ce != hipSuccess) {                                              // out of memory with allocations parked in the pool: release them, once more
+            (void)hipGetLastError();
+            bool trimmed = false;
+            { std::lock_guard<std::mutex> lk(g_mu); trimmed = !g_pool.empty(); if (trimmed) { (void)hipDeviceSynchronize(); release_pool_locked(); } }
+            if (trimmed) ce = hipMemCreate(&h, a.sizes[i], &prop, 0);
+        }
+        DA_TRY(ce, i);
         a.handles.push_back(h);
         DA_TRY(hipMemMap(base + off, a.sizes[i], 0, h, 0), i);
         off += a.sizes[i];
@@ -110,8 +155,13 @@ int pdmp_device_alloc(int32_t device, size_t bytes, size_t chunk_bytes, void **o
         int cur = dev;
         (void)hipGetDevice(&cur);
         if (cur != dev) (void)hipSetDevice(dev);
-        flush_translations();
+        const bool flushed = flush_translations();
         if (cur != dev) (void)hipSetDevice(cur);
+        if (!flushed) {                                                     // (memory so full that not even 4 MiB could be allocated and freed)
+            snprintf(g_err, sizeof g_err, "device_alloc: the translation caches could not be flushed after mapping (no memory left for the 4 MiB trial allocation)");
+            release_all(base, a, a.handles.size());
+            return PDMP_ERR_RUNTIME;
+        }
     }
 #undef DA_TRY
     {
@@ -193,7 +243,28 @@ int pdmp_device_alloc_streams(int32_t device, int32_t n, const size_t *bytes, si
     std::vector<void *> best(n, nullptr), cand(n, nullptr);
     float best_ms = -1.f;
     int rc = PDMP_OK, drawn = 0;
-    auto free_set = [&](std::vector<void *> &v) { for (auto &p : v) { if (p) (void)pdmp_device_free(p); p = nullptr; } };
+    if (pool_enabled()) {               // a set that was judged and kept before, then freed: all n of its arrays wait in the pool -> the same set again, nothing drawn
+        std::lock_guard<std::mutex> lk(g_mu);
+        std::map<long long, std::vector<void *>> sets;
+        for (auto &kv : g_pool) {
+            const ChunkedAlloc &q = kv.second;
+            if (q.set_id > 0 && q.device == dev && q.set_index < n && q.bytes == bytes[q.set_index] && q.chunk == chunk_bytes) {
+                auto &v = sets[q.set_id];
+                if (v.empty()) v.assign(n, nullptr);
+                v[q.set_index] = kv.first;
+            }
+        }
+        for (auto &sv : sets) {
+            bool whole = true;
+            for (void *p : sv.second) whole = whole && p != nullptr;
+            if (!whole) continue;
+            for (int i = 0; i < n; ++i) { g_allocs[sv.second[i]] = g_pool[sv.second[i]]; g_pool.erase(sv.second[i]); out_ptrs[i] = sv.second[i]; }
+            (void)hipSetDevice(cur);
+            if (n_drawn) *n_drawn = 0;                                       // (0 draws: the judged set of an earlier call)
+            return PDMP_OK;
+        }
+    }
+    auto free_set = [&](std::vector<void *> &v) { g_release_now = true; for (auto &p : v) { if (p) (void)pdmp_device_free(p); p = nullptr; } g_release_now = false; };
     for (int k = 0; k < (measure ? draws : 1); ++k) {
         if (k > 0) {                                                        // another set must fit beside the best one so far
             size_t fr = 0, tot = 0;
@@ -219,6 +290,11 @@ int pdmp_device_alloc_streams(int32_t device, int32_t n, const size_t *bytes, si
     }
     (void)hipSetDevice(cur);
     if (rc != PDMP_OK) return rc;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        const long long id = g_next_set++;
+        for (int i = 0; i < n; ++i) { auto it = g_allocs.find(best[i]); if (it != g_allocs.end()) { it->second.set_id = id; it->second.set_index = i; } }
+    }
     for (int i = 0; i < n; ++i) out_ptrs[i] = best[i];
     if (n_drawn) *n_drawn = drawn;
     return PDMP_OK;
@@ -239,8 +315,25 @@ int pdmp_device_free(void *ptr) {
     (void)hipGetDevice(&cur);
     (void)hipSetDevice(a.device);
     (void)hipDeviceSynchronize();                                           // no kernel may still be writing through the mapping
-    release_all((char *)ptr, a, a.handles.size());
-    flush_translations();                                                  // (no translation of the released memory may outlive it)
+    if (pool_enabled() && !g_release_now) {                                 // parked: address range and mapping intact, for the next request of this size
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_pool[ptr] = a;
+    } else {
+        release_all((char *)ptr, a, a.handles.size());
+        (void)flush_translations();                                         // (no translation of the released memory may outlive it)
+    }
+    (void)hipSetDevice(cur);
+    return PDMP_OK;
+}
+
+int pdmp_device_pool_trim(void) {
+    g_err[0] = 0;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto &kv : g_pool) { (void)hipSetDevice(kv.second.device); (void)hipDeviceSynchronize(); }
+    release_pool_locked();
+    (void)flush_translations();
     (void)hipSetDevice(cur);
     return PDMP_OK;
 }

@@ -12,6 +12,7 @@
 // step's MFMAs issue.  An fp64 MFMA occupies its SIMD for 64 cycles: eight independent accumulators per wave keep it issuing back to back.  Workgroups are numbered so that each XCD works on a contiguous range of tiles (M fastest): the B slab of a tile
 // column is fetched into ONE L2.  Edges: M and N by clamped loads + masked stores, K by zero-filled A rows.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256, 3) void dgemm_mfma_kernel(int M, int N, int K,
 // dimension goes to rocBLAS).  Returns 0 or the hipError_t of the launch.
 // pdmp_dgemm_mfma_polite: the same product launched so that at most `max_wg` of its workgroups fit on a CU (extra, unused dynamic LDS): a kernel
 // of another stream -- the step kernel of the other half-ensemble, dense_batched.hip -- finds registers and LDS beside it.
-static int g_polite_wg = 0;
+static thread_local int g_polite_wg = 0;      // (per calling thread: two engine handles on two host threads may run products at once)
 extern "C" int pdmp_dgemm_mfma(int M, int N, int K, const double *A, int lda, const double *B, int ldb, double *C, int ldc, void *stream);
 extern "C" int pdmp_dgemm_mfma_polite(int max_wg, int M, int N, int K, const double *A, int lda, const double *B, int ldb, double *C, int ldc, void *stream) {
     g_polite_wg = max_wg;
@@ -149,9 +150,15 @@ extern "C" int pdmp_dgemm_mfma(int M, int N, int K, const double *A, int lda, co
     static double *zeros[16] = {nullptr};              // 16 bytes of zeros per device, allocated on first use, never freed
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return (int)hipErrorInvalidDevice;
-    if (!zeros[dev]) {
-        if (hipMalloc(&zeros[dev], 64) != hipSuccess) return (int)hipErrorOutOfMemory;
-        if (hipMemset(zeros[dev], 0, 64) != hipSuccess) return (int)hipErrorUnknown;
+    {
+        static std::mutex zmu;
+        std::lock_guard<std::mutex> lock(zmu);
+        if (!zeros[dev]) {
+            double *z = nullptr;
+            if (hipMalloc(&z, 64) != hipSuccess) return (int)hipErrorOutOfMemory;
+            if (hipMemset(z, 0, 64) != hipSuccess) { (void)hipFree(z); return (int)hipErrorUnknown; }
+            zeros[dev] = z;
+        }
     }
     // 128 x 64 tiles unless they would leave the last round of tiles mostly alone on the machine (a lone workgroup per CU does not fill the
     // matrix core): then 64 x 64 tiles, twice as many.  PDMP_DGEMM_BM = 64 | 128 pins the shape (A/B runs).

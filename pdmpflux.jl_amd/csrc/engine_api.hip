@@ -92,6 +92,8 @@ extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_b
                                   int32_t *status, void *stream, void **ws, size_t *ws_cap, int64_t resync_events, int gemm_impl, int lanes,
                                   double t_stop, int resume, int64_t n_launch, const int64_t *chain_map, int64_t *count, char *err, int errlen);   // dense_batched.hip: BPS, one GEMM per event
 
+extern "C" void pdmp_dense_bind_context(void **slot);        // dense_batched.hip: the rocBLAS handles / side stream of the batched dense forms, per engine handle
+extern "C" void pdmp_dense_destroy_context(void *ctx);
 extern "C" int pdmp_user_compile(int device, int sampler, int fd, int kind, int rng_version, const char *source, void **fn_out, char *err, int errlen);
 extern "C" int pdmp_user_launch(void *fn, const GroupParams *gp, void *stream);
 
@@ -167,6 +169,7 @@ struct pdmp_engine {
     int32_t *d_sched = nullptr;       // group kernel: [0] unit counter, [1..nb] per-batch progress
     size_t sched_cap = 0;
     double *d_state = nullptr;        // group kernel: per-chain hand-off state (2d+4 doubles)
+    void *dense_ctx = nullptr;        // batched dense forms: this handle's rocBLAS handles, side stream and events (dense_batched.hip: DenseCtx)
     void *dense_ws = nullptr;         // incremental dense form: [x | v], [P x | P v], per-chain scalars (dense_batched.hip)
     size_t dense_ws_cap = 0;
     size_t state_cap = 0;
@@ -1091,6 +1094,7 @@ int pdmp_destroy(pdmp_handle h) {
     if (h->d_sched) (void)hipFree(h->d_sched);
     if (h->d_state) (void)hipFree(h->d_state);
     if (h->dense_ws) (void)hipFree(h->dense_ws);
+    if (h->dense_ctx) { pdmp_dense_destroy_context(h->dense_ctx); h->dense_ctx = nullptr; }
     for (int q = 0; q < 3; ++q) if (h->d_tape[q]) (void)hipFree(h->d_tape[q]);
     delete h;
     return PDMP_OK;
@@ -1221,6 +1225,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
                                           "(>= 64 chains, d <= 1024); no tape: rerun the fixed-count path with a doubled capacity instead");
     }
     const double t_stop = until ? until->T : __builtin_huge_val();
+    if (batched || bps_batched) pdmp_dense_bind_context(&h->dense_ctx);   // (this thread's batched dense runs use THIS handle's rocBLAS handles and side stream)
     if (batched) {
         char msg[256] = "";
         int rc = -5;

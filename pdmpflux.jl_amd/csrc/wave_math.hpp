@@ -276,6 +276,50 @@ __device__ __forceinline__ void det_sincos_v1(double x, double &s, double &c) {
 }
 
 
+// The coefficients of the v2 polynomials.  Default: literals -- the compiler emits v_fmac_f64 with the coefficient moved into the accumulator
+// by two v_mov_b32 (37 of a Box-Muller pair's ~150 vector instructions).  PDMP_SCONST (A/B, scripts/probes/bm_probe.hip): the coefficient
+// in a scalar register pair as the third operand of a hand-placed v_fma_f64 -- 40 % fewer vector instructions and SLOWER: 2.58 against
+// 2.08 ms per 4 000 pairs per lane at two waves per SIMD (the scalar moves and the wait state in front of each fma serialise with the
+// dependent chain), config 5 87.6 against 86.4 ms.  Measured, kept for the record, not the default.
+#ifdef PDMP_SCONST
+template <unsigned long long BITS>
+__device__ __forceinline__ double sconst_bits() {
+    unsigned lo, hi;
+    asm("s_mov_b32 %0, %1" : "=s"(lo) : "i"((int)(unsigned)(BITS & 0xffffffffull)));
+    asm("s_mov_b32 %0, %1" : "=s"(hi) : "i"((int)(unsigned)(BITS >> 32)));
+    return __hiloint2double((int)hi, (int)lo);
+}
+#define PDMP_SC(x) (sconst_bits<__builtin_bit_cast(unsigned long long, (double)(x))>())
+__device__ __forceinline__ double fma_k(double a, double b, double k_scalar) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k_scalar));
+    return r;
+}
+#define PDMP_FMA_K(a, b, K) fma_k((a), (b), PDMP_SC(K))
+#else
+#define PDMP_SC(x) (x)
+#define PDMP_FMA_K(a, b, K) fma((a), (b), (K))
+#endif
+// a / b and sqrt(x) for operands KNOWN to be finite, normal and far from the ends of the exponent range (the v2 functions below call them with
+// b in [1.7, 2.5] resp. x in [2e-16, 75]): the compiler's own expansions of the IEEE operations (v_rcp_f64 / v_rsq_f64 + Newton / Goldschmidt steps on
+// fma) WITHOUT their operand scaling (v_div_scale, v_div_fmas, v_div_fixup; the 2^256 pre-scale and the class test of sqrt), which is the identity
+// on such operands -- the same correctly rounded results as `/` and __dsqrt_rn (= the CPU checker's `/` and sqrt()), eight resp. ten
+// instructions instead of eleven resp. twenty.
+__device__ __forceinline__ double div_inrange(double a, double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(r, fma(-b, r, 1.0), r);
+    r = fma(r, fma(-b, r, 1.0), r);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+__device__ __forceinline__ double sqrt_inrange(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double s0 = x * y, h0 = 0.5 * y;
+    const double r0 = fma(-h0, s0, 0.5);
+    const double s1 = fma(s0, r0, s0), h1 = fma(h0, r0, h0);
+    const double s2 = fma(fma(-s1, s1, x), h1, s1);
+    return fma(fma(-s2, s2, x), h1, s2);
+}
 // ---- v2 (mirrored statement by statement by the CPU checker: log_v2 .. box_muller there; fma = v_fma_f64 = C fma())
 // A real function unless PDMP_INLINE_MATH is set (the lane kernels set it): inlined into the register-form group kernels -- built to the last
 // register of their budget -- it costs 2 .. 14 VGPRs more than the branchy v1 code did (measured: 19 translation units spilled; with the
@@ -286,7 +330,7 @@ __device__ __forceinline__ void det_sincos_v1(double x, double &s, double &c) {
 #define PDMP_MATH_FN __device__ __attribute__((noinline))
 #endif
 __device__ __forceinline__ double det_log_v2_inl(double x) {
-    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+    constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
                  Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
                  Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
                  Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
@@ -297,16 +341,16 @@ __device__ __forceinline__ double det_log_v2_inl(double x) {
     m = c ? m + m : m;
     e -= c ? 1 : 0;
     const double f = m - 1.0, dk = (double)e;
-    const double s = f / (2.0 + f), z = s * s;
-    const double P = fma(z, fma(z, fma(z, fma(z, fma(z, fma(z, Lg7, Lg6), Lg5), Lg4), Lg3), Lg2), Lg1);
+    const double s = div_inrange(f, 2.0 + f), z = s * s;
+    const double P = PDMP_FMA_K(z, PDMP_FMA_K(z, PDMP_FMA_K(z, PDMP_FMA_K(z, PDMP_FMA_K(z, PDMP_FMA_K(z, PDMP_SC(Lg7), Lg6), Lg5), Lg4), Lg3), Lg2), Lg1);
     const double R = z * P;
     const double hfsq = (0.5 * f) * f;
-    const double t = fma(s, hfsq + R, dk * ln2_lo);
-    return fma(dk, ln2_hi, f - (hfsq - t));
+    const double t = fma(s, hfsq + R, dk * PDMP_SC(ln2_lo));
+    return fma(dk, PDMP_SC(ln2_hi), f - (hfsq - t));
 }
 PDMP_MATH_FN double det_log_v2(double x) { return det_log_v2_inl(x); }   // (a LEAF function: a call that calls again would need a stack)
 PDMP_MATH_FN double det_exp_v2(double x) {
-    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+    constexpr double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
                  invln2 = 1.44269504088896338700e+00, P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
                  P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
     if (x != x) return x;
@@ -315,25 +359,25 @@ PDMP_MATH_FN double det_exp_v2(double x) {
     const double kf = __builtin_rint(x * invln2);
     const double hi = fma(-kf, ln2HI, x), lo = kf * ln2LO;
     const double r = hi - lo, t = r * r;
-    const double P = fma(t, fma(t, fma(t, fma(t, P5, P4), P3), P2), P1);
+    const double P = PDMP_FMA_K(t, PDMP_FMA_K(t, PDMP_FMA_K(t, PDMP_FMA_K(t, PDMP_SC(P5), P4), P3), P2), P1);
     const double c = fma(-t, P, r);
     const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
     return __builtin_amdgcn_ldexp(y, (int)kf);
 }
 __device__ __forceinline__ double ksin_v2(double a) {
-    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+    constexpr double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
                  S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
                  S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
     const double z = a * a;
-    const double P = fma(z, fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2), S1);
+    const double P = PDMP_FMA_K(z, PDMP_FMA_K(z, PDMP_FMA_K(z, PDMP_FMA_K(z, PDMP_FMA_K(z, PDMP_SC(S6), S5), S4), S3), S2), S1);
     return fma(z * a, P, a);
 }
 __device__ __forceinline__ double kcos_v2(double a) {
-    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+    constexpr double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
                  C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
                  C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
     const double z = a * a;
-    const double P = fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
+    const double P = PDMP_FMA_K(z, PDMP_FMA_K(z, PDMP_FMA_K(z, PDMP_FMA_K(z, PDMP_FMA_K(z, PDMP_SC(C6), C5), C4), C3), C2), C1);
     return fma(z * z, P, fma(z, -0.5, 1.0));
 }
 // quadrant q mod 4 as one swap and two sign flips (integer operations on the sign words)
@@ -345,10 +389,10 @@ __device__ __forceinline__ void quadrant_v2(int q, double sa, double ca, double 
 }
 struct Pair64 { double a, b; };                                  // two doubles returned in registers
 PDMP_MATH_FN Pair64 sincos_core_v2(double x) {
-    const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
+    constexpr double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
                  pio2_1t = 6.07710050650619224932e-11;
     const double fn = __builtin_rint(x * invpio2);
-    const double a = fma(-fn, pio2_1t, fma(-fn, pio2_1, x));
+    const double a = fma(-fn, PDMP_SC(pio2_1t), fma(-fn, PDMP_SC(pio2_1), x));
     Pair64 r;
     quadrant_v2((int)fn, ksin_v2(a), kcos_v2(a), r.a, r.b);
     return r;
@@ -378,8 +422,8 @@ __device__ __forceinline__ void det_sincos_2pi(double u, double &s, double &c) {
 // no quadrant reduction and no integer conversion, the same distribution.
 PDMP_MATH_FN Pair64 box_muller_core_v2(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
     const double u0 = bits_to_u_v<2>(w0, w1);
-    double rad = __dsqrt_rn(-2.0 * det_log_v2_inl(u0));
-    const double a = fma(mant_12(w2, w3), 1.57079632679489661923, -2.35619449019234492885);
+    double rad = sqrt_inrange(-2.0 * det_log_v2_inl(u0));
+    const double a = fma(mant_12(w2, w3), PDMP_SC(1.57079632679489661923), PDMP_SC(-2.35619449019234492885));
     const double sa = ksin_v2(a), ca = kcos_v2(a);
     const bool sw = (w2 & 1u) != 0u;
     rad = __hiloint2double(__double2hiint(rad) ^ (int)((w2 & 2u) << 30), __double2loint(rad));

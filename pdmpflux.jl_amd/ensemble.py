@@ -95,6 +95,14 @@ class _StreamBuffer(_ChunkedBuffer):
         self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (self.ptr, False), "version": 2, "strides": None}
 
 
+def pool_trim() -> None:
+    """Release the device memory parked in the allocator's pool (pdmp_device_pool_trim): freed arrays of pdmp_device_alloc /
+    pdmp_device_alloc_streams wait there, mapping intact, for the next request of the same size."""
+    rc = _lib.lib().pdmp_device_pool_trim()
+    if rc != 0:
+        raise _lib.EngineError(rc, (_lib.lib().pdmp_device_alloc_error() or b"").decode())
+
+
 DEFAULT_DRAWS = 3                      # sets of (X, V, t) drawn by alloc_outputs for arrays of at least CHUNKED_FROM_BYTES
 last_alloc_info: dict = {}             # what the last alloc_outputs call measured: {"draws": k, "draw_ms": [...], "seconds": s}
 
@@ -493,10 +501,13 @@ def batch_shard_range(C_total: int, batch: int, n_batches: int, rank: int, world
     return a + lo, a + hi
 
 
-def _all_gather_rows(local: torch.Tensor, C_total: int, world: int, group) -> torch.Tensor:
+def _all_gather_rows(local: torch.Tensor, C_total: int, world: int, group, via_host: bool = False) -> torch.Tensor:
     """All-gather along dim 0 of per-rank shards of (possibly) unequal length: pad to the longest shard,
-    one all_gather_into_tensor (RCCL: one direct exchange per peer link), then drop the padding."""
+    one all_gather_into_tensor (RCCL: one direct exchange per peer link), then drop the padding.
+    ``via_host`` (rehearsals of GPU ranks under gloo): through host copies."""
     import torch.distributed as dist
+    if via_host and local.is_cuda:
+        return _all_gather_rows(local.cpu(), C_total, world, group).to(local.device)
     max_rows = -(-C_total // world)
     pad = max_rows - local.shape[0]
     if pad:
@@ -643,7 +654,7 @@ def sample_skeleton_sharded(sampler: AbstractPDMP, n_sk: int, xinit: torch.Tenso
                 res[k] = out_full[k]
         elif world > 1:
             for k in ("X", "V", "t"):
-                res[k] = _all_gather_rows(res[k], C_total, world, group)
+                res[k] = _all_gather_rows(res[k], C_total, world, group, via_host=via_host)
         res["chain_range"] = (0, C_total)
         return res
     if N_samples is None or N_samples <= 0:
@@ -658,7 +669,7 @@ def sample_skeleton_sharded(sampler: AbstractPDMP, n_sk: int, xinit: torch.Tenso
         smp = (sample_from_skeleton_device(sampler, N_samples, res["X"], res["V"], res["t"], is_active=res.get("is_active"))
                if compute is None else res["samples"])
     if gather == "samples":
-        res["samples"] = _all_gather_rows(smp, C_total, world, group) if world > 1 else smp
+        res["samples"] = _all_gather_rows(smp, C_total, world, group, via_host=via_host) if world > 1 else smp
         return res
     if gather == "moments":
         if smp is not None:
@@ -666,7 +677,12 @@ def sample_skeleton_sharded(sampler: AbstractPDMP, n_sk: int, xinit: torch.Tenso
             flat = smp.reshape(-1, d)
             m = torch.cat([flat.sum(0), (flat * flat).sum(0), flat.new_tensor([float(flat.shape[0])])])
         if world > 1:
-            dist.all_reduce(m, group=group)
+            if via_host and m.is_cuda:
+                mh = m.cpu()
+                dist.all_reduce(mh, group=group)
+                m = mh.to(m.device)
+            else:
+                dist.all_reduce(m, group=group)
         n = m[-1]
         mean = m[:d] / n
         res["mean"], res["var"], res["count"] = mean, m[d:2 * d] / n - mean * mean, n

@@ -57,12 +57,31 @@ def _worker(rank, world, port, outdir):
         r = ensemble.sample_skeleton_sharded(sampler, N_SK, x[:n], v[:n], seed=SEED, gather="skeleton", compute=compute, out_full=full)
         assert r["X"] is full["X"] and r["chain_range"] == (0, n)
         res[tag] = {k: full[k].numpy().copy() for k in ("X", "V", "t")}
+    # the pipelined exchange (round 5, bench.py --pipeline): batches of chains, each batch sharded over the ranks, its all-gather issued
+    # while the next batch is sampled; ragged batches and ragged shards inside a batch (7 chains in 2 and in 3 batches over 2 ranks)
+    for tag, n, B in (("pipe2", C_TOTAL, 2), ("pipe3", C_TOTAL, 3), ("pipe3_equal", 6, 3), ("pipe_more_batches_than_chains", 3, 8)):
+        full = {"X": torch.zeros((n, N_SK, D), dtype=torch.float64), "V": torch.zeros((n, N_SK, D), dtype=torch.float64),
+                "t": torch.zeros((n, N_SK), dtype=torch.float64)}
+        r = ensemble.sample_skeleton_sharded(sampler, N_SK, x[:n], v[:n], seed=SEED, gather="skeleton", compute=compute, out_full=full, pipeline=B)
+        assert r["X"] is full["X"] and r["chain_range"] == (0, n) and 1 <= r["pipeline"] <= B
+        res[tag] = {k: full[k].numpy().copy() for k in ("X", "V", "t")}
     np.save(os.path.join(outdir, f"rank{rank}.npy"), np.array([res], dtype=object), allow_pickle=True)
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
+def test_batch_shard_ranges_partition_the_ensemble():
+    from pdmpflux.jl_amd.ensemble import batch_shard_range
+    for C_total, B, world in ((100000, 4, 8), (7, 3, 2), (6, 3, 2), (10, 4, 3), (5, 1, 2)):
+        seen = []
+        for j in range(B):
+            for r in range(world):
+                lo, hi = batch_shard_range(C_total, j, B, r, world)
+                seen += list(range(lo, hi))
+        assert seen == list(range(C_total))                                  # every chain exactly once, batch-major then rank-major
+
+
 def test_sharded_ensemble_world2(tmp_path, oracle):
     world = 2
     port = _free_port()
@@ -81,6 +100,8 @@ def test_sharded_ensemble_world2(tmp_path, oracle):
             assert np.array_equal(res["skeleton"][k], full[k]), (rank, k)              # all-gather: everyone has everything
             assert np.array_equal(res["inplace_ragged"][k], full[k]), (rank, k)        # bench.py's in-place exchange, ragged shards
             assert np.array_equal(res["inplace_equal"][k], full[k][:6]), (rank, k)     # ... and equal shards
+            assert np.array_equal(res["pipe2"][k], full[k]) and np.array_equal(res["pipe3"][k], full[k]), (rank, k)   # the pipelined exchange: the same bits
+            assert np.array_equal(res["pipe3_equal"][k], full[k][:6]) and np.array_equal(res["pipe_more_batches_than_chains"][k], full[k][:3]), (rank, k)
         assert np.array_equal(res["samples"]["samples"], full_s)
         flat = full_s.reshape(-1, D)
         np.testing.assert_allclose(res["moments"]["mean"], flat.mean(0), rtol=1e-12, atol=1e-14)

@@ -30,8 +30,30 @@ def test_bench_two_ranks_rehearsal():
     assert two["n_gpus"] == 2 and one["n_gpus"] == 1
     assert two["scaling"] == "strong" and two["unit"] == "events/s" and two["metric"] == one["metric"]
     c2 = two["config"]
-    assert c2["chains"] == 3001 and c2["chains_rank0"] == 1501                      # ragged shards: 1501 + 1500
+    assert c2["chains"] == 3001 and c2["chains_rank0"] == 1501                      # four batches of 751 / 750 chains, rank 0 takes 376 + 375 + 375 + 375
+    assert c2["pipeline_batches"] == 4 and c2["kernel_launches_per_step"] == 4
     assert c2["events_per_step"] == 3001 * 63 == one["config"]["events_per_step"]
     assert c2["exchange_bytes_per_gpu"] == 1500 * 64 * 8 * (2 * 50 + 1)             # rank 0 receives the other shard's X, V, t
-    assert two["value"] > 0 and two["roofline"]["kernel_ms"] > 0
+    assert two["value"] > 0 and two["roofline"]["kernel_ms"] > 0 and c2["exchange_ms"] > 0
     assert "hipMalloc" in c2["allocator"]                                           # the exchange buffers come from torch's allocator
+
+
+@pytest.mark.parametrize("extra", [[], ["--pipeline", "1"], ["--gather", "moments", "--n-samples", "32"], ["--gather", "samples", "--n-samples", "16"],
+                                   ["--gather", "none"]], ids=["pipelined", "unpipelined", "moments", "samples", "none"])
+def test_bench_launches_its_own_ranks(extra):
+    """Round 5: `python3 bench.py --gpus 2` WITHOUT a launcher around it (the way the driver calls `--gpus 1`) starts its two ranks itself,
+    before touching the GPU, and prints rank 0's one JSON line; here as a rehearsal on one GPU (both ranks on device 0, gloo)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PDMP_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--chains", "2000", "--n-sk", "48", "--cpu-seconds", "0",
+                "--pmc", "off"] + extra, env)
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["value"] > 0
+    c = res["config"]
+    gather = extra[1] if extra and extra[0] == "--gather" else "skeleton"
+    assert c["gather"] == gather and c["kernel_only_events_per_s"] > 0
+    if gather == "skeleton":
+        assert c["pipeline_batches"] == (1 if "--pipeline" in extra else 4) and c["exchange_ms"] > 0
+    if gather == "moments":
+        assert c["exchange_bytes_per_gpu"] == 8 * 101
+    if gather == "samples":
+        assert c["exchange_bytes_per_gpu"] == 1000 * 16 * 50 * 8

@@ -50,6 +50,14 @@ def test_device_alloc_abi(engine):
     assert L.pdmp_device_alloc(-1, 0, 0, C.byref(p)) == _lib.ERR_ARGUMENT
     assert L.pdmp_device_free(None) == 0
     torch.cuda.synchronize()
+    # round 5: the freed allocation is PARKED in the pool (mapping intact); the same request returns it at once, another size does not
+    assert torch.cuda.mem_get_info()[0] <= free0 - 3 * (1 << 30)
+    q, r = C.c_void_p(), C.c_void_p()
+    assert L.pdmp_device_alloc(-1, 3 * (1 << 30) + 12345, 0, C.byref(q)) == 0 and q.value == p.value
+    assert L.pdmp_device_alloc(-1, 3 * (1 << 30) + 12345, 0, C.byref(r)) == 0 and r.value not in (None, q.value)   # the pool is empty again: a fresh one
+    assert L.pdmp_device_free(q) == 0 and L.pdmp_device_free(r) == 0
+    assert L.pdmp_device_pool_trim() == 0
+    torch.cuda.synchronize()
     assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)            # the chunks went back to the driver
     # default policy of the host API: arrays of at least 1 GiB are chunked, smaller ones come from torch
     o = ensemble.alloc_outputs(3000, 1000, 50)
@@ -67,6 +75,7 @@ def test_streamed_outputs_are_drawn_and_equal_plain_outputs(engine, oracle):
     Cn, n_sk = 640, 64
     x, v = make_init("ZigZagAD", 50, Cn, seed=4)
     xd, vd = torch.from_numpy(x).cuda(), torch.from_numpy(v).cuda()
+    ensemble.pool_trim()
     free0 = torch.cuda.mem_get_info()[0]
     out = ensemble.alloc_outputs(Cn, n_sk, 50, chunked=True, draws=3)
     info = dict(ensemble.last_alloc_info)
@@ -77,8 +86,14 @@ def test_streamed_outputs_are_drawn_and_equal_plain_outputs(engine, oracle):
     assert_bitwise({k: got[k].cpu().numpy() for k in ("X", "V", "t")}, ref, keys=("X", "V", "t"))
     one = ensemble.alloc_outputs(Cn, n_sk, 50, chunked=True, draws=1)
     assert ensemble.last_alloc_info["draws"] == 1 and ensemble.last_alloc_info["draw_ms"] == []
+    ptr0 = out["X"].data_ptr()
     del out, got, one
     torch.cuda.synchronize()
+    again = ensemble.alloc_outputs(Cn, n_sk, 50, chunked=True, draws=3)     # round 5: the judged set comes back from the pool, in no time
+    assert ensemble.last_alloc_info["draws"] == 0 and again["X"].data_ptr() == ptr0 and ensemble.last_alloc_info["seconds"] < 0.05
+    del again
+    torch.cuda.synchronize()
+    ensemble.pool_trim()
 
 
 def test_alloc_streams_abi(engine):
@@ -92,12 +107,20 @@ def test_alloc_streams_abi(engine):
     drawn = C.c_int32(-1)
     assert L.pdmp_device_alloc_streams(-1, 3, sizes, 2 << 20, 4096, 4, ptrs, ms, C.byref(drawn)) == 0
     assert drawn.value == 4 and all(ms[i] > 0 for i in range(4)) and len({ptrs[i] for i in range(3)}) == 3
+    kept = [ptrs[i] for i in range(3)]
     for i in range(3):
         assert L.pdmp_device_free(C.c_void_p(ptrs[i])) == 0
+    # round 5: the judged set waits in the pool; the same request returns exactly it, nothing drawn or timed again
+    assert L.pdmp_device_alloc_streams(-1, 3, sizes, 2 << 20, 4096, 4, ptrs, ms, C.byref(drawn)) == 0
+    assert drawn.value == 0 and [ptrs[i] for i in range(3)] == kept
+    for i in range(3):
+        assert L.pdmp_device_free(C.c_void_p(ptrs[i])) == 0
+    assert L.pdmp_device_pool_trim() == 0
     # a stride that does not fit (not a multiple of 64 bytes) or unequal stream sizes: one set, no measurement
     assert L.pdmp_device_alloc_streams(-1, 3, sizes, 2 << 20, 100, 4, ptrs, None, C.byref(drawn)) == 0 and drawn.value == 1
     for i in range(3):
         assert L.pdmp_device_free(C.c_void_p(ptrs[i])) == 0
+    assert L.pdmp_device_pool_trim() == 0
     assert L.pdmp_device_alloc_streams(-1, 0, sizes, 0, 4096, 2, ptrs, None, None) == _lib.ERR_ARGUMENT
     zero = (C.c_size_t * 2)(1 << 20, 0)
     assert L.pdmp_device_alloc_streams(-1, 2, zero, 0, 4096, 2, ptrs, None, None) == _lib.ERR_ARGUMENT
@@ -118,6 +141,7 @@ def test_reused_addresses_point_at_the_new_memory(engine):
         keep.fill_(-7.0)
         torch.cuda.synchronize()
         del a
+        ensemble.pool_trim()                                                 # (really release it: the pool would hand the same mapping back)
         filler = torch.full((n,), 3.25, dtype=torch.float64, device="cuda")  # ordinary allocations may take the freed pages
         b = ensemble.alloc_chunked((n,), chunk_bytes=32 << 20)
         b.fill_(100.0 + rep)                                                 # written by a kernel
@@ -127,3 +151,4 @@ def test_reused_addresses_point_at_the_new_memory(engine):
         assert bool((keep.cpu() == -7.0).all()) and bool((filler.cpu() == 3.25).all())
         del b, keep, filler, host
         torch.cuda.synchronize()
+        ensemble.pool_trim()

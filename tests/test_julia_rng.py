@@ -98,3 +98,27 @@ def test_julia_source_run_replays_from_its_tapes(oracle, kind, dim, target, kw):
     # chain c draws from MersenneTwister(seed + c): chain 1 of seed 42 is chain 0 of seed 43
     c = O.sample_skeleton_julia(cfg, 60, x[1:2], v[1:2], 43)
     assert np.array_equal(c["t"][0], a["t"][1])
+
+
+def test_randn_fill_bulk_method(oracle):
+    """`randn!(rng::MersenneTwister, A::Array{Float64})` (Random/src/normal.jl, recalled): fewer than 13 elements are scalar draws; from 13 on the
+    array is first filled with the next n raw doubles and every element then goes through one ziggurat attempt, rejections drawing AFTER the
+    fill.  Until the first rejected element the two orders give the same values; the first n raw draws decide which element that is."""
+    for seed in range(1, 30):
+        assert np.array_equal(oracle.julia_randn_fill(seed, 12), oracle.julia_randn_fill(seed, 12, scalar=True))
+        assert np.array_equal(oracle.julia_randn_fill(seed, 12), oracle.julia_draws(seed, 12, "randn"))
+    differ = 0
+    for seed in range(1, 200):
+        n = 100
+        bulk, scal = oracle.julia_randn_fill(seed, n), oracle.julia_randn_fill(seed, n, scalar=True)
+        if np.array_equal(bulk, scal):
+            continue                                       # no element of the hundred was rejected (about half of the seeds)
+        differ += 1
+        k = int(np.argmax(bulk != scal))                   # the first rejected element: everything before it is the same draw in both orders
+        assert np.array_equal(bulk[:k], scal[:k])
+        # in the bulk order the elements AFTER the rejected one still come from raw draws k+1 .. n-1 of the fill: the scalar order has
+        # shifted them by the draws the rejection consumed, so its element j > k equals a later bulk-order raw draw only by accident
+        assert not np.array_equal(bulk[k + 1:], scal[k + 1:]) or k == n - 1
+    assert 50 < differ < 150                               # P(no rejection in 100 draws) = 0.993^100 = 0.5
+    z = np.concatenate([oracle.julia_randn_fill(s, 300) for s in range(300)])
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02 and abs((z ** 4).mean() - 3) < 0.15
