@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--refresh-rate", type=float, default=None, help="BPS / Boomerang refresh_rate (default: the constructor's)")
     ap.add_argument("--target", default="iso", choices=["iso", "diag", "banana", "dense", "src_banana"],
                     help="src_banana: U_banana given as source, differentiated by forward mode on the GPU (pdmp_create_from_source)")
+    ap.add_argument("--grid-size", type=int, default=None, help="grid_size of the bound (default: the constructor's 10; 0: Brent; any 2 .. 64 runs the LDS-form group kernel)")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time; 0 disables it")
     ap.add_argument("--alloc", default="auto", choices=["auto", "chunked", "hipmalloc"],
@@ -89,6 +90,8 @@ def live_counters(a):
         return None                                              # this run is itself being profiled: no nested profiler
     args = ["--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--pmc", "off", "--chains", str(a.chains), "--n-sk", str(a.n_sk),
             "--dim", str(a.dim), "--sampler", a.sampler, "--target", a.target, "--seed", str(a.seed), "--lanes", a.lanes]
+    if a.grid_size is not None:
+        args += ["--grid-size", str(a.grid_size)]
     if a.refresh_rate is not None:
         args += ["--refresh-rate", str(a.refresh_rate)]
     out, env = {}, dict(os.environ, TMPDIR="/tmp")
@@ -146,6 +149,8 @@ def make_sampler(P, a):
     tgt = {"iso": P.GaussianIso, "banana": P.Banana, "src_banana": lambda: P.SourcePotential(P.U_BANANA_SOURCE)}.get(a.target)
     tgt = tgt() if tgt else P.GaussianPrecision(dense_precision(a))
     kw = {} if a.refresh_rate is None else {"refresh_rate": a.refresh_rate}
+    if a.grid_size is not None:
+        kw["grid_size"] = a.grid_size
     if a.sampler.startswith("Sticky"):           # spike-and-slab: thawing rate 0.5 for every coordinate (tests/test_gpu_sticky.py's regime)
         import numpy as np
         return getattr(P, a.sampler)(a.dim, tgt, np.full(a.dim, 0.5), **kw)
@@ -271,6 +276,8 @@ def metric_label(a, sampler, C_total):
         extra += " (finite-difference slopes)"
     chains = "10^5" if C_total == 100_000 else ("10^4" if C_total == 10_000 else str(C_total))
     nsk = "" if a.n_sk == 1000 else f", n_sk={a.n_sk}"
+    if sampler.grid_size != 10 and not a.sampler.startswith("RHMC"):
+        extra += f" (grid_size={sampler.grid_size})"
     return f"skeleton-events/sec (whole node), {family} d={a.dim}{extra}, {chains} chains{nsk}"
 
 
@@ -681,6 +688,10 @@ def main():
                                "gemm_columns": cols,
                                "note": "achieved = 2 d^2 flop per multiplied column x columns / whole-launch time (GEMMs + step kernels); "
                                        "peak = MI355X fp64 matrix spec 78.6 TFLOP/s (datasheet; not in the local guide)"}
+        # beside `value`, at the top level: which allocator the timed arrays came from and what it cost (the selection runs before the timed region)
+        res["allocator"] = allocator
+        res["alloc_seconds"] = [q.get("seconds") for q in alloc_log[:n_sets]]
+        res["all_allocations_ms"] = res["config"]["all_allocations_ms"]
         if a.cpu_seconds > 0 and world == 1:                     # CPU baseline: rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(a, sampler)
         print(json.dumps(res), flush=True)

@@ -79,15 +79,30 @@ def test_lane_kernel_horizons(engine, oracle, lane, kw):
     assert_bitwise(got, oracle.sample_skeleton(cfg, 60, x, v, 3, diagnostics=True))
     # Which branches these cases reach (counted by the checker, equal in the engine by the comparison above): rejections in all of
     # them, horizon hits with the short horizons.  The `ar > 1` branch (erroneous_acceptance_rate!, SamplingLoopInplace.jl:131-151)
-    # is NOT reachable in this kernel: it serves the vectorised Zig-Zag bound on the isotropic Gaussian (rates linear in t) and the
-    # banana, whose only non-linear rate v1 g1(x + v t) is a cubic in t with leading coefficient 2 v1^4 > 0 -- concave, then convex --
-    # and for such a cell max(f(a), f(a) + f'(a) h, f(b)) is a true upper bound (UpperBound.jl:229-241 with quirk Q1's clamp).  The
-    # checker agrees: no erroneous bound in any of 70 x 59 events, here or with horizons up to 100.  The branch is exercised where it
-    # can fire: test_gpu_parity.py (scalar bounds, BPS / Boomerang, errored_bound.sum() > 10).
+    # does not fire at d = 50 (the checker counts no erroneous bound in any of 70 x 59 events, here or with horizons up to 100: the 48
+    # Gaussian coordinates dominate the rate); it does at d = 2, 3 with a fixed horizon of 20: test_lane_kernel_error_path below.
     assert got["rejected"].sum() > 0
     assert got["errored_bound"].sum() == 0
     if kw.get("tmax") in (0.05, 0.4):
         assert got["hitting_horizon"].sum() > 0
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("form", ["1", "2"])
+def test_lane_kernel_error_path(engine, oracle, monkeypatch, dim, form):
+    """The `ar > 1` branch of the lane kernels (erroneous_acceptance_rate!, SamplingLoopInplace.jl:131-151: the bound is rebuilt over half the
+    horizon with a fresh exponential, the ratio goes into the five-slot ring) DOES run where the banana's two twisted coordinates carry
+    most of the rate: d = 2, 3 with a fixed horizon of 20 (the checker counts 126 / 46 erroneous bounds in 70 x 199 events; none at d >= 5,
+    which is why round 4's d = 50 case above saw none) -- on the one-lane form and on the pair form, bit for bit incl. errored_bound and
+    error_value_ar."""
+    monkeypatch.setenv("PDMP_LANE", form)
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", dim, "banana", tmax=20.0, adaptive=False)
+    x, v = make_init("ZigZagAD", dim, 70, target="banana")
+    got = engine.sample_skeleton_ensemble(s, 200, x, v, seed=3, diagnostics=True)
+    assert s.last_launch_form() == (4 if form == "1" else 7)
+    ref = oracle.sample_skeleton(cfg, 200, x, v, 3, diagnostics=True)
+    assert ref["errored_bound"].sum() > 10 and (ref["error_value_ar"] > 1.0).any()
+    assert_bitwise(got, ref)
 
 
 def test_lane_kernel_zero_start(engine, oracle, lane):

@@ -35,6 +35,7 @@ WORKLOADS = [
     ("metric2_zigzagad_d50_banana_pair", "ZigZagAD", 50, "banana", {}, 10_000),
     ("zigzagad_d100_iso_pair", "ZigZagAD", 100, "iso", {}, 4_000),                 # d = 53 .. 104: a pair of lanes per chain, GROUP(8) order
     ("config3_bps_d50_banana", "BPS", 50, "banana", {}, 4_000),
+    ("config5_boomerang_d100_baseline", "Boomerang", 100, "iso", {}, 2_000),      # BASELINE config 5 at the constructor's own parameters: refresh_rate = 0.1, finite-difference slopes
     ("config5_boomerang_d100_fd", "Boomerang", 100, "iso", {"refresh_rate": 0.5}, 2_000),
     ("config5_boomerangad_d100", "BoomerangAD", 100, "iso", {"refresh_rate": 0.5}, 2_000),
     ("config4_zigzagad_d100_dense", "ZigZagAD", 100, "dense", {}, 1_000),
