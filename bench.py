@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--target", default="iso", choices=["iso", "diag", "banana", "dense", "src_banana"],
                     help="src_banana: U_banana given as source, differentiated by forward mode on the GPU (pdmp_create_from_source)")
     ap.add_argument("--grid-size", type=int, default=None, help="grid_size of the bound (default: the constructor's 10; 0: Brent; any 2 .. 64 runs the LDS-form group kernel)")
+    ap.add_argument("--rng-version", type=int, default=0, help="arithmetic contract of the random stream / elementary functions: 0 = default (2), 1 = rounds 1-4 (LDS-form kernels only)")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time; 0 disables it")
     ap.add_argument("--alloc", default="auto", choices=["auto", "chunked", "hipmalloc"],
@@ -151,6 +152,8 @@ def make_sampler(P, a):
     kw = {} if a.refresh_rate is None else {"refresh_rate": a.refresh_rate}
     if a.grid_size is not None:
         kw["grid_size"] = a.grid_size
+    if a.rng_version:
+        kw["rng_version"] = a.rng_version
     if a.sampler.startswith("Sticky"):           # spike-and-slab: thawing rate 0.5 for every coordinate (tests/test_gpu_sticky.py's regime)
         import numpy as np
         return getattr(P, a.sampler)(a.dim, tgt, np.full(a.dim, 0.5), **kw)

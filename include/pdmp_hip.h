@@ -145,7 +145,9 @@ int pdmp_suggest_group_lanes(pdmp_handle h, int64_t C);
 int pdmp_set_group_lanes(pdmp_handle h, int32_t G);
 /* Which kernel form serves a launch (results never depend on it) and the forms' tuning numbers are a per-handle POLICY, fixed when the
  * handle is created: defaults measured on MI355X, overridden by the PDMP_* environment variables of README.md (test hooks, tuning
- * scripts).  No launch reads the environment; a caller that changes it between launches of one handle calls this to re-read it. */
+ * scripts).  No launch reads the environment; a caller that changes it between launches of one handle calls this to re-read it.
+ * (Four process-wide tuning knobs are outside the policy and read ONCE per process, on first use: PDMP_DGEMM_POLITE, PDMP_DENSE_STEP_BLOCKS,
+ * PDMP_DGEMM_BM -- A/B knobs of the batched dense forms -- and PDMP_ALLOC_POOL.) */
 int pdmp_reload_policy(pdmp_handle h);
 /* Which kernel form served the handle's last pdmp_sample_skeleton* launch (waits for it to finish): a diagnostic for benchmarks and
  * tests, results do not depend on it.  PDMP_FORM_LANE: one lane per chain (csrc/lane_kernel.hpp; large Zig-Zag ensembles at

@@ -94,7 +94,7 @@ extern "C" int pdmp_dense_bps_run(int device, int boomerang, int d, int signed_b
 
 extern "C" void pdmp_dense_bind_context(void **slot);        // dense_batched.hip: the rocBLAS handles / side stream of the batched dense forms, per engine handle
 extern "C" void pdmp_dense_destroy_context(void *ctx);
-extern "C" int pdmp_user_compile(int device, int sampler, int fd, int kind, int rng_version, const char *source, void **fn_out, char *err, int errlen);
+extern "C" int pdmp_user_compile(int device, int sampler, int fd, int kind, int rng_version, int rtgrid, const char *source, void **fn_out, char *err, int errlen);
 extern "C" int pdmp_user_launch(void *fn, const GroupParams *gp, void *stream);
 
 // Launch policy of a handle: which kernel form serves a launch, and the tuning numbers of the forms.  Filled ONCE, when the handle is
@@ -979,7 +979,7 @@ static int create_impl(const pdmp_config_t *cfg, const char *source, int32_t kin
         if (h->group_lanes <= 0) { pdmp_destroy(h); return fail(PDMP_ERR_UNSUPPORTED, "potentials given as source: dim too large for the LDS tiles"); }
         static thread_local char log[sizeof g_err];
         log[0] = '\0';
-        const int rc = pdmp_user_compile(dev, c.sampler, c.deriv_mode == PDMP_DERIV_FINITE_DIFF, kind, c.rng_version, source, &h->user_fn, log, (int)sizeof log);
+        const int rc = pdmp_user_compile(dev, c.sampler, c.deriv_mode == PDMP_DERIV_FINITE_DIFF, kind, c.rng_version, (c.grid_size != GNG && c.grid_size != 0) ? 1 : 0, source, &h->user_fn, log, (int)sizeof log);
         if (rc != 0) {
             pdmp_destroy(h);
             // a potential that does not compile is the caller's mistake: the ArgumentError of ADBackend.jl:68-70

@@ -218,7 +218,10 @@ template <> struct GTarget<T_USER> {
 // records no diagnostic array and uses none of the time-horizon features (t_stop, resume, chain map, column counts) runs a kernel that
 // does not contain them -- their pointers, counters and the five-slot error ring cost scalar registers (spilled to VGPR lanes and
 // read back with v_readlane in the event loop) and instructions in kernels that are bound by VALU issue.
-template <int SAMPLER, int TARGET, bool FD, int KC = 0, int GC = 0, bool TAPE = false, bool LEAN = false>      // GC: lanes per chain when it is a compile-time constant (register form)
+// RTGRID (round 5, LDS form): grid_size is a run-time number (2 .. 64) instead of the constructors' default 10 -- a separate instantiation: with the
+// two kernels differ in registers (GroupOcc: Zig-Zag on the banana with finite-difference slopes holds three waves per SIMD only with the grid a
+// constant), so launches at grid_size 10 keep the kernel they had; measured otherwise equal (StickyZigZag 35.5 / 35.6 ms, SpeedUpZigZag 65.8 / 66.2).
+template <int SAMPLER, int TARGET, bool FD, int KC = 0, int GC = 0, bool TAPE = false, bool LEAN = false, bool RTGRID = false>      // GC: lanes per chain when it is a compile-time constant (register form)
 struct GroupChain {
     using Tgt = GTarget<TARGET>;
     static constexpr bool kReg = KC > 0;
@@ -240,8 +243,8 @@ struct GroupChain {
     // these kernels at all, which is what keeps them inside 2 waves per SIMD without spills.
     __device__ __forceinline__ bool brent() const { if constexpr (kReg) return false; else return p.n_grid == 0; }
     // grid_size of the bounds (UpperBound.jl:92,203: n_grid is a free parameter; the reference's tests use 5, 8, 10, 20): a run-time number
-    // in the LDS form (2 .. 64), the constructors' default in the register form
-    __device__ __forceinline__ int ng() const { if constexpr (kReg) return GNG; else return p.n_grid; }
+    // in the RTGRID instantiations of the LDS form (2 .. 64), the constructors' default -- a constant -- everywhere else
+    __device__ __forceinline__ int ng() const { if constexpr (RTGRID && !kReg) return p.n_grid; else return GNG; }
     __device__ __forceinline__ bool vectorized() const { if constexpr (kReg) return true; else return p.vectorized != 0; }
     __device__ __forceinline__ bool zz_signed() const { if constexpr (kReg) return true; else return p.signed_bound != 0; }
     // coordinate i = s*G + g exists (i < d): only the last slot K-1 can be partly padded (register form: a scalar test for the others)
@@ -697,6 +700,10 @@ struct GroupChain {
         const double num = (P.kind == 1) ? fp - fc : ((P.kind == 2) ? fc - fm : fp - fm);
         return (P.kind == 3) ? fc - fc : num / P.den;
     }
+    // (Round 5, measured and NOT shipped, on the vectorised Zig-Zag bound's 26 slopes per cell and lane at d = 50: (a) one refined reciprocal of
+    // P.den per grid time and the three closing steps of the division per coordinate; (b) the two TIMES of each quotient selected once per grid
+    // time instead of three values per coordinate.  Both are bit-identical to fd_slope and both made the LDS form SLOWER, 59.2 -> 68.7 ms at
+    // config-2 size: the compiler already hoists the denominator's half of its division expansion and the selects' conditions out of the slot loop.)
 
     // Progress of this lane's chain through its lazily built bound: cells [0, b_next) are summed.  The cells are built at most
     // `gp.cell_budget` per pass of the state machine: a chain that needs more (the ~2 % that run to the horizon need all nine)
@@ -1955,16 +1962,18 @@ __device__ __forceinline__ bool wait_progress(const int32_t *flag, int r) {
 // faulted at address 0, and StickyZigZag with 2x-unrolled slot loops returned wrong positions until its 12-25 spills were
 // gone).  The table below is set from the compiler's resource-usage remarks and the Makefile fails the build on any spill in
 // any inst_*.hip, so a change that adds register pressure has to lower a number here instead of shipping a spill.
-template <int SAMPLER, int TARGET, bool FD> struct GroupOcc {
+template <int SAMPLER, int TARGET, bool FD, bool RTGRID = false> struct GroupOcc {
     static constexpr int kWaves =
         (SAMPLER == S_SUZZ) ? ((TARGET == T_BANANA && !FD) ? 1 : 2)     // the flow's chain-level scalars and the speed duals on top of the Zig-Zag state
         : (TARGET == T_GAUSS_DENSE || SAMPLER == S_STICKY) ? 2          // the mat-vec's row accumulators; the active mask and the thaw clock
+        : (SAMPLER == S_ZIGZAG && TARGET == T_BANANA && FD && !RTGRID) ? 3   // (round 5: it fits 168 registers exactly when told to -- left at 2 the allocator took 169 and the
+                                                                        //  launch ran at two waves per SIMD, 96.6 -> 132 ms at config-2 size; round 4 had 167 by luck; the run-time-grid instantiation would spill 2)
         : (TARGET == T_BANANA || TARGET == T_USER) ? 2                  // banana + finite differences keeps six shared records
         : (SAMPLER == S_RHMC) ? 4
         : 3;                                                            // Zig-Zag, Boomerang, ForwardECMC on the separable Gaussians
 };
 
-template <int SAMPLER, int TARGET, bool FD, int KC = 0, int GC = 0, bool TAPE = false, bool LEAN = false>
+template <int SAMPLER, int TARGET, bool FD, int KC = 0, int GC = 0, bool TAPE = false, bool LEAN = false, bool RTGRID = false>
 __device__ __forceinline__ void group_kernel_body(const GroupParams &gp) {
     extern __shared__ double smem[];
     const int lane = lane_id();
@@ -1976,7 +1985,7 @@ __device__ __forceinline__ void group_kernel_body(const GroupParams &gp) {
     double *tile = smem + gp.tpar + (size_t)wave * gp.tiles * tsz;
     const int cpw = WAVE / gp.G;
     // register form: no x tile; one K*64-double tile per wave only where refreshed velocities are exchanged between lanes
-    GroupChain<SAMPLER, TARGET, FD, KC, GC, TAPE, LEAN> chain(gp, lane, tile, KC > 0 ? tile : tile + tsz);
+    GroupChain<SAMPLER, TARGET, FD, KC, GC, TAPE, LEAN, RTGRID> chain(gp, lane, tile, KC > 0 ? tile : tile + tsz);
     chain.tgt.init(smem, gp.s.d);
     if constexpr (SAMPLER == S_FECMC) {                              // (register form: the exchange tile first, then the four jump vectors)
         for (int q = 0; q < 4; ++q) chain.fe_t[q] = tile + ((KC > 0 ? 1 : 2) + q) * tsz;
@@ -2016,17 +2025,17 @@ __device__ __forceinline__ bool served_elsewhere(const GroupParams &gp) {
     return gp.only_if && __hip_atomic_load(gp.only_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
 }
 
-template <int SAMPLER, int TARGET, bool FD>
-__global__ __launch_bounds__(256, (GroupOcc<SAMPLER, TARGET, FD>::kWaves)) void group_kernel(const GroupParams gp) {
+template <int SAMPLER, int TARGET, bool FD, bool RTGRID = false>
+__global__ __launch_bounds__(256, (GroupOcc<SAMPLER, TARGET, FD, RTGRID>::kWaves)) void group_kernel(const GroupParams gp) {
     if (served_elsewhere(gp)) return;
-    group_kernel_body<SAMPLER, TARGET, FD>(gp);
+    group_kernel_body<SAMPLER, TARGET, FD, 0, 0, false, false, RTGRID>(gp);
 }
 // tape replay (inst_tape_*.hip): the same code with the tapes as random source; one wave per SIMD (512 registers: the tape
 // pointers and positions can never cause a spill, and a replay is a parity run, not a throughput run)
-template <int SAMPLER, int TARGET, bool FD>
+template <int SAMPLER, int TARGET, bool FD, bool RTGRID = false>
 __global__ __launch_bounds__(256, 1) void group_kernel_tape(const GroupParams gp) {
     if (served_elsewhere(gp)) return;
-    group_kernel_body<SAMPLER, TARGET, FD, 0, 0, true>(gp);
+    group_kernel_body<SAMPLER, TARGET, FD, 0, 0, true, false, RTGRID>(gp);
 }
 template <int SAMPLER, int TARGET, bool FD, int KC, int GC, bool FULL>
 __global__ __launch_bounds__(256, 1) void group_kernel_reg_tape(const GroupParams gp_in) {
@@ -2044,7 +2053,14 @@ __host__ __device__ constexpr int lane_state_words(int d) { return 2 * d + 4 < 8
 // full<GC>(): a separate instantiation without the skips for K == KC.  Set from the compiler's resource-usage remarks so that no
 // instantiation spills a VGPR (see below), and from measurements (Zig-Zag with finite differences: the LDS form is faster).
 template <int SAMPLER, int TARGET, bool FD> struct RegForm {
-    static constexpr bool kSlowZz = SAMPLER == S_ZIGZAG && FD;                       // measured: 88 ms against 73 ms in the LDS form
+    // Zig-Zag with finite-difference slopes (the default AD_backend of the manual-gradient constructor, ZigZagSamplers.jl:58-60): rounds 1-4
+    // kept it in the LDS form (13-slot register kernels spill 2 .. 59 registers with the six evaluations per coordinate and cell; seven slots at
+    // G = 8 were measured slower).  Round 5: the LEAN FULL 13-slot
+    // kernels on the Gaussians -- no diagnostic arrays, no time horizon -- are free of spills: exactly those are built (kLeanOnly); a launch
+    // that records diagnostics, the banana and every other slot count keep the LDS form.
+    static constexpr bool kZzFd = SAMPLER == S_ZIGZAG && FD;
+    static constexpr bool kLeanOnly = kZzFd;
+    static constexpr bool kSlowZz = kZzFd && TARGET == T_BANANA;
     // RHMC (round 4): the FULL 13-slot kernels are free of spills on the isotropic Gaussian and the banana, the ones with the per-slot
     // skips on the diagonal Gaussian (FULL there spills 2 - 4 registers with the diagnostic arrays compiled in); the slope mode plays no
     // part in RHMC (constant refresh clock): only FD = false is instantiated.  SpeedUpZigZag spills 110 - 700 registers in every variant
@@ -2055,7 +2071,7 @@ template <int SAMPLER, int TARGET, bool FD> struct RegForm {
     // VGPRs, no spill, two waves per SIMD; forward-mode slopes) -- d = 50: 50.4 -> 27.5 ms (iso), 72.3 -> 28.7 ms (banana) against the LDS form's best layout.
     static constexpr bool kRhmc = SAMPLER == S_RHMC;
     static constexpr bool kPartial = kRhmc ? (TARGET == T_GAUSS_DIAG)
-                                           : (!kSlowZz && !(SAMPLER == S_BOOMERANG && TARGET != T_GAUSS_DIAG));   // would spill: Boomerang iso / banana with the skips
+                                           : (!kZzFd && !(SAMPLER == S_BOOMERANG && TARGET != T_GAUSS_DIAG));   // would spill: Boomerang iso / banana with the skips
     template <int GC> static constexpr bool full() {        // would spill: Zig-Zag and (since the time-horizon stop of round 3) Boomerang on the diagonal Gaussian at one lane per chain
         if constexpr (kRhmc) return !(TARGET == T_GAUSS_DIAG && GC >= 2);
         return !kSlowZz && !((SAMPLER == S_ZIGZAG || SAMPLER == S_BOOMERANG) && TARGET == T_GAUSS_DIAG && GC == 1);
@@ -2127,15 +2143,18 @@ hipError_t launch_group_impl(const GroupParams &gp_in, hipStream_t stream) {
             if (gp.K == KC) kernel = group_kernel_reg_tape<SAMPLER, TARGET, FD, KC, GC, true>;
         } else {
             if constexpr (RF::kPartial && !EXACT) kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, false>;
-            if constexpr (RF::template full<GC>()) if (gp.K == KC) kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, true>;
+            if constexpr (RF::template full<GC>() && !RF::kLeanOnly) if (gp.K == KC) kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, true>;
             if constexpr (RF::template full<GC>() && KC == KREG) {             // the throughput kernels of the BASELINE shapes (d = 50 / G = 4, d = 100 / G = 8, ...)
                 const SkelParams &q = gp.s;
                 const bool plain = !(q.H || q.AR || q.EB || q.RJ || q.HH || q.EV || q.IA || q.count || q.chain_map || q.resume) && !(q.t_stop < __builtin_huge_val());
                 if (gp.K == KC && plain && !(gp.host_flags & 1)) kernel = group_kernel_reg<SAMPLER, TARGET, FD, KC, GC, true, true>;
             }
         }
-    } else if constexpr (TAPE) kernel = group_kernel_tape<SAMPLER, TARGET, FD>;
-    else kernel = group_kernel<SAMPLER, TARGET, FD>;
+    } else {
+        const bool rtgrid = gp.s.n_grid != GNG && gp.s.n_grid != 0;            // (0: the Brent bound, no grid at all)
+        if constexpr (TAPE) kernel = rtgrid ? group_kernel_tape<SAMPLER, TARGET, FD, true> : group_kernel_tape<SAMPLER, TARGET, FD, false>;
+        else kernel = rtgrid ? group_kernel<SAMPLER, TARGET, FD, true> : group_kernel<SAMPLER, TARGET, FD, false>;
+    }
     if (!kernel) return hipErrorNotSupported;
     hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -37,9 +37,9 @@ void put(char *err, int errlen, const std::string &s) {
 }  // namespace
 
 // 0 ok; -1 the source does not compile (log in err); -3 runtime failure
-extern "C" int pdmp_user_compile(int device, int sampler, int fd, int kind, int rng_version, const char *source, void **fn_out, char *err, int errlen) {
+extern "C" int pdmp_user_compile(int device, int sampler, int fd, int kind, int rng_version, int rtgrid, const char *source, void **fn_out, char *err, int errlen) {   // rtgrid: grid_size other than 10 / 0 (GroupChain: RTGRID)
     std::lock_guard<std::mutex> lock(g_mu);
-    const auto key = std::make_tuple(device, sampler, fd, kind + 16 * rng_version, std::string(source));   // (the arithmetic contract is part of the kernel)
+    const auto key = std::make_tuple(device, sampler, fd, kind + 16 * rng_version + 64 * (rtgrid ? 1 : 0), std::string(source));   // (the arithmetic contract is part of the kernel)
     auto it = g_cache.find(key);
     if (it != g_cache.end()) { *fn_out = (void *)it->second.fn; return 0; }
     // The kernel may not use scratch: a register spilled inside a lane-dependent branch comes back wrong in the lanes that were
@@ -58,7 +58,7 @@ extern "C" int pdmp_user_compile(int device, int sampler, int fd, int kind, int 
         prog += "\n}\n#include \"group_kernel.hpp\"\n";
         prog += "extern \"C\" __global__ __launch_bounds__(256, " + std::to_string(waves) + ") void pdmp_user_kernel(const pdmp::GroupParams gp) {\n";
         prog += "    if (pdmp::served_elsewhere(gp)) return;\n";
-        prog += "    pdmp::group_kernel_body<" + std::to_string(sampler) + ", pdmp::T_USER, " + (fd ? "true" : "false") + ">(gp);\n}\n";
+        prog += "    pdmp::group_kernel_body<" + std::to_string(sampler) + ", pdmp::T_USER, " + (fd ? "true" : "false") + ", 0, 0, false, false, " + (rtgrid ? "true" : "false") + ">(gp);\n}\n";
         hiprtcProgram p;
         if (hiprtcCreateProgram(&p, prog.c_str(), "pdmp_user.hip", k_hdr_count, (const char **)k_hdr_src, (const char **)k_hdr_names) != HIPRTC_SUCCESS) {
             put(err, errlen, "hiprtcCreateProgram failed");
