@@ -130,7 +130,11 @@ struct LaunchPolicy {
     // the one-lane kernel takes 8.2 - 9.7 ms whatever the count up to 65 536 chains and overtakes the pair form at ~37 000 (d >= 45) / ~40 000
     // (d <= 52: the pair form is the best form exactly while its waves -- 32 chains each -- are alone on their SIMDs: 32 768 chains; measured at the end of
     //  round 4, d = 16 / 32 / 50, 33 500 .. 39 000 chains: pair 6.2 / 7.0-7.2 / 8.4-8.7 ms, one lane 5.45 / 6.6 / 8.2-8.3 -- scripts/r4_lane_from.sh; before: 37 000 / 40 000)
-    int64_t lane_from_default(bool pair_dims, int dim) const { (void)dim; return pair_dims ? 28000 : 32769; }
+    // (round 5, the history length: the lane forms write 64 row streams per wave, n_sk d 8 bytes apart, and slow down faster than linearly as those
+    //  grow -- n_sk = 2000 / 4000 at 33 000 chains: group kernel 15.4 / 32.3 ms, one lane 19.2 / 41.5, pair 18.1 / 37.1; from 50 000 chains on one lane
+    //  per chain wins again (18.5 / 39.9 against 23.9 / 46.5) -- scripts/r5_thresholds.sh, profiles/r5/thresholds_nsk.jsonl: from n_sk = 1500 on
+    //  the one-lane form starts at 45 000 chains, and the pair form never runs beyond the 32 768 chains its waves are alone on their SIMDs with)
+    int64_t lane_from_default(bool pair_dims, int dim, int64_t n_sk) const { (void)dim; return pair_dims ? 28000 : (n_sk >= 1500 ? 45000 : 32769); }
 };
 
 static LaunchPolicy policy_from_env() {
@@ -1278,7 +1282,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
             // d = 53 .. 104 (the group kernel's G = 8): a PAIR of lanes per chain, 32 chains per wave, bit-identical to the G = 8 group kernel
             const bool lane2 = gp.G == 8;
             // (the pair kernel, d = 100, n_sk = 1000: 10.6 ms up to 32 768 chains -- one wave per SIMD -- against 9.5 ms of the group kernel at 25 000, 37.9 ms at 10^5)
-            const int64_t lane_from = pol.lane_min_chains >= 0 ? pol.lane_min_chains : pol.lane_from_default(lane2, c.dim);   // (d = 32, 44 000 chains: one lane 6.42 ms, pair 7.34, group kernel 7.43; 30 000: pair 4.99, group 5.92)
+            const int64_t lane_from = pol.lane_min_chains >= 0 ? pol.lane_min_chains : pol.lane_from_default(lane2, c.dim, n_sk);   // (d = 32, 44 000 chains: one lane 6.42 ms, pair 7.34, group kernel 7.43; 30 000: pair 4.99, group 5.92)
             // d = 25 .. 52 again, launches between ~a fifth and ~two fifths of the machine (the 4-GPU shard of the headline ensemble): a pair of
             // lanes per chain with two coordinates of a slot each -- GROUP(4) still -- so that 25 000 chains are 782 waves instead of 391
             // measured (d = 50 Gaussian, n_sk = 1000; group kernel / one lane / pair): 12 500 chains 4.31 / 8.36 / 5.36 ms, 18 000 6.58 / 8.41 / 5.39,
@@ -1291,7 +1295,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
             // a resumed chunk continues in the form whose state layout its first chunk left behind (until->form), whatever its size
             const int lane_mode = pol.lane_mode;                       // (2: the pair form at d <= 52 too, whatever the count -- tests)
             const bool pairq = !lane2 && !tgroup && (resuming ? until->form == PDMP_FORM_LANE_PAIR
-                                                              : (lane_mode == 2 || (lane_mode < 0 && C >= pair_from && C < lane_from)));   // (d <= 20, 10^5 chains: one lane 8.9 - 9.3 ms, pair 9.5 - 9.8)
+                                                              : (lane_mode == 2 || (lane_mode < 0 && C >= pair_from && C < lane_from && C <= 32768)));   // (d <= 20, 10^5 chains: one lane 8.9 - 9.3 ms, pair 9.5 - 9.8)
             const bool lane_wanted = resuming ? ((until->form == PDMP_FORM_LANE || until->form == PDMP_FORM_LANE_PAIR) && c.sampler == PDMP_ZIGZAG)   // (BPS: its own lane form, below)
                                               : (lane_mode != 0 && (lane_mode == 1 || lane_mode == 2 || C >= lane_from || pairq));
             if (resuming && lane_wanted && !lane_ok) {
