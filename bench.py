@@ -488,6 +488,20 @@ def main():
         r = run_step(i, sets[i % n_sets])
         last_step[:] = [r]
 
+    # The pipelined exchange has run on one GPU only (RCCL with one rank, gloo rehearsals): if its first step fails on any rank, every rank
+    # falls back to the plain exchange after the whole shard -- decided together, so that no rank waits in a collective the others left.
+    if world > 1 and pipeline > 1:
+        ok = 1
+        try:
+            step(0)
+            torch.cuda.synchronize()
+        except Exception as e:                                    # noqa: BLE001
+            ok = 0
+            print(f"[bench rank {rank}] pipelined exchange failed ({type(e).__name__}: {e}); falling back to --pipeline 1", file=sys.stderr, flush=True)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cpu" if rehearsal else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            pipeline = 1
     for i in range(a.warmup):
         step(i)
     fence()
