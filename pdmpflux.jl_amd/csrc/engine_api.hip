@@ -173,6 +173,7 @@ struct pdmp_engine {
     int32_t *d_sched = nullptr;       // group kernel: [0] unit counter, [1..nb] per-batch progress
     size_t sched_cap = 0;
     double *d_state = nullptr;        // group kernel: per-chain hand-off state (2d+4 doubles)
+    int tflags = 0;                   // SkelParams::tflags: bit 0 = diagonal Gaussian with every precision >= 0 (looked at once, when the handle is made)
     void *dense_ctx = nullptr;        // batched dense forms: this handle's rocBLAS handles, side stream and events (dense_batched.hip: DenseCtx)
     void *dense_ws = nullptr;         // incremental dense form: [x | v], [P x | P v], per-chain scalars (dense_batched.hip)
     size_t dense_ws_cap = 0;
@@ -967,6 +968,11 @@ static int create_impl(const pdmp_config_t *cfg, const char *source, int32_t kin
     h->cfg.target_params = nullptr;
     h->group_lanes = choose_group_lanes(c);
     h->policy = policy_from_env();
+    if (c.target_id == PDMP_T_GAUSS_DIAG && c.target_params && c.n_target_params >= 2 * (int64_t)c.dim) {
+        bool nonneg = true;
+        for (int i = 0; i < c.dim; ++i) nonneg = nonneg && (c.target_params[c.dim + i] >= 0.0);     // (a NaN precision fails the test)
+        h->tflags = nonneg ? 1 : 0;
+    }
 #define HIP_TRY_H(expr)                                                                            \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
@@ -1136,6 +1142,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
         p.IA = diag->is_active;
     }
     p.status = h->d_status;
+    p.tflags = h->tflags;
     p.t_stop = __builtin_huge_val();
     if (until) { p.t_stop = until->T; p.resume = until->resume; p.chain_map = until->chain_map; p.count = until->count; }
     const bool taped = h->tape_chains > 0;

@@ -91,6 +91,7 @@ __device__ __forceinline__ void publish(double *p, double x) {
     __hip_atomic_store((gu64 *)p, (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+template <bool B> struct BoolC { static constexpr bool value = B; };      // (a compile-time flag as a value: hiprtc brings no <type_traits>)
 struct TimePt { double t, s, c, sp, spe; };   // grid time (+ sin/cos for the Boomerang rotation; SpeedUpZigZag: s, c = the flow's
                                               // scalar v1 X1(t) and its t-derivative, sp, spe = speed(x_t) and its t-derivative)
 
@@ -152,7 +153,11 @@ template <> struct GTarget<T_GAUSS_DIAG> {
     static constexpr bool kShared = false, kTile = false, kUser = false;
     static constexpr bool kLinear = true;
     static constexpr int kAffineFrom = 0;
-    static constexpr bool kMonotone = false;   // a precision may be negative
+    static constexpr bool kMonotone = false;   // a precision may be negative ...
+    bool nonneg = false;                       // ... but the host has looked (SkelParams::tflags bit 0): with every precision >= 0 the Zig-Zag rate
+                                               // (prec_i (x_i + v_i t - mu_i)) v_i never decreases in t -- rounding is monotone through the fma, the subtraction and
+                                               // the two products -- so max(v0, v1, 0) IS max(v1, 0), bit for bit, and the left end of an affine cell need not be
+                                               // evaluated (round 5; the checker keeps computing max(v0, v1, 0): the same double)
     template <class T> using Sh = NoShared;
     const double *mu, *prec;            // LDS copies
     __device__ __forceinline__ void init(const double *lds_params, int d) { mu = lds_params; prec = lds_params + d; }
@@ -756,28 +761,37 @@ struct GroupChain {
                         if (__ballot(j == 0) != 0ull) { const auto f = shared_at<Dual>(p0, 0); if (j == 0) b_shf = f; }
                     }
                     const auto sh0 = b_shf, sh1 = shared_at<Dual>(p1, (j + 1) & 1);
-                    PDMP_SLOTS(s) {
-                        const int i = s * G + g;
-                        const int ip = (in_dim(s, i)) ? i : 0;
-                        const double x = X(s), v = VU(s);
-                        // "Affine cell" (arithmetic contract, GROUP order; mirrored by the checker): forward-mode Zig-Zag under the signed
-                        // bound, slot of coordinates whose gradient component is affine in its own coordinate -- the rate is linear in t,
-                        // its slope the same double at both ends of the cell, so the reference's tangent intersection (UpperBound.jl:229-237)
-                        // divides by zero, clamps to h or 0 and yields v0 or v0 + g h = v1 up to rounding: the cell maximum (:239-241) is
-                        // max(v0, v1, 0).  No slopes, no intersection; with a non-negative slope v1 >= v0 exactly (rounding is monotone),
-                        // so only the right end is evaluated.  4 instead of 15 fp64 operations per coordinate and cell on the Gaussians.
-                        if (SIGNED && SAMPLER == S_ZIGZAG && s * G >= Tgt::kAffineFrom) {      // wave-uniform; a constant in the register form
-                            const typename Tgt::template Sh<double> nosh{};                        // (an affine component reads no other coordinate)
-                            const double v1 = fval_vect<true>(ip, x, v, p1, nosh);
-                            if constexpr (Tgt::kMonotone) bsum += fmax(v1, 0.0);
-                            else bsum += fmax(fmax(fval_vect<true>(ip, x, v, p0, nosh), v1), 0.0);
-                        } else {
-                            double v0, g0, v1, g1;
-                            eval_vect<SIGNED>(ip, x, v, p0, sh0, v0, g0);
-                            eval_vect<SIGNED>(ip, x, v, p1, sh1, v1, g1);
-                            bsum += cell_vect(v0, g0, v1, g1, t0, t1, h);
+                    // "Affine cell" (arithmetic contract, GROUP order; mirrored by the checker): forward-mode Zig-Zag under the signed
+                    // bound, slot of coordinates whose gradient component is affine in its own coordinate -- the rate is linear in t,
+                    // its slope the same double at both ends of the cell, so the reference's tangent intersection (UpperBound.jl:229-237)
+                    // divides by zero, clamps to h or 0 and yields v0 or v0 + g h = v1 up to rounding: the cell maximum (:239-241) is
+                    // max(v0, v1, 0).  No slopes, no intersection; with a non-negative slope v1 >= v0 exactly (rounding is monotone),
+                    // so only the right end is evaluated.  4 instead of 15 fp64 operations per coordinate and cell on the Gaussians.
+                    // MONO: compile-time for the isotropic Gaussian / the banana; the diagonal Gaussian takes one of two copies of the slot
+                    // loop by a wave-uniform branch on GTarget::nonneg (inside the loop the compiler turned the branch into a select and
+                    // evaluated the left end regardless: measured, no gain).
+                    auto slots = [&](auto mono_c) {
+                        constexpr bool MONO = decltype(mono_c)::value;
+                        PDMP_SLOTS(s) {
+                            const int i = s * G + g;
+                            const int ip = (in_dim(s, i)) ? i : 0;
+                            const double x = X(s), v = VU(s);
+                            if (SIGNED && SAMPLER == S_ZIGZAG && s * G >= Tgt::kAffineFrom) {      // wave-uniform; a constant in the register form
+                                const typename Tgt::template Sh<double> nosh{};                        // (an affine component reads no other coordinate)
+                                const double v1 = fval_vect<true>(ip, x, v, p1, nosh);
+                                if constexpr (MONO) bsum += fmax(v1, 0.0);
+                                else bsum += fmax(fmax(fval_vect<true>(ip, x, v, p0, nosh), v1), 0.0);
+                            } else {
+                                double v0, g0, v1, g1;
+                                eval_vect<SIGNED>(ip, x, v, p0, sh0, v0, g0);
+                                eval_vect<SIGNED>(ip, x, v, p1, sh1, v1, g1);
+                                bsum += cell_vect(v0, g0, v1, g1, t0, t1, h);
+                            }
                         }
-                    }
+                    };
+                    if constexpr (TARGET == T_GAUSS_DIAG && SIGNED && SAMPLER == S_ZIGZAG) {         // (only where the affine cell exists: the other samplers keep ONE copy of the loop)
+                        if (tgt.nonneg) slots(BoolC<true>{}); else slots(BoolC<false>{});
+                    } else slots(BoolC<Tgt::kMonotone>{});
                     b_shf = sh1;
                 } else {                                                               // AD_backend = "FiniteDiff", :223-224
                     FdPt P0, P1;
@@ -1987,6 +2001,7 @@ __device__ __forceinline__ void group_kernel_body(const GroupParams &gp) {
     // register form: no x tile; one K*64-double tile per wave only where refreshed velocities are exchanged between lanes
     GroupChain<SAMPLER, TARGET, FD, KC, GC, TAPE, LEAN, RTGRID> chain(gp, lane, tile, KC > 0 ? tile : tile + tsz);
     chain.tgt.init(smem, gp.s.d);
+    if constexpr (TARGET == T_GAUSS_DIAG) chain.tgt.nonneg = (gp.s.tflags & 1) != 0;
     if constexpr (SAMPLER == S_FECMC) {                              // (register form: the exchange tile first, then the four jump vectors)
         for (int q = 0; q < 4; ++q) chain.fe_t[q] = tile + ((KC > 0 ? 1 : 2) + q) * tsz;
     }

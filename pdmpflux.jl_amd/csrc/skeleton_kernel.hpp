@@ -45,7 +45,8 @@ struct SkelParams {
     //            and (+ chain0) its random stream; outputs are indexed by the launch's own c (dense over the active chains)
     //   count    null, or count[c] = columns chain c recorded in this launch (n_sk when it used the whole capacity)
     double t_stop;
-    int32_t resume, until_pad;
+    int32_t resume;
+    int32_t tflags;    // target facts found by the host when the handle is made: bit 0 = every precision of the diagonal Gaussian is >= 0 (GTarget<T_GAUSS_DIAG>::nonneg)
     const int64_t *chain_map;
     int64_t *count;
 };

@@ -683,3 +683,26 @@ def test_group_kernel_full_machine_zigzag(engine, oracle, monkeypatch, target):
         for k in ("X", "V", "t"):
             assert np.array_equal(got[k][c], r1[k][0]), (k, c)
     assert (np.diff(got["t"], axis=1) > 0).all() and (np.abs(got["V"]) == 1.0).all()
+
+
+@pytest.mark.parametrize("dim,G", [(6, None), (50, None), (50, 0), (20, 8)])
+def test_diag_precisions_of_either_sign(engine, oracle, monkeypatch, dim, G):
+    """Round 5: with every precision of the diagonal Gaussian >= 0 (the host looks once, when the handle is made) the Zig-Zag rate of a coordinate
+    never decreases in t and the affine cell's left end is not evaluated; ONE negative or zero precision and the launch takes the general copy of
+    the slot loop, max(v0, v1, 0).  Both against the checker, which always computes max(v0, v1, 0): the same doubles."""
+    if G is not None:
+        monkeypatch.setenv("PDMP_GROUP_LANES", str(G))
+    rs = np.random.default_rng(dim)
+    mu = rs.normal(size=dim)
+    for flip in (False, True):
+        prec = np.exp(rs.uniform(-1, 1, size=dim))
+        if flip:
+            prec[rs.integers(dim)] *= -0.3                 # a saddle direction: the run stays short, the rates stay finite
+            prec[rs.integers(dim)] = 0.0
+        s = engine.ZigZagAD(dim, engine.GaussianDiag(mu, prec), tmax=0.5)
+        lanes = s.group_lanes()
+        cfg = oracle.Config(sampler=oracle.ZIGZAG, dim=dim, grid_size=10, tmax=0.5, target_id=oracle.T_GAUSS_DIAG, target_params=np.concatenate([mu, prec]),
+                            arith=oracle.ARITH_GROUP if lanes > 0 else oracle.ARITH_WAVE64, group_lanes=max(lanes, 1))
+        x, v = make_init("ZigZagAD", dim, 37, seed=3)
+        got = engine.sample_skeleton_ensemble(s, 60, x, v, seed=21, diagnostics=True)
+        assert_bitwise(got, oracle.sample_skeleton(cfg, 60, x, v, 21, diagnostics=True))
