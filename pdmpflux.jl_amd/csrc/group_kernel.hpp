@@ -225,7 +225,7 @@ template <> struct GTarget<T_USER> {
 // read back with v_readlane in the event loop) and instructions in kernels that are bound by VALU issue.
 // RTGRID (round 5, LDS form): grid_size is a run-time number (2 .. 64) instead of the constructors' default 10 -- a separate instantiation: with the
 // two kernels differ in registers (GroupOcc: Zig-Zag on the banana with finite-difference slopes holds three waves per SIMD only with the grid a
-// constant), so launches at grid_size 10 keep the kernel they had; measured otherwise equal (StickyZigZag 35.5 / 35.6 ms, SpeedUpZigZag 65.8 / 66.2).
+// constant: launch_group_impl keeps a constant-grid kernel exactly there); measured otherwise equal (StickyZigZag 35.5 / 35.6 ms, SpeedUpZigZag 65.8 / 66.2).
 template <int SAMPLER, int TARGET, bool FD, int KC = 0, int GC = 0, bool TAPE = false, bool LEAN = false, bool RTGRID = false>      // GC: lanes per chain when it is a compile-time constant (register form)
 struct GroupChain {
     using Tgt = GTarget<TARGET>;
@@ -2166,9 +2166,16 @@ hipError_t launch_group_impl(const GroupParams &gp_in, hipStream_t stream) {
             }
         }
     } else {
-        const bool rtgrid = gp.s.n_grid != GNG && gp.s.n_grid != 0;            // (0: the Brent bound, no grid at all)
-        if constexpr (TAPE) kernel = rtgrid ? group_kernel_tape<SAMPLER, TARGET, FD, true> : group_kernel_tape<SAMPLER, TARGET, FD, false>;
-        else kernel = rtgrid ? group_kernel<SAMPLER, TARGET, FD, true> : group_kernel<SAMPLER, TARGET, FD, false>;
+        // ONE instantiation per (sampler, target, slope mode) takes grid_size at run time -- measured equal to a constant grid (StickyZigZag 35.5 / 35.6 ms,
+        // SpeedUpZigZag 65.8 / 66.2) -- except where the constant buys a wave per SIMD (GroupOcc: Zig-Zag, banana, finite-difference slopes): there the
+        // default grid (and Brent, which has no grid) keeps its own kernel
+        constexpr bool kFixedToo = GroupOcc<SAMPLER, TARGET, FD, false>::kWaves != GroupOcc<SAMPLER, TARGET, FD, true>::kWaves;
+        const bool fixed = kFixedToo && (gp.s.n_grid == GNG || gp.s.n_grid == 0);
+        if constexpr (TAPE) kernel = group_kernel_tape<SAMPLER, TARGET, FD, true>;
+        else {
+            kernel = group_kernel<SAMPLER, TARGET, FD, true>;
+            if constexpr (kFixedToo) { if (fixed) kernel = group_kernel<SAMPLER, TARGET, FD, false>; }
+        }
     }
     if (!kernel) return hipErrorNotSupported;
     hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -58,7 +58,7 @@ extern "C" int pdmp_user_compile(int device, int sampler, int fd, int kind, int 
         prog += "\n}\n#include \"group_kernel.hpp\"\n";
         prog += "extern \"C\" __global__ __launch_bounds__(256, " + std::to_string(waves) + ") void pdmp_user_kernel(const pdmp::GroupParams gp) {\n";
         prog += "    if (pdmp::served_elsewhere(gp)) return;\n";
-        prog += "    pdmp::group_kernel_body<" + std::to_string(sampler) + ", pdmp::T_USER, " + (fd ? "true" : "false") + ", 0, 0, false, false, " + (rtgrid ? "true" : "false") + ">(gp);\n}\n";
+        prog += "    pdmp::group_kernel_body<" + std::to_string(sampler) + ", pdmp::T_USER, " + (fd ? "true" : "false") + ", 0, 0, false, false, " + "true>(gp);   // (grid_size at run time, as the built-in LDS-form kernels)\n}\n";
         hiprtcProgram p;
         if (hiprtcCreateProgram(&p, prog.c_str(), "pdmp_user.hip", k_hdr_count, (const char **)k_hdr_src, (const char **)k_hdr_names) != HIPRTC_SUCCESS) {
             put(err, errlen, "hiprtcCreateProgram failed");
