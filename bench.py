@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--grid-size", type=int, default=None, help="grid_size of the bound (default: the constructor's 10; 0: Brent; any 2 .. 64 runs the LDS-form group kernel)")
     ap.add_argument("--rng-version", type=int, default=0, help="arithmetic contract of the random stream / elementary functions: 0 = default (2), 1 = rounds 1-4 (LDS-form kernels only)")
     ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--ab-env", default=None, metavar="NAME=v1,v2[,..]",
+                    help="after the timed region: hipEvent-timed launches on the SAME arrays under each value of an environment knob the library reads "
+                         "at every launch (PDMP_DENSE_UNIT, PDMP_DENSE_DEBUG), interleaved -- two processes differ by their allocations' placement (~5 %%)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time; 0 disables it")
     ap.add_argument("--alloc", default="auto", choices=["auto", "chunked", "hipmalloc"],
                     help="allocator of the output arrays: chunked = ensemble.alloc_outputs (pdmp_device_alloc: independent 1-GiB physical chunks, "
@@ -528,6 +531,21 @@ def main():
     kernel_ms = tm["kernel_ms_total"] / max(a.steps, 1)        # kernel time per step on this rank: every launch of the step (a pipelined step makes one per batch;
                                                                 # --gather samples / moments add their sample_from_skeleton / moments kernel)
     launches_per_step = tm["launches"] / max(a.steps, 1)
+    ab = None
+    if a.ab_env and world == 1:
+        name, vals = a.ab_env.split("=", 1)
+        vals = vals.split(",")
+        before = os.environ.get(name)
+        ab = {"knob": name, "ms": {val: [] for val in vals}}
+        for rnd in range(3):
+            for val in vals:
+                os.environ[name] = val
+                ab["ms"][val] += [round(m, 3) for m in timed_launches(full, 2, 7000 + 10 * rnd)]
+        if before is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = before
+        ab["mean_ms"] = {val: round(sum(m) / len(m), 3) for val, m in ab["ms"].items()}
     kernel_ms_max = kernel_ms
     if world > 1:
         te = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cpu" if rehearsal else dev)
@@ -706,6 +724,8 @@ def main():
                                "note": "achieved = 2 d^2 flop per multiplied column x columns / whole-launch time (GEMMs + step kernels); "
                                        "peak = MI355X fp64 matrix spec 78.6 TFLOP/s (datasheet; not in the local guide)"}
         # beside `value`, at the top level: which allocator the timed arrays came from and what it cost (the selection runs before the timed region)
+        if ab:
+            res["ab_env"] = ab
         res["allocator"] = allocator
         res["alloc_seconds"] = [q.get("seconds") for q in alloc_log[:n_sets]]
         res["all_allocations_ms"] = res["config"]["all_allocations_ms"]

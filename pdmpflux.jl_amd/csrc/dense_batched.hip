@@ -313,6 +313,8 @@ struct DiParams {
 #else
 #define PDMP_ROW_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
 #endif
+// (round 5, same arrays, bench.py --ab-env: plain stores 7.80 ms against 7.98 with a run-time switch compiled in -- and 7.40 without the switch:
+//  the launch is bound by these stores, scripts/probes/store_probe.hip, and the kernel's schedule around them is touchy)
 // ---- Totals of sixteen per-lane values over the wave, all at once ("reduce-scatter"): instead of sixteen butterflies of six stages
 // each (16 x 22 instructions, and -- walked slot by slot until the hit -- sixteen dependent chains through the LDS crossbar), every
 // stage HALVES the number of values a lane carries while it doubles the lanes each value has been summed over:
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(256, SGN ? 2 : 1) void di_segment_kernel(const DiPa
             const int i = s * WAVE + lane;
             // whole 64-byte lines (a row is 8 d bytes, d = 1000: 125 lines), written once and not read again by this launch: streaming
             // stores keep them from displacing the columns of P in the L2
-            if (i < d) { PDMP_ROW_STORE(&Xe[i], x[s * WAVE]); PDMP_ROW_STORE(&Ve[i], v[s]); }
+            if (i < d && !(p.pad & 1)) { PDMP_ROW_STORE(&Xe[i], x[s * WAVE]); PDMP_ROW_STORE(&Ve[i], v[s]); }      // (p.pad: PDMP_DENSE_DEBUG, measurements only)
         }
         if (lane == 0) {
             p.t[e] = t;
@@ -548,7 +550,7 @@ __global__ __launch_bounds__(256, SGN ? 2 : 1) void di_segment_kernel(const DiPa
 #pragma unroll
             for (int s = 0; s < KC; ++s) {
                 const int i = s * WAVE + lane;
-                pc[s] = (i < d) ? Pm[i] : 0.0;
+                pc[s] = (i < d && !(p.pad & 2)) ? Pm[i] : 0.0;
             }
 #pragma unroll
             for (int s = 0; s < KC; ++s) if (s == ms && lane == ml) v[s] = -v[s];
@@ -1178,7 +1180,10 @@ extern "C" int pdmp_dense_incremental_run(int device, int d, int signed_bound, i
     p.In = In; p.Out = Out; p.P = P_dev; p.st = st;
     p.X = X; p.V = V; p.t = t; p.H = H; p.AR = AR; p.EV = EV; p.EB = EB; p.RJ = RJ; p.HH = HH;
     p.status = status;
-    p.refresh = 0.0; p.gaussian_velocity = 0; p.pad = 0;
+    // PDMP_DENSE_DEBUG (read at every launch; measurements only, the results are wrong): 1 = di_segment_kernel without its row stores,
+    // 2 = without its loads of P's columns -- what the launch costs beside its stores (config 4 is bound by the stores)
+    const int debug_mask = [] { const char *e = getenv("PDMP_DENSE_DEBUG"); return e ? atoi(e) : 0; }();
+    p.refresh = 0.0; p.gaussian_velocity = 0; p.pad = debug_mask;
     p.t_stop = t_stop; p.chain_map = chain_map; p.count = count; p.resume = resume; p.pad2 = 0;
     const dim3 grid((unsigned)((n_launch + 3) / 4)), block(256);
     const double one = 1.0, zero = 0.0;
