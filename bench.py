@@ -66,8 +66,8 @@ def parse():
     ap.add_argument("--rng-version", type=int, default=0, help="arithmetic contract of the random stream / elementary functions: 0 = default (2), 1 = rounds 1-4 (LDS-form kernels only)")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--ab-env", default=None, metavar="NAME=v1,v2[,..]",
-                    help="after the timed region: hipEvent-timed launches on the SAME arrays under each value of an environment knob the library reads "
-                         "at every launch (PDMP_DENSE_UNIT, PDMP_DENSE_DEBUG), interleaved -- two processes differ by their allocations' placement (~5 %%)")
+                    help="after the timed region: hipEvent-timed launches on the SAME arrays under each value of a PDMP_* knob of the launch policy "
+                         "(the handle re-reads it: pdmp_reload_policy), interleaved -- two processes differ by their allocations' placement (~5 %%)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time; 0 disables it")
     ap.add_argument("--alloc", default="auto", choices=["auto", "chunked", "hipmalloc"],
                     help="allocator of the output arrays: chunked = ensemble.alloc_outputs (pdmp_device_alloc: independent 1-GiB physical chunks, "
@@ -540,11 +540,13 @@ def main():
         for rnd in range(3):
             for val in vals:
                 os.environ[name] = val
+                sampler.reload_policy()                       # (the PDMP_* knobs are part of the handle's launch policy: no launch reads the environment)
                 ab["ms"][val] += [round(m, 3) for m in timed_launches(full, 2, 7000 + 10 * rnd)]
         if before is None:
             os.environ.pop(name, None)
         else:
             os.environ[name] = before
+        sampler.reload_policy()
         ab["mean_ms"] = {val: round(sum(m) / len(m), 3) for val, m in ab["ms"].items()}
     kernel_ms_max = kernel_ms
     if world > 1:

@@ -1180,9 +1180,10 @@ extern "C" int pdmp_dense_incremental_run(int device, int d, int signed_bound, i
     p.In = In; p.Out = Out; p.P = P_dev; p.st = st;
     p.X = X; p.V = V; p.t = t; p.H = H; p.AR = AR; p.EV = EV; p.EB = EB; p.RJ = RJ; p.HH = HH;
     p.status = status;
-    // PDMP_DENSE_DEBUG (read at every launch; measurements only, the results are wrong): 1 = di_segment_kernel without its row stores,
-    // 2 = without its loads of P's columns -- what the launch costs beside its stores (config 4 is bound by the stores)
-    const int debug_mask = [] { const char *e = getenv("PDMP_DENSE_DEBUG"); return e ? atoi(e) : 0; }();
+    // gemm_impl, bits 8 - 9: PDMP_DENSE_DEBUG of the handle's launch policy (measurements only, the results are wrong): 1 = di_segment_kernel
+    // without its row stores, 2 = without its loads of P's columns -- what the launch costs beside them
+    const int debug_mask = (gemm_impl >> 8) & 3;
+    gemm_impl &= 0xff;
     p.refresh = 0.0; p.gaussian_velocity = 0; p.pad = debug_mask;
     p.t_stop = t_stop; p.chain_map = chain_map; p.count = count; p.resume = resume; p.pad2 = 0;
     const dim3 grid((unsigned)((n_launch + 3) / 4)), block(256);

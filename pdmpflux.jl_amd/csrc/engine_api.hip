@@ -126,6 +126,8 @@ struct LaunchPolicy {
                                    //   streams (the product of one half beside the step kernel of the other)
     int no_lean = 0;               // PDMP_NO_LEAN: the full 13-slot register kernels even where a lean throughput instantiation exists (A/B, tests)
     int debug_launch = 0;          // PDMP_DEBUG_LAUNCH: print the launch geometry of the lane kernels
+    int dense_debug = 0;           // PDMP_DENSE_DEBUG (measurements only, the results are WRONG): 1 = the incremental dense form's segment kernel without its row
+                                   //   stores, 2 = without its loads of P's columns -- what a launch costs beside them (bench.py --ab-env)
     // one lane per chain from this many chains on: the pair form (GL = 2) at d = 53 .. 104 fills the machine at 32 768 chains; at d <= 52
     // the one-lane kernel takes 8.2 - 9.7 ms whatever the count up to 65 536 chains and overtakes the pair form at ~37 000 (d >= 45) / ~40 000
     // (d <= 52: the pair form is the best form exactly while its waves -- 32 chains each -- are alone on their SIMDs: 32 768 chains; measured at the end of
@@ -157,6 +159,7 @@ static LaunchPolicy policy_from_env() {
     { const int v = (int)geti("PDMP_DENSE_LANES", q.dense_lanes); if (v == 1 || v == 2) q.dense_lanes = v; }
     q.no_lean = getenv("PDMP_NO_LEAN") != nullptr;
     q.debug_launch = getenv("PDMP_DEBUG_LAUNCH") != nullptr;
+    { const int v = (int)geti("PDMP_DENSE_DEBUG", 0); if (v >= 0 && v <= 3) q.dense_debug = v; }
     return q;
 }
 
@@ -1243,7 +1246,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
         if (dense_mode != 2)                                   // P x, P v kept current incrementally: O(d) per gradient (dense_batched.hip)
             rc = pdmp_dense_incremental_run(h->device, c.dim, c.signed_bound, c.adaptive, c.tmax, c.max_iter_per_event, h->d_tparams, C_ws, n_sk,
                                             chain_id_offset, seed, xinit, vinit, X, V, t, p.H, p.AR, p.EB, p.EV, p.RJ, p.HH,
-                                            h->d_status, stream, &h->dense_ws, &h->dense_ws_cap, pol.dense_resync, pol.dense_gemm < 0 ? 1 : pol.dense_gemm,
+                                            h->d_status, stream, &h->dense_ws, &h->dense_ws_cap, pol.dense_resync, (pol.dense_gemm < 0 ? 1 : pol.dense_gemm) | (pol.dense_debug << 8),
                                             t_stop, resuming ? 1 : 0, C, until ? until->chain_map : nullptr, until ? until->count : nullptr, msg, (int)sizeof msg);
         if (rc == -5)                                           // d > 1024 (or forced): one GEMM per phase
             rc = pdmp_dense_batched_run(h->device, c.dim, c.signed_bound, c.adaptive, c.tmax, c.max_iter_per_event, h->d_tparams, C, n_sk,
