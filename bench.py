@@ -566,7 +566,8 @@ def main():
     l0, h0 = ranges_of(rank)[0]
     own = full["t"][l0:h0] if gather == "skeleton" else full["t"]
     tt = own[:256]
-    assert bool((tt[:, 1:] > tt[:, :-1]).all()) and bool(torch.isfinite((full["X"][l0:h0] if gather == "skeleton" else full["X"])[:256]).all())
+    if not (os.environ.get("PDMP_LANE_DEBUG", "0") != "0" or os.environ.get("PDMP_DENSE_DEBUG", "0") != "0"):     # (measurement knobs that drop stores: nothing to check)
+        assert bool((tt[:, 1:] > tt[:, :-1]).all()) and bool(torch.isfinite((full["X"][l0:h0] if gather == "skeleton" else full["X"])[:256]).all())
     exchange_ms = None
     if gather == "skeleton":
         cdev = "cpu" if rehearsal else dev

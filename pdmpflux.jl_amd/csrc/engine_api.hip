@@ -126,6 +126,7 @@ struct LaunchPolicy {
                                    //   streams (the product of one half beside the step kernel of the other)
     int no_lean = 0;               // PDMP_NO_LEAN: the full 13-slot register kernels even where a lean throughput instantiation exists (A/B, tests)
     int debug_launch = 0;          // PDMP_DEBUG_LAUNCH: print the launch geometry of the lane kernels
+    int lane_debug = 0;            // PDMP_LANE_DEBUG (measurements only, the results are WRONG): 1 = the lane kernels without their stores of t, 2 = of V, 4 = of X
     int dense_debug = 0;           // PDMP_DENSE_DEBUG (measurements only, the results are WRONG): 1 = the incremental dense form's segment kernel without its row
                                    //   stores, 2 = without its loads of P's columns -- what a launch costs beside them (bench.py --ab-env)
     // one lane per chain from this many chains on: the pair form (GL = 2) at d = 53 .. 104 fills the machine at 32 768 chains; at d <= 52
@@ -160,6 +161,7 @@ static LaunchPolicy policy_from_env() {
     q.no_lean = getenv("PDMP_NO_LEAN") != nullptr;
     q.debug_launch = getenv("PDMP_DEBUG_LAUNCH") != nullptr;
     { const int v = (int)geti("PDMP_DENSE_DEBUG", 0); if (v >= 0 && v <= 3) q.dense_debug = v; }
+    { const int v = (int)geti("PDMP_LANE_DEBUG", 0); if (v >= 0 && v <= 7) q.lane_debug = v; }
     return q;
 }
 
@@ -1145,7 +1147,7 @@ static int sample_skeleton_launch(pdmp_handle h, int64_t C, int64_t n_sk, int64_
         p.IA = diag->is_active;
     }
     p.status = h->d_status;
-    p.tflags = h->tflags;
+    p.tflags = h->tflags | (h->policy.lane_debug << 8);
     p.t_stop = __builtin_huge_val();
     if (until) { p.t_stop = until->T; p.resume = until->resume; p.chain_map = until->chain_map; p.count = until->count; }
     const bool taped = h->tape_chains > 0;

@@ -52,7 +52,15 @@ constexpr int LANE_LK_MIN = 1, LANE_LK_MAX = 13;          // (round 4: 3 .. 6 sl
                                                          //  then 1 and 2 slots, d = 1 .. 8 -- rows shorter than a 64-byte line, LaneChain::kShort: inst_lane_zigzag_d.hip, inst_lane2q_zigzag_d.hip)
 // gl = lanes per chain (1; 2: the chain's coordinates split over a lane pair, lane_kernel.hpp: GL)
 // pg = coordinates of a slot per lane (4; 2: the "quad pair" form, GL = 2 at d <= 52), dmax = pg gl lk = a chain's coordinates with padding
-constexpr int lane_row_stride(int lk, int gl = 1, int pg = 4) { return (7 + pg * gl * lk) | 1; }   // LDS row: up to 7 carried doubles + dmax coordinates, odd stride
+// Doubles per written line (LaneChain::LN): a store instruction writes whole lines of this length only.  64 bytes until round 5; 128 bytes -- the
+// L2's line -- for one lane per chain at d >= 25 (LANE_LINE16=0: A/B builds): a 128-byte line that two store instructions fill half by
+// half is written to memory 1.19 times on average (scripts/probes/oob_probe.hip; the launch of config 2: 14.04 64-byte lines per event for
+// 12.625 of events, 0.375 too many per row of X and of V, PDMP_LANE_DEBUG).
+#ifndef LANE_LINE16
+#define LANE_LINE16 1
+#endif
+constexpr int lane_line(int lk, int gl = 1, int pg = 4) { return (LANE_LINE16 && gl == 1 && pg == 4 && lk >= 7) ? 16 : 8; }
+constexpr int lane_row_stride(int lk, int gl = 1, int pg = 4) { return (lane_line(lk, gl, pg) - 1 + pg * gl * lk) | 1; }   // LDS row: up to LN - 1 carried doubles + dmax coordinates, odd stride
 constexpr bool lane_wide(int lk, int gl, int pg) { return 7 + pg * gl * lk > 64; }                 // a row's sign bits need more than one 64-bit word
 constexpr int lane_meta_doubles(int lk, int gl = 1, int pg = 4) { return lane_wide(lk, gl, pg) ? 4 : 2; }   // store parameters of a chain: 16 bytes (64 sign bits) / 32 bytes (128)
 constexpr int lane_lds_per_wave(int lk, int gl = 1, int pg = 4) { return (WAVE / gl) * (lane_row_stride(lk, gl, pg) + lane_meta_doubles(lk, gl, pg) + 8); } // doubles: a row + the store parameters + 8 event times per chain
@@ -138,6 +146,7 @@ struct LaneChain {
     static constexpr int DMAX = GE * LK;                 // coordinates of a chain, padding included
     static constexpr int CW = WAVE / GL;                 // chains per wave
     static constexpr int LR = lane_row_stride(LK, GL, PG);   // LDS row stride
+    static constexpr int LN = lane_line(LK, GL, PG);     // doubles per written line: 8 (64 bytes) or 16 (128 bytes, the L2's line)
     static constexpr bool kWide = lane_wide(LK, GL, PG); // 128 sign bits per row (else 64)
     static constexpr int MD = lane_meta_doubles(LK, GL, PG);   // doubles of store parameters per chain
     static constexpr int LANE_DMIN = DMAX - (GE - 1);    // the last slot may be partly padding, no other
@@ -464,7 +473,7 @@ struct LaneChain {
             return {o.lo | (((uint64_t)q1 << 32) | (uint64_t)q0), o.hi | (((uint64_t)q3 << 32) | (uint64_t)q2)};
         }
     }
-    __device__ __forceinline__ static SBits low_bits(SBits x, int a) {            // the lowest a <= 7 bits
+    __device__ __forceinline__ static SBits low_bits(SBits x, int a) {            // the lowest a <= LN - 1 bits
         if constexpr (!kWide) return x & ((1ull << a) - 1ull);
         else return {x.lo & ((1ull << a) - 1ull), 0ull};
     }
@@ -490,24 +499,27 @@ struct LaneChain {
         int64_t chains = p.C - b * CW;
         if (chains > CW) chains = CW;
         const int bytes = (int)(chains * p.n_sk * d * 8);
-        rsX = __builtin_amdgcn_make_buffer_rsrc(p.X + first, 0, bytes, 0x00020000);
-        rsV = __builtin_amdgcn_make_buffer_rsrc(p.V + first, 0, bytes, 0x00020000);
-        const int a = (int)(((uintptr_t)(p.X + ((size_t)c * (size_t)p.n_sk + (size_t)k_first) * (size_t)d) >> 3) & 7u);   // per chain
+        // (SkelParams::tflags bits 8 - 10 = PDMP_LANE_DEBUG, measurements only: a window of no bytes drops every store of that array)
+        // (one lane per chain only: the pair kernels have no register to spare)
+        const int dbg = (GL == 1) ? p.tflags : 0;
+        rsX = __builtin_amdgcn_make_buffer_rsrc(p.X + first, 0, (dbg & 0x400) ? 0 : bytes, 0x00020000);
+        rsV = __builtin_amdgcn_make_buffer_rsrc(p.V + first, 0, (dbg & 0x200) ? 0 : bytes, 0x00020000);
+        const int a = (int)(((uintptr_t)(p.X + ((size_t)c * (size_t)p.n_sk + (size_t)k_first) * (size_t)d) >> 3) & (uintptr_t)(LN - 1));   // per chain
         cl = a;
         {                                                                         // (all lanes: a = 0 moves nothing that is read)
             int l = lane;
             asm volatile("" : "+v"(l));
             double *myrow = tile + (l >> (GL - 1)) * LR;
             __builtin_amdgcn_wave_barrier();
-            row_put(myrow + 7);                                                   // the state's coordinates at row positions 7 .. 7 + DMAX - 1
+            row_put(myrow + (LN - 1));                                            // the state's coordinates at row positions LN - 1 .. LN - 1 + DMAX - 1
             __builtin_amdgcn_wave_barrier();
-            const double *from = myrow + 7 + (d - a);                             // its last a coordinates
-            double mv[7];
+            const double *from = myrow + (LN - 1) + (d - a);                      // its last a coordinates
+            double mv[LN - 1];
 #pragma unroll
-            for (int j = 0; j < 7; ++j) mv[j] = from[j];
+            for (int j = 0; j < LN - 1; ++j) mv[j] = from[j];
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int j = 0; j < 7; ++j) myrow[j] = mv[j];                         // (positions >= a are overwritten by the next row; a pair writes the same values twice)
+            for (int j = 0; j < LN - 1; ++j) myrow[j] = mv[j];                    // (positions >= a are overwritten by the next row; a pair writes the same values twice)
             if constexpr (kShort) {
                 skip = a > d ? a - d : 0;
                 Sc = low_bits(a > d ? lb_shl(signs_row(), a - d) : lb_shr(signs_row(), d - a), a);
@@ -633,7 +645,7 @@ struct LaneChain {
                                                   // event loop they would occupy ~50 registers for the whole launch
         const int cwi = l >> (GL - 1);            // my chain's row
         double *myrow = tile + cwi * LR;
-        const int total = cl + d, nfull = total & ~7;
+        const int total = cl + d, nfull = total & ~(LN - 1);
         const SBits S = lb_or(Sc, lb_shl(signs_row(), cl));
         const uint32_t off = rec ? (((uint32_t)cwi * (uint32_t)p.n_sk + (uint32_t)k) * (uint32_t)d - (uint32_t)cl) * 8u : kNoRow;
         __builtin_amdgcn_wave_barrier();
@@ -644,7 +656,7 @@ struct LaneChain {
         LANE_MARK(10);
         // nfull = 8 floor((cl + d) / 8) lies in [NF_MIN, NF_MAX]: whole tiles of 16 positions below NF_MIN need no check, the rest goes out as
         // tiles of 8 positions checked against nfull
-        constexpr int NF_MIN = LANE_DMIN & ~7, NF_MAX = (DMAX + 7) & ~7, Q0 = NF_MIN & ~15;
+        constexpr int NF_MIN = LANE_DMIN & ~(LN - 1), NF_MAX = (DMAX + LN - 1) & ~(LN - 1), Q0 = NF_MIN & ~15;
         if constexpr (kShort) {      // one tile of eight positions, checked on both sides (a pair of positions may straddle `skip`: 8-byte stores)
             static_assert(Q0 == 0 && NF_MAX == 8, "short rows: one line per event at most");
             store_tile<8, true, true>(0, l);
@@ -654,13 +666,13 @@ struct LaneChain {
         for (int q = 0; q < Q0; q += 16) store_tile<16, false, false>(q, l);
         LANE_MARK(13);
 #pragma unroll
-        for (int q = Q0; q < NF_MAX; q += 8) store_tile<8, false, true>(q, l);
+        for (int q = Q0; q < NF_MAX; q += LN) store_tile<LN, false, true>(q, l);
 #else
 #pragma unroll
         for (int q = 0; q < Q0; q += 16) store_tile2<16, false>(q, l);
         LANE_MARK(13);
 #pragma unroll
-        for (int q = Q0; q < NF_MAX; q += 8) store_tile2<8, true>(q, l);
+        for (int q = Q0; q < NF_MAX; q += LN) store_tile2<LN, true>(q, l);
 #endif
         }
         __builtin_amdgcn_wave_barrier();
@@ -668,11 +680,15 @@ struct LaneChain {
         if (rec) {
             if constexpr (kShort) { if (nfull) skip = 0; }
             const double *from = myrow + nfull;                                   // the row's tail that completes no line: the next carry
-            double mv[7];
+            double mv[LN - 1];
 #pragma unroll
-            for (int j = 0; j < 7; ++j) mv[j] = from[j];
+            for (int j = 0; j < LN - 1; ++j) mv[j] = from[j];
 #pragma unroll
-            for (int j = 0; j < 7; ++j) myrow[j] = mv[j];
+            for (int j = 0; j < LN - 1; ++j) myrow[j] = mv[j];
+            // 128-byte lines: the row (15 + 52 positions at most) may be longer than the 64 bits of S, but what is stored of it is not
+            // (nfull <= 64), and the new carry lies in the row's own coordinates (nfull >= 48 > cl): its bits come from their word
+            if constexpr (LN == 16) Sc = lb_shr(signs_row(), nfull - cl);
+            else
             Sc = lb_shr(S, nfull);
             cl = total - nfull;
             const size_t e = (size_t)c * (size_t)p.n_sk + (size_t)k;
@@ -680,7 +696,7 @@ struct LaneChain {
             if (head()) {
                 double *ring = tile + CW * LR + MD * CW + cwi;
                 ring[slot * CW] = t;
-                if (slot == 7) store_times(p.t + e - 7, ring, tfirst, 7);
+                if (slot == 7 && !(GL == 1 && (p.tflags & 0x100))) store_times(p.t + e - 7, ring, tfirst, 7);
                 if constexpr (DIAG) {
                     if (p.H) p.H[e] = horizon;
                     if (p.AR) p.AR[e] = ar;
@@ -732,7 +748,7 @@ struct LaneChain {
         __builtin_amdgcn_wave_barrier();
         meta_put(cwi, Sc, off, ((uint32_t)cl << 8) | (kShort ? (uint32_t)skip : 0u));
         __builtin_amdgcn_wave_barrier();
-        store_tile<8, kShort, true>(0, l);
+        store_tile<LN, kShort, true>(0, l);
         __builtin_amdgcn_wave_barrier();
         cl = 0; skip = 0;
         if (mine && head() && tlast >= 0)                                         // the event times of an incomplete line; k - 1 = my last event, in slot tlast
