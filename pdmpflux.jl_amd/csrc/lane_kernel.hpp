@@ -571,6 +571,16 @@ struct LaneChain {
             *(u32x2 *)(mw + 4) = o;
         }
     }
+    // the high word of +-1.0 with the sign of bit 31 of w: (w & 0x80000000) | 0x3ff00000 as one three-input bit operation
+    __device__ __forceinline__ static uint32_t one_with_sign(uint32_t w) {
+#if __has_builtin(__builtin_amdgcn_bitop3_b32)
+        uint32_t k = 0x3ff00000u;
+        asm("" : "+v"(k));                              // (in a vector register: the other constant takes the instruction's one scalar operand)
+        return __builtin_amdgcn_bitop3_b32(w, 0x80000000u, k, 0xEA);      // (a & b) | c
+#else
+        return (w & 0x80000000u) | 0x3ff00000u;
+#endif
+    }
     template <int W, bool LO, bool HI>              // W positions x 64 / W chains per store; LO / HI: check position >= skip / < nfull
     __device__ __forceinline__ void store_tile(int q, int l) {                    // l = lane (opaque copy: see record)
         constexpr int CH = WAVE / W, NR = CW / CH;                                // chains per store: store r covers chains CH r .. CH r + CH - 1
@@ -594,10 +604,10 @@ struct LaneChain {
                 uint32_t off = m[b].off + pos * 8u;
                 if constexpr (LO) off = (pos >= (m[b].nf & 0xffu)) ? off : kNoRow;
                 if constexpr (HI) off = (pos < (m[b].nf >> 8)) ? off : kNoRow;
-                const uint32_t s31 = (m[b].s << sh) & 0x80000000u;
+                const uint32_t ws = m[b].s << sh;
                 u32x2 xv, vv;
-                xv.x = (uint32_t)__double2loint(yv[b]); xv.y = (uint32_t)__double2hiint(yv[b]) ^ s31;
-                vv.x = 0u; vv.y = 0x3ff00000u | s31;
+                xv.x = (uint32_t)__double2loint(yv[b]); xv.y = (uint32_t)__double2hiint(yv[b]) ^ (ws & 0x80000000u);
+                vv.x = 0u; vv.y = one_with_sign(ws);
                 __builtin_amdgcn_raw_buffer_store_b64(xv, rsX, (int)off, 0, LANE_STORE_AUX);
                 __builtin_amdgcn_raw_buffer_store_b64(vv, rsV, (int)off, 0, LANE_STORE_AUX);
             }
@@ -627,11 +637,14 @@ struct LaneChain {
                 uint32_t off = m[b].off + pos * 8u;
                 if constexpr (HI) off = (pos < (m[b].nf >> 8)) ? off : kNoRow;
                 const uint32_t w = m[b].s;
-                const uint32_t sa = (w << sh) & 0x80000000u, sb = (w << (sh - 1u)) & 0x80000000u;
+                const uint32_t wa = w << sh, wb = w << (sh - 1u);                      // the two positions' sign bits at bit 31
                 u32x4 xv, vv;
-                xv.x = (uint32_t)__double2loint(ya[b]); xv.y = (uint32_t)__double2hiint(ya[b]) ^ sa;
-                xv.z = (uint32_t)__double2loint(yb[b]); xv.w = (uint32_t)__double2hiint(yb[b]) ^ sb;
-                vv.x = 0u; vv.y = 0x3ff00000u | sa; vv.z = 0u; vv.w = 0x3ff00000u | sb;
+                // x: the sign bit flips y's (v_bitop3_b32, which the compiler finds by itself); v: +-1.0's high word = (bit 31 of wa) | 0x3ff00000 --
+                // one v_bitop3_b32 with its two constants in a scalar and a vector register where the compiler emits v_and + v_or + a copy
+                // (gfx9 encodes no literal in a three-operand instruction): 10 -> 7 vector instructions per pair of stores, 32 pairs per event row
+                xv.x = (uint32_t)__double2loint(ya[b]); xv.y = (uint32_t)__double2hiint(ya[b]) ^ (wa & 0x80000000u);
+                xv.z = (uint32_t)__double2loint(yb[b]); xv.w = (uint32_t)__double2hiint(yb[b]) ^ (wb & 0x80000000u);
+                vv.x = 0u; vv.y = one_with_sign(wa); vv.z = 0u; vv.w = one_with_sign(wb);
                 __builtin_amdgcn_raw_buffer_store_b128(xv, rsX, (int)off, 0, LANE_STORE_AUX);
                 __builtin_amdgcn_raw_buffer_store_b128(vv, rsV, (int)off, 0, LANE_STORE_AUX);
             }
