@@ -365,8 +365,12 @@ struct LaneChain {
         for (int g = 0; g < PG; ++g) xs[g] = (mg == g) ? 0x80000000u : 0u;
 #pragma unroll
         for (int i = 0; i < LD; ++i) {                                            // padded coordinates are never read
-            asm volatile("v_add_f64 %0, %0, %1" : "+v"(y[i]) : "v"(tf));          // y_i + tf in place (a plain IEEE addition)
-            y[i] = sgn(y[i], (ms == js(i)) ? xs[jg(i)] : 0u);
+            // y_i + tf (a plain IEEE addition; as an asm so that no pass of the compiler turns  y + (moved ? t : -0.0)  into a select over
+            // the 104 registers).  Source and destination are SEPARATE operands: with the destination tied to the source ("+v") every
+            // coordinate whose register changes over the loop body -- 51 of 52 -- cost a v_mov_b64 in front of the addition
+            double yn;
+            asm volatile("v_add_f64 %0, %1, %2" : "=v"(yn) : "v"(y[i]), "v"(tf));
+            y[i] = sgn(yn, (ms == js(i)) ? xs[jg(i)] : 0u);
         }
     }
     // Returns the coordinate to flip (-1: Q11 guard, no flip); reads the state flowed by t (y_i + t: the very doubles flow_and_flip stores).
