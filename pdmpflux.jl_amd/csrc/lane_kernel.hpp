@@ -360,9 +360,11 @@ struct LaneChain {
         else { sg1 ^= (m >= 32 && m < 64) ? bit : 0u; sg2 ^= (m >= 64 && m < 96) ? bit : 0u; sg3 ^= (m >= 96) ? bit : 0u; }
         // the flip: one compare per slot of four, then per coordinate a select of the lane's word for g = m % 4 and the xor
         const int ms = m >> LGE, mg = m & (PG - 1);                               // (m = -1: slot -1, no slot matches)
-        uint32_t xs[PG];
+        uint32_t xs[PG], mk[LK];
 #pragma unroll
         for (int g = 0; g < PG; ++g) xs[g] = (mg == g) ? 0x80000000u : 0u;
+#pragma unroll
+        for (int s = 0; s < LK; ++s) { mk[s] = (ms == s) ? 0xffffffffu : 0u; if constexpr (GL == 1) asm("" : "+v"(mk[s])); }   // (a mask per slot, opaque to the compiler: the coordinate's flip is then ONE three-input bit operation, hi ^ (mk & xs); left to itself it makes a select and an xor of it)
 #pragma unroll
         for (int i = 0; i < LD; ++i) {                                            // padded coordinates are never read
             // y_i + tf (a plain IEEE addition; as an asm so that no pass of the compiler turns  y + (moved ? t : -0.0)  into a select over
@@ -370,7 +372,8 @@ struct LaneChain {
             // coordinate whose register changes over the loop body -- 51 of 52 -- cost a v_mov_b64 in front of the addition
             double yn;
             asm volatile("v_add_f64 %0, %1, %2" : "=v"(yn) : "v"(y[i]), "v"(tf));
-            y[i] = sgn(yn, (ms == js(i)) ? xs[jg(i)] : 0u);
+            if constexpr (GL == 1) y[i] = sgn(yn, mk[js(i)] & xs[jg(i)]);
+            else y[i] = sgn(yn, (ms == js(i)) ? xs[jg(i)] : 0u);               // (the pair kernels, two waves per SIMD, have no thirteen registers for the masks)
         }
     }
     // Returns the coordinate to flip (-1: Q11 guard, no flip); reads the state flowed by t (y_i + t: the very doubles flow_and_flip stores).
