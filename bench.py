@@ -692,9 +692,10 @@ def main():
                          "kernel": kernel, "kernel_ms": kernel_ms, "bytes_per_event": bytes_per_event,
                          "valu": ({"instr_per_event": cnt.get("valu_instr_per_event"), "salu_instr_per_event": cnt.get("salu_instr_per_event"), "busy": cnt.get("valu_busy"),
                                    "source": cnt.get("valu_source")} if cnt and cnt.get("valu_instr_per_event") else None),
-                         "note": ("at the write rate of the memory (roofline.traffic / kernel_ms; a plain fill of this GPU reaches ~5.6 TB/s) and at the issue rate of "
-                                  "its instruction stream at once: one wave saturates its SIMD at ~8 cycles per fp64 wave-instruction (DESIGN.md 6), so `busy`, "
-                                  "computed at 4 cycles per instruction, under-states the SIMD's utilisation; roofline.valu = wave-instructions per event"
+                         "note": ("bound by the instruction stream of the one wave per SIMD: a wave alone issues an fp64 vector instruction every ~8 cycles, and "
+                                  "roofline.valu.instr_per_event x 64 chains x 8 cycles is the launch time to the percent (DESIGN.md 4.1b) -- `busy`, computed at 4 cycles "
+                                  "per instruction, under-states the SIMD's utilisation by that factor; since round 5 the kernel writes whole 128-byte lines and "
+                                  "roofline.traffic is 1.02 x the events' bytes (a plain fill of this GPU reaches ~5.6 - 6.3 TB/s)"
                                   if form in (4, 7) else
                                   "the kernel is bound by fp64 VALU issue, not by HBM (roofline.valu: wave-instructions per event and the share of "
                                   "SIMD cycles the VALUs are busy, from the committed PMC pass); the HBM fraction is the requested headline")},
