@@ -697,6 +697,9 @@ struct LaneChain {
         }
         __builtin_amdgcn_wave_barrier();
         LANE_MARK(14);
+        // (Reading y back from the row here -- so that the compiler need not park half of it in accumulation registers across the tile stores, ~100
+        //  v_accvgpr moves per pass -- was tried: 56 vector instructions fewer per pass, 26 LDS reads more, and the launch 13.61 -> 13.86 ms: a wave
+        //  alone on its SIMD waits out every LDS round trip.)
         if (rec) {
             if constexpr (kShort) { if (nfull) skip = 0; }
             const double *from = myrow + nfull;                                   // the row's tail that completes no line: the next carry
