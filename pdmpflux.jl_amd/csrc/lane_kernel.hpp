@@ -63,7 +63,7 @@ constexpr int lane_line(int lk, int gl = 1, int pg = 4) { return (LANE_LINE16 &&
 constexpr int lane_row_stride(int lk, int gl = 1, int pg = 4) { return (lane_line(lk, gl, pg) - 1 + pg * gl * lk) | 1; }   // LDS row: up to LN - 1 carried doubles + dmax coordinates, odd stride
 constexpr bool lane_wide(int lk, int gl, int pg) { return 7 + pg * gl * lk > 64; }                 // a row's sign bits need more than one 64-bit word
 constexpr int lane_meta_doubles(int lk, int gl = 1, int pg = 4) { return lane_wide(lk, gl, pg) ? 4 : 2; }   // store parameters of a chain: 16 bytes (64 sign bits) / 32 bytes (128)
-constexpr int lane_lds_per_wave(int lk, int gl = 1, int pg = 4) { return (WAVE / gl) * (lane_row_stride(lk, gl, pg) + lane_meta_doubles(lk, gl, pg) + 8); } // doubles: a row + the store parameters + 8 event times per chain
+constexpr int lane_lds_per_wave(int lk, int gl = 1, int pg = 4) { return (WAVE / gl) * (lane_row_stride(lk, gl, pg) + lane_meta_doubles(lk, gl, pg) + 8) + (lane_line(lk, gl, pg) == 16 ? 8 : 0); } // doubles: a row + the store parameters + 8 event times per chain (+ 64 bytes: the list of the chains whose row completes a fourth line, store_tile_listed)
 
 // Two waves per SIMD (256 registers): slot loops run slot by slot -- without this the scheduler hoists the 52 independent terms of a sum
 // in front of their additions (104 more live registers, spills).  One wave per SIMD (512 registers, the build that ships): no fence, the
@@ -578,6 +578,13 @@ struct LaneChain {
             *(u32x2 *)(mw + 4) = o;
         }
     }
+    static constexpr bool defined_lane_no_list() {
+#ifdef LANE_NO_LIST            // A/B builds: the checked tile by eight store pairs
+        return true;
+#else
+        return false;
+#endif
+    }
     // the high word of +-1.0 with the sign of bit 31 of w: (w & 0x80000000) | 0x3ff00000 as one three-input bit operation
     __device__ __forceinline__ static uint32_t one_with_sign(uint32_t w) {
 #if __has_builtin(__builtin_amdgcn_bitop3_b32)
@@ -658,6 +665,44 @@ struct LaneChain {
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    // The one checked tile of a row of 128-byte lines (positions q .. q + 15, whole or not there at all: nfull = q or q + 16) for the chains
+    // that need it ONLY.  At d = 50 one row in eight completes a fourth line, but the chains of a wave are at eight different phases, so every
+    // one of the eight store pairs of store_tile2<16, true> has a chain to serve and seven lane groups out of eight carry a dropped offset:
+    // ~100 vector instructions per pass.  Here the chains that need the tile are listed (ballot, mbcnt: their ranks; 64 bytes of LDS) and
+    // store pair r serves the chains of ranks 8 r .. 8 r + 7 -- one pair instead of eight on average; when most chains need the tile (rows that
+    // are a whole number of lines: d = 48, every row) the direct form is the cheaper one again.
+    __device__ __forceinline__ void store_tile_listed(int q, int l, bool need) {
+        static_assert(GL == 1 && !kWide, "one lane per chain, 64 sign bits per row");
+        const unsigned long long mask = __ballot(need);
+        const int n = __builtin_popcountll(mask);
+        if (n == 0) return;
+        if (n > 40) { store_tile2<16, true>(q, l); return; }
+        unsigned char *list = (unsigned char *)(tile + CW * (LR + MD + 8));
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        __builtin_amdgcn_wave_barrier();
+        if (need) list[rank] = (unsigned char)l;
+        __builtin_amdgcn_wave_barrier();
+        const int sub = l & 7, grp = l >> 3;
+        const uint32_t pos = (uint32_t)(q + 2 * sub);
+        const uint32_t sh = 31u - (pos & 31u);
+        for (int r0 = 0; r0 < n; r0 += 8) {                                       // (wave-uniform)
+            const int slot = r0 + grp;
+            const bool ok = slot < n;
+            const int ch = (int)list[ok ? slot : 0];
+            const u32x4 mv = ((const u32x4 *)(tile + CW * LR))[ch];               // S (two words), window offset of row position 0, nfull << 8
+            const double *tb = tile + ch * LR + pos;
+            const double ya = tb[0], yb = tb[1];
+            const uint32_t off = ok ? mv.z + pos * 8u : kNoRow;
+            const uint32_t w = (q >= 32) ? mv.y : mv.x;
+            const uint32_t wa = w << sh, wb = w << (sh - 1u);
+            u32x4 xv, vv;
+            xv.x = (uint32_t)__double2loint(ya); xv.y = (uint32_t)__double2hiint(ya) ^ (wa & 0x80000000u);
+            xv.z = (uint32_t)__double2loint(yb); xv.w = (uint32_t)__double2hiint(yb) ^ (wb & 0x80000000u);
+            vv.x = 0u; vv.y = one_with_sign(wa); vv.z = 0u; vv.w = one_with_sign(wb);
+            __builtin_amdgcn_raw_buffer_store_b128(xv, rsX, (int)off, 0, LANE_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(vv, rsV, (int)off, 0, LANE_STORE_AUX);
+        }
+    }
     __device__ __forceinline__ void record(bool rec, int64_t c, int32_t k, double t, double horizon, double ar, int32_t errored,
                                            const double (&ev)[5], int32_t rejected, int32_t hits) {
         int l = lane;
@@ -691,8 +736,13 @@ struct LaneChain {
 #pragma unroll
         for (int q = 0; q < Q0; q += 16) store_tile2<16, false>(q, l);
         LANE_MARK(13);
+        if constexpr (LN == 16 && !defined_lane_no_list()) {
+            static_assert(NF_MAX - Q0 == 16, "128-byte lines: one checked tile per row");
+            store_tile_listed(Q0, l, rec && nfull > Q0);
+        } else {
 #pragma unroll
         for (int q = Q0; q < NF_MAX; q += LN) store_tile2<LN, true>(q, l);
+        }
 #endif
         }
         __builtin_amdgcn_wave_barrier();
