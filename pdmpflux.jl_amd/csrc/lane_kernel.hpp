@@ -53,17 +53,17 @@ constexpr int LANE_LK_MIN = 1, LANE_LK_MAX = 13;          // (round 4: 3 .. 6 sl
 // gl = lanes per chain (1; 2: the chain's coordinates split over a lane pair, lane_kernel.hpp: GL)
 // pg = coordinates of a slot per lane (4; 2: the "quad pair" form, GL = 2 at d <= 52), dmax = pg gl lk = a chain's coordinates with padding
 // Doubles per written line (LaneChain::LN): a store instruction writes whole lines of this length only.  64 bytes until round 5; 128 bytes -- the
-// L2's line -- for one lane per chain at d >= 25 (LANE_LINE16=0: A/B builds): a 128-byte line that two store instructions fill half by
+// L2's line -- for one lane per chain at d >= 25 and for the pair form at d = 53 .. 104 (LANE_LINE16=0: A/B builds): a 128-byte line that two store instructions fill half by
 // half is written to memory 1.19 times on average (scripts/probes/oob_probe.hip; the launch of config 2: 14.04 64-byte lines per event for
 // 12.625 of events, 0.375 too many per row of X and of V, PDMP_LANE_DEBUG).
 #ifndef LANE_LINE16
 #define LANE_LINE16 1
 #endif
-constexpr int lane_line(int lk, int gl = 1, int pg = 4) { return (LANE_LINE16 && gl == 1 && pg == 4 && lk >= 7) ? 16 : 8; }
+constexpr int lane_line(int lk, int gl = 1, int pg = 4) { return (LANE_LINE16 && pg == 4 && lk >= 7) ? 16 : 8; }   // (the pair form at d = 53 .. 104 too; the quad pairs -- pg = 2, two waves per SIMD -- keep 8)
 constexpr int lane_row_stride(int lk, int gl = 1, int pg = 4) { return (lane_line(lk, gl, pg) - 1 + pg * gl * lk) | 1; }   // LDS row: up to LN - 1 carried doubles + dmax coordinates, odd stride
 constexpr bool lane_wide(int lk, int gl, int pg) { return 7 + pg * gl * lk > 64; }                 // a row's sign bits need more than one 64-bit word
 constexpr int lane_meta_doubles(int lk, int gl = 1, int pg = 4) { return lane_wide(lk, gl, pg) ? 4 : 2; }   // store parameters of a chain: 16 bytes (64 sign bits) / 32 bytes (128)
-constexpr int lane_lds_per_wave(int lk, int gl = 1, int pg = 4) { return (WAVE / gl) * (lane_row_stride(lk, gl, pg) + lane_meta_doubles(lk, gl, pg) + 8) + (lane_line(lk, gl, pg) == 16 ? 8 : 0); } // doubles: a row + the store parameters + 8 event times per chain (+ 64 bytes: the list of the chains whose row completes a fourth line, store_tile_listed)
+constexpr int lane_lds_per_wave(int lk, int gl = 1, int pg = 4) { return (WAVE / gl) * (lane_row_stride(lk, gl, pg) + lane_meta_doubles(lk, gl, pg) + 8) + (lane_line(lk, gl, pg) == 16 && gl == 1 ? 8 : 0); } // doubles: a row + the store parameters + 8 event times per chain (+ 64 bytes: the list of the chains whose row completes a fourth line, store_tile_listed)
 
 // Two waves per SIMD (256 registers): slot loops run slot by slot -- without this the scheduler hoists the 52 independent terms of a sum
 // in front of their additions (104 more live registers, spills).  One wave per SIMD (512 registers, the build that ships): no fence, the
@@ -736,7 +736,7 @@ struct LaneChain {
 #pragma unroll
         for (int q = 0; q < Q0; q += 16) store_tile2<16, false>(q, l);
         LANE_MARK(13);
-        if constexpr (LN == 16 && !defined_lane_no_list()) {
+        if constexpr (LN == 16 && GL == 1 && !defined_lane_no_list()) {
             static_assert(NF_MAX - Q0 == 16, "128-byte lines: one checked tile per row");
             store_tile_listed(Q0, l, rec && nfull > Q0);
         } else {
