@@ -57,3 +57,15 @@ def test_bench_launches_its_own_ranks(extra):
         assert c["exchange_bytes_per_gpu"] == 8 * 101
     if gather == "samples":
         assert c["exchange_bytes_per_gpu"] == 1000 * 16 * 50 * 8
+
+
+def test_bench_ab_env_times_both_values_on_one_allocation():
+    """`bench.py --ab-env NAME=v1,v2`: after the timed region the same arrays are launched on again under each value of a launch-policy
+    knob (the handle re-reads its policy in between), so that two settings can be compared without the +-5 % that the placement of two
+    processes' allocations puts between them.  Here the number of work units per resident wave of the lane kernel (same results)."""
+    r = _run([sys.executable, "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--chains", "40000", "--n-sk", "64",
+              "--cpu-seconds", "0", "--pmc", "off", "--placement-survey", "off", "--ab-env", "PDMP_LANE_ROUNDS=8,24"], dict(os.environ))
+    ab = r["ab_env"]
+    assert ab["knob"] == "PDMP_LANE_ROUNDS" and set(ab["ms"]) == {"8", "24"}
+    assert all(len(v) == 6 and min(v) > 0 for v in ab["ms"].values())             # three rounds of two launches per value, interleaved
+    assert set(ab["mean_ms"]) == {"8", "24"}
