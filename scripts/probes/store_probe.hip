@@ -14,7 +14,10 @@
 #ifndef MODE
 #define MODE 1
 #endif
-constexpr int WAVE = 64, KC = 16, D = 1000, E = 199;
+#ifndef PROBE_D
+#define PROBE_D 1000       // doubles per row: 1000 = config 4 (rows of 62.5 L2 lines: every other row starts in the middle of one); 1008 = rows of 63 whole lines
+#endif
+constexpr int WAVE = 64, KC = 16, D = PROBE_D, E = 199;
 
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
