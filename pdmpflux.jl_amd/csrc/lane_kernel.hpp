@@ -24,7 +24,8 @@
 // and both with the checker), and sharding invariance holds across it.
 //
 // record! (Composites.jl:239-260) goes through the chain's LDS row so that a store instruction writes 16 consecutive doubles of each of
-// four chains (a lane's own row lies n_sk d 8 bytes from its neighbour's), and only WHOLE 64-byte lines: see `record` below.
+// four chains (a lane's own row lies n_sk d 8 bytes from its neighbour's), and only WHOLE lines -- of 128 bytes, the L2's, since round 5
+// (lane_line()): see `record` below.
 // One wave per SIMD (512 registers per lane); the launch is bound by the rate at which the events can be written.
 #pragma once
 #include "group_kernel.hpp"
@@ -439,7 +440,8 @@ struct LaneChain {
         return m;
     }
 
-    // ---- record!, Composites.jl:239-260, for the lanes with `rec`: X and V rows through LDS, stored as WHOLE 64-byte lines.
+    // ---- record!, Composites.jl:239-260, for the lanes with `rec`: X and V rows through LDS, stored as WHOLE lines of LN doubles (64 or 128 bytes;
+    // the text below says 8 and 64 bytes where the kernels with LN = 16 have 16 and 128).
     // X[c, k, :] of consecutive events of a chain are contiguous in memory (d doubles each), so a chain writes one continuous
     // stream per array.  An event row of 400 bytes straddles lines; written as it comes, the straddled lines leave the L2 half
     // written and are written twice (profiles: 93.6 GB for 80.7 GB of events).  Here the tail of a row that does not complete
