@@ -1069,6 +1069,7 @@ template <int TARGET, int LK, bool DIAG, bool TAPE = false, int GL = 1, int PG =
 inline hipError_t launch_lane(const GroupParams &gp_in, const int32_t *flag, int rounds, hipStream_t stream) {
     GroupParams gp = gp_in;
     constexpr int wpb = 4;
+    static_assert((size_t)wpb * lane_lds_per_wave(LK, GL, PG) * sizeof(double) <= 160u * 1024u, "a block of four waves must fit the CU's 160 KB of LDS (the widest rows: 15 carried + 52 coordinates, 157.9 KB)");
     const size_t lds = (size_t)wpb * lane_lds_per_wave(LK, GL, PG) * sizeof(double);
     void (*kernel)(const GroupParams, const int32_t *) = lane_kernel<TARGET, LK, DIAG, TAPE, GL, PG>;
     int per_cu = 0, dev = 0, cus = 0;
