@@ -139,7 +139,7 @@ def test_lane_kernel_full_machine(engine, oracle, monkeypatch):
     assert (np.abs(got["V"]) == 1.0).all()
 
 
-@pytest.mark.parametrize("offs", [(0, 5, 2), (8, 3, 7), (0, 0, 1), (3, 0, 0)])
+@pytest.mark.parametrize("offs", [(0, 5, 2), (8, 3, 7), (0, 0, 1), (3, 0, 0), (9, 12, 3), (15, 1, 0)])     # (the last two: phases beyond 8 doubles -- the 128-byte lines of round 5)
 @pytest.mark.parametrize("n_sk,dim", [(40, 50), (40, 51), (37, 50), (48, 27), (24, 38), (32, 45), (31, 45),
                                       (40, 2), (37, 3), (33, 5), (40, 5), (35, 6), (31, 7), (40, 8)])     # (rows shorter than a line: round 4)
 def test_lane_kernel_unaligned_outputs(engine, oracle, lane, offs, n_sk, dim):
@@ -168,6 +168,35 @@ def test_lane_kernel_unaligned_outputs(engine, oracle, lane, offs, n_sk, dim):
     for name in ("X", "V", "t"):
         b, off, n = bufs[name]
         assert got[name].data_ptr() == b.data_ptr() + 8 * off                    # the engine wrote into the view it was given
+        assert np.array_equal(got[name].cpu().numpy(), ref[name]), name
+        assert bool((b[:off] == guard).all()) and bool((b[off + n:] == guard).all()), name
+
+
+@pytest.mark.parametrize("offs", [(0, 0, 0), (9, 12, 3), (15, 1, 0), (8, 8, 1)])
+@pytest.mark.parametrize("n_sk,dim", [(24, 100), (23, 61), (25, 53), (21, 104)])
+def test_pair_form_unaligned_outputs(engine, oracle, lane, offs, n_sk, dim):
+    """The same for the pair form at d = 53 .. 104, which writes whole 128-byte lines since round 5 (carries of up to 15 doubles, rows of up to
+    15 + 104 positions in 128 sign bits): every phase of X inside a line, V at another phase, rows that are no whole number of lines, three
+    segments per chain; exactly the bytes of the arrays are written."""
+    import torch
+    lane.setenv("PDMP_FORCE_SEGMENTS", "3")
+    s, cfg = make_pair(engine, oracle, "ZigZagAD", dim, "banana")
+    C = 40
+    x, v = make_init("ZigZagAD", dim, C, seed=4, target="banana")
+    dev = torch.device("cuda:0")
+    guard = -12345.678
+    bufs, out = {}, {}
+    for name, shape, off in (("X", (C, n_sk, dim), offs[0]), ("V", (C, n_sk, dim), offs[1]), ("t", (C, n_sk), offs[2])):
+        n = int(np.prod(shape))
+        b = torch.full((n + 16,), guard, dtype=torch.float64, device=dev)
+        bufs[name] = (b, off, n)
+        out[name] = b[off:off + n].view(shape)
+    from pdmpflux.jl_amd import ensemble
+    got = ensemble.sample_skeleton_device(s, n_sk, torch.from_numpy(x).to(dev), torch.from_numpy(v).to(dev), seed=6, out=out)
+    assert s.last_launch_form() == 7
+    ref = oracle.sample_skeleton(cfg, n_sk, x, v, 6, diagnostics=False)
+    for name in ("X", "V", "t"):
+        b, off, n = bufs[name]
         assert np.array_equal(got[name].cpu().numpy(), ref[name]), name
         assert bool((b[:off] == guard).all()) and bool((b[off + n:] == guard).all()), name
 
