@@ -162,6 +162,8 @@ static LaunchPolicy policy_from_env() {
     q.debug_launch = getenv("PDMP_DEBUG_LAUNCH") != nullptr;
     { const int v = (int)geti("PDMP_DENSE_DEBUG", 0); if (v >= 0 && v <= 3) q.dense_debug = v; }
     { const int v = (int)geti("PDMP_LANE_DEBUG", 0); if (v >= 0 && v <= 7) q.lane_debug = v; }
+    if (q.lane_debug || q.dense_debug)      // (never silently: these knobs drop stores)
+        fprintf(stderr, "pdmp: PDMP_LANE_DEBUG=%d PDMP_DENSE_DEBUG=%d -- measurement knobs: stores / loads are dropped, the results of this handle are WRONG\n", q.lane_debug, q.dense_debug);
     return q;
 }
 
